@@ -1,0 +1,865 @@
+/*
+ * ude_oracle_impl.h -- type-generic body of the CPU oracle (TEST INFRASTRUCTURE, see ude_oracle.h).
+ * Included twice by ude_oracle.c with REAL = double (suffix _f64) and REAL = float (suffix _f32).
+ *
+ * Everything here restates upstream Julia packages that the reference calls but does not vendor
+ * (SURVEY.md Appendix A); each block cites the reference call site that exercises it.
+ */
+
+#ifndef REAL
+#error "include from ude_oracle.c"
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * a1/a2: activations and Dense layers.
+ *   rbf(x)=exp(-x^2)            LotkaVolterra/scenario_1.jl:59
+ *   Lux.Chain(Dense...)         scenario_1.jl:62-64; FastChain hudson_bay.jl:77-79, seir_exposure.jl:114;
+ *   Flux.Chain + destructure    FisherKPP/Fisher-KPP-CNN.jl:92-109
+ * Parameter layout per layer [vec(W) column-major (out x in); b(out)]  (verified
+ * against the stored loss known-answers).
+ * ------------------------------------------------------------------------------------------ */
+static inline REAL FN(act)(int a, REAL z) {
+    switch (a) {
+        case UDEO_ACT_TANH: return R_TANH(z);
+        case UDEO_ACT_RBF: return R_EXP(-(z * z));
+        case UDEO_ACT_RELU: return z > 0 ? z : (REAL)0;
+        default: return z;
+    }
+}
+/* derivative given pre-activation z and activation value a */
+static inline REAL FN(dact)(int a, REAL z, REAL av) {
+    switch (a) {
+        case UDEO_ACT_TANH: return (REAL)1 - av * av;
+        case UDEO_ACT_RBF: return (REAL)-2 * z * av;
+        case UDEO_ACT_RELU: return z > 0 ? (REAL)1 : (REAL)0;
+        default: return (REAL)1;
+    }
+}
+
+#define UDEO_MAXW 128 /* max layer width supported by the oracle's stack buffers */
+
+/* forward; zs/as: per-layer pre-activations / activations ([layer][UDEO_MAXW]); as[0] = input copy */
+static void FN(mlp_forward)(const udeo_model_desc* m, const REAL* p, const REAL* x,
+                            REAL zs[][UDEO_MAXW], REAL as[][UDEO_MAXW]) {
+    for (int i = 0; i < m->dims[0]; ++i) as[0][i] = x[i];
+    for (int l = 0; l < m->n_layers; ++l) {
+        const int in = m->dims[l], out = m->dims[l + 1];
+        const REAL* W = p;
+        const REAL* b = p + (size_t)in * out;
+        for (int j = 0; j < out; ++j) {
+            REAL acc = 0; /* W*x accumulated in ascending input order, then + b (Lux: W*x .+ b) */
+            for (int k = 0; k < in; ++k) acc += W[j + (size_t)k * out] * as[l][k];
+            acc += b[j];
+            zs[l][j] = acc;
+            as[l + 1][j] = FN(act)(m->act[l], acc);
+        }
+        p += (size_t)in * out + out;
+    }
+}
+
+/* reverse sweep: gy = cotangent of the output; gx = cotangent of the input; gp += parameter cotangent */
+static void FN(mlp_vjp)(const udeo_model_desc* m, const REAL* p0, REAL zs[][UDEO_MAXW],
+                        REAL as[][UDEO_MAXW], const REAL* gy, REAL* gx, REAL* gp0) {
+    REAL delta[UDEO_MAXW], prev[UDEO_MAXW];
+    size_t offs[UDEO_MAX_LAYERS];
+    size_t off = 0;
+    for (int l = 0; l < m->n_layers; ++l) {
+        offs[l] = off;
+        off += (size_t)m->dims[l] * m->dims[l + 1] + m->dims[l + 1];
+    }
+    const int L = m->n_layers;
+    for (int j = 0; j < m->dims[L]; ++j) delta[j] = gy[j];
+    for (int l = L - 1; l >= 0; --l) {
+        const int in = m->dims[l], out = m->dims[l + 1];
+        const REAL* W = p0 + offs[l];
+        for (int j = 0; j < out; ++j) delta[j] *= FN(dact)(m->act[l], zs[l][j], as[l + 1][j]);
+        if (gp0) {
+            REAL* gW = gp0 + offs[l];
+            REAL* gb = gW + (size_t)in * out;
+            for (int k = 0; k < in; ++k)
+                for (int j = 0; j < out; ++j) gW[j + (size_t)k * out] += delta[j] * as[l][k];
+            for (int j = 0; j < out; ++j) gb[j] += delta[j];
+        }
+        for (int k = 0; k < in; ++k) {
+            REAL acc = 0;
+            for (int j = 0; j < out; ++j) acc += W[j + (size_t)k * out] * delta[j];
+            prev[k] = acc;
+        }
+        for (int k = 0; k < in; ++k) delta[k] = prev[k];
+    }
+    for (int k = 0; k < m->dims[0]; ++k) gx[k] = delta[k];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a3/a4/a5: the UDE right-hand sides.
+ * ------------------------------------------------------------------------------------------ */
+static inline REAL FN(lv_lin)(const udeo_model_desc* m, const REAL* th, int i) {
+    return m->lin_idx[i] >= 0 ? (REAL)m->lin_sign[i] * th[m->lin_idx[i]] : (REAL)m->lin_const[i];
+}
+
+void FN(udeo_rhs)(const udeo_model_desc* m, const REAL* th, const REAL* u, REAL t, REAL* du) {
+    (void)t;
+    REAL zs[UDEO_MAX_LAYERS][UDEO_MAXW], as[UDEO_MAX_LAYERS + 1][UDEO_MAXW];
+    switch (m->kind) {
+        case UDEO_KIND_LV_TRUE: { /* scenario_1.jl:30-34 */
+            const REAL a = th[0], b = th[1], g = th[2], d = th[3];
+            du[0] = a * u[0] - b * u[1] * u[0];
+            du[1] = g * u[0] * u[1] - d * u[1];
+        } break;
+        case UDEO_KIND_LV_UDE: { /* scenario_1.jl:69-73 */
+            FN(mlp_forward)(m, th + m->nn_offset, u, zs, as);
+            const REAL* y = as[m->n_layers];
+            du[0] = FN(lv_lin)(m, th, 0) * u[0] + y[0];
+            du[1] = FN(lv_lin)(m, th, 1) * u[1] + y[1];
+        } break;
+        case UDEO_KIND_SEIR_TRUE: { /* seir_exposure.jl:16-30 */
+            const REAL S = u[0], E = u[1], I = u[2], Rr = u[3], N = u[4], D = u[5];
+            const REAL F = (REAL)m->consts[0], b0 = (REAL)m->consts[1], al = (REAL)m->consts[2],
+                       ka = (REAL)m->consts[3], mu = (REAL)m->consts[4], sg = (REAL)m->consts[5],
+                       ga = (REAL)m->consts[6], d = (REAL)m->consts[7], la = (REAL)m->consts[8];
+            const REAL beta = b0 * ((REAL)1 - al) * R_POW((REAL)1 - D / N, ka);
+            du[0] = -b0 * S * F / N - beta * S * I / N - mu * S;
+            du[1] = b0 * S * F / N + beta * S * I / N - (sg + mu) * E;
+            du[2] = sg * E - (ga + mu) * I;
+            du[3] = ga * I - mu * Rr;
+            du[4] = -mu * N;
+            du[5] = d * ga * I - la * D;
+            du[6] = sg * E;
+        } break;
+        case UDEO_KIND_SEIR_UDE: { /* seir_exposure.jl:117-130 */
+            const REAL S = u[0], E = u[1], I = u[2], Rr = u[3], N = u[4], D = u[5];
+            const REAL F = (REAL)m->consts[0], b0 = (REAL)m->consts[1], mu = (REAL)m->consts[4],
+                       sg = (REAL)m->consts[5], ga = (REAL)m->consts[6], d = (REAL)m->consts[7],
+                       la = (REAL)m->consts[8];
+            REAL x[3] = {S / N, I, D / N};
+            FN(mlp_forward)(m, th + m->nn_offset, x, zs, as);
+            const REAL z = as[m->n_layers][0];
+            du[0] = -b0 * S * F / N - z - mu * S;
+            du[1] = b0 * S * F / N + z - (sg + mu) * E;
+            du[2] = sg * E - (ga + mu) * I;
+            du[3] = ga * I - mu * Rr;
+            du[4] = -mu * N;
+            du[5] = d * ga * I - la * D;
+            du[6] = sg * E;
+        } break;
+        case UDEO_KIND_KPP_TRUE: { /* Fisher-KPP-CNN.jl:51-63: D*lap*rho + r*rho*(1-rho), periodic */
+            const int n = m->n_state;
+            const REAL D = (REAL)m->consts[0], r = (REAL)m->consts[1], w = (REAL)m->consts[2];
+            for (int i = 0; i < n; ++i) {
+                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                /* dense mat-vec row: nonzeros visited in ascending column order */
+                int idx[3] = {im, i, ip};
+                REAL cf[3] = {w, (REAL)-2 * w, w};
+                for (int a = 0; a < 3; ++a)
+                    for (int b2 = a + 1; b2 < 3; ++b2)
+                        if (idx[b2] < idx[a]) {
+                            int ti = idx[a]; idx[a] = idx[b2]; idx[b2] = ti;
+                            REAL tc = cf[a]; cf[a] = cf[b2]; cf[b2] = tc;
+                        }
+                REAL acc = 0;
+                for (int a = 0; a < 3; ++a) acc += cf[a] * u[idx[a]];
+                du[i] = D * acc + r * u[i] * ((REAL)1 - u[i]);
+            }
+        } break;
+        case UDEO_KIND_KPP_UDE: { /* Fisher-KPP-CNN.jl:111-126 */
+            const int n = m->n_state;
+            const REAL w1 = th[m->stencil_offset], w2 = th[m->stencil_offset + 1],
+                       w3 = th[m->stencil_offset + 2], D0 = th[m->d0_offset];
+            for (int i = 0; i < n; ++i) {
+                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                FN(mlp_forward)(m, th + m->nn_offset, &u[i], zs, as);
+                const REAL cnn = w1 * u[im] + w2 * u[i] + w3 * u[ip];
+                du[i] = as[m->n_layers][0] + D0 * cnn;
+            }
+        } break;
+        default: break;
+    }
+}
+
+/* dlam = (df/du)^T lam ; dth += (df/dtheta)^T lam.  Returns 0, or -1 if the kind has no VJP. */
+int FN(udeo_rhs_vjp)(const udeo_model_desc* m, const REAL* th, const REAL* u, REAL t,
+                     const REAL* lam, REAL* dlam, REAL* dth) {
+    (void)t;
+    REAL zs[UDEO_MAX_LAYERS][UDEO_MAXW], as[UDEO_MAX_LAYERS + 1][UDEO_MAXW];
+    switch (m->kind) {
+        case UDEO_KIND_LV_TRUE: {
+            const REAL a = th[0], b = th[1], g = th[2], d = th[3];
+            dlam[0] = (a - b * u[1]) * lam[0] + (g * u[1]) * lam[1];
+            dlam[1] = (-b * u[0]) * lam[0] + (g * u[0] - d) * lam[1];
+            if (dth) {
+                dth[0] += u[0] * lam[0];
+                dth[1] += -u[1] * u[0] * lam[0];
+                dth[2] += u[0] * u[1] * lam[1];
+                dth[3] += -u[1] * lam[1];
+            }
+        } return 0;
+        case UDEO_KIND_LV_UDE: {
+            REAL gx[2];
+            FN(mlp_forward)(m, th + m->nn_offset, u, zs, as);
+            FN(mlp_vjp)(m, th + m->nn_offset, zs, as, lam, gx, dth ? dth + m->nn_offset : 0);
+            for (int i = 0; i < 2; ++i) {
+                dlam[i] = FN(lv_lin)(m, th, i) * lam[i] + gx[i];
+                if (dth && m->lin_idx[i] >= 0) dth[m->lin_idx[i]] += (REAL)m->lin_sign[i] * u[i] * lam[i];
+            }
+        } return 0;
+        case UDEO_KIND_SEIR_UDE: {
+            const REAL S = u[0], N = u[4], D = u[5];
+            const REAL F = (REAL)m->consts[0], b0 = (REAL)m->consts[1], mu = (REAL)m->consts[4],
+                       sg = (REAL)m->consts[5], ga = (REAL)m->consts[6], d = (REAL)m->consts[7],
+                       la = (REAL)m->consts[8];
+            REAL x[3] = {S / N, u[2], D / N};
+            REAL gz[1] = {lam[1] - lam[0]}, gx[3];
+            FN(mlp_forward)(m, th + m->nn_offset, x, zs, as);
+            FN(mlp_vjp)(m, th + m->nn_offset, zs, as, gz, gx, dth ? dth + m->nn_offset : 0);
+            const REAL c = b0 * F / N;          /* d(b0 S F/N)/dS */
+            const REAL cN = b0 * S * F / (N * N); /* -d(b0 S F/N)/dN */
+            dlam[0] = (-c - mu) * lam[0] + c * lam[1] + gx[0] / N;
+            dlam[1] = -(sg + mu) * lam[1] + sg * lam[2] + sg * lam[6];
+            dlam[2] = -(ga + mu) * lam[2] + ga * lam[3] + d * ga * lam[5] + gx[1];
+            dlam[3] = -mu * lam[3];
+            dlam[4] = cN * lam[0] - cN * lam[1] - mu * lam[4] - gx[0] * S / (N * N) - gx[2] * D / (N * N);
+            dlam[5] = -la * lam[5] + gx[2] / N;
+            dlam[6] = 0;
+        } return 0;
+        case UDEO_KIND_KPP_UDE: {
+            const int n = m->n_state;
+            const REAL w1 = th[m->stencil_offset], w2 = th[m->stencil_offset + 1],
+                       w3 = th[m->stencil_offset + 2], D0 = th[m->d0_offset];
+            REAL gw1 = 0, gw2 = 0, gw3 = 0, gD = 0;
+            for (int i = 0; i < n; ++i) {
+                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                REAL gx[1];
+                FN(mlp_forward)(m, th + m->nn_offset, &u[i], zs, as);
+                FN(mlp_vjp)(m, th + m->nn_offset, zs, as, &lam[i], gx, dth ? dth + m->nn_offset : 0);
+                /* transpose of the periodic 3-tap stencil */
+                dlam[i] = gx[0] + D0 * (w1 * lam[ip] + w2 * lam[i] + w3 * lam[im]);
+                gw1 += lam[i] * u[im];
+                gw2 += lam[i] * u[i];
+                gw3 += lam[i] * u[ip];
+                gD += lam[i] * (w1 * u[im] + w2 * u[i] + w3 * u[ip]);
+            }
+            if (dth) {
+                dth[m->stencil_offset] += D0 * gw1;
+                dth[m->stencil_offset + 1] += D0 * gw2;
+                dth[m->stencil_offset + 2] += D0 * gw3;
+                dth[m->d0_offset] += gD;
+            }
+        } return 0;
+        default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a7/a8: adaptive explicit RK driver (OrdinaryDiffEq: Tsit5 / Vern7 perform_step!, PIController,
+ * ode_determine_initdt, loopheader!/loopfooter!, tstops) -- SURVEY.md App. A.1, A.2, A.4.
+ * Call sites: scenario_1.jl:41,84,191,202,206; seir_exposure.jl:37,138; Fisher-KPP-CNN.jl:66,136.
+ * Works for either time direction so the adjoint (a10) reuses it unchanged.
+ * ------------------------------------------------------------------------------------------ */
+typedef void (*FN(rhs_fn))(void* ctx, REAL t, const REAL* z, REAL* dz);
+
+typedef struct {
+    int alg, nz;
+    FN(rhs_fn) f;
+    void* fctx;
+    REAL tprev, t, dt;       /* accepted step [tprev, t], dt = the step size that was used */
+    const REAL* uprev;
+    const REAL* u;
+    REAL** k;                /* k[0..nk-1], each nz */
+    int lazy_done;           /* Vern7: k[10..15] valid */
+    int64_t* nf_lazy;
+} FN(stepinfo);
+
+typedef int (*FN(accept_fn))(void* ctx, FN(stepinfo)* si);
+typedef int (*FN(tstop_fn))(void* ctx, REAL t, REAL* z); /* returns 1 if z was modified */
+
+static REAL FN(rms)(const REAL* v, int n) {
+    REAL s = 0;
+    for (int i = 0; i < n; ++i) s += v[i] * v[i];
+    return R_SQRT(s / (REAL)(n > 0 ? n : 1));
+}
+
+/* Vern7 lazy dense-output stages k11..k16 (OrdinaryDiffEq _ode_addsteps!) */
+static void FN(vern7_extra)(FN(stepinfo)* si, REAL* tmp) {
+    if (si->lazy_done) return;
+    const int nz = si->nz;
+    REAL** k = si->k;
+    const REAL dt = si->dt, t = si->tprev;
+    const REAL* up = si->uprev;
+#define V(x) ((REAL)UDE_VERN7_##x)
+    for (int i = 0; i < nz; ++i)
+        tmp[i] = up[i] + dt * (V(a1101) * k[0][i] + V(a1104) * k[3][i] + V(a1105) * k[4][i] + V(a1106) * k[5][i] +
+                               V(a1107) * k[6][i] + V(a1108) * k[7][i] + V(a1109) * k[8][i]);
+    si->f(si->fctx, t + V(c11) * dt, tmp, k[10]);
+    for (int i = 0; i < nz; ++i)
+        tmp[i] = up[i] + dt * (V(a1201) * k[0][i] + V(a1204) * k[3][i] + V(a1205) * k[4][i] + V(a1206) * k[5][i] +
+                               V(a1207) * k[6][i] + V(a1208) * k[7][i] + V(a1209) * k[8][i] + V(a1211) * k[10][i]);
+    si->f(si->fctx, t + V(c12) * dt, tmp, k[11]);
+    for (int i = 0; i < nz; ++i)
+        tmp[i] = up[i] + dt * (V(a1301) * k[0][i] + V(a1304) * k[3][i] + V(a1305) * k[4][i] + V(a1306) * k[5][i] +
+                               V(a1307) * k[6][i] + V(a1308) * k[7][i] + V(a1309) * k[8][i] + V(a1311) * k[10][i] +
+                               V(a1312) * k[11][i]);
+    si->f(si->fctx, t + V(c13) * dt, tmp, k[12]);
+    for (int i = 0; i < nz; ++i)
+        tmp[i] = up[i] + dt * (V(a1401) * k[0][i] + V(a1404) * k[3][i] + V(a1405) * k[4][i] + V(a1406) * k[5][i] +
+                               V(a1407) * k[6][i] + V(a1408) * k[7][i] + V(a1409) * k[8][i] + V(a1411) * k[10][i] +
+                               V(a1412) * k[11][i] + V(a1413) * k[12][i]);
+    si->f(si->fctx, t + V(c14) * dt, tmp, k[13]);
+    for (int i = 0; i < nz; ++i)
+        tmp[i] = up[i] + dt * (V(a1501) * k[0][i] + V(a1504) * k[3][i] + V(a1505) * k[4][i] + V(a1506) * k[5][i] +
+                               V(a1507) * k[6][i] + V(a1508) * k[7][i] + V(a1509) * k[8][i] + V(a1511) * k[10][i] +
+                               V(a1512) * k[11][i] + V(a1513) * k[12][i]);
+    si->f(si->fctx, t + V(c15) * dt, tmp, k[14]);
+    for (int i = 0; i < nz; ++i)
+        tmp[i] = up[i] + dt * (V(a1601) * k[0][i] + V(a1604) * k[3][i] + V(a1605) * k[4][i] + V(a1606) * k[5][i] +
+                               V(a1607) * k[6][i] + V(a1608) * k[7][i] + V(a1609) * k[8][i] + V(a1611) * k[10][i] +
+                               V(a1612) * k[11][i] + V(a1613) * k[12][i]);
+    si->f(si->fctx, t + V(c16) * dt, tmp, k[15]);
+#undef V
+    si->lazy_done = 1;
+    if (si->nf_lazy) *si->nf_lazy += 6;
+}
+
+/* dense-output weights b_j(Theta) (OrdinaryDiffEq ode_interpolant; @evalpoly = Horner) */
+static void FN(tsit5_bth)(REAL th, REAL* b) {
+#define T(x) ((REAL)UDE_TSIT5_##x)
+    const REAL th2 = th * th;
+    b[0] = th * (T(r11) + th * (T(r12) + th * (T(r13) + th * T(r14))));
+    b[1] = th2 * (T(r22) + th * (T(r23) + th * T(r24)));
+    b[2] = th2 * (T(r32) + th * (T(r33) + th * T(r34)));
+    b[3] = th2 * (T(r42) + th * (T(r43) + th * T(r44)));
+    b[4] = th2 * (T(r52) + th * (T(r53) + th * T(r54)));
+    b[5] = th2 * (T(r62) + th * (T(r63) + th * T(r64)));
+    b[6] = th2 * (T(r72) + th * (T(r73) + th * T(r74)));
+#undef T
+}
+static void FN(vern7_bth)(REAL th, REAL* b /*16, unused slots zero*/) {
+#define V(x) ((REAL)UDE_VERN7_##x)
+#define P6(p) (th * th * (V(p##2) + th * (V(p##3) + th * (V(p##4) + th * (V(p##5) + th * (V(p##6) + th * V(p##7)))))))
+    for (int j = 0; j < 16; ++j) b[j] = 0;
+    b[0] = th * (V(r011) + th * (V(r012) + th * (V(r013) + th * (V(r014) + th * (V(r015) + th * (V(r016) + th * V(r017)))))));
+    b[3] = P6(r04);
+    b[4] = P6(r05);
+    b[5] = P6(r06);
+    b[6] = P6(r07);
+    b[7] = P6(r08);
+    b[8] = P6(r09);
+    b[10] = P6(r11);
+    b[11] = P6(r12);
+    b[12] = P6(r13);
+    b[13] = P6(r14);
+    b[14] = P6(r15);
+    b[15] = P6(r16);
+#undef P6
+#undef V
+}
+
+/* y = uprev + dt * sum_j b_j(theta) k_j */
+static void FN(interp)(int alg, REAL th, REAL dt, const REAL* uprev, REAL* const* k, int nz, REAL* y) {
+    REAL b[16];
+    if (alg == UDEO_ALG_TSIT5) {
+        FN(tsit5_bth)(th, b);
+        for (int i = 0; i < nz; ++i)
+            y[i] = uprev[i] + dt * (k[0][i] * b[0] + k[1][i] * b[1] + k[2][i] * b[2] + k[3][i] * b[3] +
+                                    k[4][i] * b[4] + k[5][i] * b[5] + k[6][i] * b[6]);
+    } else {
+        FN(vern7_bth)(th, b);
+        for (int i = 0; i < nz; ++i)
+            y[i] = uprev[i] + dt * (k[0][i] * b[0] + k[3][i] * b[3] + k[4][i] * b[4] + k[5][i] * b[5] +
+                                    k[6][i] * b[6] + k[7][i] * b[7] + k[8][i] * b[8] + k[10][i] * b[10] +
+                                    k[11][i] * b[11] + k[12][i] * b[12] + k[13][i] * b[13] + k[14][i] * b[14] +
+                                    k[15][i] * b[15]);
+    }
+}
+
+typedef struct {
+    REAL abstol, reltol, dtmax, qmin, qmax, gamma, qoldinit, beta1, beta2, dt0;
+    int alg, order, maxiters;
+} FN(ropts);
+
+static void FN(resolve_opts)(const udeo_solve_opts* o, REAL t0, REAL tf, FN(ropts)* r) {
+    r->alg = o->alg;
+    r->order = o->alg == UDEO_ALG_VERN7 ? 7 : 5;
+    r->maxiters = o->maxiters > 0 ? o->maxiters : 100000;
+    r->abstol = (REAL)(o->abstol > 0 ? o->abstol : 1e-6);
+    r->reltol = (REAL)(o->reltol > 0 ? o->reltol : 1e-3);
+    r->dtmax = (REAL)(o->dtmax > 0 ? o->dtmax : R_FABS(tf - t0));
+    r->qmin = (REAL)(o->qmin > 0 ? o->qmin : 0.2);
+    r->qmax = (REAL)(o->qmax > 0 ? o->qmax : 10.0);
+    r->gamma = (REAL)(o->gamma > 0 ? o->gamma : 0.9);
+    r->qoldinit = (REAL)(o->qoldinit > 0 ? o->qoldinit : 1e-4);
+    r->beta2 = (REAL)(o->beta2 > 0 ? o->beta2 : 2.0 / (5.0 * r->order));
+    r->beta1 = (REAL)(o->beta1 > 0 ? o->beta1 : 7.0 / (10.0 * r->order));
+    r->dt0 = (REAL)o->dt0;
+}
+
+/* OrdinaryDiffEq ode_determine_initdt (Hairer); 2 RHS evals; f0 returned in f0out */
+static REAL FN(initdt)(const FN(ropts)* r, FN(rhs_fn) f, void* ctx, const REAL* u0, REAL t, REAL tdir,
+                       int nz, REAL* f0, REAL* w1, REAL* w2, int* nan_out) {
+    REAL* sk = w1;
+    for (int i = 0; i < nz; ++i) sk[i] = r->abstol + R_FABS(u0[i]) * r->reltol;
+    REAL s = 0;
+    for (int i = 0; i < nz; ++i) { REAL q = u0[i] / sk[i]; s += q * q; }
+    const REAL d0 = R_SQRT(s / (REAL)nz);
+    f(ctx, t, u0, f0);
+    s = 0;
+    for (int i = 0; i < nz; ++i) { REAL q = f0[i] / sk[i]; s += q * q; }
+    const REAL d1 = R_SQRT(s / (REAL)nz);
+    if (d1 != d1) { *nan_out = 1; return (REAL)0; }
+    REAL dt0 = (d0 < (REAL)1e-5 || d1 < (REAL)1e-5) ? (REAL)1e-6 : (d0 / d1) / (REAL)100;
+    if (dt0 > r->dtmax) dt0 = r->dtmax;
+    if (dt0 < (REAL)10 * R_EPS) return tdir * (REAL)1e-6;
+    const REAL dt0t = tdir * dt0;
+    REAL* u1 = w2;          /* w2 holds 2*nz: [u1 | f1] */
+    REAL* f1 = w2 + nz;
+    for (int i = 0; i < nz; ++i) u1[i] = u0[i] + dt0t * f0[i];
+    f(ctx, t + dt0t, u1, f1);
+    s = 0;
+    for (int i = 0; i < nz; ++i) { REAL q = (f1[i] - f0[i]) / sk[i]; s += q * q; }
+    const REAL d2 = R_SQRT(s / (REAL)nz) / dt0;
+    const REAL mx = d1 > d2 ? d1 : d2;
+    REAL dt1;
+    if (mx <= (REAL)1e-15) {
+        dt1 = dt0 * (REAL)1e-3;
+        if (dt1 < (REAL)1e-6) dt1 = (REAL)1e-6;
+    } else {
+        /* 10.0^(-(2+log10(mx))/order): exponent in the problem's float type, power in Float64 */
+        const REAL ex = -((REAL)2 + R_LOG10(mx)) / (REAL)r->order;
+        dt1 = (REAL)pow(10.0, (double)ex);
+    }
+    REAL dt = (REAL)100 * dt0;
+    if (dt1 < dt) dt = dt1;
+    if (r->dtmax < dt) dt = r->dtmax;
+    return tdir * dt;
+}
+
+/* returns retcode; z is advanced from t0 to the last tstop. tstops are in integration order. */
+static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, REAL* z, REAL t0,
+                         const REAL* tstops, int ntstops, FN(accept_fn) on_accept, void* actx,
+                         FN(tstop_fn) on_tstop, void* tctx, int64_t* nf_out, int64_t* nacc_out,
+                         int64_t* nrej_out, int64_t* nf_lazy_out) {
+    const int alg = r->alg;
+    const int nk = alg == UDEO_ALG_TSIT5 ? 7 : 16;
+    const REAL tf = tstops[ntstops - 1];
+    const REAL tdir = tf >= t0 ? (REAL)1 : (REAL)-1;
+    REAL* mem = (REAL*)malloc(sizeof(REAL) * (size_t)nz * (nk + 8));
+    REAL* kk[16];
+    for (int j = 0; j < nk; ++j) kk[j] = mem + (size_t)j * nz;
+    REAL* uprev = mem + (size_t)nk * nz;
+    REAL* u = uprev + nz;
+    REAL* tmp = u + nz;
+    REAL* utilde = tmp + nz;
+    REAL* w1 = utilde + nz;
+    REAL* w2 = w1 + nz; /* 2*nz */
+    REAL* f0 = w2 + 2 * nz;
+    int64_t nf = 0, nacc = 0, nrej = 0;
+    int ret = UDEO_RET_SUCCESS;
+    int its = 0;
+    REAL t = t0, dt, qold = r->qoldinit, q11 = 1;
+    int accept = 1, iter = 0;
+    memcpy(uprev, z, sizeof(REAL) * nz);
+
+    if (r->dt0 > 0) {
+        dt = tdir * r->dt0;
+        if (alg == UDEO_ALG_TSIT5) { f(fctx, t, uprev, kk[0]); nf += 1; }
+    } else {
+        int nanflag = 0;
+        dt = FN(initdt)(r, f, fctx, uprev, t, tdir, nz, f0, w1, w2, &nanflag);
+        nf += 2;
+        if (nanflag) { ret = UDEO_RET_UNSTABLE; goto done; }
+        if (alg == UDEO_ALG_TSIT5) { memcpy(kk[0], f0, sizeof(REAL) * nz); nf += 1; } /* initialize!: fsalfirst = f(u0) */
+    }
+
+    while (its < ntstops) {
+        const REAL tstop = tstops[its];
+        while (tdir * t < tdir * tstop) {
+            /* ---- loopheader! ---- */
+            if (iter > 0 && !accept) {
+                REAL den = q11 / r->gamma; /* step_reject_controller! */
+                const REAL iq = (REAL)1 / r->qmin;
+                if (iq < den) den = iq;
+                dt = dt / den;
+            }
+            iter += 1;
+            if (R_FABS(dt) > r->dtmax) dt = tdir * r->dtmax;
+            {
+                const REAL rem = R_FABS(tstop - t); /* modify_dt_for_tstops! */
+                if (R_FABS(dt) > rem) dt = tdir * rem;
+            }
+            /* ---- check_error ---- */
+            if (iter > r->maxiters) { ret = UDEO_RET_MAXITERS; goto done; }
+            if (dt != dt) { ret = UDEO_RET_UNSTABLE; goto done; }
+            if (R_FABS(dt) <= R_EPS * R_FABS(t) && R_FABS(dt) < R_FABS(tstop - t)) { ret = UDEO_RET_DTLESSTHANMIN; goto done; }
+            /* ---- perform_step! ---- */
+            if (alg == UDEO_ALG_TSIT5) {
+#define T(x) ((REAL)UDE_TSIT5_##x)
+                REAL *k1 = kk[0], *k2 = kk[1], *k3 = kk[2], *k4 = kk[3], *k5 = kk[4], *k6 = kk[5], *k7 = kk[6];
+                const REAL a = dt * T(a21);
+                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + a * k1[i];
+                f(fctx, t + T(c1) * dt, tmp, k2);
+                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (T(a31) * k1[i] + T(a32) * k2[i]);
+                f(fctx, t + T(c2) * dt, tmp, k3);
+                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (T(a41) * k1[i] + T(a42) * k2[i] + T(a43) * k3[i]);
+                f(fctx, t + T(c3) * dt, tmp, k4);
+                for (int i = 0; i < nz; ++i)
+                    tmp[i] = uprev[i] + dt * (T(a51) * k1[i] + T(a52) * k2[i] + T(a53) * k3[i] + T(a54) * k4[i]);
+                f(fctx, t + T(c4) * dt, tmp, k5);
+                for (int i = 0; i < nz; ++i)
+                    tmp[i] = uprev[i] + dt * (T(a61) * k1[i] + T(a62) * k2[i] + T(a63) * k3[i] + T(a64) * k4[i] + T(a65) * k5[i]);
+                f(fctx, t + dt, tmp, k6);
+                for (int i = 0; i < nz; ++i)
+                    u[i] = uprev[i] + dt * (T(a71) * k1[i] + T(a72) * k2[i] + T(a73) * k3[i] + T(a74) * k4[i] +
+                                            T(a75) * k5[i] + T(a76) * k6[i]);
+                f(fctx, t + dt, u, k7);
+                nf += 6;
+                for (int i = 0; i < nz; ++i)
+                    utilde[i] = dt * (T(btilde1) * k1[i] + T(btilde2) * k2[i] + T(btilde3) * k3[i] + T(btilde4) * k4[i] +
+                                      T(btilde5) * k5[i] + T(btilde6) * k6[i] + T(btilde7) * k7[i]);
+#undef T
+            } else {
+#define V(x) ((REAL)UDE_VERN7_##x)
+                REAL *k1 = kk[0], *k2 = kk[1], *k3 = kk[2], *k4 = kk[3], *k5 = kk[4], *k6 = kk[5], *k7 = kk[6],
+                     *k8 = kk[7], *k9 = kk[8], *k10 = kk[9];
+                f(fctx, t, uprev, k1);
+                const REAL a = dt * V(a021);
+                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + a * k1[i];
+                f(fctx, t + V(c2) * dt, tmp, k2);
+                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (V(a031) * k1[i] + V(a032) * k2[i]);
+                f(fctx, t + V(c3) * dt, tmp, k3);
+                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (V(a041) * k1[i] + V(a043) * k3[i]);
+                f(fctx, t + V(c4) * dt, tmp, k4);
+                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (V(a051) * k1[i] + V(a053) * k3[i] + V(a054) * k4[i]);
+                f(fctx, t + V(c5) * dt, tmp, k5);
+                for (int i = 0; i < nz; ++i)
+                    tmp[i] = uprev[i] + dt * (V(a061) * k1[i] + V(a063) * k3[i] + V(a064) * k4[i] + V(a065) * k5[i]);
+                f(fctx, t + V(c6) * dt, tmp, k6);
+                for (int i = 0; i < nz; ++i)
+                    tmp[i] = uprev[i] + dt * (V(a071) * k1[i] + V(a073) * k3[i] + V(a074) * k4[i] + V(a075) * k5[i] + V(a076) * k6[i]);
+                f(fctx, t + V(c7) * dt, tmp, k7);
+                for (int i = 0; i < nz; ++i)
+                    tmp[i] = uprev[i] + dt * (V(a081) * k1[i] + V(a083) * k3[i] + V(a084) * k4[i] + V(a085) * k5[i] +
+                                              V(a086) * k6[i] + V(a087) * k7[i]);
+                f(fctx, t + V(c8) * dt, tmp, k8);
+                for (int i = 0; i < nz; ++i)
+                    tmp[i] = uprev[i] + dt * (V(a091) * k1[i] + V(a093) * k3[i] + V(a094) * k4[i] + V(a095) * k5[i] +
+                                              V(a096) * k6[i] + V(a097) * k7[i] + V(a098) * k8[i]);
+                f(fctx, t + dt, tmp, k9);
+                for (int i = 0; i < nz; ++i)
+                    tmp[i] = uprev[i] + dt * (V(a101) * k1[i] + V(a103) * k3[i] + V(a104) * k4[i] + V(a105) * k5[i] +
+                                              V(a106) * k6[i] + V(a107) * k7[i]);
+                f(fctx, t + dt, tmp, k10);
+                nf += 10;
+                for (int i = 0; i < nz; ++i)
+                    u[i] = uprev[i] + dt * (V(b1) * k1[i] + V(b4) * k4[i] + V(b5) * k5[i] + V(b6) * k6[i] +
+                                            V(b7) * k7[i] + V(b8) * k8[i] + V(b9) * k9[i]);
+                for (int i = 0; i < nz; ++i)
+                    utilde[i] = dt * (V(btilde1) * k1[i] + V(btilde4) * k4[i] + V(btilde5) * k5[i] + V(btilde6) * k6[i] +
+                                      V(btilde7) * k7[i] + V(btilde8) * k8[i] + V(btilde9) * k9[i] + V(btilde10) * k10[i]);
+#undef V
+            }
+            /* calculate_residuals + ODE_DEFAULT_NORM (DiffEqBase) */
+            REAL s = 0;
+            for (int i = 0; i < nz; ++i) {
+                const REAL a0 = R_FABS(uprev[i]), a1 = R_FABS(u[i]);
+                const REAL res = utilde[i] / (r->abstol + (a0 > a1 ? a0 : a1) * r->reltol);
+                s += res * res;
+            }
+            const REAL EEst = R_SQRT(s / (REAL)nz);
+            /* ---- loopfooter!: stepsize_controller! (PIController) ---- */
+            REAL q;
+            if (EEst == 0) {
+                q = (REAL)1 / r->qmax;
+            } else {
+                q11 = (REAL)udeo_fastpow((double)EEst, (double)r->beta1);
+                q = q11 / (REAL)udeo_fastpow((double)qold, (double)r->beta2);
+                q = q / r->gamma;
+                const REAL lo = (REAL)1 / r->qmax, hi = (REAL)1 / r->qmin;
+                if (q > hi) q = hi;
+                if (q < lo) q = lo;
+            }
+            accept = (EEst <= (REAL)1);
+            if (accept) {
+                nacc += 1;
+                qold = EEst > r->qoldinit ? EEst : r->qoldinit; /* step_accept_controller! */
+                REAL dtnew = dt / q;
+                const REAL tprev = t;
+                const REAL ttmp = t + dt;
+                {
+                    /* fixed_t_for_floatingpoint_error!: snap to the tstop if within 100 eps */
+                    const REAL mx = t > tstop ? t : tstop;
+                    t = R_FABS(ttmp - tstop) < (REAL)100 * FN(ulp)(mx) ? tstop : ttmp;
+                }
+                if (R_FABS(dtnew) > r->dtmax) dtnew = tdir * r->dtmax; /* calc_dt_propose! */
+                if (on_accept) {
+                    FN(stepinfo) si;
+                    si.alg = alg; si.nz = nz; si.f = f; si.fctx = fctx; si.tprev = tprev; si.t = t; si.dt = dt;
+                    si.uprev = uprev; si.u = u; si.k = kk; si.lazy_done = 0; si.nf_lazy = nf_lazy_out;
+                    if (on_accept(actx, &si)) { ret = UDEO_RET_MAXITERS; goto done; }
+                }
+                dt = dtnew;
+                memcpy(uprev, u, sizeof(REAL) * nz);
+                if (alg == UDEO_ALG_TSIT5) memcpy(kk[0], kk[6], sizeof(REAL) * nz); /* FSAL */
+                for (int i = 0; i < nz; ++i)
+                    if (u[i] != u[i]) { ret = UDEO_RET_UNSTABLE; goto done; }
+            } else {
+                nrej += 1;
+                if (EEst != EEst) { ret = UDEO_RET_UNSTABLE; goto done; }
+            }
+        }
+        /* ---- handle_tstop! + callbacks ---- */
+        its += 1;
+        if (on_tstop) {
+            if (on_tstop(tctx, t, uprev) && its < ntstops && alg == UDEO_ALG_TSIT5) {
+                f(fctx, t, uprev, kk[0]); /* reset_fsal! after u_modified! */
+                nf += 1;
+            }
+        }
+    }
+done:
+    memcpy(z, uprev, sizeof(REAL) * nz);
+    if (nf_out) *nf_out += nf;
+    if (nacc_out) *nacc_out += nacc;
+    if (nrej_out) *nrej_out += nrej;
+    free(mem);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a6/a7/a8 forward solve with saveat (OrdinaryDiffEq savevalues!) and optional dense storage.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int cap, nsteps, n, nk;
+    REAL* t; /* cap+1 */
+    REAL* u; /* n*(cap+1) */
+    REAL* k; /* n*nk*cap, step-major then stage-major */
+} FN(dense);
+
+typedef struct {
+    const udeo_model_desc* m;
+    const REAL* theta;
+} FN(fwdctx);
+
+static void FN(fwd_rhs)(void* ctx, REAL t, const REAL* z, REAL* dz) {
+    FN(fwdctx)* c = (FN(fwdctx)*)ctx;
+    FN(udeo_rhs)(c->m, c->theta, z, t, dz);
+}
+
+typedef struct {
+    int n, ns, si;
+    const REAL* saveat;
+    REAL* out; /* n x ns or NULL */
+    FN(dense)* d;
+    REAL* tmp;
+    int overflow;
+} FN(savectx);
+
+static int FN(fwd_accept)(void* ctx, FN(stepinfo)* s) {
+    FN(savectx)* c = (FN(savectx)*)ctx;
+    const int n = c->n;
+    /* savevalues!: every saveat time inside (tprev, t] */
+    while (c->si < c->ns && c->saveat[c->si] <= s->t) {
+        const REAL curt = c->saveat[c->si];
+        if (c->out) {
+            REAL* dst = c->out + (size_t)c->si * n;
+            if (curt != s->t) {
+                if (s->alg == UDEO_ALG_VERN7) FN(vern7_extra)(s, c->tmp);
+                const REAL th = (curt - s->tprev) / s->dt;
+                FN(interp)(s->alg, th, s->dt, s->uprev, s->k, n, dst);
+            } else {
+                memcpy(dst, s->u, sizeof(REAL) * n);
+            }
+        }
+        c->si += 1;
+    }
+    if (c->d) {
+        FN(dense)* d = c->d;
+        if (d->nsteps >= d->cap) { c->overflow = 1; return 1; }
+        if (s->alg == UDEO_ALG_VERN7) FN(vern7_extra)(s, c->tmp);
+        const int j = d->nsteps;
+        d->t[j + 1] = s->t;
+        memcpy(d->u + (size_t)(j + 1) * n, s->u, sizeof(REAL) * n);
+        for (int q = 0; q < d->nk; ++q) memcpy(d->k + ((size_t)j * d->nk + q) * n, s->k[q], sizeof(REAL) * n);
+        d->nsteps = j + 1;
+    }
+    return 0;
+}
+
+static int FN(solve_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const REAL* theta,
+                         const REAL* u0, REAL t0, REAL tf, const REAL* saveat, int ns, REAL* out,
+                         FN(dense)* d, int64_t* stats) {
+    const int n = m->n_state;
+    FN(ropts) r;
+    FN(resolve_opts)(o, t0, tf, &r);
+    FN(fwdctx) fc = {m, theta};
+    FN(savectx) sc;
+    sc.n = n; sc.ns = ns; sc.si = 0; sc.saveat = saveat; sc.out = out; sc.d = d; sc.overflow = 0;
+    sc.tmp = (REAL*)malloc(sizeof(REAL) * n);
+    REAL* z = (REAL*)malloc(sizeof(REAL) * n);
+    memcpy(z, u0, sizeof(REAL) * n);
+    while (sc.si < ns && saveat[sc.si] <= t0) { /* save_start */
+        if (out) memcpy(out + (size_t)sc.si * n, u0, sizeof(REAL) * n);
+        sc.si += 1;
+    }
+    if (d) {
+        d->nsteps = 0;
+        d->t[0] = t0;
+        memcpy(d->u, u0, sizeof(REAL) * n);
+    }
+    const REAL tstops[1] = {tf};
+    int ret = FN(integrate)(&r, n, FN(fwd_rhs), &fc, z, t0, tstops, 1, FN(fwd_accept), &sc, 0, 0,
+                            &stats[0], &stats[1], &stats[2], &stats[3]);
+    if (sc.overflow) ret = UDEO_RET_MAXITERS;
+    free(z);
+    free(sc.tmp);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a10: InterpolatingAdjoint (DiffEqSensitivity; call sites seir_exposure.jl:138-140,
+ * Fisher-KPP-CNN.jl:136).  SURVEY.md 3.2 / App. A.7: augmented state z = [lambda(n); mu(np)],
+ * z' = [-(df/du)^T lambda ; -(df/dtheta)^T lambda] at y(t) = dense forward interpolant, integrated
+ * tf -> t0 with the SAME alg/abstol/reltol, error norm over all n+np components, the save times as
+ * tstops with the discrete jump lambda += dL/du(t_i); jump at tf applied before the first step.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const udeo_model_desc* m;
+    const REAL* theta;
+    const FN(dense)* d;
+    int alg, n, np;
+    REAL* y;      /* n */
+    REAL* gtheta; /* np scratch */
+    const REAL* ts;
+    const REAL* cot; /* n x ns */
+    int ns, cur;     /* cur = index of the next (descending) save time to apply */
+} FN(adjctx);
+
+static void FN(dense_eval)(const FN(dense)* d, int alg, REAL t, REAL* y) {
+    /* sol(t, continuity=:right): interval [s, s+1] with t_s <= t, clamped */
+    int lo = 0, hi = d->nsteps - 1;
+    while (lo < hi) { /* largest s with t_s <= t */
+        const int mid = (lo + hi + 1) / 2;
+        if (d->t[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int s = lo;
+    const REAL dt = d->t[s + 1] - d->t[s];
+    const REAL th = (t - d->t[s]) / dt;
+    REAL* kp[16];
+    for (int q = 0; q < d->nk; ++q) kp[q] = d->k + ((size_t)s * d->nk + q) * d->n;
+    FN(interp)(alg, th, dt, d->u + (size_t)s * d->n, kp, d->n, y);
+}
+
+static void FN(adj_rhs)(void* ctx, REAL t, const REAL* z, REAL* dz) {
+    FN(adjctx)* c = (FN(adjctx)*)ctx;
+    FN(dense_eval)(c->d, c->alg, t, c->y);
+    for (int i = 0; i < c->np; ++i) c->gtheta[i] = 0;
+    FN(udeo_rhs_vjp)(c->m, c->theta, c->y, t, z, dz, c->gtheta);
+    for (int i = 0; i < c->n; ++i) dz[i] = -dz[i];
+    for (int i = 0; i < c->np; ++i) dz[c->n + i] = -c->gtheta[i];
+}
+
+static int FN(adj_tstop)(void* ctx, REAL t, REAL* z) {
+    FN(adjctx)* c = (FN(adjctx)*)ctx;
+    int mod = 0;
+    while (c->cur >= 0 && c->ts[c->cur] >= t) {
+        if (c->ts[c->cur] == t) {
+            for (int i = 0; i < c->n; ++i) z[i] += c->cot[(size_t)c->cur * c->n + i];
+            mod = 1;
+        }
+        c->cur -= 1;
+    }
+    return mod;
+}
+
+/* forward dense + backward; cot: n x ns.  grad_theta += ; grad_u0 (n) = */
+static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const REAL* theta,
+                       const REAL* u0, REAL t0, REAL tf, const REAL* saveat, int ns,
+                       const REAL* cot_in, const REAL* data, const uint8_t* mask, REAL* loss_out,
+                       REAL* u_out, REAL* grad_theta, REAL* grad_u0, int64_t* stats) {
+    const int n = m->n_state, np = m->n_param;
+    const int alg = o->alg;
+    const int nk = alg == UDEO_ALG_TSIT5 ? 7 : 16;
+    int cap = 256;
+    FN(dense) d;
+    REAL* pred = (REAL*)malloc(sizeof(REAL) * (size_t)n * ns);
+    int ret;
+    for (;;) {
+        d.cap = cap; d.n = n; d.nk = nk; d.nsteps = 0;
+        d.t = (REAL*)malloc(sizeof(REAL) * (cap + 1));
+        d.u = (REAL*)malloc(sizeof(REAL) * (size_t)n * (cap + 1));
+        d.k = (REAL*)malloc(sizeof(REAL) * (size_t)n * nk * cap);
+        int64_t st[4] = {0, 0, 0, 0};
+        ret = FN(solve_one)(m, o, theta, u0, t0, tf, saveat, ns, pred, &d, st);
+        if (ret == UDEO_RET_MAXITERS && d.nsteps >= cap && cap < (1 << 20)) {
+            free(d.t); free(d.u); free(d.k);
+            cap *= 4;
+            continue;
+        }
+        for (int i = 0; i < 4; ++i) stats[i] += st[i];
+        break;
+    }
+    /* the primal returned by concrete_solve is sol(saveat): identical interpolants to savevalues! */
+    if (u_out) memcpy(u_out, pred, sizeof(REAL) * (size_t)n * ns);
+    if (ret != UDEO_RET_SUCCESS) { free(d.t); free(d.u); free(d.k); free(pred); return ret; }
+    /* with the dense forward pass the Vern7 lazy stages are part of the adjoint's own cost */
+    stats[7] += stats[3]; stats[3] = 0;
+
+    REAL* cot = (REAL*)malloc(sizeof(REAL) * (size_t)n * ns);
+    if (cot_in) {
+        memcpy(cot, cot_in, sizeof(REAL) * (size_t)n * ns);
+    } else {
+        REAL L = 0;
+        for (int i = 0; i < ns; ++i)
+            for (int c = 0; c < n; ++c) {
+                const REAL e = (mask && !mask[c]) ? (REAL)0 : pred[(size_t)i * n + c] - data[(size_t)i * n + c];
+                L += e * e;
+                cot[(size_t)i * n + c] = (REAL)2 * e;
+            }
+        if (loss_out) *loss_out = L;
+    }
+
+    const int nz = n + np;
+    REAL* z = (REAL*)calloc(nz, sizeof(REAL));
+    FN(adjctx) ac;
+    ac.m = m; ac.theta = theta; ac.d = &d; ac.alg = alg; ac.n = n; ac.np = np;
+    ac.y = (REAL*)malloc(sizeof(REAL) * n);
+    ac.gtheta = (REAL*)malloc(sizeof(REAL) * (np > 0 ? np : 1));
+    ac.ts = saveat; ac.cot = cot; ac.ns = ns; ac.cur = ns - 1;
+    /* tstops: save times strictly inside (t0, tf) descending, then t0 */
+    REAL* tst = (REAL*)malloc(sizeof(REAL) * (ns + 1));
+    int nt = 0;
+    for (int i = ns - 1; i >= 0; --i)
+        if (saveat[i] < tf && saveat[i] > t0) tst[nt++] = saveat[i];
+    tst[nt++] = t0;
+    FN(adj_tstop)(&ac, tf, z); /* init_cb: jump at t = tf before the first step */
+    FN(ropts) r;
+    FN(resolve_opts)(o, t0, tf, &r);
+    r.dt0 = 0;
+    ret = FN(integrate)(&r, nz, FN(adj_rhs), &ac, z, tf, tst, nt, 0, 0, FN(adj_tstop), &ac,
+                        &stats[4], &stats[5], &stats[6], 0);
+    for (int i = 0; i < np; ++i) grad_theta[i] += z[n + i];
+    if (grad_u0) for (int i = 0; i < n; ++i) grad_u0[i] = z[i];
+    free(tst); free(ac.y); free(ac.gtheta); free(z); free(cot);
+    free(d.t); free(d.u); free(d.k); free(pred);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Ensemble entry points (trajectories share theta).  OpenMP over trajectories
+ * is the "CPU restatement" baseline timed by bench.py's cpu_baseline leg.
+ * ------------------------------------------------------------------------------------------ */
+int FN(udeo_solve_ensemble)(const udeo_model_desc* m, const udeo_solve_opts* o, int64_t N,
+                            const REAL* u0, const REAL* tspan, const REAL* theta, const REAL* saveat,
+                            int32_t ns, REAL* u_out, int64_t* stats, int32_t* retcode, int32_t nthreads) {
+    const int n = m->n_state;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 1 ? nthreads : 1)
+#endif
+    for (int64_t j = 0; j < N; ++j) {
+        int64_t st[UDEO_NSTATS] = {0};
+        int rc = FN(solve_one)(m, o, theta, u0 + (size_t)j * n, tspan[0], tspan[1], saveat, ns,
+                               u_out ? u_out + (size_t)j * n * ns : 0, 0, st);
+        if (stats) memcpy(stats + (size_t)j * UDEO_NSTATS, st, sizeof(st));
+        if (retcode) retcode[j] = rc;
+    }
+    return 0;
+}
