@@ -12,6 +12,8 @@
 #endif
 
 #include "ude_tableaux_gen.h"
+#include <stdio.h>
+int udeo_debug = 0; /* set to 1 (ctypes) to trace every step on stderr */
 
 /* ------------------------------------------------------------------------------------------
  * DiffEqBase.fastpow: Float64(exp2(Float32(y) * fastlog2(Float32(x)))) with

@@ -34,7 +34,7 @@ enum {
     UDEO_KIND_LV_UDE = 1,    /* ude_dynamics!     scenario_1.jl:69-73, scenario_2.jl:90-95, hudson_bay.jl:85-91 */
     UDEO_KIND_SEIR_TRUE = 2, /* corona!           SEIR_exposure/seir_exposure.jl:16-30    consts = p_[9] */
     UDEO_KIND_SEIR_UDE = 3,  /* dudt_             seir_exposure.jl:117-130 */
-    UDEO_KIND_KPP_TRUE = 4,  /* rc_ode            FisherKPP/Fisher-KPP-CNN.jl:51-63, scenario_3.jl:43-53  consts = D, r, 1/dx^2 */
+    UDEO_KIND_KPP_TRUE = 4,  /* rc_ode            FisherKPP/Fisher-KPP-CNN.jl:51-63, scenario_3.jl:43-53  consts = D/dx^2, -2D/dx^2, r */
     UDEO_KIND_KPP_UDE = 5    /* nn_ode            Fisher-KPP-CNN.jl:111-126, scenario_3.jl:103-114 */
 };
 enum { UDEO_ACT_IDENTITY = 0, UDEO_ACT_TANH = 1, UDEO_ACT_RBF = 2, UDEO_ACT_RELU = 3 };
@@ -57,7 +57,7 @@ typedef struct {
     int32_t reserved;
     double lin_sign[2];                 /* LV_UDE: du_i = (lin_idx<0 ? lin_const : lin_sign*theta[lin_idx]) * u_i + NN_i(u) */
     double lin_const[2];
-    double consts[16];                  /* SEIR: p_[0..8] = F,beta0,alpha,kappa,mu,sigma,gamma,d,lambda; KPP_TRUE: D, r, 1/dx^2 */
+    double consts[16];                  /* SEIR: p_[0..8] = F,beta0,alpha,kappa,mu,sigma,gamma,d,lambda; KPP_TRUE: D/dx^2, -2D/dx^2, r */
 } udeo_model_desc;
 
 typedef struct {

@@ -142,14 +142,15 @@ void FN(udeo_rhs)(const udeo_model_desc* m, const REAL* th, const REAL* u, REAL 
             du[5] = d * ga * I - la * D;
             du[6] = sg * E;
         } break;
-        case UDEO_KIND_KPP_TRUE: { /* Fisher-KPP-CNN.jl:51-63: D*lap*rho + r*rho*(1-rho), periodic */
+        case UDEO_KIND_KPP_TRUE: { /* Fisher-KPP-CNN.jl:51-63: (D*lap)*rho + r*rho*(1-rho), periodic */
+            /* consts = (D/dx^2, -2D/dx^2, r): the entries of the matrix D*lap as Julia forms them */
             const int n = m->n_state;
-            const REAL D = (REAL)m->consts[0], r = (REAL)m->consts[1], w = (REAL)m->consts[2];
+            const REAL coff = (REAL)m->consts[0], cdiag = (REAL)m->consts[1], r = (REAL)m->consts[2];
             for (int i = 0; i < n; ++i) {
                 const int im = (i + n - 1) % n, ip = (i + 1) % n;
                 /* dense mat-vec row: nonzeros visited in ascending column order */
                 int idx[3] = {im, i, ip};
-                REAL cf[3] = {w, (REAL)-2 * w, w};
+                REAL cf[3] = {coff, cdiag, coff};
                 for (int a = 0; a < 3; ++a)
                     for (int b2 = a + 1; b2 < 3; ++b2)
                         if (idx[b2] < idx[a]) {
@@ -158,7 +159,7 @@ void FN(udeo_rhs)(const udeo_model_desc* m, const REAL* th, const REAL* u, REAL 
                         }
                 REAL acc = 0;
                 for (int a = 0; a < 3; ++a) acc += cf[a] * u[idx[a]];
-                du[i] = D * acc + r * u[i] * ((REAL)1 - u[i]);
+                du[i] = acc + (r * u[i]) * ((REAL)1 - u[i]);
             }
         } break;
         case UDEO_KIND_KPP_UDE: { /* Fisher-KPP-CNN.jl:111-126 */
@@ -577,6 +578,7 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
                 if (q < lo) q = lo;
             }
             accept = (EEst <= (REAL)1);
+            if (udeo_debug) fprintf(stderr, "step iter=%d t=%.9g dt=%.9g EEst=%.9g q=%.9g acc=%d\n", iter, (double)t, (double)dt, (double)EEst, (double)q, accept);
             if (accept) {
                 nacc += 1;
                 qold = EEst > r->qoldinit ? EEst : r->qoldinit; /* step_accept_controller! */

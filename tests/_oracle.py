@@ -104,12 +104,17 @@ def seir_ude(p=SEIR_P):
 
 
 def kpp_true(nx=26, D=0.01, r=1.0, dx=0.04, dtype=0):
-    """rc_ode (Fisher-KPP-CNN.jl:51-63 / scenario_3.jl:43-53)"""
+    """rc_ode (Fisher-KPP-CNN.jl:51-63 / scenario_3.jl:43-53): consts = entries of D*lap and r,
+    formed in the problem's float type the way the script forms them."""
     if dtype == 1:
-        inv = float(np.float32(1.0) / (np.float32(dx) * np.float32(dx)))
+        f = np.float32
+        dx2 = f(f(dx) * f(dx))
+        off = f(np.float64(1.0) / np.float64(dx2))       # Float32.(diagm(...) ./ dx^2)
+        dia = f(np.float64(-2.0) / np.float64(dx2))
+        consts = (float(f(f(D) * off)), float(f(f(D) * dia)), float(f(r)))
     else:
-        inv = 1.0 / dx ** 2
-    return make_model(KIND_KPP_TRUE, nx, n_param=0, consts=(D, r, inv), dtype=dtype)
+        consts = (D * (1.0 / dx ** 2), D * (-2.0 / dx ** 2), r)
+    return make_model(KIND_KPP_TRUE, nx, n_param=0, consts=consts, dtype=dtype)
 
 
 def kpp_ude(nx=26, dims=(1, 10, 20, 10, 1), acts=("tanh", "tanh", "tanh", "identity"), dtype=0):

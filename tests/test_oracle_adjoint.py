@@ -1,0 +1,136 @@
+"""Oracle checks for the InterpolatingAdjoint restatement.  CPU only.
+
+The reference holds no golden for the backward solve; the only gradient pin it offers is the stored
+ADAM loss trajectory of scenario_1 (losses[1..3]); everything else is finite differences.
+"""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+S1 = "Scenario_1_recovery_0.005"
+
+
+def fd_jac(f, x, h=1e-6):
+    x = np.asarray(x, dtype=float)
+    cols = []
+    for i in range(len(x)):
+        e = np.zeros_like(x)
+        e[i] = h * max(1.0, abs(x[i]))
+        cols.append((f(x + e) - f(x - e)) / (2 * e[i]))
+    return np.array(cols).T  # (nout, nin)
+
+
+MODELS = [
+    ("lv_s1", O.lv_ude_s1, [0.7, 2.3]),
+    ("lv_s2", O.lv_ude_s2, [0.7, 2.3]),
+    ("lv_hudson", O.lv_ude_hudson, [0.4, 0.2]),
+    ("lv_tanh32", O.lv_ude_tanh32, [0.4, 0.2]),
+    ("lv_true", O.lv_true, [0.4, 1.2]),
+    # population scaled to O(100) so finite differences resolve the NN term next to beta0*S*F/N
+    ("seir", O.seir_ude, [90.0, 1.0, 2.0, 0.3, 100.0, 0.5, 3.0]),
+    ("kpp", lambda: O.kpp_ude(12), list(np.linspace(0.05, 0.9, 12))),
+    ("kpp_s3", lambda: O.kpp_ude_s3(0), list(np.linspace(0.05, 0.9, 26))),
+]
+
+
+@pytest.mark.parametrize("name,mk,u", MODELS)
+def test_rhs_vjp_matches_finite_differences(name, mk, u):
+    m = mk()
+    rng = np.random.default_rng(3)
+    th = rng.uniform(-0.5, 0.5, m.n_param)
+    if name == "lv_true":
+        th = np.array([1.3, 0.9, 0.8, 1.8])
+    if name.startswith("kpp"):
+        th[m.d0_offset] = 6.5
+        th[m.stencil_offset:m.stencil_offset + 3] = [1.1, -2.5, 1.0]
+    u = np.array(u, dtype=float)
+    lam = rng.normal(size=len(u))
+    dlam, dth = O.rhs_vjp(m, th, u, lam)
+    Ju = fd_jac(lambda x: O.rhs(m, th, x), u, 1e-6)
+    Jt = fd_jac(lambda x: O.rhs(m, x, u), th, 1e-6)
+    assert np.allclose(dlam, Ju.T @ lam, rtol=2e-6, atol=1e-8 * np.abs(Ju.T @ lam).max())
+    assert np.allclose(dth, Jt.T @ lam, rtol=2e-6, atol=1e-8 * np.abs(Jt.T @ lam).max())
+
+
+def s1_setup(golden):
+    g = golden(S1)
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+    t = np.array(g["solution"]["t"])
+    return g, X, t
+
+
+def s1_loss(theta, X, t, alg, tol):
+    out, st, rc = O.solve_ensemble(O.lv_ude_s1(), O.opts(alg, tol, tol), X[0], [t[0], t[-1]], theta, t)
+    return float(((X - out[0]) ** 2).sum())
+
+
+@pytest.mark.parametrize("alg,tol,bound", [(O.TSIT5, 1e-6, 1e-6), (O.VERN7, 1e-6, 1e-6), (O.TSIT5, 1e-9, 1e-8)])
+def test_adjoint_gradient_vs_finite_differences(golden, alg, tol, bound):
+    g, X, t = s1_setup(golden)
+    th = np.array(g["initial_parameters"])
+    r = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(alg, tol, tol), X[0], [t[0], t[-1]], th, t, X[None])
+    assert r["retcode"][0] == 0
+    fd = np.zeros_like(th)
+    for i in range(len(th)):
+        e = np.zeros_like(th)
+        e[i] = 1e-6
+        fd[i] = (s1_loss(th + e, X, t, O.VERN7, 1e-11) - s1_loss(th - e, X, t, O.VERN7, 1e-11)) / 2e-6
+    rel = np.linalg.norm(r["grad_theta"] - fd) / np.linalg.norm(fd)
+    assert rel < bound, rel
+    # loss returned by the adjoint entry point = loss of the plain solve (primal is sol(saveat))
+    assert abs(r["loss"] - s1_loss(th, X, t, alg, tol)) < 1e-12 * r["loss"]
+
+
+def test_adjoint_work_counts_cross_check(golden):
+    """SURVEY.md App. A.8 (an independent Python restatement): LV UDE at theta_init, Tsit5 tol 1e-6:
+    forward 27 steps / nf 165, backward 80 steps / nf 512."""
+    g, X, t = s1_setup(golden)
+    th = np.array(g["initial_parameters"])
+    r = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(O.TSIT5, 1e-6, 1e-6), X[0], [t[0], t[-1]], th, t, X[None])
+    st = r["stats"][0]
+    assert (st[0], st[1] + st[2]) == (165, 27)
+    assert st[5] == 80
+    assert st[4] == 512
+
+
+def test_adam_trajectory_known_answer(golden):
+    """App. A.6: Optimisers.ADAM(0.1), callback sees loss(theta_k) before the update (scenario_1.jl:99-114);
+    an adjoint gradient good to 1e-6 reproduces the stored losses[1..3]."""
+    g, X, t = s1_setup(golden)
+    gold = g["losses"]["data_colmajor"]
+    th = np.array(g["initial_parameters"])
+    m = O.lv_ude_s1()
+    o = O.opts(O.VERN7, 1e-6, 1e-6)
+    eta, b1, b2, eps = 0.1, 0.9, 0.999, np.finfo(float).eps
+    mt, vt = np.zeros_like(th), np.zeros_like(th)
+    b1t, b2t = b1, b2
+    for k in range(4):
+        r = O.loss_grad_ensemble(m, o, X[0], [t[0], t[-1]], th, t, X[None])
+        tol = 1e-11 if k == 0 else 2e-6
+        assert abs(r["loss"] - gold[k]) < tol * gold[k], (k, r["loss"], gold[k])
+        gr = r["grad_theta"]
+        mt = b1 * mt + (1 - b1) * gr
+        vt = b2 * vt + (1 - b2) * gr * gr
+        th = th - eta * (mt / (1 - b1t)) / (np.sqrt(vt / (1 - b2t)) + eps)
+        b1t *= b1
+        b2t *= b2
+
+
+def test_ensemble_gradient_is_sum_of_trajectories(golden):
+    g, X, t = s1_setup(golden)
+    th = np.array(g["trained_parameters"])
+    m = O.lv_ude_s1()
+    o = O.opts(O.TSIT5, 1e-6, 1e-6)
+    rng = np.random.default_rng(0)
+    u0 = X[0] * (1 + 0.2 * rng.uniform(-1, 1, (5, 2)))
+    data = np.repeat(X[None], 5, axis=0)
+    rall = O.loss_grad_ensemble(m, o, u0, [t[0], t[-1]], th, t, data, nthreads=2)
+    gsum = np.zeros_like(th)
+    lsum = 0.0
+    for j in range(5):
+        r = O.loss_grad_ensemble(m, o, u0[j], [t[0], t[-1]], th, t, data[j:j + 1])
+        gsum += r["grad_theta"]
+        lsum += r["loss"]
+    assert np.allclose(rall["grad_theta"], gsum, rtol=1e-12, atol=1e-14)
+    assert abs(rall["loss"] - lsum) < 1e-12 * lsum
