@@ -1,0 +1,153 @@
+/*
+ * udecore.h -- C ABI of the MI355X-native UDE training core (libudecore.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference has no
+ * FFI of its own: its extension mechanism is Julia multiple dispatch on the algorithm / sensealg /
+ * ensemble-algorithm types.  Each entry point below names the reference interface it replaces; the
+ * Julia `ccall` shim that a maintainer would add is in INTEGRATION.md / julia/UDECoreMI355.jl.
+ *
+ * Conventions: plain pointers and sizes, no torch types; every function returns 0 on success or a
+ * negative UDE_ERR_* (message via ude_last_error); the caller owns every buffer.  Arrays are
+ * column-major as Julia hands them over: u0 is n x N (trajectory j = column j), u_out / data /
+ * cotangent are n x ns x N, theta is the flat parameter vector ([leading scalars; per Dense layer
+ * vec(W) (out x in, column-major); b]).  Device-resident (`_dev`) entry points take HBM pointers of
+ * the same layouts and are asynchronous on the context's stream; the host-buffer entry points copy
+ * H<->D and block.  One context per device and host thread.
+ */
+#ifndef UDECORE_H
+#define UDECORE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UDE_VERSION 100 /* 0.1.0 */
+#define UDE_MAX_LAYERS 8
+#define UDE_NSTATS 8
+
+/* right-hand-side families ("declarative RHS descriptor": Julia closures cannot cross a C ABI) */
+enum {
+    UDE_KIND_LV_TRUE = 0,   /* lotka!        LotkaVolterra/scenario_1.jl:30-34 */
+    UDE_KIND_LV_UDE = 1,    /* ude_dynamics! scenario_1.jl:69-73, scenario_2.jl:90-95, hudson_bay.jl:85-91 */
+    UDE_KIND_SEIR_TRUE = 2, /* corona!       SEIR_exposure/seir_exposure.jl:16-30 */
+    UDE_KIND_SEIR_UDE = 3,  /* dudt_         seir_exposure.jl:117-130 */
+    UDE_KIND_KPP_TRUE = 4,  /* rc_ode        FisherKPP/Fisher-KPP-CNN.jl:51-63, LotkaVolterra/scenario_3.jl:43-53 */
+    UDE_KIND_KPP_UDE = 5    /* nn_ode        Fisher-KPP-CNN.jl:111-126, scenario_3.jl:103-114 */
+};
+enum { UDE_ACT_IDENTITY = 0, UDE_ACT_TANH = 1, UDE_ACT_RBF = 2 /* scenario_1.jl:59 */, UDE_ACT_RELU = 3 };
+enum { UDE_ALG_TSIT5 = 0 /* Tsit5() scenario_1.jl:191 */, UDE_ALG_VERN7 = 1 /* Vern7() scenario_1.jl:84 */ };
+/* per-trajectory return codes mirror the SciML retcodes stored in the reference's artifacts */
+enum { UDE_RET_SUCCESS = 0, UDE_RET_MAXITERS = 1, UDE_RET_DTLESSTHANMIN = 2, UDE_RET_UNSTABLE = 3,
+       UDE_RET_DENSE_OVERFLOW = 4 /* forward pass exceeded opts.max_dense_steps (adjoint only) */ };
+enum { UDE_OK = 0, UDE_ERR_INVALID = -1, UDE_ERR_UNSUPPORTED = -2, UDE_ERR_HIP = -3, UDE_ERR_NOMEM = -4,
+       UDE_ERR_TRAJECTORY = -5 /* at least one trajectory has retcode != Success */ };
+
+/* replaces: the RHS closure + Lux/FastChain/Flux model captured by ODEProblem(f, u0, tspan, p)
+ * (scenario_1.jl:62-78, seir_exposure.jl:114-131, Fisher-KPP-CNN.jl:92-131) */
+typedef struct {
+    int32_t kind;
+    int32_t dtype;                     /* 0 = f64 (f32 problems are not built yet: UDE_ERR_UNSUPPORTED) */
+    int32_t n_state;
+    int32_t n_param;                   /* length of theta */
+    int32_t n_layers;                  /* number of Dense layers (0 for mechanistic kinds) */
+    int32_t dims[UDE_MAX_LAYERS + 1];  /* dims[0] = in ... dims[n_layers] = out */
+    int32_t act[UDE_MAX_LAYERS];
+    int32_t nn_offset;                 /* theta index of the first NN parameter */
+    int32_t lin_idx[2];                /* LV_UDE: theta index of a trainable diagonal coefficient, or -1 */
+    int32_t stencil_offset;            /* KPP_UDE: theta index of w1 (w1, w2, w3, one unused slot) */
+    int32_t d0_offset;                 /* KPP_UDE: theta index of D0 */
+    int32_t reserved;
+    double lin_sign[2];                /* LV_UDE: du_i = (lin_idx<0 ? lin_const : lin_sign*theta[lin_idx])*u_i + NN_i(u) */
+    double lin_const[2];
+    double consts[16];                 /* SEIR: p_[0..8]; KPP_TRUE: D/dx^2, -2D/dx^2, r */
+} ude_model_desc;
+
+/* replaces: the keyword arguments of solve(prob, alg; saveat, abstol, reltol, ...) actually used by the
+ * scripts (scenario_1.jl:84-87, seir_exposure.jl:138-140, Fisher-KPP-CNN.jl:136); zero = SciML default */
+typedef struct {
+    int32_t alg;
+    int32_t maxiters;   /* <=0 -> 100000 */
+    double abstol;      /* <=0 -> 1e-6 */
+    double reltol;      /* <=0 -> 1e-3 */
+    double dtmax;       /* <=0 -> |tf - t0| */
+    double dt0;         /* >0 -> initial dt instead of the Hairer heuristic */
+    double qmin, qmax, gamma, qoldinit; /* <=0 -> 0.2, 10, 0.9, 1e-4 */
+    double beta1, beta2;                /* <=0 -> 7/(10 order), 2/(5 order) */
+} ude_solve_opts;
+
+/* launch/tuning knobs of the HIP back end (not part of the reference surface) */
+typedef struct {
+    int32_t lanes_per_traj;   /* 0 = auto; lanes of a wavefront cooperating on one trajectory (1,2,4,8,...,64) */
+    int32_t block_threads;    /* 0 = auto (64) */
+    int32_t max_dense_steps;  /* capacity of the dense forward store per trajectory, 0 = 256 */
+    int32_t reserved;
+} ude_launch_opts;
+
+/* per-trajectory stats, int64[UDE_NSTATS]:
+ * 0 nf (= upstream destats.nf) 1 naccept 2 nreject 3 nf_lazy (Vern7 lazy dense-output evals)
+ * 4 nf_bwd (augmented adjoint RHS evals) 5 naccept_bwd 6 nreject_bwd 7 nf_fwd_lazy_for_adjoint */
+
+typedef struct ude_ctx ude_ctx;
+
+int ude_version(void);
+/* one context per (device, host thread); replaces nothing (the reference is single-process CPU Julia) */
+int ude_create(int32_t device_id, ude_ctx** out);
+void ude_destroy(ude_ctx* ctx);
+const char* ude_last_error(ude_ctx* ctx);
+/* stream on which the _dev entry points enqueue (a hipStream_t); NULL = the null stream */
+int ude_set_stream(ude_ctx* ctx, void* hip_stream);
+int ude_set_launch_opts(ude_ctx* ctx, const ude_launch_opts* lo);
+/* 0 if this (model, alg) has a compiled kernel, UDE_ERR_UNSUPPORTED otherwise */
+int ude_model_supported(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int32_t need_adjoint);
+
+/* replaces: Array(solve(remake(prob; u0, tspan, p = theta), alg; saveat, abstol, reltol)) for every
+ * member of an ensemble sharing theta (predict: scenario_1.jl:82-88; scenario_2.jl:113-124 segments;
+ * EnsembleProblem slot: SciMLBase.__solve(::EnsembleProblem, alg, ::EnsembleAlgorithm)). */
+int ude_solve_ensemble(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                       const double* u0, const double* tspan, const double* theta,
+                       const double* saveat, int32_t ns, double* u_out, int64_t* stats, int32_t* retcode);
+int ude_solve_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                           const double* u0, const double* tspan, const double* theta,
+                           const double* saveat, int32_t ns, double* u_out, int64_t* stats, int32_t* retcode);
+
+/* replaces: the Zygote pullback of concrete_solve(prob, alg, u0, theta; saveat,
+ * sensealg = InterpolatingAdjoint(autojacvec = ReverseDiffVJP())) (seir_exposure.jl:138-140,
+ * Fisher-KPP-CNN.jl:136): cotangent (n x ns x N) -> grad_theta (np, summed over the ensemble),
+ * grad_u0 (n x N, may be NULL).  u_out (may be NULL) receives the primal sol(saveat). */
+int ude_vjp_ensemble(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                     const double* u0, const double* tspan, const double* theta, const double* saveat,
+                     int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
+                     double* grad_u0, int64_t* stats, int32_t* retcode);
+int ude_vjp_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                         const double* u0, const double* tspan, const double* theta, const double* saveat,
+                         int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
+                         double* grad_u0, int64_t* stats, int32_t* retcode);
+
+/* replaces: loss(theta) = sum(abs2, data[rows,:] .- predict(theta)[rows,:]) and its gradient
+ * (seir_exposure.jl:144-147 rows 2:4; Fisher-KPP-CNN.jl:140-143 without the host-side penalty term;
+ * scenario_1.jl:91-94), summed over the ensemble.  row_mask: n bytes (NULL = all rows).
+ * loss: one double.  loss_per_traj (N doubles) may be NULL. */
+int ude_loss_grad_ensemble(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                           const double* u0, const double* tspan, const double* theta,
+                           const double* saveat, int32_t ns, const double* data, const uint8_t* row_mask,
+                           double* loss, double* loss_per_traj, double* grad_theta, double* grad_u0,
+                           double* u_out, int64_t* stats, int32_t* retcode);
+int ude_loss_grad_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                               const double* u0, const double* tspan, const double* theta,
+                               const double* saveat, int32_t ns, const double* data, const uint8_t* row_mask,
+                               double* loss, double* loss_per_traj, double* grad_theta, double* grad_u0,
+                               double* u_out, int64_t* stats, int32_t* retcode);
+
+/* device time (ms) of the forward and backward kernels of the most recent call on this context,
+ * measured with HIP events on the context's stream (valid after the stream has been synchronised) */
+int ude_last_kernel_ms(ude_ctx* ctx, float* fwd_ms, float* bwd_ms);
+
+/* DiffEqBase.fastpow as evaluated on the device (one thread), for parity tests of the controller */
+int ude_fastpow_dev(ude_ctx* ctx, int64_t n, const double* x_host, const double* y_host, double* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+"""ctypes binding of libudecore.so (include/udecore.h).  The HIP library is the product: if it is
+missing this module raises -- there is no CPU fallback anywhere in the package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libudecore.so")
+MAX_LAYERS = 8
+NSTATS = 8
+
+KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE = range(6)
+ACT = {"identity": 0, "tanh": 1, "rbf": 2, "relu": 3}
+ALG_TSIT5, ALG_VERN7 = 0, 1
+RETCODES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable", 4: "DenseOverflow"}
+UDE_ERR_TRAJECTORY = -5
+
+
+class ModelDesc(C.Structure):
+    """ude_model_desc"""
+    _fields_ = [
+        ("kind", C.c_int32), ("dtype", C.c_int32), ("n_state", C.c_int32), ("n_param", C.c_int32),
+        ("n_layers", C.c_int32), ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("act", C.c_int32 * MAX_LAYERS),
+        ("nn_offset", C.c_int32), ("lin_idx", C.c_int32 * 2), ("stencil_offset", C.c_int32),
+        ("d0_offset", C.c_int32), ("reserved", C.c_int32),
+        ("lin_sign", C.c_double * 2), ("lin_const", C.c_double * 2), ("consts", C.c_double * 16),
+    ]
+
+
+class SolveOpts(C.Structure):
+    """ude_solve_opts"""
+    _fields_ = [
+        ("alg", C.c_int32), ("maxiters", C.c_int32), ("abstol", C.c_double), ("reltol", C.c_double),
+        ("dtmax", C.c_double), ("dt0", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double),
+        ("gamma", C.c_double), ("qoldinit", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+    ]
+
+
+class LaunchOpts(C.Structure):
+    """ude_launch_opts"""
+    _fields_ = [("lanes_per_traj", C.c_int32), ("block_threads", C.c_int32), ("max_dense_steps", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class UdeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("udecore error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+EXPORTS = ["ude_version", "ude_create", "ude_destroy", "ude_last_error", "ude_set_stream", "ude_set_launch_opts",
+           "ude_model_supported", "ude_solve_ensemble", "ude_solve_ensemble_dev", "ude_vjp_ensemble",
+           "ude_vjp_ensemble_dev", "ude_loss_grad_ensemble", "ude_loss_grad_ensemble_dev", "ude_last_kernel_ms",
+           "ude_fastpow_dev"]
+
+
+def load():
+    """Load libudecore.so; raises if the HIP extension has not been built (python -m ...build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libudecore.so is missing: build it with `python -m universal_differential_equations_amd.build` "
+                          "(the HIP library is required; there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.ude_version.restype = C.c_int
+    L.ude_create.argtypes = [i32, C.POINTER(vp)]
+    L.ude_destroy.argtypes = [vp]
+    L.ude_destroy.restype = None
+    L.ude_last_error.argtypes = [vp]
+    L.ude_last_error.restype = C.c_char_p
+    L.ude_set_stream.argtypes = [vp, vp]
+    L.ude_set_launch_opts.argtypes = [vp, C.POINTER(LaunchOpts)]
+    L.ude_model_supported.argtypes = [vp, C.POINTER(ModelDesc), C.POINTER(SolveOpts), i32]
+    common = [vp, C.POINTER(ModelDesc), C.POINTER(SolveOpts), i64, vp, vp, vp, vp, i32]
+    for name in ("ude_solve_ensemble", "ude_solve_ensemble_dev"):
+        getattr(L, name).argtypes = common + [vp, vp, vp]
+    for name in ("ude_vjp_ensemble", "ude_vjp_ensemble_dev"):
+        getattr(L, name).argtypes = common + [vp, vp, vp, vp, vp, vp]
+    for name in ("ude_loss_grad_ensemble", "ude_loss_grad_ensemble_dev"):
+        getattr(L, name).argtypes = common + [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ude_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ude_fastpow_dev.argtypes = [vp, i64, vp, vp, vp]
+    _lib = L
+    return L

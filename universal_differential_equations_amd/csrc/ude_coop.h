@@ -1,0 +1,189 @@
+// ude_coop.h -- lane-group cooperation primitives and the cooperative small-MLP (a2).
+//
+// Execution layout: G consecutive lanes of a 64-wide wavefront own ONE trajectory.  The small ODE state
+// (and the adjoint lambda) is replicated in the registers of all G lanes; the neurons of every Dense
+// layer -- and with them the rows of the parameter gradient mu -- are dealt round-robin to the G lanes
+// (neuron j lives on lane j % G).  One all-gather per layer hands the new activations to every lane.
+// G = 1 degenerates to "one trajectory per lane", G = 64 to "one wavefront per trajectory".
+#pragma once
+#include <type_traits>
+
+#include "ude_math.h"
+
+namespace ude {
+
+// value of x held by lane `src` of this lane's group (src < G is a compile-time constant)
+template <int G>
+__device__ __forceinline__ double group_bcast(double x, int src) {
+    if constexpr (G == 1) {
+        return x;
+    } else {
+        return __shfl(x, src, G);
+    }
+}
+
+// sum over the G lanes of a group; every lane receives the same bits (xor butterfly, commutative adds)
+template <int G>
+__device__ __forceinline__ double group_sum(double x) {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) x += __shfl_xor(x, m, G);
+    return x;
+}
+
+template <int... V>
+struct IntList {
+    static constexpr int n = sizeof...(V);
+    static constexpr int at(int i) {
+        constexpr int v[] = {V...};
+        return v[i];
+    }
+};
+
+// Dense-layer stack: dims D0 -> D1 -> ... -> DL, activation per layer.
+// theta layout per layer: [vec(W) column-major (out x in); b(out)]  (Lux / FastChain / Flux.destructure)
+template <class DIMS, class ACTS>
+struct NetCfg {
+    static constexpr int L = DIMS::n - 1;
+    static_assert(ACTS::n == L, "one activation per Dense layer");
+    static constexpr int dim(int l) { return DIMS::at(l); }
+    static constexpr int act(int l) { return ACTS::at(l); }
+    static constexpr int off(int l) {  // theta offset of layer l relative to the first NN parameter
+        int o = 0;
+        for (int i = 0; i < l; ++i) o += dim(i) * dim(i + 1) + dim(i + 1);
+        return o;
+    }
+    static constexpr int nparam = off(L);
+    static constexpr int maxdim() {
+        int m = 0;
+        for (int i = 0; i <= L; ++i) m = dim(i) > m ? dim(i) : m;
+        return m;
+    }
+};
+
+template <class N, int G>
+struct CoopMlp {
+    static constexpr int L = N::L;
+    static constexpr int own(int l) { return (N::dim(l + 1) + G - 1) / G; }  // neurons of layer l per lane
+    static constexpr int slot_off(int l) {
+        int o = 0;
+        for (int i = 0; i < l; ++i) o += own(i) * (N::dim(i) + 1);
+        return o;
+    }
+    static constexpr int NSLOT = slot_off(L);
+    static constexpr int maxown() {
+        int m = 0;
+        for (int i = 0; i < L; ++i) m = own(i) > m ? own(i) : m;
+        return m;
+    }
+    static constexpr int MAXD = N::maxdim();
+    static constexpr int MAXOWN = maxown();
+
+    struct Cache {
+        double a[L + 1][MAXD];    // replicated activations (a[0] = input)
+        double z[L][MAXOWN];      // pre-activations of the neurons this lane owns
+        double ao[L][MAXOWN];     // their activations
+    };
+
+    // th: NN parameters (LDS or global), r: lane index inside the group
+    template <class P>
+    static __device__ __forceinline__ void forward(const P* th, int r, const double* x, Cache& c, double* y) {
+        static_for<0, N::dim(0)>([&](auto k) { c.a[0][k] = x[k]; });
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            constexpr int in = N::dim(l), out = N::dim(l + 1);
+            const P* W = th + N::off(l);
+            const P* b = W + in * out;
+            static_for<0, own(l)>([&](auto mc) {
+                constexpr int m = mc;
+                const int j = r + m * G;
+                const bool valid = (own(l) * G == out) || (j < out);
+                const int jj = valid ? j : 0;
+                double acc = 0.0;
+                static_for<0, in>([&](auto k) { acc = __builtin_fma((double)W[jj + k * out], c.a[l][k], acc); });
+                acc += (double)b[jj];
+                c.z[l][m] = acc;
+                c.ao[l][m] = valid ? act_fwd<N::act(l)>(acc) : 0.0;
+            });
+            static_for<0, out>([&](auto jc) {
+                constexpr int j = jc;
+                c.a[l + 1][j] = group_bcast<G>(c.ao[l][j / G], j % G);
+            });
+        });
+        static_for<0, N::dim(L)>([&](auto k) { y[k] = c.a[L][k]; });
+    }
+
+    // gy: cotangent of the output (replicated).  gx: cotangent of the input (replicated).
+    // g[NSLOT]: this lane's slice of (dNN/dtheta)^T gy; slot (l, m, k) = slot_off(l) + m*(in+1) + k, bias at k = in.
+    template <bool WANT_PARAM, class P>
+    static __device__ __forceinline__ void vjp(const P* th, int r, const Cache& c, const double* gy, double* gx,
+                                               double* g) {
+        static_assert(N::act(L - 1) == ACT_IDENTITY, "output layer must be linear");
+        double dall[MAXD];  // replicated delta of the layer above
+        static_for<0, N::dim(L)>([&](auto k) { dall[k] = gy[k]; });
+        static_for<0, L>([&](auto lr) {
+            constexpr int l = L - 1 - lr;
+            constexpr int in = N::dim(l), out = N::dim(l + 1);
+            double down[MAXOWN];
+            static_for<0, own(l)>([&](auto mc) {
+                constexpr int m = mc;
+                const int j = r + m * G;
+                const bool valid = (own(l) * G == out) || (j < out);
+                const int jj = valid ? j : 0;
+                double gp;
+                if constexpr (l == L - 1) {
+                    gp = dall[0];  // pick element j of the replicated output cotangent
+                    static_for<1, out>([&](auto i) { gp = (jj == i) ? dall[i] : gp; });
+                } else {
+                    constexpr int out2 = N::dim(l + 2);
+                    const P* W2 = th + N::off(l + 1);  // column jj of the next layer's W (contiguous)
+                    gp = 0.0;
+                    static_for<0, out2>([&](auto i) { gp = __builtin_fma((double)W2[i + jj * out2], dall[i], gp); });
+                }
+                const double d = valid ? gp * act_bwd<N::act(l)>(c.z[l][m], c.ao[l][m]) : 0.0;
+                down[m] = d;
+                if constexpr (WANT_PARAM) {
+                    constexpr int s0 = slot_off(l) + m * (in + 1);
+                    static_for<0, in>([&](auto k) { g[s0 + k] = d * c.a[l][k]; });
+                    g[s0 + in] = d;
+                }
+            });
+            if constexpr (l > 0) {
+                static_for<0, out>([&](auto jc) {
+                    constexpr int j = jc;
+                    dall[j] = group_bcast<G>(down[j / G], j % G);
+                });
+            } else {
+                // input cotangent: gx[k] = sum_j W0[j,k] delta0[j]; every lane needs it, so gather delta0 too
+                double d0[MAXD];
+                static_for<0, out>([&](auto jc) {
+                    constexpr int j = jc;
+                    d0[j] = group_bcast<G>(down[j / G], j % G);
+                });
+                const P* W0 = th + N::off(0);
+                static_for<0, in>([&](auto k) {
+                    double s = 0.0;
+                    static_for<0, out>([&](auto j) { s = __builtin_fma((double)W0[j + k * out], d0[j], s); });
+                    gx[k] = s;
+                });
+            }
+        });
+    }
+
+    // theta index (relative to the first NN parameter) of lane r's slot s, or -1 if the slot is padding
+    static __device__ __forceinline__ int slot_index(int r, int s) {
+        int res = -1;
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            constexpr int in = N::dim(l), out = N::dim(l + 1);
+            constexpr int lo = slot_off(l), hi = slot_off(l) + own(l) * (in + 1);
+            if (s >= lo && s < hi) {
+                const int m = (s - lo) / (in + 1), k = (s - lo) % (in + 1);
+                const int j = r + m * G;
+                if (j < out) res = N::off(l) + (k < in ? j + k * out : in * out + j);
+            }
+        });
+        return res;
+    }
+};
+
+}  // namespace ude

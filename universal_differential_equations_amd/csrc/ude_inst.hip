@@ -1,0 +1,10 @@
+// ude_inst.hip -- one kernel instance per translation unit (compiled many times by build.py with
+// -DINST_NAME=... -DINST_MODEL=... -DINST_TAB=... -DINST_G=...), so the heavy templates build in parallel.
+#include <hip/hip_runtime.h>
+
+#include "ude_registry.h"
+
+using namespace ude;
+using InstModel = INST_MODEL;
+
+extern "C" void INST_NAME(Launch* out) { *out = make_launch<InstModel, INST_TAB, INST_G>(); }

@@ -1,0 +1,93 @@
+// ude_math.h -- device scalar math for the UDE core (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ude {
+
+// ---------------------------------------------------------------------------------------------
+// DiffEqBase.fastpow (the PI controller's power function; upstream DiffEqBase 6.94.4, exercised by
+// every adaptive solve in the reference, e.g. LotkaVolterra/scenario_1.jl:84,206).  Evaluated in
+// Float32: Float64(exp2(Float32(y) * fastlog2(Float32(x)))).  Every operation below is a single
+// correctly-rounded IEEE op (no contraction), so the device result is bit-identical to the CPU
+// oracle's -- the accept/reject sequence of a trajectory must not depend on where it runs.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fastlog2(float x) {
+    const float a = 0.338953f, b = 2.198599f, c = 1.523692f;
+    const uint32_t ux = __float_as_uint(x);
+    const uint32_t ex = (ux & 0x7F800000u) >> 23;
+    float fexp, signif;
+    if (ux & 0x00400000u) {  // significand > 1.5
+        signif = __uint_as_float((ux & 0x007FFFFFu) | 0x3f000000u);
+        fexp = __fsub_rn((float)ex, 126.0f);
+    } else {
+        signif = __uint_as_float((ux & 0x007FFFFFu) | 0x3f800000u);
+        fexp = __fsub_rn((float)ex, 127.0f);
+    }
+    signif = __fsub_rn(signif, 1.0f);
+    const float num = __fmul_rn(signif, __fadd_rn(__fmul_rn(a, signif), b));
+    return __fadd_rn(fexp, __fdiv_rn(num, __fadd_rn(signif, c)));
+}
+
+// correctly-rounded-by-construction exp2 for Float32 arguments (Julia evaluates its Float32 exp2
+// kernel in Float64 and rounds once): Taylor-13 of e^z in Float64 with a fixed fma order.
+__device__ __forceinline__ float exp2_f32(float x) {
+    if (x != x) return x;
+    if (x > 127.0f) return __builtin_inff();
+    if (x < -126.0f) return 0.0f;
+    const double xd = (double)x;
+    const double n = __builtin_rint(xd);
+    const double z = __dmul_rn(__dsub_rn(xd, n), 0.6931471805599453);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, z, 1.0 / 479001600.0);
+    p = __builtin_fma(p, z, 1.0 / 39916800.0);
+    p = __builtin_fma(p, z, 1.0 / 3628800.0);
+    p = __builtin_fma(p, z, 1.0 / 362880.0);
+    p = __builtin_fma(p, z, 1.0 / 40320.0);
+    p = __builtin_fma(p, z, 1.0 / 5040.0);
+    p = __builtin_fma(p, z, 1.0 / 720.0);
+    p = __builtin_fma(p, z, 1.0 / 120.0);
+    p = __builtin_fma(p, z, 1.0 / 24.0);
+    p = __builtin_fma(p, z, 1.0 / 6.0);
+    p = __builtin_fma(p, z, 0.5);
+    p = __builtin_fma(p, z, 1.0);
+    p = __builtin_fma(p, z, 1.0);
+    return (float)__builtin_ldexp(p, (int)n);
+}
+
+__device__ __forceinline__ double fastpow(double x, double y) {
+    return (double)exp2_f32(__fmul_rn((float)y, fastlog2((float)x)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations (a1): rbf(x) = exp(-x^2) LotkaVolterra/scenario_1.jl:59; tanh seir_exposure.jl:114,
+// Fisher-KPP-CNN.jl:92-94; relu highdim_pde/lambaem.jl
+// ---------------------------------------------------------------------------------------------
+enum { ACT_IDENTITY = 0, ACT_TANH = 1, ACT_RBF = 2, ACT_RELU = 3 };
+
+template <int ACT>
+__device__ __forceinline__ double act_fwd(double z) {
+    if constexpr (ACT == ACT_TANH) return tanh(z);
+    else if constexpr (ACT == ACT_RBF) return exp(-(z * z));
+    else if constexpr (ACT == ACT_RELU) return z > 0.0 ? z : 0.0;
+    else return z;
+}
+// derivative from the pre-activation z and the activation value a
+template <int ACT>
+__device__ __forceinline__ double act_bwd(double z, double a) {
+    if constexpr (ACT == ACT_TANH) return 1.0 - a * a;
+    else if constexpr (ACT == ACT_RBF) return -2.0 * z * a;
+    else if constexpr (ACT == ACT_RELU) return z > 0.0 ? 1.0 : 0.0;
+    else return 1.0;
+}
+
+// compile-time loop with integral-constant index
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+}  // namespace ude

@@ -1,0 +1,109 @@
+// ude_tableaux.h -- Tsit5 / Vern7 coefficient tables as compile-time functions.
+// Numbers come from ude_tableaux_gen.h (decoded from the reference's .jld2 artifacts).
+// Stage convention: k[0] = f(uprev); k[s] = f(uprev + dt * sum_{j<s} A(s,j) k[j]) for s = 1..S-1;
+// u_new = uprev + dt * sum_j B(j) k[j]; err = dt * sum_j BT(j) k[j].
+#pragma once
+#include "ude_tableaux_gen.h"
+
+namespace ude {
+
+#define T_(x) UDE_TSIT5_##x
+struct Tsit5Tab {  // Tsit5(): LotkaVolterra/scenario_1.jl:191,202,206; FisherKPP/Fisher-KPP-CNN.jl:66,136
+    static constexpr int S = 7, NK = 7, NEXTRA = 0, ORDER = 5;
+    static constexpr bool FSAL = true;
+    static constexpr double A(int s, int j) {
+        constexpr double a[7][7] = {
+            {0, 0, 0, 0, 0, 0, 0},
+            {T_(a21), 0, 0, 0, 0, 0, 0},
+            {T_(a31), T_(a32), 0, 0, 0, 0, 0},
+            {T_(a41), T_(a42), T_(a43), 0, 0, 0, 0},
+            {T_(a51), T_(a52), T_(a53), T_(a54), 0, 0, 0},
+            {T_(a61), T_(a62), T_(a63), T_(a64), T_(a65), 0, 0},
+            {T_(a71), T_(a72), T_(a73), T_(a74), T_(a75), T_(a76), 0}};
+        return a[s][j];
+    }
+    static constexpr double C(int s) {
+        constexpr double c[7] = {0, T_(c1), T_(c2), T_(c3), T_(c4), T_(c5), T_(c6)};
+        return c[s];
+    }
+    static constexpr double B(int j) { return A(6, j); }
+    static constexpr double BT(int j) {
+        constexpr double b[7] = {T_(btilde1), T_(btilde2), T_(btilde3), T_(btilde4), T_(btilde5), T_(btilde6), T_(btilde7)};
+        return b[j];
+    }
+    static constexpr double AE(int, int) { return 0; }
+    static constexpr double CE(int) { return 0; }
+    // dense-output weights b_j(theta), j = 0..6 (free 4th-order interpolant)
+    static __device__ __forceinline__ void bth(double th, double* b) {
+        const double th2 = th * th;
+        b[0] = th * (T_(r11) + th * (T_(r12) + th * (T_(r13) + th * T_(r14))));
+        b[1] = th2 * (T_(r22) + th * (T_(r23) + th * T_(r24)));
+        b[2] = th2 * (T_(r32) + th * (T_(r33) + th * T_(r34)));
+        b[3] = th2 * (T_(r42) + th * (T_(r43) + th * T_(r44)));
+        b[4] = th2 * (T_(r52) + th * (T_(r53) + th * T_(r54)));
+        b[5] = th2 * (T_(r62) + th * (T_(r63) + th * T_(r64)));
+        b[6] = th2 * (T_(r72) + th * (T_(r73) + th * T_(r74)));
+    }
+    static constexpr bool dense_uses(int j) { return j < 7; }
+};
+#undef T_
+
+#define V_(x) UDE_VERN7_##x
+struct Vern7Tab {  // Vern7(): scenario_1.jl:41,84; SEIR_exposure/seir_exposure.jl:37,138
+    static constexpr int S = 10, NK = 16, NEXTRA = 6, ORDER = 7;
+    static constexpr bool FSAL = false;
+    static constexpr double A(int s, int j) {
+        constexpr double a[10][10] = {
+            {0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+            {V_(a021), 0, 0, 0, 0, 0, 0, 0, 0, 0},
+            {V_(a031), V_(a032), 0, 0, 0, 0, 0, 0, 0, 0},
+            {V_(a041), 0, V_(a043), 0, 0, 0, 0, 0, 0, 0},
+            {V_(a051), 0, V_(a053), V_(a054), 0, 0, 0, 0, 0, 0},
+            {V_(a061), 0, V_(a063), V_(a064), V_(a065), 0, 0, 0, 0, 0},
+            {V_(a071), 0, V_(a073), V_(a074), V_(a075), V_(a076), 0, 0, 0, 0},
+            {V_(a081), 0, V_(a083), V_(a084), V_(a085), V_(a086), V_(a087), 0, 0, 0},
+            {V_(a091), 0, V_(a093), V_(a094), V_(a095), V_(a096), V_(a097), V_(a098), 0, 0},
+            {V_(a101), 0, V_(a103), V_(a104), V_(a105), V_(a106), V_(a107), 0, 0, 0}};
+        return a[s][j];
+    }
+    static constexpr double C(int s) {
+        constexpr double c[10] = {0, V_(c2), V_(c3), V_(c4), V_(c5), V_(c6), V_(c7), V_(c8), 1.0, 1.0};
+        return c[s];
+    }
+    static constexpr double B(int j) {
+        constexpr double b[10] = {V_(b1), 0, 0, V_(b4), V_(b5), V_(b6), V_(b7), V_(b8), V_(b9), 0};
+        return b[j];
+    }
+    static constexpr double BT(int j) {
+        constexpr double b[10] = {V_(btilde1), 0, 0, V_(btilde4), V_(btilde5), V_(btilde6), V_(btilde7),
+                                  V_(btilde8), V_(btilde9), V_(btilde10)};
+        return b[j];
+    }
+    // lazy dense-output stages k[10..15] (upstream k11..k16): k[10+e] = f(uprev + dt*sum_j AE(e,j) k[j])
+    static constexpr double AE(int e, int j) {
+        constexpr double a[6][16] = {
+            {V_(a1101), 0, 0, V_(a1104), V_(a1105), V_(a1106), V_(a1107), V_(a1108), V_(a1109), 0, 0, 0, 0, 0, 0, 0},
+            {V_(a1201), 0, 0, V_(a1204), V_(a1205), V_(a1206), V_(a1207), V_(a1208), V_(a1209), 0, V_(a1211), 0, 0, 0, 0, 0},
+            {V_(a1301), 0, 0, V_(a1304), V_(a1305), V_(a1306), V_(a1307), V_(a1308), V_(a1309), 0, V_(a1311), V_(a1312), 0, 0, 0, 0},
+            {V_(a1401), 0, 0, V_(a1404), V_(a1405), V_(a1406), V_(a1407), V_(a1408), V_(a1409), 0, V_(a1411), V_(a1412), V_(a1413), 0, 0, 0},
+            {V_(a1501), 0, 0, V_(a1504), V_(a1505), V_(a1506), V_(a1507), V_(a1508), V_(a1509), 0, V_(a1511), V_(a1512), V_(a1513), 0, 0, 0},
+            {V_(a1601), 0, 0, V_(a1604), V_(a1605), V_(a1606), V_(a1607), V_(a1608), V_(a1609), 0, V_(a1611), V_(a1612), V_(a1613), 0, 0, 0}};
+        return a[e][j];
+    }
+    static constexpr double CE(int e) {
+        constexpr double c[6] = {V_(c11), V_(c12), V_(c13), V_(c14), V_(c15), V_(c16)};
+        return c[e];
+    }
+#define P6_(p) (th * th * (V_(p##2) + th * (V_(p##3) + th * (V_(p##4) + th * (V_(p##5) + th * (V_(p##6) + th * V_(p##7)))))))
+    static __device__ __forceinline__ void bth(double th, double* b) {
+        b[0] = th * (V_(r011) + th * (V_(r012) + th * (V_(r013) + th * (V_(r014) + th * (V_(r015) + th * (V_(r016) + th * V_(r017)))))));
+        b[1] = 0; b[2] = 0; b[9] = 0;
+        b[3] = P6_(r04); b[4] = P6_(r05); b[5] = P6_(r06); b[6] = P6_(r07); b[7] = P6_(r08); b[8] = P6_(r09);
+        b[10] = P6_(r11); b[11] = P6_(r12); b[12] = P6_(r13); b[13] = P6_(r14); b[14] = P6_(r15); b[15] = P6_(r16);
+    }
+#undef P6_
+    static constexpr bool dense_uses(int j) { return !(j == 1 || j == 2 || j == 9); }
+};
+#undef V_
+
+}  // namespace ude

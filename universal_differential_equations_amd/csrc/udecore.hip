@@ -1,0 +1,531 @@
+// udecore.hip -- C ABI (include/udecore.h) over the fused HIP kernels.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/udecore.h"
+#include "ude_registry.h"
+
+using namespace ude;
+
+namespace ude {
+// out[i] = sum_w part[w][i] in fixed order (w ascending): deterministic for a given launch shape
+__global__ void reduce_rows_kernel(const double* part, int64_t nrows, int32_t ncols, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncols) return;
+    double s = 0.0;
+    for (int64_t w = 0; w < nrows; ++w) s += part[(size_t)w * ncols + i];
+    out[i] = s;
+}
+
+// total = sum_j v[j], fixed tree
+__global__ void reduce_sum_kernel(const double* v, int64_t n, double* out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+__global__ void fastpow_kernel(const double* x, const double* y, double* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fastpow(x[i], y[i]);
+}
+
+}  // namespace ude
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ude_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    ude_launch_opts lo{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/end, bwd start/end
+    bool ev_fwd = false, ev_bwd = false;
+    // workspaces (grow on demand, reused across calls)
+    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats;
+    // staging for the host-buffer entry points
+    DevBuf s_u0, s_theta, s_saveat, s_out, s_data, s_mask, s_gtheta, s_gu0, s_loss, s_lpt, s_stats, s_ret;
+};
+
+static int fail(ude_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail(c, UDE_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static int ensure(ude_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return UDE_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return fail(c, UDE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    b.cap = want;
+    return UDE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// compiled model table (instances live in their own translation units, see build.py)
+// ---------------------------------------------------------------------------------------------
+#include "ude_instances_gen.h"
+
+struct InstanceRow {
+    int mid, alg, G;
+    void (*get)(Launch*);
+};
+static const InstanceRow kInstances[] = {UDE_INSTANCE_TABLE};
+
+static bool dims_are(const ude_model_desc* m, std::initializer_list<int> d, std::initializer_list<int> a) {
+    if ((int)d.size() != m->n_layers + 1) return false;
+    int i = 0;
+    for (int v : d)
+        if (m->dims[i++] != v) return false;
+    i = 0;
+    for (int v : a)
+        if (m->act[i++] != v) return false;
+    return true;
+}
+
+static int model_id(const ude_model_desc* m) {
+    if (m->dtype != 0) return MID_NONE;
+    if (m->kind == UDE_KIND_LV_TRUE && m->n_state == 2 && m->n_param == 4) return MID_LV_TRUE;
+    if (m->kind == UDE_KIND_LV_UDE && m->n_state == 2) {
+        if (dims_are(m, {2, 5, 5, 5, 2}, {ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY})) return MID_LV_S1;
+        if (dims_are(m, {2, 5, 5, 5, 2}, {ACT_RBF, ACT_RBF, ACT_TANH, ACT_IDENTITY})) return MID_LV_HUDSON;
+        if (dims_are(m, {2, 32, 2}, {ACT_TANH, ACT_IDENTITY})) return MID_LV_TANH32;
+    }
+    return MID_NONE;
+}
+
+static int default_lanes(int mid) {
+    switch (mid) {
+        case MID_LV_TRUE: return 1;
+        case MID_LV_S1:
+        case MID_LV_HUDSON: return 8;
+        case MID_LV_TANH32: return 32;
+    }
+    return 1;
+}
+
+static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, Launch& l, int& G) {
+    const int mid = model_id(m);
+    if (mid == MID_NONE)
+        return fail(c, UDE_ERR_UNSUPPORTED, "no compiled kernel for model kind=%d dtype=%d n_layers=%d (see udecore.hip model table)",
+                    m->kind, m->dtype, m->n_layers);
+    G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid);
+    bool ok = false;
+    for (const InstanceRow& row : kInstances)
+        if (row.mid == mid && row.alg == o->alg && row.G == G) {
+            row.get(&l);
+            ok = true;
+            break;
+        }
+    if (!ok) return fail(c, UDE_ERR_UNSUPPORTED, "no kernel instance for model %d alg %d lanes_per_traj %d", mid, o->alg, G);
+    return UDE_OK;
+}
+
+static void fill_params(KParams& p, const ude_model_desc* m, const ude_solve_opts* o, double t0, double tf) {
+    memset(&p, 0, sizeof p);
+    const int order = o->alg == UDE_ALG_VERN7 ? 7 : 5;
+    p.o.abstol = o->abstol > 0 ? o->abstol : 1e-6;
+    p.o.reltol = o->reltol > 0 ? o->reltol : 1e-3;
+    p.o.dtmax = o->dtmax > 0 ? o->dtmax : fabs(tf - t0);
+    p.o.dt0 = o->dt0;
+    p.o.qmin = o->qmin > 0 ? o->qmin : 0.2;
+    p.o.qmax = o->qmax > 0 ? o->qmax : 10.0;
+    p.o.gamma = o->gamma > 0 ? o->gamma : 0.9;
+    p.o.qoldinit = o->qoldinit > 0 ? o->qoldinit : 1e-4;
+    p.o.beta2 = o->beta2 > 0 ? o->beta2 : 2.0 / (5.0 * order);
+    p.o.beta1 = o->beta1 > 0 ? o->beta1 : 7.0 / (10.0 * order);
+    p.o.maxiters = o->maxiters > 0 ? o->maxiters : 100000;
+    p.t0 = t0;
+    p.tf = tf;
+    p.n_state = m->n_state;
+    p.n_param = m->n_param;
+    p.mc.n_state = m->n_state;
+    p.mc.n_param = m->n_param;
+    p.mc.nn_offset = m->nn_offset;
+    p.mc.stencil_offset = m->stencil_offset;
+    p.mc.d0_offset = m->d0_offset;
+    for (int i = 0; i < 2; ++i) {
+        p.mc.lin_idx[i] = m->lin_idx[i];
+        p.mc.lin_sign[i] = m->lin_sign[i];
+        p.mc.lin_const[i] = m->lin_const[i];
+    }
+    for (int i = 0; i < 16; ++i) p.mc.consts[i] = m->consts[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int ude_version(void) { return UDE_VERSION; }
+
+extern "C" int ude_create(int32_t device_id, ude_ctx** out) {
+    if (!out) return UDE_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return UDE_ERR_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return UDE_ERR_HIP;
+    ude_ctx* c = new ude_ctx();
+    c->device = device_id;
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete c;
+            return UDE_ERR_HIP;
+        }
+    *out = c;
+    return UDE_OK;
+}
+
+extern "C" void ude_destroy(ude_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats,
+                      &c->s_u0, &c->s_theta, &c->s_saveat, &c->s_out, &c->s_data, &c->s_mask, &c->s_gtheta,
+                      &c->s_gu0, &c->s_loss, &c->s_lpt, &c->s_stats, &c->s_ret};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" const char* ude_last_error(ude_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int ude_set_stream(ude_ctx* c, void* s) {
+    if (!c) return UDE_ERR_INVALID;
+    c->stream = (hipStream_t)s;
+    return UDE_OK;
+}
+
+extern "C" int ude_set_launch_opts(ude_ctx* c, const ude_launch_opts* lo) {
+    if (!c || !lo) return UDE_ERR_INVALID;
+    c->lo = *lo;
+    return UDE_OK;
+}
+
+extern "C" int ude_model_supported(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int32_t) {
+    if (!c || !m || !o) return UDE_ERR_INVALID;
+    Launch l;
+    int G;
+    return resolve(c, m, o, l, G);
+}
+
+extern "C" int ude_last_kernel_ms(ude_ctx* c, float* fwd_ms, float* bwd_ms) {
+    if (!c) return UDE_ERR_INVALID;
+    if (fwd_ms) {
+        *fwd_ms = 0.f;
+        if (c->ev_fwd) HIPCHK(c, hipEventElapsedTime(fwd_ms, c->ev[0], c->ev[1]));
+    }
+    if (bwd_ms) {
+        *bwd_ms = 0.f;
+        if (c->ev_bwd) HIPCHK(c, hipEventElapsedTime(bwd_ms, c->ev[2], c->ev[3]));
+    }
+    return UDE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-resident entry points
+// ---------------------------------------------------------------------------------------------
+static int common_checks(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N, const void* u0,
+                         const double* tspan_host, const void* theta, const void* saveat, int32_t ns) {
+    if (!c) return UDE_ERR_INVALID;
+    if (!m || !o || !u0 || !tspan_host || !saveat || N <= 0 || ns <= 0) return fail(c, UDE_ERR_INVALID, "null argument or empty ensemble");
+    if (m->n_param > 0 && !theta) return fail(c, UDE_ERR_INVALID, "theta is null");
+    if (!(tspan_host[1] > tspan_host[0])) return fail(c, UDE_ERR_INVALID, "tspan must be increasing");
+    return UDE_OK;
+}
+
+// tspan is always a HOST pointer (two doubles), also for the _dev entry points
+static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N, const double* u0,
+                          const double* tspan, const double* theta, const double* saveat, int32_t ns,
+                          double* u_out, int64_t* stats, int32_t* retcode) {
+    int rc = common_checks(c, m, o, N, u0, tspan, theta, saveat, ns);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    Launch l;
+    int G;
+    if ((rc = resolve(c, m, o, l, G))) return rc;
+    KParams p;
+    fill_params(p, m, o, tspan[0], tspan[1]);
+    p.N = N;
+    p.Npad = N;
+    p.ns = ns;
+    p.u0 = u0;
+    p.theta = theta;
+    p.saveat = saveat;
+    p.u_out = u_out;
+    p.stats = stats;
+    if (!retcode) {
+        if ((rc = ensure(c, c->retcode, sizeof(int32_t) * N))) return rc;
+        retcode = (int32_t*)c->retcode.p;
+    }
+    p.retcode = retcode;
+    const int64_t threads = N * G;
+    const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
+    const size_t shmem = sizeof(double) * (size_t)(m->n_param > 0 ? m->n_param : 1);
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    c->ev_fwd = true;
+    c->ev_bwd = false;
+    return UDE_OK;
+}
+
+static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N, const double* u0,
+                         const double* tspan, const double* theta, const double* saveat, int32_t ns,
+                         const double* cot_in, const double* data, const uint8_t* row_mask, double* loss,
+                         double* loss_per_traj, double* u_out, double* grad_theta, double* grad_u0, int64_t* stats,
+                         int32_t* retcode) {
+    int rc = common_checks(c, m, o, N, u0, tspan, theta, saveat, ns);
+    if (rc) return rc;
+    if (!grad_theta) return fail(c, UDE_ERR_INVALID, "grad_theta is null");
+    if (!cot_in && !data) return fail(c, UDE_ERR_INVALID, "need a cotangent or data");
+    if (m->n_param <= 0) return fail(c, UDE_ERR_UNSUPPORTED, "model has no parameters to differentiate");
+    HIPCHK(c, hipSetDevice(c->device));
+    Launch l;
+    int G;
+    if ((rc = resolve(c, m, o, l, G))) return rc;
+    KParams p;
+    fill_params(p, m, o, tspan[0], tspan[1]);
+    const int n = m->n_state, np = m->n_param;
+    const int cap = c->lo.max_dense_steps > 0 ? c->lo.max_dense_steps : 256;
+    const int64_t threads = N * G;
+    const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
+    const int64_t nwaves = (int64_t)grid * (BLOCK / 64);
+    p.N = N;
+    p.Npad = (N + 7) / 8 * 8;
+    p.ns = ns;
+    p.cap = cap;
+    p.u0 = u0;
+    p.theta = theta;
+    p.saveat = saveat;
+    p.u_out = u_out;
+    p.data = cot_in ? nullptr : data;
+    p.row_mask = row_mask;
+    p.cot_in = cot_in;
+    if ((rc = ensure(c, c->dense, sizeof(double) * (size_t)cap * l.nf * p.Npad))) return rc;
+    if ((rc = ensure(c, c->dense_n, sizeof(int32_t) * N))) return rc;
+    if ((rc = ensure(c, c->cot, sizeof(double) * (size_t)ns * n * p.Npad))) return rc;
+    if ((rc = ensure(c, c->loss_traj, sizeof(double) * N))) return rc;
+    if ((rc = ensure(c, c->grad_part, sizeof(double) * (size_t)nwaves * np))) return rc;
+    if (!retcode) {
+        if ((rc = ensure(c, c->retcode, sizeof(int32_t) * N))) return rc;
+        retcode = (int32_t*)c->retcode.p;
+    }
+    if (!stats) {
+        if ((rc = ensure(c, c->stats, sizeof(int64_t) * 8 * N))) return rc;
+        stats = (int64_t*)c->stats.p;
+    }
+    p.stats = stats;
+    p.retcode = retcode;
+    p.dense = (double*)c->dense.p;
+    p.dense_n = (int32_t*)c->dense_n.p;
+    p.cot = (double*)c->cot.p;
+    p.loss_traj = loss_per_traj ? loss_per_traj : (double*)c->loss_traj.p;
+    p.grad_part = (double*)c->grad_part.p;
+    p.grad_u0 = grad_u0;
+    const size_t shmem = sizeof(double) * (size_t)np;
+    HIPCHK(c, hipMemsetAsync(p.grad_part, 0, sizeof(double) * (size_t)nwaves * np, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(l.adj, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    c->ev_fwd = c->ev_bwd = true;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((np + 127) / 128), dim3(128), 0, c->stream, (const double*)p.grad_part,
+                       nwaves, (int32_t)np, grad_theta);
+    HIPCHK(c, hipGetLastError());
+    if (loss && !cot_in) {
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)p.loss_traj, N, loss);
+        HIPCHK(c, hipGetLastError());
+    }
+    return UDE_OK;
+}
+
+extern "C" int ude_solve_ensemble_dev(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                                      const double* u0, const double* tspan, const double* theta,
+                                      const double* saveat, int32_t ns, double* u_out, int64_t* stats,
+                                      int32_t* retcode) {
+    return solve_dev_impl(c, m, o, N, u0, tspan, theta, saveat, ns, u_out, stats, retcode);
+}
+
+extern "C" int ude_vjp_ensemble_dev(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                                    const double* u0, const double* tspan, const double* theta, const double* saveat,
+                                    int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
+                                    double* grad_u0, int64_t* stats, int32_t* retcode) {
+    if (c && !cotangent) return fail(c, UDE_ERR_INVALID, "cotangent is null");
+    return grad_dev_impl(c, m, o, N, u0, tspan, theta, saveat, ns, cotangent, nullptr, nullptr, nullptr, nullptr, u_out,
+                         grad_theta, grad_u0, stats, retcode);
+}
+
+extern "C" int ude_loss_grad_ensemble_dev(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                                          const double* u0, const double* tspan, const double* theta,
+                                          const double* saveat, int32_t ns, const double* data,
+                                          const uint8_t* row_mask, double* loss, double* loss_per_traj,
+                                          double* grad_theta, double* grad_u0, double* u_out, int64_t* stats,
+                                          int32_t* retcode) {
+    if (c && !data) return fail(c, UDE_ERR_INVALID, "data is null");
+    return grad_dev_impl(c, m, o, N, u0, tspan, theta, saveat, ns, nullptr, data, row_mask, loss, loss_per_traj, u_out,
+                         grad_theta, grad_u0, stats, retcode);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-buffer entry points (what a Julia ccall binds): stage H->D, run, D->H, block
+// ---------------------------------------------------------------------------------------------
+static int up(ude_ctx* c, DevBuf& b, const void* src, size_t bytes, void** dst) {
+    *dst = nullptr;
+    if (!src || bytes == 0) return UDE_OK;
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    *dst = b.p;
+    return UDE_OK;
+}
+static int dn(ude_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!dst || !src || bytes == 0) return UDE_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return UDE_OK;
+}
+static int any_failed(ude_ctx* c, const int32_t* rc, int64_t N) {
+    for (int64_t j = 0; j < N; ++j)
+        if (rc[j] != UDE_RET_SUCCESS)
+            return fail(c, UDE_ERR_TRAJECTORY, "trajectory %lld ended with retcode %d (see retcode array)", (long long)j, rc[j]);
+    return UDE_OK;
+}
+
+extern "C" int ude_solve_ensemble(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                                  const double* u0, const double* tspan, const double* theta, const double* saveat,
+                                  int32_t ns, double* u_out, int64_t* stats, int32_t* retcode) {
+    int rc = common_checks(c, m, o, N, u0, tspan, theta, saveat, ns);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = m->n_state;
+    void *du0, *dth, *dsv;
+    if ((rc = up(c, c->s_u0, u0, sizeof(double) * n * N, &du0))) return rc;
+    if ((rc = up(c, c->s_theta, theta, sizeof(double) * m->n_param, &dth))) return rc;
+    if ((rc = up(c, c->s_saveat, saveat, sizeof(double) * ns, &dsv))) return rc;
+    if ((rc = ensure(c, c->s_out, sizeof(double) * n * ns * N))) return rc;
+    if ((rc = ensure(c, c->s_stats, sizeof(int64_t) * 8 * N))) return rc;
+    if ((rc = ensure(c, c->s_ret, sizeof(int32_t) * N))) return rc;
+    rc = solve_dev_impl(c, m, o, N, (double*)du0, tspan, (double*)dth, (double*)dsv, ns, (double*)c->s_out.p,
+                        (int64_t*)c->s_stats.p, (int32_t*)c->s_ret.p);
+    if (rc) return rc;
+    std::vector<int32_t> rtmp(N);
+    if ((rc = dn(c, u_out, c->s_out.p, sizeof(double) * n * ns * N))) return rc;
+    if ((rc = dn(c, stats, c->s_stats.p, sizeof(int64_t) * 8 * N))) return rc;
+    if ((rc = dn(c, rtmp.data(), c->s_ret.p, sizeof(int32_t) * N))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (retcode) memcpy(retcode, rtmp.data(), sizeof(int32_t) * N);
+    return any_failed(c, rtmp.data(), N);
+}
+
+static int grad_host(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N, const double* u0,
+                     const double* tspan, const double* theta, const double* saveat, int32_t ns, const double* cot,
+                     const double* data, const uint8_t* row_mask, double* loss, double* loss_per_traj, double* u_out,
+                     double* grad_theta, double* grad_u0, int64_t* stats, int32_t* retcode) {
+    int rc = common_checks(c, m, o, N, u0, tspan, theta, saveat, ns);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = m->n_state, np = m->n_param;
+    void *du0, *dth, *dsv, *ddat, *dmask;
+    if ((rc = up(c, c->s_u0, u0, sizeof(double) * n * N, &du0))) return rc;
+    if ((rc = up(c, c->s_theta, theta, sizeof(double) * np, &dth))) return rc;
+    if ((rc = up(c, c->s_saveat, saveat, sizeof(double) * ns, &dsv))) return rc;
+    if ((rc = up(c, c->s_data, cot ? cot : data, sizeof(double) * n * ns * N, &ddat))) return rc;
+    if ((rc = up(c, c->s_mask, row_mask, n, &dmask))) return rc;
+    if ((rc = ensure(c, c->s_out, sizeof(double) * n * ns * N))) return rc;
+    if ((rc = ensure(c, c->s_stats, sizeof(int64_t) * 8 * N))) return rc;
+    if ((rc = ensure(c, c->s_ret, sizeof(int32_t) * N))) return rc;
+    if ((rc = ensure(c, c->s_gtheta, sizeof(double) * np))) return rc;
+    if ((rc = ensure(c, c->s_gu0, sizeof(double) * n * N))) return rc;
+    if ((rc = ensure(c, c->s_loss, sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->s_lpt, sizeof(double) * N))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->s_stats.p, 0, sizeof(int64_t) * 8 * N, c->stream));
+    rc = grad_dev_impl(c, m, o, N, (double*)du0, tspan, (double*)dth, (double*)dsv, ns, cot ? (double*)ddat : nullptr,
+                       cot ? nullptr : (double*)ddat, (uint8_t*)dmask, (double*)c->s_loss.p, (double*)c->s_lpt.p,
+                       (double*)c->s_out.p, (double*)c->s_gtheta.p, (double*)c->s_gu0.p, (int64_t*)c->s_stats.p,
+                       (int32_t*)c->s_ret.p);
+    if (rc) return rc;
+    std::vector<int32_t> rtmp(N);
+    if ((rc = dn(c, u_out, c->s_out.p, sizeof(double) * n * ns * N))) return rc;
+    if ((rc = dn(c, stats, c->s_stats.p, sizeof(int64_t) * 8 * N))) return rc;
+    if ((rc = dn(c, rtmp.data(), c->s_ret.p, sizeof(int32_t) * N))) return rc;
+    if ((rc = dn(c, grad_theta, c->s_gtheta.p, sizeof(double) * np))) return rc;
+    if ((rc = dn(c, grad_u0, c->s_gu0.p, sizeof(double) * n * N))) return rc;
+    if (!cot) {
+        if ((rc = dn(c, loss, c->s_loss.p, sizeof(double)))) return rc;
+        if ((rc = dn(c, loss_per_traj, c->s_lpt.p, sizeof(double) * N))) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (retcode) memcpy(retcode, rtmp.data(), sizeof(int32_t) * N);
+    return any_failed(c, rtmp.data(), N);
+}
+
+extern "C" int ude_vjp_ensemble(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                                const double* u0, const double* tspan, const double* theta, const double* saveat,
+                                int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
+                                double* grad_u0, int64_t* stats, int32_t* retcode) {
+    if (c && !cotangent) return fail(c, UDE_ERR_INVALID, "cotangent is null");
+    return grad_host(c, m, o, N, u0, tspan, theta, saveat, ns, cotangent, nullptr, nullptr, nullptr, nullptr, u_out,
+                     grad_theta, grad_u0, stats, retcode);
+}
+
+extern "C" int ude_loss_grad_ensemble(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
+                                      const double* u0, const double* tspan, const double* theta,
+                                      const double* saveat, int32_t ns, const double* data, const uint8_t* row_mask,
+                                      double* loss, double* loss_per_traj, double* grad_theta, double* grad_u0,
+                                      double* u_out, int64_t* stats, int32_t* retcode) {
+    if (c && !data) return fail(c, UDE_ERR_INVALID, "data is null");
+    return grad_host(c, m, o, N, u0, tspan, theta, saveat, ns, nullptr, data, row_mask, loss, loss_per_traj, u_out,
+                     grad_theta, grad_u0, stats, retcode);
+}
+
+extern "C" int ude_fastpow_dev(ude_ctx* c, int64_t n, const double* x, const double* y, double* out) {
+    if (!c || !x || !y || !out || n <= 0) return UDE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    void *dx, *dy;
+    if ((rc = up(c, c->s_u0, x, sizeof(double) * n, &dx))) return rc;
+    if ((rc = up(c, c->s_data, y, sizeof(double) * n, &dy))) return rc;
+    if ((rc = ensure(c, c->s_out, sizeof(double) * n))) return rc;
+    hipLaunchKernelGGL(fastpow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)dx,
+                       (const double*)dy, (double*)c->s_out.p, n);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = dn(c, out, c->s_out.p, sizeof(double) * n))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return UDE_OK;
+}

@@ -1,0 +1,347 @@
+"""Host-side mirror of the SciML surface the reference scripts use for the hot path.
+
+    prob  = ODEProblem(f, u0, tspan, p)                      scenario_1.jl:78, seir_exposure.jl:131
+    _prob = remake(prob; u0, tspan, p)                       scenario_1.jl:83
+    sol   = solve(_prob, Vern7(); saveat, abstol, reltol)    scenario_1.jl:84-87     -> Array(sol), sol.t, sol.destats
+    concrete_solve(prob, alg, u0, p; saveat, sensealg)       seir_exposure.jl:138-140, Fisher-KPP-CNN.jl:136
+    EnsembleProblem(prob; u0s) + solve(ens, alg, EnsembleMI355(); ...)   (SciML's ensemble slot; BASELINE C2/C3)
+
+`f` is a declarative RHS descriptor from .models (closures cannot cross the C ABI).  All arithmetic runs in
+libudecore.so on the GPU; numpy in/out uses the host-buffer C entry points, torch CUDA tensors use the
+device-resident ones on torch's current stream.  Arrays follow Julia's layout: a solution is
+(n, ns) per trajectory, an ensemble solution (N, ns, n) in C order == n x ns x N column-major.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALG_TSIT5, ALG_VERN7, LaunchOpts, ModelDesc, NSTATS, RETCODES, SolveOpts, UdeError
+
+
+# ---- algorithm / sensealg / ensemble tags (dispatch types in Julia) -------------------------------------
+class Tsit5:
+    alg = ALG_TSIT5
+    order = 5
+
+
+class Vern7:
+    alg = ALG_VERN7
+    order = 7
+
+
+class InterpolatingAdjoint:
+    """sensealg = InterpolatingAdjoint(autojacvec = ReverseDiffVJP())  (seir_exposure.jl:140).
+    autojacvec is accepted and ignored: the VJP is hand-derived inside the fused kernel."""
+
+    def __init__(self, autojacvec=None, checkpointing=False):
+        if checkpointing:
+            raise NotImplementedError("checkpointing=true is not used by the reference and not built")
+
+
+class ReverseDiffVJP:
+    pass
+
+
+class EnsembleMI355:
+    """ensemble algorithm tag: trajectories run as lane groups of the fused HIP kernels"""
+
+    def __init__(self, lanes_per_traj=0, max_dense_steps=0):
+        self.lanes_per_traj, self.max_dense_steps = lanes_per_traj, max_dense_steps
+
+
+class DEStats:
+    def __init__(self, row):
+        (self.nf, self.naccept, self.nreject, self.nf_lazy, self.nf_bwd, self.naccept_bwd, self.nreject_bwd,
+         self.nf_fwd_lazy_adj) = (int(x) for x in row)
+
+    def __repr__(self):
+        return "DEStats(nf=%d, naccept=%d, nreject=%d)" % (self.nf, self.naccept, self.nreject)
+
+
+# ---- engine context ---------------------------------------------------------------------------------------
+class Engine:
+    """One ude_ctx (device + stream).  Created lazily per device."""
+
+    _by_device = {}
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.ude_create(device, C.byref(h))
+        if rc != 0:
+            raise UdeError(rc, "ude_create(device=%d) failed (no MI355X visible?)" % device)
+        self.h = h
+        self.device = device
+
+    @classmethod
+    def get(cls, device=0):
+        if device not in cls._by_device:
+            cls._by_device[device] = Engine(device)
+        return cls._by_device[device]
+
+    def check(self, rc, allow_traj=False):
+        if rc != 0 and not (allow_traj and rc == _lib.UDE_ERR_TRAJECTORY):
+            raise UdeError(rc, self.L.ude_last_error(self.h).decode())
+        return rc
+
+    def set_launch(self, lanes_per_traj=0, max_dense_steps=0):
+        lo = LaunchOpts(lanes_per_traj, 0, max_dense_steps, 0)
+        self.check(self.L.ude_set_launch_opts(self.h, C.byref(lo)))
+
+    def set_stream(self, stream_ptr):
+        self.check(self.L.ude_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def kernel_ms(self):
+        f, b = C.c_float(0), C.c_float(0)
+        self.check(self.L.ude_last_kernel_ms(self.h, C.byref(f), C.byref(b)))
+        return f.value, b.value
+
+    def fastpow(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(np.broadcast_to(y, x.shape), dtype=np.float64)
+        out = np.empty_like(x)
+        self.check(self.L.ude_fastpow_dev(self.h, x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data))
+        return out
+
+
+def _opts(alg, abstol=None, reltol=None, dtmax=None, dt=None, maxiters=None, **kw):
+    o = SolveOpts()
+    o.alg = alg.alg if not isinstance(alg, int) else alg
+    o.abstol = abstol or 0.0
+    o.reltol = reltol or 0.0
+    o.dtmax = dtmax or 0.0
+    o.dt0 = dt or 0.0
+    o.maxiters = int(maxiters or 0)
+    for k in ("qmin", "qmax", "gamma", "qoldinit", "beta1", "beta2"):
+        setattr(o, k, kw.pop(k, 0.0) or 0.0)
+    if kw:
+        raise TypeError("unsupported solve keyword(s): %s" % sorted(kw))
+    return o
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(x.ctypes.data)
+
+
+def _np(x, dtype=np.float64):
+    return np.ascontiguousarray(np.asarray(x, dtype=dtype))
+
+
+# ---- problems and solutions ------------------------------------------------------------------------------
+class ODEProblem:
+    """ODEProblem(f, u0, tspan, p; saveat=...) -- f is a ModelDesc from .models"""
+
+    def __init__(self, f, u0, tspan, p=None, **kwargs):
+        assert isinstance(f, ModelDesc), "f must be an RHS descriptor from universal_differential_equations_amd.models"
+        self.f, self.u0, self.tspan, self.p, self.kwargs = f, u0, (float(tspan[0]), float(tspan[1])), p, kwargs
+
+
+def remake(prob, u0=None, tspan=None, p=None):
+    """remake(prob; u0, tspan, p)  (scenario_1.jl:83)"""
+    return ODEProblem(prob.f, prob.u0 if u0 is None else u0, prob.tspan if tspan is None else tspan,
+                      prob.p if p is None else p, **prob.kwargs)
+
+
+class EnsembleProblem:
+    """EnsembleProblem(prob; u0s): N trajectories sharing prob.p (theta); u0s is (N, n)."""
+
+    def __init__(self, prob, u0s):
+        self.prob, self.u0s = prob, u0s
+
+
+class ODESolution:
+    def __init__(self, t, u, stats, retcode):
+        self.t, self._u = t, u          # u: (ns, n)
+        self.destats = DEStats(stats)
+        self.retcode = RETCODES.get(int(retcode), "Unknown")
+
+    @property
+    def u(self):
+        return [self._u[i] for i in range(self._u.shape[0])]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._u.T                    # Array(sol) is n x ns
+        return a.astype(dtype) if dtype else a
+
+
+class EnsembleSolution:
+    def __init__(self, t, u, stats, retcode):
+        self.t, self.u, self.stats, self.retcodes = t, u, stats, retcode   # u: (N, ns, n)
+
+    def __getitem__(self, j):
+        return ODESolution(self.t, self.u[j], self.stats[j], self.retcodes[j])
+
+    def __len__(self):
+        return self.u.shape[0]
+
+
+def _saveat_grid(saveat, tspan):
+    if saveat is None:
+        raise NotImplementedError("solve without saveat (save every step) is not part of the hot path; pass saveat")
+    if np.isscalar(saveat):
+        n = int(np.floor((tspan[1] - tspan[0]) / saveat * (1 + 1e-12))) + 1
+        ts = tspan[0] + saveat * np.arange(n)
+        if ts[-1] < tspan[1] and abs(ts[-1] - tspan[1]) < 1e-12 * max(1.0, abs(tspan[1])):
+            ts[-1] = tspan[1]
+        return ts
+    return _np(saveat)
+
+
+def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=None, device=0, **kw):
+    """solve(prob, alg; saveat, abstol, reltol, ...) -> ODESolution  /  EnsembleSolution"""
+    ens = isinstance(prob, EnsembleProblem)
+    base = prob.prob if ens else prob
+    saveat = base.kwargs.get("saveat") if saveat is None else saveat
+    ts = _saveat_grid(saveat, base.tspan)
+    eng = Engine.get(device)
+    if isinstance(ensemblealg, EnsembleMI355):
+        eng.set_launch(ensemblealg.lanes_per_traj, ensemblealg.max_dense_steps)
+    o = _opts(alg, **kw)
+    u0 = _np(prob.u0s if ens else base.u0)
+    if u0.ndim == 1:
+        u0 = u0[None, :]
+    N, n = u0.shape
+    assert n == base.f.n_state
+    theta = _np(base.p if base.p is not None else [])
+    assert theta.size == base.f.n_param, "theta has %d entries, model expects %d" % (theta.size, base.f.n_param)
+    tspan = _np(base.tspan)
+    out = np.empty((N, len(ts), n))
+    stats = np.zeros((N, NSTATS), dtype=np.int64)
+    rc = np.zeros(N, dtype=np.int32)
+    eng.check(eng.L.ude_solve_ensemble(eng.h, C.byref(base.f), C.byref(o), N, _ptr(u0), _ptr(tspan), _ptr(theta),
+                                       _ptr(ts), len(ts), _ptr(out), _ptr(stats), _ptr(rc)), allow_traj=True)
+    if ens:
+        return EnsembleSolution(ts, out, stats, rc)
+    return ODESolution(ts, out[0], stats[0], rc[0])
+
+
+def concrete_solve(prob, alg, u0, p, saveat=None, sensealg=None, **kw):
+    """concrete_solve(prob, alg, u0, p; saveat, abstol, reltol, sensealg)  (seir_exposure.jl:138)"""
+    return solve(remake(prob, u0=u0, p=p), alg, saveat=saveat, sensealg=sensealg, **kw)
+
+
+class GradResult:
+    pass
+
+
+def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblealg, kw):
+    ens = isinstance(prob, EnsembleProblem)
+    base = prob.prob if ens else prob
+    saveat = base.kwargs.get("saveat") if saveat is None else saveat
+    ts = _saveat_grid(saveat, base.tspan)
+    eng = Engine.get(device)
+    if isinstance(ensemblealg, EnsembleMI355):
+        eng.set_launch(ensemblealg.lanes_per_traj, ensemblealg.max_dense_steps)
+    o = _opts(alg, **kw)
+    u0 = _np(prob.u0s if ens else base.u0)
+    if u0.ndim == 1:
+        u0 = u0[None, :]
+    N, n = u0.shape
+    theta = _np(base.p)
+    assert theta.size == base.f.n_param
+    tspan = _np(base.tspan)
+    ns = len(ts)
+    r = GradResult()
+    r.t = ts
+    r.u = np.empty((N, ns, n))
+    r.grad_theta = np.zeros(theta.size)
+    r.grad_u0 = np.zeros((N, n))
+    r.stats = np.zeros((N, NSTATS), dtype=np.int64)
+    r.retcode = np.zeros(N, dtype=np.int32)
+    if cotangent is not None:
+        cot = _np(cotangent).reshape(N, ns, n)
+        rc = eng.L.ude_vjp_ensemble(eng.h, C.byref(base.f), C.byref(o), N, _ptr(u0), _ptr(tspan), _ptr(theta),
+                                    _ptr(ts), ns, _ptr(cot), _ptr(r.u), _ptr(r.grad_theta), _ptr(r.grad_u0),
+                                    _ptr(r.stats), _ptr(r.retcode))
+        r.loss = None
+    else:
+        dat = _np(data).reshape(N, ns, n)
+        mask = None if row_mask is None else _np(row_mask, np.uint8)
+        loss = C.c_double(0.0)
+        r.loss_per_traj = np.zeros(N)
+        rc = eng.L.ude_loss_grad_ensemble(eng.h, C.byref(base.f), C.byref(o), N, _ptr(u0), _ptr(tspan), _ptr(theta),
+                                          _ptr(ts), ns, _ptr(dat), _ptr(mask), C.byref(loss), _ptr(r.loss_per_traj),
+                                          _ptr(r.grad_theta), _ptr(r.grad_u0), _ptr(r.u), _ptr(r.stats),
+                                          _ptr(r.retcode))
+        r.loss = loss.value
+    eng.check(rc, allow_traj=True)
+    r.kernel_ms = eng.kernel_ms()
+    return r
+
+
+def loss_and_gradient(prob, alg, data, row_mask=None, saveat=None, sensealg=None, ensemblealg=None, device=0, **kw):
+    """loss(theta) = sum(abs2, data[rows,:] .- Array(solve(...))[rows,:]) and dloss/dtheta by the
+    interpolating adjoint (seir_exposure.jl:137-147; Fisher-KPP-CNN.jl:134-143; scenario_1.jl:82-94),
+    summed over an ensemble.  data: (N, ns, n)."""
+    return _grad_common(prob, alg, data, None, row_mask, saveat, device, ensemblealg, kw)
+
+
+def adjoint_pullback(prob, alg, cotangent, saveat=None, sensealg=None, ensemblealg=None, device=0, **kw):
+    """The ChainRules pullback of concrete_solve under InterpolatingAdjoint: cotangent (N, ns, n) of
+    Array(sol) -> (grad_theta, grad_u0)."""
+    return _grad_common(prob, alg, None, cotangent, None, saveat, device, ensemblealg, kw)
+
+
+# ---- device-resident path (torch CUDA tensors; used by bench.py and the training loop) -------------------
+class DeviceEnsemble:
+    """Ensemble whose u0 / data / theta already live in HBM (torch float64 CUDA tensors).  Every call
+    enqueues on torch's current stream and returns torch tensors; nothing touches the host."""
+
+    def __init__(self, f, alg, tspan, saveat, u0, data=None, row_mask=None, lanes_per_traj=0, max_dense_steps=0,
+                 **kw):
+        import torch
+        self.torch = torch
+        self.f, self.o = f, _opts(alg, **kw)
+        dev = u0.device
+        assert dev.type == "cuda" and u0.dtype == torch.float64
+        self.eng = Engine.get(dev.index or 0)
+        self.launch = (lanes_per_traj, max_dense_steps)
+        self.N, self.n = u0.shape
+        self.u0 = u0.contiguous()
+        self.tspan = _np(tspan)
+        ts = _saveat_grid(saveat, (float(tspan[0]), float(tspan[1])))
+        self.ns = len(ts)
+        self.saveat = torch.tensor(ts, dtype=torch.float64, device=dev)
+        self.data = None if data is None else data.contiguous()
+        self.mask = None if row_mask is None else torch.tensor(list(row_mask), dtype=torch.uint8, device=dev)
+        self.u = torch.empty((self.N, self.ns, self.n), dtype=torch.float64, device=dev)
+        self.stats = torch.zeros((self.N, NSTATS), dtype=torch.int64, device=dev)
+        self.retcode = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.grad = torch.zeros(f.n_param + 1, dtype=torch.float64, device=dev)  # [grad(np); loss]
+        self.grad_u0 = torch.zeros((self.N, self.n), dtype=torch.float64, device=dev)
+
+    def _bind(self):
+        self.eng.set_launch(*self.launch)
+        self.eng.set_stream(self.torch.cuda.current_stream().cuda_stream)
+
+    def solve(self, theta):
+        self._bind()
+        L, e = self.eng.L, self.eng
+        e.check(L.ude_solve_ensemble_dev(e.h, C.byref(self.f), C.byref(self.o), self.N, _ptr(self.u0), _ptr(self.tspan),
+                                         _ptr(theta), _ptr(self.saveat), self.ns, _ptr(self.u), _ptr(self.stats),
+                                         _ptr(self.retcode)))
+        return self.u
+
+    def loss_grad(self, theta):
+        """returns a view: grad[:np] = dloss/dtheta, grad[np] = loss (one buffer so a single all-reduce moves both)"""
+        self._bind()
+        L, e = self.eng.L, self.eng
+        np_ = self.f.n_param
+        loss_ptr = C.c_void_p(self.grad.data_ptr() + 8 * np_)
+        e.check(L.ude_loss_grad_ensemble_dev(e.h, C.byref(self.f), C.byref(self.o), self.N, _ptr(self.u0),
+                                             _ptr(self.tspan), _ptr(theta), _ptr(self.saveat), self.ns,
+                                             _ptr(self.data), _ptr(self.mask), loss_ptr, None, _ptr(self.grad),
+                                             _ptr(self.grad_u0), _ptr(self.u), _ptr(self.stats), _ptr(self.retcode)))
+        return self.grad
+
+    def kernel_ms(self):
+        return self.eng.kernel_ms()
