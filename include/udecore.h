@@ -144,6 +144,11 @@ int ude_loss_grad_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_
  * measured with HIP events on the context's stream (valid after the stream has been synchronised) */
 int ude_last_kernel_ms(ude_ctx* ctx, float* fwd_ms, float* bwd_ms);
 
+/* debugging aid for parity work: record (t, dt, EEst, q, accepted) of every step attempt of trajectory
+ * `traj` (forward rows [0,cap), backward rows [cap,2cap), 5 doubles each); traj < 0 switches it off */
+int ude_set_trace(ude_ctx* ctx, int64_t traj, int32_t cap);
+int ude_get_trace(ude_ctx* ctx, double* out_host /* 2*cap*5 */);
+
 /* DiffEqBase.fastpow as evaluated on the device (one thread), for parity tests of the controller */
 int ude_fastpow_dev(ude_ctx* ctx, int64_t n, const double* x_host, const double* y_host, double* out_host);
 

@@ -1,0 +1,27 @@
+import ctypes, json, os, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+import _oracle as O
+import universal_differential_equations_amd as U
+from universal_differential_equations_amd import models
+g = json.load(open("tests/golden/Scenario_1_recovery_0.005.json"))
+X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+t = np.array(g["solution"]["t"])
+eng = U.Engine.get(0)
+rng = np.random.default_rng(5)
+th2 = models.tanh32_chain().glorot_uniform(rng) * 0.5
+rng = np.random.default_rng(7)
+N = 4
+u0 = np.array([0.44249296, 4.6280594]) * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))
+data = np.repeat(X[None], N, axis=0)
+for lanes in (32, 8):
+    eng.set_trace(0, 64)
+    ens = U.EnsembleProblem(U.ODEProblem(models.ude_dynamics(models.tanh32_chain()), u0[0], (t[0], t[-1]), th2), u0)
+    r = U.loss_and_gradient(ens, U.Vern7(), data, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=U.EnsembleMI355(lanes))
+    print("lanes", lanes, r.stats[0], r.retcode)
+    tr = eng.get_trace()[1]
+    for row in tr[:20]:
+        print("  t=%.17g dt=%.17g EEst=%.12g q=%.9g acc=%d" % tuple(row))
+ref = O.loss_grad_ensemble(O.lv_ude_tanh32(), O.opts(O.VERN7, 1e-6, 1e-6), u0, [t[0], t[-1]], th2, t, data)
+print("oracle", ref["stats"][0])
+print("grad rel", np.linalg.norm(r.grad_theta - ref["grad_theta"]) / np.linalg.norm(ref["grad_theta"]))

@@ -52,7 +52,7 @@ _lib = None
 EXPORTS = ["ude_version", "ude_create", "ude_destroy", "ude_last_error", "ude_set_stream", "ude_set_launch_opts",
            "ude_model_supported", "ude_solve_ensemble", "ude_solve_ensemble_dev", "ude_vjp_ensemble",
            "ude_vjp_ensemble_dev", "ude_loss_grad_ensemble", "ude_loss_grad_ensemble_dev", "ude_last_kernel_ms",
-           "ude_fastpow_dev"]
+           "ude_fastpow_dev", "ude_set_trace", "ude_get_trace"]
 
 
 def load():
@@ -63,6 +63,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libudecore.so is missing: build it with `python -m universal_differential_equations_amd.build` "
                           "(the HIP library is required; there is no CPU fallback)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64 (same SONAME as
+    # /opt/rocm's).  Whichever is mapped first serves both, so torch must come first when it is installed --
+    # a system runtime initialised before torch leaves torch without GPUs.  (A non-Python host, e.g. the Julia
+    # ccall shim, simply gets /opt/rocm's runtime through libudecore's RUNPATH.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.ude_version.restype = C.c_int
@@ -83,5 +91,7 @@ def load():
         getattr(L, name).argtypes = common + [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ude_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ude_fastpow_dev.argtypes = [vp, i64, vp, vp, vp]
+    L.ude_set_trace.argtypes = [vp, i64, i32]
+    L.ude_get_trace.argtypes = [vp, vp]
     _lib = L
     return L

@@ -49,6 +49,10 @@ struct KParams {
     // backward outputs
     double* grad_part;  // [nwaves_total][np] per-wave partial gradients
     double* grad_u0;    // n x N or null
+    // debugging: per-iteration trace (t, dt, EEst, q, accept) of one trajectory; fwd rows first, then bwd
+    double* trace;      // [2][trace_cap][5] or null
+    int64_t trace_traj;
+    int32_t trace_cap;
 };
 
 __device__ __forceinline__ double ulp_of(double x) {
@@ -232,6 +236,7 @@ struct Driver {
                 q = fmax(q, 1.0 / o.qmax);
             }
             accept = (EEst <= 1.0);
+            sys.trace(iter, t, dt, EEst, q, accept);
             if (accept) {
                 st.nacc += 1;
                 qold = fmax(EEst, o.qoldinit);
@@ -317,6 +322,12 @@ struct FwdSys {
     __device__ __forceinline__ bool next_tstop(double&) const { return false; }
     __device__ __forceinline__ bool at_tstop(double, double*) const { return false; }
     __device__ __forceinline__ void eval(double, const double* z, double* kr, double*) { Model::rhs(mctx, z, kr); }
+    __device__ __forceinline__ void trace(int iter, double t, double dt, double e, double q, bool acc) const {
+        if (p->trace && writer && j == p->trace_traj && iter <= p->trace_cap) {
+            double* row = p->trace + (size_t)(iter - 1) * 5;
+            row[0] = t; row[1] = dt; row[2] = e; row[3] = q; row[4] = acc ? 1.0 : 0.0;
+        }
+    }
     __device__ __forceinline__ void fsal_slots(double*) {}
     __device__ __forceinline__ void store_fsal_slots(const double*) {}
 
@@ -475,6 +486,12 @@ struct AdjSys {
     }
     __device__ __forceinline__ void fsal_slots(double*) {}
     __device__ __forceinline__ void store_fsal_slots(const double*) {}
+    __device__ __forceinline__ void trace(int iter, double t, double dt, double e, double q, bool acc) const {
+        if (p->trace && mctx.r == 0 && j == p->trace_traj && iter <= p->trace_cap) {
+            double* row = p->trace + ((size_t)p->trace_cap + (iter - 1)) * 5;
+            row[0] = t; row[1] = dt; row[2] = e; row[3] = q; row[4] = acc ? 1.0 : 0.0;
+        }
+    }
 
     __device__ __forceinline__ double tstop_from_cur() const {
         // next save time strictly inside (t0, t) in descending order, else t0

@@ -13,31 +13,37 @@ namespace ude {
 // oracle's -- the accept/reject sequence of a trajectory must not depend on where it runs.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fastlog2(float x) {
+#pragma clang fp contract(off)  // every operation rounds separately, exactly like the Julia source
     const float a = 0.338953f, b = 2.198599f, c = 1.523692f;
     const uint32_t ux = __float_as_uint(x);
     const uint32_t ex = (ux & 0x7F800000u) >> 23;
     float fexp, signif;
     if (ux & 0x00400000u) {  // significand > 1.5
         signif = __uint_as_float((ux & 0x007FFFFFu) | 0x3f000000u);
-        fexp = __fsub_rn((float)ex, 126.0f);
+        fexp = (float)ex - 126.0f;
     } else {
         signif = __uint_as_float((ux & 0x007FFFFFu) | 0x3f800000u);
-        fexp = __fsub_rn((float)ex, 127.0f);
+        fexp = (float)ex - 127.0f;
     }
-    signif = __fsub_rn(signif, 1.0f);
-    const float num = __fmul_rn(signif, __fadd_rn(__fmul_rn(a, signif), b));
-    return __fadd_rn(fexp, __fdiv_rn(num, __fadd_rn(signif, c)));
+    signif = signif - 1.0f;
+    const float t1 = a * signif;
+    const float t2 = t1 + b;
+    const float t3 = signif * t2;
+    const float t4 = signif + c;
+    const float t5 = __fdiv_rn(t3, t4);
+    return fexp + t5;
 }
 
 // correctly-rounded-by-construction exp2 for Float32 arguments (Julia evaluates its Float32 exp2
 // kernel in Float64 and rounds once): Taylor-13 of e^z in Float64 with a fixed fma order.
 __device__ __forceinline__ float exp2_f32(float x) {
+#pragma clang fp contract(off)
     if (x != x) return x;
     if (x > 127.0f) return __builtin_inff();
     if (x < -126.0f) return 0.0f;
     const double xd = (double)x;
     const double n = __builtin_rint(xd);
-    const double z = __dmul_rn(__dsub_rn(xd, n), 0.6931471805599453);
+    const double z = (xd - n) * 0.6931471805599453;  // xd - n is exact
     double p = 1.0 / 6227020800.0;
     p = __builtin_fma(p, z, 1.0 / 479001600.0);
     p = __builtin_fma(p, z, 1.0 / 39916800.0);
@@ -56,7 +62,9 @@ __device__ __forceinline__ float exp2_f32(float x) {
 }
 
 __device__ __forceinline__ double fastpow(double x, double y) {
-    return (double)exp2_f32(__fmul_rn((float)y, fastlog2((float)x)));
+#pragma clang fp contract(off)
+    const float prod = (float)y * fastlog2((float)x);
+    return (double)exp2_f32(prod);
 }
 
 // ---------------------------------------------------------------------------------------------

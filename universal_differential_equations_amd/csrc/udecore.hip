@@ -56,7 +56,9 @@ struct ude_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/end, bwd start/end
     bool ev_fwd = false, ev_bwd = false;
     // workspaces (grow on demand, reused across calls)
-    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats;
+    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace;
+    int64_t trace_traj = -1;
+    int32_t trace_cap = 0;
     // staging for the host-buffer entry points
     DevBuf s_u0, s_theta, s_saveat, s_out, s_data, s_mask, s_gtheta, s_gu0, s_loss, s_lpt, s_stats, s_ret;
 };
@@ -209,7 +211,7 @@ extern "C" void ude_destroy(ude_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats,
+    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace,
                       &c->s_u0, &c->s_theta, &c->s_saveat, &c->s_out, &c->s_data, &c->s_mask, &c->s_gtheta,
                       &c->s_gu0, &c->s_loss, &c->s_lpt, &c->s_stats, &c->s_ret};
     for (DevBuf* b : bufs)
@@ -238,6 +240,25 @@ extern "C" int ude_model_supported(ude_ctx* c, const ude_model_desc* m, const ud
     Launch l;
     int G;
     return resolve(c, m, o, l, G);
+}
+
+extern "C" int ude_set_trace(ude_ctx* c, int64_t traj, int32_t cap) {
+    if (!c) return UDE_ERR_INVALID;
+    c->trace_traj = traj;
+    c->trace_cap = traj >= 0 ? cap : 0;
+    if (c->trace_cap > 0) {
+        int rc = ensure(c, c->trace, sizeof(double) * 10 * (size_t)cap);
+        if (rc) return rc;
+        HIPCHK(c, hipMemset(c->trace.p, 0, sizeof(double) * 10 * (size_t)cap));
+    }
+    return UDE_OK;
+}
+
+extern "C" int ude_get_trace(ude_ctx* c, double* out_host) {
+    if (!c || !out_host || c->trace_cap <= 0) return UDE_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out_host, c->trace.p, sizeof(double) * 10 * (size_t)c->trace_cap, hipMemcpyDeviceToHost));
+    return UDE_OK;
 }
 
 extern "C" int ude_last_kernel_ms(ude_ctx* c, float* fwd_ms, float* bwd_ms) {
@@ -277,6 +298,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
+    if (c->trace_cap > 0) { p.trace = (double*)c->trace.p; p.trace_traj = c->trace_traj; p.trace_cap = c->trace_cap; }
     p.N = N;
     p.Npad = N;
     p.ns = ns;
@@ -318,6 +340,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
+    if (c->trace_cap > 0) { p.trace = (double*)c->trace.p; p.trace_traj = c->trace_traj; p.trace_cap = c->trace_cap; }
     const int n = m->n_state, np = m->n_param;
     const int cap = c->lo.max_dense_steps > 0 ? c->lo.max_dense_steps : 256;
     const int64_t threads = N * G;

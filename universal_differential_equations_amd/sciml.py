@@ -97,6 +97,15 @@ class Engine:
         self.check(self.L.ude_last_kernel_ms(self.h, C.byref(f), C.byref(b)))
         return f.value, b.value
 
+    def set_trace(self, traj, cap=512):
+        self._trace_cap = cap
+        self.check(self.L.ude_set_trace(self.h, traj, cap))
+
+    def get_trace(self):
+        out = np.zeros((2, self._trace_cap, 5))
+        self.check(self.L.ude_get_trace(self.h, out.ctypes.data))
+        return out
+
     def fastpow(self, x, y):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(np.broadcast_to(y, x.shape), dtype=np.float64)
