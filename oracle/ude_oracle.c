@@ -78,6 +78,72 @@ double udeo_fastpow(double x, double y) {
     return (double)udeo_exp2f(prod);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * ARITH-SPEC elementary functions.  The step sequence of an adaptive solve is chaotic in the last
+ * bit of every intermediate (sliver steps before a tstop have a pure-rounding-noise error estimate;
+ * see DESIGN.md "Arithmetic specification"), so "bit-exact step counts" between this oracle and the
+ * HIP kernels is only meaningful if both evaluate exp/tanh/log10/pow10 with the SAME sequence of
+ * IEEE operations.  These are fixed-order fma() kernels (about 1 ulp), restated independently in
+ * universal_differential_equations_amd/csrc/ude_math.h.
+ * ------------------------------------------------------------------------------------------ */
+double udeo_exp(double x) {
+    if (x != x) return x;
+    if (x > 709.0) return INFINITY;
+    if (x < -745.0) return 0.0;
+    const double k = rint(x * 1.4426950408889634);
+    double r = fma(-k, 0.6931471803691238, x);       /* ln2 hi (32 bits) */
+    r = fma(-k, 1.9082149292705877e-10, r);           /* ln2 lo */
+    double p = 1.0 / 6227020800.0;                    /* Taylor 13, |r| <= 0.3466 */
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+double udeo_tanh(double x) {
+    if (x != x) return x;
+    const double ax = fabs(x);
+    double t;
+    if (ax < 0.3) {
+        /* expm1(2|x|) by its Taylor series in Horner form, then tanh = em/(em+2) */
+        const double z = ax + ax;
+        double p = 1.0;
+        for (int n = 18; n >= 2; --n) p = fma(z * (1.0 / (double)n), p, 1.0);
+        const double em = z * p;
+        t = em / (em + 2.0);
+    } else if (ax < 20.0) {
+        const double e = udeo_exp(ax + ax);
+        t = 1.0 - 2.0 / (e + 1.0);
+    } else {
+        t = 1.0;
+    }
+    return x < 0 ? -t : t;
+}
+
+double udeo_log10(double x) { /* x > 0, finite (initial-dt heuristic only) */
+    int e;
+    double m = frexp(x, &e); /* m in [0.5, 1) */
+    if (m < 0.7071067811865476) { m = m + m; e -= 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 23.0;
+    for (int n = 21; n >= 1; n -= 2) p = fma(p, s2, 1.0 / (double)n);
+    const double lnm = (s + s) * p;
+    return fma((double)e, 0.6931471805599453, lnm) * 0.4342944819032518;
+}
+
+double udeo_pow10(double y) { return udeo_exp(y * 2.302585092994046); }
+
 int udeo_num_params(const udeo_model_desc* m) {
     int c = 0;
     for (int l = 0; l < m->n_layers; ++l) c += m->dims[l] * m->dims[l + 1] + m->dims[l + 1];
@@ -90,12 +156,14 @@ static float ulp_f32(float x) { x = fabsf(x); return nextafterf(x, INFINITY) - x
 /* ---- f64 instantiation ---- */
 #define REAL double
 #define FN(name) name##_f64
-#define R_EXP exp
-#define R_TANH tanh
+#define R_EXP udeo_exp
+#define R_TANH udeo_tanh
 #define R_SQRT sqrt
 #define R_FABS fabs
-#define R_LOG10 log10
+#define R_LOG10 udeo_log10
 #define R_POW pow
+#define R_POW10(x) udeo_pow10(x)
+#define R_FMA fma
 #define R_EPS 2.220446049250313e-16
 #include "ude_oracle_impl.h"
 #include "ude_oracle_adj.h"
@@ -107,6 +175,8 @@ static float ulp_f32(float x) { x = fabsf(x); return nextafterf(x, INFINITY) - x
 #undef R_FABS
 #undef R_LOG10
 #undef R_POW
+#undef R_POW10
+#undef R_FMA
 #undef R_EPS
 
 /* ---- f32 instantiation ---- */
@@ -118,6 +188,8 @@ static float ulp_f32(float x) { x = fabsf(x); return nextafterf(x, INFINITY) - x
 #define R_FABS fabsf
 #define R_LOG10 log10f
 #define R_POW powf
+#define R_POW10(x) ((float)pow(10.0, (double)(x)))
+#define R_FMA fmaf
 #define R_EPS 1.1920929e-07f
 #include "ude_oracle_impl.h"
 #undef REAL

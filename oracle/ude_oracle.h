@@ -80,6 +80,10 @@ typedef struct {
 float udeo_fastlog2(float x);
 float udeo_exp2f(float x);
 double udeo_fastpow(double x, double y);
+double udeo_exp(double x);   /* ARITH-SPEC deterministic elementary functions (see ude_oracle.c) */
+double udeo_tanh(double x);
+double udeo_log10(double x);
+double udeo_pow10(double y);
 int udeo_num_params(const udeo_model_desc* m); /* NN parameter count implied by dims */
 
 /* ---- f64 API ---- */

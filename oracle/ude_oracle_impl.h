@@ -29,8 +29,8 @@ static inline REAL FN(act)(int a, REAL z) {
 /* derivative given pre-activation z and activation value a */
 static inline REAL FN(dact)(int a, REAL z, REAL av) {
     switch (a) {
-        case UDEO_ACT_TANH: return (REAL)1 - av * av;
-        case UDEO_ACT_RBF: return (REAL)-2 * z * av;
+        case UDEO_ACT_TANH: return R_FMA(-av, av, (REAL)1);
+        case UDEO_ACT_RBF: return ((REAL)-2 * z) * av;
         case UDEO_ACT_RELU: return z > 0 ? (REAL)1 : (REAL)0;
         default: return (REAL)1;
     }
@@ -47,8 +47,8 @@ static void FN(mlp_forward)(const udeo_model_desc* m, const REAL* p, const REAL*
         const REAL* W = p;
         const REAL* b = p + (size_t)in * out;
         for (int j = 0; j < out; ++j) {
-            REAL acc = 0; /* W*x accumulated in ascending input order, then + b (Lux: W*x .+ b) */
-            for (int k = 0; k < in; ++k) acc += W[j + (size_t)k * out] * as[l][k];
+            REAL acc = 0; /* ARITH-SPEC: fma chain in ascending input order from 0, then + b (Lux: W*x .+ b) */
+            for (int k = 0; k < in; ++k) acc = R_FMA(W[j + (size_t)k * out], as[l][k], acc);
             acc += b[j];
             zs[l][j] = acc;
             as[l + 1][j] = FN(act)(m->act[l], acc);
@@ -82,7 +82,7 @@ static void FN(mlp_vjp)(const udeo_model_desc* m, const REAL* p0, REAL zs[][UDEO
         }
         for (int k = 0; k < in; ++k) {
             REAL acc = 0;
-            for (int j = 0; j < out; ++j) acc += W[j + (size_t)k * out] * delta[j];
+            for (int j = 0; j < out; ++j) acc = R_FMA(W[j + (size_t)k * out], delta[j], acc);
             prev[k] = acc;
         }
         for (int k = 0; k < in; ++k) delta[k] = prev[k];
@@ -109,8 +109,8 @@ void FN(udeo_rhs)(const udeo_model_desc* m, const REAL* th, const REAL* u, REAL 
         case UDEO_KIND_LV_UDE: { /* scenario_1.jl:69-73 */
             FN(mlp_forward)(m, th + m->nn_offset, u, zs, as);
             const REAL* y = as[m->n_layers];
-            du[0] = FN(lv_lin)(m, th, 0) * u[0] + y[0];
-            du[1] = FN(lv_lin)(m, th, 1) * u[1] + y[1];
+            du[0] = R_FMA(FN(lv_lin)(m, th, 0), u[0], y[0]);
+            du[1] = R_FMA(FN(lv_lin)(m, th, 1), u[1], y[1]);
         } break;
         case UDEO_KIND_SEIR_TRUE: { /* seir_exposure.jl:16-30 */
             const REAL S = u[0], E = u[1], I = u[2], Rr = u[3], N = u[4], D = u[5];
@@ -199,8 +199,8 @@ int FN(udeo_rhs_vjp)(const udeo_model_desc* m, const REAL* th, const REAL* u, RE
             FN(mlp_forward)(m, th + m->nn_offset, u, zs, as);
             FN(mlp_vjp)(m, th + m->nn_offset, zs, as, lam, gx, dth ? dth + m->nn_offset : 0);
             for (int i = 0; i < 2; ++i) {
-                dlam[i] = FN(lv_lin)(m, th, i) * lam[i] + gx[i];
-                if (dth && m->lin_idx[i] >= 0) dth[m->lin_idx[i]] += (REAL)m->lin_sign[i] * u[i] * lam[i];
+                dlam[i] = R_FMA(FN(lv_lin)(m, th, i), lam[i], gx[i]);
+                if (dth && m->lin_idx[i] >= 0) dth[m->lin_idx[i]] += ((REAL)m->lin_sign[i] * u[i]) * lam[i];
             }
         } return 0;
         case UDEO_KIND_SEIR_UDE: {
@@ -279,65 +279,98 @@ static REAL FN(rms)(const REAL* v, int n) {
     return R_SQRT(s / (REAL)(n > 0 ? n : 1));
 }
 
+/* coefficient tables (zeros are skipped, sums are fma chains in ascending stage order: ARITH-SPEC) */
+static void FN(tab_tsit5)(REAL A[7][7], REAL* B, REAL* BT, REAL* C) {
+#define T(x) ((REAL)UDE_TSIT5_##x)
+    memset(A, 0, sizeof(REAL) * 49);
+    A[1][0] = T(a21);
+    A[2][0] = T(a31); A[2][1] = T(a32);
+    A[3][0] = T(a41); A[3][1] = T(a42); A[3][2] = T(a43);
+    A[4][0] = T(a51); A[4][1] = T(a52); A[4][2] = T(a53); A[4][3] = T(a54);
+    A[5][0] = T(a61); A[5][1] = T(a62); A[5][2] = T(a63); A[5][3] = T(a64); A[5][4] = T(a65);
+    A[6][0] = T(a71); A[6][1] = T(a72); A[6][2] = T(a73); A[6][3] = T(a74); A[6][4] = T(a75); A[6][5] = T(a76);
+    for (int j = 0; j < 7; ++j) B[j] = A[6][j];
+    BT[0] = T(btilde1); BT[1] = T(btilde2); BT[2] = T(btilde3); BT[3] = T(btilde4); BT[4] = T(btilde5);
+    BT[5] = T(btilde6); BT[6] = T(btilde7);
+    C[0] = 0; C[1] = T(c1); C[2] = T(c2); C[3] = T(c3); C[4] = T(c4); C[5] = T(c5); C[6] = T(c6);
+#undef T
+}
+static void FN(tab_vern7)(REAL A[10][10], REAL* B, REAL* BT, REAL* C, REAL AE[6][16], REAL* CE) {
+#define V(x) ((REAL)UDE_VERN7_##x)
+    memset(A, 0, sizeof(REAL) * 100);
+    memset(AE, 0, sizeof(REAL) * 96);
+    A[1][0] = V(a021);
+    A[2][0] = V(a031); A[2][1] = V(a032);
+    A[3][0] = V(a041); A[3][2] = V(a043);
+    A[4][0] = V(a051); A[4][2] = V(a053); A[4][3] = V(a054);
+    A[5][0] = V(a061); A[5][2] = V(a063); A[5][3] = V(a064); A[5][4] = V(a065);
+    A[6][0] = V(a071); A[6][2] = V(a073); A[6][3] = V(a074); A[6][4] = V(a075); A[6][5] = V(a076);
+    A[7][0] = V(a081); A[7][2] = V(a083); A[7][3] = V(a084); A[7][4] = V(a085); A[7][5] = V(a086); A[7][6] = V(a087);
+    A[8][0] = V(a091); A[8][2] = V(a093); A[8][3] = V(a094); A[8][4] = V(a095); A[8][5] = V(a096); A[8][6] = V(a097); A[8][7] = V(a098);
+    A[9][0] = V(a101); A[9][2] = V(a103); A[9][3] = V(a104); A[9][4] = V(a105); A[9][5] = V(a106); A[9][6] = V(a107);
+    for (int j = 0; j < 10; ++j) { B[j] = 0; BT[j] = 0; }
+    B[0] = V(b1); B[3] = V(b4); B[4] = V(b5); B[5] = V(b6); B[6] = V(b7); B[7] = V(b8); B[8] = V(b9);
+    BT[0] = V(btilde1); BT[3] = V(btilde4); BT[4] = V(btilde5); BT[5] = V(btilde6); BT[6] = V(btilde7);
+    BT[7] = V(btilde8); BT[8] = V(btilde9); BT[9] = V(btilde10);
+    C[0] = 0; C[1] = V(c2); C[2] = V(c3); C[3] = V(c4); C[4] = V(c5); C[5] = V(c6); C[6] = V(c7); C[7] = V(c8); C[8] = 1; C[9] = 1;
+    AE[0][0] = V(a1101); AE[0][3] = V(a1104); AE[0][4] = V(a1105); AE[0][5] = V(a1106); AE[0][6] = V(a1107); AE[0][7] = V(a1108); AE[0][8] = V(a1109);
+    AE[1][0] = V(a1201); AE[1][3] = V(a1204); AE[1][4] = V(a1205); AE[1][5] = V(a1206); AE[1][6] = V(a1207); AE[1][7] = V(a1208); AE[1][8] = V(a1209); AE[1][10] = V(a1211);
+    AE[2][0] = V(a1301); AE[2][3] = V(a1304); AE[2][4] = V(a1305); AE[2][5] = V(a1306); AE[2][6] = V(a1307); AE[2][7] = V(a1308); AE[2][8] = V(a1309); AE[2][10] = V(a1311); AE[2][11] = V(a1312);
+    AE[3][0] = V(a1401); AE[3][3] = V(a1404); AE[3][4] = V(a1405); AE[3][5] = V(a1406); AE[3][6] = V(a1407); AE[3][7] = V(a1408); AE[3][8] = V(a1409); AE[3][10] = V(a1411); AE[3][11] = V(a1412); AE[3][12] = V(a1413);
+    AE[4][0] = V(a1501); AE[4][3] = V(a1504); AE[4][4] = V(a1505); AE[4][5] = V(a1506); AE[4][6] = V(a1507); AE[4][7] = V(a1508); AE[4][8] = V(a1509); AE[4][10] = V(a1511); AE[4][11] = V(a1512); AE[4][12] = V(a1513);
+    AE[5][0] = V(a1601); AE[5][3] = V(a1604); AE[5][4] = V(a1605); AE[5][5] = V(a1606); AE[5][6] = V(a1607); AE[5][7] = V(a1608); AE[5][8] = V(a1609); AE[5][10] = V(a1611); AE[5][11] = V(a1612); AE[5][12] = V(a1613);
+    CE[0] = V(c11); CE[1] = V(c12); CE[2] = V(c13); CE[3] = V(c14); CE[4] = V(c15); CE[5] = V(c16);
+#undef V
+}
+
+/* out[i] = base[i] + dt * chain_j(coef[j], k[j][i]) over the nonzero coef in ascending j (ARITH-SPEC) */
+static void FN(combine)(const REAL* coef, int nj, REAL* const* k, REAL dt, const REAL* base, int nz, REAL* out) {
+    for (int i = 0; i < nz; ++i) {
+        REAL acc = 0;
+        int first = 1;
+        for (int j = 0; j < nj; ++j) {
+            if (coef[j] == 0) continue;
+            acc = first ? coef[j] * k[j][i] : R_FMA(coef[j], k[j][i], acc);
+            first = 0;
+        }
+        out[i] = R_FMA(dt, acc, base[i]);
+    }
+}
+
 /* Vern7 lazy dense-output stages k11..k16 (OrdinaryDiffEq _ode_addsteps!) */
 static void FN(vern7_extra)(FN(stepinfo)* si, REAL* tmp) {
     if (si->lazy_done) return;
-    const int nz = si->nz;
-    REAL** k = si->k;
-    const REAL dt = si->dt, t = si->tprev;
-    const REAL* up = si->uprev;
-#define V(x) ((REAL)UDE_VERN7_##x)
-    for (int i = 0; i < nz; ++i)
-        tmp[i] = up[i] + dt * (V(a1101) * k[0][i] + V(a1104) * k[3][i] + V(a1105) * k[4][i] + V(a1106) * k[5][i] +
-                               V(a1107) * k[6][i] + V(a1108) * k[7][i] + V(a1109) * k[8][i]);
-    si->f(si->fctx, t + V(c11) * dt, tmp, k[10]);
-    for (int i = 0; i < nz; ++i)
-        tmp[i] = up[i] + dt * (V(a1201) * k[0][i] + V(a1204) * k[3][i] + V(a1205) * k[4][i] + V(a1206) * k[5][i] +
-                               V(a1207) * k[6][i] + V(a1208) * k[7][i] + V(a1209) * k[8][i] + V(a1211) * k[10][i]);
-    si->f(si->fctx, t + V(c12) * dt, tmp, k[11]);
-    for (int i = 0; i < nz; ++i)
-        tmp[i] = up[i] + dt * (V(a1301) * k[0][i] + V(a1304) * k[3][i] + V(a1305) * k[4][i] + V(a1306) * k[5][i] +
-                               V(a1307) * k[6][i] + V(a1308) * k[7][i] + V(a1309) * k[8][i] + V(a1311) * k[10][i] +
-                               V(a1312) * k[11][i]);
-    si->f(si->fctx, t + V(c13) * dt, tmp, k[12]);
-    for (int i = 0; i < nz; ++i)
-        tmp[i] = up[i] + dt * (V(a1401) * k[0][i] + V(a1404) * k[3][i] + V(a1405) * k[4][i] + V(a1406) * k[5][i] +
-                               V(a1407) * k[6][i] + V(a1408) * k[7][i] + V(a1409) * k[8][i] + V(a1411) * k[10][i] +
-                               V(a1412) * k[11][i] + V(a1413) * k[12][i]);
-    si->f(si->fctx, t + V(c14) * dt, tmp, k[13]);
-    for (int i = 0; i < nz; ++i)
-        tmp[i] = up[i] + dt * (V(a1501) * k[0][i] + V(a1504) * k[3][i] + V(a1505) * k[4][i] + V(a1506) * k[5][i] +
-                               V(a1507) * k[6][i] + V(a1508) * k[7][i] + V(a1509) * k[8][i] + V(a1511) * k[10][i] +
-                               V(a1512) * k[11][i] + V(a1513) * k[12][i]);
-    si->f(si->fctx, t + V(c15) * dt, tmp, k[14]);
-    for (int i = 0; i < nz; ++i)
-        tmp[i] = up[i] + dt * (V(a1601) * k[0][i] + V(a1604) * k[3][i] + V(a1605) * k[4][i] + V(a1606) * k[5][i] +
-                               V(a1607) * k[6][i] + V(a1608) * k[7][i] + V(a1609) * k[8][i] + V(a1611) * k[10][i] +
-                               V(a1612) * k[11][i] + V(a1613) * k[12][i]);
-    si->f(si->fctx, t + V(c16) * dt, tmp, k[15]);
-#undef V
+    REAL A[10][10], B[10], BT[10], C[10], AE[6][16], CE[6];
+    FN(tab_vern7)(A, B, BT, C, AE, CE);
+    for (int e = 0; e < 6; ++e) {
+        FN(combine)(AE[e], 10 + e, si->k, si->dt, si->uprev, si->nz, tmp);
+        si->f(si->fctx, si->tprev + CE[e] * si->dt, tmp, si->k[10 + e]);
+    }
     si->lazy_done = 1;
     if (si->nf_lazy) *si->nf_lazy += 6;
 }
 
-/* dense-output weights b_j(Theta) (OrdinaryDiffEq ode_interpolant; @evalpoly = Horner) */
+/* dense-output weights b_j(Theta) (OrdinaryDiffEq ode_interpolant; @evalpoly = Horner with muladd) */
 static void FN(tsit5_bth)(REAL th, REAL* b) {
 #define T(x) ((REAL)UDE_TSIT5_##x)
+#define H3(p) (th2 * R_FMA(th, R_FMA(th, T(p##4), T(p##3)), T(p##2)))
     const REAL th2 = th * th;
-    b[0] = th * (T(r11) + th * (T(r12) + th * (T(r13) + th * T(r14))));
-    b[1] = th2 * (T(r22) + th * (T(r23) + th * T(r24)));
-    b[2] = th2 * (T(r32) + th * (T(r33) + th * T(r34)));
-    b[3] = th2 * (T(r42) + th * (T(r43) + th * T(r44)));
-    b[4] = th2 * (T(r52) + th * (T(r53) + th * T(r54)));
-    b[5] = th2 * (T(r62) + th * (T(r63) + th * T(r64)));
-    b[6] = th2 * (T(r72) + th * (T(r73) + th * T(r74)));
+    b[0] = th * R_FMA(th, R_FMA(th, R_FMA(th, T(r14), T(r13)), T(r12)), T(r11));
+    b[1] = H3(r2);
+    b[2] = H3(r3);
+    b[3] = H3(r4);
+    b[4] = H3(r5);
+    b[5] = H3(r6);
+    b[6] = H3(r7);
+#undef H3
 #undef T
 }
 static void FN(vern7_bth)(REAL th, REAL* b /*16, unused slots zero*/) {
 #define V(x) ((REAL)UDE_VERN7_##x)
-#define P6(p) (th * th * (V(p##2) + th * (V(p##3) + th * (V(p##4) + th * (V(p##5) + th * (V(p##6) + th * V(p##7)))))))
+#define P6(p) (th2 * R_FMA(th, R_FMA(th, R_FMA(th, R_FMA(th, R_FMA(th, V(p##7), V(p##6)), V(p##5)), V(p##4)), V(p##3)), V(p##2)))
+    const REAL th2 = th * th;
     for (int j = 0; j < 16; ++j) b[j] = 0;
-    b[0] = th * (V(r011) + th * (V(r012) + th * (V(r013) + th * (V(r014) + th * (V(r015) + th * (V(r016) + th * V(r017)))))));
+    b[0] = th * R_FMA(th, R_FMA(th, R_FMA(th, R_FMA(th, R_FMA(th, R_FMA(th, V(r017), V(r016)), V(r015)), V(r014)), V(r013)), V(r012)), V(r011));
     b[3] = P6(r04);
     b[4] = P6(r05);
     b[5] = P6(r06);
@@ -354,21 +387,18 @@ static void FN(vern7_bth)(REAL th, REAL* b /*16, unused slots zero*/) {
 #undef V
 }
 
-/* y = uprev + dt * sum_j b_j(theta) k_j */
+/* y = uprev + dt * sum_j b_j(theta) k_j   (ARITH-SPEC: fma chain over the used stages in ascending order) */
 static void FN(interp)(int alg, REAL th, REAL dt, const REAL* uprev, REAL* const* k, int nz, REAL* y) {
     REAL b[16];
-    if (alg == UDEO_ALG_TSIT5) {
-        FN(tsit5_bth)(th, b);
-        for (int i = 0; i < nz; ++i)
-            y[i] = uprev[i] + dt * (k[0][i] * b[0] + k[1][i] * b[1] + k[2][i] * b[2] + k[3][i] * b[3] +
-                                    k[4][i] * b[4] + k[5][i] * b[5] + k[6][i] * b[6]);
-    } else {
-        FN(vern7_bth)(th, b);
-        for (int i = 0; i < nz; ++i)
-            y[i] = uprev[i] + dt * (k[0][i] * b[0] + k[3][i] * b[3] + k[4][i] * b[4] + k[5][i] * b[5] +
-                                    k[6][i] * b[6] + k[7][i] * b[7] + k[8][i] * b[8] + k[10][i] * b[10] +
-                                    k[11][i] * b[11] + k[12][i] * b[12] + k[13][i] * b[13] + k[14][i] * b[14] +
-                                    k[15][i] * b[15]);
+    static const int use5[7] = {0, 1, 2, 3, 4, 5, 6};
+    static const int use7[13] = {0, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15};
+    const int* use = alg == UDEO_ALG_TSIT5 ? use5 : use7;
+    const int nu = alg == UDEO_ALG_TSIT5 ? 7 : 13;
+    if (alg == UDEO_ALG_TSIT5) FN(tsit5_bth)(th, b); else FN(vern7_bth)(th, b);
+    for (int i = 0; i < nz; ++i) {
+        REAL acc = k[use[0]][i] * b[use[0]];
+        for (int q = 1; q < nu; ++q) acc = R_FMA(k[use[q]][i], b[use[q]], acc);
+        y[i] = R_FMA(dt, acc, uprev[i]);
     }
 }
 
@@ -393,18 +423,31 @@ static void FN(resolve_opts)(const udeo_solve_opts* o, REAL t0, REAL tf, FN(ropt
     r->dt0 = (REAL)o->dt0;
 }
 
-/* OrdinaryDiffEq ode_determine_initdt (Hairer); 2 RHS evals; f0 returned in f0out */
+/* ARITH-SPEC: the three norms of the initial-dt heuristic enter dt at full precision (no Float32 controller
+ * quantisation absorbs a last-bit difference), so their sums of squares are accumulated in double-double
+ * (two-sum) arithmetic: the rounded result is then independent of the summation order, which differs between
+ * this sequential loop and the lane-parallel reduction of the kernels. */
+static inline void FN(dd_acc)(REAL* hi, REAL* lo, REAL x) {
+    const REAL s = *hi + x;
+    const REAL bb = s - *hi;
+    const REAL e = (*hi - (s - bb)) + (x - bb);
+    *hi = s;
+    *lo += e;
+}
+
+/* OrdinaryDiffEq ode_determine_initdt (Hairer); 2 RHS evals; f0 returned in f0out.
+ * ARITH-SPEC: sk = fma(|u|, reltol, abstol); q*q summed in double-double; d = sqrt(s / n). */
 static REAL FN(initdt)(const FN(ropts)* r, FN(rhs_fn) f, void* ctx, const REAL* u0, REAL t, REAL tdir,
                        int nz, REAL* f0, REAL* w1, REAL* w2, int* nan_out) {
     REAL* sk = w1;
-    for (int i = 0; i < nz; ++i) sk[i] = r->abstol + R_FABS(u0[i]) * r->reltol;
-    REAL s = 0;
-    for (int i = 0; i < nz; ++i) { REAL q = u0[i] / sk[i]; s += q * q; }
-    const REAL d0 = R_SQRT(s / (REAL)nz);
+    for (int i = 0; i < nz; ++i) sk[i] = R_FMA(R_FABS(u0[i]), r->reltol, r->abstol);
+    REAL hi = 0, lo = 0;
+    for (int i = 0; i < nz; ++i) { REAL q = u0[i] / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
+    const REAL d0 = R_SQRT((hi + lo) / (REAL)nz);
     f(ctx, t, u0, f0);
-    s = 0;
-    for (int i = 0; i < nz; ++i) { REAL q = f0[i] / sk[i]; s += q * q; }
-    const REAL d1 = R_SQRT(s / (REAL)nz);
+    hi = 0; lo = 0;
+    for (int i = 0; i < nz; ++i) { REAL q = f0[i] / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
+    const REAL d1 = R_SQRT((hi + lo) / (REAL)nz);
     if (d1 != d1) { *nan_out = 1; return (REAL)0; }
     REAL dt0 = (d0 < (REAL)1e-5 || d1 < (REAL)1e-5) ? (REAL)1e-6 : (d0 / d1) / (REAL)100;
     if (dt0 > r->dtmax) dt0 = r->dtmax;
@@ -412,20 +455,20 @@ static REAL FN(initdt)(const FN(ropts)* r, FN(rhs_fn) f, void* ctx, const REAL* 
     const REAL dt0t = tdir * dt0;
     REAL* u1 = w2;          /* w2 holds 2*nz: [u1 | f1] */
     REAL* f1 = w2 + nz;
-    for (int i = 0; i < nz; ++i) u1[i] = u0[i] + dt0t * f0[i];
+    for (int i = 0; i < nz; ++i) u1[i] = R_FMA(dt0t, f0[i], u0[i]);
     f(ctx, t + dt0t, u1, f1);
-    s = 0;
-    for (int i = 0; i < nz; ++i) { REAL q = (f1[i] - f0[i]) / sk[i]; s += q * q; }
-    const REAL d2 = R_SQRT(s / (REAL)nz) / dt0;
+    hi = 0; lo = 0;
+    for (int i = 0; i < nz; ++i) { REAL q = (f1[i] - f0[i]) / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
+    const REAL d2 = R_SQRT((hi + lo) / (REAL)nz) / dt0;
     const REAL mx = d1 > d2 ? d1 : d2;
     REAL dt1;
     if (mx <= (REAL)1e-15) {
         dt1 = dt0 * (REAL)1e-3;
         if (dt1 < (REAL)1e-6) dt1 = (REAL)1e-6;
     } else {
-        /* 10.0^(-(2+log10(mx))/order): exponent in the problem's float type, power in Float64 */
+        /* 10.0^(-(2+log10(mx))/order) */
         const REAL ex = -((REAL)2 + R_LOG10(mx)) / (REAL)r->order;
-        dt1 = (REAL)pow(10.0, (double)ex);
+        dt1 = R_POW10(ex);
     }
     REAL dt = (REAL)100 * dt0;
     if (dt1 < dt) dt = dt1;
@@ -455,6 +498,9 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
     int64_t nf = 0, nacc = 0, nrej = 0;
     int ret = UDEO_RET_SUCCESS;
     int its = 0;
+    REAL A5[7][7], A7[10][10], AE7[6][16], CE7[6], Btab[10], BTtab[10], Ctab[10];
+    if (alg == UDEO_ALG_TSIT5) FN(tab_tsit5)(A5, Btab, BTtab, Ctab);
+    else FN(tab_vern7)(A7, Btab, BTtab, Ctab, AE7, CE7);
     REAL t = t0, dt, qold = r->qoldinit, q11 = 1;
     int accept = 1, iter = 0;
     memcpy(uprev, z, sizeof(REAL) * nz);
@@ -490,79 +536,35 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
             if (iter > r->maxiters) { ret = UDEO_RET_MAXITERS; goto done; }
             if (dt != dt) { ret = UDEO_RET_UNSTABLE; goto done; }
             if (R_FABS(dt) <= R_EPS * R_FABS(t) && R_FABS(dt) < R_FABS(tstop - t)) { ret = UDEO_RET_DTLESSTHANMIN; goto done; }
-            /* ---- perform_step! ---- */
-            if (alg == UDEO_ALG_TSIT5) {
-#define T(x) ((REAL)UDE_TSIT5_##x)
-                REAL *k1 = kk[0], *k2 = kk[1], *k3 = kk[2], *k4 = kk[3], *k5 = kk[4], *k6 = kk[5], *k7 = kk[6];
-                const REAL a = dt * T(a21);
-                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + a * k1[i];
-                f(fctx, t + T(c1) * dt, tmp, k2);
-                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (T(a31) * k1[i] + T(a32) * k2[i]);
-                f(fctx, t + T(c2) * dt, tmp, k3);
-                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (T(a41) * k1[i] + T(a42) * k2[i] + T(a43) * k3[i]);
-                f(fctx, t + T(c3) * dt, tmp, k4);
-                for (int i = 0; i < nz; ++i)
-                    tmp[i] = uprev[i] + dt * (T(a51) * k1[i] + T(a52) * k2[i] + T(a53) * k3[i] + T(a54) * k4[i]);
-                f(fctx, t + T(c4) * dt, tmp, k5);
-                for (int i = 0; i < nz; ++i)
-                    tmp[i] = uprev[i] + dt * (T(a61) * k1[i] + T(a62) * k2[i] + T(a63) * k3[i] + T(a64) * k4[i] + T(a65) * k5[i]);
-                f(fctx, t + dt, tmp, k6);
-                for (int i = 0; i < nz; ++i)
-                    u[i] = uprev[i] + dt * (T(a71) * k1[i] + T(a72) * k2[i] + T(a73) * k3[i] + T(a74) * k4[i] +
-                                            T(a75) * k5[i] + T(a76) * k6[i]);
-                f(fctx, t + dt, u, k7);
-                nf += 6;
-                for (int i = 0; i < nz; ++i)
-                    utilde[i] = dt * (T(btilde1) * k1[i] + T(btilde2) * k2[i] + T(btilde3) * k3[i] + T(btilde4) * k4[i] +
-                                      T(btilde5) * k5[i] + T(btilde6) * k6[i] + T(btilde7) * k7[i]);
-#undef T
-            } else {
-#define V(x) ((REAL)UDE_VERN7_##x)
-                REAL *k1 = kk[0], *k2 = kk[1], *k3 = kk[2], *k4 = kk[3], *k5 = kk[4], *k6 = kk[5], *k7 = kk[6],
-                     *k8 = kk[7], *k9 = kk[8], *k10 = kk[9];
-                f(fctx, t, uprev, k1);
-                const REAL a = dt * V(a021);
-                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + a * k1[i];
-                f(fctx, t + V(c2) * dt, tmp, k2);
-                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (V(a031) * k1[i] + V(a032) * k2[i]);
-                f(fctx, t + V(c3) * dt, tmp, k3);
-                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (V(a041) * k1[i] + V(a043) * k3[i]);
-                f(fctx, t + V(c4) * dt, tmp, k4);
-                for (int i = 0; i < nz; ++i) tmp[i] = uprev[i] + dt * (V(a051) * k1[i] + V(a053) * k3[i] + V(a054) * k4[i]);
-                f(fctx, t + V(c5) * dt, tmp, k5);
-                for (int i = 0; i < nz; ++i)
-                    tmp[i] = uprev[i] + dt * (V(a061) * k1[i] + V(a063) * k3[i] + V(a064) * k4[i] + V(a065) * k5[i]);
-                f(fctx, t + V(c6) * dt, tmp, k6);
-                for (int i = 0; i < nz; ++i)
-                    tmp[i] = uprev[i] + dt * (V(a071) * k1[i] + V(a073) * k3[i] + V(a074) * k4[i] + V(a075) * k5[i] + V(a076) * k6[i]);
-                f(fctx, t + V(c7) * dt, tmp, k7);
-                for (int i = 0; i < nz; ++i)
-                    tmp[i] = uprev[i] + dt * (V(a081) * k1[i] + V(a083) * k3[i] + V(a084) * k4[i] + V(a085) * k5[i] +
-                                              V(a086) * k6[i] + V(a087) * k7[i]);
-                f(fctx, t + V(c8) * dt, tmp, k8);
-                for (int i = 0; i < nz; ++i)
-                    tmp[i] = uprev[i] + dt * (V(a091) * k1[i] + V(a093) * k3[i] + V(a094) * k4[i] + V(a095) * k5[i] +
-                                              V(a096) * k6[i] + V(a097) * k7[i] + V(a098) * k8[i]);
-                f(fctx, t + dt, tmp, k9);
-                for (int i = 0; i < nz; ++i)
-                    tmp[i] = uprev[i] + dt * (V(a101) * k1[i] + V(a103) * k3[i] + V(a104) * k4[i] + V(a105) * k5[i] +
-                                              V(a106) * k6[i] + V(a107) * k7[i]);
-                f(fctx, t + dt, tmp, k10);
-                nf += 10;
-                for (int i = 0; i < nz; ++i)
-                    u[i] = uprev[i] + dt * (V(b1) * k1[i] + V(b4) * k4[i] + V(b5) * k5[i] + V(b6) * k6[i] +
-                                            V(b7) * k7[i] + V(b8) * k8[i] + V(b9) * k9[i]);
-                for (int i = 0; i < nz; ++i)
-                    utilde[i] = dt * (V(btilde1) * k1[i] + V(btilde4) * k4[i] + V(btilde5) * k5[i] + V(btilde6) * k6[i] +
-                                      V(btilde7) * k7[i] + V(btilde8) * k8[i] + V(btilde9) * k9[i] + V(btilde10) * k10[i]);
-#undef V
+            /* ---- perform_step! (table-driven; ARITH-SPEC fma chains) ---- */
+            {
+                const int S = alg == UDEO_ALG_TSIT5 ? 7 : 10;
+                if (alg == UDEO_ALG_VERN7) f(fctx, t, uprev, kk[0]); /* not FSAL */
+                for (int sidx = 1; sidx < S; ++sidx) {
+                    const REAL* row = alg == UDEO_ALG_TSIT5 ? A5[sidx] : A7[sidx];
+                    REAL* dst = (alg == UDEO_ALG_TSIT5 && sidx == S - 1) ? u : tmp;
+                    FN(combine)(row, sidx, kk, dt, uprev, nz, dst);
+                    f(fctx, t + Ctab[sidx] * dt, dst, kk[sidx]);
+                }
+                nf += alg == UDEO_ALG_TSIT5 ? 6 : 10;
+                if (alg == UDEO_ALG_VERN7) FN(combine)(Btab, S, kk, dt, uprev, nz, u);
+                for (int i = 0; i < nz; ++i) {
+                    REAL acc = 0;
+                    int first = 1;
+                    for (int j = 0; j < S; ++j) {
+                        if (BTtab[j] == 0) continue;
+                        acc = first ? BTtab[j] * kk[j][i] : R_FMA(BTtab[j], kk[j][i], acc);
+                        first = 0;
+                    }
+                    utilde[i] = dt * acc;
+                }
             }
             /* calculate_residuals + ODE_DEFAULT_NORM (DiffEqBase) */
             REAL s = 0;
             for (int i = 0; i < nz; ++i) {
                 const REAL a0 = R_FABS(uprev[i]), a1 = R_FABS(u[i]);
-                const REAL res = utilde[i] / (r->abstol + (a0 > a1 ? a0 : a1) * r->reltol);
-                s += res * res;
+                const REAL res = utilde[i] / R_FMA((a0 > a1 ? a0 : a1), r->reltol, r->abstol);
+                s = R_FMA(res, res, s);
             }
             const REAL EEst = R_SQRT(s / (REAL)nz);
             /* ---- loopfooter!: stepsize_controller! (PIController) ---- */
@@ -812,7 +814,7 @@ static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const
         for (int i = 0; i < ns; ++i)
             for (int c = 0; c < n; ++c) {
                 const REAL e = (mask && !mask[c]) ? (REAL)0 : pred[(size_t)i * n + c] - data[(size_t)i * n + c];
-                L += e * e;
+                L = R_FMA(e, e, L);
                 cot[(size_t)i * n + c] = (REAL)2 * e;
             }
         if (loss_out) *loss_out = L;

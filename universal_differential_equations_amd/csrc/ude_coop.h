@@ -30,6 +30,28 @@ __device__ __forceinline__ double group_sum(double x) {
     return x;
 }
 
+// double-double accumulation (two-sum): order-independent sums for the initial-dt norms (ARITH-SPEC)
+__device__ __forceinline__ void dd_acc(double& hi, double& lo, double x) {
+    const double s = hi + x;
+    const double bb = s - hi;
+    const double e = (hi - (s - bb)) + (x - bb);
+    hi = s;
+    lo += e;
+}
+// combine the (hi, lo) pairs of the G lanes of a group; every lane ends with the same pair
+template <int G>
+__device__ __forceinline__ void group_dd_sum(double& hi, double& lo) {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) {
+        const double h2 = __shfl_xor(hi, m, G), l2 = __shfl_xor(lo, m, G);
+        const double s = hi + h2;
+        const double bb = s - hi;
+        const double e = (hi - (s - bb)) + (h2 - bb);
+        lo = (lo + l2) + e;
+        hi = s;
+    }
+}
+
 template <int... V>
 struct IntList {
     static constexpr int n = sizeof...(V);

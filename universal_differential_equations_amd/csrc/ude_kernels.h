@@ -53,6 +53,7 @@ struct KParams {
     double* trace;      // [2][trace_cap][5] or null
     int64_t trace_traj;
     int32_t trace_cap;
+    const struct TabDev* tab;  // tableau of the algorithm (device memory)
 };
 
 __device__ __forceinline__ double ulp_of(double x) {
@@ -61,92 +62,155 @@ __device__ __forceinline__ double ulp_of(double x) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tableau in memory: the stage loop is a RUNTIME loop (one inlined copy of the right-hand side instead
+// of one per stage -- the fully unrolled kernels were ~100 KB of code, beyond the instruction cache), so
+// coefficients are read with a wave-uniform index from this table (scalar loads).
+// Rows 0..S-1: a_sj; rows S..S+NEXTRA-1: the lazy dense-output stages.
+// ARITH-SPEC: every weighted sum is an fma chain in ascending stage order started by the product with the
+// (always nonzero) first coefficient; zero coefficients contribute fma(0, k, acc) == acc exactly, so the
+// value equals the oracle's skip-zeros chain (oracle/ude_oracle_impl.h: combine()).
+// ---------------------------------------------------------------------------------------------
+struct TabDev {
+    double A[16][16];
+    double B[16], BT[16], C[16];
+};
+
+template <class Tab>
+inline TabDev make_tabdev() {
+    TabDev t{};
+    for (int s = 0; s < Tab::S; ++s) {
+        for (int j = 0; j < s; ++j) t.A[s][j] = Tab::A(s, j);
+        t.B[s] = Tab::B(s);
+        t.BT[s] = Tab::BT(s);
+        t.C[s] = Tab::C(s);
+    }
+    for (int e = 0; e < Tab::NEXTRA; ++e) {
+        for (int j = 0; j < Tab::S + e; ++j) t.A[Tab::S + e][j] = Tab::AE(e, j);
+        t.C[Tab::S + e] = Tab::CE(e);
+    }
+    return t;
+}
+
+template <class Tab>
+struct RowDense { static constexpr double at(int q) { return Tab::dense_uses(q) ? 1.0 : 0.0; } };
+
+// sum_j v1(j) * v2(j) over the j with Row::at(j) != 0, j ascending (compile-time indices)
+template <class Row, int N, class V1, class V2>
+__device__ __forceinline__ double chain2(V1 v1, V2 v2) {
+    double acc = 0.0;
+    bool first = true;
+    static_for<0, N>([&](auto j) {
+        constexpr int jj = decltype(j)::value;
+        if constexpr (Row::at(jj) != 0.0) {
+            acc = first ? v1(j) * v2(j) : __builtin_fma(v1(j), v2(j), acc);
+            first = false;
+        }
+    });
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic driver
 // ---------------------------------------------------------------------------------------------
-template <class Tab, class Sys, int G>
+template <class Tab, class Sys, int G, int BLOCK>
 struct Driver {
     static constexpr int NR = Sys::NR, NSL = Sys::NSL, NSLA = NSL > 0 ? NSL : 1;
     static constexpr int S = Tab::S, NK = Tab::NK;
     static constexpr bool USE_FSAL = Tab::FSAL && !Sys::ALWAYS_K0;
+    static constexpr int LDS_DOUBLES_PER_THREAD = NK * NR + NSL;  // stage derivatives + slot state
 
     struct Stats {
         int64_t nf = 0, nacc = 0, nrej = 0, nlazy = 0;
     };
 
-    // z: replicated state; mu: slot state.  Integrates from t0 along tdir through sys' tstops.
-    static __device__ __forceinline__ int run(Sys& sys, const Opts& o, double (&z)[NR], double (&mu)[NSLA],
-                                              double t0, double tdir, double inv_ntot, Stats& st) {
-        double k[NK][NR];
+    // Per-thread LDS arrays (element i of this thread at base[i * BLOCK]: conflict-free):
+    //   kl: stage derivatives of the replicated part, k(j, c) = kl[(j*NR + c) * BLOCK]
+    //   mu: slot state (touched once per step)
+    // z: replicated state (registers).  Integrates from t0 along tdir through sys' tstops.
+    static __device__ __forceinline__ int run(Sys& sys, const Opts& o, const TabDev* __restrict__ tab, double (&z)[NR],
+                                              double* kl, double* mu, double t0, double tdir, double ntot, Stats& st) {
         double accb[NSLA], acce[NSLA];
         double t = t0, dt, qold = o.qoldinit, q11 = 1.0;
         bool accept = true, done = false;
         int iter = 0, ret = RET_SUCCESS;
         double tstop = sys.first_tstop();
+        auto K = [&](int j, int c) -> double& { return kl[(j * NR + c) * BLOCK]; };
 
         // ---- initial dt (ode_determine_initdt), 2 evals ----
         if (o.dt0 > 0.0) {
             dt = tdir * o.dt0;
             if constexpr (USE_FSAL) {
-                double gs[NSLA];
-                sys.eval(t, z, k[0], gs);
+                double kr[NR], gs[NSLA];
+                sys.eval(t, z, kr, gs);
+                static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
             }
             if constexpr (Tab::FSAL) st.nf += 1;
         } else {
-            double gs0[NSLA], f1[NR], gs1[NSLA], z1[NR];
-            sys.eval(t, z, k[0], gs0);
-            double s0 = 0.0, s1 = 0.0;
-            static_for<0, NR>([&](auto c) {
-                const double sk = o.abstol + fabs(z[c]) * o.reltol;
-                const double q0 = z[c] / sk, q1 = k[0][c] / sk;
-                s0 += q0 * q0;
-                s1 += q1 * q1;
-            });
+            double f0[NR], gs0[NSLA], f1[NR], gs1[NSLA], z1[NR];
+            sys.eval(t, z, f0, gs0);
+            static_for<0, NR>([&](auto c) { K(0, c) = f0[c]; });
+            // norms in double-double: slots first (lane-parallel), then the replicated components once
+            double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
             if constexpr (NSL > 0) {
-                double p0 = 0.0, p1 = 0.0;
                 static_for<0, NSL>([&](auto c) {
-                    const double sk = o.abstol + fabs(mu[c]) * o.reltol;
-                    const double q0 = mu[c] / sk, q1 = gs0[c] / sk;
-                    p0 += q0 * q0;
-                    p1 += q1 * q1;
+                    const double m = mu[c * BLOCK];
+                    const double sk = __builtin_fma(fabs(m), o.reltol, o.abstol);
+                    const double q0 = m / sk, q1 = gs0[c] / sk;
+                    dd_acc(h0, l0, q0 * q0);
+                    dd_acc(h1, l1, q1 * q1);
                 });
-                s0 += group_sum<G>(p0);
-                s1 += group_sum<G>(p1);
+                group_dd_sum<G>(h0, l0);
+                group_dd_sum<G>(h1, l1);
             }
-            const double d0 = sqrt(s0 * inv_ntot), d1 = sqrt(s1 * inv_ntot);
+            static_for<0, NR>([&](auto c) {
+                const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
+                const double q0 = z[c] / sk, q1 = f0[c] / sk;
+                dd_acc(h0, l0, q0 * q0);
+                dd_acc(h1, l1, q1 * q1);
+            });
+            const double s0 = h0 + l0, s1 = h1 + l1;
+            const double d0 = sqrt(s0 / ntot), d1 = sqrt(s1 / ntot);
             if (d1 != d1) {
                 ret = RET_UNSTABLE;
                 done = true;
             }
             double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : (d0 / d1) / 100.0;
-            dt0 = fmin(dt0, o.dtmax);
+            if (dt0 > o.dtmax) dt0 = o.dtmax;
             if (dt0 < 10.0 * 2.220446049250313e-16) {
                 dt = tdir * 1e-6;
             } else {
                 const double dt0t = tdir * dt0;
-                static_for<0, NR>([&](auto c) { z1[c] = z[c] + dt0t * k[0][c]; });
+                static_for<0, NR>([&](auto c) { z1[c] = __builtin_fma(dt0t, f0[c], z[c]); });
                 // (the slot part of u1 does not enter f: mu' is independent of mu)
                 sys.eval(t + dt0t, z1, f1, gs1);
-                double s2 = 0.0;
-                static_for<0, NR>([&](auto c) {
-                    const double sk = o.abstol + fabs(z[c]) * o.reltol;
-                    const double q = (f1[c] - k[0][c]) / sk;
-                    s2 += q * q;
-                });
+                double h2 = 0.0, l2 = 0.0;
                 if constexpr (NSL > 0) {
-                    double p2 = 0.0;
                     static_for<0, NSL>([&](auto c) {
-                        const double sk = o.abstol + fabs(mu[c]) * o.reltol;
+                        const double sk = __builtin_fma(fabs(mu[c * BLOCK]), o.reltol, o.abstol);
                         const double q = (gs1[c] - gs0[c]) / sk;
-                        p2 += q * q;
+                        dd_acc(h2, l2, q * q);
                     });
-                    s2 += group_sum<G>(p2);
+                    group_dd_sum<G>(h2, l2);
                 }
-                const double d2 = sqrt(s2 * inv_ntot) / dt0;
-                const double mx = fmax(d1, d2);
+                static_for<0, NR>([&](auto c) {
+                    const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
+                    const double q = (f1[c] - f0[c]) / sk;
+                    dd_acc(h2, l2, q * q);
+                });
+                const double s2 = h2 + l2;
+                const double d2 = sqrt(s2 / ntot) / dt0;
+                const double mx = d1 > d2 ? d1 : d2;
                 double dt1;
-                if (mx <= 1e-15) dt1 = fmax(1e-6, dt0 * 1e-3);
-                else dt1 = pow(10.0, -(2.0 + log10(mx)) / (double)Tab::ORDER);
-                dt = tdir * fmin(fmin(100.0 * dt0, dt1), o.dtmax);
+                if (mx <= 1e-15) {
+                    dt1 = dt0 * 1e-3;
+                    if (dt1 < 1e-6) dt1 = 1e-6;
+                } else {
+                    dt1 = dpow10(-(2.0 + dlog10(mx)) / (double)Tab::ORDER);
+                }
+                double d = 100.0 * dt0;
+                if (dt1 < d) d = dt1;
+                if (o.dtmax < d) d = o.dtmax;
+                dt = tdir * d;
             }
             st.nf += 2;
             if constexpr (Tab::FSAL) st.nf += 1;  // initialize!: fsalfirst = f(u0) (same value, reused)
@@ -154,7 +218,12 @@ struct Driver {
 
         while (!done) {
             // ---- loopheader! ----
-            if (iter > 0 && !accept) dt = dt / fmin(1.0 / o.qmin, q11 / o.gamma);  // step_reject_controller!
+            if (iter > 0 && !accept) {  // step_reject_controller!
+                double den = q11 / o.gamma;
+                const double iq = 1.0 / o.qmin;
+                if (iq < den) den = iq;
+                dt = dt / den;
+            }
             iter += 1;
             if (fabs(dt) > o.dtmax) dt = tdir * o.dtmax;
             {
@@ -165,64 +234,67 @@ struct Driver {
             if (dt != dt) { ret = RET_UNSTABLE; break; }
             if (fabs(dt) <= 2.220446049250313e-16 * fabs(t) && fabs(dt) < fabs(tstop - t)) { ret = RET_DTLESSTHANMIN; break; }
 
-            // ---- perform_step! ----
-            {
-                double gs[NSLA];
-                if constexpr (!USE_FSAL) sys.eval(t, z, k[0], gs);
-                else if constexpr (NSL > 0) sys.fsal_slots(gs);
-                static_for<0, NSL>([&](auto c) {
-                    accb[c] = (dt * Tab::B(0)) * gs[c];
-                    acce[c] = (dt * Tab::BT(0)) * gs[c];
-                });
-            }
+            // ---- perform_step!: runtime stage loop (wave-uniform s) ----
             double znew[NR];
-            static_for<1, S>([&](auto sc) {
-                constexpr int s = sc;
-                double zs[NR], gs[NSLA];
-                static_for<0, NR>([&](auto c) {
-                    double acc = 0.0;
-                    static_for<0, s>([&](auto j) {
-                        if constexpr (Tab::A(s, j) != 0.0) acc += Tab::A(s, j) * k[j][c];
+            for (int s = USE_FSAL ? 1 : 0; s < S; ++s) {
+                double zs[NR], kr[NR], gs[NSLA];
+                if (s == 0) {
+                    static_for<0, NR>([&](auto c) { zs[c] = z[c]; });
+                } else {
+                    static_for<0, NR>([&](auto c) {
+                        double acc = tab->A[s][0] * K(0, c);
+                        for (int j = 1; j < s; ++j) acc = __builtin_fma(tab->A[s][j], K(j, c), acc);
+                        zs[c] = __builtin_fma(dt, acc, z[c]);
                     });
-                    zs[c] = z[c] + dt * acc;
-                });
-                if constexpr (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
-                sys.eval(t + Tab::C(s) * dt, zs, k[s], gs);
-                static_for<0, NSL>([&](auto c) {
-                    if constexpr (Tab::B(s) != 0.0) accb[c] = __builtin_fma(dt * Tab::B(s), gs[c], accb[c]);
-                    if constexpr (Tab::BT(s) != 0.0) acce[c] = __builtin_fma(dt * Tab::BT(s), gs[c], acce[c]);
-                });
-                if constexpr (USE_FSAL && NSL > 0 && s == S - 1) sys.store_fsal_slots(gs);
-            });
+                }
+                if (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
+                sys.eval(t + tab->C[s] * dt, zs, kr, gs);
+                static_for<0, NR>([&](auto c) { K(s, c) = kr[c]; });
+                if constexpr (NSL > 0) {
+                    const double bs = tab->B[s], es = tab->BT[s];
+                    if (s == 0) {
+                        static_for<0, NSL>([&](auto c) {
+                            accb[c] = bs * gs[c];
+                            acce[c] = es * gs[c];
+                        });
+                    } else {
+                        static_for<0, NSL>([&](auto c) {
+                            accb[c] = __builtin_fma(bs, gs[c], accb[c]);
+                            acce[c] = __builtin_fma(es, gs[c], acce[c]);
+                        });
+                    }
+                }
+            }
             st.nf += Tab::FSAL ? S - 1 : S;
             if constexpr (!Tab::FSAL) {
                 static_for<0, NR>([&](auto c) {
-                    double acc = 0.0;
-                    static_for<0, S>([&](auto j) {
-                        if constexpr (Tab::B(j) != 0.0) acc += Tab::B(j) * k[j][c];
-                    });
-                    znew[c] = z[c] + dt * acc;
+                    double acc = tab->B[0] * K(0, c);
+                    for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->B[j], K(j, c), acc);
+                    znew[c] = __builtin_fma(dt, acc, z[c]);
                 });
             }
             // calculate_residuals + ODE_DEFAULT_NORM
             double ss = 0.0;
             static_for<0, NR>([&](auto c) {
-                double acc = 0.0;
-                static_for<0, S>([&](auto j) {
-                    if constexpr (Tab::BT(j) != 0.0) acc += Tab::BT(j) * k[j][c];
-                });
-                const double res = (dt * acc) / (o.abstol + fmax(fabs(z[c]), fabs(znew[c])) * o.reltol);
-                ss += res * res;
+                double acc = tab->BT[0] * K(0, c);
+                for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->BT[j], K(j, c), acc);
+                const double a0 = fabs(z[c]), a1 = fabs(znew[c]);
+                const double res = (dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
+                ss = __builtin_fma(res, res, ss);
             });
             if constexpr (NSL > 0) {
                 double ps = 0.0;
                 static_for<0, NSL>([&](auto c) {
-                    const double res = acce[c] / (o.abstol + fmax(fabs(mu[c]), fabs(mu[c] + accb[c])) * o.reltol);
-                    ps += res * res;
+                    const double m0 = mu[c * BLOCK];
+                    const double m1 = __builtin_fma(dt, accb[c], m0);
+                    accb[c] = m1;  // candidate new value
+                    const double a0 = fabs(m0), a1 = fabs(m1);
+                    const double res = (dt * acce[c]) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
+                    ps = __builtin_fma(res, res, ps);
                 });
                 ss += group_sum<G>(ps);
             }
-            const double EEst = sqrt(ss * inv_ntot);
+            const double EEst = sqrt(ss / ntot);
 
             // ---- loopfooter!: PIController ----
             double q;
@@ -232,18 +304,22 @@ struct Driver {
                 q11 = fastpow(EEst, o.beta1);
                 q = q11 / fastpow(qold, o.beta2);
                 q = q / o.gamma;
-                q = fmin(q, 1.0 / o.qmin);  // NaN-safe ordering not needed: NaN EEst is rejected below
-                q = fmax(q, 1.0 / o.qmax);
+                const double lo = 1.0 / o.qmax, hi = 1.0 / o.qmin;
+                if (q > hi) q = hi;
+                if (q < lo) q = lo;
             }
             accept = (EEst <= 1.0);
             sys.trace(iter, t, dt, EEst, q, accept);
             if (accept) {
                 st.nacc += 1;
-                qold = fmax(EEst, o.qoldinit);
+                qold = EEst > o.qoldinit ? EEst : o.qoldinit;
                 double dtnew = dt / q;
                 const double tprev = t;
                 const double ttmp = t + dt;
-                t = fabs(ttmp - tstop) < 100.0 * ulp_of(fmax(t, tstop)) ? tstop : ttmp;
+                {
+                    const double mxt = t > tstop ? t : tstop;
+                    t = fabs(ttmp - tstop) < 100.0 * ulp_of(mxt) ? tstop : ttmp;
+                }
                 if (fabs(dtnew) > o.dtmax) dtnew = tdir * o.dtmax;
                 // hook: saveat interpolation / dense store (forward); may build the lazy stages
                 {
@@ -251,24 +327,23 @@ struct Driver {
                     auto lazy = [&]() {
                         if constexpr (Tab::NEXTRA > 0) {
                             if (!lazy_done) {
-                                static_for<0, Tab::NEXTRA>([&](auto ec) {
-                                    constexpr int e = ec;
-                                    double zs[NR], gs[NSLA];
+                                for (int e = 0; e < Tab::NEXTRA; ++e) {
+                                    double zs[NR], kr[NR], gs[NSLA];
+                                    const int row = S + e;
                                     static_for<0, NR>([&](auto c) {
-                                        double acc = 0.0;
-                                        static_for<0, S + e>([&](auto j) {
-                                            if constexpr (Tab::AE(e, j) != 0.0) acc += Tab::AE(e, j) * k[j][c];
-                                        });
-                                        zs[c] = z[c] + dt * acc;
+                                        double acc = tab->A[row][0] * K(0, c);
+                                        for (int j = 1; j < row; ++j) acc = __builtin_fma(tab->A[row][j], K(j, c), acc);
+                                        zs[c] = __builtin_fma(dt, acc, z[c]);
                                     });
-                                    sys.eval(tprev + Tab::CE(e) * dt, zs, k[S + e], gs);
-                                });
+                                    sys.eval(tprev + tab->C[row] * dt, zs, kr, gs);
+                                    static_for<0, NR>([&](auto c) { K(row, c) = kr[c]; });
+                                }
                                 lazy_done = true;
                                 st.nlazy += Tab::NEXTRA;
                             }
                         }
                     };
-                    const int hr = sys.accepted(tprev, t, dt, z, znew, k, lazy);
+                    const int hr = sys.accepted(tprev, t, dt, z, znew, kl, lazy);
                     if (hr != RET_SUCCESS) { ret = hr; done = true; }
                 }
                 dt = dtnew;
@@ -277,8 +352,8 @@ struct Driver {
                     z[c] = znew[c];
                     bad = bad || (znew[c] != znew[c]);
                 });
-                static_for<0, NSL>([&](auto c) { mu[c] += accb[c]; });
-                if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { k[0][c] = k[S - 1][c]; });
+                static_for<0, NSL>([&](auto c) { mu[c * BLOCK] = accb[c]; });
+                if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
                 if (bad) { ret = RET_UNSTABLE; done = true; }
                 if (t == tstop) {  // handle_tstop! + callbacks
                     const bool modified = sys.at_tstop(t, z);
@@ -287,9 +362,9 @@ struct Driver {
                     else if (modified) {
                         if constexpr (Tab::FSAL) st.nf += 1;  // reset_fsal! after u_modified!
                         if constexpr (USE_FSAL) {
-                            double gs[NSLA];
-                            sys.eval(t, z, k[0], gs);
-                            if constexpr (NSL > 0) sys.store_fsal_slots(gs);
+                            double kr[NR], gs[NSLA];
+                            sys.eval(t, z, kr, gs);
+                            static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
                         }
                     }
                 }
@@ -306,7 +381,7 @@ struct Driver {
 // forward system: model RHS + saveat (savevalues!) + dense store + loss/cotangent
 // dense field layout per step: 0 t_start, 1 t_end, 2..2+NS u_start, then k[q][c]
 // ---------------------------------------------------------------------------------------------
-template <class Model, class Tab, int G>
+template <class Model, class Tab, int G, int BLOCKDIM>
 struct FwdSys {
     static constexpr int NR = Model::NS, NSL = 0;
     static constexpr bool ALWAYS_K0 = false;
@@ -321,7 +396,10 @@ struct FwdSys {
     __device__ __forceinline__ double first_tstop() const { return p->tf; }
     __device__ __forceinline__ bool next_tstop(double&) const { return false; }
     __device__ __forceinline__ bool at_tstop(double, double*) const { return false; }
-    __device__ __forceinline__ void eval(double, const double* z, double* kr, double*) { Model::rhs(mctx, z, kr); }
+    __device__ __forceinline__ void eval(double, const double* z, double* kr, double*) {
+        asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
+        Model::rhs(mctx, z, kr);
+    }
     __device__ __forceinline__ void trace(int iter, double t, double dt, double e, double q, bool acc) const {
         if (p->trace && writer && j == p->trace_traj && iter <= p->trace_cap) {
             double* row = p->trace + (size_t)(iter - 1) * 5;
@@ -342,7 +420,7 @@ struct FwdSys {
             static_for<0, NR>([&](auto c) {
                 const double on = (p->row_mask && !p->row_mask[c]) ? 0.0 : 1.0;
                 const double e = on * (v[c] - d[c]);
-                loss += e * e;
+                loss = __builtin_fma(e, e, loss);
                 if (writer) p->cot[((size_t)i * n + c) * p->Npad + j] = 2.0 * e;
             });
         }
@@ -350,7 +428,8 @@ struct FwdSys {
 
     template <class Lazy>
     __device__ __forceinline__ int accepted(double tprev, double t, double dt, const double* z, const double* znew,
-                                            double (&k)[Tab::NK][NR], Lazy& lazy) {
+                                            const double* kl, Lazy& lazy) {
+        auto k = [&](int q, int c) { return kl[(q * NR + c) * BLOCKDIM]; };
         while (si < p->ns && p->saveat[si] <= t) {
             const double curt = p->saveat[si];
             if (curt != t) {
@@ -359,11 +438,8 @@ struct FwdSys {
                 double b[Tab::NK], y[NR];
                 Tab::bth(th, b);
                 static_for<0, NR>([&](auto c) {
-                    double acc = 0.0;
-                    static_for<0, Tab::NK>([&](auto q) {
-                        if constexpr (Tab::dense_uses(q)) acc += k[q][c] * b[q];
-                    });
-                    y[c] = z[c] + dt * acc;
+                    const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return k(q, c); }, [&](auto q) { return b[q]; });
+                    y[c] = __builtin_fma(dt, acc, z[c]);
                 });
                 save_point(si, y);
             } else {
@@ -381,7 +457,7 @@ struct FwdSys {
                 static_for<0, NR>([&](auto c) { base[(size_t)(2 + c) * p->Npad] = z[c]; });
                 static_for<0, Tab::NK>([&](auto q) {
                     if constexpr (Tab::dense_uses(q))
-                        static_for<0, NR>([&](auto c) { base[(size_t)(2 + NR + q * NR + c) * p->Npad] = k[q][c]; });
+                        static_for<0, NR>([&](auto c) { base[(size_t)(2 + NR + q * NR + c) * p->Npad] = k(q, c); });
                 });
             }
             nsteps += 1;
@@ -400,8 +476,8 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
     const int r = threadIdx.x % G;
     if (gid >= p.N) return;  // whole groups leave together
-    using Sys = FwdSys<Model, Tab, G>;
-    using Drv = Driver<Tab, Sys, G>;
+    using Sys = FwdSys<Model, Tab, G, BLOCK>;
+    using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
     Model::init(sys.mctx, th, p.mc, r);
     sys.p = &p;
@@ -410,14 +486,16 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     sys.si = 0;
     sys.nsteps = 0;
     sys.loss = 0.0;
-    double z[Sys::NR], mu[1] = {0.0};
+    double z[Sys::NR];
+    double* kl = th + ((p.n_param + 1) & ~1) + threadIdx.x;  // per-thread stage derivatives behind theta
+    double* mu = nullptr;                                      // no slot state in the forward pass
     static_for<0, Sys::NR>([&](auto c) { z[c] = p.u0[(size_t)gid * Sys::NR + c]; });
     while (sys.si < p.ns && p.saveat[sys.si] <= p.t0) {  // save_start
         sys.save_point(sys.si, z);
         sys.si += 1;
     }
     typename Drv::Stats st;
-    const int ret = Drv::run(sys, p.o, z, mu, p.t0, 1.0, 1.0 / (double)Sys::NR, st);
+    const int ret = Drv::run(sys, p.o, p.tab, z, kl, mu, p.t0, 1.0, (double)Sys::NR, st);
     if (sys.writer) {
         if (p.stats) {
             int64_t* s = p.stats + (size_t)gid * 8;
@@ -468,17 +546,15 @@ struct AdjSys {
         while (t >= te && sf < nsteps - 1) load_interval(sf + 1);
     }
     __device__ __forceinline__ void eval(double t, const double* lam, double* klam, double* g) {
+        asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
         locate(t);
         const double dtf = te - ts;
         const double th = (t - ts) / dtf;
         double b[Tab::NK], y[NR], dl[NR];
         Tab::bth(th, b);
         static_for<0, NR>([&](auto c) {
-            double acc = 0.0;
-            static_for<0, Tab::NK>([&](auto q) {
-                if constexpr (Tab::dense_uses(q)) acc += ks[q][c] * b[q];
-            });
-            y[c] = us[c] + dtf * acc;
+            const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][c]; }, [&](auto q) { return b[q]; });
+            y[c] = __builtin_fma(dtf, acc, us[c]);
         });
         Model::template vjp<true>(mctx, y, lam, dl, g);
         static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
@@ -515,14 +591,16 @@ struct AdjSys {
         return true;
     }
     template <class Lazy>
-    __device__ __forceinline__ int accepted(double, double, double, const double*, const double*,
-                                            double (&)[Tab::NK][NR], Lazy&) {
+    __device__ __forceinline__ int accepted(double, double, double, const double*, const double*, const double*, Lazy&) {
         return RET_SUCCESS;
     }
 };
 
 template <class Model, class Tab, int G, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) adj_kernel(const KParams p) {
+#ifndef UDE_ADJ_MIN_WAVES
+#define UDE_ADJ_MIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* th = reinterpret_cast<double*>(smem_raw);
     for (int i = threadIdx.x; i < p.n_param; i += BLOCK) th[i] = p.theta[i];
@@ -531,11 +609,14 @@ __global__ void __launch_bounds__(BLOCK) adj_kernel(const KParams p) {
     const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
     const int r = threadIdx.x % G;
     using Sys = AdjSys<Model, Tab, G>;
-    using Drv = Driver<Tab, Sys, G>;
+    using Drv = Driver<Tab, Sys, G, BLOCK>;
     constexpr int NSL = Sys::NSL;
-    double lam[Sys::NR], mu[NSL];
+    // slot state mu lives in LDS behind theta: element c of thread tid at mu_lds[c * BLOCK + tid]
+    double* kl = th + ((p.n_param + 1) & ~1) + threadIdx.x;
+    double* mu_lds = kl + (size_t)Tab::NK * Sys::NR * BLOCK;
+    double lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
-    static_for<0, NSL>([&](auto c) { mu[c] = 0.0; });
+    static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
     const bool in_range = gid < p.N;
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
@@ -557,7 +638,7 @@ __global__ void __launch_bounds__(BLOCK) adj_kernel(const KParams p) {
         sys.load_interval(sys.nsteps - 1);
         sys.at_tstop(p.tf, lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
-        const int ret = Drv::run(sys, p.o, lam, mu, p.tf, -1.0, 1.0 / (double)(Sys::NR + p.n_param), st);
+        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(Sys::NR + p.n_param), st);
         if (r == 0) {
             if (p.stats) {
                 int64_t* s = p.stats + (size_t)gid * 8;
@@ -566,8 +647,10 @@ __global__ void __launch_bounds__(BLOCK) adj_kernel(const KParams p) {
             if (ret != RET_SUCCESS) p.retcode[gid] = ret;
             if (p.grad_u0) static_for<0, Sys::NR>([&](auto c) { p.grad_u0[(size_t)gid * Sys::NR + c] = lam[c]; });
         }
-        if (ret != RET_SUCCESS) static_for<0, NSL>([&](auto c) { mu[c] = 0.0; });  // never poison the batch gradient
+        if (ret != RET_SUCCESS) static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });  // never poison the batch gradient
     }
+    double mu[NSL];
+    static_for<0, NSL>([&](auto c) { mu[c] = mu_lds[c * BLOCK]; });
     // ---- deterministic reduction: groups of a wave (xor butterfly), then one partial row per wave ----
     static_for<0, NSL>([&](auto c) {
         double v = mu[c];

@@ -68,6 +68,72 @@ __device__ __forceinline__ double fastpow(double x, double y) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ARITH-SPEC elementary functions.  The accept/reject sequence of an adaptive solve is chaotic in the
+// last bit of every intermediate (a sliver step in front of a tstop has a pure-rounding-noise error
+// estimate), so the kernels evaluate exp / tanh / log10 / 10^x with a FIXED sequence of IEEE operations
+// (explicit fma, no contraction: the library is compiled with -ffp-contract=off).  The CPU oracle restates
+// the same sequences independently (oracle/ude_oracle.c); tests/test_gpu_parity.py checks bitwise equality.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dexp(double x) {
+    if (x != x) return x;
+    if (x > 709.0) return __builtin_inf();
+    if (x < -745.0) return 0.0;
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-k, 0.6931471803691238, x);
+    r = __builtin_fma(-k, 1.9082149292705877e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+
+__device__ __forceinline__ double dtanh(double x) {
+    if (x != x) return x;
+    const double ax = fabs(x);
+    double t;
+    if (ax < 0.3) {
+        const double z = ax + ax;
+        double p = 1.0;
+#pragma unroll
+        for (int n = 18; n >= 2; --n) p = __builtin_fma(z * (1.0 / (double)n), p, 1.0);
+        const double em = z * p;
+        t = em / (em + 2.0);
+    } else if (ax < 20.0) {
+        const double e = dexp(ax + ax);
+        t = 1.0 - 2.0 / (e + 1.0);
+    } else {
+        t = 1.0;
+    }
+    return x < 0 ? -t : t;
+}
+
+__device__ __forceinline__ double dlog10(double x) {
+    int e;
+    double m = __builtin_frexp(x, &e);
+    if (m < 0.7071067811865476) { m = m + m; e -= 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 23.0;
+#pragma unroll
+    for (int n = 21; n >= 1; n -= 2) p = __builtin_fma(p, s2, 1.0 / (double)n);
+    const double lnm = (s + s) * p;
+    return __builtin_fma((double)e, 0.6931471805599453, lnm) * 0.4342944819032518;
+}
+
+__device__ __forceinline__ double dpow10(double y) { return dexp(y * 2.302585092994046); }
+
+// ---------------------------------------------------------------------------------------------
 // activations (a1): rbf(x) = exp(-x^2) LotkaVolterra/scenario_1.jl:59; tanh seir_exposure.jl:114,
 // Fisher-KPP-CNN.jl:92-94; relu highdim_pde/lambaem.jl
 // ---------------------------------------------------------------------------------------------
@@ -75,16 +141,16 @@ enum { ACT_IDENTITY = 0, ACT_TANH = 1, ACT_RBF = 2, ACT_RELU = 3 };
 
 template <int ACT>
 __device__ __forceinline__ double act_fwd(double z) {
-    if constexpr (ACT == ACT_TANH) return tanh(z);
-    else if constexpr (ACT == ACT_RBF) return exp(-(z * z));
+    if constexpr (ACT == ACT_TANH) return dtanh(z);
+    else if constexpr (ACT == ACT_RBF) return dexp(-(z * z));
     else if constexpr (ACT == ACT_RELU) return z > 0.0 ? z : 0.0;
     else return z;
 }
 // derivative from the pre-activation z and the activation value a
 template <int ACT>
 __device__ __forceinline__ double act_bwd(double z, double a) {
-    if constexpr (ACT == ACT_TANH) return 1.0 - a * a;
-    else if constexpr (ACT == ACT_RBF) return -2.0 * z * a;
+    if constexpr (ACT == ACT_TANH) return __builtin_fma(-a, a, 1.0);
+    else if constexpr (ACT == ACT_RBF) return (-2.0 * z) * a;
     else if constexpr (ACT == ACT_RELU) return z > 0.0 ? 1.0 : 0.0;
     else return 1.0;
 }

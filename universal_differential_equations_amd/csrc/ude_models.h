@@ -84,8 +84,8 @@ struct LvUde {
         typename Mlp::Cache cache;
         double y[2];
         Mlp::forward(c.nn, c.r, u, cache, y);
-        du[0] = c.lin[0] * u[0] + y[0];
-        du[1] = c.lin[1] * u[1] + y[1];
+        du[0] = __builtin_fma(c.lin[0], u[0], y[0]);
+        du[1] = __builtin_fma(c.lin[1], u[1], y[1]);
     }
     template <bool WANT_PARAM>
     static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam,
@@ -94,11 +94,11 @@ struct LvUde {
         double y[2], gx[2];
         Mlp::forward(c.nn, c.r, u, cache, y);
         Mlp::template vjp<WANT_PARAM>(c.nn, c.r, cache, lam, gx, g);
-        dlam[0] = c.lin[0] * lam[0] + gx[0];
-        dlam[1] = c.lin[1] * lam[1] + gx[1];
+        dlam[0] = __builtin_fma(c.lin[0], lam[0], gx[0]);
+        dlam[1] = __builtin_fma(c.lin[1], lam[1], gx[1]);
         if constexpr (WANT_PARAM) {
-            g[Mlp::NSLOT + 0] = c.lead_on[0] * u[0] * lam[0];
-            g[Mlp::NSLOT + 1] = c.lead_on[1] * u[1] * lam[1];
+            g[Mlp::NSLOT + 0] = (c.lead_on[0] * u[0]) * lam[0];
+            g[Mlp::NSLOT + 1] = (c.lead_on[1] * u[1]) * lam[1];
         }
     }
     static __device__ __forceinline__ int slot_index(const ModelConsts& mc, int r, int s) {

@@ -9,6 +9,7 @@ struct Launch {
     void (*adj)(const KParams);
     int nf;  // dense fields per step
     int G, block;
+    int lds_fwd, lds_adj;  // dynamic LDS doubles per thread besides theta (stage derivatives [+ slot state])
 };
 
 constexpr int BLOCK = 64;
@@ -21,6 +22,8 @@ inline Launch make_launch() {
     l.nf = 2 + Model::NS + Tab::NK * Model::NS;
     l.G = G;
     l.block = BLOCK;
+    l.lds_fwd = Tab::NK * Model::NS;
+    l.lds_adj = Tab::NK * Model::NS + Model::NSL;
     return l;
 }
 

@@ -35,14 +35,17 @@ struct Tsit5Tab {  // Tsit5(): LotkaVolterra/scenario_1.jl:191,202,206; FisherKP
     static constexpr double CE(int) { return 0; }
     // dense-output weights b_j(theta), j = 0..6 (free 4th-order interpolant)
     static __device__ __forceinline__ void bth(double th, double* b) {
+        // ARITH-SPEC: Horner with fma (upstream @evalpoly uses muladd)
+#define H3_(p) (th2 * __builtin_fma(th, __builtin_fma(th, T_(p##4), T_(p##3)), T_(p##2)))
         const double th2 = th * th;
-        b[0] = th * (T_(r11) + th * (T_(r12) + th * (T_(r13) + th * T_(r14))));
-        b[1] = th2 * (T_(r22) + th * (T_(r23) + th * T_(r24)));
-        b[2] = th2 * (T_(r32) + th * (T_(r33) + th * T_(r34)));
-        b[3] = th2 * (T_(r42) + th * (T_(r43) + th * T_(r44)));
-        b[4] = th2 * (T_(r52) + th * (T_(r53) + th * T_(r54)));
-        b[5] = th2 * (T_(r62) + th * (T_(r63) + th * T_(r64)));
-        b[6] = th2 * (T_(r72) + th * (T_(r73) + th * T_(r74)));
+        b[0] = th * __builtin_fma(th, __builtin_fma(th, __builtin_fma(th, T_(r14), T_(r13)), T_(r12)), T_(r11));
+        b[1] = H3_(r2);
+        b[2] = H3_(r3);
+        b[3] = H3_(r4);
+        b[4] = H3_(r5);
+        b[5] = H3_(r6);
+        b[6] = H3_(r7);
+#undef H3_
     }
     static constexpr bool dense_uses(int j) { return j < 7; }
 };
@@ -94,14 +97,17 @@ struct Vern7Tab {  // Vern7(): scenario_1.jl:41,84; SEIR_exposure/seir_exposure.
         constexpr double c[6] = {V_(c11), V_(c12), V_(c13), V_(c14), V_(c15), V_(c16)};
         return c[e];
     }
-#define P6_(p) (th * th * (V_(p##2) + th * (V_(p##3) + th * (V_(p##4) + th * (V_(p##5) + th * (V_(p##6) + th * V_(p##7)))))))
+#define F_ __builtin_fma
+#define P6_(p) (th2 * F_(th, F_(th, F_(th, F_(th, F_(th, V_(p##7), V_(p##6)), V_(p##5)), V_(p##4)), V_(p##3)), V_(p##2)))
     static __device__ __forceinline__ void bth(double th, double* b) {
-        b[0] = th * (V_(r011) + th * (V_(r012) + th * (V_(r013) + th * (V_(r014) + th * (V_(r015) + th * (V_(r016) + th * V_(r017)))))));
+        const double th2 = th * th;
+        b[0] = th * F_(th, F_(th, F_(th, F_(th, F_(th, F_(th, V_(r017), V_(r016)), V_(r015)), V_(r014)), V_(r013)), V_(r012)), V_(r011));
         b[1] = 0; b[2] = 0; b[9] = 0;
         b[3] = P6_(r04); b[4] = P6_(r05); b[5] = P6_(r06); b[6] = P6_(r07); b[7] = P6_(r08); b[8] = P6_(r09);
         b[10] = P6_(r11); b[11] = P6_(r12); b[12] = P6_(r13); b[13] = P6_(r14); b[14] = P6_(r15); b[15] = P6_(r16);
     }
 #undef P6_
+#undef F_
     static constexpr bool dense_uses(int j) { return !(j == 1 || j == 2 || j == 9); }
 };
 #undef V_

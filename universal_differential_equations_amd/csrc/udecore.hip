@@ -41,6 +41,25 @@ __global__ void fastpow_kernel(const double* x, const double* y, double* out, in
     if (i < n) out[i] = fastpow(x[i], y[i]);
 }
 
+// ARITH-SPEC primitives evaluated on the device, for bitwise comparison with the oracle
+__global__ void math_kernel(int op, const double* x, const double* y, double* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x[i], b = y[i];
+    double r;
+    switch (op) {
+        case 0: r = fastpow(a, b); break;
+        case 1: r = dexp(a); break;
+        case 2: r = dtanh(a); break;
+        case 3: r = dlog10(a); break;
+        case 4: r = dpow10(a); break;
+        case 5: r = sqrt(a); break;
+        case 6: r = a / b; break;
+        default: r = __builtin_fma(a, b, a); break;
+    }
+    out[i] = r;
+}
+
 }  // namespace ude
 
 struct DevBuf {
@@ -56,7 +75,7 @@ struct ude_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/end, bwd start/end
     bool ev_fwd = false, ev_bwd = false;
     // workspaces (grow on demand, reused across calls)
-    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace;
+    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs;
     int64_t trace_traj = -1;
     int32_t trace_cap = 0;
     // staging for the host-buffer entry points
@@ -203,6 +222,15 @@ extern "C" int ude_create(int32_t device_id, ude_ctx** out) {
             delete c;
             return UDE_ERR_HIP;
         }
+    {   // tableaux in device memory: [0] Tsit5, [1] Vern7
+        TabDev host[2] = {make_tabdev<Tsit5Tab>(), make_tabdev<Vern7Tab>()};
+        if (hipMalloc(&c->tabs.p, sizeof host) != hipSuccess ||
+            hipMemcpy(c->tabs.p, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) {
+            delete c;
+            return UDE_ERR_HIP;
+        }
+        c->tabs.cap = sizeof host;
+    }
     *out = c;
     return UDE_OK;
 }
@@ -211,7 +239,7 @@ extern "C" void ude_destroy(ude_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace,
+    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs,
                       &c->s_u0, &c->s_theta, &c->s_saveat, &c->s_out, &c->s_data, &c->s_mask, &c->s_gtheta,
                       &c->s_gu0, &c->s_loss, &c->s_lpt, &c->s_stats, &c->s_ret};
     for (DevBuf* b : bufs)
@@ -298,6 +326,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
+    p.tab = (const TabDev*)c->tabs.p + (o->alg == UDE_ALG_VERN7 ? 1 : 0);
     if (c->trace_cap > 0) { p.trace = (double*)c->trace.p; p.trace_traj = c->trace_traj; p.trace_cap = c->trace_cap; }
     p.N = N;
     p.Npad = N;
@@ -314,7 +343,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     p.retcode = retcode;
     const int64_t threads = N * G;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
-    const size_t shmem = sizeof(double) * (size_t)(m->n_param > 0 ? m->n_param : 1);
+    const size_t shmem = sizeof(double) * (size_t)(((m->n_param + 1) & ~1) + l.lds_fwd * BLOCK);
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
     HIPCHK(c, hipGetLastError());
@@ -340,6 +369,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
+    p.tab = (const TabDev*)c->tabs.p + (o->alg == UDE_ALG_VERN7 ? 1 : 0);
     if (c->trace_cap > 0) { p.trace = (double*)c->trace.p; p.trace_traj = c->trace_traj; p.trace_cap = c->trace_cap; }
     const int n = m->n_state, np = m->n_param;
     const int cap = c->lo.max_dense_steps > 0 ? c->lo.max_dense_steps : 256;
@@ -378,14 +408,15 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.loss_traj = loss_per_traj ? loss_per_traj : (double*)c->loss_traj.p;
     p.grad_part = (double*)c->grad_part.p;
     p.grad_u0 = grad_u0;
-    const size_t shmem = sizeof(double) * (size_t)np;
+    const size_t shmem_f = sizeof(double) * (size_t)(((np + 1) & ~1) + l.lds_fwd * BLOCK);
+    const size_t shmem_a = sizeof(double) * (size_t)(((np + 1) & ~1) + l.lds_adj * BLOCK);
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, sizeof(double) * (size_t)nwaves * np, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
+    hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(l.adj, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
+    hipLaunchKernelGGL(l.adj, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->ev_fwd = c->ev_bwd = true;
@@ -535,6 +566,22 @@ extern "C" int ude_loss_grad_ensemble(ude_ctx* c, const ude_model_desc* m, const
     if (c && !data) return fail(c, UDE_ERR_INVALID, "data is null");
     return grad_host(c, m, o, N, u0, tspan, theta, saveat, ns, nullptr, data, row_mask, loss, loss_per_traj, u_out,
                      grad_theta, grad_u0, stats, retcode);
+}
+
+extern "C" int ude_math_dev(ude_ctx* c, int32_t op, int64_t n, const double* x, const double* y, double* out) {
+    if (!c || !x || !y || !out || n <= 0) return UDE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    void *dx, *dy;
+    if ((rc = up(c, c->s_u0, x, sizeof(double) * n, &dx))) return rc;
+    if ((rc = up(c, c->s_data, y, sizeof(double) * n, &dy))) return rc;
+    if ((rc = ensure(c, c->s_out, sizeof(double) * n))) return rc;
+    hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)op, (const double*)dx,
+                       (const double*)dy, (double*)c->s_out.p, n);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = dn(c, out, c->s_out.p, sizeof(double) * n))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return UDE_OK;
 }
 
 extern "C" int ude_fastpow_dev(ude_ctx* c, int64_t n, const double* x, const double* y, double* out) {

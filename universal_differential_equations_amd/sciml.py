@@ -106,6 +106,14 @@ class Engine:
         self.check(self.L.ude_get_trace(self.h, out.ctypes.data))
         return out
 
+    def math(self, op, x, y=None):
+        """ARITH-SPEC primitive `op` on the device: 0 fastpow, 1 exp, 2 tanh, 3 log10, 4 pow10, 5 sqrt, 6 div, 7 fma(x,y,x)"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(np.broadcast_to(1.0 if y is None else y, x.shape), dtype=np.float64)
+        out = np.empty_like(x)
+        self.check(self.L.ude_math_dev(self.h, op, x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data))
+        return out
+
     def fastpow(self, x, y):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(np.broadcast_to(y, x.shape), dtype=np.float64)
