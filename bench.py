@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--traj", type=int, default=10000, help="trajectories per GPU")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = library default)")
+    ap.add_argument("--waves", type=int, default=0, help="adjoint kernel variant: waves per SIMD (0 = default)")
     ap.add_argument("--alg", default="tsit5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -98,7 +99,7 @@ def main():
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)
     alg = U.Tsit5() if a.alg == "tsit5" else U.Vern7()
     ens = U.DeviceEnsemble(models.ude_dynamics(), alg, (0.0, 3.0), t, u0_d, data=data, lanes_per_traj=a.lanes,
-                           abstol=1e-6, reltol=1e-6)
+                           waves_per_simd=a.waves, abstol=1e-6, reltol=1e-6)
 
     def step():
         g = ens.loss_grad(theta)

@@ -82,7 +82,7 @@ typedef struct {
     int32_t lanes_per_traj;   /* 0 = auto; lanes of a wavefront cooperating on one trajectory (1,2,4,8,...,64) */
     int32_t block_threads;    /* 0 = auto (64) */
     int32_t max_dense_steps;  /* capacity of the dense forward store per trajectory, 0 = 256 */
-    int32_t reserved;
+    int32_t waves_per_simd;   /* 0/1 = default; 2 = adjoint kernel variant register-bounded for 2 waves per SIMD */
 } ude_launch_opts;
 
 /* per-trajectory stats, int64[UDE_NSTATS]:

@@ -144,6 +144,19 @@ double udeo_log10(double x) { /* x > 0, finite (initial-dt heuristic only) */
 
 double udeo_pow10(double y) { return udeo_exp(y * 2.302585092994046); }
 
+double udeo_log(double x) { /* x > 0, finite */
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.7071067811865476) { m = m + m; e -= 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 23.0;
+    for (int n = 21; n >= 1; n -= 2) p = fma(p, s2, 1.0 / (double)n);
+    return fma((double)e, 0.6931471805599453, (s + s) * p);
+}
+
+double udeo_pow(double x, double y) { return udeo_exp(y * udeo_log(x)); } /* x > 0 */
+
 int udeo_num_params(const udeo_model_desc* m) {
     int c = 0;
     for (int l = 0; l < m->n_layers; ++l) c += m->dims[l] * m->dims[l + 1] + m->dims[l + 1];
@@ -161,7 +174,7 @@ static float ulp_f32(float x) { x = fabsf(x); return nextafterf(x, INFINITY) - x
 #define R_SQRT sqrt
 #define R_FABS fabs
 #define R_LOG10 udeo_log10
-#define R_POW pow
+#define R_POW udeo_pow
 #define R_POW10(x) udeo_pow10(x)
 #define R_FMA fma
 #define R_EPS 2.220446049250313e-16

@@ -84,6 +84,8 @@ double udeo_exp(double x);   /* ARITH-SPEC deterministic elementary functions (s
 double udeo_tanh(double x);
 double udeo_log10(double x);
 double udeo_pow10(double y);
+double udeo_log(double x);
+double udeo_pow(double x, double y);
 int udeo_num_params(const udeo_model_desc* m); /* NN parameter count implied by dims */
 
 /* ---- f64 API ---- */

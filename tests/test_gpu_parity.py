@@ -62,6 +62,12 @@ def test_arith_spec_primitives_bitwise_equal_to_oracle():
         f.restype, f.argtypes = C.c_double, [C.c_double]
         ref = np.array([f(float(v)) for v in x])
         assert_bitwise(eng.math(op, x), ref, name)
+    L.udeo_log.restype, L.udeo_log.argtypes = C.c_double, [C.c_double]
+    L.udeo_pow.restype, L.udeo_pow.argtypes = C.c_double, [C.c_double, C.c_double]
+    x = 10.0 ** rng.uniform(-18, 18, 20000)
+    assert_bitwise(eng.math(8, x), np.array([L.udeo_log(float(v)) for v in x]), "udeo_log")
+    xb, yb = rng.uniform(0.9, 1.0, 20000), rng.uniform(1.0, 1200.0, 20000)
+    assert_bitwise(eng.math(9, xb, yb), np.array([L.udeo_pow(float(a_), float(b_)) for a_, b_ in zip(xb, yb)]), "udeo_pow")
     x = 10.0 ** rng.uniform(-200, 200, 40000)
     y = 10.0 ** rng.uniform(-200, 200, 40000) * rng.choice([-1.0, 1.0], 40000)
     assert_bitwise(eng.math(5, x), np.sqrt(x), "sqrt is correctly rounded")
@@ -252,6 +258,55 @@ def test_full_size_ensemble_properties(golden):
     assert_bitwise(full.loss_per_traj[idx], ref["loss_per_traj"], "per-trajectory loss")
     assert_bitwise(full.grad_u0[idx], ref["grad_u0"], "dL/du0")
     assert_bitwise(full.u[idx], ref["u"], "saved states")
+
+
+def seir_inputs(N, seed=3):
+    """SURVEY.md 8(d) C3: u0_j = (f_j*S0, 0,0,0, S0, 0,0), S0 = 14e6, f_j in U(0.8,0.95); tspan (0,21), saveat 0:1:21;
+    data from corona! (seir_exposure.jl:16-37) solved by the engine itself at tol 1e-12."""
+    rng = np.random.default_rng(seed)
+    S0 = 14e6
+    u0 = np.zeros((N, 7))
+    u0[:, 0] = rng.uniform(0.8, 0.95, N) * S0
+    u0[:, 4] = S0
+    t = np.arange(22.0)
+    return u0, t
+
+
+def test_seir_true_matches_oracle():
+    u0, t = seir_inputs(40)
+    ens = U.EnsembleProblem(U.ODEProblem(models.corona(), u0[0], (0.0, 21.0), []), u0)
+    sol = U.solve(ens, U.Vern7(), saveat=t, abstol=1e-12, reltol=1e-12)
+    out, st, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+    assert_bitwise(sol.retcodes, rc, "retcode")
+    assert_bitwise(sol.stats[:, :4], st[:, :4], "counts")
+    assert_bitwise(sol.u, out, "states")
+    assert (rc == 0).all() and out[:, -1, 2].min() > 0          # the epidemic actually develops
+
+
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+def test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg):
+    """dudt_ (seir_exposure.jl:114-147): 3-64-64-1 tanh exposure network, loss on rows 2:4 (E, I, R)."""
+    N = 12
+    u0, t = seir_inputs(N)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+    rng = np.random.default_rng(11)
+    th = models.seir_chain().glorot_uniform(rng)
+    th[-65:-1] *= 10.0      # a larger exposure term (stronger coupling into S and E) without leaving the non-stiff regime
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    f = models.dudt_()
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 21.0), th), u0)
+    sol = U.solve(ens, alg(), saveat=t, abstol=1e-6, reltol=1e-6)
+    out, st, rc = O.solve_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6), u0, [0.0, 21.0], th, t)
+    assert (rc == 0).all()
+    assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts")
+    assert_bitwise(sol.u, out, "forward states")
+    r = U.loss_and_gradient(ens, alg(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6)
+    ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6), u0, [0.0, 21.0], th, t, truth, row_mask=mask, nthreads=4)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+    assert np.linalg.norm(ref["grad_theta"]) > 0
 
 
 def test_failed_trajectory_is_reported_not_summed(golden):

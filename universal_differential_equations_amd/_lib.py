@@ -38,7 +38,7 @@ class SolveOpts(C.Structure):
 class LaunchOpts(C.Structure):
     """ude_launch_opts"""
     _fields_ = [("lanes_per_traj", C.c_int32), ("block_threads", C.c_int32), ("max_dense_steps", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("waves_per_simd", C.c_int32)]
 
 
 class UdeError(RuntimeError):

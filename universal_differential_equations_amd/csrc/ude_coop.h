@@ -12,21 +12,36 @@
 
 namespace ude {
 
+// ---- DPP (data-parallel primitives): cross-lane moves inside the VALU, no LDS round trip -------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <- lane 7-i inside each 8 lanes
+
 // value of x held by lane `src` of this lane's group (src < G is a compile-time constant)
-template <int G>
-__device__ __forceinline__ double group_bcast(double x, int src) {
+template <int G, int SRC>
+__device__ __forceinline__ double group_bcast(double x) {
     if constexpr (G == 1) {
         return x;
+    } else if constexpr (G == 4) {
+        return dpp_mov<DPP_QUAD(SRC, SRC, SRC, SRC)>(x);  // one DPP move per 32-bit half
     } else {
-        return __shfl(x, src, G);
+        return __shfl(x, SRC, G);  // ds_bpermute
     }
 }
 
 // sum over the G lanes of a group; every lane receives the same bits (xor butterfly, commutative adds)
 template <int G>
 __device__ __forceinline__ double group_sum(double x) {
+    if constexpr (G >= 2) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x) : __shfl_xor(x, 1, G);
+    if constexpr (G >= 4) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x) : __shfl_xor(x, 2, G);
+    if constexpr (G >= 8) x += (G == 8) ? dpp_mov<DPP_ROW_HALF_MIRROR>(x) : __shfl_xor(x, 4, G);
 #pragma unroll
-    for (int m = 1; m < G; m <<= 1) x += __shfl_xor(x, m, G);
+    for (int m = 8; m < G; m <<= 1) x += __shfl_xor(x, m, G);
     return x;
 }
 
@@ -128,7 +143,7 @@ struct CoopMlp {
             });
             static_for<0, out>([&](auto jc) {
                 constexpr int j = jc;
-                c.a[l + 1][j] = group_bcast<G>(c.ao[l][j / G], j % G);
+                c.a[l + 1][j] = group_bcast<G, j % G>(c.ao[l][j / G]);
             });
         });
         static_for<0, N::dim(L)>([&](auto k) { y[k] = c.a[L][k]; });
@@ -172,14 +187,14 @@ struct CoopMlp {
             if constexpr (l > 0) {
                 static_for<0, out>([&](auto jc) {
                     constexpr int j = jc;
-                    dall[j] = group_bcast<G>(down[j / G], j % G);
+                    dall[j] = group_bcast<G, j % G>(down[j / G]);
                 });
             } else {
                 // input cotangent: gx[k] = sum_j W0[j,k] delta0[j]; every lane needs it, so gather delta0 too
                 double d0[MAXD];
                 static_for<0, out>([&](auto jc) {
                     constexpr int j = jc;
-                    d0[j] = group_bcast<G>(down[j / G], j % G);
+                    d0[j] = group_bcast<G, j % G>(down[j / G]);
                 });
                 const P* W0 = th + N::off(0);
                 static_for<0, in>([&](auto k) {

@@ -117,7 +117,9 @@ struct Driver {
     static constexpr int NR = Sys::NR, NSL = Sys::NSL, NSLA = NSL > 0 ? NSL : 1;
     static constexpr int S = Tab::S, NK = Tab::NK;
     static constexpr bool USE_FSAL = Tab::FSAL && !Sys::ALWAYS_K0;
-    static constexpr int LDS_DOUBLES_PER_THREAD = NK * NR + NSL;  // stage derivatives + slot state
+    static constexpr bool LDS_SLOTS = Sys::SLOTS_IN_LDS;  // slot state + accumulators are theta-indexed LDS arrays
+    // stage derivatives of a REPLICATED state are stored once per group (all lanes read/write the same word)
+    static constexpr int KSTRIDE = Sys::STATE_DISTRIBUTED ? BLOCK : BLOCK / G;
 
     struct Stats {
         int64_t nf = 0, nacc = 0, nrej = 0, nlazy = 0;
@@ -134,7 +136,7 @@ struct Driver {
         bool accept = true, done = false;
         int iter = 0, ret = RET_SUCCESS;
         double tstop = sys.first_tstop();
-        auto K = [&](int j, int c) -> double& { return kl[(j * NR + c) * BLOCK]; };
+        auto K = [&](int j, int c) -> double& { return kl[(j * NR + c) * KSTRIDE]; };
 
         // ---- initial dt (ode_determine_initdt), 2 evals ----
         if (o.dt0 > 0.0) {
@@ -147,11 +149,23 @@ struct Driver {
             if constexpr (Tab::FSAL) st.nf += 1;
         } else {
             double f0[NR], gs0[NSLA], f1[NR], gs1[NSLA], z1[NR];
-            sys.eval(t, z, f0, gs0);
+            if constexpr (LDS_SLOTS) sys.eval_acc(t, z, f0, 1.0, 0.0, true);  // ab = g0, ae = 0
+            else sys.eval(t, z, f0, gs0);
             static_for<0, NR>([&](auto c) { K(0, c) = f0[c]; });
             // norms in double-double: slots first (lane-parallel), then the replicated components once
             double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
-            if constexpr (NSL > 0) {
+            if constexpr (LDS_SLOTS) {
+                sys.lds_sync();
+                for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) {
+                    const double m = sys.mu[i];
+                    const double sk = __builtin_fma(fabs(m), o.reltol, o.abstol);
+                    const double q0 = m / sk, q1 = sys.ab[i] / sk;
+                    dd_acc(h0, l0, q0 * q0);
+                    dd_acc(h1, l1, q1 * q1);
+                }
+                group_dd_sum<G>(h0, l0);
+                group_dd_sum<G>(h1, l1);
+            } else if constexpr (NSL > 0) {
                 static_for<0, NSL>([&](auto c) {
                     const double m = mu[c * BLOCK];
                     const double sk = __builtin_fma(fabs(m), o.reltol, o.abstol);
@@ -162,12 +176,27 @@ struct Driver {
                 group_dd_sum<G>(h0, l0);
                 group_dd_sum<G>(h1, l1);
             }
-            static_for<0, NR>([&](auto c) {
-                const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
-                const double q0 = z[c] / sk, q1 = f0[c] / sk;
-                dd_acc(h0, l0, q0 * q0);
-                dd_acc(h1, l1, q1 * q1);
-            });
+            if constexpr (Sys::STATE_DISTRIBUTED) {
+                double hs0 = 0.0, ls0 = 0.0, hs1 = 0.0, ls1 = 0.0;
+                static_for<0, NR>([&](auto c) {
+                    const double on = sys.state_on(c);
+                    const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
+                    const double q0 = on * (z[c] / sk), q1 = on * (f0[c] / sk);
+                    dd_acc(hs0, ls0, q0 * q0);
+                    dd_acc(hs1, ls1, q1 * q1);
+                });
+                group_dd_sum<G>(hs0, ls0);
+                group_dd_sum<G>(hs1, ls1);
+                dd_acc(h0, l0, hs0); dd_acc(h0, l0, ls0);
+                dd_acc(h1, l1, hs1); dd_acc(h1, l1, ls1);
+            } else {
+                static_for<0, NR>([&](auto c) {
+                    const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
+                    const double q0 = z[c] / sk, q1 = f0[c] / sk;
+                    dd_acc(h0, l0, q0 * q0);
+                    dd_acc(h1, l1, q1 * q1);
+                });
+            }
             const double s0 = h0 + l0, s1 = h1 + l1;
             const double d0 = sqrt(s0 / ntot), d1 = sqrt(s1 / ntot);
             if (d1 != d1) {
@@ -182,9 +211,19 @@ struct Driver {
                 const double dt0t = tdir * dt0;
                 static_for<0, NR>([&](auto c) { z1[c] = __builtin_fma(dt0t, f0[c], z[c]); });
                 // (the slot part of u1 does not enter f: mu' is independent of mu)
-                sys.eval(t + dt0t, z1, f1, gs1);
+                if constexpr (LDS_SLOTS) sys.eval_acc(t + dt0t, z1, f1, 0.0, 1.0, false);  // ae = g1, ab untouched
+                else sys.eval(t + dt0t, z1, f1, gs1);
                 double h2 = 0.0, l2 = 0.0;
-                if constexpr (NSL > 0) {
+                if constexpr (LDS_SLOTS) {
+                    sys.lds_sync();
+                    for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) {
+                        const double sk = __builtin_fma(fabs(sys.mu[i]), o.reltol, o.abstol);
+                        const double q = (sys.ae[i] - sys.ab[i]) / sk;
+                        dd_acc(h2, l2, q * q);
+                    }
+                    group_dd_sum<G>(h2, l2);
+                    sys.lds_sync();
+                } else if constexpr (NSL > 0) {
                     static_for<0, NSL>([&](auto c) {
                         const double sk = __builtin_fma(fabs(mu[c * BLOCK]), o.reltol, o.abstol);
                         const double q = (gs1[c] - gs0[c]) / sk;
@@ -192,11 +231,22 @@ struct Driver {
                     });
                     group_dd_sum<G>(h2, l2);
                 }
-                static_for<0, NR>([&](auto c) {
-                    const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
-                    const double q = (f1[c] - f0[c]) / sk;
-                    dd_acc(h2, l2, q * q);
-                });
+                if constexpr (Sys::STATE_DISTRIBUTED) {
+                    double hs = 0.0, ls = 0.0;
+                    static_for<0, NR>([&](auto c) {
+                        const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
+                        const double q = sys.state_on(c) * ((f1[c] - f0[c]) / sk);
+                        dd_acc(hs, ls, q * q);
+                    });
+                    group_dd_sum<G>(hs, ls);
+                    dd_acc(h2, l2, hs); dd_acc(h2, l2, ls);
+                } else {
+                    static_for<0, NR>([&](auto c) {
+                        const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
+                        const double q = (f1[c] - f0[c]) / sk;
+                        dd_acc(h2, l2, q * q);
+                    });
+                }
                 const double s2 = h2 + l2;
                 const double d2 = sqrt(s2 / ntot) / dt0;
                 const double mx = d1 > d2 ? d1 : d2;
@@ -248,9 +298,10 @@ struct Driver {
                     });
                 }
                 if (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
-                sys.eval(t + tab->C[s] * dt, zs, kr, gs);
+                if constexpr (LDS_SLOTS) sys.eval_acc(t + tab->C[s] * dt, zs, kr, tab->B[s], tab->BT[s], s == 0);
+                else sys.eval(t + tab->C[s] * dt, zs, kr, gs);
                 static_for<0, NR>([&](auto c) { K(s, c) = kr[c]; });
-                if constexpr (NSL > 0) {
+                if constexpr (NSL > 0 && !LDS_SLOTS) {
                     const double bs = tab->B[s], es = tab->BT[s];
                     if (s == 0) {
                         static_for<0, NSL>([&](auto c) {
@@ -279,10 +330,24 @@ struct Driver {
                 double acc = tab->BT[0] * K(0, c);
                 for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->BT[j], K(j, c), acc);
                 const double a0 = fabs(z[c]), a1 = fabs(znew[c]);
-                const double res = (dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
+                double res = (dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
+                if constexpr (Sys::STATE_DISTRIBUTED) res *= sys.state_on(c);
                 ss = __builtin_fma(res, res, ss);
             });
-            if constexpr (NSL > 0) {
+            if constexpr (Sys::STATE_DISTRIBUTED) ss = group_sum<G>(ss);
+            if constexpr (LDS_SLOTS) {
+                sys.lds_sync();
+                double ps = 0.0;
+                for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) {
+                    const double m0 = sys.mu[i];
+                    const double m1 = __builtin_fma(dt, sys.ab[i], m0);
+                    sys.ab[i] = m1;  // candidate new value
+                    const double a0 = fabs(m0), a1 = fabs(m1);
+                    const double res = (dt * sys.ae[i]) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
+                    ps = __builtin_fma(res, res, ps);
+                }
+                ss += group_sum<G>(ps);
+            } else if constexpr (NSL > 0) {
                 double ps = 0.0;
                 static_for<0, NSL>([&](auto c) {
                     const double m0 = mu[c * BLOCK];
@@ -352,7 +417,13 @@ struct Driver {
                     z[c] = znew[c];
                     bad = bad || (znew[c] != znew[c]);
                 });
-                static_for<0, NSL>([&](auto c) { mu[c * BLOCK] = accb[c]; });
+                if constexpr (Sys::STATE_DISTRIBUTED) bad = __any(bad);  // same decision on every lane of the wave
+                if constexpr (LDS_SLOTS) {
+                    for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) sys.mu[i] = sys.ab[i];
+                    sys.lds_sync();
+                } else {
+                    static_for<0, NSL>([&](auto c) { mu[c * BLOCK] = accb[c]; });
+                }
                 if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
                 if (bad) { ret = RET_UNSTABLE; done = true; }
                 if (t == tstop) {  // handle_tstop! + callbacks
@@ -384,7 +455,7 @@ struct Driver {
 template <class Model, class Tab, int G, int BLOCKDIM>
 struct FwdSys {
     static constexpr int NR = Model::NS, NSL = 0;
-    static constexpr bool ALWAYS_K0 = false;
+    static constexpr bool ALWAYS_K0 = false, SLOTS_IN_LDS = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     static constexpr int NF = 2 + NR + Tab::NK * NR;
     typename Model::Ctx mctx;
     const KParams* p;
@@ -408,6 +479,12 @@ struct FwdSys {
     }
     __device__ __forceinline__ void fsal_slots(double*) {}
     __device__ __forceinline__ void store_fsal_slots(const double*) {}
+    double *mu = nullptr, *ab = nullptr, *ae = nullptr;  // (LDS slot mode is adjoint-only)
+    __device__ __forceinline__ int slot_begin() const { return 0; }
+    __device__ __forceinline__ int slot_end() const { return 0; }
+    __device__ __forceinline__ void lds_sync() const {}
+    __device__ __forceinline__ void eval_acc(double, const double*, double*, double, double, bool) {}
+    __device__ __forceinline__ double state_on(int) const { return 1.0; }
 
     __device__ __forceinline__ void save_point(int i, const double* v) {
         const int n = NR;
@@ -429,7 +506,7 @@ struct FwdSys {
     template <class Lazy>
     __device__ __forceinline__ int accepted(double tprev, double t, double dt, const double* z, const double* znew,
                                             const double* kl, Lazy& lazy) {
-        auto k = [&](int q, int c) { return kl[(q * NR + c) * BLOCKDIM]; };
+        auto k = [&](int q, int c) { return kl[(q * NR + c) * (STATE_DISTRIBUTED ? BLOCKDIM : BLOCKDIM / G)]; };
         while (si < p->ns && p->saveat[si] <= t) {
             const double curt = p->saveat[si];
             if (curt != t) {
@@ -466,11 +543,22 @@ struct FwdSys {
     }
 };
 
+// LDS layout of a block: [theta copy | model scratch | stage derivatives k | slot state]
+template <class Model, class Tab, int G, int BLOCK>
+struct Layout {
+    static constexpr int KSTRIDE = Model::STATE_DISTRIBUTED ? BLOCK : BLOCK / G;
+    static constexpr int K_DOUBLES = Tab::NK * Model::NS * KSTRIDE;
+    static __host__ __device__ constexpr int np_pad(int np) { return (np + 1) & ~1; }
+};
+
 template <class Model, class Tab, int G, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using L = Layout<Model, Tab, G, BLOCK>;
     double* th = reinterpret_cast<double*>(smem_raw);
-    for (int i = threadIdx.x; i < p.n_param; i += BLOCK) th[i] = p.theta[i];
+    double* scratch = th + Model::theta_lds(p.n_param);
+    double* kbase = scratch + Model::SCRATCH;
+    Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     __syncthreads();
 
     const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
@@ -479,7 +567,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     using Sys = FwdSys<Model, Tab, G, BLOCK>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
-    Model::init(sys.mctx, th, p.mc, r);
+    Model::init(sys.mctx, th, scratch, nullptr, 0, p.mc, r);
     sys.p = &p;
     sys.j = gid;
     sys.writer = (r == 0);
@@ -487,8 +575,8 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     sys.nsteps = 0;
     sys.loss = 0.0;
     double z[Sys::NR];
-    double* kl = th + ((p.n_param + 1) & ~1) + threadIdx.x;  // per-thread stage derivatives behind theta
-    double* mu = nullptr;                                      // no slot state in the forward pass
+    double* kl = kbase + (Model::STATE_DISTRIBUTED ? threadIdx.x : threadIdx.x / G);
+    double* mu = nullptr;  // no slot state in the forward pass
     static_for<0, Sys::NR>([&](auto c) { z[c] = p.u0[(size_t)gid * Sys::NR + c]; });
     while (sys.si < p.ns && p.saveat[sys.si] <= p.t0) {  // save_start
         sys.save_point(sys.si, z);
@@ -518,6 +606,7 @@ template <class Model, class Tab, int G>
 struct AdjSys {
     static constexpr int NR = Model::NS, NSL = Model::NSL;
     static constexpr bool ALWAYS_K0 = true;  // stage 0 re-evaluated every step: no FSAL slot storage, uniform flow
+    static constexpr bool SLOTS_IN_LDS = Model::SLOTS_IN_LDS, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     static constexpr int NF = 2 + NR + Tab::NK * NR;
     typename Model::Ctx mctx;
     const KParams* p;
@@ -546,6 +635,7 @@ struct AdjSys {
         while (t >= te && sf < nsteps - 1) load_interval(sf + 1);
     }
     __device__ __forceinline__ void eval(double t, const double* lam, double* klam, double* g) {
+      if constexpr (!SLOTS_IN_LDS) {
         asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
         locate(t);
         const double dtf = te - ts;
@@ -559,6 +649,29 @@ struct AdjSys {
         Model::template vjp<true>(mctx, y, lam, dl, g);
         static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
         static_for<0, NSL>([&](auto c) { g[c] = -g[c]; });
+      }
+    }
+    // ---- LDS slot mode (theta-indexed mu / accumulators shared by the group) ----
+    double *mu, *ab, *ae;
+    int np_, r_;
+    __device__ __forceinline__ int slot_begin() const { return r_; }
+    __device__ __forceinline__ int slot_end() const { return np_; }
+    __device__ __forceinline__ void lds_sync() const { __syncthreads(); }
+    __device__ __forceinline__ void eval_acc(double t, const double* lam, double* klam, double bs, double es, bool first) {
+        if constexpr (SLOTS_IN_LDS) {
+            asm volatile("" ::: "memory");
+            locate(t);
+            const double dtf = te - ts;
+            const double th = (t - ts) / dtf;
+            double b[Tab::NK], y[NR], dl[NR];
+            Tab::bth(th, b);
+            static_for<0, NR>([&](auto c) {
+                const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][c]; }, [&](auto q) { return b[q]; });
+                y[c] = __builtin_fma(dtf, acc, us[c]);
+            });
+            Model::vjp_acc(mctx, y, lam, dl, bs, es, first);
+            static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
+        }
     }
     __device__ __forceinline__ void fsal_slots(double*) {}
     __device__ __forceinline__ void store_fsal_slots(const double*) {}
@@ -569,6 +682,7 @@ struct AdjSys {
         }
     }
 
+    __device__ __forceinline__ double state_on(int) const { return 1.0; }
     __device__ __forceinline__ double tstop_from_cur() const {
         // next save time strictly inside (t0, t) in descending order, else t0
         return (cur >= 0 && p->saveat[cur] > p->t0) ? p->saveat[cur] : p->t0;
@@ -596,14 +710,22 @@ struct AdjSys {
     }
 };
 
-template <class Model, class Tab, int G, int BLOCK>
 #ifndef UDE_ADJ_MIN_WAVES
 #define UDE_ADJ_MIN_WAVES 1
 #endif
+template <class Model, class Tab, int G, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using L = Layout<Model, Tab, G, BLOCK>;
     double* th = reinterpret_cast<double*>(smem_raw);
-    for (int i = threadIdx.x; i < p.n_param; i += BLOCK) th[i] = p.theta[i];
+    double* scratch = th + Model::theta_lds(p.n_param);
+    double* kbase = scratch + Model::SCRATCH;
+    double* slots = kbase + L::K_DOUBLES;
+    const int np_pad = L::np_pad(p.n_param);
+    Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
+    if constexpr (Model::SLOTS_IN_LDS) {
+        for (int i = threadIdx.x; i < 3 * np_pad; i += BLOCK) slots[i] = 0.0;
+    }
     __syncthreads();
 
     const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
@@ -611,9 +733,10 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     using Sys = AdjSys<Model, Tab, G>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     constexpr int NSL = Sys::NSL;
-    // slot state mu lives in LDS behind theta: element c of thread tid at mu_lds[c * BLOCK + tid]
-    double* kl = th + ((p.n_param + 1) & ~1) + threadIdx.x;
-    double* mu_lds = kl + (size_t)Tab::NK * Sys::NR * BLOCK;
+    constexpr int NSLA = NSL > 0 ? NSL : 1;
+    double* kl = kbase + (Model::STATE_DISTRIBUTED ? threadIdx.x : threadIdx.x / G);
+    // register-slot mode: slot state mu of thread tid, element c at mu_lds[c * BLOCK]
+    double* mu_lds = slots + threadIdx.x;
     double lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
     static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
@@ -621,7 +744,9 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         Sys sys;
-        Model::init(sys.mctx, th, p.mc, r);
+        Model::init(sys.mctx, th, scratch, slots, np_pad, p.mc, r);
+        sys.mu = slots; sys.ab = slots + np_pad; sys.ae = slots + 2 * np_pad;
+        sys.np_ = p.n_param; sys.r_ = r;
         sys.p = &p;
         sys.j = gid;
         sys.nsteps = p.dense_n[gid];
@@ -647,9 +772,23 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
             if (ret != RET_SUCCESS) p.retcode[gid] = ret;
             if (p.grad_u0) static_for<0, Sys::NR>([&](auto c) { p.grad_u0[(size_t)gid * Sys::NR + c] = lam[c]; });
         }
-        if (ret != RET_SUCCESS) static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });  // never poison the batch gradient
+        if (ret != RET_SUCCESS) {  // never poison the batch gradient
+            static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
+            if constexpr (Model::SLOTS_IN_LDS) {
+                __syncthreads();
+                for (int i = r; i < p.n_param; i += G) slots[i] = 0.0;
+            }
+        }
     }
-    double mu[NSL];
+    if constexpr (Model::SLOTS_IN_LDS) {
+        // one trajectory per block (G == BLOCK): mu is already the theta-indexed row of this wave
+        __syncthreads();
+        const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64;
+        double* row = p.grad_part + (size_t)wave * p.n_param;
+        for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = slots[i];
+    }
+    if constexpr (!Model::SLOTS_IN_LDS) {
+    double mu[NSLA];
     static_for<0, NSL>([&](auto c) { mu[c] = mu_lds[c * BLOCK]; });
     // ---- deterministic reduction: groups of a wave (xor butterfly), then one partial row per wave ----
     static_for<0, NSL>([&](auto c) {
@@ -670,6 +809,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
                 row[idx] = v;
             }
         }
+    }
     }
 }
 

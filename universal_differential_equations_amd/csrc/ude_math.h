@@ -133,6 +133,20 @@ __device__ __forceinline__ double dlog10(double x) {
 
 __device__ __forceinline__ double dpow10(double y) { return dexp(y * 2.302585092994046); }
 
+// natural log and x^y = exp(y*log(x)) for x > 0 (corona!'s (1 - D/N)^kappa, seir_exposure.jl:30)
+__device__ __forceinline__ double dlog(double x) {
+    int e;
+    double m = __builtin_frexp(x, &e);
+    if (m < 0.7071067811865476) { m = m + m; e -= 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 23.0;
+#pragma unroll
+    for (int n = 21; n >= 1; n -= 2) p = __builtin_fma(p, s2, 1.0 / (double)n);
+    return __builtin_fma((double)e, 0.6931471805599453, (s + s) * p);
+}
+__device__ __forceinline__ double dpow(double x, double y) { return dexp(y * dlog(x)); }
+
 // ---------------------------------------------------------------------------------------------
 // activations (a1): rbf(x) = exp(-x^2) LotkaVolterra/scenario_1.jl:59; tanh seir_exposure.jl:114,
 // Fisher-KPP-CNN.jl:92-94; relu highdim_pde/lambaem.jl

@@ -9,7 +9,15 @@ struct Launch {
     void (*adj)(const KParams);
     int nf;  // dense fields per step
     int G, block;
-    int lds_fwd, lds_adj;  // dynamic LDS doubles per thread besides theta (stage derivatives [+ slot state])
+    // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ slots: NSL*BLOCK registers-mode mu, or 3*np_pad]
+    int theta_lds, scratch, k_doubles, slots_reg;
+    bool slots_lds;
+    size_t lds_bytes(int np, bool adjoint) const {
+        const size_t np_pad = (size_t)((np + 1) & ~1);
+        size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + scratch + k_doubles;
+        if (adjoint) d += slots_lds ? 3 * np_pad : (size_t)slots_reg;
+        return d * sizeof(double) + 16;
+    }
 };
 
 constexpr int BLOCK = 64;
@@ -22,8 +30,11 @@ inline Launch make_launch() {
     l.nf = 2 + Model::NS + Tab::NK * Model::NS;
     l.G = G;
     l.block = BLOCK;
-    l.lds_fwd = Tab::NK * Model::NS;
-    l.lds_adj = Tab::NK * Model::NS + Model::NSL;
+    l.theta_lds = Model::theta_lds(7) == 8 ? -1 : Model::theta_lds(0);
+    l.scratch = Model::SCRATCH;
+    l.k_doubles = Layout<Model, Tab, G, BLOCK>::K_DOUBLES;
+    l.slots_reg = Model::NSL * BLOCK;
+    l.slots_lds = Model::SLOTS_IN_LDS;
     return l;
 }
 
@@ -32,6 +43,6 @@ using NetS1 = NetCfg<IntList<2, 5, 5, 5, 2>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, 
 using NetHudson = NetCfg<IntList<2, 5, 5, 5, 2>, IntList<ACT_RBF, ACT_RBF, ACT_TANH, ACT_IDENTITY>>;  // hudson_bay.jl:77-79
 using NetTanh32 = NetCfg<IntList<2, 32, 2>, IntList<ACT_TANH, ACT_IDENTITY>>;                         // BASELINE C2 "2-layer tanh"
 
-enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32 };
+enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, MID_SEIR_TRUE, MID_SEIR_UDE };
 
 }  // namespace ude

@@ -13,13 +13,20 @@
 using namespace ude;
 
 namespace ude {
-// out[i] = sum_w part[w][i] in fixed order (w ascending): deterministic for a given launch shape
+// out[i] = sum_w part[w][i]: one block per column, fixed strided partial sums + fixed LDS tree
+// (deterministic for a given launch shape; the order is independent of timing)
 __global__ void reduce_rows_kernel(const double* part, int64_t nrows, int32_t ncols, double* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ncols) return;
+    __shared__ double sh[256];
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (int64_t w = 0; w < nrows; ++w) s += part[(size_t)w * ncols + i];
-    out[i] = s;
+    for (int64_t w = threadIdx.x; w < nrows; w += 256) s += part[(size_t)w * ncols + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = sh[0];
 }
 
 // total = sum_j v[j], fixed tree
@@ -55,6 +62,8 @@ __global__ void math_kernel(int op, const double* x, const double* y, double* ou
         case 4: r = dpow10(a); break;
         case 5: r = sqrt(a); break;
         case 6: r = a / b; break;
+        case 8: r = dlog(a); break;
+        case 9: r = dpow(a, b); break;
         default: r = __builtin_fma(a, b, a); break;
     }
     out[i] = r;
@@ -119,7 +128,7 @@ static int ensure(ude_ctx* c, DevBuf& b, size_t bytes) {
 #include "ude_instances_gen.h"
 
 struct InstanceRow {
-    int mid, alg, G;
+    int mid, alg, G, W;
     void (*get)(Launch*);
 };
 static const InstanceRow kInstances[] = {UDE_INSTANCE_TABLE};
@@ -143,15 +152,21 @@ static int model_id(const ude_model_desc* m) {
         if (dims_are(m, {2, 5, 5, 5, 2}, {ACT_RBF, ACT_RBF, ACT_TANH, ACT_IDENTITY})) return MID_LV_HUDSON;
         if (dims_are(m, {2, 32, 2}, {ACT_TANH, ACT_IDENTITY})) return MID_LV_TANH32;
     }
+    if (m->kind == UDE_KIND_SEIR_TRUE && m->n_state == 7 && m->n_param == 0) return MID_SEIR_TRUE;
+    if (m->kind == UDE_KIND_SEIR_UDE && m->n_state == 7 && m->nn_offset == 0 && m->n_param == 4481 &&
+        dims_are(m, {3, 64, 64, 1}, {ACT_TANH, ACT_TANH, ACT_IDENTITY}))
+        return MID_SEIR_UDE;
     return MID_NONE;
 }
 
 static int default_lanes(int mid) {
     switch (mid) {
         case MID_LV_TRUE: return 1;
-        case MID_LV_S1:
+        case MID_LV_S1: return 4;  // measured on C2: 2.9 ms (4 lanes) vs 3.7 ms (8 lanes) per adjoint pass
         case MID_LV_HUDSON: return 8;
         case MID_LV_TANH32: return 32;
+        case MID_SEIR_TRUE: return 1;
+        case MID_SEIR_UDE: return 64;
     }
     return 1;
 }
@@ -162,14 +177,15 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
         return fail(c, UDE_ERR_UNSUPPORTED, "no compiled kernel for model kind=%d dtype=%d n_layers=%d (see udecore.hip model table)",
                     m->kind, m->dtype, m->n_layers);
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid);
+    const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
     bool ok = false;
     for (const InstanceRow& row : kInstances)
-        if (row.mid == mid && row.alg == o->alg && row.G == G) {
+        if (row.mid == mid && row.alg == o->alg && row.G == G && row.W == W) {
             row.get(&l);
             ok = true;
             break;
         }
-    if (!ok) return fail(c, UDE_ERR_UNSUPPORTED, "no kernel instance for model %d alg %d lanes_per_traj %d", mid, o->alg, G);
+    if (!ok) return fail(c, UDE_ERR_UNSUPPORTED, "no kernel instance for model %d alg %d lanes_per_traj %d waves_per_simd %d", mid, o->alg, G, W);
     return UDE_OK;
 }
 
@@ -343,7 +359,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     p.retcode = retcode;
     const int64_t threads = N * G;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
-    const size_t shmem = sizeof(double) * (size_t)(((m->n_param + 1) & ~1) + l.lds_fwd * BLOCK);
+    const size_t shmem = l.lds_bytes(m->n_param, false);
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
     HIPCHK(c, hipGetLastError());
@@ -408,8 +424,11 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.loss_traj = loss_per_traj ? loss_per_traj : (double*)c->loss_traj.p;
     p.grad_part = (double*)c->grad_part.p;
     p.grad_u0 = grad_u0;
-    const size_t shmem_f = sizeof(double) * (size_t)(((np + 1) & ~1) + l.lds_fwd * BLOCK);
-    const size_t shmem_a = sizeof(double) * (size_t)(((np + 1) & ~1) + l.lds_adj * BLOCK);
+    const size_t shmem_f = l.lds_bytes(np, false);
+    const size_t shmem_a = l.lds_bytes(np, true);
+    if (shmem_a > 64 * 1024) {  // more than the default dynamic-LDS limit: opt in (MI355X has 160 KiB per CU)
+        HIPCHK(c, hipFuncSetAttribute((const void*)l.adj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
+    }
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, sizeof(double) * (size_t)nwaves * np, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
@@ -420,7 +439,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->ev_fwd = c->ev_bwd = true;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((np + 127) / 128), dim3(128), 0, c->stream, (const double*)p.grad_part,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(np), dim3(256), 0, c->stream, (const double*)p.grad_part,
                        nwaves, (int32_t)np, grad_theta);
     HIPCHK(c, hipGetLastError());
     if (loss && !cot_in) {

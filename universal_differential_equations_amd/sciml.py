@@ -85,8 +85,8 @@ class Engine:
             raise UdeError(rc, self.L.ude_last_error(self.h).decode())
         return rc
 
-    def set_launch(self, lanes_per_traj=0, max_dense_steps=0):
-        lo = LaunchOpts(lanes_per_traj, 0, max_dense_steps, 0)
+    def set_launch(self, lanes_per_traj=0, max_dense_steps=0, waves_per_simd=0):
+        lo = LaunchOpts(lanes_per_traj, 0, max_dense_steps, waves_per_simd)
         self.check(self.L.ude_set_launch_opts(self.h, C.byref(lo)))
 
     def set_stream(self, stream_ptr):
@@ -314,14 +314,14 @@ class DeviceEnsemble:
     enqueues on torch's current stream and returns torch tensors; nothing touches the host."""
 
     def __init__(self, f, alg, tspan, saveat, u0, data=None, row_mask=None, lanes_per_traj=0, max_dense_steps=0,
-                 **kw):
+                 waves_per_simd=0, **kw):
         import torch
         self.torch = torch
         self.f, self.o = f, _opts(alg, **kw)
         dev = u0.device
         assert dev.type == "cuda" and u0.dtype == torch.float64
         self.eng = Engine.get(dev.index or 0)
-        self.launch = (lanes_per_traj, max_dense_steps)
+        self.launch = (lanes_per_traj, max_dense_steps, waves_per_simd)
         self.N, self.n = u0.shape
         self.u0 = u0.contiguous()
         self.tspan = _np(tspan)
