@@ -22,7 +22,7 @@ def assert_bitwise(a, b, what):
         what, (~same).sum(), same.size, np.nanmax(np.abs(a.astype(float) - b.astype(float))))
 
 
-def check_per_trajectory(r, ref, with_adjoint=True):
+def check_per_trajectory(r, ref, with_adjoint=True, loss_bitwise=True):
     """ARITH-SPEC: the kernels and the oracle evaluate every trajectory with the same sequence of
     IEEE operations, so everything that belongs to ONE trajectory is bit-identical -- step counts forward and
     backward, saved states, per-trajectory loss and dL/du0.  (The only association that differs is the sum of
@@ -307,6 +307,60 @@ def test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg):
     assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
     assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
     assert np.linalg.norm(ref["grad_theta"]) > 0
+
+
+def kpp_case(nx, N, chain, omodel, seed=4):
+    rng = np.random.default_rng(seed)
+    th = models.kpp_theta(chain, rng)
+    u0 = np.clip(models.rho0(nx)[None, :] * (1 + 0.1 * rng.uniform(-1, 1, (N, 1))) + 0.01 * rng.uniform(0, 1, (N, nx)), 0, None)
+    t = np.arange(11) * 0.5
+    truth, st, rc = O.solve_ensemble(O.kpp_true(nx), O.opts(O.TSIT5), u0, [0.0, 5.0], [], t)
+    assert (rc == 0).all()
+    return th, u0, t, truth
+
+
+def test_kpp_true_matches_oracle():
+    """rc_ode (Fisher-KPP-CNN.jl:51-66): Tsit5 at default tolerances, 26 points, periodic."""
+    th, u0, t, truth = kpp_case(26, 6, models.kpp_chain(), None)
+    ens = U.EnsembleProblem(U.ODEProblem(models.rc_ode(26), u0[0], (0.0, 5.0), []), u0)
+    sol = U.solve(ens, U.Tsit5(), saveat=t)
+    out, st, rc = O.solve_ensemble(O.kpp_true(26), O.opts(O.TSIT5), u0, [0.0, 5.0], [], t)
+    assert_bitwise(sol.stats[:, :4], st[:, :4], "counts")
+    assert_bitwise(sol.u, out, "states")
+
+
+KPP_CASES = [
+    ("cnn26", 26, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Tsit5, O.TSIT5, {}),                       # Fisher-KPP-CNN.jl:136 (default tol)
+    ("cnn26_vern7", 26, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Vern7, O.VERN7, dict(abstol=1e-6, reltol=1e-6)),
+    ("s3_26", 26, models.kpp_s3_chain, lambda nx: O.kpp_ude_s3(0), U.Vern7, O.VERN7, {}),                    # scenario_3.jl:123 (Float64 here)
+    ("cnn1024", 1024, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Tsit5, O.TSIT5, {}),                    # BASELINE C4 size
+]
+
+
+@pytest.mark.parametrize("name,nx,chain,omk,alg,oalg,kw", KPP_CASES)
+def test_kpp_ude_forward_and_adjoint_match_oracle(name, nx, chain, omk, alg, oalg, kw):
+    N = 3 if nx > 100 else 5
+    th, u0, t, truth = kpp_case(nx, N, chain(), omk)
+    if nx > 100:   # dx kept at 0.04 (SURVEY 8(d) C4): tile the 26-point bump, the UDE stays in the non-stiff regime
+        u0 = np.tile(u0[:, :26], (1, 40))[:, :nx]
+        truth, _, rc = O.solve_ensemble(O.kpp_true(nx), O.opts(O.TSIT5), u0, [0.0, 5.0], [], t)
+    f = models.nn_ode(nx, chain())
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 5.0), th), u0)
+    o = O.opts(oalg, kw.get("abstol", 0.0), kw.get("reltol", 0.0))
+    sol = U.solve(ens, alg(), saveat=t, **kw)
+    out, st, rc = O.solve_ensemble(omk(nx), o, u0, [0.0, 5.0], th, t)
+    assert (rc == 0).all()
+    assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts")
+    assert_bitwise(sol.u, out, "forward states")
+    r = U.loss_and_gradient(ens, alg(), truth, saveat=t, **kw)
+    ref = O.loss_grad_ensemble(omk(nx), o, u0, [0.0, 5.0], th, t, truth, nthreads=4)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    # the state is distributed over lanes: the per-trajectory loss is a lane-parallel sum (order differs from the oracle)
+    assert np.abs(r.loss_per_traj - ref["loss_per_traj"]).max() < 1e-13 * ref["loss_per_traj"].max()
+    gn = np.linalg.norm(ref["grad_theta"])
+    assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
+    assert r.grad_theta[f.stencil_offset + 3] == 0.0          # the unused conv bias never receives a gradient
 
 
 def test_failed_trajectory_is_reported_not_summed(golden):

@@ -151,9 +151,18 @@ struct CoopMlp {
 
     // gy: cotangent of the output (replicated).  gx: cotangent of the input (replicated).
     // g[NSLOT]: this lane's slice of (dNN/dtheta)^T gy; slot (l, m, k) = slot_off(l) + m*(in+1) + k, bias at k = in.
+    struct NoSink {
+        __device__ __forceinline__ void operator()(int, int, double) const {}
+    };
     template <bool WANT_PARAM, class P>
     static __device__ __forceinline__ void vjp(const P* th, int r, const Cache& c, const double* gy, double* gx,
                                                double* g) {
+        vjp_sink<WANT_PARAM>(th, r, c, gy, gx, g, NoSink{});
+    }
+    // sink(l, m, d): receives the delta of this lane's m-th neuron of layer l (pointwise networks export it)
+    template <bool WANT_PARAM, class P, class Sink>
+    static __device__ __forceinline__ void vjp_sink(const P* th, int r, const Cache& c, const double* gy, double* gx,
+                                                    double* g, Sink sink) {
         static_assert(N::act(L - 1) == ACT_IDENTITY, "output layer must be linear");
         double dall[MAXD];  // replicated delta of the layer above
         static_for<0, N::dim(L)>([&](auto k) { dall[k] = gy[k]; });
@@ -178,6 +187,7 @@ struct CoopMlp {
                 }
                 const double d = valid ? gp * act_bwd<N::act(l)>(c.z[l][m], c.ao[l][m]) : 0.0;
                 down[m] = d;
+                sink(l, m, d);
                 if constexpr (WANT_PARAM) {
                     constexpr int s0 = slot_off(l) + m * (in + 1);
                     static_for<0, in>([&](auto k) { g[s0 + k] = d * c.a[l][k]; });

@@ -7,4 +7,7 @@
 using namespace ude;
 using InstModel = INST_MODEL;
 
-extern "C" void INST_NAME(Launch* out) { *out = make_launch<InstModel, INST_TAB, INST_G>(); }
+#ifndef INST_BLOCK
+#define INST_BLOCK 64
+#endif
+extern "C" void INST_NAME(Launch* out) { *out = make_launch<InstModel, INST_TAB, INST_G, INST_BLOCK>(); }

@@ -456,13 +456,17 @@ template <class Model, class Tab, int G, int BLOCKDIM>
 struct FwdSys {
     static constexpr int NR = Model::NS, NSL = 0;
     static constexpr bool ALWAYS_K0 = false, SLOTS_IN_LDS = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
-    static constexpr int NF = 2 + NR + Tab::NK * NR;
     typename Model::Ctx mctx;
     const KParams* p;
-    int64_t j;      // trajectory (clamped)
-    bool writer;    // lane 0 of an in-range group
-    int si, nsteps;
+    int64_t j;      // trajectory
+    bool writer;    // lane 0 of the group
+    int si, nsteps, r, n;
     double loss;
+    // component c of this lane is state index comp(c); replicated states: every lane holds all of them
+    __device__ __forceinline__ int comp(int c) const { return STATE_DISTRIBUTED ? c * G + r : c; }
+    __device__ __forceinline__ bool cvalid(int c) const { return comp(c) < n; }
+    __device__ __forceinline__ bool cwrite(int c) const { return STATE_DISTRIBUTED ? cvalid(c) : writer; }
+    __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
 
     __device__ __forceinline__ double first_tstop() const { return p->tf; }
     __device__ __forceinline__ bool next_tstop(double&) const { return false; }
@@ -484,21 +488,22 @@ struct FwdSys {
     __device__ __forceinline__ int slot_end() const { return 0; }
     __device__ __forceinline__ void lds_sync() const {}
     __device__ __forceinline__ void eval_acc(double, const double*, double*, double, double, bool) {}
-    __device__ __forceinline__ double state_on(int) const { return 1.0; }
 
     __device__ __forceinline__ void save_point(int i, const double* v) {
-        const int n = NR;
-        if (p->u_out && writer) {
+        if (p->u_out) {
             double* dst = p->u_out + ((size_t)j * p->ns + i) * n;
-            static_for<0, NR>([&](auto c) { dst[c] = v[c]; });
+            static_for<0, NR>([&](auto c) { if (cwrite(c)) dst[comp(c)] = v[c]; });
         }
         if (p->data) {
             const double* d = p->data + ((size_t)j * p->ns + i) * n;
             static_for<0, NR>([&](auto c) {
-                const double on = (p->row_mask && !p->row_mask[c]) ? 0.0 : 1.0;
-                const double e = on * (v[c] - d[c]);
-                loss = __builtin_fma(e, e, loss);
-                if (writer) p->cot[((size_t)i * n + c) * p->Npad + j] = 2.0 * e;
+                if (cvalid(c)) {
+                    const int ci = comp(c);
+                    const double on = (p->row_mask && !p->row_mask[ci]) ? 0.0 : 1.0;
+                    const double e = on * (v[c] - d[ci]);
+                    loss = __builtin_fma(e, e, loss);
+                    if (cwrite(c)) p->cot[((size_t)i * n + ci) * p->Npad + j] = 2.0 * e;
+                }
             });
         }
     }
@@ -527,14 +532,19 @@ struct FwdSys {
         if (p->dense) {
             if (nsteps >= p->cap) return RET_DENSE_OVERFLOW;
             lazy();
-            if (writer) {
-                double* base = p->dense + ((size_t)nsteps * NF) * p->Npad + j;
-                base[0] = tprev;
-                base[(size_t)1 * p->Npad] = t;
-                static_for<0, NR>([&](auto c) { base[(size_t)(2 + c) * p->Npad] = z[c]; });
+            {
+                const int nf = 2 + n + Tab::NK * n;
+                double* base = p->dense + ((size_t)nsteps * nf) * p->Npad + j;
+                if (writer) {
+                    base[0] = tprev;
+                    base[(size_t)1 * p->Npad] = t;
+                }
+                static_for<0, NR>([&](auto c) { if (cwrite(c)) base[(size_t)(2 + comp(c)) * p->Npad] = z[c]; });
                 static_for<0, Tab::NK>([&](auto q) {
                     if constexpr (Tab::dense_uses(q))
-                        static_for<0, NR>([&](auto c) { base[(size_t)(2 + NR + q * NR + c) * p->Npad] = k(q, c); });
+                        static_for<0, NR>([&](auto c) {
+                            if (cwrite(c)) base[(size_t)(2 + n + q * n + comp(c)) * p->Npad] = k(q, c);
+                        });
                 });
             }
             nsteps += 1;
@@ -574,16 +584,19 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     sys.si = 0;
     sys.nsteps = 0;
     sys.loss = 0.0;
+    sys.r = r;
+    sys.n = p.n_state;
     double z[Sys::NR];
     double* kl = kbase + (Model::STATE_DISTRIBUTED ? threadIdx.x : threadIdx.x / G);
     double* mu = nullptr;  // no slot state in the forward pass
-    static_for<0, Sys::NR>([&](auto c) { z[c] = p.u0[(size_t)gid * Sys::NR + c]; });
+    static_for<0, Sys::NR>([&](auto c) { z[c] = sys.cvalid(c) ? p.u0[(size_t)gid * p.n_state + sys.comp(c)] : 0.0; });
     while (sys.si < p.ns && p.saveat[sys.si] <= p.t0) {  // save_start
         sys.save_point(sys.si, z);
         sys.si += 1;
     }
     typename Drv::Stats st;
-    const int ret = Drv::run(sys, p.o, p.tab, z, kl, mu, p.t0, 1.0, (double)Sys::NR, st);
+    const int ret = Drv::run(sys, p.o, p.tab, z, kl, mu, p.t0, 1.0, (double)p.n_state, st);
+    if constexpr (Model::STATE_DISTRIBUTED) sys.loss = group_sum<G>(sys.loss);  // per-lane partial sums of the loss
     if (sys.writer) {
         if (p.stats) {
             int64_t* s = p.stats + (size_t)gid * 8;
@@ -607,11 +620,14 @@ struct AdjSys {
     static constexpr int NR = Model::NS, NSL = Model::NSL;
     static constexpr bool ALWAYS_K0 = true;  // stage 0 re-evaluated every step: no FSAL slot storage, uniform flow
     static constexpr bool SLOTS_IN_LDS = Model::SLOTS_IN_LDS, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
-    static constexpr int NF = 2 + NR + Tab::NK * NR;
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;
-    int nsteps, sf, cur;
+    int nsteps, sf, cur, n;
+    __device__ __forceinline__ int comp(int c) const { return STATE_DISTRIBUTED ? c * G + mctx.r : c; }
+    __device__ __forceinline__ bool cvalid(int c) const { return comp(c) < n; }
+    __device__ __forceinline__ bool cwrite(int c) const { return STATE_DISTRIBUTED ? cvalid(c) : mctx.r == 0; }
+    __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
     // cached forward interval
     double ts, te, us[NR], ks[Tab::NK][NR];
     // cotangent access
@@ -620,13 +636,16 @@ struct AdjSys {
 
     __device__ __forceinline__ void load_interval(int s) {
         sf = s;
-        const double* base = p->dense + ((size_t)s * NF) * p->Npad + j;
+        const int nf = 2 + n + Tab::NK * n;
+        const double* base = p->dense + ((size_t)s * nf) * p->Npad + j;
         ts = base[0];
         te = base[(size_t)1 * p->Npad];
-        static_for<0, NR>([&](auto c) { us[c] = base[(size_t)(2 + c) * p->Npad]; });
+        static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(2 + comp(c)) * p->Npad] : 0.0; });
         static_for<0, Tab::NK>([&](auto q) {
             if constexpr (Tab::dense_uses(q))
-                static_for<0, NR>([&](auto c) { ks[q][c] = base[(size_t)(2 + NR + q * NR + c) * p->Npad]; });
+                static_for<0, NR>([&](auto c) {
+                    ks[q][c] = cvalid(c) ? base[(size_t)(2 + n + q * n + comp(c)) * p->Npad] : 0.0;
+                });
         });
     }
     // sol(t, continuity = :right): interval [s, s+1] with t_s <= t, clamped to the stored range
@@ -682,7 +701,6 @@ struct AdjSys {
         }
     }
 
-    __device__ __forceinline__ double state_on(int) const { return 1.0; }
     __device__ __forceinline__ double tstop_from_cur() const {
         // next save time strictly inside (t0, t) in descending order, else t0
         return (cur >= 0 && p->saveat[cur] > p->t0) ? p->saveat[cur] : p->t0;
@@ -692,7 +710,9 @@ struct AdjSys {
         bool mod = false;
         while (cur >= 0 && p->saveat[cur] >= t) {
             if (p->saveat[cur] == t) {
-                static_for<0, NR>([&](auto c) { lam[c] += cot[(size_t)cur * cot_si + (size_t)c * cot_sc]; });
+                static_for<0, NR>([&](auto c) {
+                    if (cvalid(c)) lam[c] += cot[(size_t)cur * cot_si + (size_t)comp(c) * cot_sc];
+                });
                 mod = true;
             }
             cur -= 1;
@@ -749,29 +769,33 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         sys.np_ = p.n_param; sys.r_ = r;
         sys.p = &p;
         sys.j = gid;
+        sys.n = p.n_state;
         sys.nsteps = p.dense_n[gid];
         if (p.cot_in) {
-            sys.cot = p.cot_in + (size_t)gid * p.ns * Sys::NR;
-            sys.cot_si = Sys::NR;
+            sys.cot = p.cot_in + (size_t)gid * p.ns * p.n_state;
+            sys.cot_si = p.n_state;
             sys.cot_sc = 1;
         } else {
             sys.cot = p.cot + gid;
-            sys.cot_si = (size_t)Sys::NR * p.Npad;
+            sys.cot_si = (size_t)p.n_state * p.Npad;
             sys.cot_sc = p.Npad;
         }
         sys.cur = p.ns - 1;
         sys.load_interval(sys.nsteps - 1);
         sys.at_tstop(p.tf, lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
-        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(Sys::NR + p.n_param), st);
+        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st);
         if (r == 0) {
             if (p.stats) {
                 int64_t* s = p.stats + (size_t)gid * 8;
                 s[4] = st.nf; s[5] = st.nacc; s[6] = st.nrej;
             }
             if (ret != RET_SUCCESS) p.retcode[gid] = ret;
-            if (p.grad_u0) static_for<0, Sys::NR>([&](auto c) { p.grad_u0[(size_t)gid * Sys::NR + c] = lam[c]; });
         }
+        if (p.grad_u0)
+            static_for<0, Sys::NR>([&](auto c) {
+                if (sys.cwrite(c)) p.grad_u0[(size_t)gid * p.n_state + sys.comp(c)] = lam[c];
+            });
         if (ret != RET_SUCCESS) {  // never poison the batch gradient
             static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
             if constexpr (Model::SLOTS_IN_LDS) {
@@ -783,7 +807,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     if constexpr (Model::SLOTS_IN_LDS) {
         // one trajectory per block (G == BLOCK): mu is already the theta-indexed row of this wave
         __syncthreads();
-        const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64;
+        const int64_t wave = BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
         double* row = p.grad_part + (size_t)wave * p.n_param;
         for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = slots[i];
     }
@@ -794,12 +818,12 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     static_for<0, NSL>([&](auto c) {
         double v = mu[c];
 #pragma unroll
-        for (int m = G; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+        for (int m = G; m < (BLOCK < 64 ? BLOCK : 64); m <<= 1) v += __shfl_xor(v, m, 64);
         mu[c] = v;
     });
     const int lane = threadIdx.x & 63;
     if (lane < G) {
-        const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64;
+        const int64_t wave = BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
         double* row = p.grad_part + (size_t)wave * p.n_param;
         for (int s = 0; s < NSL; ++s) {
             const int idx = Model::slot_index(p.mc, lane, s);

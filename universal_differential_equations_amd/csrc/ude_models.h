@@ -289,4 +289,215 @@ struct SeirUde {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Fisher-KPP (FisherKPP/Fisher-KPP-CNN.jl, LotkaVolterra/scenario_3.jl): 1-D reaction-diffusion on a periodic
+// grid of n_state points.  The STATE is distributed: point i = c*G + r lives on lane r (register slot c);
+// neighbours are exchanged through an LDS row.  One block per trajectory (BLOCK == G).
+// ---------------------------------------------------------------------------------------------
+// rc_ode(rho,p,t) = (D*lap)*rho + r*rho*(1-rho)   (Fisher-KPP-CNN.jl:51-63); consts = D/dx^2, -2D/dx^2, r
+template <int G, int PPL>
+struct KppTrue : LinearTheta {
+    static constexpr int NS = PPL, NSL = 0;
+    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = true;
+    static constexpr int SCRATCH = G * PPL + 2;
+    struct Ctx {
+        double* row;
+        double coff, cdiag, rr;
+        int r, n;
+    };
+    static __device__ __forceinline__ void init(Ctx& c, double*, double* scratch, double*, int, const ModelConsts& mc, int r) {
+        c.row = scratch;
+        c.coff = mc.consts[0]; c.cdiag = mc.consts[1]; c.rr = mc.consts[2];
+        c.r = r; c.n = mc.n_state;
+    }
+    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
+        const int n = c.n;
+        __syncthreads();
+        static_for<0, PPL>([&](auto cc) { const int i = cc * G + c.r; if (i < n) c.row[i] = u[cc]; });
+        __syncthreads();
+        static_for<0, PPL>([&](auto cc) {
+            const int i = cc * G + c.r;
+            if (i < n) {
+                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                // dense mat-vec row: the three nonzeros in ascending column order (oracle: same order)
+                double acc = 0.0;
+                if (i == 0) {
+                    acc += c.cdiag * c.row[i]; acc += c.coff * c.row[ip]; acc += c.coff * c.row[im];
+                } else if (i == n - 1) {
+                    acc += c.coff * c.row[ip]; acc += c.coff * c.row[im]; acc += c.cdiag * c.row[i];
+                } else {
+                    acc += c.coff * c.row[im]; acc += c.cdiag * c.row[i]; acc += c.coff * c.row[ip];
+                }
+                du[cc] = acc + (c.rr * u[cc]) * (1.0 - u[cc]);
+            } else {
+                du[cc] = 0.0;
+            }
+        });
+    }
+    template <bool WANT_PARAM>
+    static __device__ __forceinline__ void vjp(const Ctx&, const double*, const double*, double*, double*) {}
+    static __device__ __forceinline__ int slot_index(const ModelConsts&, int, int) { return -1; }
+};
+
+// nn_ode(u,p,t)  (Fisher-KPP-CNN.jl:111-126; scenario_3.jl:103-114):
+//   du_i = NN(u_i) + D0*(w1*u_{i-1} + w2*u_i + w3*u_{i+1}),  theta = [NN; w1 w2 w3 unused; D0]
+// Forward: every lane runs the whole pointwise network for its points (weights broadcast from LDS).
+// Adjoint: per tile of G points the layer inputs a_l and deltas d_l go to LDS ([row][point]); then the lanes
+// switch role and OWN PARAMETERS (theta index p = r + G*m): each accumulates sum_i d_l[j][i]*a_{l-1}[k][i]
+// over the points in ascending order -- the oracle's order, so the result is bit-identical.
+template <class Net, int G, int PPL>
+struct KppUde : LinearTheta {
+    using Mlp = CoopMlp<Net, 1>;
+    static_assert(Net::dim(0) == 1 && Net::dim(Net::L) == 1, "pointwise reaction network R -> R");
+    static constexpr int NS = PPL;
+    static constexpr int NP = Net::nparam + 5;
+    static constexpr int NSL = (NP + G - 1) / G;
+    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = true;
+    static constexpr int L = Net::L;
+    static constexpr int rows_a() { int s = 0; for (int l = 0; l < L; ++l) s += Net::dim(l); return s; }
+    static constexpr int rows_d() { int s = 0; for (int l = 0; l < L; ++l) s += Net::dim(l + 1); return s; }
+    static constexpr int a_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += Net::dim(i); return s; }
+    static constexpr int d_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += Net::dim(i + 1); return s; }
+    static constexpr int NPT = G * PPL;
+    static constexpr int SCRATCH = 2 * NPT + 4 + (rows_a() + rows_d()) * G;  // u row, lambda row, A tile, D tile
+    struct Ctx {
+        const double* th;
+        const double* nn;
+        double *urow, *lrow, *A, *Dt;
+        double w1, w2, w3, D0;
+        int r, n, so, d0o, nno;
+        int a_row[NSL], d_row[NSL];  // per owned parameter: LDS row of its a factor (-1: bias) and of its delta (-1: not NN)
+        int kind[NSL];               // 0 NN weight/bias, 1 w1, 2 w2, 3 w3, 4 D0, -1 padding / unused slot
+    };
+    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r) {
+        c.th = th_lds;
+        c.nn = th_lds + mc.nn_offset;
+        c.urow = scratch; c.lrow = scratch + NPT + 2; c.A = scratch + 2 * NPT + 4; c.Dt = c.A + rows_a() * G;
+        c.r = r; c.n = mc.n_state; c.so = mc.stencil_offset; c.d0o = mc.d0_offset; c.nno = mc.nn_offset;
+        c.w1 = th_lds[c.so]; c.w2 = th_lds[c.so + 1]; c.w3 = th_lds[c.so + 2]; c.D0 = th_lds[c.d0o];
+        for (int m = 0; m < NSL; ++m) {
+            const int p = r + G * m;
+            c.kind[m] = -1; c.a_row[m] = -1; c.d_row[m] = -1;
+            if (p >= mc.n_param) continue;
+            if (p == c.so) c.kind[m] = 1;
+            else if (p == c.so + 1) c.kind[m] = 2;
+            else if (p == c.so + 2) c.kind[m] = 3;
+            else if (p == c.d0o) c.kind[m] = 4;
+            else if (p >= c.nno && p < c.nno + Net::nparam) {
+                const int q = p - c.nno;
+                static_for<0, L>([&](auto lc) {
+                    constexpr int l = lc;
+                    constexpr int in = Net::dim(l), out = Net::dim(l + 1);
+                    if (q >= Net::off(l) && q < Net::off(l) + in * out + out) {
+                        const int e = q - Net::off(l);
+                        c.kind[m] = 0;
+                        if (e < in * out) { c.d_row[m] = d_off(l) + e % out; c.a_row[m] = a_off(l) + e / out; }
+                        else { c.d_row[m] = d_off(l) + (e - in * out); c.a_row[m] = -1; }
+                    }
+                });
+            }
+        }
+    }
+    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
+        const int n = c.n;
+        __syncthreads();
+        static_for<0, PPL>([&](auto cc) { const int i = cc * G + c.r; if (i < n) c.urow[i] = u[cc]; });
+        __syncthreads();
+        for (int cc = 0; cc < PPL; ++cc) {
+            const int i = cc * G + c.r;
+            double out = 0.0;
+            if (i < n) {
+                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                typename Mlp::Cache cache;
+                double y[1];
+                const double ui = c.urow[i];
+                Mlp::forward(c.nn, 0, &ui, cache, y);
+                const double cnn = c.w1 * c.urow[im] + c.w2 * ui + c.w3 * c.urow[ip];
+                out = y[0] + c.D0 * cnn;
+            }
+            du[cc] = out;
+        }
+    }
+    template <bool WANT_PARAM>
+    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam, double* g) {
+        const int n = c.n;
+        __syncthreads();
+        static_for<0, PPL>([&](auto cc) {
+            const int i = cc * G + c.r;
+            if (i < n) { c.urow[i] = u[cc]; c.lrow[i] = lam[cc]; }
+        });
+        __syncthreads();
+        double acc[NSL];
+        static_for<0, NSL>([&](auto m) { acc[m] = 0.0; });
+        for (int cc = 0; cc < PPL; ++cc) {  // tile cc = points cc*G .. cc*G + G-1 (ascending)
+            const int i = cc * G + c.r;
+            double gxi = 0.0;
+            if (i < n) {
+                typename Mlp::Cache cache;
+                double y[1], gx[1];
+                const double ui = c.urow[i], li = c.lrow[i];
+                Mlp::forward(c.nn, 0, &ui, cache, y);
+                static_for<0, L>([&](auto lc) {
+                    constexpr int l = lc;
+                    static_for<0, Net::dim(l)>([&](auto k) { c.A[(a_off(l) + k) * G + c.r] = cache.a[l][k]; });
+                });
+                Mlp::template vjp_sink<false>(c.nn, 0, cache, &li, gx, (double*)nullptr,
+                                              [&](int l, int m, double d) { c.Dt[(d_off_rt(l) + m) * G + c.r] = d; });
+                gxi = gx[0];
+            }
+            // transpose of the periodic stencil (the oracle's expression)
+            if (i < n) {
+                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                dlam[cc] = gxi + c.D0 * (c.w1 * c.lrow[ip] + c.w2 * c.lrow[i] + c.w3 * c.lrow[im]);
+            } else {
+                dlam[cc] = 0.0;
+            }
+            __syncthreads();
+            if constexpr (WANT_PARAM) {
+                const int npts = (n - cc * G) < G ? (n - cc * G) : G;  // points of this tile
+                static_for<0, NSL>([&](auto mc) {
+                    constexpr int m = mc;
+                    if (c.kind[m] == 0) {
+                        const double* dr = c.Dt + c.d_row[m] * G;
+                        if (c.a_row[m] >= 0) {
+                            const double* ar = c.A + c.a_row[m] * G;
+                            for (int q = 0; q < npts; ++q) acc[m] += dr[q] * ar[q];
+                        } else {
+                            for (int q = 0; q < npts; ++q) acc[m] += dr[q];
+                        }
+                    }
+                });
+            }
+            __syncthreads();
+        }
+        if constexpr (WANT_PARAM) {
+            // stencil weights and D0: sequential sums over ALL points (oracle order), by the owning lanes
+            static_for<0, NSL>([&](auto mc) {
+                constexpr int m = mc;
+                const int kd = c.kind[m];
+                if (kd >= 1) {
+                    double s = 0.0;
+                    for (int i = 0; i < n; ++i) {
+                        const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                        if (kd == 1) s += c.lrow[i] * c.urow[im];
+                        else if (kd == 2) s += c.lrow[i] * c.urow[i];
+                        else if (kd == 3) s += c.lrow[i] * c.urow[ip];
+                        else s += c.lrow[i] * (c.w1 * c.urow[im] + c.w2 * c.urow[i] + c.w3 * c.urow[ip]);
+                    }
+                    acc[m] = kd == 4 ? s : c.D0 * s;
+                }
+            });
+            static_for<0, NSL>([&](auto m) { g[m] = acc[m]; });
+        }
+        __syncthreads();
+    }
+    static constexpr int d_off_rt(int l) { return d_off(l); }
+    static __device__ __forceinline__ int slot_index(const ModelConsts& mc, int r, int s) {
+        const int p = r + G * s;
+        if (p >= mc.n_param) return -1;
+        if (p == mc.stencil_offset + 3) return -1;  // the unused conv bias (Fisher-KPP-CNN.jl:100-109): gradient stays 0
+        return p;
+    }
+};
+
 }  // namespace ude

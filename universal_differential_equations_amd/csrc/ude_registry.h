@@ -20,14 +20,12 @@ struct Launch {
     }
 };
 
-constexpr int BLOCK = 64;
-
-template <class Model, class Tab, int G>
+template <class Model, class Tab, int G, int BLOCK = 64>
 inline Launch make_launch() {
     Launch l;
     l.fwd = fwd_kernel<Model, Tab, G, BLOCK>;
     l.adj = adj_kernel<Model, Tab, G, BLOCK>;
-    l.nf = 2 + Model::NS + Tab::NK * Model::NS;
+    l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;
     l.theta_lds = Model::theta_lds(7) == 8 ? -1 : Model::theta_lds(0);
@@ -43,6 +41,10 @@ using NetS1 = NetCfg<IntList<2, 5, 5, 5, 2>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, 
 using NetHudson = NetCfg<IntList<2, 5, 5, 5, 2>, IntList<ACT_RBF, ACT_RBF, ACT_TANH, ACT_IDENTITY>>;  // hudson_bay.jl:77-79
 using NetTanh32 = NetCfg<IntList<2, 32, 2>, IntList<ACT_TANH, ACT_IDENTITY>>;                         // BASELINE C2 "2-layer tanh"
 
-enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, MID_SEIR_TRUE, MID_SEIR_UDE };
+enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, MID_SEIR_TRUE, MID_SEIR_UDE,
+       MID_KPP_TRUE_32, MID_KPP_TRUE_1024, MID_KPP_UDE_32, MID_KPP_UDE_1024, MID_KPP_S3_32 };
+
+using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
+using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88
 
 }  // namespace ude

@@ -152,6 +152,16 @@ static int model_id(const ude_model_desc* m) {
         if (dims_are(m, {2, 5, 5, 5, 2}, {ACT_RBF, ACT_RBF, ACT_TANH, ACT_IDENTITY})) return MID_LV_HUDSON;
         if (dims_are(m, {2, 32, 2}, {ACT_TANH, ACT_IDENTITY})) return MID_LV_TANH32;
     }
+    if (m->kind == UDE_KIND_KPP_TRUE && m->n_param == 0 && m->n_state >= 3)
+        return m->n_state <= 32 ? MID_KPP_TRUE_32 : m->n_state <= 1024 ? MID_KPP_TRUE_1024 : MID_NONE;
+    if (m->kind == UDE_KIND_KPP_UDE && m->nn_offset == 0 && m->n_state >= 3) {
+        if (dims_are(m, {1, 10, 20, 10, 1}, {ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY}) && m->n_param == 466 &&
+            m->stencil_offset == 461 && m->d0_offset == 465)
+            return m->n_state <= 32 ? MID_KPP_UDE_32 : m->n_state <= 1024 ? MID_KPP_UDE_1024 : MID_NONE;
+        if (dims_are(m, {1, 5, 5, 5, 1}, {ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY}) && m->n_param == 81 &&
+            m->stencil_offset == 76 && m->d0_offset == 80 && m->n_state <= 32)
+            return MID_KPP_S3_32;
+    }
     if (m->kind == UDE_KIND_SEIR_TRUE && m->n_state == 7 && m->n_param == 0) return MID_SEIR_TRUE;
     if (m->kind == UDE_KIND_SEIR_UDE && m->n_state == 7 && m->nn_offset == 0 && m->n_param == 4481 &&
         dims_are(m, {3, 64, 64, 1}, {ACT_TANH, ACT_TANH, ACT_IDENTITY}))
@@ -167,6 +177,11 @@ static int default_lanes(int mid) {
         case MID_LV_TANH32: return 32;
         case MID_SEIR_TRUE: return 1;
         case MID_SEIR_UDE: return 64;
+        case MID_KPP_TRUE_32:
+        case MID_KPP_UDE_32:
+        case MID_KPP_S3_32: return 32;
+        case MID_KPP_TRUE_1024:
+        case MID_KPP_UDE_1024: return 64;
     }
     return 1;
 }
@@ -357,9 +372,12 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
         retcode = (int32_t*)c->retcode.p;
     }
     p.retcode = retcode;
+    const int BLOCK = l.block;
     const int64_t threads = N * G;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
     const size_t shmem = l.lds_bytes(m->n_param, false);
+    if (shmem > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)l.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
     HIPCHK(c, hipGetLastError());
@@ -389,9 +407,11 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if (c->trace_cap > 0) { p.trace = (double*)c->trace.p; p.trace_traj = c->trace_traj; p.trace_cap = c->trace_cap; }
     const int n = m->n_state, np = m->n_param;
     const int cap = c->lo.max_dense_steps > 0 ? c->lo.max_dense_steps : 256;
+    const int BLOCK = l.block;
     const int64_t threads = N * G;
     const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
-    const int64_t nwaves = (int64_t)grid * (BLOCK / 64);
+    const int64_t nwaves = (int64_t)grid * (BLOCK >= 64 ? BLOCK / 64 : 1);
+    const int nf = 2 + n + l.nf * n;
     p.N = N;
     p.Npad = (N + 7) / 8 * 8;
     p.ns = ns;
@@ -403,7 +423,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.data = cot_in ? nullptr : data;
     p.row_mask = row_mask;
     p.cot_in = cot_in;
-    if ((rc = ensure(c, c->dense, sizeof(double) * (size_t)cap * l.nf * p.Npad))) return rc;
+    if ((rc = ensure(c, c->dense, sizeof(double) * (size_t)cap * nf * p.Npad))) return rc;
     if ((rc = ensure(c, c->dense_n, sizeof(int32_t) * N))) return rc;
     if ((rc = ensure(c, c->cot, sizeof(double) * (size_t)ns * n * p.Npad))) return rc;
     if ((rc = ensure(c, c->loss_traj, sizeof(double) * N))) return rc;
@@ -426,9 +446,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.grad_u0 = grad_u0;
     const size_t shmem_f = l.lds_bytes(np, false);
     const size_t shmem_a = l.lds_bytes(np, true);
-    if (shmem_a > 64 * 1024) {  // more than the default dynamic-LDS limit: opt in (MI355X has 160 KiB per CU)
+    if (shmem_a > 64 * 1024)  // more than the default dynamic-LDS limit: opt in (MI355X has 160 KiB per CU)
         HIPCHK(c, hipFuncSetAttribute((const void*)l.adj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
-    }
+    if (shmem_f > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)l.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, sizeof(double) * (size_t)nwaves * np, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);

@@ -122,12 +122,31 @@ def dudt_(chain=None, p_=SEIR_P):
 
 def rc_ode(nx=26, D=0.01, r=1.0, dx=0.04):
     """rc_ode(rho,p,t) = D*lap*rho + reaction.(rho)  FisherKPP/Fisher-KPP-CNN.jl:51-63 (periodic)"""
-    return _desc(KIND_KPP_TRUE, nx, n_param=0, consts=(D / dx ** 2, -2.0 * D / dx ** 2, r))
+    # D * lap with lap = diagm(-2, 1, 1) ./ dx^2: the entries Julia forms are D*(1/dx^2) and D*(-2/dx^2)
+    return _desc(KIND_KPP_TRUE, nx, n_param=0, consts=(D * (1.0 / dx ** 2), D * (-2.0 / dx ** 2), r))
 
 
 def kpp_chain():
     """rx_nn = Chain(Dense(1,10,tanh), Dense(10,20,tanh), Dense(20,10,tanh), Dense(10,1))  Fisher-KPP-CNN.jl:92-96"""
     return Chain(Dense(1, 10, "tanh"), Dense(10, 20, "tanh"), Dense(20, 10, "tanh"), Dense(10, 1))
+
+
+def kpp_s3_chain():
+    """rx_nn = Lux.Chain(Dense(1,5,rbf), Dense(5,5,rbf), Dense(5,5,rbf), Dense(5,1))  LotkaVolterra/scenario_3.jl:83-88"""
+    return Chain(Dense(1, 5, "rbf"), Dense(5, 5, "rbf"), Dense(5, 5, "rbf"), Dense(5, 1))
+
+
+def kpp_theta(chain, rng, stencil=(1.1, -2.5, 1.0), D0=6.5):
+    """p = [p1; p2; D0] with the reference's initial stencil and D0 (Fisher-KPP-CNN.jl:98-109)"""
+    import numpy as np
+    return np.concatenate([chain.glorot_uniform(rng), list(stencil), [0.0], [D0]])
+
+
+def rho0(nx=26, dx=0.04, amp=1.0, delta=0.2):
+    """IC-1 of Fisher-KPP-CNN.jl:27-31 on x = 0:dx:(nx-1)*dx"""
+    import numpy as np
+    x = dx * np.arange(nx)
+    return amp * (np.tanh((x - (0.5 - delta / 2)) / (delta / 10)) - np.tanh((x - (0.5 + delta / 2)) / (delta / 10))) / 2
 
 
 def nn_ode(nx=26, chain=None):
