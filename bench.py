@@ -21,7 +21,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector == FP64 matrix peak
-FLOPS_FWD_EVAL, FLOPS_BWD_EVAL = 160.0, 550.0   # algorithmic flop per work unit
+# algorithmic flop per work unit (forward RHS eval, adjoint eval): SURVEY.md 8(d) roofline table
+FLOPS = {"lv": (160.0, 550.0), "seir": (8744.0, 26000.0), "kpp": (0.87e6, 2.6e6)}
+
+
+def synth_inputs_other(workload, N, rank, device):
+    """SEIR (BASELINE configs[2] per-GPU share) and Fisher-KPP (configs[3]) synthetic inputs, SURVEY.md 8(d)."""
+    import universal_differential_equations_amd as U
+    from universal_differential_equations_amd import models
+    rng = np.random.default_rng(1234 + rank)
+    if workload == "seir":
+        S0 = 14e6
+        u0 = np.zeros((N, 7))
+        u0[:, 0] = rng.uniform(0.8, 0.95, N) * S0
+        u0[:, 4] = S0
+        t = np.arange(22.0)
+        tspan, f_true, f_ude = (0.0, 21.0), models.corona(), models.dudt_()
+        theta = models.seir_chain().glorot_uniform(rng)
+        mask, alg, tol = [0, 1, 1, 1, 0, 0, 0], U.Vern7(), dict(abstol=1e-6, reltol=1e-6)
+        true_alg, true_tol = U.Vern7(), dict(abstol=1e-12, reltol=1e-12)
+    else:
+        nx = 1024
+        base = models.rho0(26)
+        u0 = np.tile(base, 40)[None, :nx] * (1 + 0.1 * rng.uniform(-1, 1, (N, 1)))
+        t = np.arange(11) * 0.5
+        tspan, f_true, f_ude = (0.0, 5.0), models.rc_ode(nx), models.nn_ode(nx)
+        theta = models.kpp_theta(models.kpp_chain(), rng)
+        mask, alg, tol = None, U.Tsit5(), {}
+        true_alg, true_tol = U.Tsit5(), {}
+    u0_d = torch.tensor(u0, dtype=torch.float64, device=device)
+    truth = U.DeviceEnsemble(f_true, true_alg, tspan, t, u0_d, **true_tol)
+    X = truth.solve(torch.zeros(1, dtype=torch.float64, device=device)).clone()
+    torch.cuda.synchronize()
+    assert int((truth.retcode != 0).sum()) == 0
+    return dict(theta=theta, u0=u0_d, t=t, data=X, tspan=tspan, f=f_ude, mask=mask, alg=alg, tol=tol)
 
 
 def synth_inputs(N, rank, device):
@@ -45,21 +78,26 @@ def synth_inputs(N, rank, device):
     return theta, u0_d, t, data
 
 
-def cpu_baseline(theta, u0, t, data, seconds_target=15.0):
+def cpu_baseline(theta, u0, t, data, seconds_target=15.0, workload="lv", mask=None):
     """The CPU restatement (oracle, kind "port") on this box's host cores, bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     cores = os.cpu_count() or 1
-    m, o = O.lv_ude_s1(), O.opts(O.TSIT5, 1e-6, 1e-6)
-    n = min(len(u0), 64 * cores)
+    if workload == "lv":
+        m, o = O.lv_ude_s1(), O.opts(O.TSIT5, 1e-6, 1e-6)
+    elif workload == "seir":
+        m, o = O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6)
+    else:
+        m, o = O.kpp_ude(u0.shape[1]), O.opts(O.TSIT5)
+    n = min(len(u0), cores if workload != "lv" else 64 * cores)
     t0 = time.perf_counter()
-    r = O.loss_grad_ensemble(m, o, u0[:n], [t[0], t[-1]], theta, t, data[:n], nthreads=cores)
+    r = O.loss_grad_ensemble(m, o, u0[:n], [t[0], t[-1]], theta, t, data[:n], row_mask=mask, nthreads=cores)
     dt = time.perf_counter() - t0
     per_traj = dt / n
     n2 = int(min(len(u0), max(n, seconds_target / max(per_traj, 1e-9))))
     if n2 > n:
         t0 = time.perf_counter()
-        r = O.loss_grad_ensemble(m, o, u0[:n2], [t[0], t[-1]], theta, t, data[:n2], nthreads=cores)
+        r = O.loss_grad_ensemble(m, o, u0[:n2], [t[0], t[-1]], theta, t, data[:n2], row_mask=mask, nthreads=cores)
         dt = time.perf_counter() - t0
         n = n2
     evals = int(r["stats"][:, 0].sum() + r["stats"][:, 4].sum())
@@ -72,7 +110,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--traj", type=int, default=10000, help="trajectories per GPU")
+    ap.add_argument("--traj", type=int, default=0, help="trajectories per GPU (0 = workload default)")
+    ap.add_argument("--workload", default="lv", choices=["lv", "seir", "kpp"],
+                    help="lv = BASELINE configs[1] (the headline); seir / kpp = configs[2] per-GPU share / configs[3]")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = library default)")
     ap.add_argument("--waves", type=int, default=0, help="adjoint kernel variant: waves per SIMD (0 = default)")
     ap.add_argument("--alg", default="tsit5")
@@ -94,12 +134,24 @@ def main():
     from universal_differential_equations_amd import models
     from universal_differential_equations_amd.parallel import allreduce_grad
 
-    N = a.traj
-    theta_h, u0_d, t, data = synth_inputs(N, rank, device)
+    N = a.traj or {"lv": 10000, "seir": 6250, "kpp": 256}[a.workload]
+    mask = None
+    if a.workload == "lv":
+        theta_h, u0_d, t, data = synth_inputs(N, rank, device)
+        alg = U.Tsit5() if a.alg == "tsit5" else U.Vern7()
+        ens = U.DeviceEnsemble(models.ude_dynamics(), alg, (0.0, 3.0), t, u0_d, data=data, lanes_per_traj=a.lanes,
+                               waves_per_simd=a.waves, abstol=1e-6, reltol=1e-6)
+        wl_name = ("BASELINE configs[1]: LV UDE (2-5-5-5-2 rbf, 87 params, theta_init of scenario_1), %d trajectories per GPU, "
+                   "%s abstol=reltol=1e-6, 31 save points, loss + InterpolatingAdjoint gradient" % (N, a.alg))
+    else:
+        w = synth_inputs_other(a.workload, N, rank, device)
+        theta_h, u0_d, t, data, mask = w["theta"], w["u0"], w["t"], w["data"], w["mask"]
+        ens = U.DeviceEnsemble(w["f"], w["alg"], w["tspan"], t, u0_d, data=data, row_mask=mask, **w["tol"])
+        wl_name = {"seir": "BASELINE configs[2] per-GPU share: SEIR exposure UDE (7 states, NN 3-64-64-1 tanh, 4481 params), %d trajectories "
+                           "per GPU, Vern7 abstol=reltol=1e-6, 22 save points, loss rows 2:4 + InterpolatingAdjoint gradient",
+                   "kpp": "BASELINE configs[3]: Fisher-KPP UDE, 1024 points (dx = 0.04), NN 1-10-20-10-1 tanh + 3-tap stencil (466 params), "
+                          "%d PDEs per GPU, Tsit5 default tol, 11 save points, loss + InterpolatingAdjoint gradient"}[a.workload] % N
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)
-    alg = U.Tsit5() if a.alg == "tsit5" else U.Vern7()
-    ens = U.DeviceEnsemble(models.ude_dynamics(), alg, (0.0, 3.0), t, u0_d, data=data, lanes_per_traj=a.lanes,
-                           waves_per_simd=a.waves, abstol=1e-6, reltol=1e-6)
 
     def step():
         g = ens.loss_grad(theta)
@@ -145,15 +197,13 @@ def main():
 
     if rank == 0:
         bwd = float(np.mean(bwd_ms)) * 1e-3
-        flops_bwd = nf_bwd * FLOPS_BWD_EVAL
+        flops_bwd = nf_bwd * FLOPS[a.workload][1]
         achieved = flops_bwd / bwd / 1e12
         out = {
             "metric": "ODE RHS-evals/s (fwd+adjoint)", "value": value, "unit": "RHS-evals/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: LV UDE (2-5-5-5-2 rbf, 87 params, theta_init of scenario_1), "
-                                   "%d trajectories per GPU, %s abstol=reltol=1e-6, 31 save points, loss + "
-                                   "InterpolatingAdjoint gradient" % (N, a.alg),
+            "config": {"workload": wl_name,
                        "trajectories_per_gpu": N, "lanes_per_trajectory": a.lanes or "default",
                        "evals_per_step_fwd": nf_fwd, "evals_per_step_bwd": nf_bwd, "failed_trajectories": int(evals[1].item()),
                        "adjoint_grad_wallclock_ms": ms_per_step, "fwd_kernel_ms": float(np.mean(fwd_ms)),
@@ -161,11 +211,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "adj_kernel (interpolating adjoint)", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": None,
-                         "note": "FP64 vector/matrix peak (both 78.6 TF); algorithmic 550 flop per adjoint eval; "
-                                 "the path is FP64-ALU/latency bound, not HBM bound (DESIGN.md)"},
+                         "note": "FP64 vector/matrix peak (both 78.6 TF); algorithmic %g flop per adjoint eval; "
+                                 "the path is FP64-ALU/latency bound, not HBM bound (DESIGN.md)" % FLOPS[a.workload][1]},
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(theta_h, u0_d.cpu().numpy(), t, data.cpu().numpy())
+            out["cpu_baseline"] = cpu_baseline(theta_h, u0_d.cpu().numpy(), t, data.cpu().numpy(), workload=a.workload, mask=mask)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
