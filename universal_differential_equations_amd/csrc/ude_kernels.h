@@ -130,7 +130,10 @@ struct Driver {
     //   mu: slot state (touched once per step)
     // z: replicated state (registers).  Integrates from t0 along tdir through sys' tstops.
     static __device__ __forceinline__ int run(Sys& sys, const Opts& o, const TabDev* __restrict__ tab, double (&z)[NR],
-                                              double* kl, double* mu, double t0, double tdir, double ntot, Stats& st) {
+                                              double* kl, double* mu, double t0, double tdir, double ntot, Stats& st,
+                                              double* gtmp = nullptr) {
+        // gtmp: per-thread LDS scratch (element c at gtmp[c * BLOCK]) that parks the slot derivative f0 of the
+        // initial-dt heuristic across its second evaluation (keeps the register peak of the kernel down)
         double accb[NSLA], acce[NSLA];
         double t = t0, dt, qold = o.qoldinit, q11 = 1.0;
         bool accept = true, done = false;
@@ -172,9 +175,11 @@ struct Driver {
                     const double q0 = m / sk, q1 = gs0[c] / sk;
                     dd_acc(h0, l0, q0 * q0);
                     dd_acc(h1, l1, q1 * q1);
+                    gtmp[c * BLOCK] = gs0[c];
                 });
                 group_dd_sum<G>(h0, l0);
                 group_dd_sum<G>(h1, l1);
+                asm volatile("" ::: "memory");
             }
             if constexpr (Sys::STATE_DISTRIBUTED) {
                 double hs0 = 0.0, ls0 = 0.0, hs1 = 0.0, ls1 = 0.0;
@@ -226,7 +231,7 @@ struct Driver {
                 } else if constexpr (NSL > 0) {
                     static_for<0, NSL>([&](auto c) {
                         const double sk = __builtin_fma(fabs(mu[c * BLOCK]), o.reltol, o.abstol);
-                        const double q = (gs1[c] - gs0[c]) / sk;
+                        const double q = (gs1[c] - gtmp[c * BLOCK]) / sk;
                         dd_acc(h2, l2, q * q);
                     });
                     group_dd_sum<G>(h2, l2);
@@ -558,6 +563,9 @@ template <class Model, class Tab, int G, int BLOCK>
 struct Layout {
     static constexpr int KSTRIDE = Model::STATE_DISTRIBUTED ? BLOCK : BLOCK / G;
     static constexpr int K_DOUBLES = Tab::NK * Model::NS * KSTRIDE;
+    // group-shared forward-interval cache of the adjoint kernel (see AdjSys::IC_LDS)
+    static constexpr bool IC_LDS = (G >= 8) && !Model::STATE_DISTRIBUTED && !Model::SLOTS_IN_LDS;
+    static constexpr int IC_DOUBLES = IC_LDS ? (Model::NS + Tab::NK * Model::NS) * (BLOCK / G) : 0;
     static __host__ __device__ constexpr int np_pad(int np) { return (np + 1) & ~1; }
 };
 
@@ -628,8 +636,17 @@ struct AdjSys {
     __device__ __forceinline__ bool cvalid(int c) const { return comp(c) < n; }
     __device__ __forceinline__ bool cwrite(int c) const { return STATE_DISTRIBUTED ? cvalid(c) : mctx.r == 0; }
     __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
-    // cached forward interval
-    double ts, te, us[NR], ks[Tab::NK][NR];
+    // cached forward interval: t_start/t_end in registers; u_start and the k's either in registers (IC_LDS = false)
+    // or in a group-shared LDS row (IC_LDS: saves 2*NR*(NK+1) VGPRs per lane; reads are broadcasts inside the group)
+    static constexpr bool IC_LDS = (G >= 8) && !STATE_DISTRIBUTED && !SLOTS_IN_LDS;
+    static constexpr int IC_FIELDS = NR + Tab::NK * NR;
+    double ts, te, us[IC_LDS ? 1 : NR], ks[IC_LDS ? 1 : Tab::NK][IC_LDS ? 1 : NR];
+    double* ic;      // LDS: field f of this group at ic[f * icstride]
+    int icstride;
+    __device__ __forceinline__ double US(int c) const { if constexpr (IC_LDS) return ic[c * icstride]; else return us[c]; }
+    __device__ __forceinline__ double KS(int q, int c) const {
+        if constexpr (IC_LDS) return ic[(NR + q * NR + c) * icstride]; else return ks[q][c];
+    }
     // cotangent access
     const double* cot;
     size_t cot_si, cot_sc;  // strides of save index / component
@@ -640,13 +657,20 @@ struct AdjSys {
         const double* base = p->dense + ((size_t)s * nf) * p->Npad + j;
         ts = base[0];
         te = base[(size_t)1 * p->Npad];
-        static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(2 + comp(c)) * p->Npad] : 0.0; });
-        static_for<0, Tab::NK>([&](auto q) {
-            if constexpr (Tab::dense_uses(q))
-                static_for<0, NR>([&](auto c) {
-                    ks[q][c] = cvalid(c) ? base[(size_t)(2 + n + q * n + comp(c)) * p->Npad] : 0.0;
-                });
-        });
+        if constexpr (IC_LDS) {
+            // the G lanes of the group fetch the fields round-robin and publish them in the group's LDS row
+            asm volatile("" ::: "memory");
+            for (int f = mctx.r; f < IC_FIELDS; f += G) ic[f * icstride] = base[(size_t)(2 + f) * p->Npad];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(2 + comp(c)) * p->Npad] : 0.0; });
+            static_for<0, Tab::NK>([&](auto q) {
+                if constexpr (Tab::dense_uses(q))
+                    static_for<0, NR>([&](auto c) {
+                        ks[q][c] = cvalid(c) ? base[(size_t)(2 + n + q * n + comp(c)) * p->Npad] : 0.0;
+                    });
+            });
+        }
     }
     // sol(t, continuity = :right): interval [s, s+1] with t_s <= t, clamped to the stored range
     __device__ __forceinline__ void locate(double t) {
@@ -662,8 +686,8 @@ struct AdjSys {
         double b[Tab::NK], y[NR], dl[NR];
         Tab::bth(th, b);
         static_for<0, NR>([&](auto c) {
-            const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][c]; }, [&](auto q) { return b[q]; });
-            y[c] = __builtin_fma(dtf, acc, us[c]);
+            const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
+            y[c] = __builtin_fma(dtf, acc, US(c));
         });
         Model::template vjp<true>(mctx, y, lam, dl, g);
         static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
@@ -685,8 +709,8 @@ struct AdjSys {
             double b[Tab::NK], y[NR], dl[NR];
             Tab::bth(th, b);
             static_for<0, NR>([&](auto c) {
-                const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][c]; }, [&](auto q) { return b[q]; });
-                y[c] = __builtin_fma(dtf, acc, us[c]);
+                const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
+                y[c] = __builtin_fma(dtf, acc, US(c));
             });
             Model::vjp_acc(mctx, y, lam, dl, bs, es, first);
             static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
@@ -757,6 +781,8 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     double* kl = kbase + (Model::STATE_DISTRIBUTED ? threadIdx.x : threadIdx.x / G);
     // register-slot mode: slot state mu of thread tid, element c at mu_lds[c * BLOCK]
     double* mu_lds = slots + threadIdx.x;
+    double* gtmp = slots + (size_t)NSLA * BLOCK + threadIdx.x;        // initial-dt scratch, element c at gtmp[c * BLOCK]
+    double* icbase = slots + (size_t)2 * NSLA * BLOCK;                 // interval cache rows (IC_LDS), one per group
     double lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
     static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
@@ -770,6 +796,8 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         sys.p = &p;
         sys.j = gid;
         sys.n = p.n_state;
+        sys.ic = icbase + threadIdx.x / G;
+        sys.icstride = BLOCK / G;
         sys.nsteps = p.dense_n[gid];
         if (p.cot_in) {
             sys.cot = p.cot_in + (size_t)gid * p.ns * p.n_state;
@@ -784,7 +812,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         sys.load_interval(sys.nsteps - 1);
         sys.at_tstop(p.tf, lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
-        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st);
+        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st, gtmp);
         if (r == 0) {
             if (p.stats) {
                 int64_t* s = p.stats + (size_t)gid * 8;
