@@ -175,7 +175,7 @@ def test_adjoint_gradient_matches_oracle(golden, name, mk, omk, npar, alg, oalg)
     assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
 
 
-@pytest.mark.parametrize("lanes", [1, 4, 8])
+@pytest.mark.parametrize("lanes", [1, 4, 5, 8])
 def test_lanes_per_trajectory_variants_agree(golden, lanes):
     g, X, t = s1_data(golden)
     th = np.array(g["initial_parameters"])

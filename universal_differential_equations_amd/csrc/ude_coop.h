@@ -22,6 +22,18 @@ __device__ __forceinline__ double dpp_mov(double x) {
 constexpr int DPP_QUAD(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <- lane 7-i inside each 8 lanes
 
+// Lane groups need not be a power of two: G = 5 puts 12 trajectories in a wavefront (lanes 60-63 idle) with
+// every lane of a 5-wide layer busy.  Groups start at lane multiples of G; for such G the cross-lane moves go
+// through ds_bpermute with a computed source lane and sums are formed in a fixed sequential order.
+template <int G>
+constexpr bool pow2_group() { return (G & (G - 1)) == 0; }
+
+__device__ __forceinline__ double bpermute_f64(int byte_addr, double x) {
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
 // value of x held by lane `src` of this lane's group (src < G is a compile-time constant)
 template <int G, int SRC>
 __device__ __forceinline__ double group_bcast(double x) {
@@ -29,20 +41,33 @@ __device__ __forceinline__ double group_bcast(double x) {
         return x;
     } else if constexpr (G == 4) {
         return dpp_mov<DPP_QUAD(SRC, SRC, SRC, SRC)>(x);  // one DPP move per 32-bit half
-    } else {
+    } else if constexpr (pow2_group<G>()) {
         return __shfl(x, SRC, G);  // ds_bpermute
+    } else {
+        const int lane = threadIdx.x & 63;
+        return bpermute_f64((lane - lane % G + SRC) << 2, x);
     }
 }
 
-// sum over the G lanes of a group; every lane receives the same bits (xor butterfly, commutative adds)
+// sum over the G lanes of a group; every lane receives the same bits (xor butterfly of commutative adds, or
+// the same sequential order on every lane)
 template <int G>
 __device__ __forceinline__ double group_sum(double x) {
-    if constexpr (G >= 2) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x) : __shfl_xor(x, 1, G);
-    if constexpr (G >= 4) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x) : __shfl_xor(x, 2, G);
-    if constexpr (G >= 8) x += (G == 8) ? dpp_mov<DPP_ROW_HALF_MIRROR>(x) : __shfl_xor(x, 4, G);
+    if constexpr (!pow2_group<G>()) {
+        const int lane = threadIdx.x & 63;
+        const int base = (lane - lane % G) << 2;
+        double s = bpermute_f64(base, x);
+#pragma unroll 1
+        for (int i = 1; i < G; ++i) s += bpermute_f64(base + (i << 2), x);
+        return s;
+    } else {
+        if constexpr (G >= 2) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x) : __shfl_xor(x, 1, G);
+        if constexpr (G >= 4) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x) : __shfl_xor(x, 2, G);
+        if constexpr (G >= 8) x += (G == 8) ? dpp_mov<DPP_ROW_HALF_MIRROR>(x) : __shfl_xor(x, 4, G);
 #pragma unroll
-    for (int m = 8; m < G; m <<= 1) x += __shfl_xor(x, m, G);
-    return x;
+        for (int m = 8; m < G; m <<= 1) x += __shfl_xor(x, m, G);
+        return x;
+    }
 }
 
 // double-double accumulation (two-sum): order-independent sums for the initial-dt norms (ARITH-SPEC)
@@ -56,6 +81,23 @@ __device__ __forceinline__ void dd_acc(double& hi, double& lo, double x) {
 // combine the (hi, lo) pairs of the G lanes of a group; every lane ends with the same pair
 template <int G>
 __device__ __forceinline__ void group_dd_sum(double& hi, double& lo) {
+    if constexpr (!pow2_group<G>()) {
+        const int lane = threadIdx.x & 63;
+        const int base = (lane - lane % G) << 2;
+        double h = bpermute_f64(base, hi), l = bpermute_f64(base, lo);
+#pragma unroll 1
+        for (int i = 1; i < G; ++i) {
+            const double h2 = bpermute_f64(base + (i << 2), hi), l2 = bpermute_f64(base + (i << 2), lo);
+            const double s = h + h2;
+            const double bb = s - h;
+            const double e = (h - (s - bb)) + (h2 - bb);
+            l = (l + l2) + e;
+            h = s;
+        }
+        hi = h;
+        lo = l;
+        return;
+    }
 #pragma unroll
     for (int m = 1; m < G; m <<= 1) {
         const double h2 = __shfl_xor(hi, m, G), l2 = __shfl_xor(lo, m, G);

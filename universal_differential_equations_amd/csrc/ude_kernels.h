@@ -564,7 +564,7 @@ struct Layout {
     static constexpr int KSTRIDE = Model::STATE_DISTRIBUTED ? BLOCK : BLOCK / G;
     static constexpr int K_DOUBLES = Tab::NK * Model::NS * KSTRIDE;
     // group-shared forward-interval cache of the adjoint kernel (see AdjSys::IC_LDS)
-    static constexpr bool IC_LDS = (G >= 8) && !Model::STATE_DISTRIBUTED && !Model::SLOTS_IN_LDS;
+    static constexpr bool IC_LDS = (G >= 5) && !Model::STATE_DISTRIBUTED && !Model::SLOTS_IN_LDS;
     static constexpr int IC_DOUBLES = IC_LDS ? (Model::NS + Tab::NK * Model::NS) * (BLOCK / G) : 0;
     static __host__ __device__ constexpr int np_pad(int np) { return (np + 1) & ~1; }
 };
@@ -579,9 +579,10 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     __syncthreads();
 
-    const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
+    constexpr int GROUPS = BLOCK / G;  // trajectories per block (lanes beyond GROUPS*G idle when G is not a power of two)
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
     const int r = threadIdx.x % G;
-    if (gid >= p.N) return;  // whole groups leave together
+    if (gid >= p.N || (int)threadIdx.x >= GROUPS * G) return;  // whole groups leave together
     using Sys = FwdSys<Model, Tab, G, BLOCK>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
@@ -638,7 +639,7 @@ struct AdjSys {
     __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
     // cached forward interval: t_start/t_end in registers; u_start and the k's either in registers (IC_LDS = false)
     // or in a group-shared LDS row (IC_LDS: saves 2*NR*(NK+1) VGPRs per lane; reads are broadcasts inside the group)
-    static constexpr bool IC_LDS = (G >= 8) && !STATE_DISTRIBUTED && !SLOTS_IN_LDS;
+    static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !SLOTS_IN_LDS;
     static constexpr int IC_FIELDS = NR + Tab::NK * NR;
     double ts, te, us[IC_LDS ? 1 : NR], ks[IC_LDS ? 1 : Tab::NK][IC_LDS ? 1 : NR];
     double* ic;      // LDS: field f of this group at ic[f * icstride]
@@ -772,7 +773,8 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     }
     __syncthreads();
 
-    const int64_t gid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / G;
+    constexpr int GROUPS = BLOCK / G;
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
     const int r = threadIdx.x % G;
     using Sys = AdjSys<Model, Tab, G>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
@@ -786,7 +788,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     double lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
     static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
-    const bool in_range = gid < p.N;
+    const bool in_range = gid < p.N && (int)threadIdx.x < GROUPS * G;
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         Sys sys;
@@ -839,7 +841,25 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         double* row = p.grad_part + (size_t)wave * p.n_param;
         for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = slots[i];
     }
-    if constexpr (!Model::SLOTS_IN_LDS) {
+    if constexpr (!Model::SLOTS_IN_LDS && !pow2_group<G>()) {
+        // mu already sits in LDS ([slot][thread]): lane r of group 0 adds the r-th lanes of all groups in ascending
+        // group order and writes the wave's partial row (runtime loops: this tail must not inflate the register peak)
+        __syncthreads();
+        if ((int)threadIdx.x < G) {
+            const int64_t wave = BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
+            double* row = p.grad_part + (size_t)wave * p.n_param;
+            const double* base = slots;
+            for (int s = 0; s < NSL; ++s) {
+                const int idx = Model::slot_index(p.mc, (int)threadIdx.x, s);
+                if (idx >= 0) {
+                    double acc = 0.0;
+                    for (int gq = 0; gq < GROUPS; ++gq) acc += base[s * BLOCK + gq * G + (int)threadIdx.x];
+                    row[idx] = acc;
+                }
+            }
+        }
+    }
+    if constexpr (!Model::SLOTS_IN_LDS && pow2_group<G>()) {
     double mu[NSLA];
     static_for<0, NSL>([&](auto c) { mu[c] = mu_lds[c * BLOCK]; });
     // ---- deterministic reduction: groups of a wave (xor butterfly), then one partial row per wave ----

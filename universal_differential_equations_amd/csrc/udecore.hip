@@ -172,7 +172,7 @@ static int model_id(const ude_model_desc* m) {
 static int default_lanes(int mid) {
     switch (mid) {
         case MID_LV_TRUE: return 1;
-        case MID_LV_S1: return 4;  // measured on C2: 2.9 ms (4 lanes) vs 3.7 ms (8 lanes) per adjoint pass
+        case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
         case MID_LV_HUDSON: return 8;
         case MID_LV_TANH32: return 32;
         case MID_SEIR_TRUE: return 1;
@@ -373,8 +373,8 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     }
     p.retcode = retcode;
     const int BLOCK = l.block;
-    const int64_t threads = N * G;
-    const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
+    const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
+    const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const size_t shmem = l.lds_bytes(m->n_param, false);
     if (shmem > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)l.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -408,8 +408,8 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const int n = m->n_state, np = m->n_param;
     const int cap = c->lo.max_dense_steps > 0 ? c->lo.max_dense_steps : 256;
     const int BLOCK = l.block;
-    const int64_t threads = N * G;
-    const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
+    const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
+    const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const int64_t nwaves = (int64_t)grid * (BLOCK >= 64 ? BLOCK / 64 : 1);
     const int nf = 2 + n + l.nf * n;
     p.N = N;
