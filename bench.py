@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = library default)")
     ap.add_argument("--waves", type=int, default=0, help="adjoint kernel variant: waves per SIMD (0 = default)")
     ap.add_argument("--alg", default="tsit5")
+    ap.add_argument("--sensealg", default="adjoint", choices=["adjoint", "discrete"],
+                    help="adjoint = InterpolatingAdjoint (the north-star path); discrete = frozen-step reverse sweep (a9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -140,7 +142,8 @@ def main():
         theta_h, u0_d, t, data = synth_inputs(N, rank, device)
         alg = U.Tsit5() if a.alg == "tsit5" else U.Vern7()
         ens = U.DeviceEnsemble(models.ude_dynamics(), alg, (0.0, 3.0), t, u0_d, data=data, lanes_per_traj=a.lanes,
-                               waves_per_simd=a.waves, abstol=1e-6, reltol=1e-6)
+                               waves_per_simd=a.waves, abstol=1e-6, reltol=1e-6,
+                               sensealg=U.ForwardDiffSensitivity() if a.sensealg == "discrete" else None)
         wl_name = ("BASELINE configs[1]: LV UDE (2-5-5-5-2 rbf, 87 params, theta_init of scenario_1), %d trajectories per GPU, "
                    "%s abstol=reltol=1e-6, 31 save points, loss + InterpolatingAdjoint gradient" % (N, a.alg))
     else:
@@ -204,7 +207,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name,
-                       "trajectories_per_gpu": N, "lanes_per_trajectory": a.lanes or "default",
+                       "trajectories_per_gpu": N, "sensealg": a.sensealg, "lanes_per_trajectory": a.lanes or "default",
                        "evals_per_step_fwd": nf_fwd, "evals_per_step_bwd": nf_bwd, "failed_trajectories": int(evals[1].item()),
                        "adjoint_grad_wallclock_ms": ms_per_step, "fwd_kernel_ms": float(np.mean(fwd_ms)),
                        "bwd_kernel_ms": float(np.mean(bwd_ms))},

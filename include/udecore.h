@@ -37,6 +37,9 @@ enum {
     UDE_KIND_KPP_UDE = 5    /* nn_ode        Fisher-KPP-CNN.jl:111-126, scenario_3.jl:103-114 */
 };
 enum { UDE_ACT_IDENTITY = 0, UDE_ACT_TANH = 1, UDE_ACT_RBF = 2 /* scenario_1.jl:59 */, UDE_ACT_RELU = 3 };
+/* sensealg: InterpolatingAdjoint(autojacvec=ReverseDiffVJP()) seir_exposure.jl:140, Fisher-KPP-CNN.jl:136;
+ * discretise-then-optimise = the frozen-step derivative that ForwardDiffSensitivity() requests, scenario_1.jl:86 */
+enum { UDE_SENSE_INTERPOLATING_ADJOINT = 0, UDE_SENSE_DISCRETE = 1 };
 enum { UDE_ALG_TSIT5 = 0 /* Tsit5() scenario_1.jl:191 */, UDE_ALG_VERN7 = 1 /* Vern7() scenario_1.jl:84 */ };
 /* per-trajectory return codes mirror the SciML retcodes stored in the reference's artifacts */
 enum { UDE_RET_SUCCESS = 0, UDE_RET_MAXITERS = 1, UDE_RET_DTLESSTHANMIN = 2, UDE_RET_UNSTABLE = 3,
@@ -75,6 +78,8 @@ typedef struct {
     double dt0;         /* >0 -> initial dt instead of the Hairer heuristic */
     double qmin, qmax, gamma, qoldinit; /* <=0 -> 0.2, 10, 0.9, 1e-4 */
     double beta1, beta2;                /* <=0 -> 7/(10 order), 2/(5 order) */
+    int32_t sensealg;   /* UDE_SENSE_*: how ude_vjp / ude_loss_grad differentiate */
+    int32_t reserved;
 } ude_solve_opts;
 
 /* launch/tuning knobs of the HIP back end (not part of the reference surface) */

@@ -29,6 +29,7 @@ struct SolveOpts
     alg::Int32; maxiters::Int32
     abstol::Float64; reltol::Float64; dtmax::Float64; dt0::Float64
     qmin::Float64; qmax::Float64; gamma::Float64; qoldinit::Float64; beta1::Float64; beta2::Float64
+    sensealg::Int32; reserved::Int32   # 0 InterpolatingAdjoint, 1 discretise-then-optimise (ForwardDiffSensitivity)
 end
 
 const KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE = Int32.(0:5)
@@ -73,8 +74,8 @@ struct MI355Vern7 <: SciMLBase.AbstractODEAlgorithm end
 struct EnsembleMI355 <: SciMLBase.EnsembleAlgorithm end
 algcode(::MI355Tsit5) = Int32(0)
 algcode(::MI355Vern7) = Int32(1)
-opts(alg; abstol = 0.0, reltol = 0.0, dtmax = 0.0, dt = 0.0, maxiters = 0, kw...) =
-    SolveOpts(algcode(alg), maxiters, abstol, reltol, dtmax, dt, 0, 0, 0, 0, 0, 0)
+opts(alg; abstol = 0.0, reltol = 0.0, dtmax = 0.0, dt = 0.0, maxiters = 0, discrete = false, kw...) =
+    SolveOpts(algcode(alg), maxiters, abstol, reltol, dtmax, dt, 0, 0, 0, 0, 0, 0, discrete ? 1 : 0, 0)
 grid(saveat::Number, tspan) = collect(tspan[1]:saveat:tspan[2])
 grid(saveat, tspan) = collect(Float64, saveat)
 

@@ -84,7 +84,7 @@ int udeo_solve_dense_f64(const udeo_model_desc* m, const udeo_solve_opts* o, con
                          double* u_steps, double* k_steps, int64_t* stats) {
     dense_f64 d;
     d.cap = cap; d.n = m->n_state; d.nk = o->alg == UDEO_ALG_TSIT5 ? 7 : 16; d.nsteps = 0;
-    d.t = t_steps; d.u = u_steps; d.k = k_steps;
+    d.t = t_steps; d.u = u_steps; d.k = k_steps; d.dt = 0;
     int64_t st[UDEO_NSTATS] = {0};
     int rc = solve_one_f64(m, o, theta, u0, tspan[0], tspan[1], 0, 0, 0, &d, st);
     if (stats) memcpy(stats, st, sizeof(st));

@@ -632,9 +632,10 @@ done:
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int cap, nsteps, n, nk;
-    REAL* t; /* cap+1 */
-    REAL* u; /* n*(cap+1) */
-    REAL* k; /* n*nk*cap, step-major then stage-major */
+    REAL* t;  /* cap+1 */
+    REAL* u;  /* n*(cap+1) */
+    REAL* k;  /* n*nk*cap, step-major then stage-major */
+    REAL* dt; /* cap: the step size each accepted step used (t[j+1]-t[j] up to the tstop snap); may be NULL */
 } FN(dense);
 
 typedef struct {
@@ -679,6 +680,7 @@ static int FN(fwd_accept)(void* ctx, FN(stepinfo)* s) {
         if (d->nsteps >= d->cap) { c->overflow = 1; return 1; }
         if (s->alg == UDEO_ALG_VERN7) FN(vern7_extra)(s, c->tmp);
         const int j = d->nsteps;
+        if (d->dt) d->dt[j] = s->dt;
         d->t[j + 1] = s->t;
         memcpy(d->u + (size_t)(j + 1) * n, s->u, sizeof(REAL) * n);
         for (int q = 0; q < d->nk; ++q) memcpy(d->k + ((size_t)j * d->nk + q) * n, s->k[q], sizeof(REAL) * n);
@@ -773,6 +775,118 @@ static int FN(adj_tstop)(void* ctx, REAL t, REAL* z) {
     return mod;
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * a9 / SURVEY 8(f) N2: discretise-then-optimise gradient = what `sensealg = ForwardDiffSensitivity()`
+ * (scenario_1.jl:86, scenario_2.jl:108, scenario_3.jl:124, hudson_bay.jl:102) differentiates: the discrete
+ * Tsit5/Vern7 map with the step sequence and the save-point interpolation weights FROZEN (upstream's
+ * controller strips the duals: EEst = value(EEst)).  Reverse sweep over the stored steps, one VJP per stage
+ * (plus the lazy Vern7 stages of steps that contain a save point); exact derivative of the primal to rounding.
+ * (Upstream's own dual solve additionally lets the partials enter the error norm, which changes ITS step
+ * sequence per chunk; that cannot be restated -- this is the frozen-step derivative of the primal solve.)
+ * ARITH-SPEC order of the accumulations is documented inline; the kernels mirror it.
+ * ------------------------------------------------------------------------------------------ */
+static int FN(discrete_sweep)(const udeo_model_desc* m, const REAL* theta, const FN(dense)* d, int alg, REAL t0,
+                              const REAL* saveat, int ns, const REAL* cot, REAL* grad_theta, REAL* grad_u0,
+                              int64_t* stats) {
+    const int n = m->n_state, np = m->n_param, nk = d->nk;
+    const int S = alg == UDEO_ALG_TSIT5 ? 7 : 10;
+    const int fsal = alg == UDEO_ALG_TSIT5;
+    REAL A5[7][7], A7[10][10], AE7[6][16], CE7[6], Btab[10], BTtab[10], Ctab[10];
+    if (alg == UDEO_ALG_TSIT5) FN(tab_tsit5)(A5, Btab, BTtab, Ctab);
+    else FN(tab_vern7)(A7, Btab, BTtab, Ctab, AE7, CE7);
+    REAL* kb = (REAL*)calloc((size_t)nk * n, sizeof(REAL));   /* kbar_j */
+    REAL* ubar = (REAL*)calloc(n, sizeof(REAL));              /* cotangent of u_{n+1} carried backward */
+    REAL* un = (REAL*)malloc(sizeof(REAL) * n);               /* cotangent of u_n being built */
+    REAL* carry = (REAL*)calloc(n, sizeof(REAL));             /* FSAL: kbar_0 of the later step */
+    REAL* g = (REAL*)malloc(sizeof(REAL) * n);
+    REAL* w = (REAL*)malloc(sizeof(REAL) * n);
+    REAL* gth = (REAL*)malloc(sizeof(REAL) * (np > 0 ? np : 1));
+    REAL* acc = (REAL*)calloc(np > 0 ? np : 1, sizeof(REAL));
+    REAL bw[16];
+    int si = ns - 1;
+    int64_t nvjp = 0;
+    for (int st = d->nsteps - 1; st >= 0; --st) {
+        const REAL tn = d->t[st], tn1 = d->t[st + 1], dt = d->dt[st];
+        const REAL* u_n = d->u + (size_t)st * n;
+        REAL* kp[16];
+        for (int q = 0; q < nk; ++q) kp[q] = d->k + ((size_t)st * nk + q) * n;
+        /* (1) saves exactly at the step end feed the cotangent of u_{n+1} */
+        while (si >= 0 && saveat[si] >= tn1) {
+            if (saveat[si] == tn1) for (int c = 0; c < n; ++c) ubar[c] += cot[(size_t)si * n + c];
+            si -= 1;
+        }
+        /* (2) u_{n+1} = u_n + dt*sum B_j k_j */
+        for (int c = 0; c < n; ++c) un[c] = ubar[c];
+        for (int j = 0; j < nk; ++j)
+            for (int c = 0; c < n; ++c) kb[(size_t)j * n + c] = (j < S && Btab[j] != 0) ? (dt * Btab[j]) * ubar[c] : (REAL)0;
+        if (fsal) for (int c = 0; c < n; ++c) kb[(size_t)(S - 1) * n + c] += carry[c];
+        /* (3) saves strictly inside the step, descending: y = u_n + dt*sum b_j(theta) k_j */
+        int interior = 0;
+        while (si >= 0 && saveat[si] > tn) {
+            const REAL th = (saveat[si] - tn) / dt;
+            if (alg == UDEO_ALG_TSIT5) FN(tsit5_bth)(th, bw); else FN(vern7_bth)(th, bw);
+            for (int c = 0; c < n; ++c) {
+                const REAL dl = cot[(size_t)si * n + c];
+                un[c] += dl;
+                for (int j = 0; j < nk; ++j)
+                    if ((alg == UDEO_ALG_TSIT5) || !(j == 1 || j == 2 || j == 9))
+                        kb[(size_t)j * n + c] = R_FMA(dt * bw[j], dl, kb[(size_t)j * n + c]);
+            }
+            interior = 1;
+            si -= 1;
+        }
+        /* (4) lazy dense-output stages (Vern7), reverse order, only if a save point used them */
+        if (alg == UDEO_ALG_VERN7 && interior) {
+            for (int e = 5; e >= 0; --e) {
+                const int row = S + e;
+                FN(combine)(AE7[e], row, kp, dt, u_n, n, g);
+                for (int i = 0; i < np; ++i) gth[i] = 0;
+                FN(udeo_rhs_vjp)(m, theta, g, tn, kb + (size_t)row * n, w, gth);
+                nvjp += 1;
+                for (int i = 0; i < np; ++i) acc[i] += gth[i];
+                for (int c = 0; c < n; ++c) un[c] += w[c];
+                for (int j = 0; j < row; ++j)
+                    if (AE7[e][j] != 0)
+                        for (int c = 0; c < n; ++c) kb[(size_t)j * n + c] = R_FMA(dt * AE7[e][j], w[c], kb[(size_t)j * n + c]);
+            }
+        }
+        /* (5) main stages S-1 .. 1 */
+        for (int sidx = S - 1; sidx >= 1; --sidx) {
+            const REAL* row = alg == UDEO_ALG_TSIT5 ? A5[sidx] : A7[sidx];
+            FN(combine)(row, sidx, kp, dt, u_n, n, g);
+            for (int i = 0; i < np; ++i) gth[i] = 0;
+            FN(udeo_rhs_vjp)(m, theta, g, tn, kb + (size_t)sidx * n, w, gth);
+            nvjp += 1;
+            for (int i = 0; i < np; ++i) acc[i] += gth[i];
+            for (int c = 0; c < n; ++c) un[c] += w[c];
+            for (int j = 0; j < sidx; ++j)
+                if (row[j] != 0)
+                    for (int c = 0; c < n; ++c) kb[(size_t)j * n + c] = R_FMA(dt * row[j], w[c], kb[(size_t)j * n + c]);
+        }
+        /* (6) stage 0: k_0 = f(u_n).  FSAL: it is the previous step's last stage -- hand kbar_0 over */
+        if (fsal && st > 0) {
+            for (int c = 0; c < n; ++c) carry[c] = kb[c];
+        } else {
+            for (int i = 0; i < np; ++i) gth[i] = 0;
+            FN(udeo_rhs_vjp)(m, theta, u_n, tn, kb, w, gth);
+            nvjp += 1;
+            for (int i = 0; i < np; ++i) acc[i] += gth[i];
+            for (int c = 0; c < n; ++c) un[c] += w[c];
+        }
+        for (int c = 0; c < n; ++c) ubar[c] = un[c];
+    }
+    while (si >= 0) { /* saves at t0 (save_start) */
+        if (saveat[si] == t0) for (int c = 0; c < n; ++c) ubar[c] += cot[(size_t)si * n + c];
+        si -= 1;
+    }
+    for (int i = 0; i < np; ++i) grad_theta[i] += acc[i];
+    if (grad_u0) for (int c = 0; c < n; ++c) grad_u0[c] = ubar[c];
+    stats[4] += nvjp;
+    free(kb); free(ubar); free(un); free(carry); free(g); free(w); free(gth); free(acc);
+    return UDEO_RET_SUCCESS;
+}
+
 /* forward dense + backward; cot: n x ns.  grad_theta += ; grad_u0 (n) = */
 static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const REAL* theta,
                        const REAL* u0, REAL t0, REAL tf, const REAL* saveat, int ns,
@@ -787,13 +901,14 @@ static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const
     int ret;
     for (;;) {
         d.cap = cap; d.n = n; d.nk = nk; d.nsteps = 0;
+        d.dt = (REAL*)malloc(sizeof(REAL) * cap);
         d.t = (REAL*)malloc(sizeof(REAL) * (cap + 1));
         d.u = (REAL*)malloc(sizeof(REAL) * (size_t)n * (cap + 1));
         d.k = (REAL*)malloc(sizeof(REAL) * (size_t)n * nk * cap);
         int64_t st[4] = {0, 0, 0, 0};
         ret = FN(solve_one)(m, o, theta, u0, t0, tf, saveat, ns, pred, &d, st);
         if (ret == UDEO_RET_MAXITERS && d.nsteps >= cap && cap < (1 << 20)) {
-            free(d.t); free(d.u); free(d.k);
+            free(d.t); free(d.u); free(d.k); free(d.dt);
             cap *= 4;
             continue;
         }
@@ -802,7 +917,7 @@ static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const
     }
     /* the primal returned by concrete_solve is sol(saveat): identical interpolants to savevalues! */
     if (u_out) memcpy(u_out, pred, sizeof(REAL) * (size_t)n * ns);
-    if (ret != UDEO_RET_SUCCESS) { free(d.t); free(d.u); free(d.k); free(pred); return ret; }
+    if (ret != UDEO_RET_SUCCESS) { free(d.t); free(d.u); free(d.k); free(d.dt); free(pred); return ret; }
     /* with the dense forward pass the Vern7 lazy stages are part of the adjoint's own cost */
     stats[7] += stats[3]; stats[3] = 0;
 
@@ -820,6 +935,11 @@ static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const
         if (loss_out) *loss_out = L;
     }
 
+    if (o->sensealg == UDEO_SENSE_DISCRETE) {
+        ret = FN(discrete_sweep)(m, theta, &d, alg, t0, saveat, ns, cot, grad_theta, grad_u0, stats);
+        free(cot); free(d.t); free(d.u); free(d.k); free(d.dt); free(pred);
+        return ret;
+    }
     const int nz = n + np;
     REAL* z = (REAL*)calloc(nz, sizeof(REAL));
     FN(adjctx) ac;
@@ -842,7 +962,7 @@ static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const
     for (int i = 0; i < np; ++i) grad_theta[i] += z[n + i];
     if (grad_u0) for (int i = 0; i < n; ++i) grad_u0[i] = z[i];
     free(tst); free(ac.y); free(ac.gtheta); free(z); free(cot);
-    free(d.t); free(d.u); free(d.k); free(pred);
+    free(d.t); free(d.u); free(d.k); free(d.dt); free(pred);
     return ret;
 }
 

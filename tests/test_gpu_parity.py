@@ -363,6 +363,52 @@ def test_kpp_ude_forward_and_adjoint_match_oracle(name, nx, chain, omk, alg, oal
     assert r.grad_theta[f.stencil_offset + 3] == 0.0          # the unused conv bias never receives a gradient
 
 
+DISCRETE_CASES = [
+    ("s1_tsit5", lambda: models.ude_dynamics(), O.lv_ude_s1, U.Tsit5, O.TSIT5),
+    ("s1_vern7", lambda: models.ude_dynamics(), O.lv_ude_s1, U.Vern7, O.VERN7),
+    ("hudson_vern7", lambda: models.ude_dynamics(models.hudson_chain(), trainable="both"), O.lv_ude_hudson, U.Vern7, O.VERN7),
+    ("s2_tsit5", lambda: models.ude_dynamics(trainable="delta"), O.lv_ude_s2, U.Tsit5, O.TSIT5),
+]
+
+
+@pytest.mark.parametrize("name,mk,omk,alg,oalg", DISCRETE_CASES)
+def test_discrete_gradient_matches_oracle(golden, name, mk, omk, alg, oalg):
+    """sensealg = ForwardDiffSensitivity() (scenario_1.jl:86): frozen-step reverse sweep, bit-identical per trajectory."""
+    g, X, t = s1_data(golden)
+    th = theta_for(name.split("_")[0], golden, mk().n_param)
+    N = 50
+    u0 = ensemble_u0(X, N, 21)
+    data = np.repeat(X[None], N, axis=0)
+    ens = U.EnsembleProblem(U.ODEProblem(mk(), u0[0], (t[0], t[-1]), th), u0)
+    r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=U.ForwardDiffSensitivity())
+    ref = O.loss_grad_ensemble(omk(), O.opts(oalg, 1e-6, 1e-6, sensealg=1), u0, [t[0], t[-1]], th, t, data, nthreads=4)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)                      # incl. stats[4] = number of VJPs and dL/du0
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+    # consistent with the continuous adjoint to the solver tolerance
+    ra = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6)
+    assert np.linalg.norm(r.grad_theta - ra.grad_theta) < 1e-4 * np.linalg.norm(ra.grad_theta)
+
+
+def test_discrete_gradient_seir_and_kpp_match_oracle():
+    u0, t = seir_inputs(6)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+    th = models.seir_chain().glorot_uniform(np.random.default_rng(11))
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 21.0), th), u0)
+    r = U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=U.ForwardDiffSensitivity())
+    ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=1), u0, [0.0, 21.0], th, t, truth, row_mask=mask, nthreads=4)
+    check_per_trajectory(r, ref)
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+    th, u0, t, truth = kpp_case(26, 4, models.kpp_chain(), None)
+    f = models.nn_ode(26)
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 5.0), th), u0)
+    r = U.loss_and_gradient(ens, U.Tsit5(), truth, saveat=t, sensealg=U.ForwardDiffSensitivity())
+    ref = O.loss_grad_ensemble(O.kpp_ude(26), O.opts(O.TSIT5, sensealg=1), u0, [0.0, 5.0], th, t, truth, nthreads=4)
+    check_per_trajectory(r, ref)
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+
+
 def test_failed_trajectory_is_reported_not_summed(golden):
     g, X, t = s1_data(golden)
     th = np.array(g["initial_parameters"])

@@ -134,3 +134,125 @@ def test_ensemble_gradient_is_sum_of_trajectories(golden):
         lsum += r["loss"]
     assert np.allclose(rall["grad_theta"], gsum, rtol=1e-12, atol=1e-14)
     assert abs(rall["loss"] - lsum) < 1e-12 * lsum
+
+
+# ---------------------------------------------------------------------------------------------
+# a9 / N2: discretise-then-optimise gradient (the ForwardDiffSensitivity-equivalent, frozen step sequence)
+# ---------------------------------------------------------------------------------------------
+def _mlp_np(th, x, acts):
+    off = 0
+    dims = [2, 5, 5, 5, 2]
+    a = x
+    for l in range(4):
+        i, o = dims[l], dims[l + 1]
+        W = th[off:off + i * o].reshape(i, o).T          # column-major (out x in)
+        b = th[off + i * o:off + i * o + o]
+        z = W @ a + b
+        a = np.exp(-z * z) if acts[l] == "rbf" else z
+        off += i * o + o
+    return a
+
+
+def _fixed_step_loss(th, u0, tsteps, saveat, X, tab):
+    """Tsit5 with the step sequence FROZEN (numpy, independent of the oracle): loss = sum (u(saveat) - X)^2"""
+    f = lambda u: np.array([1.3, -1.8]) * u + _mlp_np(th, u, ["rbf", "rbf", "rbf", "id"])
+    A = {2: ["a21"], 3: ["a31", "a32"], 4: ["a41", "a42", "a43"], 5: ["a51", "a52", "a53", "a54"],
+         6: ["a61", "a62", "a63", "a64", "a65"], 7: ["a71", "a72", "a73", "a74", "a75", "a76"]}
+    u = np.array(u0, dtype=float)
+    loss, si = 0.0, 0
+    while si < len(saveat) and saveat[si] <= tsteps[0]:
+        loss += ((u - X[si]) ** 2).sum(); si += 1
+    k1 = f(u)
+    for n in range(len(tsteps) - 1):
+        dt = tsteps[n + 1] - tsteps[n]
+        ks = [k1]
+        for s in range(2, 8):
+            ks.append(f(u + dt * sum(tab[a] * ks[j] for j, a in enumerate(A[s]))))
+        unew = u + dt * sum(tab[a] * ks[j] for j, a in enumerate(A[7]))
+        while si < len(saveat) and saveat[si] <= tsteps[n + 1]:
+            ts = saveat[si]
+            if ts == tsteps[n + 1]:
+                y = unew
+            else:
+                th_ = (ts - tsteps[n]) / dt
+                b = [th_ * (tab["r11"] + th_ * (tab["r12"] + th_ * (tab["r13"] + th_ * tab["r14"])))]
+                b += [th_ * th_ * (tab["r%d2" % j] + th_ * (tab["r%d3" % j] + th_ * tab["r%d4" % j])) for j in range(2, 8)]
+                y = u + dt * sum(bj * kj for bj, kj in zip(b, ks))
+            loss += ((y - X[si]) ** 2).sum(); si += 1
+        u, k1 = unew, ks[6]
+    return loss
+
+
+def test_discrete_gradient_is_the_exact_derivative_of_the_frozen_step_map(golden):
+    g, X, t = s1_setup(golden)
+    tab = golden("tableaux")["tsit5_float64"]
+    th = np.array(g["initial_parameters"])
+    m = O.lv_ude_s1()
+    o = O.opts(O.TSIT5, 1e-6, 1e-6, sensealg=1)
+    r = O.loss_grad_ensemble(m, o, X[0], [t[0], t[-1]], th, t, X[None])
+    assert r["retcode"][0] == 0
+    assert r["stats"][0][4] == 6 * (r["stats"][0][1]) + 1               # one VJP per stage: 6 per step + the first k1
+    tsteps, usteps, ksteps, st = O.solve_dense(m, O.opts(O.TSIT5, 1e-6, 1e-6), X[0], [t[0], t[-1]], th)
+    assert abs(_fixed_step_loss(th, X[0], tsteps, t, X, tab) - r["loss"]) < 1e-12 * r["loss"]
+    fd = np.zeros_like(th)
+    for i in range(len(th)):
+        e = np.zeros_like(th); e[i] = 1e-6
+        fd[i] = (_fixed_step_loss(th + e, X[0], tsteps, t, X, tab) - _fixed_step_loss(th - e, X[0], tsteps, t, X, tab)) / 2e-6
+    rel = np.linalg.norm(r["grad_theta"] - fd) / np.linalg.norm(fd)
+    assert rel < 1e-8, rel
+    # and it agrees with the continuous adjoint to the solver tolerance (both approximate the same dL/dtheta)
+    ra = O.loss_grad_ensemble(m, O.opts(O.TSIT5, 1e-6, 1e-6), X[0], [t[0], t[-1]], th, t, X[None])
+    assert np.linalg.norm(r["grad_theta"] - ra["grad_theta"]) < 1e-5 * np.linalg.norm(fd)
+    # u0 gradient by the same check
+    fdu = np.zeros(2)
+    for i in range(2):
+        e = np.zeros(2); e[i] = 1e-6
+        fdu[i] = (_fixed_step_loss(th, X[0] + e, tsteps, t, X, tab) - _fixed_step_loss(th, X[0] - e, tsteps, t, X, tab)) / 2e-6
+    assert np.allclose(r["grad_u0"][0], fdu, rtol=1e-7)
+
+
+@pytest.mark.parametrize("mk,u,alg", [(O.lv_ude_s1, [0.44, 4.6], O.VERN7), (O.lv_ude_hudson, [0.4, 0.2], O.VERN7),
+                                      (O.lv_ude_s2, [0.44, 4.6], O.TSIT5)])
+def test_discrete_gradient_vs_finite_differences_tight_tolerance(golden, mk, u, alg):
+    """With a tight tolerance the adaptive loss is smooth enough for central differences to see the discrete gradient."""
+    g, X, t = s1_setup(golden)
+    m = mk()
+    rng = np.random.default_rng(2)
+    th = rng.uniform(-0.4, 0.4, m.n_param)
+    if m.lin_idx[1] >= 0:
+        th[m.lin_idx[1]] = 1.8
+    if m.lin_idx[0] >= 0:
+        th[m.lin_idx[0]] = 1.3
+    ts = t[::3]
+    data = X[::3]
+    r = O.loss_grad_ensemble(m, O.opts(alg, 1e-11, 1e-11, sensealg=1), u, [0.0, 3.0], th, ts, data[None])
+    assert r["retcode"][0] == 0
+
+    def loss(p):
+        out, st, rc = O.solve_ensemble(m, O.opts(alg, 1e-12, 1e-12), u, [0.0, 3.0], p, ts)
+        return float(((out[0] - data) ** 2).sum())
+
+    idx = rng.choice(m.n_param, 12, replace=False)
+    for i in idx:
+        e = np.zeros_like(th); e[i] = 1e-5
+        fd = (loss(th + e) - loss(th - e)) / 2e-5
+        assert abs(r["grad_theta"][i] - fd) < 2e-6 * max(1.0, np.abs(r["grad_theta"]).max()), (i, r["grad_theta"][i], fd)
+
+
+def test_adam_trajectory_with_discrete_gradient(golden):
+    """scenario_1.jl requests ForwardDiffSensitivity (line 86): the stored ADAM losses with the discrete gradient."""
+    g, X, t = s1_setup(golden)
+    gold = g["losses"]["data_colmajor"]
+    th = np.array(g["initial_parameters"])
+    m, o = O.lv_ude_s1(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=1)
+    eta, b1, b2, eps = 0.1, 0.9, 0.999, np.finfo(float).eps
+    mt, vt, b1t, b2t = np.zeros_like(th), np.zeros_like(th), b1, b2
+    for k in range(4):
+        r = O.loss_grad_ensemble(m, o, X[0], [t[0], t[-1]], th, t, X[None])
+        assert abs(r["loss"] - gold[k]) < (1e-11 if k == 0 else 2e-6) * gold[k], (k, r["loss"], gold[k])
+        gr = r["grad_theta"]
+        mt = b1 * mt + (1 - b1) * gr
+        vt = b2 * vt + (1 - b2) * gr * gr
+        th = th - eta * (mt / (1 - b1t)) / (np.sqrt(vt / (1 - b2t)) + eps)
+        b1t *= b1
+        b2t *= b2

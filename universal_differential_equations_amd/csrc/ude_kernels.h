@@ -455,7 +455,7 @@ struct Driver {
 
 // ---------------------------------------------------------------------------------------------
 // forward system: model RHS + saveat (savevalues!) + dense store + loss/cotangent
-// dense field layout per step: 0 t_start, 1 t_end, 2..2+NS u_start, then k[q][c]
+// dense field layout per step: 0 t_start, 1 t_end, 2 dt (the step size used), 3..3+n u_start, then k[q][c]
 // ---------------------------------------------------------------------------------------------
 template <class Model, class Tab, int G, int BLOCKDIM>
 struct FwdSys {
@@ -538,18 +538,19 @@ struct FwdSys {
             if (nsteps >= p->cap) return RET_DENSE_OVERFLOW;
             lazy();
             {
-                const int nf = 2 + n + Tab::NK * n;
+                const int nf = 3 + n + Tab::NK * n;
                 double* base = p->dense + ((size_t)nsteps * nf) * p->Npad + j;
                 if (writer) {
                     base[0] = tprev;
                     base[(size_t)1 * p->Npad] = t;
+                    base[(size_t)2 * p->Npad] = dt;
                 }
-                static_for<0, NR>([&](auto c) { if (cwrite(c)) base[(size_t)(2 + comp(c)) * p->Npad] = z[c]; });
+                static_for<0, NR>([&](auto c) { if (cwrite(c)) base[(size_t)(3 + comp(c)) * p->Npad] = z[c]; });
                 static_for<0, Tab::NK>([&](auto q) {
-                    if constexpr (Tab::dense_uses(q))
-                        static_for<0, NR>([&](auto c) {
-                            if (cwrite(c)) base[(size_t)(2 + n + q * n + comp(c)) * p->Npad] = k(q, c);
-                        });
+                    // every stage is stored (the discrete adjoint needs k2, k3, k10 too, not only the dense-output ones)
+                    static_for<0, NR>([&](auto c) {
+                        if (cwrite(c)) base[(size_t)(3 + n + q * n + comp(c)) * p->Npad] = k(q, c);
+                    });
                 });
             }
             nsteps += 1;
@@ -654,21 +655,21 @@ struct AdjSys {
 
     __device__ __forceinline__ void load_interval(int s) {
         sf = s;
-        const int nf = 2 + n + Tab::NK * n;
+        const int nf = 3 + n + Tab::NK * n;
         const double* base = p->dense + ((size_t)s * nf) * p->Npad + j;
         ts = base[0];
         te = base[(size_t)1 * p->Npad];
         if constexpr (IC_LDS) {
             // the G lanes of the group fetch the fields round-robin and publish them in the group's LDS row
             asm volatile("" ::: "memory");
-            for (int f = mctx.r; f < IC_FIELDS; f += G) ic[f * icstride] = base[(size_t)(2 + f) * p->Npad];
+            for (int f = mctx.r; f < IC_FIELDS; f += G) ic[f * icstride] = base[(size_t)(3 + f) * p->Npad];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
-            static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(2 + comp(c)) * p->Npad] : 0.0; });
+            static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p->Npad] : 0.0; });
             static_for<0, Tab::NK>([&](auto q) {
                 if constexpr (Tab::dense_uses(q))
                     static_for<0, NR>([&](auto c) {
-                        ks[q][c] = cvalid(c) ? base[(size_t)(2 + n + q * n + comp(c)) * p->Npad] : 0.0;
+                        ks[q][c] = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * p->Npad] : 0.0;
                     });
             });
         }
@@ -882,6 +883,173 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
             }
         }
     }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a9 / SURVEY 8(f) N2: discretise-then-optimise gradient -- what `sensealg = ForwardDiffSensitivity()`
+// (scenario_1.jl:86, scenario_2.jl:108, scenario_3.jl:124, hudson_bay.jl:102) differentiates: the discrete RK map
+// with the step sequence and the save-point interpolation weights frozen.  Reverse sweep over the stored steps,
+// one VJP per stage (+ the lazy Vern7 stages of steps that contain a save point); no error control, no
+// divisions.  Accumulation order = oracle/ude_oracle_impl.h: discrete_sweep (ARITH-SPEC), so per-trajectory
+// results are bit-identical to the oracle.
+// ---------------------------------------------------------------------------------------------
+template <class Model, class Tab, int G, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using L = Layout<Model, Tab, G, BLOCK>;
+    constexpr int NR = Model::NS, NSL = Model::NSL, NSLA = NSL > 0 ? NSL : 1;
+    constexpr int S = Tab::S, NK = Tab::NK, KSTRIDE = L::KSTRIDE, GROUPS = BLOCK / G;
+    constexpr bool DIST = Model::STATE_DISTRIBUTED;
+    double* th = reinterpret_cast<double*>(smem_raw);
+    double* scratch = th + Model::theta_lds(p.n_param);
+    double* kbase = scratch + Model::SCRATCH;  // k of the current step
+    double* kbbase = kbase + L::K_DOUBLES;      // kbar
+    double* slots = kbbase + L::K_DOUBLES;
+    const int np_pad = L::np_pad(p.n_param);
+    Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
+    if constexpr (Model::SLOTS_IN_LDS) {
+        for (int i = threadIdx.x; i < 3 * np_pad; i += BLOCK) slots[i] = 0.0;
+    }
+    double* acc_lds = slots + threadIdx.x;  // register-slot models: accumulator row, element c at acc_lds[c*BLOCK]
+    static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = 0.0; });
+    __syncthreads();
+
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
+    const int r = threadIdx.x % G;
+    const bool in_range = gid < p.N && (int)threadIdx.x < GROUPS * G;
+    const bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
+    if (ok) {
+        typename Model::Ctx mctx;
+        Model::init(mctx, th, scratch, slots, np_pad, p.mc, r);
+        const int n = p.n_state;
+        auto comp = [&](int c) { return DIST ? c * G + r : c; };
+        auto cvalid = [&](int c) { return comp(c) < n; };
+        auto cwrite = [&](int c) { return DIST ? cvalid(c) : r == 0; };
+        const int koff = DIST ? threadIdx.x : threadIdx.x / G;
+        auto K = [&](int j, int c) -> double& { return kbase[(j * NR + c) * KSTRIDE + koff]; };
+        auto KB = [&](int j, int c) -> double& { return kbbase[(j * NR + c) * KSTRIDE + koff]; };
+        const TabDev* tab = p.tab;
+        const double* cot;
+        size_t cot_si, cot_sc;
+        if (p.cot_in) {
+            cot = p.cot_in + (size_t)gid * p.ns * n;
+            cot_si = n;
+            cot_sc = 1;
+        } else {
+            cot = p.cot + gid;
+            cot_si = (size_t)n * p.Npad;
+            cot_sc = p.Npad;
+        }
+        auto COT = [&](int i, int c) { return cot[(size_t)i * cot_si + (size_t)comp(c) * cot_sc]; };
+        const int nsteps = p.dense_n[gid];
+        const int nf = 3 + n + NK * n;
+        double ubar[NR], un[NR], carry[NR], acc[NSLA];
+        static_for<0, NR>([&](auto c) { ubar[c] = 0.0; carry[c] = 0.0; });
+        static_for<0, NSL>([&](auto c) { acc[c] = 0.0; });
+        int si = p.ns - 1;
+        int64_t nvjp = 0;
+        // one VJP at stage input g with stage cotangent kbrow: w = (df/du)^T kbrow; parameter part into acc
+        auto stage_vjp = [&](const double* g, const double* kbrow, double* w) {
+            asm volatile("" ::: "memory");
+            if constexpr (Model::SLOTS_IN_LDS) {
+                Model::vjp_acc(mctx, g, kbrow, w, 1.0, 0.0, false);  // ab -= (df/dtheta)^T kbar (sign undone at the end)
+            } else {
+                double gs[NSLA];
+                Model::template vjp<true>(mctx, g, kbrow, w, gs);
+                static_for<0, NSL>([&](auto c) { acc[c] += gs[c]; });
+            }
+            static_for<0, NR>([&](auto c) { un[c] += w[c]; });
+            nvjp += 1;
+        };
+        for (int st = nsteps - 1; st >= 0; --st) {
+            const double* base = p.dense + ((size_t)st * nf) * p.Npad + gid;
+            const double tn = base[0], tn1 = base[(size_t)1 * p.Npad], dt = base[(size_t)2 * p.Npad];
+            double u_n[NR];
+            static_for<0, NR>([&](auto c) { u_n[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p.Npad] : 0.0; });
+            for (int q = 0; q < NK; ++q)
+                static_for<0, NR>([&](auto c) {
+                    K(q, c) = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * p.Npad] : 0.0;
+                });
+            // (1) saves exactly at the step end feed the cotangent of u_{n+1}
+            while (si >= 0 && p.saveat[si] >= tn1) {
+                if (p.saveat[si] == tn1) static_for<0, NR>([&](auto c) { if (cvalid(c)) ubar[c] += COT(si, c); });
+                si -= 1;
+            }
+            // (2) u_{n+1} = u_n + dt*sum B_j k_j
+            static_for<0, NR>([&](auto c) { un[c] = ubar[c]; });
+            for (int j = 0; j < NK; ++j) {
+                const double bj = j < S ? tab->B[j] : 0.0;
+                static_for<0, NR>([&](auto c) { KB(j, c) = bj != 0.0 ? (dt * bj) * ubar[c] : 0.0; });
+            }
+            if constexpr (Tab::FSAL) static_for<0, NR>([&](auto c) { KB(S - 1, c) += carry[c]; });
+            // (3) saves strictly inside the step, descending: y = u_n + dt*sum b_j(theta) k_j
+            bool interior = false;
+            while (si >= 0 && p.saveat[si] > tn) {
+                const double thv = (p.saveat[si] - tn) / dt;
+                double bw[NK];
+                Tab::bth(thv, bw);
+                static_for<0, NR>([&](auto c) {
+                    const double dl = cvalid(c) ? COT(si, c) : 0.0;
+                    un[c] += dl;
+                    static_for<0, NK>([&](auto j) {
+                        if constexpr (Tab::dense_uses(j)) KB(j, c) = __builtin_fma(dt * bw[j], dl, KB(j, c));
+                    });
+                });
+                interior = true;
+                si -= 1;
+            }
+            if constexpr (DIST) interior = __any(interior);  // wave-uniform (the save grid is shared anyway)
+            // (4)+(5) lazy dense-output stages (only if a save point used them), then the main stages S-1 .. 1
+            for (int row = (Tab::NEXTRA > 0 && interior) ? S + Tab::NEXTRA - 1 : S - 1; row >= 1; --row) {
+                double g[NR], kbrow[NR], w[NR];
+                static_for<0, NR>([&](auto c) {
+                    double a = tab->A[row][0] * K(0, c);
+                    for (int j = 1; j < row; ++j) a = __builtin_fma(tab->A[row][j], K(j, c), a);
+                    g[c] = __builtin_fma(dt, a, u_n[c]);
+                    kbrow[c] = KB(row, c);
+                });
+                stage_vjp(g, kbrow, w);
+                static_for<0, NR>([&](auto c) {
+                    for (int j = 0; j < row; ++j) KB(j, c) = __builtin_fma(dt * tab->A[row][j], w[c], KB(j, c));
+                });
+            }
+            // (6) stage 0: k_0 = f(u_n); FSAL: it is the previous step's last stage -- hand kbar_0 over
+            if (Tab::FSAL && st > 0) {
+                static_for<0, NR>([&](auto c) { carry[c] = KB(0, c); });
+            } else {
+                double kbrow[NR], w[NR];
+                static_for<0, NR>([&](auto c) { kbrow[c] = KB(0, c); });
+                stage_vjp(u_n, kbrow, w);
+            }
+            static_for<0, NR>([&](auto c) { ubar[c] = un[c]; });
+        }
+        while (si >= 0) {  // saves at t0 (save_start)
+            if (p.saveat[si] == p.t0) static_for<0, NR>([&](auto c) { if (cvalid(c)) ubar[c] += COT(si, c); });
+            si -= 1;
+        }
+        if (r == 0 && p.stats) p.stats[(size_t)gid * 8 + 4] = nvjp;
+        if (p.grad_u0)
+            static_for<0, NR>([&](auto c) { if (cwrite(c)) p.grad_u0[(size_t)gid * n + comp(c)] = ubar[c]; });
+        static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = acc[c]; });
+    }
+    // ---- per-wave partial gradient row (fixed order) ----
+    __syncthreads();
+    const int64_t wave = BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
+    double* row = p.grad_part + (size_t)wave * p.n_param;
+    if constexpr (Model::SLOTS_IN_LDS) {
+        for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = -slots[np_pad + i];  // ab holds the negated sum
+    } else {
+        if ((int)threadIdx.x < G) {
+            for (int s = 0; s < NSL; ++s) {
+                const int idx = Model::slot_index(p.mc, (int)threadIdx.x, s);
+                if (idx >= 0) {
+                    double a = 0.0;
+                    for (int gq = 0; gq < GROUPS; ++gq) a += slots[s * BLOCK + gq * G + (int)threadIdx.x];
+                    row[idx] = a;
+                }
+            }
+        }
     }
 }
 

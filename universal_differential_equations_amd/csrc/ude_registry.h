@@ -7,14 +7,16 @@ namespace ude {
 struct Launch {
     void (*fwd)(const KParams);
     void (*adj)(const KParams);
+    void (*dadj)(const KParams);  // discretise-then-optimise reverse sweep (a9)
     int nf;  // dense fields per step
     int G, block;
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ slots: NSL*BLOCK registers-mode mu, or 3*np_pad]
     int theta_lds, scratch, k_doubles, slots_reg;
     bool slots_lds;
-    size_t lds_bytes(int np, bool adjoint) const {
+    size_t lds_bytes(int np, bool adjoint, bool discrete = false) const {
         const size_t np_pad = (size_t)((np + 1) & ~1);
         size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + scratch + k_doubles;
+        if (discrete) d += k_doubles;  // kbar
         if (adjoint) d += slots_lds ? 3 * np_pad : (size_t)slots_reg;
         return d * sizeof(double) + 16;
     }
@@ -25,6 +27,7 @@ inline Launch make_launch() {
     Launch l;
     l.fwd = fwd_kernel<Model, Tab, G, BLOCK>;
     l.adj = adj_kernel<Model, Tab, G, BLOCK>;
+    l.dadj = dadj_kernel<Model, Tab, G, BLOCK>;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;

@@ -411,7 +411,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const int64_t nwaves = (int64_t)grid * (BLOCK >= 64 ? BLOCK / 64 : 1);
-    const int nf = 2 + n + l.nf * n;
+    const int nf = 3 + n + l.nf * n;
     p.N = N;
     p.Npad = (N + 7) / 8 * 8;
     p.ns = ns;
@@ -444,10 +444,13 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.loss_traj = loss_per_traj ? loss_per_traj : (double*)c->loss_traj.p;
     p.grad_part = (double*)c->grad_part.p;
     p.grad_u0 = grad_u0;
+    const bool discrete = o->sensealg == UDE_SENSE_DISCRETE;
+    if (o->sensealg != UDE_SENSE_INTERPOLATING_ADJOINT && !discrete) return fail(c, UDE_ERR_INVALID, "unknown sensealg %d", o->sensealg);
+    void (*bwd)(const KParams) = discrete ? l.dadj : l.adj;
     const size_t shmem_f = l.lds_bytes(np, false);
-    const size_t shmem_a = l.lds_bytes(np, true);
+    const size_t shmem_a = l.lds_bytes(np, true, discrete);
     if (shmem_a > 64 * 1024)  // more than the default dynamic-LDS limit: opt in (MI355X has 160 KiB per CU)
-        HIPCHK(c, hipFuncSetAttribute((const void*)l.adj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
+        HIPCHK(c, hipFuncSetAttribute((const void*)bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
     if (shmem_f > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)l.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, sizeof(double) * (size_t)nwaves * np, c->stream));
@@ -456,7 +459,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(l.adj, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
+    hipLaunchKernelGGL(bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->ev_fwd = c->ev_bwd = true;

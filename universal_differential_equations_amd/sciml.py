@@ -43,6 +43,15 @@ class ReverseDiffVJP:
     pass
 
 
+class ForwardDiffSensitivity:
+    """sensealg = ForwardDiffSensitivity()  (scenario_1.jl:86, scenario_2.jl:108, scenario_3.jl:124, hudson_bay.jl:102):
+    discretise-then-optimise.  Here: the exact reverse-mode derivative of the discrete Tsit5/Vern7 map of the primal
+    solve with its step sequence frozen -- one VJP per stage, no second adaptive solve."""
+
+    def __init__(self, convert_tspan=None):
+        pass
+
+
 class EnsembleMI355:
     """ensemble algorithm tag: trajectories run as lane groups of the fused HIP kernels"""
 
@@ -122,9 +131,10 @@ class Engine:
         return out
 
 
-def _opts(alg, abstol=None, reltol=None, dtmax=None, dt=None, maxiters=None, **kw):
+def _opts(alg, abstol=None, reltol=None, dtmax=None, dt=None, maxiters=None, sensealg=None, **kw):
     o = SolveOpts()
     o.alg = alg.alg if not isinstance(alg, int) else alg
+    o.sensealg = 1 if isinstance(sensealg, ForwardDiffSensitivity) else 0
     o.abstol = abstol or 0.0
     o.reltol = reltol or 0.0
     o.dtmax = dtmax or 0.0
@@ -250,7 +260,7 @@ class GradResult:
     pass
 
 
-def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblealg, kw):
+def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblealg, kw, sensealg=None):
     ens = isinstance(prob, EnsembleProblem)
     base = prob.prob if ens else prob
     saveat = base.kwargs.get("saveat") if saveat is None else saveat
@@ -258,7 +268,7 @@ def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblea
     eng = Engine.get(device)
     if isinstance(ensemblealg, EnsembleMI355):
         eng.set_launch(ensemblealg.lanes_per_traj, ensemblealg.max_dense_steps)
-    o = _opts(alg, **kw)
+    o = _opts(alg, sensealg=sensealg, **kw)
     u0 = _np(prob.u0s if ens else base.u0)
     if u0.ndim == 1:
         u0 = u0[None, :]
@@ -299,13 +309,13 @@ def loss_and_gradient(prob, alg, data, row_mask=None, saveat=None, sensealg=None
     """loss(theta) = sum(abs2, data[rows,:] .- Array(solve(...))[rows,:]) and dloss/dtheta by the
     interpolating adjoint (seir_exposure.jl:137-147; Fisher-KPP-CNN.jl:134-143; scenario_1.jl:82-94),
     summed over an ensemble.  data: (N, ns, n)."""
-    return _grad_common(prob, alg, data, None, row_mask, saveat, device, ensemblealg, kw)
+    return _grad_common(prob, alg, data, None, row_mask, saveat, device, ensemblealg, kw, sensealg)
 
 
 def adjoint_pullback(prob, alg, cotangent, saveat=None, sensealg=None, ensemblealg=None, device=0, **kw):
     """The ChainRules pullback of concrete_solve under InterpolatingAdjoint: cotangent (N, ns, n) of
     Array(sol) -> (grad_theta, grad_u0)."""
-    return _grad_common(prob, alg, None, cotangent, None, saveat, device, ensemblealg, kw)
+    return _grad_common(prob, alg, None, cotangent, None, saveat, device, ensemblealg, kw, sensealg)
 
 
 # ---- device-resident path (torch CUDA tensors; used by bench.py and the training loop) -------------------
@@ -314,10 +324,10 @@ class DeviceEnsemble:
     enqueues on torch's current stream and returns torch tensors; nothing touches the host."""
 
     def __init__(self, f, alg, tspan, saveat, u0, data=None, row_mask=None, lanes_per_traj=0, max_dense_steps=0,
-                 waves_per_simd=0, **kw):
+                 waves_per_simd=0, sensealg=None, **kw):
         import torch
         self.torch = torch
-        self.f, self.o = f, _opts(alg, **kw)
+        self.f, self.o = f, _opts(alg, sensealg=sensealg, **kw)
         dev = u0.device
         assert dev.type == "cuda" and u0.dtype == torch.float64
         self.eng = Engine.get(dev.index or 0)
