@@ -359,7 +359,8 @@ struct KppUde : LinearTheta {
     static constexpr int a_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += Net::dim(i); return s; }
     static constexpr int d_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += Net::dim(i + 1); return s; }
     static constexpr int NPT = G * PPL;
-    static constexpr int SCRATCH = 2 * NPT + 4 + (rows_a() + rows_d()) * G;  // u row, lambda row, A tile, D tile
+    static constexpr int RA = rows_a() | 1, RD = rows_d() | 1;                // odd row strides of the [point][row] tiles
+    static constexpr int SCRATCH = 2 * NPT + 4 + (RA + RD) * G;               // u row, lambda row, A tile, D tile
     struct Ctx {
         const double* th;
         const double* nn;
@@ -372,7 +373,7 @@ struct KppUde : LinearTheta {
     static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r) {
         c.th = th_lds;
         c.nn = th_lds + mc.nn_offset;
-        c.urow = scratch; c.lrow = scratch + NPT + 2; c.A = scratch + 2 * NPT + 4; c.Dt = c.A + rows_a() * G;
+        c.urow = scratch; c.lrow = scratch + NPT + 2; c.A = scratch + 2 * NPT + 4; c.Dt = c.A + RA * G;
         c.r = r; c.n = mc.n_state; c.so = mc.stencil_offset; c.d0o = mc.d0_offset; c.nno = mc.nn_offset;
         c.w1 = th_lds[c.so]; c.w2 = th_lds[c.so + 1]; c.w3 = th_lds[c.so + 2]; c.D0 = th_lds[c.d0o];
         for (int m = 0; m < NSL; ++m) {
@@ -439,10 +440,10 @@ struct KppUde : LinearTheta {
                 Mlp::forward(c.nn, 0, &ui, cache, y);
                 static_for<0, L>([&](auto lc) {
                     constexpr int l = lc;
-                    static_for<0, Net::dim(l)>([&](auto k) { c.A[(a_off(l) + k) * G + c.r] = cache.a[l][k]; });
+                    static_for<0, Net::dim(l)>([&](auto k) { c.A[c.r * RA + (a_off(l) + k)] = cache.a[l][k]; });
                 });
                 Mlp::template vjp_sink<false>(c.nn, 0, cache, &li, gx, (double*)nullptr,
-                                              [&](int l, int m, double d) { c.Dt[(d_off_rt(l) + m) * G + c.r] = d; });
+                                              [&](int l, int m, double d) { c.Dt[c.r * RD + (d_off_rt(l) + m)] = d; });
                 gxi = gx[0];
             }
             // transpose of the periodic stencil (the oracle's expression)
@@ -458,12 +459,14 @@ struct KppUde : LinearTheta {
                 static_for<0, NSL>([&](auto mc) {
                     constexpr int m = mc;
                     if (c.kind[m] == 0) {
-                        const double* dr = c.Dt + c.d_row[m] * G;
+                        // tiles are [point][row] (row stride odd): the owners of different parameters read different
+                        // banks of the same point's row block -- no bank conflicts in this (dominant) loop
+                        const double* dr = c.Dt + c.d_row[m];
                         if (c.a_row[m] >= 0) {
-                            const double* ar = c.A + c.a_row[m] * G;
-                            for (int q = 0; q < npts; ++q) acc[m] += dr[q] * ar[q];
+                            const double* ar = c.A + c.a_row[m];
+                            for (int q = 0; q < npts; ++q) acc[m] += dr[q * RD] * ar[q * RA];
                         } else {
-                            for (int q = 0; q < npts; ++q) acc[m] += dr[q];
+                            for (int q = 0; q < npts; ++q) acc[m] += dr[q * RD];
                         }
                     }
                 });
