@@ -297,8 +297,11 @@ struct Driver {
                     static_for<0, NR>([&](auto c) { zs[c] = z[c]; });
                 } else {
                     static_for<0, NR>([&](auto c) {
+                        // all S-1 possible terms, unrolled: the coefficients of stages >= s are zero in the table and the
+                        // (zero-initialised, always finite) k storage makes fma(0, k, acc) == acc exact -- one batch of
+                        // scalar + LDS loads and one wait per stage instead of a load-wait-fma round trip per term
                         double acc = tab->A[s][0] * K(0, c);
-                        for (int j = 1; j < s; ++j) acc = __builtin_fma(tab->A[s][j], K(j, c), acc);
+                        static_for<1, S - 1>([&](auto j) { acc = __builtin_fma(tab->A[s][j], K(j, c), acc); });
                         zs[c] = __builtin_fma(dt, acc, z[c]);
                     });
                 }
@@ -578,6 +581,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     double* scratch = th + Model::theta_lds(p.n_param);
     double* kbase = scratch + Model::SCRATCH;
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
+    for (int i = threadIdx.x; i < L::K_DOUBLES; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
     __syncthreads();
 
     constexpr int GROUPS = BLOCK / G;  // trajectories per block (lanes beyond GROUPS*G idle when G is not a power of two)
@@ -769,6 +773,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     double* slots = kbase + L::K_DOUBLES;
     const int np_pad = L::np_pad(p.n_param);
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
+    for (int i = threadIdx.x; i < L::K_DOUBLES; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
     if constexpr (Model::SLOTS_IN_LDS) {
         for (int i = threadIdx.x; i < 3 * np_pad; i += BLOCK) slots[i] = 0.0;
     }
