@@ -163,23 +163,60 @@ struct CoopMlp {
         double ao[L][MAXOWN];     // their activations
     };
 
-    // th: NN parameters (LDS or global), r: lane index inside the group
+    // Register-resident copy of the weights THIS lane touches: the rows of its neurons (forward), the columns of
+    // the next layer at its neurons (backward) and the first layer (input cotangent).  Loaded once per kernel; takes
+    // the LDS round trips of the weight fetches out of the per-evaluation latency chain.
+    struct WReg {
+        double row[L][MAXOWN][MAXD + 1];  // [l][m][k], bias at k = dim(l)
+        double col[L][MAXOWN][MAXD];      // [l][m][i] = W_{l+1}[i, j]
+        double w0[MAXD * MAXD];           // W_0[j + k*out]
+    };
     template <class P>
-    static __device__ __forceinline__ void forward(const P* th, int r, const double* x, Cache& c, double* y) {
-        static_for<0, N::dim(0)>([&](auto k) { c.a[0][k] = x[k]; });
+    static __device__ __forceinline__ void load_weights(const P* th, int r, WReg& w) {
         static_for<0, L>([&](auto lc) {
             constexpr int l = lc;
             constexpr int in = N::dim(l), out = N::dim(l + 1);
             const P* W = th + N::off(l);
-            const P* b = W + in * out;
+            static_for<0, own(l)>([&](auto mc) {
+                constexpr int m = mc;
+                const int j = r + m * G;
+                const int jj = ((own(l) * G == out) || (j < out)) ? j : 0;
+                static_for<0, in>([&](auto k) { w.row[l][m][k] = (double)W[jj + k * out]; });
+                w.row[l][m][in] = (double)W[in * out + jj];
+                if constexpr (l + 1 < L) {
+                    constexpr int out2 = N::dim(l + 2);
+                    const P* W2 = th + N::off(l + 1);
+                    static_for<0, out2>([&](auto i) { w.col[l][m][i] = (double)W2[i + jj * out2]; });
+                }
+            });
+        });
+        static_for<0, N::dim(0) * N::dim(1)>([&](auto i) { w.w0[i] = (double)th[N::off(0) + i]; });
+    }
+
+    // WS = const P* (weights read from LDS/global at every use) or WReg (register-resident copy)
+    template <class WS>
+    static constexpr bool ws_is_reg = std::is_same<WS, WReg>::value;
+
+    // th: NN parameters (LDS or global) or a WReg; r: lane index inside the group
+    template <class WS>
+    static __device__ __forceinline__ void forward(const WS& th, int r, const double* x, Cache& c, double* y) {
+        static_for<0, N::dim(0)>([&](auto k) { c.a[0][k] = x[k]; });
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            constexpr int in = N::dim(l), out = N::dim(l + 1);
             static_for<0, own(l)>([&](auto mc) {
                 constexpr int m = mc;
                 const int j = r + m * G;
                 const bool valid = (own(l) * G == out) || (j < out);
                 const int jj = valid ? j : 0;
                 double acc = 0.0;
-                static_for<0, in>([&](auto k) { acc = __builtin_fma((double)W[jj + k * out], c.a[l][k], acc); });
-                acc += (double)b[jj];
+                if constexpr (ws_is_reg<WS>) {
+                    static_for<0, in>([&](auto k) { acc = __builtin_fma(th.row[l][m][k], c.a[l][k], acc); });
+                    acc += th.row[l][m][in];
+                } else {
+                    static_for<0, in>([&](auto k) { acc = __builtin_fma((double)th[N::off(l) + jj + k * out], c.a[l][k], acc); });
+                    acc += (double)th[N::off(l) + in * out + jj];
+                }
                 c.z[l][m] = acc;
                 c.ao[l][m] = valid ? act_fwd<N::act(l)>(acc) : 0.0;
             });
@@ -196,14 +233,14 @@ struct CoopMlp {
     struct NoSink {
         __device__ __forceinline__ void operator()(int, int, double) const {}
     };
-    template <bool WANT_PARAM, class P>
-    static __device__ __forceinline__ void vjp(const P* th, int r, const Cache& c, const double* gy, double* gx,
+    template <bool WANT_PARAM, class WS>
+    static __device__ __forceinline__ void vjp(const WS& th, int r, const Cache& c, const double* gy, double* gx,
                                                double* g) {
         vjp_sink<WANT_PARAM>(th, r, c, gy, gx, g, NoSink{});
     }
     // sink(l, m, d): receives the delta of this lane's m-th neuron of layer l (pointwise networks export it)
-    template <bool WANT_PARAM, class P, class Sink>
-    static __device__ __forceinline__ void vjp_sink(const P* th, int r, const Cache& c, const double* gy, double* gx,
+    template <bool WANT_PARAM, class WS, class Sink>
+    static __device__ __forceinline__ void vjp_sink(const WS& th, int r, const Cache& c, const double* gy, double* gx,
                                                     double* g, Sink sink) {
         static_assert(N::act(L - 1) == ACT_IDENTITY, "output layer must be linear");
         double dall[MAXD];  // replicated delta of the layer above
@@ -223,9 +260,14 @@ struct CoopMlp {
                     static_for<1, out>([&](auto i) { gp = (jj == i) ? dall[i] : gp; });
                 } else {
                     constexpr int out2 = N::dim(l + 2);
-                    const P* W2 = th + N::off(l + 1);  // column jj of the next layer's W (contiguous)
-                    gp = 0.0;
-                    static_for<0, out2>([&](auto i) { gp = __builtin_fma((double)W2[i + jj * out2], dall[i], gp); });
+                    gp = 0.0;  // column jj of the next layer's W (contiguous in theta)
+                    if constexpr (ws_is_reg<WS>) {
+                        static_for<0, out2>([&](auto i) { gp = __builtin_fma(th.col[l][m][i], dall[i], gp); });
+                    } else {
+                        static_for<0, out2>([&](auto i) {
+                            gp = __builtin_fma((double)th[N::off(l + 1) + i + jj * out2], dall[i], gp);
+                        });
+                    }
                 }
                 const double d = valid ? gp * act_bwd<N::act(l)>(c.z[l][m], c.ao[l][m]) : 0.0;
                 down[m] = d;
@@ -248,10 +290,13 @@ struct CoopMlp {
                     constexpr int j = jc;
                     d0[j] = group_bcast<G, j % G>(down[j / G]);
                 });
-                const P* W0 = th + N::off(0);
                 static_for<0, in>([&](auto k) {
                     double s = 0.0;
-                    static_for<0, out>([&](auto j) { s = __builtin_fma((double)W0[j + k * out], d0[j], s); });
+                    if constexpr (ws_is_reg<WS>) {
+                        static_for<0, out>([&](auto j) { s = __builtin_fma(th.w0[j + k * out], d0[j], s); });
+                    } else {
+                        static_for<0, out>([&](auto j) { s = __builtin_fma((double)th[N::off(0) + j + k * out], d0[j], s); });
+                    }
                     gx[k] = s;
                 });
             }

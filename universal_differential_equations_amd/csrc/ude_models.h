@@ -76,12 +76,15 @@ struct LvUde : LinearTheta {
     static constexpr int NS = 2;
     static constexpr int NSL = Mlp::NSLOT + 2;  // + the two (optional) trainable diagonal coefficients
     static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = false;
+    // weights in registers when the lane's share is small (narrow layers spread over >= 5 lanes), else read from LDS
+    static constexpr bool REGW = (G >= 5) && (Net::maxdim() <= 8);
     struct Ctx {
         const double* th;   // full theta (LDS)
         const double* nn;   // th + nn_offset
         double lin[2];
         double lead_on[2];  // sign if this lane owns a trainable diagonal coefficient, else 0
         int r;
+        typename Mlp::WReg w;  // (unused members are never materialised when REGW is false)
     };
     static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double*, double*, int, const ModelConsts& mc, int r) {
         c.th = th_lds;
@@ -91,11 +94,13 @@ struct LvUde : LinearTheta {
             c.lin[i] = mc.lin_idx[i] >= 0 ? mc.lin_sign[i] * th_lds[mc.lin_idx[i]] : mc.lin_const[i];
             c.lead_on[i] = (mc.lin_idx[i] >= 0 && r == 0) ? mc.lin_sign[i] : 0.0;
         }
+        if constexpr (REGW) Mlp::load_weights(c.nn, r, c.w);
     }
     static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
         typename Mlp::Cache cache;
         double y[2];
-        Mlp::forward(c.nn, c.r, u, cache, y);
+        if constexpr (REGW) Mlp::forward(c.w, c.r, u, cache, y);
+        else Mlp::forward(c.nn, c.r, u, cache, y);
         du[0] = __builtin_fma(c.lin[0], u[0], y[0]);
         du[1] = __builtin_fma(c.lin[1], u[1], y[1]);
     }
@@ -104,8 +109,13 @@ struct LvUde : LinearTheta {
                                                double* g) {
         typename Mlp::Cache cache;
         double y[2], gx[2];
-        Mlp::forward(c.nn, c.r, u, cache, y);
-        Mlp::template vjp<WANT_PARAM>(c.nn, c.r, cache, lam, gx, g);
+        if constexpr (REGW) {
+            Mlp::forward(c.w, c.r, u, cache, y);
+            Mlp::template vjp<WANT_PARAM>(c.w, c.r, cache, lam, gx, g);
+        } else {
+            Mlp::forward(c.nn, c.r, u, cache, y);
+            Mlp::template vjp<WANT_PARAM>(c.nn, c.r, cache, lam, gx, g);
+        }
         dlam[0] = __builtin_fma(c.lin[0], lam[0], gx[0]);
         dlam[1] = __builtin_fma(c.lin[1], lam[1], gx[1]);
         if constexpr (WANT_PARAM) {
