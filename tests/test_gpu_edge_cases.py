@@ -91,3 +91,26 @@ def test_adam_then_bfgs_reduce_the_scenario1_loss(golden):
         assert abs(l1[k] - gold[k]) < 1e-4 * gold[k], (k, l1[k], gold[k])      # the stored ADAM trajectory (ForwardDiff gradients upstream)
     th2, l2 = training.bfgs(lg, th1, initial_stepnorm=0.01, maxiters=40)
     assert l2[-1] < l2[0] and l2[-1] < 0.5 * l1[-1]
+
+
+def test_scenario2_segment_loss_as_one_ensemble(golden):
+    """scenario_2.jl:113-124 through the ensemble API (examples/scenario_2.py): stored losses[0] = 5298.020541174686."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("scenario_2", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "scenario_2.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g, XS, TS, YS = mod.build()
+    assert XS.shape == (5, 13)
+    lg = mod.make_loss(XS, TS, YS)
+    th = np.array(g["initial_parameters"])
+    l0, g0 = lg(th)
+    gold = g["losses"]["data_colmajor"]
+    assert abs(l0 - gold[0]) < 1e-11 * gold[0]
+    # gradient of the mixed abs2/abs loss + regulariser: directional finite difference
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=th.size)
+    d /= np.linalg.norm(d)
+    h = 1e-6
+    fd = (lg(th + h * d)[0] - lg(th - h * d)[0]) / (2 * h)
+    assert abs(fd - g0 @ d) < 2e-5 * abs(fd)
