@@ -118,6 +118,7 @@ struct Driver {
     static constexpr int S = Tab::S, NK = Tab::NK;
     static constexpr bool USE_FSAL = Tab::FSAL && !Sys::ALWAYS_K0;
     static constexpr bool LDS_SLOTS = Sys::SLOTS_IN_LDS;  // slot state + accumulators are theta-indexed LDS arrays
+    static constexpr bool SLOT_FSAL = USE_FSAL && NSL > 0 && !LDS_SLOTS;  // stage-0 slot derivative handed over in LDS
     // stage derivatives of a REPLICATED state are stored once per group (all lanes read/write the same word)
     static constexpr int KSTRIDE = Sys::STATE_DISTRIBUTED ? BLOCK : BLOCK / G;
 
@@ -131,9 +132,10 @@ struct Driver {
     // z: replicated state (registers).  Integrates from t0 along tdir through sys' tstops.
     static __device__ __forceinline__ int run(Sys& sys, const Opts& o, const TabDev* __restrict__ tab, double (&z)[NR],
                                               double* kl, double* mu, double t0, double tdir, double ntot, Stats& st,
-                                              double* gtmp = nullptr) {
-        // gtmp: per-thread LDS scratch (element c at gtmp[c * BLOCK]) that parks the slot derivative f0 of the
-        // initial-dt heuristic across its second evaluation (keeps the register peak of the kernel down)
+                                              double* gtmp = nullptr, double* gtmp2 = nullptr) {
+        // gtmp: per-thread LDS row (element c at gtmp[c * BLOCK]) holding the slot derivative of stage 0: parked there
+        // by the initial-dt heuristic, and -- FSAL tableaux -- handed over from the last stage of an accepted step
+        // (gtmp2 receives the last stage's slot derivative; the two rows swap on acceptance)
         double accb[NSLA], acce[NSLA];
         double t = t0, dt, qold = o.qoldinit, q11 = 1.0;
         bool accept = true, done = false;
@@ -148,6 +150,7 @@ struct Driver {
                 double kr[NR], gs[NSLA];
                 sys.eval(t, z, kr, gs);
                 static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
+                if constexpr (SLOT_FSAL) static_for<0, NSL>([&](auto c) { gtmp[c * BLOCK] = gs[c]; });
             }
             if constexpr (Tab::FSAL) st.nf += 1;
         } else {
@@ -291,6 +294,14 @@ struct Driver {
 
             // ---- perform_step!: runtime stage loop (wave-uniform s) ----
             double znew[NR];
+            if constexpr (SLOT_FSAL) {
+                const double bs = tab->B[0], es = tab->BT[0];
+                static_for<0, NSL>([&](auto c) {
+                    const double g0 = gtmp[c * BLOCK];
+                    accb[c] = bs * g0;
+                    acce[c] = es * g0;
+                });
+            }
             for (int s = USE_FSAL ? 1 : 0; s < S; ++s) {
                 double zs[NR], kr[NR], gs[NSLA];
                 if (s == 0) {
@@ -321,6 +332,9 @@ struct Driver {
                             accb[c] = __builtin_fma(bs, gs[c], accb[c]);
                             acce[c] = __builtin_fma(es, gs[c], acce[c]);
                         });
+                    }
+                    if constexpr (SLOT_FSAL) {
+                        if (s == S - 1) static_for<0, NSL>([&](auto c) { gtmp2[c * BLOCK] = gs[c]; });
                     }
                 }
             }
@@ -433,6 +447,7 @@ struct Driver {
                     static_for<0, NSL>([&](auto c) { mu[c * BLOCK] = accb[c]; });
                 }
                 if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
+                if constexpr (SLOT_FSAL) { double* tsw = gtmp; gtmp = gtmp2; gtmp2 = tsw; }
                 if (bad) { ret = RET_UNSTABLE; done = true; }
                 if (t == tstop) {  // handle_tstop! + callbacks
                     const bool modified = sys.at_tstop(t, z);
@@ -444,6 +459,7 @@ struct Driver {
                             double kr[NR], gs[NSLA];
                             sys.eval(t, z, kr, gs);
                             static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
+                            if constexpr (SLOT_FSAL) static_for<0, NSL>([&](auto c) { gtmp[c * BLOCK] = gs[c]; });
                         }
                     }
                 }
@@ -632,8 +648,10 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
 template <class Model, class Tab, int G>
 struct AdjSys {
     static constexpr int NR = Model::NS, NSL = Model::NSL;
-    static constexpr bool ALWAYS_K0 = true;  // stage 0 re-evaluated every step: no FSAL slot storage, uniform flow
     static constexpr bool SLOTS_IN_LDS = Model::SLOTS_IN_LDS, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
+    // LDS-slot models re-evaluate stage 0 every step (its parameter cotangent is folded straight into the shared
+    // accumulators); register-slot models hand k_S -> k_0 AND its slot derivative over (FSAL, as upstream)
+    static constexpr bool ALWAYS_K0 = SLOTS_IN_LDS;
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;
@@ -790,7 +808,8 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     // register-slot mode: slot state mu of thread tid, element c at mu_lds[c * BLOCK]
     double* mu_lds = slots + threadIdx.x;
     double* gtmp = slots + (size_t)NSLA * BLOCK + threadIdx.x;        // initial-dt scratch, element c at gtmp[c * BLOCK]
-    double* icbase = slots + (size_t)2 * NSLA * BLOCK;                 // interval cache rows (IC_LDS), one per group
+    double* gtmp2 = slots + (size_t)2 * NSLA * BLOCK + threadIdx.x;    // last-stage slot derivative (FSAL hand-over)
+    double* icbase = slots + (size_t)3 * NSLA * BLOCK;                 // interval cache rows (IC_LDS), one per group
     double lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
     static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
@@ -820,7 +839,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         sys.load_interval(sys.nsteps - 1);
         sys.at_tstop(p.tf, lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
-        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st, gtmp);
+        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st, gtmp, gtmp2);
         if (r == 0) {
             if (p.stats) {
                 int64_t* s = p.stats + (size_t)gid * 8;

@@ -34,7 +34,7 @@ inline Launch make_launch() {
     l.theta_lds = Model::theta_lds(7) == 8 ? -1 : Model::theta_lds(0);
     l.scratch = Model::SCRATCH;
     l.k_doubles = Layout<Model, Tab, G, BLOCK>::K_DOUBLES;
-    l.slots_reg = 2 * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
+    l.slots_reg = 3 * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
     l.slots_lds = Model::SLOTS_IN_LDS;
     return l;
 }
