@@ -149,7 +149,8 @@ def main():
     else:
         w = synth_inputs_other(a.workload, N, rank, device)
         theta_h, u0_d, t, data, mask = w["theta"], w["u0"], w["t"], w["data"], w["mask"]
-        ens = U.DeviceEnsemble(w["f"], w["alg"], w["tspan"], t, u0_d, data=data, row_mask=mask, **w["tol"])
+        ens = U.DeviceEnsemble(w["f"], w["alg"], w["tspan"], t, u0_d, data=data, row_mask=mask, lanes_per_traj=a.lanes,
+                               sensealg=U.ForwardDiffSensitivity() if a.sensealg == "discrete" else None, **w["tol"])
         wl_name = {"seir": "BASELINE configs[2] per-GPU share: SEIR exposure UDE (7 states, NN 3-64-64-1 tanh, 4481 params), %d trajectories "
                            "per GPU, Vern7 abstol=reltol=1e-6, 22 save points, loss rows 2:4 + InterpolatingAdjoint gradient",
                    "kpp": "BASELINE configs[3]: Fisher-KPP UDE, 1024 points (dx = 0.04), NN 1-10-20-10-1 tanh + 3-tap stencil (466 params), "

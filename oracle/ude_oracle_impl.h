@@ -38,6 +38,34 @@ static inline REAL FN(dact)(int a, REAL z, REAL av) {
 
 #define UDEO_MAXW 128 /* max layer width supported by the oracle's stack buffers */
 
+/* ARITH-SPEC dot product of one matrix-vector product with `nres` results of `n` terms each; term i = w[i*ws] * x[i].
+ *   n < 64            : one fma chain in ascending order started from 0
+ *   n >= 64, nres >= 64: blocks of 16 consecutive terms, each an fma chain started from 0; the block sums are added
+ *                       left to right (the device splits the blocks over the wavefronts of a trajectory)
+ *   n >= 64, nres < 64 : rounded products, then the binary tree over adjacent index pairs (the device's xor
+ *                       butterfly across the 64 lanes of a wavefront); n must be a power of two            */
+static inline REAL FN(wide_dot)(int n, int nres, const REAL* w, size_t ws, const REAL* x) {
+    if (n < 64 || (n % 16) != 0) {
+        REAL acc = 0;
+        for (int i = 0; i < n; ++i) acc = R_FMA(w[(size_t)i * ws], x[i], acc);
+        return acc;
+    }
+    if (nres >= 64 || (n & (n - 1)) != 0) {
+        REAL tot = 0;
+        for (int b = 0; b < n; b += 16) {
+            REAL acc = 0;
+            for (int i = b; i < b + 16; ++i) acc = R_FMA(w[(size_t)i * ws], x[i], acc);
+            tot = b == 0 ? acc : tot + acc;
+        }
+        return tot;
+    }
+    REAL v[UDEO_MAXW];
+    for (int i = 0; i < n; ++i) v[i] = w[(size_t)i * ws] * x[i];
+    for (int m = n; m > 1; m >>= 1)
+        for (int i = 0; i < m / 2; ++i) v[i] = v[2 * i] + v[2 * i + 1];
+    return v[0];
+}
+
 /* forward; zs/as: per-layer pre-activations / activations ([layer][UDEO_MAXW]); as[0] = input copy */
 static void FN(mlp_forward)(const udeo_model_desc* m, const REAL* p, const REAL* x,
                             REAL zs[][UDEO_MAXW], REAL as[][UDEO_MAXW]) {
@@ -47,8 +75,9 @@ static void FN(mlp_forward)(const udeo_model_desc* m, const REAL* p, const REAL*
         const REAL* W = p;
         const REAL* b = p + (size_t)in * out;
         for (int j = 0; j < out; ++j) {
-            REAL acc = 0; /* ARITH-SPEC: fma chain in ascending input order from 0, then + b (Lux: W*x .+ b) */
-            for (int k = 0; k < in; ++k) acc = R_FMA(W[j + (size_t)k * out], as[l][k], acc);
+            /* ARITH-SPEC: fma chain in ascending input order from 0, then + b (Lux: W*x .+ b); dots of >= 64 terms
+             * follow the wide-dot rule (see FN(wide_dot)) */
+            REAL acc = FN(wide_dot)(in, out, W + j, (size_t)out, as[l]);
             acc += b[j];
             zs[l][j] = acc;
             as[l + 1][j] = FN(act)(m->act[l], acc);
@@ -80,11 +109,7 @@ static void FN(mlp_vjp)(const udeo_model_desc* m, const REAL* p0, REAL zs[][UDEO
                 for (int j = 0; j < out; ++j) gW[j + (size_t)k * out] += delta[j] * as[l][k];
             for (int j = 0; j < out; ++j) gb[j] += delta[j];
         }
-        for (int k = 0; k < in; ++k) {
-            REAL acc = 0;
-            for (int j = 0; j < out; ++j) acc = R_FMA(W[j + (size_t)k * out], delta[j], acc);
-            prev[k] = acc;
-        }
+        for (int k = 0; k < in; ++k) prev[k] = FN(wide_dot)(out, in, W + (size_t)k * out, (size_t)1, delta);
         for (int k = 0; k < in; ++k) delta[k] = prev[k];
     }
     for (int k = 0; k < m->dims[0]; ++k) gx[k] = delta[k];

@@ -51,9 +51,43 @@ __device__ __forceinline__ double group_bcast(double x) {
 
 // sum over the G lanes of a group; every lane receives the same bits (xor butterfly of commutative adds, or
 // the same sequential order on every lane)
+constexpr int DPP_ROW_MIRROR = 0x140;  // lane i <- lane 15-i inside each row of 16
+// scratch of the cross-wave reductions (trajectories spanning several wavefronts of one block)
+__device__ __forceinline__ double* xwave_buf() {
+    __shared__ double buf[16];
+    return buf;
+}
+// value of lane k (wave-uniform k) of this wavefront, as a scalar
+__device__ __forceinline__ double readlane_f64(double x, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(hi, lo);
+}
+// ARITH-SPEC tree sum over the 64 lanes of a wavefront: binary tree over adjacent index pairs (every lane gets
+// the total; at each level both partners add the same two values, so all lanes hold identical bits)
+__device__ __forceinline__ double wave_tree_sum(double x) {
+    x += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x);
+    x += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x);
+    x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
+    x += dpp_mov<DPP_ROW_MIRROR>(x);
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
 template <int G>
 __device__ __forceinline__ double group_sum(double x) {
-    if constexpr (!pow2_group<G>()) {
+    if constexpr (G > 64) {
+        // trajectory spans G/64 wavefronts: butterfly inside each, then the wave sums in ascending order through LDS
+        x = group_sum<64>(x);
+        double* buf = xwave_buf();
+        if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = x;
+        __syncthreads();
+        double s = buf[0];
+#pragma unroll
+        for (int i = 1; i < G / 64; ++i) s += buf[i];
+        __syncthreads();
+        return s;
+    } else if constexpr (!pow2_group<G>()) {
         const int lane = threadIdx.x & 63;
         const int base = (lane - lane % G) << 2;
         double s = bpermute_f64(base, x);
@@ -81,6 +115,29 @@ __device__ __forceinline__ void dd_acc(double& hi, double& lo, double x) {
 // combine the (hi, lo) pairs of the G lanes of a group; every lane ends with the same pair
 template <int G>
 __device__ __forceinline__ void group_dd_sum(double& hi, double& lo) {
+    if constexpr (G > 64) {
+        group_dd_sum<64>(hi, lo);
+        double* buf = xwave_buf();
+        if ((threadIdx.x & 63) == 0) {
+            buf[2 * (threadIdx.x >> 6)] = hi;
+            buf[2 * (threadIdx.x >> 6) + 1] = lo;
+        }
+        __syncthreads();
+        double h = buf[0], l = buf[1];
+#pragma unroll
+        for (int i = 1; i < G / 64; ++i) {
+            const double h2 = buf[2 * i], l2 = buf[2 * i + 1];
+            const double s = h + h2;
+            const double bb = s - h;
+            const double e = (h - (s - bb)) + (h2 - bb);
+            l = (l + l2) + e;
+            h = s;
+        }
+        __syncthreads();
+        hi = h;
+        lo = l;
+        return;
+    }
     if constexpr (!pow2_group<G>()) {
         const int lane = threadIdx.x & 63;
         const int base = (lane - lane % G) << 2;

@@ -112,6 +112,19 @@ __device__ __forceinline__ double chain2(V1 v1, V2 v2) {
 // ---------------------------------------------------------------------------------------------
 // generic driver
 // ---------------------------------------------------------------------------------------------
+// Stage storage of a REPLICATED state: one LDS word per (stage, component) and lane group -- or per wavefront when
+// a trajectory spans several (every wavefront keeps a private copy: no cross-wave ordering needed)
+template <bool DIST, int G, int BLOCK>
+constexpr int k_stride() { return DIST ? BLOCK : (G > 64 ? BLOCK / 64 : BLOCK / G); }
+template <bool DIST, int G>
+__device__ __forceinline__ int k_offset() { return DIST ? threadIdx.x : (G > 64 ? threadIdx.x / 64 : threadIdx.x / G); }
+// row of the partial-gradient matrix this thread's wavefront (or multi-wave trajectory) reports into
+template <int G, int BLOCK>
+__device__ __forceinline__ int64_t part_row() {
+    if constexpr (G > 64) return (int64_t)blockIdx.x;
+    else return BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
+}
+
 template <class Tab, class Sys, int G, int BLOCK>
 struct Driver {
     static constexpr int NR = Sys::NR, NSL = Sys::NSL, NSLA = NSL > 0 ? NSL : 1;
@@ -120,7 +133,7 @@ struct Driver {
     static constexpr bool LDS_SLOTS = Sys::SLOTS_IN_LDS;  // slot state + accumulators are theta-indexed LDS arrays
     static constexpr bool SLOT_FSAL = USE_FSAL && NSL > 0 && !LDS_SLOTS;  // stage-0 slot derivative handed over in LDS
     // stage derivatives of a REPLICATED state are stored once per group (all lanes read/write the same word)
-    static constexpr int KSTRIDE = Sys::STATE_DISTRIBUTED ? BLOCK : BLOCK / G;
+    static constexpr int KSTRIDE = k_stride<Sys::STATE_DISTRIBUTED, G, BLOCK>();
 
     struct Stats {
         int64_t nf = 0, nacc = 0, nrej = 0, nlazy = 0;
@@ -535,7 +548,7 @@ struct FwdSys {
     template <class Lazy>
     __device__ __forceinline__ int accepted(double tprev, double t, double dt, const double* z, const double* znew,
                                             const double* kl, Lazy& lazy) {
-        auto k = [&](int q, int c) { return kl[(q * NR + c) * (STATE_DISTRIBUTED ? BLOCKDIM : BLOCKDIM / G)]; };
+        auto k = [&](int q, int c) { return kl[(q * NR + c) * k_stride<STATE_DISTRIBUTED, G, BLOCKDIM>()]; };
         while (si < p->ns && p->saveat[si] <= t) {
             const double curt = p->saveat[si];
             if (curt != t) {
@@ -581,7 +594,7 @@ struct FwdSys {
 // LDS layout of a block: [theta copy | model scratch | stage derivatives k | slot state]
 template <class Model, class Tab, int G, int BLOCK>
 struct Layout {
-    static constexpr int KSTRIDE = Model::STATE_DISTRIBUTED ? BLOCK : BLOCK / G;
+    static constexpr int KSTRIDE = k_stride<Model::STATE_DISTRIBUTED, G, BLOCK>();
     static constexpr int K_DOUBLES = Tab::NK * Model::NS * KSTRIDE;
     // group-shared forward-interval cache of the adjoint kernel (see AdjSys::IC_LDS)
     static constexpr bool IC_LDS = (G >= 5) && !Model::STATE_DISTRIBUTED && !Model::SLOTS_IN_LDS;
@@ -607,7 +620,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     using Sys = FwdSys<Model, Tab, G, BLOCK>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
-    Model::init(sys.mctx, th, scratch, nullptr, 0, p.mc, r);
+    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, nullptr, 0, p.mc, r);
     sys.p = &p;
     sys.j = gid;
     sys.writer = (r == 0);
@@ -617,7 +630,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     sys.r = r;
     sys.n = p.n_state;
     double z[Sys::NR];
-    double* kl = kbase + (Model::STATE_DISTRIBUTED ? threadIdx.x : threadIdx.x / G);
+    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G>();
     double* mu = nullptr;  // no slot state in the forward pass
     static_for<0, Sys::NR>([&](auto c) { z[c] = sys.cvalid(c) ? p.u0[(size_t)gid * p.n_state + sys.comp(c)] : 0.0; });
     while (sys.si < p.ns && p.saveat[sys.si] <= p.t0) {  // save_start
@@ -684,8 +697,10 @@ struct AdjSys {
         if constexpr (IC_LDS) {
             // the G lanes of the group fetch the fields round-robin and publish them in the group's LDS row
             asm volatile("" ::: "memory");
+            if constexpr (G > 64) __syncthreads();  // (block-uniform: t is replicated) readers of the old row are done
             for (int f = mctx.r; f < IC_FIELDS; f += G) ic[f * icstride] = base[(size_t)(3 + f) * p->Npad];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (G > 64) __syncthreads();
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
             static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p->Npad] : 0.0; });
             static_for<0, Tab::NK>([&](auto q) {
@@ -804,7 +819,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     constexpr int NSL = Sys::NSL;
     constexpr int NSLA = NSL > 0 ? NSL : 1;
-    double* kl = kbase + (Model::STATE_DISTRIBUTED ? threadIdx.x : threadIdx.x / G);
+    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G>();
     // register-slot mode: slot state mu of thread tid, element c at mu_lds[c * BLOCK]
     double* mu_lds = slots + threadIdx.x;
     double* gtmp = slots + (size_t)NSLA * BLOCK + threadIdx.x;        // initial-dt scratch, element c at gtmp[c * BLOCK]
@@ -817,7 +832,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         Sys sys;
-        Model::init(sys.mctx, th, scratch, slots, np_pad, p.mc, r);
+        Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r);
         sys.mu = slots; sys.ab = slots + np_pad; sys.ae = slots + 2 * np_pad;
         sys.np_ = p.n_param; sys.r_ = r;
         sys.p = &p;
@@ -862,7 +877,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     if constexpr (Model::SLOTS_IN_LDS) {
         // one trajectory per block (G == BLOCK): mu is already the theta-indexed row of this wave
         __syncthreads();
-        const int64_t wave = BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
+        const int64_t wave = part_row<G, BLOCK>();
         double* row = p.grad_part + (size_t)wave * p.n_param;
         for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = slots[i];
     }
@@ -871,7 +886,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         // group order and writes the wave's partial row (runtime loops: this tail must not inflate the register peak)
         __syncthreads();
         if ((int)threadIdx.x < G) {
-            const int64_t wave = BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
+            const int64_t wave = part_row<G, BLOCK>();
             double* row = p.grad_part + (size_t)wave * p.n_param;
             const double* base = slots;
             for (int s = 0; s < NSL; ++s) {
@@ -894,9 +909,9 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         for (int m = G; m < (BLOCK < 64 ? BLOCK : 64); m <<= 1) v += __shfl_xor(v, m, 64);
         mu[c] = v;
     });
-    const int lane = threadIdx.x & 63;
+    const int lane = G > 64 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     if (lane < G) {
-        const int64_t wave = BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
+        const int64_t wave = part_row<G, BLOCK>();
         double* row = p.grad_part + (size_t)wave * p.n_param;
         for (int s = 0; s < NSL; ++s) {
             const int idx = Model::slot_index(p.mc, lane, s);
@@ -945,12 +960,12 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     const bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         typename Model::Ctx mctx;
-        Model::init(mctx, th, scratch, slots, np_pad, p.mc, r);
+        Model::init(mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r);
         const int n = p.n_state;
         auto comp = [&](int c) { return DIST ? c * G + r : c; };
         auto cvalid = [&](int c) { return comp(c) < n; };
         auto cwrite = [&](int c) { return DIST ? cvalid(c) : r == 0; };
-        const int koff = DIST ? threadIdx.x : threadIdx.x / G;
+        const int koff = k_offset<DIST, G>();
         auto K = [&](int j, int c) -> double& { return kbase[(j * NR + c) * KSTRIDE + koff]; };
         auto KB = [&](int j, int c) -> double& { return kbbase[(j * NR + c) * KSTRIDE + koff]; };
         const TabDev* tab = p.tab;
@@ -1059,7 +1074,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     }
     // ---- per-wave partial gradient row (fixed order) ----
     __syncthreads();
-    const int64_t wave = BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
+    const int64_t wave = part_row<G, BLOCK>();
     double* row = p.grad_part + (size_t)wave * p.n_param;
     if constexpr (Model::SLOTS_IN_LDS) {
         for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = -slots[np_pad + i];  // ab holds the negated sum

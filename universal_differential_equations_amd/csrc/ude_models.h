@@ -25,6 +25,7 @@ struct LinearTheta {
         for (int i = tid; i < np; i += nthreads) th[i] = theta[i];
     }
     static constexpr int SCRATCH = 0;
+    static constexpr bool THETA_GLOBAL = false;  // init() receives the LDS copy of theta
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -167,75 +168,91 @@ struct SeirTrue : LinearTheta {
 };
 
 // ---------------------------------------------------------------------------------------------
-// dudt_  (seir_exposure.jl:114-130): z = ann([S/N, I, D/N]) with ann = 3 -> 64 -> 64 -> 1 tanh
-// (4481 parameters); dS = -beta0*S*F/N - z - mu*S, dE = beta0*S*F/N + z - (sigma+mu)*E, ...
-//
-// One WAVEFRONT per trajectory (G = 64): lane j owns hidden neuron j of both hidden layers; activations and
-// deltas of a layer are exchanged through LDS (one 64-double row each, broadcast reads); theta is staged in
-// LDS with the 64x64 matrix padded to a leading dimension of 65 so that row reads (forward) and column
-// reads (backward) are both bank-conflict free.  The parameter cotangent mu and its two accumulators are
-// theta-indexed LDS arrays (3 x 4481 doubles = 105 KiB): "parity mode" of SURVEY.md 7.6 -- mu takes part in
-// the error norm exactly as upstream's augmented state does.
+// dudt_(u,p,t) = corona with the exposure term replaced by ann([S/N, I, D/N], p)[1]
+//   (SEIR_exposure/seir_exposure.jl:114-131), ann = 3 -> 64 (tanh) -> 64 (tanh) -> 1, theta = FastChain layout
+//   [W1 (64x3, column-major); b1; W2 (64x64); b2; W3 (1x64); b3] = 4481 parameters.
+// One trajectory per BLOCK of NW = G/64 wavefronts.  Everything the network needs lives in registers:
+//   lane (w, j) holds row j of W2 restricted to ITS k-blocks (forward), column j restricted to its i-blocks
+//   (transposed product), W1[j,:], b1[j], b2[j], W3[j]; the 64-term dots follow the ARITH-SPEC wide-dot rule
+//   (oracle: wide_dot): hidden-layer dots = 4 blocks of 16 terms, the blocks dealt to the wavefronts, block sums
+//   exchanged through LDS and added left to right; the two reductions to a replicated scalar (output layer,
+//   input cotangent) are wavefront tree sums.  Activations cross lanes with v_readlane (no LDS round trip).
+// The parameter cotangent is register-slot state: lane (w, j) owns W2[j, its k's] plus a share of the 7 "extra"
+// per-neuron parameter rows, so mu and the RK accumulators never touch LDS inside an evaluation.
 // ---------------------------------------------------------------------------------------------
 template <int G>
 struct SeirUde {
-    static_assert(G == 64, "SEIR UDE kernel is wavefront-per-trajectory");
-    static constexpr int NS = 7, NSL = 0, H = 64, LD = 65;
-    static constexpr bool SLOTS_IN_LDS = true, STATE_DISTRIBUTED = false;
-    static constexpr int NPARAM = 3 * H + H + H * H + H + H + 1;           // 4481
-    static constexpr int THETA_LDS = 3 * H + H + H * LD + H + H + 2;       // padded copy
-    static constexpr int SCRATCH = 4 * H;                                  // act1, act2, delta2, delta1
+    static_assert(G == 128 || G == 256, "SEIR UDE kernel: 2 or 4 wavefronts per trajectory");
+    static constexpr int NW = G / 64, H = 64, NBLK = 4, BPW = NBLK / NW, KB = 16 * BPW;  // k's per lane
+    static constexpr int NS = 7;
+    static constexpr int NEXTRA = 7, XS = (NEXTRA + NW - 1) / NW;  // W1[:,0..2], b1, b2, W3, b3
+    static constexpr int NSL = KB + XS;
+    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = false, THETA_GLOBAL = true;
+    static constexpr int NPARAM = 3 * H + H + H * H + H + H + 1;  // 4481
+    static constexpr int OFF_W1 = 0, OFF_B1 = 3 * H, OFF_W2 = 4 * H, OFF_B2 = 4 * H + H * H, OFF_W3 = OFF_B2 + H,
+                         OFF_B3 = OFF_W3 + H;
+    static constexpr int SCRATCH = 3 * NBLK * H;  // block sums: forward (double-buffered) + transposed product
     struct Ctx {
-        const double *W1, *b1, *W2p, *b2, *W3, *b3;
-        double *act1, *act2, *dl2, *dl1;
-        double *mu, *ab, *ae;
+        double w2row[KB], w2col[KB], w1[3], b1, b2, w3, b3;
+        double *pf, *pb;  // LDS block-sum exchange
         double F, b0, mu_c, sg, ga, d, la;
-        int r;
+        int j, w, r;
+        mutable int flip;
     };
-    static __host__ __device__ constexpr int theta_lds(int) { return THETA_LDS; }
-    // theta (global) -> padded LDS copy
-    static __device__ __forceinline__ void stage_theta(double* th, const double* theta, int, int tid, int nthreads) {
-        for (int i = tid; i < 3 * H + H; i += nthreads) th[i] = theta[i];                       // W1, b1
-        for (int i = tid; i < H * H; i += nthreads) th[4 * H + (i % H) + (i / H) * LD] = theta[4 * H + i];  // W2 -> ld 65
-        for (int i = tid; i < H + H + 1; i += nthreads) th[4 * H + H * LD + i] = theta[4 * H + H * H + i];  // b2, W3, b3
-    }
-    static __device__ __forceinline__ void init(Ctx& c, double* th, double* scratch, double* slots, int np_pad,
+    static __host__ __device__ constexpr int theta_lds(int) { return 0; }
+    static __device__ __forceinline__ void stage_theta(double*, const double*, int, int, int) {}
+    static __device__ __forceinline__ void init(Ctx& c, double* theta, double* scratch, double*, int,
                                                 const ModelConsts& mc, int r) {
-        c.W1 = th; c.b1 = th + 3 * H; c.W2p = th + 4 * H; c.b2 = c.W2p + H * LD; c.W3 = c.b2 + H; c.b3 = c.W3 + H;
-        c.act1 = scratch; c.act2 = scratch + H; c.dl2 = scratch + 2 * H; c.dl1 = scratch + 3 * H;
-        c.mu = slots; c.ab = slots + np_pad; c.ae = slots + 2 * np_pad;
+        const int j = r & 63;
+        const int w = __builtin_amdgcn_readfirstlane(r >> 6);
+        c.j = j; c.w = w; c.r = r; c.flip = 0;
+        c.pf = scratch; c.pb = scratch + 2 * NBLK * H;
+        static_for<0, KB>([&](auto i) {
+            const int k = w * KB + i;
+            c.w2row[i] = theta[OFF_W2 + j + k * H];  // W2[j, k]
+            c.w2col[i] = theta[OFF_W2 + k + j * H];  // W2[k, j]
+        });
+        static_for<0, 3>([&](auto m) { c.w1[m] = theta[OFF_W1 + j + m * H]; });
+        c.b1 = theta[OFF_B1 + j]; c.b2 = theta[OFF_B2 + j]; c.w3 = theta[OFF_W3 + j]; c.b3 = theta[OFF_B3];
         c.F = mc.consts[0]; c.b0 = mc.consts[1]; c.mu_c = mc.consts[4]; c.sg = mc.consts[5]; c.ga = mc.consts[6];
         c.d = mc.consts[7]; c.la = mc.consts[8];
-        c.r = r;
     }
-    // forward network: returns z; leaves act1/act2 in LDS and this lane's pre-activation-free cache in registers
-    static __device__ __forceinline__ double net(const Ctx& c, const double* x, double& a1, double& a2) {
-        const int j = c.r;
-        double acc = 0.0;
-        static_for<0, 3>([&](auto k) { acc = __builtin_fma(c.W1[j + k * H], x[k], acc); });
-        acc += c.b1[j];
-        a1 = dtanh(acc);
-        c.act1[j] = a1;
+    // block sums of one 64-term hidden dot: this wavefront's blocks -> LDS, barrier, all four added left to right
+    template <class Wt>
+    static __device__ __forceinline__ double hidden_dot(const Ctx& c, const Wt& wt, double v, double* buf, double* vk) {
+        static_for<0, BPW>([&](auto bc) {
+            constexpr int b = bc;
+            double acc = 0.0;
+            static_for<0, 16>([&](auto ic) {
+                constexpr int i = b * 16 + ic;
+                const double x = readlane_f64(v, c.w * KB + i);
+                if (vk) vk[i] = x;
+                acc = __builtin_fma(wt[i], x, acc);
+            });
+            buf[(c.w * BPW + b) * H + c.j] = acc;
+        });
         __syncthreads();
-        acc = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) acc = __builtin_fma(c.W2p[j + k * LD], c.act1[k], acc);
-        acc += c.b2[j];
-        a2 = dtanh(acc);
-        c.act2[j] = a2;
-        __syncthreads();
-        double zz = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) zz = __builtin_fma(c.W3[k], c.act2[k], zz);
-        zz += c.b3[0];
-        return zz;
+        double tot = buf[c.j];
+        static_for<1, NBLK>([&](auto b) { tot += buf[b * H + c.j]; });
+        return tot;
+    }
+    // forward network; a1k (optional): this lane's k-range of the first hidden activation
+    static __device__ __forceinline__ double net(const Ctx& c, const double* x, double& a1, double& a2, double* a1k) {
+        double z1 = 0.0;
+        static_for<0, 3>([&](auto k) { z1 = __builtin_fma(c.w1[k], x[k], z1); });
+        z1 += c.b1;
+        a1 = dtanh(z1);
+        double* pf = c.pf + (c.flip & 1) * NBLK * H;
+        c.flip ^= 1;
+        const double z2 = hidden_dot(c, c.w2row, a1, pf, a1k) + c.b2;
+        a2 = dtanh(z2);
+        return wave_tree_sum(c.w3 * a2) + c.b3;
     }
     static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
         const double S = u[0], E = u[1], I = u[2], Rr = u[3], N = u[4], D = u[5];
         const double x[3] = {S / N, I, D / N};
         double a1, a2;
-        const double z = net(c, x, a1, a2);
-        __syncthreads();  // act rows are rewritten by the next evaluation
+        const double z = net(c, x, a1, a2, nullptr);
         du[0] = -c.b0 * S * c.F / N - z - c.mu_c * S;
         du[1] = c.b0 * S * c.F / N + z - (c.sg + c.mu_c) * E;
         du[2] = c.sg * E - (c.ga + c.mu_c) * I;
@@ -244,49 +261,47 @@ struct SeirUde {
         du[5] = c.d * c.ga * I - c.la * D;
         du[6] = c.sg * E;
     }
-    // adjoint evaluation: dlam = (df/du)^T lam; the NEGATED parameter cotangent g = -(df/dtheta)^T lam is
-    // accumulated straight into the LDS accumulators: ab = first ? bs*g : fma(bs, g, ab) (ae likewise with es)
-    static __device__ __forceinline__ void vjp_acc(const Ctx& c, const double* u, const double* lam, double* dlam,
-                                                   double bs, double es, bool first) {
-        const int j = c.r;
+    // extra parameter row e (0..6) of neuron j: theta index / cotangent
+    static __device__ __forceinline__ int extra_index(int e, int j) {
+        switch (e) {
+            case 0: case 1: case 2: return OFF_W1 + j + e * H;
+            case 3: return OFF_B1 + j;
+            case 4: return OFF_B2 + j;
+            case 5: return OFF_W3 + j;
+            default: return (e == 6 && j == 0) ? OFF_B3 : -1;
+        }
+    }
+    template <bool WANT_PARAM>
+    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam,
+                                               double* g) {
         const double S = u[0], N = u[4], D = u[5];
         const double x[3] = {S / N, u[2], D / N};
-        double a1, a2;
-        net(c, x, a1, a2);
-        auto acc = [&](int idx, double gpos) {
-            const double g = -gpos;
-            c.ab[idx] = first ? bs * g : __builtin_fma(bs, g, c.ab[idx]);
-            c.ae[idx] = first ? es * g : __builtin_fma(es, g, c.ae[idx]);
-        };
-        const double d3 = (lam[1] - lam[0]) * 1.0;                        // output layer is linear
-        // layer 3 (W3: 1 x 64, b3): lane k owns W3[k]
-        acc(4 * H + H * H + H + j, d3 * c.act2[j]);
-        if (j == 0) acc(4 * H + H * H + 2 * H, d3);
-        // delta2_j = (W3[j] * d3) * tanh'(a2_j)
-        const double d2 = __builtin_fma(c.W3[j], d3, 0.0) * __builtin_fma(-a2, a2, 1.0);
-        c.dl2[j] = d2;
-        // layer 2 row j: dW2[j,k] = d2 * act1[k], db2[j] = d2
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) acc(4 * H + j + k * H, d2 * c.act1[k]);
-        acc(4 * H + H * H + j, d2);
-        __syncthreads();
-        // delta1_j = (sum_i W2[i,j] * delta2[i]) * tanh'(a1_j)   (column j of W2)
-        double s1 = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < H; ++i) s1 = __builtin_fma(c.W2p[i + j * LD], c.dl2[i], s1);
+        double a1, a2, a1k[KB];
+        net(c, x, a1, a2, a1k);
+        const double d3 = (lam[1] - lam[0]) * 1.0;  // output layer is linear
+        const double d2 = __builtin_fma(c.w3, d3, 0.0) * __builtin_fma(-a2, a2, 1.0);
+        const double s1 = hidden_dot(c, c.w2col, d2, c.pb, nullptr);
         const double d1 = s1 * __builtin_fma(-a1, a1, 1.0);
-        c.dl1[j] = d1;
-        static_for<0, 3>([&](auto m) { acc(j + m * H, d1 * x[m]); });
-        acc(3 * H + j, d1);
-        __syncthreads();
         double gx[3];
-        static_for<0, 3>([&](auto m) {
-            double s = 0.0;
-#pragma unroll 8
-            for (int i = 0; i < H; ++i) s = __builtin_fma(c.W1[i + m * H], c.dl1[i], s);
-            gx[m] = s;
-        });
-        __syncthreads();
+        static_for<0, 3>([&](auto m) { gx[m] = wave_tree_sum(c.w1[m] * d1); });
+        if constexpr (WANT_PARAM) {
+            static_for<0, KB>([&](auto i) { g[i] = d2 * a1k[i]; });
+            static_for<0, XS>([&](auto q) {
+                const int e = q * NW + c.w;  // wave-uniform
+                double v;
+                switch (e) {
+                    case 0: v = d1 * x[0]; break;
+                    case 1: v = d1 * x[1]; break;
+                    case 2: v = d1 * x[2]; break;
+                    case 3: v = d1; break;
+                    case 4: v = d2; break;
+                    case 5: v = d3 * a2; break;
+                    case 6: v = (c.j == 0) ? d3 : 0.0; break;
+                    default: v = 0.0;
+                }
+                g[KB + q] = v;
+            });
+        }
         const double cc = c.b0 * c.F / N;
         const double cN = c.b0 * S * c.F / (N * N);
         dlam[0] = (-cc - c.mu_c) * lam[0] + cc * lam[1] + gx[0] / N;
@@ -296,6 +311,12 @@ struct SeirUde {
         dlam[4] = cN * lam[0] - cN * lam[1] - c.mu_c * lam[4] - gx[0] * S / (N * N) - gx[2] * D / (N * N);
         dlam[5] = -c.la * lam[5] + gx[2] / N;
         dlam[6] = 0.0;
+    }
+    static __device__ __forceinline__ int slot_index(const ModelConsts&, int r, int s) {
+        const int j = r & 63, w = r >> 6;
+        if (s < KB) return OFF_W2 + j + (w * KB + s) * H;
+        const int e = (s - KB) * NW + w;
+        return e < NEXTRA ? extra_index(e, j) : -1;
     }
 };
 

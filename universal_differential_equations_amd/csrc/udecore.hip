@@ -176,7 +176,7 @@ static int default_lanes(int mid) {
         case MID_LV_HUDSON: return 8;
         case MID_LV_TANH32: return 32;
         case MID_SEIR_TRUE: return 1;
-        case MID_SEIR_UDE: return 64;
+        case MID_SEIR_UDE: return 256;  // 4 wavefronts per trajectory
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32: return 32;
@@ -410,7 +410,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const int BLOCK = l.block;
     const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
-    const int64_t nwaves = (int64_t)grid * (BLOCK >= 64 ? BLOCK / 64 : 1);
+    const int64_t nwaves = (int64_t)grid * ((BLOCK >= 64 && G <= 64) ? BLOCK / 64 : 1);  // rows of the partial-gradient matrix
     const int nf = 3 + n + l.nf * n;
     p.N = N;
     p.Npad = (N + 7) / 8 * 8;
