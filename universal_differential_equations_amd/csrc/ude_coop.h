@@ -63,6 +63,18 @@ __device__ __forceinline__ double readlane_f64(double x, int k) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
     return __hiloint2double(hi, lo);
 }
+// component-per-lane helpers (replicated small states, one wavefront per trajectory): lane c keeps component c
+template <int NR>
+__device__ __forceinline__ double own_of(const double (&v)[NR]) {
+    const int lane = threadIdx.x & 63;
+    double r = 0.0;
+    static_for<0, NR>([&](auto c) { r = (lane == (int)decltype(c)::value) ? v[c] : r; });
+    return r;
+}
+template <int NR>
+__device__ __forceinline__ void bcast_all(double own, double (&out)[NR]) {
+    static_for<0, NR>([&](auto c) { out[c] = readlane_f64(own, decltype(c)::value); });
+}
 // ARITH-SPEC tree sum over the 64 lanes of a wavefront: binary tree over adjacent index pairs (every lane gets
 // the total; at each level both partners add the same two values, so all lanes hold identical bits)
 __device__ __forceinline__ double wave_tree_sum(double x) {

@@ -48,6 +48,7 @@ struct KParams {
     double* loss_traj;        // N
     // backward outputs
     double* grad_part;  // [nwaves_total][np] per-wave partial gradients
+    double* slot_glob;  // SLOTS_GLOBAL models: slot state mu in HBM, element c of thread g at slot_glob[c * nthreads + g]
     double* grad_u0;    // n x N or null
     // debugging: per-iteration trace (t, dt, EEst, q, accept) of one trajectory; fwd rows first, then bwd
     double* trace;      // [2][trace_cap][5] or null
@@ -114,10 +115,11 @@ __device__ __forceinline__ double chain2(V1 v1, V2 v2) {
 // ---------------------------------------------------------------------------------------------
 // Stage storage of a REPLICATED state: one LDS word per (stage, component) and lane group -- or per wavefront when
 // a trajectory spans several (every wavefront keeps a private copy: no cross-wave ordering needed)
-template <bool DIST, int G, int BLOCK>
-constexpr int k_stride() { return DIST ? BLOCK : (G > 64 ? BLOCK / 64 : BLOCK / G); }
-template <bool DIST, int G>
-__device__ __forceinline__ int k_offset() { return DIST ? threadIdx.x : (G > 64 ? threadIdx.x / 64 : threadIdx.x / G); }
+// Component-per-lane (CPL) systems keep ONE component per lane: thread-private column, like a distributed state.
+template <bool DIST, int G, int BLOCK, bool CPL = false>
+constexpr int k_stride() { return (DIST || CPL) ? BLOCK : (G > 64 ? BLOCK / 64 : BLOCK / G); }
+template <bool DIST, int G, bool CPL = false>
+__device__ __forceinline__ int k_offset() { return (DIST || CPL) ? threadIdx.x : (G > 64 ? threadIdx.x / 64 : threadIdx.x / G); }
 // row of the partial-gradient matrix this thread's wavefront (or multi-wave trajectory) reports into
 template <int G, int BLOCK>
 __device__ __forceinline__ int64_t part_row() {
@@ -132,8 +134,15 @@ struct Driver {
     static constexpr bool USE_FSAL = Tab::FSAL && !Sys::ALWAYS_K0;
     static constexpr bool LDS_SLOTS = Sys::SLOTS_IN_LDS;  // slot state + accumulators are theta-indexed LDS arrays
     static constexpr bool SLOT_FSAL = USE_FSAL && NSL > 0 && !LDS_SLOTS;  // stage-0 slot derivative handed over in LDS
+    // fused accumulation: the model folds its parameter cotangent straight into accb/acce (no g[] array in between)
+    static constexpr bool FUSED = NSL > 0 && Sys::FUSED_ACC;
+    static_assert(!(FUSED && (USE_FSAL || LDS_SLOTS)), "fused accumulation re-evaluates stage 0");
     // stage derivatives of a REPLICATED state are stored once per group (all lanes read/write the same word)
-    static constexpr int KSTRIDE = k_stride<Sys::STATE_DISTRIBUTED, G, BLOCK>();
+    // CPL: stage derivatives stored one component per lane (lane c <-> component c): the weighted stage sums are
+    // formed by that lane alone and broadcast with v_readlane -- NR times fewer LDS reads and fma's per lane
+    static constexpr bool CPL = Sys::CPL;
+    static_assert(!CPL || (G == 64 && !Sys::STATE_DISTRIBUTED && NR <= 64), "component-per-lane: one wavefront per trajectory");
+    static constexpr int KSTRIDE = k_stride<Sys::STATE_DISTRIBUTED, G, BLOCK, CPL>();
 
     struct Stats {
         int64_t nf = 0, nacc = 0, nrej = 0, nlazy = 0;
@@ -145,7 +154,8 @@ struct Driver {
     // z: replicated state (registers).  Integrates from t0 along tdir through sys' tstops.
     static __device__ __forceinline__ int run(Sys& sys, const Opts& o, const TabDev* __restrict__ tab, double (&z)[NR],
                                               double* kl, double* mu, double t0, double tdir, double ntot, Stats& st,
-                                              double* gtmp = nullptr, double* gtmp2 = nullptr) {
+                                              double* gtmp = nullptr, double* gtmp2 = nullptr, int mustride = BLOCK) {
+        const int MS = Sys::SLOTS_GLOBAL ? mustride : BLOCK;  // element c of this thread's slot column at mu[c * MS]
         // gtmp: per-thread LDS row (element c at gtmp[c * BLOCK]) holding the slot derivative of stage 0: parked there
         // by the initial-dt heuristic, and -- FSAL tableaux -- handed over from the last stage of an accepted step
         // (gtmp2 receives the last stage's slot derivative; the two rows swap on acceptance)
@@ -155,6 +165,7 @@ struct Driver {
         int iter = 0, ret = RET_SUCCESS;
         double tstop = sys.first_tstop();
         auto K = [&](int j, int c) -> double& { return kl[(j * NR + c) * KSTRIDE]; };
+        auto K1 = [&](int j) -> double& { return kl[j * BLOCK]; };  // CPL: this lane's component of stage j
 
         // ---- initial dt (ode_determine_initdt), 2 evals ----
         if (o.dt0 > 0.0) {
@@ -162,15 +173,20 @@ struct Driver {
             if constexpr (USE_FSAL) {
                 double kr[NR], gs[NSLA];
                 sys.eval(t, z, kr, gs);
-                static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
+                if constexpr (CPL) K1(0) = own_of(kr);
+                else static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
                 if constexpr (SLOT_FSAL) static_for<0, NSL>([&](auto c) { gtmp[c * BLOCK] = gs[c]; });
             }
             if constexpr (Tab::FSAL) st.nf += 1;
         } else {
             double f0[NR], gs0[NSLA], f1[NR], gs1[NSLA], z1[NR];
             if constexpr (LDS_SLOTS) sys.eval_acc(t, z, f0, 1.0, 0.0, true);  // ab = g0, ae = 0
-            else sys.eval(t, z, f0, gs0);
-            static_for<0, NR>([&](auto c) { K(0, c) = f0[c]; });
+            else if constexpr (FUSED) {
+                static_for<0, NSL>([&](auto c) { accb[c] = 0.0; acce[c] = 0.0; });
+                sys.eval_fused(t, z, f0, accb, acce, 1.0, 0.0);  // accb = g0
+            } else sys.eval(t, z, f0, gs0);
+            if constexpr (CPL) K1(0) = own_of(f0);
+            else static_for<0, NR>([&](auto c) { K(0, c) = f0[c]; });
             // norms in double-double: slots first (lane-parallel), then the replicated components once
             double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
             if constexpr (LDS_SLOTS) {
@@ -182,6 +198,16 @@ struct Driver {
                     dd_acc(h0, l0, q0 * q0);
                     dd_acc(h1, l1, q1 * q1);
                 }
+                group_dd_sum<G>(h0, l0);
+                group_dd_sum<G>(h1, l1);
+            } else if constexpr (FUSED) {
+                static_for<0, NSL>([&](auto c) {
+                    const double m = mu[c * MS];
+                    const double sk = __builtin_fma(fabs(m), o.reltol, o.abstol);
+                    const double q0 = m / sk, q1 = accb[c] / sk;
+                    dd_acc(h0, l0, q0 * q0);
+                    dd_acc(h1, l1, q1 * q1);
+                });
                 group_dd_sum<G>(h0, l0);
                 group_dd_sum<G>(h1, l1);
             } else if constexpr (NSL > 0) {
@@ -233,6 +259,7 @@ struct Driver {
                 static_for<0, NR>([&](auto c) { z1[c] = __builtin_fma(dt0t, f0[c], z[c]); });
                 // (the slot part of u1 does not enter f: mu' is independent of mu)
                 if constexpr (LDS_SLOTS) sys.eval_acc(t + dt0t, z1, f1, 0.0, 1.0, false);  // ae = g1, ab untouched
+                else if constexpr (FUSED) sys.eval_fused(t + dt0t, z1, f1, accb, acce, 0.0, 1.0);  // acce = g1
                 else sys.eval(t + dt0t, z1, f1, gs1);
                 double h2 = 0.0, l2 = 0.0;
                 if constexpr (LDS_SLOTS) {
@@ -244,6 +271,13 @@ struct Driver {
                     }
                     group_dd_sum<G>(h2, l2);
                     sys.lds_sync();
+                } else if constexpr (FUSED) {
+                    static_for<0, NSL>([&](auto c) {
+                        const double sk = __builtin_fma(fabs(mu[c * MS]), o.reltol, o.abstol);
+                        const double q = (acce[c] - accb[c]) / sk;
+                        dd_acc(h2, l2, q * q);
+                    });
+                    group_dd_sum<G>(h2, l2);
                 } else if constexpr (NSL > 0) {
                     static_for<0, NSL>([&](auto c) {
                         const double sk = __builtin_fma(fabs(mu[c * BLOCK]), o.reltol, o.abstol);
@@ -307,6 +341,7 @@ struct Driver {
 
             // ---- perform_step!: runtime stage loop (wave-uniform s) ----
             double znew[NR];
+            [[maybe_unused]] const double zo = CPL ? own_of(z) : 0.0;  // this lane's component of z
             if constexpr (SLOT_FSAL) {
                 const double bs = tab->B[0], es = tab->BT[0];
                 static_for<0, NSL>([&](auto c) {
@@ -315,10 +350,16 @@ struct Driver {
                     acce[c] = es * g0;
                 });
             }
+            if constexpr (FUSED) static_for<0, NSL>([&](auto c) { accb[c] = 0.0; acce[c] = 0.0; });
             for (int s = USE_FSAL ? 1 : 0; s < S; ++s) {
-                double zs[NR], kr[NR], gs[NSLA];
+                double zs[NR], kr[NR], gs[FUSED ? 1 : NSLA];
                 if (s == 0) {
                     static_for<0, NR>([&](auto c) { zs[c] = z[c]; });
+                } else if constexpr (CPL) {
+                    double acc = tab->A[s][0] * K1(0);
+#pragma unroll 4
+                    for (int j = 1; j < s; ++j) acc = __builtin_fma(tab->A[s][j], K1(j), acc);  // (a_sj = 0 for j >= s)
+                    bcast_all(__builtin_fma(dt, acc, zo), zs);
                 } else {
                     static_for<0, NR>([&](auto c) {
                         // all S-1 possible terms, unrolled: the coefficients of stages >= s are zero in the table and the
@@ -331,9 +372,11 @@ struct Driver {
                 }
                 if (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
                 if constexpr (LDS_SLOTS) sys.eval_acc(t + tab->C[s] * dt, zs, kr, tab->B[s], tab->BT[s], s == 0);
+                else if constexpr (FUSED) sys.eval_fused(t + tab->C[s] * dt, zs, kr, accb, acce, tab->B[s], tab->BT[s]);
                 else sys.eval(t + tab->C[s] * dt, zs, kr, gs);
-                static_for<0, NR>([&](auto c) { K(s, c) = kr[c]; });
-                if constexpr (NSL > 0 && !LDS_SLOTS) {
+                if constexpr (CPL) K1(s) = own_of(kr);
+                else static_for<0, NR>([&](auto c) { K(s, c) = kr[c]; });
+                if constexpr (NSL > 0 && !LDS_SLOTS && !FUSED) {
                     const double bs = tab->B[s], es = tab->BT[s];
                     if (s == 0) {
                         static_for<0, NSL>([&](auto c) {
@@ -352,7 +395,12 @@ struct Driver {
                 }
             }
             st.nf += Tab::FSAL ? S - 1 : S;
-            if constexpr (!Tab::FSAL) {
+            if constexpr (!Tab::FSAL && CPL) {
+                double acc = tab->B[0] * K1(0);
+#pragma unroll 3
+                for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->B[j], K1(j), acc);
+                bcast_all(__builtin_fma(dt, acc, zo), znew);
+            } else if constexpr (!Tab::FSAL) {
                 static_for<0, NR>([&](auto c) {
                     double acc = tab->B[0] * K(0, c);
                     for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->B[j], K(j, c), acc);
@@ -361,6 +409,15 @@ struct Driver {
             }
             // calculate_residuals + ODE_DEFAULT_NORM
             double ss = 0.0;
+            if constexpr (CPL) {
+                double acc = tab->BT[0] * K1(0);
+#pragma unroll 3
+                for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->BT[j], K1(j), acc);
+                const double a0 = fabs(zo), a1 = fabs(own_of(znew));
+                double res[NR];
+                bcast_all((dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
+                static_for<0, NR>([&](auto c) { ss = __builtin_fma(res[c], res[c], ss); });
+            } else
             static_for<0, NR>([&](auto c) {
                 double acc = tab->BT[0] * K(0, c);
                 for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->BT[j], K(j, c), acc);
@@ -385,7 +442,7 @@ struct Driver {
             } else if constexpr (NSL > 0) {
                 double ps = 0.0;
                 static_for<0, NSL>([&](auto c) {
-                    const double m0 = mu[c * BLOCK];
+                    const double m0 = mu[c * MS];
                     const double m1 = __builtin_fma(dt, accb[c], m0);
                     accb[c] = m1;  // candidate new value
                     const double a0 = fabs(m0), a1 = fabs(m1);
@@ -428,15 +485,22 @@ struct Driver {
                         if constexpr (Tab::NEXTRA > 0) {
                             if (!lazy_done) {
                                 for (int e = 0; e < Tab::NEXTRA; ++e) {
-                                    double zs[NR], kr[NR], gs[NSLA];
+                                    double zs[NR], kr[NR], gs[FUSED ? 1 : NSLA];
                                     const int row = S + e;
+                                    if constexpr (CPL) {
+                                        double acc = tab->A[row][0] * K1(0);
+#pragma unroll 3
+                                        for (int j = 1; j < row; ++j) acc = __builtin_fma(tab->A[row][j], K1(j), acc);
+                                        bcast_all(__builtin_fma(dt, acc, zo), zs);
+                                    } else
                                     static_for<0, NR>([&](auto c) {
                                         double acc = tab->A[row][0] * K(0, c);
                                         for (int j = 1; j < row; ++j) acc = __builtin_fma(tab->A[row][j], K(j, c), acc);
                                         zs[c] = __builtin_fma(dt, acc, z[c]);
                                     });
                                     sys.eval(tprev + tab->C[row] * dt, zs, kr, gs);
-                                    static_for<0, NR>([&](auto c) { K(row, c) = kr[c]; });
+                                    if constexpr (CPL) K1(row) = own_of(kr);
+                                    else static_for<0, NR>([&](auto c) { K(row, c) = kr[c]; });
                                 }
                                 lazy_done = true;
                                 st.nlazy += Tab::NEXTRA;
@@ -457,9 +521,10 @@ struct Driver {
                     for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) sys.mu[i] = sys.ab[i];
                     sys.lds_sync();
                 } else {
-                    static_for<0, NSL>([&](auto c) { mu[c * BLOCK] = accb[c]; });
+                    static_for<0, NSL>([&](auto c) { mu[c * MS] = accb[c]; });
                 }
-                if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
+                if constexpr (USE_FSAL && CPL) K1(0) = K1(S - 1);
+                else if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
                 if constexpr (SLOT_FSAL) { double* tsw = gtmp; gtmp = gtmp2; gtmp2 = tsw; }
                 if (bad) { ret = RET_UNSTABLE; done = true; }
                 if (t == tstop) {  // handle_tstop! + callbacks
@@ -471,7 +536,8 @@ struct Driver {
                         if constexpr (USE_FSAL) {
                             double kr[NR], gs[NSLA];
                             sys.eval(t, z, kr, gs);
-                            static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
+                            if constexpr (CPL) K1(0) = own_of(kr);
+                            else static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
                             if constexpr (SLOT_FSAL) static_for<0, NSL>([&](auto c) { gtmp[c * BLOCK] = gs[c]; });
                         }
                     }
@@ -493,6 +559,7 @@ template <class Model, class Tab, int G, int BLOCKDIM>
 struct FwdSys {
     static constexpr int NR = Model::NS, NSL = 0;
     static constexpr bool ALWAYS_K0 = false, SLOTS_IN_LDS = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
+    static constexpr bool FUSED_ACC = false, SLOTS_GLOBAL = false, CPL = Model::CPL;
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;      // trajectory
@@ -549,6 +616,7 @@ struct FwdSys {
     __device__ __forceinline__ int accepted(double tprev, double t, double dt, const double* z, const double* znew,
                                             const double* kl, Lazy& lazy) {
         auto k = [&](int q, int c) { return kl[(q * NR + c) * k_stride<STATE_DISTRIBUTED, G, BLOCKDIM>()]; };
+        auto k1 = [&](int q) { return kl[q * BLOCKDIM]; };  // CPL: this lane's component
         while (si < p->ns && p->saveat[si] <= t) {
             const double curt = p->saveat[si];
             if (curt != t) {
@@ -556,6 +624,10 @@ struct FwdSys {
                 const double th = (curt - tprev) / dt;
                 double b[Tab::NK], y[NR];
                 Tab::bth(th, b);
+                if constexpr (CPL) {
+                    const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return k1(q); }, [&](auto q) { return b[q]; });
+                    bcast_all(__builtin_fma(dt, acc, own_of<NR>(reinterpret_cast<const double(&)[NR]>(*z))), y);
+                } else
                 static_for<0, NR>([&](auto c) {
                     const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return k(q, c); }, [&](auto q) { return b[q]; });
                     y[c] = __builtin_fma(dt, acc, z[c]);
@@ -577,6 +649,14 @@ struct FwdSys {
                     base[(size_t)1 * p->Npad] = t;
                     base[(size_t)2 * p->Npad] = dt;
                 }
+                if constexpr (CPL) {
+                    // lane c stores component c of u and of every stage
+                    const double zo = own_of<NR>(reinterpret_cast<const double(&)[NR]>(*z));
+                    if (r < n) {
+                        base[(size_t)(3 + r) * p->Npad] = zo;
+                        static_for<0, Tab::NK>([&](auto q) { base[(size_t)(3 + n + q * n + r) * p->Npad] = k1(q); });
+                    }
+                } else {
                 static_for<0, NR>([&](auto c) { if (cwrite(c)) base[(size_t)(3 + comp(c)) * p->Npad] = z[c]; });
                 static_for<0, Tab::NK>([&](auto q) {
                     // every stage is stored (the discrete adjoint needs k2, k3, k10 too, not only the dense-output ones)
@@ -584,6 +664,7 @@ struct FwdSys {
                         if (cwrite(c)) base[(size_t)(3 + n + q * n + comp(c)) * p->Npad] = k(q, c);
                     });
                 });
+                }
             }
             nsteps += 1;
         }
@@ -592,12 +673,12 @@ struct FwdSys {
 };
 
 // LDS layout of a block: [theta copy | model scratch | stage derivatives k | slot state]
-template <class Model, class Tab, int G, int BLOCK>
+template <class Model, class Tab, int G, int BLOCK, bool CPL = Model::CPL>
 struct Layout {
-    static constexpr int KSTRIDE = k_stride<Model::STATE_DISTRIBUTED, G, BLOCK>();
-    static constexpr int K_DOUBLES = Tab::NK * Model::NS * KSTRIDE;
+    static constexpr int KSTRIDE = k_stride<Model::STATE_DISTRIBUTED, G, BLOCK, CPL>();
+    static constexpr int K_DOUBLES = Tab::NK * (CPL ? 1 : Model::NS) * KSTRIDE;
     // group-shared forward-interval cache of the adjoint kernel (see AdjSys::IC_LDS)
-    static constexpr bool IC_LDS = (G >= 5) && !Model::STATE_DISTRIBUTED && !Model::SLOTS_IN_LDS;
+    static constexpr bool IC_LDS = (G >= 5) && !Model::STATE_DISTRIBUTED && !Model::SLOTS_IN_LDS && !Model::CPL;
     static constexpr int IC_DOUBLES = IC_LDS ? (Model::NS + Tab::NK * Model::NS) * (BLOCK / G) : 0;
     static __host__ __device__ constexpr int np_pad(int np) { return (np + 1) & ~1; }
 };
@@ -620,7 +701,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     using Sys = FwdSys<Model, Tab, G, BLOCK>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
-    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, nullptr, 0, p.mc, r);
+    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, nullptr, 0, p.mc, r, p.theta);
     sys.p = &p;
     sys.j = gid;
     sys.writer = (r == 0);
@@ -630,7 +711,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     sys.r = r;
     sys.n = p.n_state;
     double z[Sys::NR];
-    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G>();
+    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>();
     double* mu = nullptr;  // no slot state in the forward pass
     static_for<0, Sys::NR>([&](auto c) { z[c] = sys.cvalid(c) ? p.u0[(size_t)gid * p.n_state + sys.comp(c)] : 0.0; });
     while (sys.si < p.ns && p.saveat[sys.si] <= p.t0) {  // save_start
@@ -664,7 +745,8 @@ struct AdjSys {
     static constexpr bool SLOTS_IN_LDS = Model::SLOTS_IN_LDS, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     // LDS-slot models re-evaluate stage 0 every step (its parameter cotangent is folded straight into the shared
     // accumulators); register-slot models hand k_S -> k_0 AND its slot derivative over (FSAL, as upstream)
-    static constexpr bool ALWAYS_K0 = SLOTS_IN_LDS;
+    static constexpr bool FUSED_ACC = Model::FUSED_ACC, SLOTS_GLOBAL = Model::SLOTS_GLOBAL, CPL = Model::CPL;
+    static constexpr bool ALWAYS_K0 = SLOTS_IN_LDS || FUSED_ACC;
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;
@@ -675,9 +757,11 @@ struct AdjSys {
     __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
     // cached forward interval: t_start/t_end in registers; u_start and the k's either in registers (IC_LDS = false)
     // or in a group-shared LDS row (IC_LDS: saves 2*NR*(NK+1) VGPRs per lane; reads are broadcasts inside the group)
-    static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !SLOTS_IN_LDS;
+    // CPL: lane c caches component c only (u_start and the k's of the interval: 1 + NK registers)
+    static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !SLOTS_IN_LDS && !CPL;
     static constexpr int IC_FIELDS = NR + Tab::NK * NR;
-    double ts, te, us[IC_LDS ? 1 : NR], ks[IC_LDS ? 1 : Tab::NK][IC_LDS ? 1 : NR];
+    static constexpr int IC_NR = (IC_LDS || CPL) ? 1 : NR;
+    double ts, te, us[IC_NR], ks[IC_LDS ? 1 : Tab::NK][IC_NR];
     double* ic;      // LDS: field f of this group at ic[f * icstride]
     int icstride;
     __device__ __forceinline__ double US(int c) const { if constexpr (IC_LDS) return ic[c * icstride]; else return us[c]; }
@@ -701,6 +785,13 @@ struct AdjSys {
             for (int f = mctx.r; f < IC_FIELDS; f += G) ic[f * icstride] = base[(size_t)(3 + f) * p->Npad];
             if constexpr (G > 64) __syncthreads();
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if constexpr (CPL) {
+            const bool on = mctx.r < n;
+            const int rc = on ? mctx.r : 0;
+            us[0] = on ? base[(size_t)(3 + rc) * p->Npad] : 0.0;
+            static_for<0, Tab::NK>([&](auto q) {
+                if constexpr (Tab::dense_uses(q)) ks[q][0] = on ? base[(size_t)(3 + n + q * n + rc) * p->Npad] : 0.0;
+            });
         } else {
             static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p->Npad] : 0.0; });
             static_for<0, Tab::NK>([&](auto q) {
@@ -716,8 +807,30 @@ struct AdjSys {
         while (t < ts && sf > 0) load_interval(sf - 1);
         while (t >= te && sf < nsteps - 1) load_interval(sf + 1);
     }
+    // fused accumulation: accb = fma(bs, g, accb), acce = fma(es, g, acce) with g = -(df/dtheta)^T lam
+    __device__ __forceinline__ void eval_fused(double t, const double* lam, double* klam, double* accb, double* acce,
+                                               double bs, double es) {
+        if constexpr (FUSED_ACC) {
+            asm volatile("" ::: "memory");
+            locate(t);
+            const double dtf = te - ts;
+            const double th = (t - ts) / dtf;
+            double b[Tab::NK], y[NR], dl[NR];
+            Tab::bth(th, b);
+            if constexpr (CPL) {
+                const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][0]; }, [&](auto q) { return b[q]; });
+                bcast_all(__builtin_fma(dtf, acc, us[0]), y);
+            } else
+            static_for<0, NR>([&](auto c) {
+                const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
+                y[c] = __builtin_fma(dtf, acc, US(c));
+            });
+            Model::template vjp_acc<true>(mctx, y, lam, dl, accb, acce, bs, es);
+            static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
+        }
+    }
     __device__ __forceinline__ void eval(double t, const double* lam, double* klam, double* g) {
-      if constexpr (!SLOTS_IN_LDS) {
+      if constexpr (!SLOTS_IN_LDS && !FUSED_ACC) {
         asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
         locate(t);
         const double dtf = te - ts;
@@ -819,20 +932,22 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     constexpr int NSL = Sys::NSL;
     constexpr int NSLA = NSL > 0 ? NSL : 1;
-    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G>();
+    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>();
     // register-slot mode: slot state mu of thread tid, element c at mu_lds[c * BLOCK]
-    double* mu_lds = slots + threadIdx.x;
+    constexpr bool SG = Model::SLOTS_GLOBAL;  // mu in HBM (fused-accumulation models: nothing else needs a column)
+    const int MS = SG ? (int)(gridDim.x * BLOCK) : BLOCK;
+    double* mu_lds = SG ? p.slot_glob + (size_t)blockIdx.x * BLOCK + threadIdx.x : slots + threadIdx.x;
     double* gtmp = slots + (size_t)NSLA * BLOCK + threadIdx.x;        // initial-dt scratch, element c at gtmp[c * BLOCK]
     double* gtmp2 = slots + (size_t)2 * NSLA * BLOCK + threadIdx.x;    // last-stage slot derivative (FSAL hand-over)
-    double* icbase = slots + (size_t)3 * NSLA * BLOCK;                 // interval cache rows (IC_LDS), one per group
+    double* icbase = slots + (SG ? (size_t)0 : (size_t)3 * NSLA * BLOCK);  // interval cache rows (IC_LDS), one per group
     double lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
-    static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
+    static_for<0, NSL>([&](auto c) { mu_lds[c * MS] = 0.0; });
     const bool in_range = gid < p.N && (int)threadIdx.x < GROUPS * G;
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         Sys sys;
-        Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r);
+        Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
         sys.mu = slots; sys.ab = slots + np_pad; sys.ae = slots + 2 * np_pad;
         sys.np_ = p.n_param; sys.r_ = r;
         sys.p = &p;
@@ -854,7 +969,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         sys.load_interval(sys.nsteps - 1);
         sys.at_tstop(p.tf, lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
-        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st, gtmp, gtmp2);
+        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st, gtmp, gtmp2, MS);
         if (r == 0) {
             if (p.stats) {
                 int64_t* s = p.stats + (size_t)gid * 8;
@@ -867,7 +982,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
                 if (sys.cwrite(c)) p.grad_u0[(size_t)gid * p.n_state + sys.comp(c)] = lam[c];
             });
         if (ret != RET_SUCCESS) {  // never poison the batch gradient
-            static_for<0, NSL>([&](auto c) { mu_lds[c * BLOCK] = 0.0; });
+            static_for<0, NSL>([&](auto c) { mu_lds[c * MS] = 0.0; });
             if constexpr (Model::SLOTS_IN_LDS) {
                 __syncthreads();
                 for (int i = r; i < p.n_param; i += G) slots[i] = 0.0;
@@ -899,7 +1014,16 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
             }
         }
     }
-    if constexpr (!Model::SLOTS_IN_LDS && pow2_group<G>()) {
+    if constexpr (SG) {
+        // one wavefront per trajectory, mu in HBM: the wave's partial row is its own mu, slot by slot
+        static_assert(G == 64, "HBM slot state: one wavefront per trajectory");
+        double* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
+        static_for<0, NSL>([&](auto c) {
+            const int idx = Model::slot_index(p.mc, r, c);
+            if (idx >= 0) row[idx] = mu_lds[c * MS];
+        });
+    }
+    if constexpr (!SG && !Model::SLOTS_IN_LDS && pow2_group<G>()) {
     double mu[NSLA];
     static_for<0, NSL>([&](auto c) { mu[c] = mu_lds[c * BLOCK]; });
     // ---- deterministic reduction: groups of a wave (xor butterfly), then one partial row per wave ----
@@ -936,7 +1060,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
 template <class Model, class Tab, int G, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    using L = Layout<Model, Tab, G, BLOCK>;
+    using L = Layout<Model, Tab, G, BLOCK, false>;  // (the reverse sweep keeps the replicated stage layout)
     constexpr int NR = Model::NS, NSL = Model::NSL, NSLA = NSL > 0 ? NSL : 1;
     constexpr int S = Tab::S, NK = Tab::NK, KSTRIDE = L::KSTRIDE, GROUPS = BLOCK / G;
     constexpr bool DIST = Model::STATE_DISTRIBUTED;
@@ -950,8 +1074,9 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     if constexpr (Model::SLOTS_IN_LDS) {
         for (int i = threadIdx.x; i < 3 * np_pad; i += BLOCK) slots[i] = 0.0;
     }
+    constexpr bool SG = Model::SLOTS_GLOBAL;
     double* acc_lds = slots + threadIdx.x;  // register-slot models: accumulator row, element c at acc_lds[c*BLOCK]
-    static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = 0.0; });
+    if constexpr (!SG) static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = 0.0; });
     __syncthreads();
 
     const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
@@ -960,7 +1085,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     const bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         typename Model::Ctx mctx;
-        Model::init(mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r);
+        Model::init(mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
         const int n = p.n_state;
         auto comp = [&](int c) { return DIST ? c * G + r : c; };
         auto cvalid = [&](int c) { return comp(c) < n; };
@@ -993,6 +1118,8 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             asm volatile("" ::: "memory");
             if constexpr (Model::SLOTS_IN_LDS) {
                 Model::vjp_acc(mctx, g, kbrow, w, 1.0, 0.0, false);  // ab -= (df/dtheta)^T kbar (sign undone at the end)
+            } else if constexpr (Model::FUSED_ACC) {
+                Model::template vjp_acc<false>(mctx, g, kbrow, w, acc, acc, -1.0, 0.0);  // acc += (df/dtheta)^T kbar
             } else {
                 double gs[NSLA];
                 Model::template vjp<true>(mctx, g, kbrow, w, gs);
@@ -1070,7 +1197,15 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         if (r == 0 && p.stats) p.stats[(size_t)gid * 8 + 4] = nvjp;
         if (p.grad_u0)
             static_for<0, NR>([&](auto c) { if (cwrite(c)) p.grad_u0[(size_t)gid * n + comp(c)] = ubar[c]; });
-        static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = acc[c]; });
+        if constexpr (SG) {
+            double* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
+            static_for<0, NSL>([&](auto c) {
+                const int idx = Model::slot_index(p.mc, r, c);
+                if (idx >= 0) row[idx] = acc[c];
+            });
+        } else {
+            static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = acc[c]; });
+        }
     }
     // ---- per-wave partial gradient row (fixed order) ----
     __syncthreads();
@@ -1078,7 +1213,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     double* row = p.grad_part + (size_t)wave * p.n_param;
     if constexpr (Model::SLOTS_IN_LDS) {
         for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = -slots[np_pad + i];  // ab holds the negated sum
-    } else {
+    } else if constexpr (!SG) {
         if ((int)threadIdx.x < G) {
             for (int s = 0; s < NSL; ++s) {
                 const int idx = Model::slot_index(p.mc, (int)threadIdx.x, s);

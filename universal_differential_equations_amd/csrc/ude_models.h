@@ -26,6 +26,9 @@ struct LinearTheta {
     }
     static constexpr int SCRATCH = 0;
     static constexpr bool THETA_GLOBAL = false;  // init() receives the LDS copy of theta
+    static constexpr bool FUSED_ACC = false;     // parameter cotangent returned as g[] (not folded into accumulators)
+    static constexpr bool SLOTS_GLOBAL = false;  // slot state mu in LDS (per-thread column)
+    static constexpr bool CPL = false;           // component-per-lane stage storage (replicated small states, G = 64)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -40,7 +43,7 @@ struct LvTrue : LinearTheta {
         const double* th;
         int r;
     };
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double*, double*, int, const ModelConsts&, int r) {
+    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double*, double*, int, const ModelConsts&, int r, const double* = nullptr) {
         c.th = th_lds;
         c.r = r;
     }
@@ -87,7 +90,7 @@ struct LvUde : LinearTheta {
         int r;
         typename Mlp::WReg w;  // (unused members are never materialised when REGW is false)
     };
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double*, double*, int, const ModelConsts& mc, int r) {
+    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double*, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
         c.th = th_lds;
         c.nn = th_lds + mc.nn_offset;
         c.r = r;
@@ -146,7 +149,7 @@ struct SeirTrue : LinearTheta {
         double F, b0, al, ka, mu, sg, ga, d, la;
         int r;
     };
-    static __device__ __forceinline__ void init(Ctx& c, double*, double*, double*, int, const ModelConsts& mc, int r) {
+    static __device__ __forceinline__ void init(Ctx& c, double*, double*, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
         c.F = mc.consts[0]; c.b0 = mc.consts[1]; c.al = mc.consts[2]; c.ka = mc.consts[3]; c.mu = mc.consts[4];
         c.sg = mc.consts[5]; c.ga = mc.consts[6]; c.d = mc.consts[7]; c.la = mc.consts[8];
         c.r = r;
@@ -182,61 +185,92 @@ struct SeirTrue : LinearTheta {
 // ---------------------------------------------------------------------------------------------
 template <int G>
 struct SeirUde {
-    static_assert(G == 128 || G == 256, "SEIR UDE kernel: 2 or 4 wavefronts per trajectory");
+    static_assert(G == 64 || G == 128 || G == 256, "SEIR UDE kernel: 1, 2 or 4 wavefronts per trajectory");
     static constexpr int NW = G / 64, H = 64, NBLK = 4, BPW = NBLK / NW, KB = 16 * BPW;  // k's per lane
     static constexpr int NS = 7;
     static constexpr int NEXTRA = 7, XS = (NEXTRA + NW - 1) / NW;  // W1[:,0..2], b1, b2, W3, b3
     static constexpr int NSL = KB + XS;
-    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = false, THETA_GLOBAL = true;
+    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = false;
+    // one wavefront per trajectory (G = 64): W2 is read from a padded LDS copy shared by the block's trajectories,
+    // the 71 parameter-cotangent accumulators per lane stay in registers (fused accumulation: no g[] array) and mu
+    // itself (touched once per step) lives in HBM.  G = 128/256: W2 slices in registers, theta read from HBM once.
+    static constexpr bool ONE = NW == 1;
+    static constexpr bool THETA_GLOBAL = !ONE, FUSED_ACC = ONE, SLOTS_GLOBAL = ONE, CPL = ONE;
+    static constexpr int LD = 65;  // leading dimension of the LDS copy of W2: row AND column reads conflict-free
     static constexpr int NPARAM = 3 * H + H + H * H + H + H + 1;  // 4481
     static constexpr int OFF_W1 = 0, OFF_B1 = 3 * H, OFF_W2 = 4 * H, OFF_B2 = 4 * H + H * H, OFF_W3 = OFF_B2 + H,
                          OFF_B3 = OFF_W3 + H;
-    static constexpr int SCRATCH = 3 * NBLK * H;  // block sums: forward (double-buffered) + transposed product
+    static constexpr int SCRATCH = ONE ? 0 : 3 * NBLK * H;  // block sums: forward (double-buffered) + transposed
     struct Ctx {
-        double w2row[KB], w2col[KB], w1[3], b1, b2, w3, b3;
-        double *pf, *pb;  // LDS block-sum exchange
+        double w2row[ONE ? 1 : KB], w2col[ONE ? 1 : KB], w1[3], b1, b2, w3, b3;
+        const double* W2p;  // LDS, ld = 65 (ONE)
+        double *pf, *pb;    // LDS block-sum exchange (multi-wave)
         double F, b0, mu_c, sg, ga, d, la;
         int j, w, r;
         mutable int flip;
     };
-    static __host__ __device__ constexpr int theta_lds(int) { return 0; }
-    static __device__ __forceinline__ void stage_theta(double*, const double*, int, int, int) {}
-    static __device__ __forceinline__ void init(Ctx& c, double* theta, double* scratch, double*, int,
-                                                const ModelConsts& mc, int r) {
+    static __host__ __device__ constexpr int theta_lds(int) { return ONE ? ((H * LD + 1) & ~1) : 0; }
+    static __device__ __forceinline__ void stage_theta(double* th, const double* theta, int, int tid, int nthreads) {
+        if constexpr (ONE)
+            for (int i = tid; i < H * H; i += nthreads) th[(i % H) + (i / H) * LD] = theta[OFF_W2 + i];
+    }
+    // th: LDS copy of W2 (ONE) / theta in HBM (multi-wave); theta_g: theta in HBM
+    static __device__ __forceinline__ void init(Ctx& c, double* th, double* scratch, double*, int,
+                                                const ModelConsts& mc, int r, const double* theta_g) {
         const int j = r & 63;
         const int w = __builtin_amdgcn_readfirstlane(r >> 6);
         c.j = j; c.w = w; c.r = r; c.flip = 0;
+        c.W2p = th;
         c.pf = scratch; c.pb = scratch + 2 * NBLK * H;
-        static_for<0, KB>([&](auto i) {
-            const int k = w * KB + i;
-            c.w2row[i] = theta[OFF_W2 + j + k * H];  // W2[j, k]
-            c.w2col[i] = theta[OFF_W2 + k + j * H];  // W2[k, j]
-        });
-        static_for<0, 3>([&](auto m) { c.w1[m] = theta[OFF_W1 + j + m * H]; });
-        c.b1 = theta[OFF_B1 + j]; c.b2 = theta[OFF_B2 + j]; c.w3 = theta[OFF_W3 + j]; c.b3 = theta[OFF_B3];
+        if constexpr (!ONE)
+            static_for<0, KB>([&](auto i) {
+                const int k = w * KB + i;
+                c.w2row[i] = theta_g[OFF_W2 + j + k * H];  // W2[j, k]
+                c.w2col[i] = theta_g[OFF_W2 + k + j * H];  // W2[k, j]
+            });
+        static_for<0, 3>([&](auto m) { c.w1[m] = theta_g[OFF_W1 + j + m * H]; });
+        c.b1 = theta_g[OFF_B1 + j]; c.b2 = theta_g[OFF_B2 + j]; c.w3 = theta_g[OFF_W3 + j]; c.b3 = theta_g[OFF_B3];
         c.F = mc.consts[0]; c.b0 = mc.consts[1]; c.mu_c = mc.consts[4]; c.sg = mc.consts[5]; c.ga = mc.consts[6];
         c.d = mc.consts[7]; c.la = mc.consts[8];
     }
-    // block sums of one 64-term hidden dot: this wavefront's blocks -> LDS, barrier, all four added left to right
-    template <class Wt>
-    static __device__ __forceinline__ double hidden_dot(const Ctx& c, const Wt& wt, double v, double* buf, double* vk) {
-        static_for<0, BPW>([&](auto bc) {
-            constexpr int b = bc;
-            double acc = 0.0;
-            static_for<0, 16>([&](auto ic) {
-                constexpr int i = b * 16 + ic;
-                const double x = readlane_f64(v, c.w * KB + i);
-                if (vk) vk[i] = x;
-                acc = __builtin_fma(wt[i], x, acc);
+    // 64-term hidden dot (ARITH-SPEC wide-dot rule: 4 blocks of 16, block sums added left to right)
+    //   ONE: the lane runs the four chains itself, W2 from LDS (row j, or column j when TRANSPOSED)
+    //   multi-wave: this wavefront's blocks -> LDS, barrier, all four added
+    template <bool TRANSPOSED>
+    static __device__ __forceinline__ double hidden_dot(const Ctx& c, double v, double* buf, double* vk) {
+        if constexpr (ONE) {
+            double tot = 0.0;
+            static_for<0, NBLK>([&](auto bc) {
+                constexpr int b = bc;
+                double acc = 0.0;
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int k = b * 16 + ic;
+                    const double x = readlane_f64(v, k);
+                    const double wv = TRANSPOSED ? c.W2p[k + c.j * LD] : c.W2p[c.j + k * LD];
+                    acc = __builtin_fma(wv, x, acc);
+                });
+                tot = b == 0 ? acc : tot + acc;
             });
-            buf[(c.w * BPW + b) * H + c.j] = acc;
-        });
-        __syncthreads();
-        double tot = buf[c.j];
-        static_for<1, NBLK>([&](auto b) { tot += buf[b * H + c.j]; });
-        return tot;
+            return tot;
+        } else {
+            static_for<0, BPW>([&](auto bc) {
+                constexpr int b = bc;
+                double acc = 0.0;
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = b * 16 + ic;
+                    const double x = readlane_f64(v, c.w * KB + i);
+                    if (vk) vk[i] = x;
+                    acc = __builtin_fma(TRANSPOSED ? c.w2col[i] : c.w2row[i], x, acc);
+                });
+                buf[(c.w * BPW + b) * H + c.j] = acc;
+            });
+            __syncthreads();
+            double tot = buf[c.j];
+            static_for<1, NBLK>([&](auto b) { tot += buf[b * H + c.j]; });
+            return tot;
+        }
     }
-    // forward network; a1k (optional): this lane's k-range of the first hidden activation
+    // forward network; a1k (optional, multi-wave): this lane's k-range of the first hidden activation
     static __device__ __forceinline__ double net(const Ctx& c, const double* x, double& a1, double& a2, double* a1k) {
         double z1 = 0.0;
         static_for<0, 3>([&](auto k) { z1 = __builtin_fma(c.w1[k], x[k], z1); });
@@ -244,7 +278,7 @@ struct SeirUde {
         a1 = dtanh(z1);
         double* pf = c.pf + (c.flip & 1) * NBLK * H;
         c.flip ^= 1;
-        const double z2 = hidden_dot(c, c.w2row, a1, pf, a1k) + c.b2;
+        const double z2 = hidden_dot<false>(c, a1, pf, a1k) + c.b2;
         a2 = dtanh(z2);
         return wave_tree_sum(c.w3 * a2) + c.b3;
     }
@@ -261,7 +295,7 @@ struct SeirUde {
         du[5] = c.d * c.ga * I - c.la * D;
         du[6] = c.sg * E;
     }
-    // extra parameter row e (0..6) of neuron j: theta index / cotangent
+    // extra parameter row e (0..6) of neuron j: theta index
     static __device__ __forceinline__ int extra_index(int e, int j) {
         switch (e) {
             case 0: case 1: case 2: return OFF_W1 + j + e * H;
@@ -271,37 +305,21 @@ struct SeirUde {
             default: return (e == 6 && j == 0) ? OFF_B3 : -1;
         }
     }
-    template <bool WANT_PARAM>
-    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam,
-                                               double* g) {
+    // shared part of the reverse sweep: deltas of the three layers and the state cotangent
+    struct Bwd {
+        double x[3], a1, a2, d1, d2, d3;
+    };
+    static __device__ __forceinline__ void sweep(const Ctx& c, const double* u, const double* lam, double* dlam, Bwd& q,
+                                                 double* a1k) {
         const double S = u[0], N = u[4], D = u[5];
-        const double x[3] = {S / N, u[2], D / N};
-        double a1, a2, a1k[KB];
-        net(c, x, a1, a2, a1k);
-        const double d3 = (lam[1] - lam[0]) * 1.0;  // output layer is linear
-        const double d2 = __builtin_fma(c.w3, d3, 0.0) * __builtin_fma(-a2, a2, 1.0);
-        const double s1 = hidden_dot(c, c.w2col, d2, c.pb, nullptr);
-        const double d1 = s1 * __builtin_fma(-a1, a1, 1.0);
+        q.x[0] = S / N; q.x[1] = u[2]; q.x[2] = D / N;
+        net(c, q.x, q.a1, q.a2, a1k);
+        q.d3 = (lam[1] - lam[0]) * 1.0;  // output layer is linear
+        q.d2 = __builtin_fma(c.w3, q.d3, 0.0) * __builtin_fma(-q.a2, q.a2, 1.0);
+        const double s1 = hidden_dot<true>(c, q.d2, c.pb, nullptr);
+        q.d1 = s1 * __builtin_fma(-q.a1, q.a1, 1.0);
         double gx[3];
-        static_for<0, 3>([&](auto m) { gx[m] = wave_tree_sum(c.w1[m] * d1); });
-        if constexpr (WANT_PARAM) {
-            static_for<0, KB>([&](auto i) { g[i] = d2 * a1k[i]; });
-            static_for<0, XS>([&](auto q) {
-                const int e = q * NW + c.w;  // wave-uniform
-                double v;
-                switch (e) {
-                    case 0: v = d1 * x[0]; break;
-                    case 1: v = d1 * x[1]; break;
-                    case 2: v = d1 * x[2]; break;
-                    case 3: v = d1; break;
-                    case 4: v = d2; break;
-                    case 5: v = d3 * a2; break;
-                    case 6: v = (c.j == 0) ? d3 : 0.0; break;
-                    default: v = 0.0;
-                }
-                g[KB + q] = v;
-            });
-        }
+        static_for<0, 3>([&](auto m) { gx[m] = wave_tree_sum(c.w1[m] * q.d1); });
         const double cc = c.b0 * c.F / N;
         const double cN = c.b0 * S * c.F / (N * N);
         dlam[0] = (-cc - c.mu_c) * lam[0] + cc * lam[1] + gx[0] / N;
@@ -311,6 +329,44 @@ struct SeirUde {
         dlam[4] = cN * lam[0] - cN * lam[1] - c.mu_c * lam[4] - gx[0] * S / (N * N) - gx[2] * D / (N * N);
         dlam[5] = -c.la * lam[5] + gx[2] / N;
         dlam[6] = 0.0;
+    }
+    static __device__ __forceinline__ double extra_value(const Ctx& c, const Bwd& q, int e) {
+        switch (e) {
+            case 0: return q.d1 * q.x[0];
+            case 1: return q.d1 * q.x[1];
+            case 2: return q.d1 * q.x[2];
+            case 3: return q.d1;
+            case 4: return q.d2;
+            case 5: return q.d3 * q.a2;
+            case 6: return (c.j == 0) ? q.d3 : 0.0;
+            default: return 0.0;
+        }
+    }
+    template <bool WANT_PARAM>
+    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam,
+                                               double* g) {
+        Bwd q;
+        double a1k[KB];
+        sweep(c, u, lam, dlam, q, ONE ? nullptr : a1k);
+        if constexpr (WANT_PARAM && !ONE) {
+            static_for<0, KB>([&](auto i) { g[i] = q.d2 * a1k[i]; });
+            static_for<0, XS>([&](auto qq) { g[KB + qq] = extra_value(c, q, qq * NW + c.w); });  // wave-uniform row
+        }
+    }
+    // fused accumulation (ONE): ab[s] = fma(bs, -g_s, ab[s]) (ae likewise with es) for this lane's 71 parameters;
+    // g = (df/dtheta)^T lam, so the accumulators hold the NEGATED cotangent the adjoint ODE integrates
+    template <bool WANT_E>
+    static __device__ __forceinline__ void vjp_acc(const Ctx& c, const double* u, const double* lam, double* dlam,
+                                                   double* ab, double* ae, double bs, double es) {
+        Bwd q;
+        sweep(c, u, lam, dlam, q, nullptr);
+        auto upd = [&](auto sc, double gpos) {
+            constexpr int s = sc;
+            ab[s] = __builtin_fma(bs, -gpos, ab[s]);
+            if constexpr (WANT_E) ae[s] = __builtin_fma(es, -gpos, ae[s]);
+        };
+        static_for<0, H>([&](auto k) { upd(k, q.d2 * readlane_f64(q.a1, decltype(k)::value)); });
+        static_for<0, NEXTRA>([&](auto e) { upd(std::integral_constant<int, H + decltype(e)::value>{}, extra_value(c, q, decltype(e)::value)); });
     }
     static __device__ __forceinline__ int slot_index(const ModelConsts&, int r, int s) {
         const int j = r & 63, w = r >> 6;
@@ -336,7 +392,7 @@ struct KppTrue : LinearTheta {
         double coff, cdiag, rr;
         int r, n;
     };
-    static __device__ __forceinline__ void init(Ctx& c, double*, double* scratch, double*, int, const ModelConsts& mc, int r) {
+    static __device__ __forceinline__ void init(Ctx& c, double*, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
         c.row = scratch;
         c.coff = mc.consts[0]; c.cdiag = mc.consts[1]; c.rr = mc.consts[2];
         c.r = r; c.n = mc.n_state;
@@ -401,7 +457,7 @@ struct KppUde : LinearTheta {
         int a_row[NSL], d_row[NSL];  // per owned parameter: LDS row of its a factor (-1: bias) and of its delta (-1: not NN)
         int kind[NSL];               // 0 NN weight/bias, 1 w1, 2 w2, 3 w3, 4 D0, -1 padding / unused slot
     };
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r) {
+    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
         c.th = th_lds;
         c.nn = th_lds + mc.nn_offset;
         c.urow = scratch; c.lrow = scratch + NPT + 2; c.A = scratch + 2 * NPT + 4; c.Dt = c.A + RA * G;

@@ -84,7 +84,7 @@ struct ude_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/end, bwd start/end
     bool ev_fwd = false, ev_bwd = false;
     // workspaces (grow on demand, reused across calls)
-    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs;
+    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs, slot_glob;
     int64_t trace_traj = -1;
     int32_t trace_cap = 0;
     // staging for the host-buffer entry points
@@ -176,7 +176,7 @@ static int default_lanes(int mid) {
         case MID_LV_HUDSON: return 8;
         case MID_LV_TANH32: return 32;
         case MID_SEIR_TRUE: return 1;
-        case MID_SEIR_UDE: return 256;  // 4 wavefronts per trajectory
+        case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32: return 32;
@@ -270,7 +270,7 @@ extern "C" void ude_destroy(ude_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs,
+    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs, &c->slot_glob,
                       &c->s_u0, &c->s_theta, &c->s_saveat, &c->s_out, &c->s_data, &c->s_mask, &c->s_gtheta,
                       &c->s_gu0, &c->s_loss, &c->s_lpt, &c->s_stats, &c->s_ret};
     for (DevBuf* b : bufs)
@@ -428,6 +428,11 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = ensure(c, c->cot, sizeof(double) * (size_t)ns * n * p.Npad))) return rc;
     if ((rc = ensure(c, c->loss_traj, sizeof(double) * N))) return rc;
     if ((rc = ensure(c, c->grad_part, sizeof(double) * (size_t)nwaves * np))) return rc;
+    p.slot_glob = nullptr;
+    if (l.slot_glob > 0) {  // slot state mu of the adjoint in HBM: [slot][thread]
+        if ((rc = ensure(c, c->slot_glob, sizeof(double) * (size_t)l.slot_glob * grid * BLOCK))) return rc;
+        p.slot_glob = (double*)c->slot_glob.p;
+    }
     if (!retcode) {
         if ((rc = ensure(c, c->retcode, sizeof(int32_t) * N))) return rc;
         retcode = (int32_t*)c->retcode.p;
