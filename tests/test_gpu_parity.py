@@ -283,10 +283,13 @@ def test_seir_true_matches_oracle():
     assert (rc == 0).all() and out[:, -1, 2].min() > 0          # the epidemic actually develops
 
 
-@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
-def test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg):
-    """dudt_ (seir_exposure.jl:114-147): 3-64-64-1 tanh exposure network, loss on rows 2:4 (E, I, R)."""
+@pytest.mark.parametrize("alg,oalg,lanes", [(U.Vern7, O.VERN7, 0), (U.Tsit5, O.TSIT5, 0), (U.Vern7, O.VERN7, 256), (U.Tsit5, O.TSIT5, 256)])
+def test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg, lanes):
+    """dudt_ (seir_exposure.jl:114-147): 3-64-64-1 tanh exposure network, loss on rows 2:4 (E, I, R).
+    lanes = 0: the default wavefront-per-trajectory kernels (deferred parameter cotangent); 256: four wavefronts per
+    trajectory (register-resident weight slices) -- both bit-identical to the oracle's wide-dot arithmetic."""
     N = 12
+    kw = {"ensemblealg": U.EnsembleMI355(lanes)} if lanes else {}
     u0, t = seir_inputs(N)
     truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
     rng = np.random.default_rng(11)
@@ -295,12 +298,12 @@ def test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg):
     mask = [0, 1, 1, 1, 0, 0, 0]
     f = models.dudt_()
     ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 21.0), th), u0)
-    sol = U.solve(ens, alg(), saveat=t, abstol=1e-6, reltol=1e-6)
+    sol = U.solve(ens, alg(), saveat=t, abstol=1e-6, reltol=1e-6, **kw)
     out, st, rc = O.solve_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6), u0, [0.0, 21.0], th, t)
     assert (rc == 0).all()
     assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts")
     assert_bitwise(sol.u, out, "forward states")
-    r = U.loss_and_gradient(ens, alg(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6)
+    r = U.loss_and_gradient(ens, alg(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6, **kw)
     ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6), u0, [0.0, 21.0], th, t, truth, row_mask=mask, nthreads=4)
     assert (r.retcode == 0).all()
     check_per_trajectory(r, ref)

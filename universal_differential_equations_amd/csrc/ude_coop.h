@@ -57,6 +57,12 @@ __device__ __forceinline__ double* xwave_buf() {
     __shared__ double buf[16];
     return buf;
 }
+// a wave-uniform value, forced into scalar registers
+__device__ __forceinline__ double uniform_f64(double x) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 // value of lane k (wave-uniform k) of this wavefront, as a scalar
 __device__ __forceinline__ double readlane_f64(double x, int k) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);

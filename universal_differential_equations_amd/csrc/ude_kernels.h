@@ -74,6 +74,7 @@ __device__ __forceinline__ double ulp_of(double x) {
 struct TabDev {
     double A[16][16];
     double B[16], BT[16], C[16];
+    double R[16][8];  // dense-output weights b_q(theta): 7-slot Horner tables (Tab::R), lane q of a CPL wavefront loads row q
 };
 
 template <class Tab>
@@ -89,6 +90,8 @@ inline TabDev make_tabdev() {
         for (int j = 0; j < Tab::S + e; ++j) t.A[Tab::S + e][j] = Tab::AE(e, j);
         t.C[Tab::S + e] = Tab::CE(e);
     }
+    for (int q = 0; q < Tab::NK; ++q)
+        for (int i = 0; i < 7; ++i) t.R[q][i] = Tab::R(q, i);
     return t;
 }
 
@@ -115,11 +118,20 @@ __device__ __forceinline__ double chain2(V1 v1, V2 v2) {
 // ---------------------------------------------------------------------------------------------
 // Stage storage of a REPLICATED state: one LDS word per (stage, component) and lane group -- or per wavefront when
 // a trajectory spans several (every wavefront keeps a private copy: no cross-wave ordering needed)
-// Component-per-lane (CPL) systems keep ONE component per lane: thread-private column, like a distributed state.
+// Component-per-lane (CPL) systems keep ONE component per lane (lane c <-> component c, c < KCP - 1; the other lanes
+// share the spare column KCP - 1 and only ever write zeros there): stage j of a wavefront at [wave][j][KCP].
+constexpr int KCP = 8;
 template <bool DIST, int G, int BLOCK, bool CPL = false>
-constexpr int k_stride() { return (DIST || CPL) ? BLOCK : (G > 64 ? BLOCK / 64 : BLOCK / G); }
+constexpr int k_stride() { return CPL ? KCP : DIST ? BLOCK : (G > 64 ? BLOCK / 64 : BLOCK / G); }
 template <bool DIST, int G, bool CPL = false>
-__device__ __forceinline__ int k_offset() { return (DIST || CPL) ? threadIdx.x : (G > 64 ? threadIdx.x / 64 : threadIdx.x / G); }
+__device__ __forceinline__ int k_offset(int nk = 0) {
+    if constexpr (CPL) {
+        const int lane = threadIdx.x & 63;
+        return (threadIdx.x >> 6) * nk * KCP + (lane < KCP - 1 ? lane : KCP - 1);
+    } else {
+        return DIST ? threadIdx.x : (G > 64 ? threadIdx.x / 64 : threadIdx.x / G);
+    }
+}
 // row of the partial-gradient matrix this thread's wavefront (or multi-wave trajectory) reports into
 template <int G, int BLOCK>
 __device__ __forceinline__ int64_t part_row() {
@@ -134,9 +146,9 @@ struct Driver {
     static constexpr bool USE_FSAL = Tab::FSAL && !Sys::ALWAYS_K0;
     static constexpr bool LDS_SLOTS = Sys::SLOTS_IN_LDS;  // slot state + accumulators are theta-indexed LDS arrays
     static constexpr bool SLOT_FSAL = USE_FSAL && NSL > 0 && !LDS_SLOTS;  // stage-0 slot derivative handed over in LDS
-    // fused accumulation: the model folds its parameter cotangent straight into accb/acce (no g[] array in between)
-    static constexpr bool FUSED = NSL > 0 && Sys::FUSED_ACC;
-    static_assert(!(FUSED && (USE_FSAL || LDS_SLOTS)), "fused accumulation re-evaluates stage 0");
+    // deferred slots: the system keeps per-stage factors and forms the slot sums / error norm / candidate at step end
+    static constexpr bool DEFER = Sys::DEFERRED;
+    static_assert(!DEFER || (NSL == 0 && !USE_FSAL), "deferred slots: the system owns the slot state");
     // stage derivatives of a REPLICATED state are stored once per group (all lanes read/write the same word)
     // CPL: stage derivatives stored one component per lane (lane c <-> component c): the weighted stage sums are
     // formed by that lane alone and broadcast with v_readlane -- NR times fewer LDS reads and fma's per lane
@@ -165,7 +177,7 @@ struct Driver {
         int iter = 0, ret = RET_SUCCESS;
         double tstop = sys.first_tstop();
         auto K = [&](int j, int c) -> double& { return kl[(j * NR + c) * KSTRIDE]; };
-        auto K1 = [&](int j) -> double& { return kl[j * BLOCK]; };  // CPL: this lane's component of stage j
+        auto K1 = [&](int j) -> double& { return kl[j * KCP]; };  // CPL: this lane's component of stage j
 
         // ---- initial dt (ode_determine_initdt), 2 evals ----
         if (o.dt0 > 0.0) {
@@ -180,16 +192,18 @@ struct Driver {
             if constexpr (Tab::FSAL) st.nf += 1;
         } else {
             double f0[NR], gs0[NSLA], f1[NR], gs1[NSLA], z1[NR];
-            if constexpr (LDS_SLOTS) sys.eval_acc(t, z, f0, 1.0, 0.0, true);  // ab = g0, ae = 0
-            else if constexpr (FUSED) {
-                static_for<0, NSL>([&](auto c) { accb[c] = 0.0; acce[c] = 0.0; });
-                sys.eval_fused(t, z, f0, accb, acce, 1.0, 0.0);  // accb = g0
-            } else sys.eval(t, z, f0, gs0);
+            if constexpr (DEFER) sys.eval_store(t, z, f0, 0);
+            else if constexpr (LDS_SLOTS) sys.eval_acc(t, z, f0, 1.0, 0.0, true);  // ab = g0, ae = 0
+            else sys.eval(t, z, f0, gs0);
             if constexpr (CPL) K1(0) = own_of(f0);
             else static_for<0, NR>([&](auto c) { K(0, c) = f0[c]; });
             // norms in double-double: slots first (lane-parallel), then the replicated components once
             double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
-            if constexpr (LDS_SLOTS) {
+            if constexpr (DEFER) {
+                sys.slot_init01(o, h0, l0, h1, l1);
+                group_dd_sum<G>(h0, l0);
+                group_dd_sum<G>(h1, l1);
+            } else if constexpr (LDS_SLOTS) {
                 sys.lds_sync();
                 for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) {
                     const double m = sys.mu[i];
@@ -198,16 +212,6 @@ struct Driver {
                     dd_acc(h0, l0, q0 * q0);
                     dd_acc(h1, l1, q1 * q1);
                 }
-                group_dd_sum<G>(h0, l0);
-                group_dd_sum<G>(h1, l1);
-            } else if constexpr (FUSED) {
-                static_for<0, NSL>([&](auto c) {
-                    const double m = mu[c * MS];
-                    const double sk = __builtin_fma(fabs(m), o.reltol, o.abstol);
-                    const double q0 = m / sk, q1 = accb[c] / sk;
-                    dd_acc(h0, l0, q0 * q0);
-                    dd_acc(h1, l1, q1 * q1);
-                });
                 group_dd_sum<G>(h0, l0);
                 group_dd_sum<G>(h1, l1);
             } else if constexpr (NSL > 0) {
@@ -258,11 +262,14 @@ struct Driver {
                 const double dt0t = tdir * dt0;
                 static_for<0, NR>([&](auto c) { z1[c] = __builtin_fma(dt0t, f0[c], z[c]); });
                 // (the slot part of u1 does not enter f: mu' is independent of mu)
-                if constexpr (LDS_SLOTS) sys.eval_acc(t + dt0t, z1, f1, 0.0, 1.0, false);  // ae = g1, ab untouched
-                else if constexpr (FUSED) sys.eval_fused(t + dt0t, z1, f1, accb, acce, 0.0, 1.0);  // acce = g1
+                if constexpr (DEFER) sys.eval_store(t + dt0t, z1, f1, 1);
+                else if constexpr (LDS_SLOTS) sys.eval_acc(t + dt0t, z1, f1, 0.0, 1.0, false);  // ae = g1, ab untouched
                 else sys.eval(t + dt0t, z1, f1, gs1);
                 double h2 = 0.0, l2 = 0.0;
-                if constexpr (LDS_SLOTS) {
+                if constexpr (DEFER) {
+                    sys.slot_init2(o, h2, l2);
+                    group_dd_sum<G>(h2, l2);
+                } else if constexpr (LDS_SLOTS) {
                     sys.lds_sync();
                     for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) {
                         const double sk = __builtin_fma(fabs(sys.mu[i]), o.reltol, o.abstol);
@@ -271,13 +278,6 @@ struct Driver {
                     }
                     group_dd_sum<G>(h2, l2);
                     sys.lds_sync();
-                } else if constexpr (FUSED) {
-                    static_for<0, NSL>([&](auto c) {
-                        const double sk = __builtin_fma(fabs(mu[c * MS]), o.reltol, o.abstol);
-                        const double q = (acce[c] - accb[c]) / sk;
-                        dd_acc(h2, l2, q * q);
-                    });
-                    group_dd_sum<G>(h2, l2);
                 } else if constexpr (NSL > 0) {
                     static_for<0, NSL>([&](auto c) {
                         const double sk = __builtin_fma(fabs(mu[c * BLOCK]), o.reltol, o.abstol);
@@ -350,9 +350,8 @@ struct Driver {
                     acce[c] = es * g0;
                 });
             }
-            if constexpr (FUSED) static_for<0, NSL>([&](auto c) { accb[c] = 0.0; acce[c] = 0.0; });
             for (int s = USE_FSAL ? 1 : 0; s < S; ++s) {
-                double zs[NR], kr[NR], gs[FUSED ? 1 : NSLA];
+                double zs[NR], kr[NR], gs[NSLA];
                 if (s == 0) {
                     static_for<0, NR>([&](auto c) { zs[c] = z[c]; });
                 } else if constexpr (CPL) {
@@ -371,12 +370,12 @@ struct Driver {
                     });
                 }
                 if (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
-                if constexpr (LDS_SLOTS) sys.eval_acc(t + tab->C[s] * dt, zs, kr, tab->B[s], tab->BT[s], s == 0);
-                else if constexpr (FUSED) sys.eval_fused(t + tab->C[s] * dt, zs, kr, accb, acce, tab->B[s], tab->BT[s]);
+                if constexpr (DEFER) sys.eval_store(t + tab->C[s] * dt, zs, kr, s);
+                else if constexpr (LDS_SLOTS) sys.eval_acc(t + tab->C[s] * dt, zs, kr, tab->B[s], tab->BT[s], s == 0);
                 else sys.eval(t + tab->C[s] * dt, zs, kr, gs);
                 if constexpr (CPL) K1(s) = own_of(kr);
                 else static_for<0, NR>([&](auto c) { K(s, c) = kr[c]; });
-                if constexpr (NSL > 0 && !LDS_SLOTS && !FUSED) {
+                if constexpr (NSL > 0 && !LDS_SLOTS) {
                     const double bs = tab->B[s], es = tab->BT[s];
                     if (s == 0) {
                         static_for<0, NSL>([&](auto c) {
@@ -427,6 +426,7 @@ struct Driver {
                 ss = __builtin_fma(res, res, ss);
             });
             if constexpr (Sys::STATE_DISTRIBUTED) ss = group_sum<G>(ss);
+            if constexpr (DEFER) ss += group_sum<G>(sys.slot_step(dt, tab, o));
             if constexpr (LDS_SLOTS) {
                 sys.lds_sync();
                 double ps = 0.0;
@@ -485,7 +485,7 @@ struct Driver {
                         if constexpr (Tab::NEXTRA > 0) {
                             if (!lazy_done) {
                                 for (int e = 0; e < Tab::NEXTRA; ++e) {
-                                    double zs[NR], kr[NR], gs[FUSED ? 1 : NSLA];
+                                    double zs[NR], kr[NR], gs[NSLA];
                                     const int row = S + e;
                                     if constexpr (CPL) {
                                         double acc = tab->A[row][0] * K1(0);
@@ -523,6 +523,7 @@ struct Driver {
                 } else {
                     static_for<0, NSL>([&](auto c) { mu[c * MS] = accb[c]; });
                 }
+                if constexpr (DEFER) sys.slot_accept();
                 if constexpr (USE_FSAL && CPL) K1(0) = K1(S - 1);
                 else if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
                 if constexpr (SLOT_FSAL) { double* tsw = gtmp; gtmp = gtmp2; gtmp2 = tsw; }
@@ -559,7 +560,7 @@ template <class Model, class Tab, int G, int BLOCKDIM>
 struct FwdSys {
     static constexpr int NR = Model::NS, NSL = 0;
     static constexpr bool ALWAYS_K0 = false, SLOTS_IN_LDS = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
-    static constexpr bool FUSED_ACC = false, SLOTS_GLOBAL = false, CPL = Model::CPL;
+    static constexpr bool SLOTS_GLOBAL = false, CPL = Model::CPL, DEFERRED = false;
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;      // trajectory
@@ -616,7 +617,7 @@ struct FwdSys {
     __device__ __forceinline__ int accepted(double tprev, double t, double dt, const double* z, const double* znew,
                                             const double* kl, Lazy& lazy) {
         auto k = [&](int q, int c) { return kl[(q * NR + c) * k_stride<STATE_DISTRIBUTED, G, BLOCKDIM>()]; };
-        auto k1 = [&](int q) { return kl[q * BLOCKDIM]; };  // CPL: this lane's component
+        auto k1 = [&](int q) { return kl[q * KCP]; };  // CPL: this lane's component
         while (si < p->ns && p->saveat[si] <= t) {
             const double curt = p->saveat[si];
             if (curt != t) {
@@ -676,7 +677,8 @@ struct FwdSys {
 template <class Model, class Tab, int G, int BLOCK, bool CPL = Model::CPL>
 struct Layout {
     static constexpr int KSTRIDE = k_stride<Model::STATE_DISTRIBUTED, G, BLOCK, CPL>();
-    static constexpr int K_DOUBLES = Tab::NK * (CPL ? 1 : Model::NS) * KSTRIDE;
+    static_assert(!CPL || Model::NS < KCP, "component-per-lane: state must fit the KCP columns");
+    static constexpr int K_DOUBLES = CPL ? (BLOCK / 64) * Tab::NK * KCP : Tab::NK * Model::NS * KSTRIDE;
     // group-shared forward-interval cache of the adjoint kernel (see AdjSys::IC_LDS)
     static constexpr bool IC_LDS = (G >= 5) && !Model::STATE_DISTRIBUTED && !Model::SLOTS_IN_LDS && !Model::CPL;
     static constexpr int IC_DOUBLES = IC_LDS ? (Model::NS + Tab::NK * Model::NS) * (BLOCK / G) : 0;
@@ -711,7 +713,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     sys.r = r;
     sys.n = p.n_state;
     double z[Sys::NR];
-    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>();
+    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>(Tab::NK);
     double* mu = nullptr;  // no slot state in the forward pass
     static_for<0, Sys::NR>([&](auto c) { z[c] = sys.cvalid(c) ? p.u0[(size_t)gid * p.n_state + sys.comp(c)] : 0.0; });
     while (sys.si < p.ns && p.saveat[sys.si] <= p.t0) {  // save_start
@@ -741,12 +743,13 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
 // ---------------------------------------------------------------------------------------------
 template <class Model, class Tab, int G>
 struct AdjSys {
-    static constexpr int NR = Model::NS, NSL = Model::NSL;
+    static constexpr bool DEFERRED = Model::DEFERRED;
+    static constexpr int NR = Model::NS, NSL = DEFERRED ? 0 : Model::NSL;
     static constexpr bool SLOTS_IN_LDS = Model::SLOTS_IN_LDS, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     // LDS-slot models re-evaluate stage 0 every step (its parameter cotangent is folded straight into the shared
     // accumulators); register-slot models hand k_S -> k_0 AND its slot derivative over (FSAL, as upstream)
-    static constexpr bool FUSED_ACC = Model::FUSED_ACC, SLOTS_GLOBAL = Model::SLOTS_GLOBAL, CPL = Model::CPL;
-    static constexpr bool ALWAYS_K0 = SLOTS_IN_LDS || FUSED_ACC;
+    static constexpr bool SLOTS_GLOBAL = Model::SLOTS_GLOBAL, CPL = Model::CPL;
+    static constexpr bool ALWAYS_K0 = SLOTS_IN_LDS || DEFERRED;
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;
@@ -807,30 +810,54 @@ struct AdjSys {
         while (t < ts && sf > 0) load_interval(sf - 1);
         while (t >= te && sf < nsteps - 1) load_interval(sf + 1);
     }
-    // fused accumulation: accb = fma(bs, g, accb), acce = fma(es, g, acce) with g = -(df/dtheta)^T lam
-    __device__ __forceinline__ void eval_fused(double t, const double* lam, double* klam, double* accb, double* acce,
-                                               double bs, double es) {
-        if constexpr (FUSED_ACC) {
+    // ---- deferred slots: slot state in HBM, two columns (current / candidate) that swap on acceptance ----
+    double *mu_cur, *mu_new;
+    int ms;
+    double rq[7];  // CPL: lane q's Horner table of b_q(theta)
+    __device__ __forceinline__ void load_bth_table() {
+        const int q = mctx.r < Tab::NK ? mctx.r : 0;
+        static_for<0, 7>([&](auto i) { rq[i] = p->tab->R[q][i]; });
+    }
+    // b_q(theta) evaluated by lane q alone (bit-identical to Tab::bth), handed to the component lanes as scalars
+    __device__ __forceinline__ void bth_lanes(double th, double* b) const {
+        double h = rq[0];
+        static_for<1, 7>([&](auto i) { h = __builtin_fma(th, h, rq[i]); });
+        const double bq = (mctx.r == 0 ? th : th * th) * h;
+        static_for<0, Tab::NK>([&](auto q) {
+            if constexpr (Tab::dense_uses(q)) b[q] = readlane_f64(bq, decltype(q)::value);
+        });
+    }
+    __device__ __forceinline__ void eval_store(double t, const double* lam, double* klam, int s) {
+        if constexpr (DEFERRED) {
             asm volatile("" ::: "memory");
             locate(t);
             const double dtf = te - ts;
             const double th = (t - ts) / dtf;
             double b[Tab::NK], y[NR], dl[NR];
-            Tab::bth(th, b);
-            if constexpr (CPL) {
-                const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][0]; }, [&](auto q) { return b[q]; });
-                bcast_all(__builtin_fma(dtf, acc, us[0]), y);
-            } else
-            static_for<0, NR>([&](auto c) {
-                const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
-                y[c] = __builtin_fma(dtf, acc, US(c));
-            });
-            Model::template vjp_acc<true>(mctx, y, lam, dl, accb, acce, bs, es);
+            bth_lanes(th, b);
+            static_assert(!DEFERRED || CPL, "deferred slots come with component-per-lane interval caches");
+            const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][0]; }, [&](auto q) { return b[q]; });
+            bcast_all(__builtin_fma(dtf, acc, us[0]), y);
+            Model::vjp_store(mctx, y, lam, dl, s);
             static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
         }
     }
+    __device__ __forceinline__ void slot_init01(const Opts& o, double& h0, double& l0, double& h1, double& l1) {
+        if constexpr (DEFERRED) Model::init_norm01(mctx, o.abstol, o.reltol, mu_cur, ms, h0, l0, h1, l1);
+    }
+    __device__ __forceinline__ void slot_init2(const Opts& o, double& h2, double& l2) {
+        if constexpr (DEFERRED) Model::init_norm2(mctx, o.abstol, o.reltol, mu_cur, ms, h2, l2);
+    }
+    __device__ __forceinline__ double slot_step(double dt, const TabDev* tab, const Opts& o) {
+        if constexpr (DEFERRED)
+            return Model::template step_slots<Tab::S>(mctx, tab->B, tab->BT, dt, o.abstol, o.reltol, mu_cur, mu_new, ms);
+        else return 0.0;
+    }
+    __device__ __forceinline__ void slot_accept() {
+        double* t = mu_cur; mu_cur = mu_new; mu_new = t;
+    }
     __device__ __forceinline__ void eval(double t, const double* lam, double* klam, double* g) {
-      if constexpr (!SLOTS_IN_LDS && !FUSED_ACC) {
+      if constexpr (!SLOTS_IN_LDS && !DEFERRED) {
         asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
         locate(t);
         const double dtf = te - ts;
@@ -932,7 +959,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     constexpr int NSL = Sys::NSL;
     constexpr int NSLA = NSL > 0 ? NSL : 1;
-    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>();
+    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>(Tab::NK);
     // register-slot mode: slot state mu of thread tid, element c at mu_lds[c * BLOCK]
     constexpr bool SG = Model::SLOTS_GLOBAL;  // mu in HBM (fused-accumulation models: nothing else needs a column)
     const int MS = SG ? (int)(gridDim.x * BLOCK) : BLOCK;
@@ -942,7 +969,9 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     double* icbase = slots + (SG ? (size_t)0 : (size_t)3 * NSLA * BLOCK);  // interval cache rows (IC_LDS), one per group
     double lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
-    static_for<0, NSL>([&](auto c) { mu_lds[c * MS] = 0.0; });
+    constexpr int NSLOT = Model::DEFERRED ? Model::NSL : NSL;  // slots this thread reports (deferred: system-owned)
+    static_for<0, NSLOT>([&](auto c) { mu_lds[(size_t)c * MS] = 0.0; });
+    double* mu_final = mu_lds;
     const bool in_range = gid < p.N && (int)threadIdx.x < GROUPS * G;
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
@@ -953,6 +982,10 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         sys.p = &p;
         sys.j = gid;
         sys.n = p.n_state;
+        if constexpr (Model::DEFERRED) sys.load_bth_table();
+        sys.mu_cur = mu_lds;
+        sys.mu_new = mu_lds + (size_t)(Model::DEFERRED ? Model::NSL : 0) * MS;
+        sys.ms = MS;
         sys.ic = icbase + threadIdx.x / G;
         sys.icstride = BLOCK / G;
         sys.nsteps = p.dense_n[gid];
@@ -970,6 +1003,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         sys.at_tstop(p.tf, lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
         const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st, gtmp, gtmp2, MS);
+        if constexpr (Model::DEFERRED) mu_final = sys.mu_cur;
         if (r == 0) {
             if (p.stats) {
                 int64_t* s = p.stats + (size_t)gid * 8;
@@ -982,7 +1016,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
                 if (sys.cwrite(c)) p.grad_u0[(size_t)gid * p.n_state + sys.comp(c)] = lam[c];
             });
         if (ret != RET_SUCCESS) {  // never poison the batch gradient
-            static_for<0, NSL>([&](auto c) { mu_lds[c * MS] = 0.0; });
+            static_for<0, NSLOT>([&](auto c) { mu_final[(size_t)c * MS] = 0.0; });
             if constexpr (Model::SLOTS_IN_LDS) {
                 __syncthreads();
                 for (int i = r; i < p.n_param; i += G) slots[i] = 0.0;
@@ -1018,9 +1052,9 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         // one wavefront per trajectory, mu in HBM: the wave's partial row is its own mu, slot by slot
         static_assert(G == 64, "HBM slot state: one wavefront per trajectory");
         double* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
-        static_for<0, NSL>([&](auto c) {
+        static_for<0, NSLOT>([&](auto c) {
             const int idx = Model::slot_index(p.mc, r, c);
-            if (idx >= 0) row[idx] = mu_lds[c * MS];
+            if (idx >= 0) row[idx] = mu_final[(size_t)c * MS];
         });
     }
     if constexpr (!SG && !Model::SLOTS_IN_LDS && pow2_group<G>()) {

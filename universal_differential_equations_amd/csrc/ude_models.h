@@ -29,6 +29,7 @@ struct LinearTheta {
     static constexpr bool FUSED_ACC = false;     // parameter cotangent returned as g[] (not folded into accumulators)
     static constexpr bool SLOTS_GLOBAL = false;  // slot state mu in LDS (per-thread column)
     static constexpr bool CPL = false;           // component-per-lane stage storage (replicated small states, G = 64)
+    static constexpr bool DEFERRED = false;      // adjoint keeps per-stage FACTORS of the parameter cotangent (see SeirUde)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -196,15 +197,22 @@ struct SeirUde {
     // itself (touched once per step) lives in HBM.  G = 128/256: W2 slices in registers, theta read from HBM once.
     static constexpr bool ONE = NW == 1;
     static constexpr bool THETA_GLOBAL = !ONE, FUSED_ACC = ONE, SLOTS_GLOBAL = ONE, CPL = ONE;
+    // DEFERRED (ONE): the W2 cotangent of a stage is the outer product -delta2 (x) a1, so the adjoint pass stores the
+    // FACTORS of every stage (5 doubles per lane and stage, LDS) and forms the RK-weighted sums slot by slot at the
+    // end of the step, fused with the error norm and the mu update: the identical fma chains (ascending stage
+    // order), but no 2 x 71 persistent accumulators per lane and no per-evaluation broadcast of a1 for them.
+    static constexpr bool DEFERRED = ONE;
+    static constexpr int NSTG = 10, NFAC = 5, WPB = 4;  // stages stored (Vern7), factor fields, wavefronts per block
     static constexpr int LD = 65;  // leading dimension of the LDS copy of W2: row AND column reads conflict-free
     static constexpr int NPARAM = 3 * H + H + H * H + H + H + 1;  // 4481
     static constexpr int OFF_W1 = 0, OFF_B1 = 3 * H, OFF_W2 = 4 * H, OFF_B2 = 4 * H + H * H, OFF_W3 = OFF_B2 + H,
                          OFF_B3 = OFF_W3 + H;
-    static constexpr int SCRATCH = ONE ? 0 : 3 * NBLK * H;  // block sums: forward (double-buffered) + transposed
+    static constexpr int SCRATCH = ONE ? WPB * NSTG * NFAC * H : 3 * NBLK * H;  // stage factors / block sums
     struct Ctx {
         double w2row[ONE ? 1 : KB], w2col[ONE ? 1 : KB], w1[3], b1, b2, w3, b3;
         const double* W2p;  // LDS, ld = 65 (ONE)
         double *pf, *pb;    // LDS block-sum exchange (multi-wave)
+        double* fac;        // LDS stage factors of this wavefront: field f of stage s at fac[(s*NFAC + f)*H + lane]
         double F, b0, mu_c, sg, ga, d, la;
         int j, w, r;
         mutable int flip;
@@ -222,6 +230,7 @@ struct SeirUde {
         c.j = j; c.w = w; c.r = r; c.flip = 0;
         c.W2p = th;
         c.pf = scratch; c.pb = scratch + 2 * NBLK * H;
+        c.fac = scratch + ((threadIdx.x >> 6) % WPB) * (NSTG * NFAC * H);
         if constexpr (!ONE)
             static_for<0, KB>([&](auto i) {
                 const int k = w * KB + i;
@@ -239,18 +248,21 @@ struct SeirUde {
     template <bool TRANSPOSED>
     static __device__ __forceinline__ double hidden_dot(const Ctx& c, double v, double* buf, double* vk) {
         if constexpr (ONE) {
+            // one block of 16 terms per trip of a RUNTIME loop: bounds the loads / scalars in flight (the fully
+            // unrolled 64-term dot made the compiler hoist everything and spill)
             double tot = 0.0;
-            static_for<0, NBLK>([&](auto bc) {
-                constexpr int b = bc;
+            const double* wp = TRANSPOSED ? c.W2p + c.j * LD : c.W2p + c.j;
+#pragma unroll 1
+            for (int b = 0; b < NBLK; ++b) {
                 double acc = 0.0;
                 static_for<0, 16>([&](auto ic) {
-                    constexpr int k = b * 16 + ic;
+                    const int k = b * 16 + decltype(ic)::value;
                     const double x = readlane_f64(v, k);
-                    const double wv = TRANSPOSED ? c.W2p[k + c.j * LD] : c.W2p[c.j + k * LD];
+                    const double wv = TRANSPOSED ? wp[k] : wp[k * LD];
                     acc = __builtin_fma(wv, x, acc);
                 });
                 tot = b == 0 ? acc : tot + acc;
-            });
+            }
             return tot;
         } else {
             static_for<0, BPW>([&](auto bc) {
@@ -367,6 +379,124 @@ struct SeirUde {
         };
         static_for<0, H>([&](auto k) { upd(k, q.d2 * readlane_f64(q.a1, decltype(k)::value)); });
         static_for<0, NEXTRA>([&](auto e) { upd(std::integral_constant<int, H + decltype(e)::value>{}, extra_value(c, q, decltype(e)::value)); });
+    }
+    // ---- deferred parameter cotangent (ONE) ----
+    // reverse sweep at stage s: state cotangent out, factors (a1, a2, delta1, delta2 | x0 x1 x2 d3 on lanes 0..3) to LDS
+    static __device__ __forceinline__ void vjp_store(const Ctx& c, const double* u, const double* lam, double* dlam, int s) {
+        Bwd q;
+        sweep(c, u, lam, dlam, q, nullptr);
+        double* f = c.fac + s * (NFAC * H) + c.j;
+        f[0] = q.a1; f[H] = q.a2; f[2 * H] = q.d1; f[3 * H] = q.d2;
+        f[4 * H] = c.j == 0 ? q.x[0] : c.j == 1 ? q.x[1] : c.j == 2 ? q.x[2] : q.d3;
+    }
+    // g_s of slot `slot` of this lane: the NEGATED cotangent -(df/dtheta)^T lam at stage s (what the adjoint integrates)
+    //   slot k < 64: W2[j,k]: -(delta2_s[j] * a1_s[k]);  64..66: W1[j,m]: -(delta1*x_m); 67: b1: -delta1; 68: b2: -delta2;
+    //   69: W3[j]: -(d3*a2); 70: b3 (lane 0): -d3
+    struct Fac {  // this lane's factors of all stages (registers)
+        double a2[NSTG], d1[NSTG], d2[NSTG];
+    };
+    template <int NST>
+    static __device__ __forceinline__ void load_factors(const Ctx& c, Fac& f) {
+        static_for<0, NST>([&](auto s) {
+            const double* p = c.fac + decltype(s)::value * (NFAC * H) + c.j;
+            f.a2[s] = p[H]; f.d1[s] = p[2 * H]; f.d2[s] = p[3 * H];
+        });
+    }
+    // g_s (all stored stages) of one slot; slot index wave-uniform
+    template <int NST>
+    static __device__ __forceinline__ void g_w2(const Ctx& c, const Fac& f, int k, double* g) {
+        static_for<0, NST>([&](auto s) { g[s] = -(f.d2[s] * c.fac[decltype(s)::value * (NFAC * H) + k]); });
+    }
+    template <int NST>
+    static __device__ __forceinline__ void g_extra(const Ctx& c, const Fac& f, int e, double* g) {
+        static_for<0, NST>([&](auto s) {
+            const double* p = c.fac + decltype(s)::value * (NFAC * H) + 4 * H;  // x0 x1 x2 d3
+            double v;
+            switch (e) {
+                case 0: v = -(f.d1[s] * p[0]); break;
+                case 1: v = -(f.d1[s] * p[1]); break;
+                case 2: v = -(f.d1[s] * p[2]); break;
+                case 3: v = -f.d1[s]; break;
+                case 4: v = -f.d2[s]; break;
+                case 5: v = -(p[3] * f.a2[s]); break;
+                default: v = c.j == 0 ? -p[3] : -0.0;
+            }
+            g[s] = v;
+        });
+    }
+    // slots in order 0..70, mu read in chunks of CH (next chunk in flight while this one is processed):
+    // body(slot, g[NST], m) with m = mu[slot]
+    template <int NST, class Body>
+    static __device__ __forceinline__ void for_each_slot(const Ctx& c, const Fac& f, const double* mu, int ms, Body body) {
+        constexpr int CH = 8;
+        double mcur[CH], mnext[CH];
+        static_for<0, CH>([&](auto i) { mcur[i] = mu[(size_t)decltype(i)::value * ms]; });
+#pragma unroll 1
+        for (int k0 = 0; k0 < H; k0 += CH) {
+            // prefetch: next W2 chunk, or (last round) the 7 extras
+            static_for<0, CH>([&](auto i) {
+                const int sl = k0 + CH + decltype(i)::value;
+                mnext[i] = sl < NSL ? mu[(size_t)sl * ms] : 0.0;
+            });
+            static_for<0, CH>([&](auto i) {
+                double g[NST];
+                g_w2<NST>(c, f, k0 + decltype(i)::value, g);
+                body(k0 + decltype(i)::value, g, mcur[i]);
+            });
+            static_for<0, CH>([&](auto i) { mcur[i] = mnext[i]; });
+        }
+        static_for<0, NEXTRA>([&](auto e) {
+            double g[NST];
+            g_extra<NST>(c, f, decltype(e)::value, g);
+            body(H + decltype(e)::value, g, mcur[e]);
+        });
+    }
+    // end of a step with NST stages: for every slot, ab = sum_s B_s g_s and ae = sum_s BT_s g_s (fma chains in ascending
+    // stage order, started by the product), candidate mu_new = fma(dt, ab, mu), residual^2 accumulated in slot order
+    template <int NST>
+    static __device__ __forceinline__ double step_slots(const Ctx& c, const double* B, const double* BT, double dt,
+                                                        double abstol, double reltol, const double* mu, double* mu_new,
+                                                        int ms) {
+        Fac f;
+        load_factors<NST>(c, f);
+        double bb[NST], bt[NST];  // tableau weights as scalars (one load per step, not per slot)
+        static_for<0, NST>([&](auto s) { bb[s] = uniform_f64(B[s]); bt[s] = uniform_f64(BT[s]); });
+        double ps = 0.0;
+        for_each_slot<NST>(c, f, mu, ms, [&](int slot, const double* g, double m0) {
+            double ab = bb[0] * g[0], ae = bt[0] * g[0];
+            static_for<1, NST>([&](auto s) {
+                ab = __builtin_fma(bb[s], g[s], ab);
+                ae = __builtin_fma(bt[s], g[s], ae);
+            });
+            const double m1 = __builtin_fma(dt, ab, m0);
+            mu_new[(size_t)slot * ms] = m1;
+            const double a0 = fabs(m0), a1 = fabs(m1);
+            const double res = (dt * ae) / __builtin_fma((a0 > a1 ? a0 : a1), reltol, abstol);
+            ps = __builtin_fma(res, res, ps);
+        });
+        return ps;
+    }
+    // initial-dt norms: stage 0 holds g0 = f0's slot part, stage 1 (second call) g1
+    static __device__ __forceinline__ void init_norm01(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
+                                                       double& h0, double& l0, double& h1, double& l1) {
+        Fac f;
+        load_factors<1>(c, f);
+        for_each_slot<1>(c, f, mu, ms, [&](int, const double* g, double m) {
+            const double sk = __builtin_fma(fabs(m), reltol, abstol);
+            const double q0 = m / sk, q1 = g[0] / sk;
+            dd_acc(h0, l0, q0 * q0);
+            dd_acc(h1, l1, q1 * q1);
+        });
+    }
+    static __device__ __forceinline__ void init_norm2(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
+                                                      double& h2, double& l2) {
+        Fac f;
+        load_factors<2>(c, f);
+        for_each_slot<2>(c, f, mu, ms, [&](int, const double* g, double m) {
+            const double sk = __builtin_fma(fabs(m), reltol, abstol);
+            const double q = (g[1] - g[0]) / sk;
+            dd_acc(h2, l2, q * q);
+        });
     }
     static __device__ __forceinline__ int slot_index(const ModelConsts&, int r, int s) {
         const int j = r & 63, w = r >> 6;

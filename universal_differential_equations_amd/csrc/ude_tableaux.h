@@ -48,6 +48,16 @@ struct Tsit5Tab {  // Tsit5(): LotkaVolterra/scenario_1.jl:191,202,206; FisherKP
 #undef H3_
     }
     static constexpr bool dense_uses(int j) { return j < 7; }
+    // b_q(theta) as a 7-slot Horner table, highest order first, padded with LEADING zeros (fma(th, 0, c) == c exactly):
+    //   h = R(q,0); h = fma(th, h, R(q,i)) i = 1..6;  b_q = (q == 0 ? th : th*th) * h  -- bit-identical to bth()
+    static constexpr double R(int q, int i) {
+        constexpr double r[7][7] = {
+            {0, 0, 0, T_(r14), T_(r13), T_(r12), T_(r11)},
+            {0, 0, 0, 0, T_(r24), T_(r23), T_(r22)}, {0, 0, 0, 0, T_(r34), T_(r33), T_(r32)},
+            {0, 0, 0, 0, T_(r44), T_(r43), T_(r42)}, {0, 0, 0, 0, T_(r54), T_(r53), T_(r52)},
+            {0, 0, 0, 0, T_(r64), T_(r63), T_(r62)}, {0, 0, 0, 0, T_(r74), T_(r73), T_(r72)}};
+        return r[q][i];
+    }
 };
 #undef T_
 
@@ -109,6 +119,27 @@ struct Vern7Tab {  // Vern7(): scenario_1.jl:41,84; SEIR_exposure/seir_exposure.
 #undef P6_
 #undef F_
     static constexpr bool dense_uses(int j) { return !(j == 1 || j == 2 || j == 9); }
+    // 7-slot Horner table of b_q(theta) (see Tsit5Tab::R)
+    static constexpr double R(int q, int i) {
+        constexpr double r[16][7] = {
+            {V_(r017), V_(r016), V_(r015), V_(r014), V_(r013), V_(r012), V_(r011)},
+            {0, 0, 0, 0, 0, 0, 0},
+            {0, 0, 0, 0, 0, 0, 0},
+            {0, V_(r047), V_(r046), V_(r045), V_(r044), V_(r043), V_(r042)},
+            {0, V_(r057), V_(r056), V_(r055), V_(r054), V_(r053), V_(r052)},
+            {0, V_(r067), V_(r066), V_(r065), V_(r064), V_(r063), V_(r062)},
+            {0, V_(r077), V_(r076), V_(r075), V_(r074), V_(r073), V_(r072)},
+            {0, V_(r087), V_(r086), V_(r085), V_(r084), V_(r083), V_(r082)},
+            {0, V_(r097), V_(r096), V_(r095), V_(r094), V_(r093), V_(r092)},
+            {0, 0, 0, 0, 0, 0, 0},
+            {0, V_(r117), V_(r116), V_(r115), V_(r114), V_(r113), V_(r112)},
+            {0, V_(r127), V_(r126), V_(r125), V_(r124), V_(r123), V_(r122)},
+            {0, V_(r137), V_(r136), V_(r135), V_(r134), V_(r133), V_(r132)},
+            {0, V_(r147), V_(r146), V_(r145), V_(r144), V_(r143), V_(r142)},
+            {0, V_(r157), V_(r156), V_(r155), V_(r154), V_(r153), V_(r152)},
+            {0, V_(r167), V_(r166), V_(r165), V_(r164), V_(r163), V_(r162)}};
+        return r[q][i];
+    }
 };
 #undef V_
 

@@ -232,6 +232,8 @@ def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=
     eng = Engine.get(device)
     if isinstance(ensemblealg, EnsembleMI355):
         eng.set_launch(ensemblealg.lanes_per_traj, ensemblealg.max_dense_steps)
+    else:
+        eng.set_launch()  # library defaults (the engine is shared: do not inherit another call's launch options)
     o = _opts(alg, **kw)
     u0 = _np(prob.u0s if ens else base.u0)
     if u0.ndim == 1:
@@ -268,6 +270,8 @@ def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblea
     eng = Engine.get(device)
     if isinstance(ensemblealg, EnsembleMI355):
         eng.set_launch(ensemblealg.lanes_per_traj, ensemblealg.max_dense_steps)
+    else:
+        eng.set_launch()  # library defaults (the engine is shared: do not inherit another call's launch options)
     o = _opts(alg, sensealg=sensealg, **kw)
     u0 = _np(prob.u0s if ens else base.u0)
     if u0.ndim == 1:
