@@ -251,24 +251,45 @@ int FN(udeo_rhs_vjp)(const udeo_model_desc* m, const REAL* th, const REAL* u, RE
             const int n = m->n_state;
             const REAL w1 = th[m->stencil_offset], w2 = th[m->stencil_offset + 1],
                        w3 = th[m->stencil_offset + 2], D0 = th[m->d0_offset];
-            REAL gw1 = 0, gw2 = 0, gw3 = 0, gD = 0;
-            for (int i = 0; i < n; ++i) {
-                const int im = (i + n - 1) % n, ip = (i + 1) % n;
-                REAL gx[1];
-                FN(mlp_forward)(m, th + m->nn_offset, &u[i], zs, as);
-                FN(mlp_vjp)(m, th + m->nn_offset, zs, as, &lam[i], gx, dth ? dth + m->nn_offset : 0);
-                /* transpose of the periodic 3-tap stencil */
-                dlam[i] = gx[0] + D0 * (w1 * lam[ip] + w2 * lam[i] + w3 * lam[im]);
-                gw1 += lam[i] * u[im];
-                gw2 += lam[i] * u[i];
-                gw3 += lam[i] * u[ip];
-                gD += lam[i] * (w1 * u[im] + w2 * u[i] + w3 * u[ip]);
+            /* ARITH-SPEC: every parameter-cotangent sum over the grid runs over BLOCKS of 256 consecutive points: a
+             * sequential chain (from 0, ascending points) inside a block, the block sums added left to right.  (The
+             * device gives each 256-point block to one wavefront; grids of <= 256 points are a single chain.) */
+            enum { KPP_BLOCK = 256 };
+            const int np = m->n_param;
+            REAL* blk = dth ? (REAL*)calloc((size_t)2 * np + 8, sizeof(REAL)) : 0;
+            REAL* tot = blk ? blk + np : 0;
+            REAL tw1 = 0, tw2 = 0, tw3 = 0, tD = 0;
+            for (int i0 = 0; i0 < n; i0 += KPP_BLOCK) {
+                const int i1 = i0 + KPP_BLOCK < n ? i0 + KPP_BLOCK : n;
+                REAL gw1 = 0, gw2 = 0, gw3 = 0, gD = 0;
+                if (blk) memset(blk, 0, sizeof(REAL) * np);
+                for (int i = i0; i < i1; ++i) {
+                    const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                    REAL gx[1];
+                    FN(mlp_forward)(m, th + m->nn_offset, &u[i], zs, as);
+                    FN(mlp_vjp)(m, th + m->nn_offset, zs, as, &lam[i], gx, blk ? blk + m->nn_offset : 0);
+                    /* transpose of the periodic 3-tap stencil */
+                    dlam[i] = gx[0] + D0 * (w1 * lam[ip] + w2 * lam[i] + w3 * lam[im]);
+                    gw1 += lam[i] * u[im];
+                    gw2 += lam[i] * u[i];
+                    gw3 += lam[i] * u[ip];
+                    gD += lam[i] * (w1 * u[im] + w2 * u[i] + w3 * u[ip]);
+                }
+                if (i0 == 0) {
+                    if (blk) memcpy(tot, blk, sizeof(REAL) * np);
+                    tw1 = gw1; tw2 = gw2; tw3 = gw3; tD = gD;
+                } else {
+                    if (blk) for (int q = 0; q < np; ++q) tot[q] += blk[q];
+                    tw1 += gw1; tw2 += gw2; tw3 += gw3; tD += gD;
+                }
             }
             if (dth) {
-                dth[m->stencil_offset] += D0 * gw1;
-                dth[m->stencil_offset + 1] += D0 * gw2;
-                dth[m->stencil_offset + 2] += D0 * gw3;
-                dth[m->d0_offset] += gD;
+                for (int q = 0; q < np; ++q) dth[q] += tot[q];
+                dth[m->stencil_offset] += D0 * tw1;
+                dth[m->stencil_offset + 1] += D0 * tw2;
+                dth[m->stencil_offset + 2] += D0 * tw3;
+                dth[m->d0_offset] += tD;
+                free(blk);
             }
         } return 0;
         default: return -1;

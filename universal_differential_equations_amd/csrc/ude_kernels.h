@@ -516,7 +516,9 @@ struct Driver {
                     z[c] = znew[c];
                     bad = bad || (znew[c] != znew[c]);
                 });
-                if constexpr (Sys::STATE_DISTRIBUTED) bad = __any(bad);  // same decision on every lane of the wave
+                if constexpr (Sys::STATE_DISTRIBUTED) {  // same decision on every lane of the trajectory
+                    if constexpr (G > 64) bad = __syncthreads_or(bad); else bad = __any(bad);
+                }
                 if constexpr (LDS_SLOTS) {
                     for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) sys.mu[i] = sys.ab[i];
                     sys.lds_sync();
@@ -568,7 +570,9 @@ struct FwdSys {
     int si, nsteps, r, n;
     double loss;
     // component c of this lane is state index comp(c); replicated states: every lane holds all of them
-    __device__ __forceinline__ int comp(int c) const { return STATE_DISTRIBUTED ? c * G + r : c; }
+    __device__ __forceinline__ int comp(int c) const {
+        if constexpr (STATE_DISTRIBUTED) return Model::point(c, r); else return c;
+    }
     __device__ __forceinline__ bool cvalid(int c) const { return comp(c) < n; }
     __device__ __forceinline__ bool cwrite(int c) const { return STATE_DISTRIBUTED ? cvalid(c) : writer; }
     __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
@@ -754,7 +758,9 @@ struct AdjSys {
     const KParams* p;
     int64_t j;
     int nsteps, sf, cur, n;
-    __device__ __forceinline__ int comp(int c) const { return STATE_DISTRIBUTED ? c * G + mctx.r : c; }
+    __device__ __forceinline__ int comp(int c) const {
+        if constexpr (STATE_DISTRIBUTED) return Model::point(c, mctx.r); else return c;
+    }
     __device__ __forceinline__ bool cvalid(int c) const { return comp(c) < n; }
     __device__ __forceinline__ bool cwrite(int c) const { return STATE_DISTRIBUTED ? cvalid(c) : mctx.r == 0; }
     __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
@@ -1121,7 +1127,9 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         typename Model::Ctx mctx;
         Model::init(mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
         const int n = p.n_state;
-        auto comp = [&](int c) { return DIST ? c * G + r : c; };
+        auto comp = [&](int c) {
+            if constexpr (DIST) return Model::point(c, r); else return c;
+        };
         auto cvalid = [&](int c) { return comp(c) < n; };
         auto cwrite = [&](int c) { return DIST ? cvalid(c) : r == 0; };
         const int koff = k_offset<DIST, G>();

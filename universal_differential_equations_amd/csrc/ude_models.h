@@ -514,6 +514,7 @@ struct SeirUde {
 // rc_ode(rho,p,t) = (D*lap)*rho + r*rho*(1-rho)   (Fisher-KPP-CNN.jl:51-63); consts = D/dx^2, -2D/dx^2, r
 template <int G, int PPL>
 struct KppTrue : LinearTheta {
+    static __host__ __device__ constexpr int point(int c, int r) { return c * G + r; }  // grid point of (register slot, lane)
     static constexpr int NS = PPL, NSL = 0;
     static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = true;
     static constexpr int SCRATCH = G * PPL + 2;
@@ -564,6 +565,7 @@ struct KppTrue : LinearTheta {
 // over the points in ascending order -- the oracle's order, so the result is bit-identical.
 template <class Net, int G, int PPL>
 struct KppUde : LinearTheta {
+    static __host__ __device__ constexpr int point(int c, int r) { return c * G + r; }
     using Mlp = CoopMlp<Net, 1>;
     static_assert(Net::dim(0) == 1 && Net::dim(Net::L) == 1, "pointwise reaction network R -> R");
     static constexpr int NS = PPL;
@@ -712,6 +714,236 @@ struct KppUde : LinearTheta {
         __syncthreads();
     }
     static constexpr int d_off_rt(int l) { return d_off(l); }
+    static __device__ __forceinline__ int slot_index(const ModelConsts& mc, int r, int s) {
+        const int p = r + G * s;
+        if (p >= mc.n_param) return -1;
+        if (p == mc.stencil_offset + 3) return -1;  // the unused conv bias (Fisher-KPP-CNN.jl:100-109): gradient stays 0
+        return p;
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// nn_ode on LARGE grids (BASELINE configs[3]: 1024 points): one trajectory per block of 4 wavefronts.
+// Wavefront w owns the 256 consecutive points 256w .. 256w+255 (4 per lane: point = 256w + 64c + lane), i.e. one
+// ARITH-SPEC block of the parameter-cotangent sums (oracle: KPP_BLOCK): it forms its block's partial sums alone, in
+// a WAVE-PRIVATE [point][row] LDS tile, one layer at a time (lanes switch from owning a point to owning a
+// parameter of that layer and walk the tile's 64 points in ascending order); the four block sums meet in LDS and
+// are added left to right by the parameter's final owner (theta index p = r + 256 m: the Driver's register slots).
+// ---------------------------------------------------------------------------------------------
+template <class Net>
+struct KppUdeW : LinearTheta {
+    static constexpr int G = 256, PPL = 4, NWV = 4, TP = 64, BLK = 256;
+    static __host__ __device__ constexpr int point(int c, int r) { return (r >> 6) * BLK + c * TP + (r & 63); }
+    static_assert(Net::dim(0) == 1 && Net::dim(Net::L) == 1, "pointwise reaction network R -> R");
+    static constexpr int NS = PPL;
+    static constexpr int NP = Net::nparam + 5;
+    static constexpr int NSL = (NP + G - 1) / G;
+    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = true;
+    static constexpr int L = Net::L;
+    static constexpr int NPT = G * PPL;
+    static constexpr int MAXD = Net::maxdim();
+    static constexpr bool acts_ok() {  // the reverse sweep rebuilds act' from the activation VALUE (tanh family only)
+        for (int l = 0; l + 1 < L; ++l)
+            if (Net::act(l) != ACT_TANH) return false;
+        return Net::act(L - 1) == ACT_IDENTITY;
+    }
+    static_assert(acts_ok(), "KppUdeW: tanh hidden layers, linear output");
+    static constexpr int cnt(int l) { return Net::dim(l) * Net::dim(l + 1) + Net::dim(l + 1); }  // parameters of layer l
+    static constexpr int sl(int l) { return (cnt(l) + TP - 1) / TP; }                             // ... per lane
+    static constexpr int sl_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += sl(i); return s; }
+    static constexpr int NACC = sl_off(L);
+    static constexpr int maxrows() { int m = 0; for (int l = 0; l < L; ++l) { int r = Net::dim(l) + Net::dim(l + 1); m = r > m ? r : m; } return m; }
+    static constexpr int RS = maxrows() | 1;                 // odd row stride of the tile: owners of different rows hit different banks
+    static constexpr int TILE = TP * RS;                     // doubles per wavefront
+    static constexpr int NPP = (NP + 1) & ~1;                // block-sum row (aliases the tile once the tiles are consumed)
+    static_assert(NPP <= TILE, "block sums must fit the tile they alias");
+    static constexpr int SCRATCH = 3 * (NPT + 2) + NWV * TILE;  // u, lambda, result rows + tiles
+    // LDS pointers carry their address space in the type (no reliance on the compiler inferring it: a FLAT load on
+    // every tile access would cost VMEM latency)
+    typedef __attribute__((address_space(3))) double lds_t;
+    struct Ctx {
+        const lds_t* nn;
+        lds_t *urow, *lrow, *orow, *tile, *part;
+        double w1, w2, w3, D0;
+        int r, lane, w, n, so, d0o, nno;
+    };
+    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
+        lds_t* th = (lds_t*)th_lds;
+        lds_t* sc = (lds_t*)scratch;
+        c.nn = th + mc.nn_offset;
+        c.urow = sc; c.lrow = sc + NPT + 2; c.orow = sc + 2 * (NPT + 2);
+        c.part = sc + 3 * (NPT + 2);  // [NWV][TILE]; wavefront w's tile = its block-sum row afterwards
+        c.r = r; c.lane = r & 63; c.w = r >> 6;
+        c.tile = c.part + c.w * TILE;
+        c.n = mc.n_state; c.so = mc.stencil_offset; c.d0o = mc.d0_offset; c.nno = mc.nn_offset;
+        c.w1 = th[c.so]; c.w2 = th[c.so + 1]; c.w3 = th[c.so + 2]; c.D0 = th[c.d0o];
+    }
+    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
+        const int n = c.n;
+        __syncthreads();
+        static_for<0, PPL>([&](auto cc) { const int i = point(cc, c.r); if (i < n) c.urow[i] = u[cc]; });
+        __syncthreads();
+        // ONE copy of the per-point code (runtime loop over this lane's four points); results return through the
+        // lane's own words of an LDS row, so no register array is indexed with a runtime index
+#pragma unroll 1
+        for (int cc = 0; cc < PPL; ++cc) {
+            const int i = point(cc, c.r);
+            double out = 0.0;
+            if (i < n) {
+                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                const double ui = c.urow[i];
+                // forward only: two ping-pong activation rows (the same fma chains as CoopMlp::forward)
+                double ain[MAXD], aout[MAXD];
+                ain[0] = ui;
+                static_for<0, L>([&](auto lc) {
+                    constexpr int l = lc;
+                    constexpr int in = Net::dim(l), nout = Net::dim(l + 1);
+                    static_for<0, nout>([&](auto j) {
+                        double s = 0.0;
+                        static_for<0, in>([&](auto k) { s = __builtin_fma((double)c.nn[Net::off(l) + j + k * nout], ain[k], s); });
+                        s += (double)c.nn[Net::off(l) + in * nout + j];
+                        aout[j] = act_fwd<Net::act(l)>(s);
+                    });
+                    static_for<0, nout>([&](auto j) { ain[j] = aout[j]; });
+                });
+                const double cnn = c.w1 * c.urow[im] + c.w2 * ui + c.w3 * c.urow[ip];
+                out = ain[0] + c.D0 * cnn;
+            }
+            c.orow[point(cc, c.r)] = out;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<0, PPL>([&](auto cc) { du[cc] = c.orow[point(cc, c.r)]; });
+    }
+    static __device__ __forceinline__ void wave_sync() {
+        // the tile is private to the wavefront (lock-step lanes): only the LDS queue has to drain
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    template <bool WANT_PARAM>
+    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam, double* g) {
+        const int n = c.n;
+        __syncthreads();
+        static_for<0, PPL>([&](auto cc) {
+            const int i = point(cc, c.r);
+            if (i < n) { c.urow[i] = u[cc]; c.lrow[i] = lam[cc]; }
+        });
+        __syncthreads();
+        double acc[NACC];  // this lane's share of the wavefront's block sums (chains run on across its four tiles)
+        static_for<0, NACC>([&](auto m) { acc[m] = 0.0; });
+#pragma unroll 1
+        for (int cc = 0; cc < PPL; ++cc) {
+            const int i = point(cc, c.r);
+            const bool valid = i < n;
+            const double ui = valid ? c.urow[i] : 0.0, li = valid ? c.lrow[i] : 0.0;
+            // forward, keeping the INPUT of every layer (act[l] = a_l, a_0 = u): the same fma chains as CoopMlp::forward
+            double act[L][MAXD];
+            act[0][0] = ui;
+            static_for<0, L - 1>([&](auto lc) {
+                constexpr int l = lc;
+                constexpr int in = Net::dim(l), out = Net::dim(l + 1);
+                static_for<0, out>([&](auto j) {
+                    double s = 0.0;
+                    static_for<0, in>([&](auto k) { s = __builtin_fma((double)c.nn[Net::off(l) + j + k * out], act[l][k], s); });
+                    s += (double)c.nn[Net::off(l) + in * out + j];
+                    act[l + 1][j] = act_fwd<Net::act(l)>(s);
+                });
+            });
+            // reverse sweep, one layer at a time from the top: parameters of layer l (tile phase) BEFORE its inputs'
+            // deltas are formed, so at most one activation row and two delta rows are live besides the stored inputs
+            double dcur[MAXD];
+            dcur[0] = li * 1.0;  // linear output layer
+            // points of this tile that exist (ascending from the tile's first point)
+            const int t0 = c.w * BLK + cc * TP;
+            const int npts = n - t0 < 0 ? 0 : (n - t0 < TP ? n - t0 : TP);
+            double gxi = 0.0;
+            static_for<0, L>([&](auto lr) {
+                constexpr int l = L - 1 - lr;
+                constexpr int in = Net::dim(l), out = Net::dim(l + 1);
+                if constexpr (WANT_PARAM) {
+                    wave_sync();  // owners of the previous layer are done with the tile
+                    lds_t* row = c.tile + c.lane * RS;
+                    static_for<0, in>([&](auto k) { row[k] = act[l][k]; });
+                    static_for<0, out>([&](auto j) { row[in + j] = dcur[j]; });
+                    wave_sync();
+                    static_for<0, sl(l)>([&](auto mc) {
+                        constexpr int m = mc;
+                        const int e = c.lane + TP * m;
+                        if (e < in * out) {
+                            const lds_t* dr = c.tile + in + e % out;
+                            const lds_t* ar = c.tile + e / out;
+                            double a = acc[sl_off(l) + m];
+#pragma unroll 8
+                            for (int q = 0; q < npts; ++q) a += dr[q * RS] * ar[q * RS];
+                            acc[sl_off(l) + m] = a;
+                        } else if (e < in * out + out) {
+                            const lds_t* dr = c.tile + in + (e - in * out);
+                            double a = acc[sl_off(l) + m];
+#pragma unroll 8
+                            for (int q = 0; q < npts; ++q) a += dr[q * RS];
+                            acc[sl_off(l) + m] = a;
+                        }
+                    });
+                }
+                // cotangent of this layer's input: (W_l^T delta_l) [* act'(a_l) for hidden inputs]
+                double dprev[MAXD];
+                static_for<0, in>([&](auto k) {
+                    double s = 0.0;
+                    static_for<0, out>([&](auto j) { s = __builtin_fma((double)c.nn[Net::off(l) + j + k * out], dcur[j], s); });
+                    if constexpr (l > 0) dprev[k] = valid ? s * act_bwd<Net::act(l - 1)>(0.0, act[l][k]) : 0.0;
+                    else dprev[k] = s;
+                });
+                if constexpr (l > 0) static_for<0, in>([&](auto k) { dcur[k] = dprev[k]; });
+                else gxi = dprev[0];
+            });
+            if (valid) {  // transpose of the periodic stencil (the oracle's expression)
+                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                c.orow[i] = gxi + c.D0 * (c.w1 * c.lrow[ip] + c.w2 * c.lrow[i] + c.w3 * c.lrow[im]);
+            } else {
+                c.orow[i] = 0.0;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<0, PPL>([&](auto cc) { dlam[cc] = c.orow[point(cc, c.r)]; });
+        if constexpr (WANT_PARAM) {
+            // stencil weights and D0: this wavefront's block of the oracle's four running sums, lanes 0..3
+            double sblk = 0.0;
+            if (c.lane < 4) {
+                const int b0 = c.w * BLK, b1 = b0 + BLK < n ? b0 + BLK : n;
+                for (int i = b0; i < b1; ++i) {
+                    const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                    if (c.lane == 0) sblk += c.lrow[i] * c.urow[im];
+                    else if (c.lane == 1) sblk += c.lrow[i] * c.urow[i];
+                    else if (c.lane == 2) sblk += c.lrow[i] * c.urow[ip];
+                    else sblk += c.lrow[i] * (c.w1 * c.urow[im] + c.w2 * c.urow[i] + c.w3 * c.urow[ip]);
+                }
+            }
+            // block sums -> this wavefront's row (aliases its tile)
+            wave_sync();
+            lds_t* prow = c.tile;
+            static_for<0, L>([&](auto lc) {
+                constexpr int l = lc;
+                static_for<0, sl(l)>([&](auto mc) {
+                    const int e = c.lane + TP * decltype(mc)::value;
+                    if (e < cnt(l)) prow[c.nno + Net::off(l) + e] = acc[sl_off(l) + decltype(mc)::value];
+                });
+            });
+            if (c.lane < 3) prow[c.so + c.lane] = sblk;
+            if (c.lane == 3) { prow[c.d0o] = sblk; prow[c.so + 3] = 0.0; }
+            __syncthreads();
+            static_for<0, NSL>([&](auto s) {
+                const int p = c.r + G * decltype(s)::value;
+                double v = 0.0;
+                if (p < NP) {
+                    v = c.part[p];
+                    static_for<1, NWV>([&](auto w) { v += c.part[decltype(w)::value * TILE + p]; });
+                    if (p >= c.so && p < c.so + 3) v = c.D0 * v;
+                }
+                g[s] = v;
+            });
+        }
+        __syncthreads();
+    }
     static __device__ __forceinline__ int slot_index(const ModelConsts& mc, int r, int s) {
         const int p = r + G * s;
         if (p >= mc.n_param) return -1;

@@ -169,7 +169,7 @@ static int model_id(const ude_model_desc* m) {
     return MID_NONE;
 }
 
-static int default_lanes(int mid) {
+static int default_lanes(int mid, bool discrete) {
     switch (mid) {
         case MID_LV_TRUE: return 1;
         case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
@@ -180,8 +180,8 @@ static int default_lanes(int mid) {
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32: return 32;
-        case MID_KPP_TRUE_1024:
-        case MID_KPP_UDE_1024: return 64;
+        case MID_KPP_TRUE_1024: return 64;
+        case MID_KPP_UDE_1024: return discrete ? 64 : 256;  // 4 wavefronts per PDE (the reverse sweep keeps the 64-lane layout)
     }
     return 1;
 }
@@ -191,7 +191,7 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
     if (mid == MID_NONE)
         return fail(c, UDE_ERR_UNSUPPORTED, "no compiled kernel for model kind=%d dtype=%d n_layers=%d (see udecore.hip model table)",
                     m->kind, m->dtype, m->n_layers);
-    G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid);
+    G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
     const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
     bool ok = false;
     for (const InstanceRow& row : kInstances)
