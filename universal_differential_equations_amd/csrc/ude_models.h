@@ -754,7 +754,8 @@ struct KppUdeW : LinearTheta {
     static constexpr int sl_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += sl(i); return s; }
     static constexpr int NACC = sl_off(L);
     static constexpr int maxrows() { int m = 0; for (int l = 0; l < L; ++l) { int r = Net::dim(l) + Net::dim(l + 1); m = r > m ? r : m; } return m; }
-    static constexpr int RS = maxrows() | 1;                 // odd row stride of the tile: owners of different rows hit different banks
+    static constexpr int RS = (maxrows() + 1) | 1;           // odd row stride of the tile; last column holds 1.0 (bias parameters)
+    static constexpr int ONE_COL = RS - 1;
     static constexpr int TILE = TP * RS;                     // doubles per wavefront
     static constexpr int NPP = (NP + 1) & ~1;                // block-sum row (aliases the tile once the tiles are consumed)
     static_assert(NPP <= TILE, "block sums must fit the tile they alias");
@@ -865,25 +866,25 @@ struct KppUdeW : LinearTheta {
                     lds_t* row = c.tile + c.lane * RS;
                     static_for<0, in>([&](auto k) { row[k] = act[l][k]; });
                     static_for<0, out>([&](auto j) { row[in + j] = dcur[j]; });
+                    row[ONE_COL] = 1.0;  // bias parameters: delta * 1.0 == delta exactly
                     wave_sync();
+                    // this lane's parameters of the layer advance TOGETHER through the tile's points (independent
+                    // chains interleaved: the add latency of one hides behind the others); lanes beyond the layer's
+                    // parameter count redo its last parameter (never written out) instead of branching
+                    int doff[sl(l)], aoff[sl(l)];
                     static_for<0, sl(l)>([&](auto mc) {
-                        constexpr int m = mc;
-                        const int e = c.lane + TP * m;
-                        if (e < in * out) {
-                            const lds_t* dr = c.tile + in + e % out;
-                            const lds_t* ar = c.tile + e / out;
-                            double a = acc[sl_off(l) + m];
-#pragma unroll 8
-                            for (int q = 0; q < npts; ++q) a += dr[q * RS] * ar[q * RS];
-                            acc[sl_off(l) + m] = a;
-                        } else if (e < in * out + out) {
-                            const lds_t* dr = c.tile + in + (e - in * out);
-                            double a = acc[sl_off(l) + m];
-#pragma unroll 8
-                            for (int q = 0; q < npts; ++q) a += dr[q * RS];
-                            acc[sl_off(l) + m] = a;
-                        }
+                        int e = c.lane + TP * decltype(mc)::value;
+                        e = e < cnt(l) ? e : cnt(l) - 1;
+                        doff[mc] = e < in * out ? in + e % out : in + (e - in * out);
+                        aoff[mc] = e < in * out ? e / out : ONE_COL;
                     });
+#pragma unroll 4
+                    for (int q = 0; q < npts; ++q) {
+                        const lds_t* pt = c.tile + q * RS;
+                        static_for<0, sl(l)>([&](auto mc) {
+                            acc[sl_off(l) + decltype(mc)::value] += pt[doff[mc]] * pt[aoff[mc]];
+                        });
+                    }
                 }
                 // cotangent of this layer's input: (W_l^T delta_l) [* act'(a_l) for hidden inputs]
                 double dprev[MAXD];
@@ -910,12 +911,12 @@ struct KppUdeW : LinearTheta {
             double sblk = 0.0;
             if (c.lane < 4) {
                 const int b0 = c.w * BLK, b1 = b0 + BLK < n ? b0 + BLK : n;
+#pragma unroll 4
                 for (int i = b0; i < b1; ++i) {
                     const int im = (i + n - 1) % n, ip = (i + 1) % n;
-                    if (c.lane == 0) sblk += c.lrow[i] * c.urow[im];
-                    else if (c.lane == 1) sblk += c.lrow[i] * c.urow[i];
-                    else if (c.lane == 2) sblk += c.lrow[i] * c.urow[ip];
-                    else sblk += c.lrow[i] * (c.w1 * c.urow[im] + c.w2 * c.urow[i] + c.w3 * c.urow[ip]);
+                    const double um = c.urow[im], u0 = c.urow[i], up = c.urow[ip];
+                    const double term = c.lane == 0 ? um : c.lane == 1 ? u0 : c.lane == 2 ? up : (c.w1 * um + c.w2 * u0 + c.w3 * up);
+                    sblk += c.lrow[i] * term;
                 }
             }
             // block sums -> this wavefront's row (aliases its tile)
