@@ -972,7 +972,9 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     double* mu_lds = SG ? p.slot_glob + (size_t)blockIdx.x * BLOCK + threadIdx.x : slots + threadIdx.x;
     double* gtmp = slots + (size_t)NSLA * BLOCK + threadIdx.x;        // initial-dt scratch, element c at gtmp[c * BLOCK]
     double* gtmp2 = slots + (size_t)2 * NSLA * BLOCK + threadIdx.x;    // last-stage slot derivative (FSAL hand-over)
-    double* icbase = slots + (SG ? (size_t)0 : (size_t)3 * NSLA * BLOCK);  // interval cache rows (IC_LDS), one per group
+    // (the third column only exists for FSAL tableaux: at 4 blocks per CU every LDS kilobyte counts -- the C2 ensemble
+    // must fit the chip in ONE round of blocks)
+    double* icbase = slots + (SG ? (size_t)0 : (size_t)(Tab::FSAL ? 3 : 2) * NSLA * BLOCK);  // interval cache rows (IC_LDS)
     double lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
     constexpr int NSLOT = Model::DEFERRED ? Model::NSL : NSL;  // slots this thread reports (deferred: system-owned)

@@ -36,7 +36,7 @@ inline Launch make_launch() {
     l.scratch = Model::SCRATCH;
     l.k_doubles = Layout<Model, Tab, G, BLOCK>::K_DOUBLES;
     l.k_doubles_d = Layout<Model, Tab, G, BLOCK, false>::K_DOUBLES;
-    l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : 3 * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
+    l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : (Tab::FSAL ? 3 : 2) * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
     l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL : 0;
     l.slots_lds = Model::SLOTS_IN_LDS;
     return l;
