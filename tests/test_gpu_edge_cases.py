@@ -114,3 +114,22 @@ def test_scenario2_segment_loss_as_one_ensemble(golden):
     h = 1e-6
     fd = (lg(th + h * d)[0] - lg(th - h * d)[0]) / (2 * h)
     assert abs(fd - g0 @ d) < 2e-5 * abs(fd)
+
+
+def test_multiple_shoot_on_device_matches_oracle_backend(golden):
+    """hudson_bay.jl:108-118: the groups of DiffEqFlux.multiple_shoot as one ensemble through libudecore."""
+    from universal_differential_equations_amd import training
+    from test_multiple_shoot_cpu import OracleBackend
+    g = golden("Scenario_1_recovery_0.005")
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2).T
+    t = np.array(g["t"])
+    th = np.array(g["initial_parameters"])
+    prob = U.ODEProblem(models.ude_dynamics(), X[:, 0], (0.0, 3.0), th)
+    dev = training.EngineBackend(prob, U.Vern7(), abstol=1e-6, reltol=1e-6)
+    ref = OracleBackend(O.lv_ude_s1(), O.opts(O.VERN7, 1e-6, 1e-6))
+    l1, g1, p1 = training.multiple_shoot(th, X, t, dev, 5, continuity_term=200.0)
+    l2, g2, p2 = training.multiple_shoot(th, X, t, ref, 5, continuity_term=200.0)
+    assert abs(l1 - l2) <= 1e-13 * abs(l2)
+    assert np.linalg.norm(g1 - g2) <= 1e-11 * np.linalg.norm(g2)
+    for a, b in zip(p1, p2):
+        assert (a == b).all()
