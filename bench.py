@@ -105,6 +105,30 @@ def cpu_baseline(theta, u0, t, data, seconds_target=15.0, workload="lv", mask=No
             "sample": "%d of the %d trajectories, one loss+adjoint-gradient pass, OpenMP over trajectories (%.1f s)" % (n, len(u0), dt)}
 
 
+def pmc_traffic(a):
+    """HBM bytes per adj_kernel launch of the default C2 command, as collected by `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` (tools/prof_pass.sh; counters in KB) and committed under profiles/ -- PMC passes cannot run
+    inside the timed bench itself.  None when the run is not that command or the summary is absent."""
+    if a.workload != "lv" or a.alg != "tsit5" or a.sensealg != "adjoint" or a.lanes or a.waves or a.traj:
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v4_pmc.md")
+    try:
+        txt = open(path).read()
+    except OSError:
+        return None
+    sec = txt.split("### ")
+    for blk in sec:
+        if blk.startswith("`void adj_kernel<LvUde"):
+            vals = {}
+            for line in blk.splitlines():
+                c = [x.strip() for x in line.split("|")]
+                if len(c) >= 5 and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[c[1]] = float(c[4])
+            if len(vals) == 2:
+                return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,11 +238,13 @@ def main():
                        "bwd_kernel_ms": float(np.mean(bwd_ms))},
             "roofline": {"bound": "mfma", "kernel": "adj_kernel (interpolating adjoint)", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": None,
+                         "traffic": pmc_traffic(a),
                          "note": "FP64 vector/matrix peak (both 78.6 TF); algorithmic %g flop per adjoint eval; "
-                                 "the path is FP64-ALU/latency bound, not HBM bound (DESIGN.md)" % FLOPS[a.workload][1]},
+                                 "the path is FP64-ALU/latency bound, not HBM bound (DESIGN.md); traffic = FETCH_SIZE + "
+                                 "WRITE_SIZE bytes per adj_kernel launch from the separate rocprofv3 --pmc passes of this "
+                                 "command (profiles/r01_v4_pmc.md), null for other workloads" % FLOPS[a.workload][1]},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # (the CPU leg is a rank-0, N=1 measurement)
             out["cpu_baseline"] = cpu_baseline(theta_h, u0_d.cpu().numpy(), t, data.cpu().numpy(), workload=a.workload, mask=mask)
         print(json.dumps(out))
     if dist is not None:
