@@ -207,10 +207,12 @@ struct SeirUde {
     static constexpr int NPARAM = 3 * H + H + H * H + H + H + 1;  // 4481
     static constexpr int OFF_W1 = 0, OFF_B1 = 3 * H, OFF_W2 = 4 * H, OFF_B2 = 4 * H + H * H, OFF_W3 = OFF_B2 + H,
                          OFF_B3 = OFF_W3 + H;
-    static constexpr int SCRATCH = ONE ? WPB * NSTG * NFAC * H : 3 * NBLK * H;  // stage factors / block sums
+    static constexpr int SCRATCH = ONE ? WPB * (NSTG * NFAC + 2) * H : 3 * NBLK * H;  // stage factors + 2 broadcast rows / block sums
+    typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
         double w2row[ONE ? 1 : KB], w2col[ONE ? 1 : KB], w1[3], b1, b2, w3, b3;
-        const double* W2p;  // LDS, ld = 65 (ONE)
+        const lds_t* W2p;   // LDS, ld = 65 (ONE)
+        lds_t* bc;          // ONE: two wave-private broadcast rows (a1 / delta2): lane j writes, every lane reads all 64
         double *pf, *pb;    // LDS block-sum exchange (multi-wave)
         double* fac;        // LDS stage factors of this wavefront: field f of stage s at fac[(s*NFAC + f)*H + lane]
         double F, b0, mu_c, sg, ga, d, la;
@@ -228,7 +230,8 @@ struct SeirUde {
         const int j = r & 63;
         const int w = __builtin_amdgcn_readfirstlane(r >> 6);
         c.j = j; c.w = w; c.r = r; c.flip = 0;
-        c.W2p = th;
+        c.W2p = (const lds_t*)th;
+        c.bc = (lds_t*)scratch + WPB * NSTG * NFAC * H + ((threadIdx.x >> 6) % WPB) * 2 * H;
         c.pf = scratch; c.pb = scratch + 2 * NBLK * H;
         c.fac = scratch + ((threadIdx.x >> 6) % WPB) * (NSTG * NFAC * H);
         if constexpr (!ONE)
@@ -250,14 +253,18 @@ struct SeirUde {
         if constexpr (ONE) {
             // one block of 16 terms per trip of a RUNTIME loop: bounds the loads / scalars in flight (the fully
             // unrolled 64-term dot made the compiler hoist everything and spill)
+            // the 64 inputs cross lanes through a wave-private LDS row (uniform-address reads broadcast; LDS is in
+            // order per wavefront, so the row needs no barrier) -- cheaper than 128 v_readlane + hazard nops per dot
             double tot = 0.0;
-            const double* wp = TRANSPOSED ? c.W2p + c.j * LD : c.W2p + c.j;
+            const lds_t* wp = TRANSPOSED ? c.W2p + c.j * LD : c.W2p + c.j;
+            lds_t* row = c.bc + (TRANSPOSED ? H : 0);
+            row[c.j] = v;
 #pragma unroll 1
             for (int b = 0; b < NBLK; ++b) {
                 double acc = 0.0;
                 static_for<0, 16>([&](auto ic) {
                     const int k = b * 16 + decltype(ic)::value;
-                    const double x = readlane_f64(v, k);
+                    const double x = row[k];
                     const double wv = TRANSPOSED ? wp[k] : wp[k * LD];
                     acc = __builtin_fma(wv, x, acc);
                 });
