@@ -232,7 +232,26 @@ struct CoopMlp {
     static constexpr int MAXD = N::maxdim();
     static constexpr int MAXOWN = maxown();
 
+    typedef __attribute__((address_space(3))) double lds_t;
+    // all-gather of one value per lane inside a group.  Power-of-two groups: DPP / bpermute broadcasts.  Other groups
+    // (G = 5): through the group's words of a wave-private LDS row -- one ds_write + three ds_read2 per gather instead
+    // of ten ds_bpermute (LDS is in order per wavefront: no barrier; `gb` = this GROUP's first word)
+    static constexpr bool LDS_GATHER = !pow2_group<G>();
+    template <int CNT>
+    static __device__ __forceinline__ void allgather(lds_t* gb, int r, const double* own, double* out) {
+        if constexpr (LDS_GATHER) {
+            static_assert(CNT <= G, "LDS gather: one value per lane");
+            gb[r] = own[0];
+            static_for<0, CNT>([&](auto j) { out[j] = gb[decltype(j)::value]; });
+        } else {
+            static_for<0, CNT>([&](auto jc) {
+                constexpr int j = jc;
+                out[j] = group_bcast<G, j % G>(own[j / G]);
+            });
+        }
+    }
     struct Cache {
+        lds_t* gb;                // LDS gather row of this group (LDS_GATHER)
         double a[L + 1][MAXD];    // replicated activations (a[0] = input)
         double z[L][MAXOWN];      // pre-activations of the neurons this lane owns
         double ao[L][MAXOWN];     // their activations
@@ -295,10 +314,7 @@ struct CoopMlp {
                 c.z[l][m] = acc;
                 c.ao[l][m] = valid ? act_fwd<N::act(l)>(acc) : 0.0;
             });
-            static_for<0, out>([&](auto jc) {
-                constexpr int j = jc;
-                c.a[l + 1][j] = group_bcast<G, j % G>(c.ao[l][j / G]);
-            });
+            allgather<out>(c.gb, r, c.ao[l], c.a[l + 1]);
         });
         static_for<0, N::dim(L)>([&](auto k) { y[k] = c.a[L][k]; });
     }
@@ -354,17 +370,11 @@ struct CoopMlp {
                 }
             });
             if constexpr (l > 0) {
-                static_for<0, out>([&](auto jc) {
-                    constexpr int j = jc;
-                    dall[j] = group_bcast<G, j % G>(down[j / G]);
-                });
+                allgather<out>(c.gb, r, down, dall);
             } else {
                 // input cotangent: gx[k] = sum_j W0[j,k] delta0[j]; every lane needs it, so gather delta0 too
                 double d0[MAXD];
-                static_for<0, out>([&](auto jc) {
-                    constexpr int j = jc;
-                    d0[j] = group_bcast<G, j % G>(down[j / G]);
-                });
+                allgather<out>(c.gb, r, down, d0);
                 static_for<0, in>([&](auto k) {
                     double s = 0.0;
                     if constexpr (ws_is_reg<WS>) {

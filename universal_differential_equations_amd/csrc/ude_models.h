@@ -89,9 +89,12 @@ struct LvUde : LinearTheta {
         double lin[2];
         double lead_on[2];  // sign if this lane owns a trainable diagonal coefficient, else 0
         int r;
+        typename Mlp::lds_t* gb;  // LDS gather row of this lane group (non-power-of-two groups)
         typename Mlp::WReg w;  // (unused members are never materialised when REGW is false)
     };
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double*, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
+    static constexpr int SCRATCH = 64;  // one gather word per lane (LV blocks are one wavefront; every LDS byte counts: 4 blocks per CU)
+    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
+        c.gb = (typename Mlp::lds_t*)scratch + (threadIdx.x - r);
         c.th = th_lds;
         c.nn = th_lds + mc.nn_offset;
         c.r = r;
@@ -103,6 +106,7 @@ struct LvUde : LinearTheta {
     }
     static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
         typename Mlp::Cache cache;
+        cache.gb = c.gb;
         double y[2];
         if constexpr (REGW) Mlp::forward(c.w, c.r, u, cache, y);
         else Mlp::forward(c.nn, c.r, u, cache, y);
@@ -113,6 +117,7 @@ struct LvUde : LinearTheta {
     static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam,
                                                double* g) {
         typename Mlp::Cache cache;
+        cache.gb = c.gb;
         double y[2], gx[2];
         if constexpr (REGW) {
             Mlp::forward(c.w, c.r, u, cache, y);
