@@ -432,3 +432,57 @@ def test_unsupported_descriptor_is_an_error():
     prob = U.ODEProblem(models.ude_dynamics(models.Chain(models.Dense(2, 7, "tanh"), models.Dense(7, 2))), [1.0, 1.0], (0.0, 1.0), np.zeros(37))
     with pytest.raises(U.sciml.UdeError):
         U.solve(prob, U.Tsit5(), saveat=0.5)
+
+
+def test_full_size_seir_and_kpp_properties():
+    """BASELINE configs[2] per-GPU share (6250 SEIR trajectories) and configs[3] (256 PDEs x 1024 points): the
+    size-independent properties -- determinism, additivity over shards (what the multi-GPU all-reduce relies on), the
+    work-count identities -- plus the oracle on a subsample."""
+    # ---- SEIR ----
+    N = 6250
+    u0, t = seir_inputs(N)
+    th = models.seir_chain().glorot_uniform(np.random.default_rng(11))
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    f = models.dudt_()
+    truth = np.asarray(U.solve(U.EnsembleProblem(U.ODEProblem(models.corona(), u0[0], (0.0, 21.0), []), u0), U.Vern7(),
+                               saveat=t, abstol=1e-12, reltol=1e-12).u)
+
+    def run(sl):
+        ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 21.0), th), u0[sl])
+        return U.loss_and_gradient(ens, U.Vern7(), truth[sl], row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6)
+
+    full, again = run(slice(0, N)), run(slice(0, N))
+    assert (full.retcode == 0).all()
+    assert np.array_equal(full.grad_theta, again.grad_theta) and full.loss == again.loss
+    a, b = run(slice(0, 4000)), run(slice(4000, N))
+    gsum = a.grad_theta + b.grad_theta
+    assert np.linalg.norm(full.grad_theta - gsum) < 1e-12 * np.linalg.norm(gsum)
+    assert np.array_equal(full.stats[:4000], a.stats) and np.array_equal(full.stats[4000:], b.stats)
+    assert np.array_equal(full.stats[:, 0], 2 + 10 * (full.stats[:, 1] + full.stats[:, 2]))      # nf identity (Vern7: 10 stages, no FSAL)
+    assert np.array_equal(full.stats[:, 4], 2 + 10 * (full.stats[:, 5] + full.stats[:, 6]))      # ... and backward
+    idx = np.arange(0, N, 625)
+    ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6), u0[idx], [0.0, 21.0], th, t, truth[idx], row_mask=mask, nthreads=4)
+    assert_bitwise(full.stats[idx][:, :7], ref["stats"][:, :7], "SEIR stats of the subsample")
+    assert_bitwise(full.grad_u0[idx], ref["grad_u0"], "SEIR dL/du0")
+    assert_bitwise(full.u[idx], ref["u"], "SEIR saved states")
+    # ---- Fisher-KPP, 1024 points ----
+    B = 256
+    thk, uk, tk, truthk = kpp_case(1024, B, models.kpp_chain(), None)
+    fk = models.nn_ode(1024, models.kpp_chain())
+
+    def runk(sl):
+        ens = U.EnsembleProblem(U.ODEProblem(fk, uk[0], (0.0, 5.0), thk), uk[sl])
+        return U.loss_and_gradient(ens, U.Tsit5(), truthk[sl], saveat=tk)
+
+    fullk, againk = runk(slice(0, B)), runk(slice(0, B))
+    assert (fullk.retcode == 0).all()
+    assert np.array_equal(fullk.grad_theta, againk.grad_theta) and fullk.loss == againk.loss
+    ak, bk = runk(slice(0, 100)), runk(slice(100, B))
+    gk = ak.grad_theta + bk.grad_theta
+    assert np.linalg.norm(fullk.grad_theta - gk) < 1e-12 * np.linalg.norm(gk)
+    assert np.array_equal(fullk.stats[:, 0], 3 + 6 * (fullk.stats[:, 1] + fullk.stats[:, 2]))    # nf identity (Tsit5, FSAL)
+    idk = np.array([0, 131, 255])
+    refk = O.loss_grad_ensemble(O.kpp_ude(1024), O.opts(O.TSIT5), uk[idk], [0.0, 5.0], thk, tk, truthk[idk], nthreads=3)
+    assert_bitwise(fullk.stats[idk][:, :7], refk["stats"][:, :7], "KPP stats of the subsample")
+    assert_bitwise(fullk.u[idk], refk["u"], "KPP saved states")
+    assert_bitwise(fullk.grad_u0[idk], refk["grad_u0"], "KPP dL/du0")
