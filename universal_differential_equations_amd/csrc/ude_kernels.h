@@ -854,9 +854,16 @@ struct AdjSys {
     __device__ __forceinline__ void slot_init2(const Opts& o, double& h2, double& l2) {
         if constexpr (DEFERRED) Model::init_norm2(mctx, o.abstol, o.reltol, mu_cur, ms, h2, l2);
     }
+    // stages whose B and BT weights are both zero (Vern7: stages 2, 3) drop out of the deferred sums at compile time
+    static constexpr unsigned stage_mask() {
+        unsigned m = 0;
+        for (int s = 0; s < Tab::S; ++s)
+            if (Tab::B(s) != 0.0 || Tab::BT(s) != 0.0) m |= 1u << s;
+        return m;
+    }
     __device__ __forceinline__ double slot_step(double dt, const TabDev* tab, const Opts& o) {
         if constexpr (DEFERRED)
-            return Model::template step_slots<Tab::S>(mctx, tab->B, tab->BT, dt, o.abstol, o.reltol, mu_cur, mu_new, ms);
+            return Model::template step_slots<Tab::S, stage_mask()>(mctx, tab->B, tab->BT, dt, o.abstol, o.reltol, mu_cur, mu_new, ms);
         else return 0.0;
     }
     __device__ __forceinline__ void slot_accept() {

@@ -407,21 +407,28 @@ struct SeirUde {
     struct Fac {  // this lane's factors of all stages (registers)
         double a2[NSTG], d1[NSTG], d2[NSTG];
     };
-    template <int NST>
+    // MASK: bit s set = stage s carries a nonzero B or BT weight (stages with both zero contribute fma(0, g, acc) == acc
+    // exactly, so their factors are never loaded and their products never formed)
+    template <int NST, unsigned MASK>
     static __device__ __forceinline__ void load_factors(const Ctx& c, Fac& f) {
         static_for<0, NST>([&](auto s) {
-            const double* p = c.fac + decltype(s)::value * (NFAC * H) + c.j;
-            f.a2[s] = p[H]; f.d1[s] = p[2 * H]; f.d2[s] = p[3 * H];
+            if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                const double* p = c.fac + decltype(s)::value * (NFAC * H) + c.j;
+                f.a2[s] = p[H]; f.d1[s] = p[2 * H]; f.d2[s] = p[3 * H];
+            }
         });
     }
     // g_s (all stored stages) of one slot; slot index wave-uniform
-    template <int NST>
+    template <int NST, unsigned MASK>
     static __device__ __forceinline__ void g_w2(const Ctx& c, const Fac& f, int k, double* g) {
-        static_for<0, NST>([&](auto s) { g[s] = -(f.d2[s] * c.fac[decltype(s)::value * (NFAC * H) + k]); });
+        static_for<0, NST>([&](auto s) {
+            if constexpr ((MASK >> decltype(s)::value) & 1u) g[s] = -(f.d2[s] * c.fac[decltype(s)::value * (NFAC * H) + k]);
+        });
     }
-    template <int NST>
+    template <int NST, unsigned MASK>
     static __device__ __forceinline__ void g_extra(const Ctx& c, const Fac& f, int e, double* g) {
         static_for<0, NST>([&](auto s) {
+          if constexpr ((MASK >> decltype(s)::value) & 1u) {
             const double* p = c.fac + decltype(s)::value * (NFAC * H) + 4 * H;  // x0 x1 x2 d3
             double v;
             switch (e) {
@@ -434,11 +441,12 @@ struct SeirUde {
                 default: v = c.j == 0 ? -p[3] : -0.0;
             }
             g[s] = v;
+          }
         });
     }
     // slots in order 0..70, mu read in chunks of CH (next chunk in flight while this one is processed):
     // body(slot, g[NST], m) with m = mu[slot]
-    template <int NST, class Body>
+    template <int NST, unsigned MASK, class Body>
     static __device__ __forceinline__ void for_each_slot(const Ctx& c, const Fac& f, const double* mu, int ms, Body body) {
         constexpr int CH = 8;
         double mcur[CH], mnext[CH];
@@ -452,33 +460,36 @@ struct SeirUde {
             });
             static_for<0, CH>([&](auto i) {
                 double g[NST];
-                g_w2<NST>(c, f, k0 + decltype(i)::value, g);
+                g_w2<NST, MASK>(c, f, k0 + decltype(i)::value, g);
                 body(k0 + decltype(i)::value, g, mcur[i]);
             });
             static_for<0, CH>([&](auto i) { mcur[i] = mnext[i]; });
         }
         static_for<0, NEXTRA>([&](auto e) {
             double g[NST];
-            g_extra<NST>(c, f, decltype(e)::value, g);
+            g_extra<NST, MASK>(c, f, decltype(e)::value, g);
             body(H + decltype(e)::value, g, mcur[e]);
         });
     }
     // end of a step with NST stages: for every slot, ab = sum_s B_s g_s and ae = sum_s BT_s g_s (fma chains in ascending
     // stage order, started by the product), candidate mu_new = fma(dt, ab, mu), residual^2 accumulated in slot order
-    template <int NST>
+    template <int NST, unsigned MASK>
     static __device__ __forceinline__ double step_slots(const Ctx& c, const double* B, const double* BT, double dt,
                                                         double abstol, double reltol, const double* mu, double* mu_new,
                                                         int ms) {
+        static_assert(MASK & 1u, "the first stage starts the chains");
         Fac f;
-        load_factors<NST>(c, f);
+        load_factors<NST, MASK>(c, f);
         double bb[NST], bt[NST];  // tableau weights as scalars (one load per step, not per slot)
         static_for<0, NST>([&](auto s) { bb[s] = uniform_f64(B[s]); bt[s] = uniform_f64(BT[s]); });
         double ps = 0.0;
-        for_each_slot<NST>(c, f, mu, ms, [&](int slot, const double* g, double m0) {
+        for_each_slot<NST, MASK>(c, f, mu, ms, [&](int slot, const double* g, double m0) {
             double ab = bb[0] * g[0], ae = bt[0] * g[0];
             static_for<1, NST>([&](auto s) {
-                ab = __builtin_fma(bb[s], g[s], ab);
-                ae = __builtin_fma(bt[s], g[s], ae);
+                if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                    ab = __builtin_fma(bb[s], g[s], ab);
+                    ae = __builtin_fma(bt[s], g[s], ae);
+                }
             });
             const double m1 = __builtin_fma(dt, ab, m0);
             mu_new[(size_t)slot * ms] = m1;
@@ -492,8 +503,8 @@ struct SeirUde {
     static __device__ __forceinline__ void init_norm01(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
                                                        double& h0, double& l0, double& h1, double& l1) {
         Fac f;
-        load_factors<1>(c, f);
-        for_each_slot<1>(c, f, mu, ms, [&](int, const double* g, double m) {
+        load_factors<1, 1u>(c, f);
+        for_each_slot<1, 1u>(c, f, mu, ms, [&](int, const double* g, double m) {
             const double sk = __builtin_fma(fabs(m), reltol, abstol);
             const double q0 = m / sk, q1 = g[0] / sk;
             dd_acc(h0, l0, q0 * q0);
@@ -503,8 +514,8 @@ struct SeirUde {
     static __device__ __forceinline__ void init_norm2(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
                                                       double& h2, double& l2) {
         Fac f;
-        load_factors<2>(c, f);
-        for_each_slot<2>(c, f, mu, ms, [&](int, const double* g, double m) {
+        load_factors<2, 3u>(c, f);
+        for_each_slot<2, 3u>(c, f, mu, ms, [&](int, const double* g, double m) {
             const double sk = __builtin_fma(fabs(m), reltol, abstol);
             const double q = (g[1] - g[0]) / sk;
             dd_acc(h2, l2, q * q);
