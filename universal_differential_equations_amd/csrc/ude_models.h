@@ -787,15 +787,19 @@ struct KppUdeW : LinearTheta {
     // every tile access would cost VMEM latency)
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
-        const lds_t* nn;
+        const lds_t* nn;  // network weights, LDS copy (reverse sweep: its scalar-load counter is shared with the tile traffic)
+        // forward pass: weights through the CONSTANT address space (theta is read-only for the kernel): every index is a
+        // compile-time constant and the address wave-uniform -> scalar loads (K$), no LDS traffic, no VGPRs for weights
+        const __attribute__((address_space(4))) double* nnc;
         lds_t *urow, *lrow, *orow, *tile, *part;
         double w1, w2, w3, D0;
         int r, lane, w, n, so, d0o, nno;
     };
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
+    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* theta_g = nullptr) {
         lds_t* th = (lds_t*)th_lds;
         lds_t* sc = (lds_t*)scratch;
         c.nn = th + mc.nn_offset;
+        c.nnc = (const __attribute__((address_space(4))) double*)(theta_g + mc.nn_offset);
         c.urow = sc; c.lrow = sc + NPT + 2; c.orow = sc + 2 * (NPT + 2);
         c.part = sc + 3 * (NPT + 2);  // [NWV][TILE]; wavefront w's tile = its block-sum row afterwards
         c.r = r; c.lane = r & 63; c.w = r >> 6;
@@ -825,8 +829,8 @@ struct KppUdeW : LinearTheta {
                     constexpr int in = Net::dim(l), nout = Net::dim(l + 1);
                     static_for<0, nout>([&](auto j) {
                         double s = 0.0;
-                        static_for<0, in>([&](auto k) { s = __builtin_fma((double)c.nn[Net::off(l) + j + k * nout], ain[k], s); });
-                        s += (double)c.nn[Net::off(l) + in * nout + j];
+                        static_for<0, in>([&](auto k) { s = __builtin_fma((double)c.nnc[Net::off(l) + j + k * nout], ain[k], s); });
+                        s += (double)c.nnc[Net::off(l) + in * nout + j];
                         aout[j] = act_fwd<Net::act(l)>(s);
                     });
                     static_for<0, nout>([&](auto j) { ain[j] = aout[j]; });
