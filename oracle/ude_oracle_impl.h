@@ -87,8 +87,10 @@ static void FN(mlp_forward)(const udeo_model_desc* m, const REAL* p, const REAL*
 }
 
 /* reverse sweep: gy = cotangent of the output; gx = cotangent of the input; gp += parameter cotangent */
-static void FN(mlp_vjp)(const udeo_model_desc* m, const REAL* p0, REAL zs[][UDEO_MAXW],
-                        REAL as[][UDEO_MAXW], const REAL* gy, REAL* gx, REAL* gp0) {
+/* fma_acc: accumulate the parameter cotangent as gp = fma(delta, a, gp) (Fisher-KPP sums over grid points: the order
+ * and fusing of v_mfma_f64_16x16x4, measured by tools/probe/mfma_order_probe.hip) instead of gp += delta * a */
+static void FN(mlp_vjp_acc)(const udeo_model_desc* m, const REAL* p0, REAL zs[][UDEO_MAXW],
+                            REAL as[][UDEO_MAXW], const REAL* gy, REAL* gx, REAL* gp0, int fma_acc) {
     REAL delta[UDEO_MAXW], prev[UDEO_MAXW];
     size_t offs[UDEO_MAX_LAYERS];
     size_t off = 0;
@@ -106,13 +108,19 @@ static void FN(mlp_vjp)(const udeo_model_desc* m, const REAL* p0, REAL zs[][UDEO
             REAL* gW = gp0 + offs[l];
             REAL* gb = gW + (size_t)in * out;
             for (int k = 0; k < in; ++k)
-                for (int j = 0; j < out; ++j) gW[j + (size_t)k * out] += delta[j] * as[l][k];
-            for (int j = 0; j < out; ++j) gb[j] += delta[j];
+                for (int j = 0; j < out; ++j)
+                    gW[j + (size_t)k * out] = fma_acc ? R_FMA(delta[j], as[l][k], gW[j + (size_t)k * out])
+                                                      : gW[j + (size_t)k * out] + delta[j] * as[l][k];
+            for (int j = 0; j < out; ++j) gb[j] += delta[j]; /* == fma(delta, 1, gb) */
         }
         for (int k = 0; k < in; ++k) prev[k] = FN(wide_dot)(out, in, W + (size_t)k * out, (size_t)1, delta);
         for (int k = 0; k < in; ++k) delta[k] = prev[k];
     }
     for (int k = 0; k < m->dims[0]; ++k) gx[k] = delta[k];
+}
+static void FN(mlp_vjp)(const udeo_model_desc* m, const REAL* p0, REAL zs[][UDEO_MAXW],
+                        REAL as[][UDEO_MAXW], const REAL* gy, REAL* gx, REAL* gp0) {
+    FN(mlp_vjp_acc)(m, p0, zs, as, gy, gx, gp0, 0);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -252,8 +260,9 @@ int FN(udeo_rhs_vjp)(const udeo_model_desc* m, const REAL* th, const REAL* u, RE
             const REAL w1 = th[m->stencil_offset], w2 = th[m->stencil_offset + 1],
                        w3 = th[m->stencil_offset + 2], D0 = th[m->d0_offset];
             /* ARITH-SPEC: every parameter-cotangent sum over the grid runs over BLOCKS of 256 consecutive points: a
-             * sequential chain (from 0, ascending points) inside a block, the block sums added left to right.  (The
-             * device gives each 256-point block to one wavefront; grids of <= 256 points are a single chain.) */
+             * sequential FUSED chain acc = fma(delta, a, acc) (from 0, ascending points) inside a block, the block sums
+             * added left to right.  (The device gives each 256-point block to one wavefront and runs the chain on the
+             * matrix cores: v_mfma_f64_16x16x4 is exactly this fma chain; grids of <= 256 points are a single chain.) */
             enum { KPP_BLOCK = 256 };
             const int np = m->n_param;
             REAL* blk = dth ? (REAL*)calloc((size_t)2 * np + 8, sizeof(REAL)) : 0;
@@ -267,13 +276,14 @@ int FN(udeo_rhs_vjp)(const udeo_model_desc* m, const REAL* th, const REAL* u, RE
                     const int im = (i + n - 1) % n, ip = (i + 1) % n;
                     REAL gx[1];
                     FN(mlp_forward)(m, th + m->nn_offset, &u[i], zs, as);
-                    FN(mlp_vjp)(m, th + m->nn_offset, zs, as, &lam[i], gx, blk ? blk + m->nn_offset : 0);
+                    FN(mlp_vjp_acc)(m, th + m->nn_offset, zs, as, &lam[i], gx, blk ? blk + m->nn_offset : 0, 1);
                     /* transpose of the periodic 3-tap stencil */
                     dlam[i] = gx[0] + D0 * (w1 * lam[ip] + w2 * lam[i] + w3 * lam[im]);
-                    gw1 += lam[i] * u[im];
-                    gw2 += lam[i] * u[i];
-                    gw3 += lam[i] * u[ip];
-                    gD += lam[i] * (w1 * u[im] + w2 * u[i] + w3 * u[ip]);
+                    /* (fused accumulation, as the network parameters: the device forms these on the matrix cores too) */
+                    gw1 = R_FMA(lam[i], u[im], gw1);
+                    gw2 = R_FMA(lam[i], u[i], gw2);
+                    gw3 = R_FMA(lam[i], u[ip], gw3);
+                    gD = R_FMA(lam[i], w1 * u[im] + w2 * u[i] + w3 * u[ip], gD);
                 }
                 if (i0 == 0) {
                     if (blk) memcpy(tot, blk, sizeof(REAL) * np);

@@ -670,8 +670,10 @@ struct KppUde : LinearTheta {
             if (i < n) { c.urow[i] = u[cc]; c.lrow[i] = lam[cc]; }
         });
         __syncthreads();
-        double acc[NSL];
-        static_for<0, NSL>([&](auto m) { acc[m] = 0.0; });
+        // ARITH-SPEC: fused chains over blocks of 256 consecutive points, block sums added left to right
+        static_assert(256 % G == 0, "a 256-point block is a whole number of tiles");
+        double acc[NSL], tot[NSL];
+        static_for<0, NSL>([&](auto m) { acc[m] = 0.0; tot[m] = 0.0; });
         for (int cc = 0; cc < PPL; ++cc) {  // tile cc = points cc*G .. cc*G + G-1 (ascending)
             const int i = cc * G + c.r;
             double gxi = 0.0;
@@ -706,7 +708,7 @@ struct KppUde : LinearTheta {
                         const double* dr = c.Dt + c.d_row[m];
                         if (c.a_row[m] >= 0) {
                             const double* ar = c.A + c.a_row[m];
-                            for (int q = 0; q < npts; ++q) acc[m] += dr[q * RD] * ar[q * RA];
+                            for (int q = 0; q < npts; ++q) acc[m] = __builtin_fma(dr[q * RD], ar[q * RA], acc[m]);  // ARITH-SPEC: fused chain
                         } else {
                             for (int q = 0; q < npts; ++q) acc[m] += dr[q * RD];
                         }
@@ -714,21 +716,30 @@ struct KppUde : LinearTheta {
                 });
             }
             __syncthreads();
+            if constexpr (WANT_PARAM) {
+                if (((cc + 1) * G) % 256 == 0 || cc == PPL - 1) {  // end of a 256-point block (or of the grid)
+                    const bool firstb = (cc * G) < 256;
+                    static_for<0, NSL>([&](auto m) { tot[m] = firstb ? acc[m] : tot[m] + acc[m]; acc[m] = 0.0; });
+                }
+            }
         }
         if constexpr (WANT_PARAM) {
-            // stencil weights and D0: sequential sums over ALL points (oracle order), by the owning lanes
+            static_for<0, NSL>([&](auto m) { acc[m] = tot[m]; });
+            // stencil weights and D0: fused sums over blocks of 256 points (oracle order), by the owning lanes
             static_for<0, NSL>([&](auto mc) {
                 constexpr int m = mc;
                 const int kd = c.kind[m];
                 if (kd >= 1) {
-                    double s = 0.0;
+                    double s = 0.0, st = 0.0;
                     for (int i = 0; i < n; ++i) {
+                        if (i > 0 && i % 256 == 0) { st = i == 256 ? s : st + s; s = 0.0; }
                         const int im = (i + n - 1) % n, ip = (i + 1) % n;
-                        if (kd == 1) s += c.lrow[i] * c.urow[im];
-                        else if (kd == 2) s += c.lrow[i] * c.urow[i];
-                        else if (kd == 3) s += c.lrow[i] * c.urow[ip];
-                        else s += c.lrow[i] * (c.w1 * c.urow[im] + c.w2 * c.urow[i] + c.w3 * c.urow[ip]);
+                        if (kd == 1) s = __builtin_fma(c.lrow[i], c.urow[im], s);
+                        else if (kd == 2) s = __builtin_fma(c.lrow[i], c.urow[i], s);
+                        else if (kd == 3) s = __builtin_fma(c.lrow[i], c.urow[ip], s);
+                        else s = __builtin_fma(c.lrow[i], c.w1 * c.urow[im] + c.w2 * c.urow[i] + c.w3 * c.urow[ip], s);
                     }
+                    s = n > 256 ? st + s : s;
                     acc[m] = kd == 4 ? s : c.D0 * s;
                 }
             });
@@ -773,9 +784,17 @@ struct KppUdeW : LinearTheta {
     }
     static_assert(acts_ok(), "KppUdeW: tanh hidden layers, linear output");
     static constexpr int cnt(int l) { return Net::dim(l) * Net::dim(l + 1) + Net::dim(l + 1); }  // parameters of layer l
-    static constexpr int sl(int l) { return (cnt(l) + TP - 1) / TP; }                             // ... per lane
-    static constexpr int sl_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += sl(i); return s; }
-    static constexpr int NACC = sl_off(L);
+    // The parameter cotangent of layer l over a tile of 64 points is the matrix product
+    //   D[i][j] += sum_q delta_l[i](q) * ahat_{l}[j](q),  ahat = [a_l ; 1]   (out x 64) . (64 x (in+1))
+    // and runs on the matrix cores: v_mfma_f64_16x16x4 executes d = fma(a_k, b_k, d) for k = 0..3 in ascending order
+    // (tools/probe/mfma_order_probe.hip: 51200/51200 results bit-identical), i.e. exactly ARITH-SPEC's fused chain over
+    // ascending points.  16 instructions per 16x16 output tile and 64 points; accumulators stay in (A)GPRs across the
+    // wavefront's four tiles.
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    static constexpr int mt(int l) { return (Net::dim(l + 1) + 15) / 16; }   // 16-row tiles of delta
+    static constexpr int nt(int l) { return (Net::dim(l) + 1 + 15) / 16; }   // 16-column tiles of [a ; 1]
+    static constexpr int acc_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += mt(i) * nt(i); return s; }
+    static constexpr int NACC = acc_off(L);
     static constexpr int maxrows() { int m = 0; for (int l = 0; l < L; ++l) { int r = Net::dim(l) + Net::dim(l + 1); m = r > m ? r : m; } return m; }
     static constexpr int RS = (maxrows() + 1) | 1;           // odd row stride of the tile; last column holds 1.0 (bias parameters)
     static constexpr int ONE_COL = RS - 1;
@@ -857,8 +876,9 @@ struct KppUdeW : LinearTheta {
             if (i < n) { c.urow[i] = u[cc]; c.lrow[i] = lam[cc]; }
         });
         __syncthreads();
-        double acc[NACC];  // this lane's share of the wavefront's block sums (chains run on across its four tiles)
-        static_for<0, NACC>([&](auto m) { acc[m] = 0.0; });
+        v4d acc[NACC];  // output tiles of the wavefront's block sums (the chains run on across its four point tiles)
+        static_for<0, NACC>([&](auto m) { acc[m] = v4d{0.0, 0.0, 0.0, 0.0}; });
+        const int l16 = c.lane & 15, kq = c.lane >> 4;
 #pragma unroll 1
         for (int cc = 0; cc < PPL; ++cc) {
             const int i = point(cc, c.r);
@@ -895,22 +915,30 @@ struct KppUdeW : LinearTheta {
                     static_for<0, out>([&](auto j) { row[in + j] = dcur[j]; });
                     row[ONE_COL] = 1.0;  // bias parameters: delta * 1.0 == delta exactly
                     wave_sync();
-                    // this lane's parameters of the layer advance TOGETHER through the tile's points (independent
-                    // chains interleaved: the add latency of one hides behind the others); lanes beyond the layer's
-                    // parameter count redo its last parameter (never written out) instead of branching
-                    int doff[sl(l)], aoff[sl(l)];
-                    static_for<0, sl(l)>([&](auto mc) {
-                        int e = c.lane + TP * decltype(mc)::value;
-                        e = e < cnt(l) ? e : cnt(l) - 1;
-                        doff[mc] = e < in * out ? in + e % out : in + (e - in * out);
-                        aoff[mc] = e < in * out ? e / out : ONE_COL;
+                    // operands: lane (i, k) = (lane % 16, lane / 16): A[i][k] = delta_i(point 4s + k), B[k][j] = ahat_j(point 4s + k);
+                    // rows / columns beyond the layer's sizes are clamped (their outputs are never written out)
+                    int aoff[mt(l)], boff[nt(l)];
+                    static_for<0, mt(l)>([&](auto m) {
+                        const int i = l16 + 16 * decltype(m)::value;
+                        aoff[m] = in + (i < out ? i : out - 1);
                     });
+                    static_for<0, nt(l)>([&](auto nn) {
+                        const int j = l16 + 16 * decltype(nn)::value;
+                        boff[nn] = j < in ? j : ONE_COL;
+                    });
+                    const lds_t* pt = c.tile + kq * RS;
 #pragma unroll 4
-                    for (int q = 0; q < npts; ++q) {
-                        const lds_t* pt = c.tile + q * RS;
-                        static_for<0, sl(l)>([&](auto mc) {
-                            acc[sl_off(l) + decltype(mc)::value] += pt[doff[mc]] * pt[aoff[mc]];
+                    for (int s4 = 0; s4 < TP / 4; ++s4) {
+                        double av[mt(l)], bv[nt(l)];
+                        static_for<0, mt(l)>([&](auto m) { av[m] = pt[aoff[m]]; });
+                        static_for<0, nt(l)>([&](auto nn) { bv[nn] = pt[boff[nn]]; });
+                        static_for<0, mt(l)>([&](auto m) {
+                            static_for<0, nt(l)>([&](auto nn) {
+                                constexpr int ai = acc_off(l) + decltype(m)::value * nt(l) + decltype(nn)::value;
+                                acc[ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[nn], acc[ai], 0, 0, 0);
+                            });
                         });
+                        pt += 4 * RS;
                     }
                 }
                 // cotangent of this layer's input: (W_l^T delta_l) [* act'(a_l) for hidden inputs]
@@ -934,30 +962,44 @@ struct KppUdeW : LinearTheta {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         static_for<0, PPL>([&](auto cc) { dlam[cc] = c.orow[point(cc, c.r)]; });
         if constexpr (WANT_PARAM) {
-            // stencil weights and D0: this wavefront's block of the oracle's four running sums, lanes 0..3
-            double sblk = 0.0;
-            if (c.lane < 4) {
-                const int b0 = c.w * BLK, b1 = b0 + BLK < n ? b0 + BLK : n;
+            // stencil weights and D0: the block's four fused sums as ONE more matrix product, row 0 of
+            //   lambda(1 x 256) . [u_{i-1}, u_i, u_{i+1}, w1 u_{i-1} + w2 u_i + w3 u_{i+1}](256 x 4)
+            v4d sacc = v4d{0.0, 0.0, 0.0, 0.0};
+            {
+                const int b0 = c.w * BLK;
 #pragma unroll 4
-                for (int i = b0; i < b1; ++i) {
-                    const int im = (i + n - 1) % n, ip = (i + 1) % n;
-                    const double um = c.urow[im], u0 = c.urow[i], up = c.urow[ip];
-                    const double term = c.lane == 0 ? um : c.lane == 1 ? u0 : c.lane == 2 ? up : (c.w1 * um + c.w2 * u0 + c.w3 * up);
-                    sblk += c.lrow[i] * term;
+                for (int s4 = 0; s4 < BLK / 4; ++s4) {
+                    const int i = b0 + 4 * s4 + kq;
+                    double av = 0.0, bv = 0.0;
+                    if (i < n) {
+                        const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                        const double um = c.urow[im], u0 = c.urow[i], up = c.urow[ip];
+                        av = c.lrow[i];
+                        bv = l16 == 0 ? um : l16 == 1 ? u0 : l16 == 2 ? up : l16 == 3 ? (c.w1 * um + c.w2 * u0 + c.w3 * up) : 0.0;
+                    }
+                    sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, sacc, 0, 0, 0);
                 }
             }
-            // block sums -> this wavefront's row (aliases its tile)
+            // block sums -> this wavefront's row (aliases its tile).  Output element (i, j) of a 16x16 tile sits in lane
+            // (i % 4 ... ) : row i = lane / 16 + 4 r, column j = lane % 16 of register r
             wave_sync();
             lds_t* prow = c.tile;
             static_for<0, L>([&](auto lc) {
                 constexpr int l = lc;
-                static_for<0, sl(l)>([&](auto mc) {
-                    const int e = c.lane + TP * decltype(mc)::value;
-                    if (e < cnt(l)) prow[c.nno + Net::off(l) + e] = acc[sl_off(l) + decltype(mc)::value];
+                constexpr int in = Net::dim(l), out = Net::dim(l + 1);
+                static_for<0, mt(l)>([&](auto m) {
+                    static_for<0, nt(l)>([&](auto nn) {
+                        constexpr int ai = acc_off(l) + decltype(m)::value * nt(l) + decltype(nn)::value;
+                        const int j = l16 + 16 * decltype(nn)::value;
+                        static_for<0, 4>([&](auto r) {
+                            const int i = kq + 4 * decltype(r)::value + 16 * decltype(m)::value;
+                            if (i < out && j <= in) prow[c.nno + Net::off(l) + (j < in ? i + j * out : in * out + i)] = acc[ai][decltype(r)::value];
+                        });
+                    });
                 });
             });
-            if (c.lane < 3) prow[c.so + c.lane] = sblk;
-            if (c.lane == 3) { prow[c.d0o] = sblk; prow[c.so + 3] = 0.0; }
+            if (kq == 0 && l16 < 3) prow[c.so + l16] = sacc[0];   // row 0 lives in register 0 of lanes 0..15
+            if (kq == 0 && l16 == 3) { prow[c.d0o] = sacc[0]; prow[c.so + 3] = 0.0; }
             __syncthreads();
             static_for<0, NSL>([&](auto s) {
                 const int p = c.r + G * decltype(s)::value;
