@@ -758,16 +758,26 @@ struct KppUde : LinearTheta {
 
 
 // ---------------------------------------------------------------------------------------------
-// nn_ode on LARGE grids (BASELINE configs[3]: 1024 points): one trajectory per block of 4 wavefronts.
-// Wavefront w owns the 256 consecutive points 256w .. 256w+255 (4 per lane: point = 256w + 64c + lane), i.e. one
-// ARITH-SPEC block of the parameter-cotangent sums (oracle: KPP_BLOCK): it forms its block's partial sums alone, in
-// a WAVE-PRIVATE [point][row] LDS tile, one layer at a time (lanes switch from owning a point to owning a
-// parameter of that layer and walk the tile's 64 points in ascending order); the four block sums meet in LDS and
-// are added left to right by the parameter's final owner (theta index p = r + 256 m: the Driver's register slots).
+// nn_ode on LARGE grids (BASELINE configs[3]: 1024 points): one trajectory per block of 4 wavefronts, the pointwise
+// network AND its parameter contraction on the FP64 matrix cores.
+//
+// v_mfma_f64_16x16x4 computes D = C + A(16x4) B(4x16) as d = fma(a_k, b_k, d) for k = 0..3 IN ASCENDING ORDER
+// (tools/probe/mfma_order_probe.hip: 51200/51200 results bit-identical to that chain) -- exactly ARITH-SPEC's fma chain
+// in ascending index order started from 0.  So for a tile of 16 grid points (columns):
+//   forward   z_l = W_l a_l          A = W_l (neurons x inputs, registers, zero padded), B = a_l, chain over inputs
+//   backward  g   = W_l^T delta_l    A = W_l^T, B = delta_l,                                  chain over outputs
+//   contraction dW_l += delta_l [a_l ; 1]^T   A = delta_l, B = [a_l ; 1], chain over the GRID POINTS (fused, ascending)
+// and the output layout of one product (lane (k, j), register r <-> row k + 4r, column j) IS the B-operand layout of
+// the next one (k-step s <-> register s): activations and deltas never leave the registers between layers.  Only the
+// contraction needs points along K, i.e. a transpose, through a wave-private [point][row] LDS tile.  Zero padding is
+// exact: fma(0, b, acc) == acc for finite b.
+// Wavefront w owns the 256 consecutive points 256w .. 256w+255 (16 column tiles), one ARITH-SPEC block of the
+// parameter sums; the four block sums meet in LDS and are added left to right by the parameter's final owner
+// (theta index p = r + 256 m: the Driver's register slots).  The state itself is distributed 4 points per lane.
 // ---------------------------------------------------------------------------------------------
 template <class Net>
 struct KppUdeW : LinearTheta {
-    static constexpr int G = 256, PPL = 4, NWV = 4, TP = 64, BLK = 256;
+    static constexpr int G = 256, PPL = 4, NWV = 4, TP = 64, BLK = 256, NTILE = BLK / 16;
     static __host__ __device__ constexpr int point(int c, int r) { return (r >> 6) * BLK + c * TP + (r & 63); }
     static_assert(Net::dim(0) == 1 && Net::dim(Net::L) == 1, "pointwise reaction network R -> R");
     static constexpr int NS = PPL;
@@ -776,91 +786,122 @@ struct KppUdeW : LinearTheta {
     static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = true;
     static constexpr int L = Net::L;
     static constexpr int NPT = G * PPL;
-    static constexpr int MAXD = Net::maxdim();
-    static constexpr bool acts_ok() {  // the reverse sweep rebuilds act' from the activation VALUE (tanh family only)
+    static constexpr bool acts_ok() {  // the reverse sweep rebuilds act' from the activation VALUE (tanh only)
         for (int l = 0; l + 1 < L; ++l)
             if (Net::act(l) != ACT_TANH) return false;
         return Net::act(L - 1) == ACT_IDENTITY;
     }
-    static_assert(acts_ok(), "KppUdeW: tanh hidden layers, linear output");
-    static constexpr int cnt(int l) { return Net::dim(l) * Net::dim(l + 1) + Net::dim(l + 1); }  // parameters of layer l
-    // The parameter cotangent of layer l over a tile of 64 points is the matrix product
-    //   D[i][j] += sum_q delta_l[i](q) * ahat_{l}[j](q),  ahat = [a_l ; 1]   (out x 64) . (64 x (in+1))
-    // and runs on the matrix cores: v_mfma_f64_16x16x4 executes d = fma(a_k, b_k, d) for k = 0..3 in ascending order
-    // (tools/probe/mfma_order_probe.hip: 51200/51200 results bit-identical), i.e. exactly ARITH-SPEC's fused chain over
-    // ascending points.  16 instructions per 16x16 output tile and 64 points; accumulators stay in (A)GPRs across the
-    // wavefront's four tiles.
+    static_assert(acts_ok(), "KppUdeW: tanh hidden layers (tanh(0) == 0 keeps the padding rows at zero), linear output");
     typedef double v4d __attribute__((ext_vector_type(4)));
-    static constexpr int mt(int l) { return (Net::dim(l + 1) + 15) / 16; }   // 16-row tiles of delta
-    static constexpr int nt(int l) { return (Net::dim(l) + 1 + 15) / 16; }   // 16-column tiles of [a ; 1]
-    static constexpr int acc_off(int l) { int s = 0; for (int i = 0; i < l; ++i) s += mt(i) * nt(i); return s; }
+    typedef __attribute__((address_space(3))) double lds_t;
+    static constexpr int MT(int n) { return (n + 15) / 16; }  // 16-row output tiles
+    static constexpr int KS(int n) { return (n + 3) / 4; }    // k-steps of 4
+    static constexpr int MAXR = 4 * MT(Net::maxdim());         // registers of one activation / delta vector (D layout)
+    // operand tables (per lane): forward A_l[mt][s], backward AT_l[mt][s], biases in D layout
+    static constexpr int af_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += MT(Net::dim(i + 1)) * KS(Net::dim(i)); return o; }
+    static constexpr int ab_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += MT(Net::dim(i)) * KS(Net::dim(i + 1)); return o; }
+    static constexpr int bs_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += 4 * MT(Net::dim(i + 1)); return o; }
+    static constexpr int NAF = af_off(L), NAB = ab_off(L), NBS = bs_off(L);
+    // contraction: LDS tile [16 points][rows], rows = a_0 | a_1 .. a_{L-1} | delta_0 .. delta_{L-1} | 1
+    static constexpr int a_row(int l) { int o = 0; for (int i = 0; i < l; ++i) o += Net::dim(i); return o; }
+    static constexpr int ROWS_A = a_row(L);
+    static constexpr int d_row(int l) { int o = ROWS_A; for (int i = 0; i < l; ++i) o += Net::dim(i + 1); return o; }
+    static constexpr int ONE_COL = d_row(L);
+    static constexpr int RS = (ONE_COL + 1) | 1;  // odd row stride
+    static constexpr int TILE = 16 * RS;
+    static constexpr int cmt(int l) { return MT(Net::dim(l + 1)); }      // contraction output tiles: delta rows ...
+    static constexpr int cnt_(int l) { return MT(Net::dim(l) + 1); }     // ... x [a ; 1] columns
+    static constexpr int acc_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += cmt(i) * cnt_(i); return o; }
     static constexpr int NACC = acc_off(L);
-    static constexpr int maxrows() { int m = 0; for (int l = 0; l < L; ++l) { int r = Net::dim(l) + Net::dim(l + 1); m = r > m ? r : m; } return m; }
-    static constexpr int RS = (maxrows() + 1) | 1;           // odd row stride of the tile; last column holds 1.0 (bias parameters)
-    static constexpr int ONE_COL = RS - 1;
-    static constexpr int TILE = TP * RS;                     // doubles per wavefront
-    static constexpr int NPP = (NP + 1) & ~1;                // block-sum row (aliases the tile once the tiles are consumed)
+    static constexpr int NPP = (NP + 1) & ~1;  // block-sum row (aliases the tile once the column tiles are consumed)
     static_assert(NPP <= TILE, "block sums must fit the tile they alias");
     static constexpr int SCRATCH = 3 * (NPT + 2) + NWV * TILE;  // u, lambda, result rows + tiles
-    // LDS pointers carry their address space in the type (no reliance on the compiler inferring it: a FLAT load on
-    // every tile access would cost VMEM latency)
-    typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
-        const lds_t* nn;  // network weights, LDS copy (reverse sweep: its scalar-load counter is shared with the tile traffic)
-        // forward pass: weights through the CONSTANT address space (theta is read-only for the kernel): every index is a
-        // compile-time constant and the address wave-uniform -> scalar loads (K$), no LDS traffic, no VGPRs for weights
-        const __attribute__((address_space(4))) double* nnc;
+        double af[NAF], ab[NAB], bs[NBS];
         lds_t *urow, *lrow, *orow, *tile, *part;
         double w1, w2, w3, D0;
-        int r, lane, w, n, so, d0o, nno;
+        int r, lane, w, l16, kq, n, so, d0o, nno;
     };
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* theta_g = nullptr) {
-        lds_t* th = (lds_t*)th_lds;
+    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
+        const lds_t* th = (const lds_t*)th_lds;
         lds_t* sc = (lds_t*)scratch;
-        c.nn = th + mc.nn_offset;
-        c.nnc = (const __attribute__((address_space(4))) double*)(theta_g + mc.nn_offset);
         c.urow = sc; c.lrow = sc + NPT + 2; c.orow = sc + 2 * (NPT + 2);
         c.part = sc + 3 * (NPT + 2);  // [NWV][TILE]; wavefront w's tile = its block-sum row afterwards
-        c.r = r; c.lane = r & 63; c.w = r >> 6;
+        c.r = r; c.lane = r & 63; c.w = r >> 6; c.l16 = c.lane & 15; c.kq = c.lane >> 4;
         c.tile = c.part + c.w * TILE;
         c.n = mc.n_state; c.so = mc.stencil_offset; c.d0o = mc.d0_offset; c.nno = mc.nn_offset;
         c.w1 = th[c.so]; c.w2 = th[c.so + 1]; c.w3 = th[c.so + 2]; c.D0 = th[c.d0o];
+        const lds_t* nn = th + mc.nn_offset;
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            constexpr int in = Net::dim(l), out = Net::dim(l + 1);
+            static_for<0, MT(out)>([&](auto m) {
+                static_for<0, KS(in)>([&](auto s) {  // forward: A[i][k] = W_l[i][k]
+                    const int i = c.l16 + 16 * decltype(m)::value, k = 4 * decltype(s)::value + c.kq;
+                    c.af[af_off(l) + decltype(m)::value * KS(in) + decltype(s)::value] = (i < out && k < in) ? (double)nn[Net::off(l) + i + k * out] : 0.0;
+                });
+                static_for<0, 4>([&](auto rr) {
+                    const int i = c.kq + 4 * decltype(rr)::value + 16 * decltype(m)::value;
+                    c.bs[bs_off(l) + 4 * decltype(m)::value + decltype(rr)::value] = i < out ? (double)nn[Net::off(l) + in * out + i] : 0.0;
+                });
+            });
+            static_for<0, MT(in)>([&](auto m) {
+                static_for<0, KS(out)>([&](auto s) {  // backward: A[i][k] = W_l[k][i]
+                    const int i = c.l16 + 16 * decltype(m)::value, k = 4 * decltype(s)::value + c.kq;
+                    c.ab[ab_off(l) + decltype(m)::value * KS(out) + decltype(s)::value] = (i < in && k < out) ? (double)nn[Net::off(l) + k + i * out] : 0.0;
+                });
+            });
+        });
+    }
+    static __device__ __forceinline__ v4d mfma(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // forward pass of one column tile.  b0: this lane's B operand of layer 0 (u of point l16 on lanes k = 0, else 0).
+    // act[l] (l >= 1): output of layer l-1 = input of layer l, D layout (register m*4 + r <-> neuron kq + 4r + 16m).
+    // Returns the network output y (row 0: meaningful on lanes with kq == 0).
+    static __device__ __forceinline__ double forward_tile(const Ctx& c, double b0, double (&act)[L][MAXR]) {
+        double y = 0.0;
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            constexpr int in = Net::dim(l), out = Net::dim(l + 1);
+            static_for<0, MT(out)>([&](auto m) {
+                v4d d = v4d{0.0, 0.0, 0.0, 0.0};
+                static_for<0, KS(in)>([&](auto s) {
+                    const double bop = l == 0 ? b0 : act[l][decltype(s)::value];
+                    d = mfma(c.af[af_off(l) + decltype(m)::value * KS(in) + decltype(s)::value], bop, d);
+                });
+                static_for<0, 4>([&](auto rr) {
+                    constexpr int r0 = 4 * decltype(rr)::value + 16 * decltype(m)::value;  // first neuron of this register
+                    if constexpr (r0 < out) {
+                        const double z = d[decltype(rr)::value] + c.bs[bs_off(l) + 4 * decltype(m)::value + decltype(rr)::value];
+                        if constexpr (l + 1 < L) act[l + 1][4 * decltype(m)::value + decltype(rr)::value] = act_fwd<Net::act(l)>(z);
+                        else if constexpr (r0 == 0) y = z;
+                    } else if constexpr (l + 1 < L) {
+                        act[l + 1][4 * decltype(m)::value + decltype(rr)::value] = 0.0;
+                    }
+                });
+            });
+        });
+        return y;
     }
     static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
         const int n = c.n;
         __syncthreads();
         static_for<0, PPL>([&](auto cc) { const int i = point(cc, c.r); if (i < n) c.urow[i] = u[cc]; });
         __syncthreads();
-        // ONE copy of the per-point code (runtime loop over this lane's four points); results return through the
-        // lane's own words of an LDS row, so no register array is indexed with a runtime index
 #pragma unroll 1
-        for (int cc = 0; cc < PPL; ++cc) {
-            const int i = point(cc, c.r);
-            double out = 0.0;
-            if (i < n) {
+        for (int t = 0; t < NTILE; ++t) {
+            const int i = c.w * BLK + 16 * t + c.l16;  // this lane's column
+            const bool on = c.kq == 0 && i < n;
+            const double ui = on ? c.urow[i] : 0.0;
+            double act[L][MAXR];
+            const double y = forward_tile(c, ui, act);
+            if (on) {
                 const int im = (i + n - 1) % n, ip = (i + 1) % n;
-                const double ui = c.urow[i];
-                // forward only: two ping-pong activation rows (the same fma chains as CoopMlp::forward)
-                double ain[MAXD], aout[MAXD];
-                ain[0] = ui;
-                static_for<0, L>([&](auto lc) {
-                    constexpr int l = lc;
-                    constexpr int in = Net::dim(l), nout = Net::dim(l + 1);
-                    static_for<0, nout>([&](auto j) {
-                        double s = 0.0;
-                        static_for<0, in>([&](auto k) { s = __builtin_fma((double)c.nnc[Net::off(l) + j + k * nout], ain[k], s); });
-                        s += (double)c.nnc[Net::off(l) + in * nout + j];
-                        aout[j] = act_fwd<Net::act(l)>(s);
-                    });
-                    static_for<0, nout>([&](auto j) { ain[j] = aout[j]; });
-                });
                 const double cnn = c.w1 * c.urow[im] + c.w2 * ui + c.w3 * c.urow[ip];
-                out = ain[0] + c.D0 * cnn;
+                c.orow[i] = y + c.D0 * cnn;
             }
-            c.orow[point(cc, c.r)] = out;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        static_for<0, PPL>([&](auto cc) { du[cc] = c.orow[point(cc, c.r)]; });
+        __syncthreads();  // (columns were produced by other lanes than the ones that own the points)
+        static_for<0, PPL>([&](auto cc) { const int i = point(cc, c.r); du[cc] = i < n ? c.orow[i] : 0.0; });
     }
     static __device__ __forceinline__ void wave_sync() {
         // the tile is private to the wavefront (lock-step lanes): only the LDS queue has to drain
@@ -876,91 +917,100 @@ struct KppUdeW : LinearTheta {
             if (i < n) { c.urow[i] = u[cc]; c.lrow[i] = lam[cc]; }
         });
         __syncthreads();
-        v4d acc[NACC];  // output tiles of the wavefront's block sums (the chains run on across its four point tiles)
+        v4d acc[NACC];  // output tiles of the wavefront's block sums (the fused chains run on across its 16 column tiles)
         static_for<0, NACC>([&](auto m) { acc[m] = v4d{0.0, 0.0, 0.0, 0.0}; });
-        const int l16 = c.lane & 15, kq = c.lane >> 4;
+        const int l16 = c.l16, kq = c.kq;
 #pragma unroll 1
-        for (int cc = 0; cc < PPL; ++cc) {
-            const int i = point(cc, c.r);
-            const bool valid = i < n;
-            const double ui = valid ? c.urow[i] : 0.0, li = valid ? c.lrow[i] : 0.0;
-            // forward, keeping the INPUT of every layer (act[l] = a_l, a_0 = u): the same fma chains as CoopMlp::forward
-            double act[L][MAXD];
-            act[0][0] = ui;
-            static_for<0, L - 1>([&](auto lc) {
-                constexpr int l = lc;
-                constexpr int in = Net::dim(l), out = Net::dim(l + 1);
-                static_for<0, out>([&](auto j) {
-                    double s = 0.0;
-                    static_for<0, in>([&](auto k) { s = __builtin_fma((double)c.nn[Net::off(l) + j + k * out], act[l][k], s); });
-                    s += (double)c.nn[Net::off(l) + in * out + j];
-                    act[l + 1][j] = act_fwd<Net::act(l)>(s);
+        for (int t = 0; t < NTILE; ++t) {
+            const int i = c.w * BLK + 16 * t + l16;  // this lane's column
+            const bool on = kq == 0 && i < n;
+            const double ui = on ? c.urow[i] : 0.0, li = on ? c.lrow[i] : 0.0;
+            double act[L][MAXR];
+            forward_tile(c, ui, act);
+            if constexpr (WANT_PARAM) {
+                wave_sync();  // the contraction of the previous column tile is done with the LDS tile
+                lds_t* row = c.tile + l16 * RS;
+                if (kq == 0) { row[0] = ui; row[ONE_COL] = 1.0; }
+                static_for<1, L>([&](auto lc) {  // a_l, l >= 1 (D layout -> rows)
+                    constexpr int l = lc;
+                    constexpr int in = Net::dim(l);
+                    static_for<0, 4 * MT(in)>([&](auto q) {
+                        constexpr int r0 = 4 * (decltype(q)::value % 4) + 16 * (decltype(q)::value / 4);
+                        if constexpr (r0 < in) { if (r0 + kq < in) row[a_row(l) + r0 + kq] = act[l][q]; }
+                    });
                 });
-            });
-            // reverse sweep, one layer at a time from the top: parameters of layer l (tile phase) BEFORE its inputs'
-            // deltas are formed, so at most one activation row and two delta rows are live besides the stored inputs
-            double dcur[MAXD];
-            dcur[0] = li * 1.0;  // linear output layer
-            // points of this tile that exist (ascending from the tile's first point)
-            const int t0 = c.w * BLK + cc * TP;
-            const int npts = n - t0 < 0 ? 0 : (n - t0 < TP ? n - t0 : TP);
+            }
+            // reverse sweep: dcur = delta of layer l (D layout), from the linear output layer down
+            double dcur[MAXR];
+            dcur[0] = li * 1.0;
             double gxi = 0.0;
             static_for<0, L>([&](auto lr) {
                 constexpr int l = L - 1 - lr;
                 constexpr int in = Net::dim(l), out = Net::dim(l + 1);
                 if constexpr (WANT_PARAM) {
-                    wave_sync();  // owners of the previous layer are done with the tile
-                    lds_t* row = c.tile + c.lane * RS;
-                    static_for<0, in>([&](auto k) { row[k] = act[l][k]; });
-                    static_for<0, out>([&](auto j) { row[in + j] = dcur[j]; });
-                    row[ONE_COL] = 1.0;  // bias parameters: delta * 1.0 == delta exactly
-                    wave_sync();
-                    // operands: lane (i, k) = (lane % 16, lane / 16): A[i][k] = delta_i(point 4s + k), B[k][j] = ahat_j(point 4s + k);
-                    // rows / columns beyond the layer's sizes are clamped (their outputs are never written out)
-                    int aoff[mt(l)], boff[nt(l)];
-                    static_for<0, mt(l)>([&](auto m) {
-                        const int i = l16 + 16 * decltype(m)::value;
-                        aoff[m] = in + (i < out ? i : out - 1);
+                    lds_t* row = c.tile + l16 * RS;
+                    static_for<0, 4 * MT(out)>([&](auto q) {
+                        constexpr int r0 = 4 * (decltype(q)::value % 4) + 16 * (decltype(q)::value / 4);
+                        if constexpr (r0 < out) { if (r0 + kq < out) row[d_row(l) + r0 + kq] = dcur[q]; }
                     });
-                    static_for<0, nt(l)>([&](auto nn) {
-                        const int j = l16 + 16 * decltype(nn)::value;
-                        boff[nn] = j < in ? j : ONE_COL;
-                    });
-                    const lds_t* pt = c.tile + kq * RS;
-#pragma unroll 4
-                    for (int s4 = 0; s4 < TP / 4; ++s4) {
-                        double av[mt(l)], bv[nt(l)];
-                        static_for<0, mt(l)>([&](auto m) { av[m] = pt[aoff[m]]; });
-                        static_for<0, nt(l)>([&](auto nn) { bv[nn] = pt[boff[nn]]; });
-                        static_for<0, mt(l)>([&](auto m) {
-                            static_for<0, nt(l)>([&](auto nn) {
-                                constexpr int ai = acc_off(l) + decltype(m)::value * nt(l) + decltype(nn)::value;
-                                acc[ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[nn], acc[ai], 0, 0, 0);
-                            });
-                        });
-                        pt += 4 * RS;
-                    }
                 }
-                // cotangent of this layer's input: (W_l^T delta_l) [* act'(a_l) for hidden inputs]
-                double dprev[MAXD];
-                static_for<0, in>([&](auto k) {
-                    double s = 0.0;
-                    static_for<0, out>([&](auto j) { s = __builtin_fma((double)c.nn[Net::off(l) + j + k * out], dcur[j], s); });
-                    if constexpr (l > 0) dprev[k] = valid ? s * act_bwd<Net::act(l - 1)>(0.0, act[l][k]) : 0.0;
-                    else dprev[k] = s;
+                double dprev[MAXR];
+                static_for<0, MT(in)>([&](auto m) {
+                    v4d gq = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, KS(out)>([&](auto s) {
+                        gq = mfma(c.ab[ab_off(l) + decltype(m)::value * KS(out) + decltype(s)::value], dcur[decltype(s)::value], gq);
+                    });
+                    static_for<0, 4>([&](auto rr) {
+                        constexpr int q = 4 * decltype(m)::value + decltype(rr)::value;
+                        constexpr int r0 = 4 * decltype(rr)::value + 16 * decltype(m)::value;
+                        if constexpr (l > 0) {
+                            if constexpr (r0 < in) dprev[q] = gq[decltype(rr)::value] * act_bwd<Net::act(l - 1)>(0.0, act[l][q]);
+                            else dprev[q] = 0.0;
+                        } else if constexpr (q == 0) {
+                            gxi = gq[0];
+                        }
+                    });
                 });
-                if constexpr (l > 0) static_for<0, in>([&](auto k) { dcur[k] = dprev[k]; });
-                else gxi = dprev[0];
+                if constexpr (l > 0) static_for<0, 4 * MT(in)>([&](auto q) { dcur[q] = dprev[q]; });
             });
-            if (valid) {  // transpose of the periodic stencil (the oracle's expression)
+            if (on) {  // transpose of the periodic stencil (the oracle's expression)
                 const int im = (i + n - 1) % n, ip = (i + 1) % n;
                 c.orow[i] = gxi + c.D0 * (c.w1 * c.lrow[ip] + c.w2 * c.lrow[i] + c.w3 * c.lrow[im]);
-            } else {
-                c.orow[i] = 0.0;
+            }
+            if constexpr (WANT_PARAM) {
+                // contraction over the 16 points of the tile: 4 k-steps per output tile.  Lane (i, k) = (l16, kq):
+                // A[i][k] = delta_i(point 4s + k), B[k][j] = [a ; 1]_j(point 4s + k); rows / columns beyond the layer's
+                // sizes are clamped (their outputs are never written out)
+                wave_sync();
+                static_for<0, L>([&](auto lc) {
+                    constexpr int l = lc;
+                    constexpr int in = Net::dim(l), out = Net::dim(l + 1);
+                    int aoff[cmt(l)], boff[cnt_(l)];
+                    static_for<0, cmt(l)>([&](auto m) {
+                        const int ii = l16 + 16 * decltype(m)::value;
+                        aoff[m] = d_row(l) + (ii < out ? ii : out - 1);
+                    });
+                    static_for<0, cnt_(l)>([&](auto nn) {
+                        const int j = l16 + 16 * decltype(nn)::value;
+                        boff[nn] = j < in ? a_row(l) + j : ONE_COL;
+                    });
+                    static_for<0, 4>([&](auto s4) {
+                        const lds_t* pt = c.tile + (4 * decltype(s4)::value + kq) * RS;
+                        double av[cmt(l)], bv[cnt_(l)];
+                        static_for<0, cmt(l)>([&](auto m) { av[m] = pt[aoff[m]]; });
+                        static_for<0, cnt_(l)>([&](auto nn) { bv[nn] = pt[boff[nn]]; });
+                        static_for<0, cmt(l)>([&](auto m) {
+                            static_for<0, cnt_(l)>([&](auto nn) {
+                                constexpr int ai = acc_off(l) + decltype(m)::value * cnt_(l) + decltype(nn)::value;
+                                acc[ai] = mfma(av[m], bv[nn], acc[ai]);
+                            });
+                        });
+                    });
+                });
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        static_for<0, PPL>([&](auto cc) { dlam[cc] = c.orow[point(cc, c.r)]; });
+        __syncthreads();  // (columns were produced by other lanes than the ones that own the points)
+        static_for<0, PPL>([&](auto cc) { const int i = point(cc, c.r); dlam[cc] = i < n ? c.orow[i] : 0.0; });
         if constexpr (WANT_PARAM) {
             // stencil weights and D0: the block's four fused sums as ONE more matrix product, row 0 of
             //   lambda(1 x 256) . [u_{i-1}, u_i, u_{i+1}, w1 u_{i-1} + w2 u_i + w3 u_{i+1}](256 x 4)
@@ -977,23 +1027,22 @@ struct KppUdeW : LinearTheta {
                         av = c.lrow[i];
                         bv = l16 == 0 ? um : l16 == 1 ? u0 : l16 == 2 ? up : l16 == 3 ? (c.w1 * um + c.w2 * u0 + c.w3 * up) : 0.0;
                     }
-                    sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, sacc, 0, 0, 0);
+                    sacc = mfma(av, bv, sacc);
                 }
             }
-            // block sums -> this wavefront's row (aliases its tile).  Output element (i, j) of a 16x16 tile sits in lane
-            // (i % 4 ... ) : row i = lane / 16 + 4 r, column j = lane % 16 of register r
+            // block sums -> this wavefront's row (aliases its tile).  Output element: row = lane / 16 + 4 r, column = lane % 16
             wave_sync();
             lds_t* prow = c.tile;
             static_for<0, L>([&](auto lc) {
                 constexpr int l = lc;
                 constexpr int in = Net::dim(l), out = Net::dim(l + 1);
-                static_for<0, mt(l)>([&](auto m) {
-                    static_for<0, nt(l)>([&](auto nn) {
-                        constexpr int ai = acc_off(l) + decltype(m)::value * nt(l) + decltype(nn)::value;
+                static_for<0, cmt(l)>([&](auto m) {
+                    static_for<0, cnt_(l)>([&](auto nn) {
+                        constexpr int ai = acc_off(l) + decltype(m)::value * cnt_(l) + decltype(nn)::value;
                         const int j = l16 + 16 * decltype(nn)::value;
-                        static_for<0, 4>([&](auto r) {
-                            const int i = kq + 4 * decltype(r)::value + 16 * decltype(m)::value;
-                            if (i < out && j <= in) prow[c.nno + Net::off(l) + (j < in ? i + j * out : in * out + i)] = acc[ai][decltype(r)::value];
+                        static_for<0, 4>([&](auto rr) {
+                            const int ii = kq + 4 * decltype(rr)::value + 16 * decltype(m)::value;
+                            if (ii < out && j <= in) prow[c.nno + Net::off(l) + (j < in ? ii + j * out : in * out + ii)] = acc[ai][decltype(rr)::value];
                         });
                     });
                 });
