@@ -158,7 +158,9 @@ int ude_set_trace(ude_ctx* ctx, int64_t traj, int32_t cap);
 int ude_get_trace(ude_ctx* ctx, double* out_host /* 2*cap*5 */);
 
 /* ARITH-SPEC primitives as evaluated on the device (parity tests): op 0 fastpow(x,y), 1 exp, 2 tanh,
- * 3 log10, 4 10^x, 5 sqrt, 6 x/y, 7 fma(x,y,x) */
+ * 3 log10, 4 10^x, 5 sqrt, 6 x/y, 7 fma(x,y,x), 8 log, 9 x^y,
+ * 10 v_mfma_f64_16x16x4 probe: per group of 64 values lane l supplies A[l%16][l/16] = x, B[l/16][l%16] = y, C = 0 and
+ *    receives D[l/16][l%16] (n must be a multiple of 64) */
 int ude_math_dev(ude_ctx* ctx, int32_t op, int64_t n, const double* x_host, const double* y_host, double* out_host);
 
 /* DiffEqBase.fastpow as evaluated on the device (one thread), for parity tests of the controller */

@@ -486,3 +486,28 @@ def test_full_size_seir_and_kpp_properties():
     assert_bitwise(fullk.stats[idk][:, :7], refk["stats"][:, :7], "KPP stats of the subsample")
     assert_bitwise(fullk.u[idk], refk["u"], "KPP saved states")
     assert_bitwise(fullk.grad_u0[idk], refk["grad_u0"], "KPP dL/du0")
+
+
+def test_mfma_f64_is_the_ascending_fused_chain():
+    """The Fisher-KPP kernels put ARITH-SPEC fma chains on the matrix cores.  That is only bit-exact if
+    v_mfma_f64_16x16x4 computes d = fma(a_k, b_k, d) for k = 0..3 in ascending order starting from C: checked here
+    against exact rational arithmetic (Fraction -> float is correctly rounded) on random operands."""
+    from fractions import Fraction
+    rng = np.random.default_rng(5)
+    nb = 40
+    x = rng.normal(size=(nb, 64)) * np.exp2(rng.integers(-6, 6, size=(nb, 64)))
+    y = rng.normal(size=(nb, 64)) * np.exp2(rng.integers(-6, 6, size=(nb, 64)))
+    out = U.Engine.get(0).math(10, x.ravel(), y.ravel()).reshape(nb, 64)
+
+    def fma(a, b, c):
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    for b in range(nb):
+        A = lambda i, k: float(x[b, i + 16 * k])      # lane l = i + 16 k supplies A[i][k]
+        B = lambda k, j: float(y[b, j + 16 * k])      # lane l = j + 16 k supplies B[k][j]
+        for lane in range(64):
+            i, j = lane // 16, lane % 16                # register 0 of lane l holds D[l/16][l%16]
+            d = 0.0
+            for k in range(4):
+                d = fma(A(i, k), B(k, j), d)
+            assert d == out[b, lane], (b, lane)

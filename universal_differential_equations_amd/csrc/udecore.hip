@@ -69,6 +69,15 @@ __global__ void math_kernel(int op, const double* x, const double* y, double* ou
     out[i] = r;
 }
 
+// op 10: the operation sequence of the FP64 matrix cores.  Per wavefront: lane l supplies A[l%16][l/16] = x, B[l/16][l%16] = y,
+// C = 0; out = register 0 of D, i.e. D[l/16][l%16].  tests/ check it against the ascending fused chain ARITH-SPEC assumes.
+__global__ void mfma_probe_kernel(const double* x, const double* y, double* out) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], y[i], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+    out[i] = d[0];
+}
+
 }  // namespace ude
 
 struct DevBuf {
@@ -624,6 +633,11 @@ extern "C" int ude_math_dev(ude_ctx* c, int32_t op, int64_t n, const double* x, 
     if ((rc = up(c, c->s_u0, x, sizeof(double) * n, &dx))) return rc;
     if ((rc = up(c, c->s_data, y, sizeof(double) * n, &dy))) return rc;
     if ((rc = ensure(c, c->s_out, sizeof(double) * n))) return rc;
+    if (op == 10) {
+        if (n % 64) return fail(c, UDE_ERR_INVALID, "op 10 (mfma probe): n must be a multiple of 64");
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3((unsigned)(n / 64)), dim3(64), 0, c->stream, (const double*)dx,
+                           (const double*)dy, (double*)c->s_out.p);
+    } else
     hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)op, (const double*)dx,
                        (const double*)dy, (double*)c->s_out.p, n);
     HIPCHK(c, hipGetLastError());
