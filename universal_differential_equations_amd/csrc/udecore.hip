@@ -463,6 +463,9 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     void (*bwd)(const KParams) = discrete ? l.dadj : l.adj;
     const size_t shmem_f = l.lds_bytes(np, false);
     const size_t shmem_a = l.lds_bytes(np, true, discrete);
+    if (shmem_a > 160 * 1024 || shmem_f > 160 * 1024)
+        return fail(c, UDE_ERR_UNSUPPORTED, "kernel instance needs %zu / %zu bytes of LDS (forward / backward), more than the 160 KiB of a CU: "
+                                            "this (model, lanes_per_traj, sensealg) combination is not available", shmem_f, shmem_a);
     if (shmem_a > 64 * 1024)  // more than the default dynamic-LDS limit: opt in (MI355X has 160 KiB per CU)
         HIPCHK(c, hipFuncSetAttribute((const void*)bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
     if (shmem_f > 64 * 1024)
