@@ -109,7 +109,7 @@ def pmc_traffic(a):
     """HBM bytes per adj_kernel launch of the default C2 command, as collected by `rocprofv3 --pmc FETCH_SIZE` /
     `--pmc WRITE_SIZE` (tools/prof_pass.sh; counters in KB) and committed under profiles/ -- PMC passes cannot run
     inside the timed bench itself.  None when the run is not that command or the summary is absent."""
-    if a.workload != "lv" or a.alg != "tsit5" or a.sensealg != "adjoint" or a.lanes or a.waves or a.traj:
+    if a.workload != "lv" or a.net != "s1" or a.alg != "tsit5" or a.sensealg != "adjoint" or a.lanes or a.waves or a.traj:
         return None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v4_pmc.md")
     try:
@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--alg", default="tsit5")
     ap.add_argument("--sensealg", default="adjoint", choices=["adjoint", "discrete"],
                     help="adjoint = InterpolatingAdjoint (the north-star path); discrete = frozen-step reverse sweep (a9)")
+    ap.add_argument("--net", default="s1", choices=["s1", "tanh32"],
+                    help="lv workload: s1 = the reference 2-5-5-5-2 rbf chain (headline), tanh32 = BASELINE's '2-layer tanh' 2-32-2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -165,11 +167,16 @@ def main():
     if a.workload == "lv":
         theta_h, u0_d, t, data = synth_inputs(N, rank, device)
         alg = U.Tsit5() if a.alg == "tsit5" else U.Vern7()
-        ens = U.DeviceEnsemble(models.ude_dynamics(), alg, (0.0, 3.0), t, u0_d, data=data, lanes_per_traj=a.lanes,
+        f_lv = models.ude_dynamics()
+        if a.net == "tanh32":
+            f_lv = models.ude_dynamics(models.tanh32_chain())
+            theta_h = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(7))
+        ens = U.DeviceEnsemble(f_lv, alg, (0.0, 3.0), t, u0_d, data=data, lanes_per_traj=a.lanes,
                                waves_per_simd=a.waves, abstol=1e-6, reltol=1e-6,
                                sensealg=U.ForwardDiffSensitivity() if a.sensealg == "discrete" else None)
-        wl_name = ("BASELINE configs[1]: LV UDE (2-5-5-5-2 rbf, 87 params, theta_init of scenario_1), %d trajectories per GPU, "
-                   "%s abstol=reltol=1e-6, 31 save points, loss + InterpolatingAdjoint gradient" % (N, a.alg))
+        wl_name = ("BASELINE configs[1]: LV UDE (%s), %d trajectories per GPU, "
+                   "%s abstol=reltol=1e-6, 31 save points, loss + InterpolatingAdjoint gradient"
+                   % ("2-5-5-5-2 rbf, 87 params, theta_init of scenario_1" if a.net == "s1" else "2-32-2 tanh, 162 params, 0.1 x glorot", N, a.alg))
     else:
         w = synth_inputs_other(a.workload, N, rank, device)
         theta_h, u0_d, t, data, mask = w["theta"], w["u0"], w["t"], w["data"], w["mask"]

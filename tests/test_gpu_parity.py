@@ -521,3 +521,20 @@ def test_mfma_f64_is_the_ascending_fused_chain():
             for k in range(4):
                 d = fma(A(i, k), B(k, j), d)
             assert d == out[b, lane], (b, lane)
+
+
+def test_tanh32_wide_lane_group_variant():
+    """BASELINE's '2-layer tanh' (2-32-2): the default is 8 lanes per trajectory; the 32-lane build (one neuron per lane)
+    must return the same bits."""
+    rng = np.random.default_rng(3)
+    N = 24
+    t = np.arange(31) * 0.1
+    u0 = np.array([0.44249296, 4.6280594]) * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))
+    th = theta_tanh32 = models.tanh32_chain().glorot_uniform(rng) * 0.5
+    data, _, rc = O.solve_ensemble(O.lv_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 3.0], [1.3, 0.9, 0.8, 1.8], t)
+    ens = U.EnsembleProblem(U.ODEProblem(models.ude_dynamics(models.tanh32_chain()), u0[0], (0.0, 3.0), th), u0)
+    ref = O.loss_grad_ensemble(O.lv_ude_tanh32(), O.opts(O.TSIT5, 1e-6, 1e-6), u0, [0.0, 3.0], th, t, data, nthreads=4)
+    for lanes in (0, 32):
+        r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, abstol=1e-6, reltol=1e-6,
+                                **({"ensemblealg": U.EnsembleMI355(lanes)} if lanes else {}))
+        check_per_trajectory(r, ref)

@@ -183,7 +183,7 @@ static int default_lanes(int mid, bool discrete) {
         case MID_LV_TRUE: return 1;
         case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
         case MID_LV_HUDSON: return 8;
-        case MID_LV_TANH32: return 32;
+        case MID_LV_TANH32: return 8;  // (32 lanes = 5000 wavefronts = five rounds for 10k trajectories: 16.5 ms vs 7.6 ms per gradient)
         case MID_SEIR_TRUE: return 1;
         case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
         case MID_KPP_TRUE_32:
