@@ -111,22 +111,32 @@ double udeo_exp(double x) {
 }
 
 double udeo_tanh(double x) {
+    /* ARITH-SPEC tanh, one path: z = 2|x| = k ln2 + r; q = expm1(r) (udeo_exp's polynomial without its final + 1);
+     * em = expm1(z) = 2^k q + (2^k - 1); tanh = em / (em + 2); |x| >= 20 rounds to 1 */
     if (x != x) return x;
     const double ax = fabs(x);
-    double t;
-    if (ax < 0.3) {
-        /* expm1(2|x|) by its Taylor series in Horner form, then tanh = em/(em+2) */
-        const double z = ax + ax;
-        double p = 1.0;
-        for (int n = 18; n >= 2; --n) p = fma(z * (1.0 / (double)n), p, 1.0);
-        const double em = z * p;
-        t = em / (em + 2.0);
-    } else if (ax < 20.0) {
-        const double e = udeo_exp(ax + ax);
-        t = 1.0 - 2.0 / (e + 1.0);
-    } else {
-        t = 1.0;
-    }
+    const double z = ax < 20.0 ? ax + ax : 40.0;
+    const double k = rint(z * 1.4426950408889634);
+    double r = fma(-k, 0.6931471803691238, z);
+    r = fma(-k, 1.9082149292705877e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    const double q = p * r;
+    const double s = ldexp(1.0, (int)k);
+    const double em = fma(s, q, s - 1.0);
+    double t = em / (em + 2.0);
+    t = ax < 20.0 ? t : 1.0;
     return x < 0 ? -t : t;
 }
 

@@ -99,22 +99,34 @@ __device__ __forceinline__ double dexp(double x) {
 }
 
 __device__ __forceinline__ double dtanh(double x) {
+    // ARITH-SPEC tanh: ONE branch-free path (lanes of a wavefront never diverge over the argument's size):
+    //   z = 2|x| = k ln2 + r;  q = expm1(r) (dexp's Taylor polynomial without its final + 1);
+    //   em = expm1(z) = 2^k q + (2^k - 1) (one fma, 2^k - 1 exact);  tanh = em / (em + 2)
+    // accurate for small |x| (k = 0: em = q) and large alike; |x| >= 20 rounds to 1
     if (x != x) return x;
     const double ax = fabs(x);
-    double t;
-    if (ax < 0.3) {
-        const double z = ax + ax;
-        double p = 1.0;
-#pragma unroll
-        for (int n = 18; n >= 2; --n) p = __builtin_fma(z * (1.0 / (double)n), p, 1.0);
-        const double em = z * p;
-        t = em / (em + 2.0);
-    } else if (ax < 20.0) {
-        const double e = dexp(ax + ax);
-        t = 1.0 - 2.0 / (e + 1.0);
-    } else {
-        t = 1.0;
-    }
+    const double z = ax < 20.0 ? ax + ax : 40.0;
+    const double k = __builtin_rint(z * 1.4426950408889634);
+    double r = __builtin_fma(-k, 0.6931471803691238, z);
+    r = __builtin_fma(-k, 1.9082149292705877e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    const double q = p * r;
+    const double s = __builtin_ldexp(1.0, (int)k);
+    const double em = __builtin_fma(s, q, s - 1.0);
+    double t = em / (em + 2.0);
+    t = ax < 20.0 ? t : 1.0;
     return x < 0 ? -t : t;
 }
 
