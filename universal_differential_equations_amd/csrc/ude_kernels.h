@@ -144,8 +144,7 @@ struct Driver {
     static constexpr int NR = Sys::NR, NSL = Sys::NSL, NSLA = NSL > 0 ? NSL : 1;
     static constexpr int S = Tab::S, NK = Tab::NK;
     static constexpr bool USE_FSAL = Tab::FSAL && !Sys::ALWAYS_K0;
-    static constexpr bool LDS_SLOTS = Sys::SLOTS_IN_LDS;  // slot state + accumulators are theta-indexed LDS arrays
-    static constexpr bool SLOT_FSAL = USE_FSAL && NSL > 0 && !LDS_SLOTS;  // stage-0 slot derivative handed over in LDS
+    static constexpr bool SLOT_FSAL = USE_FSAL && NSL > 0;  // stage-0 slot derivative handed over in LDS
     // deferred slots: the system keeps per-stage factors and forms the slot sums / error norm / candidate at step end
     static constexpr bool DEFER = Sys::DEFERRED;
     static_assert(!DEFER || (NSL == 0 && !USE_FSAL), "deferred slots: the system owns the slot state");
@@ -193,7 +192,6 @@ struct Driver {
         } else {
             double f0[NR], gs0[NSLA], f1[NR], gs1[NSLA], z1[NR];
             if constexpr (DEFER) sys.eval_store(t, z, f0, 0);
-            else if constexpr (LDS_SLOTS) sys.eval_acc(t, z, f0, 1.0, 0.0, true);  // ab = g0, ae = 0
             else sys.eval(t, z, f0, gs0);
             if constexpr (CPL) K1(0) = own_of(f0);
             else static_for<0, NR>([&](auto c) { K(0, c) = f0[c]; });
@@ -201,17 +199,6 @@ struct Driver {
             double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
             if constexpr (DEFER) {
                 sys.slot_init01(o, h0, l0, h1, l1);
-                group_dd_sum<G>(h0, l0);
-                group_dd_sum<G>(h1, l1);
-            } else if constexpr (LDS_SLOTS) {
-                sys.lds_sync();
-                for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) {
-                    const double m = sys.mu[i];
-                    const double sk = __builtin_fma(fabs(m), o.reltol, o.abstol);
-                    const double q0 = m / sk, q1 = sys.ab[i] / sk;
-                    dd_acc(h0, l0, q0 * q0);
-                    dd_acc(h1, l1, q1 * q1);
-                }
                 group_dd_sum<G>(h0, l0);
                 group_dd_sum<G>(h1, l1);
             } else if constexpr (NSL > 0) {
@@ -263,21 +250,11 @@ struct Driver {
                 static_for<0, NR>([&](auto c) { z1[c] = __builtin_fma(dt0t, f0[c], z[c]); });
                 // (the slot part of u1 does not enter f: mu' is independent of mu)
                 if constexpr (DEFER) sys.eval_store(t + dt0t, z1, f1, 1);
-                else if constexpr (LDS_SLOTS) sys.eval_acc(t + dt0t, z1, f1, 0.0, 1.0, false);  // ae = g1, ab untouched
                 else sys.eval(t + dt0t, z1, f1, gs1);
                 double h2 = 0.0, l2 = 0.0;
                 if constexpr (DEFER) {
                     sys.slot_init2(o, h2, l2);
                     group_dd_sum<G>(h2, l2);
-                } else if constexpr (LDS_SLOTS) {
-                    sys.lds_sync();
-                    for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) {
-                        const double sk = __builtin_fma(fabs(sys.mu[i]), o.reltol, o.abstol);
-                        const double q = (sys.ae[i] - sys.ab[i]) / sk;
-                        dd_acc(h2, l2, q * q);
-                    }
-                    group_dd_sum<G>(h2, l2);
-                    sys.lds_sync();
                 } else if constexpr (NSL > 0) {
                     static_for<0, NSL>([&](auto c) {
                         const double sk = __builtin_fma(fabs(mu[c * BLOCK]), o.reltol, o.abstol);
@@ -371,11 +348,10 @@ struct Driver {
                 }
                 if (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
                 if constexpr (DEFER) sys.eval_store(t + tab->C[s] * dt, zs, kr, s);
-                else if constexpr (LDS_SLOTS) sys.eval_acc(t + tab->C[s] * dt, zs, kr, tab->B[s], tab->BT[s], s == 0);
                 else sys.eval(t + tab->C[s] * dt, zs, kr, gs);
                 if constexpr (CPL) K1(s) = own_of(kr);
                 else static_for<0, NR>([&](auto c) { K(s, c) = kr[c]; });
-                if constexpr (NSL > 0 && !LDS_SLOTS) {
+                if constexpr (NSL > 0) {
                     const double bs = tab->B[s], es = tab->BT[s];
                     if (s == 0) {
                         static_for<0, NSL>([&](auto c) {
@@ -427,19 +403,7 @@ struct Driver {
             });
             if constexpr (Sys::STATE_DISTRIBUTED) ss = group_sum<G>(ss);
             if constexpr (DEFER) ss += group_sum<G>(sys.slot_step(dt, tab, o));
-            if constexpr (LDS_SLOTS) {
-                sys.lds_sync();
-                double ps = 0.0;
-                for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) {
-                    const double m0 = sys.mu[i];
-                    const double m1 = __builtin_fma(dt, sys.ab[i], m0);
-                    sys.ab[i] = m1;  // candidate new value
-                    const double a0 = fabs(m0), a1 = fabs(m1);
-                    const double res = (dt * sys.ae[i]) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
-                    ps = __builtin_fma(res, res, ps);
-                }
-                ss += group_sum<G>(ps);
-            } else if constexpr (NSL > 0) {
+            if constexpr (NSL > 0) {
                 double ps = 0.0;
                 static_for<0, NSL>([&](auto c) {
                     const double m0 = mu[c * MS];
@@ -519,12 +483,7 @@ struct Driver {
                 if constexpr (Sys::STATE_DISTRIBUTED) {  // same decision on every lane of the trajectory
                     if constexpr (G > 64) bad = __syncthreads_or(bad); else bad = __any(bad);
                 }
-                if constexpr (LDS_SLOTS) {
-                    for (int i = sys.slot_begin(); i < sys.slot_end(); i += G) sys.mu[i] = sys.ab[i];
-                    sys.lds_sync();
-                } else {
-                    static_for<0, NSL>([&](auto c) { mu[c * MS] = accb[c]; });
-                }
+                static_for<0, NSL>([&](auto c) { mu[c * MS] = accb[c]; });
                 if constexpr (DEFER) sys.slot_accept();
                 if constexpr (USE_FSAL && CPL) K1(0) = K1(S - 1);
                 else if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
@@ -561,7 +520,7 @@ struct Driver {
 template <class Model, class Tab, int G, int BLOCKDIM>
 struct FwdSys {
     static constexpr int NR = Model::NS, NSL = 0;
-    static constexpr bool ALWAYS_K0 = false, SLOTS_IN_LDS = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
+    static constexpr bool ALWAYS_K0 = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     static constexpr bool SLOTS_GLOBAL = false, CPL = Model::CPL, DEFERRED = false;
     typename Model::Ctx mctx;
     const KParams* p;
@@ -590,13 +549,6 @@ struct FwdSys {
             row[0] = t; row[1] = dt; row[2] = e; row[3] = q; row[4] = acc ? 1.0 : 0.0;
         }
     }
-    __device__ __forceinline__ void fsal_slots(double*) {}
-    __device__ __forceinline__ void store_fsal_slots(const double*) {}
-    double *mu = nullptr, *ab = nullptr, *ae = nullptr;  // (LDS slot mode is adjoint-only)
-    __device__ __forceinline__ int slot_begin() const { return 0; }
-    __device__ __forceinline__ int slot_end() const { return 0; }
-    __device__ __forceinline__ void lds_sync() const {}
-    __device__ __forceinline__ void eval_acc(double, const double*, double*, double, double, bool) {}
 
     __device__ __forceinline__ void save_point(int i, const double* v) {
         if (p->u_out) {
@@ -684,7 +636,7 @@ struct Layout {
     static_assert(!CPL || Model::NS < KCP, "component-per-lane: state must fit the KCP columns");
     static constexpr int K_DOUBLES = CPL ? (BLOCK / 64) * Tab::NK * KCP : Tab::NK * Model::NS * KSTRIDE;
     // group-shared forward-interval cache of the adjoint kernel (see AdjSys::IC_LDS)
-    static constexpr bool IC_LDS = (G >= 5) && !Model::STATE_DISTRIBUTED && !Model::SLOTS_IN_LDS && !Model::CPL;
+    static constexpr bool IC_LDS = (G >= 5) && !Model::STATE_DISTRIBUTED && !Model::CPL;
     static constexpr int IC_DOUBLES = IC_LDS ? (Model::NS + Tab::NK * Model::NS) * (BLOCK / G) : 0;
     static __host__ __device__ constexpr int np_pad(int np) { return (np + 1) & ~1; }
 };
@@ -749,11 +701,11 @@ template <class Model, class Tab, int G>
 struct AdjSys {
     static constexpr bool DEFERRED = Model::DEFERRED;
     static constexpr int NR = Model::NS, NSL = DEFERRED ? 0 : Model::NSL;
-    static constexpr bool SLOTS_IN_LDS = Model::SLOTS_IN_LDS, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
+    static constexpr bool STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     // LDS-slot models re-evaluate stage 0 every step (its parameter cotangent is folded straight into the shared
     // accumulators); register-slot models hand k_S -> k_0 AND its slot derivative over (FSAL, as upstream)
     static constexpr bool SLOTS_GLOBAL = Model::SLOTS_GLOBAL, CPL = Model::CPL;
-    static constexpr bool ALWAYS_K0 = SLOTS_IN_LDS || DEFERRED;
+    static constexpr bool ALWAYS_K0 = DEFERRED;
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;
@@ -767,7 +719,7 @@ struct AdjSys {
     // cached forward interval: t_start/t_end in registers; u_start and the k's either in registers (IC_LDS = false)
     // or in a group-shared LDS row (IC_LDS: saves 2*NR*(NK+1) VGPRs per lane; reads are broadcasts inside the group)
     // CPL: lane c caches component c only (u_start and the k's of the interval: 1 + NK registers)
-    static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !SLOTS_IN_LDS && !CPL;
+    static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !CPL;
     static constexpr int IC_FIELDS = NR + Tab::NK * NR;
     static constexpr int IC_NR = (IC_LDS || CPL) ? 1 : NR;
     double ts, te, us[IC_NR], ks[IC_LDS ? 1 : Tab::NK][IC_NR];
@@ -870,7 +822,7 @@ struct AdjSys {
         double* t = mu_cur; mu_cur = mu_new; mu_new = t;
     }
     __device__ __forceinline__ void eval(double t, const double* lam, double* klam, double* g) {
-      if constexpr (!SLOTS_IN_LDS && !DEFERRED) {
+      if constexpr (!DEFERRED) {
         asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
         locate(t);
         const double dtf = te - ts;
@@ -886,30 +838,6 @@ struct AdjSys {
         static_for<0, NSL>([&](auto c) { g[c] = -g[c]; });
       }
     }
-    // ---- LDS slot mode (theta-indexed mu / accumulators shared by the group) ----
-    double *mu, *ab, *ae;
-    int np_, r_;
-    __device__ __forceinline__ int slot_begin() const { return r_; }
-    __device__ __forceinline__ int slot_end() const { return np_; }
-    __device__ __forceinline__ void lds_sync() const { __syncthreads(); }
-    __device__ __forceinline__ void eval_acc(double t, const double* lam, double* klam, double bs, double es, bool first) {
-        if constexpr (SLOTS_IN_LDS) {
-            asm volatile("" ::: "memory");
-            locate(t);
-            const double dtf = te - ts;
-            const double th = (t - ts) / dtf;
-            double b[Tab::NK], y[NR], dl[NR];
-            Tab::bth(th, b);
-            static_for<0, NR>([&](auto c) {
-                const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
-                y[c] = __builtin_fma(dtf, acc, US(c));
-            });
-            Model::vjp_acc(mctx, y, lam, dl, bs, es, first);
-            static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
-        }
-    }
-    __device__ __forceinline__ void fsal_slots(double*) {}
-    __device__ __forceinline__ void store_fsal_slots(const double*) {}
     __device__ __forceinline__ void trace(int iter, double t, double dt, double e, double q, bool acc) const {
         if (p->trace && mctx.r == 0 && j == p->trace_traj && iter <= p->trace_cap) {
             double* row = p->trace + ((size_t)p->trace_cap + (iter - 1)) * 5;
@@ -960,9 +888,6 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     const int np_pad = L::np_pad(p.n_param);
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     for (int i = threadIdx.x; i < L::K_DOUBLES; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
-    if constexpr (Model::SLOTS_IN_LDS) {
-        for (int i = threadIdx.x; i < 3 * np_pad; i += BLOCK) slots[i] = 0.0;
-    }
     __syncthreads();
 
     constexpr int GROUPS = BLOCK / G;
@@ -992,8 +917,6 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     if (ok) {
         Sys sys;
         Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
-        sys.mu = slots; sys.ab = slots + np_pad; sys.ae = slots + 2 * np_pad;
-        sys.np_ = p.n_param; sys.r_ = r;
         sys.p = &p;
         sys.j = gid;
         sys.n = p.n_state;
@@ -1032,20 +955,9 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
             });
         if (ret != RET_SUCCESS) {  // never poison the batch gradient
             static_for<0, NSLOT>([&](auto c) { mu_final[(size_t)c * MS] = 0.0; });
-            if constexpr (Model::SLOTS_IN_LDS) {
-                __syncthreads();
-                for (int i = r; i < p.n_param; i += G) slots[i] = 0.0;
-            }
         }
     }
-    if constexpr (Model::SLOTS_IN_LDS) {
-        // one trajectory per block (G == BLOCK): mu is already the theta-indexed row of this wave
-        __syncthreads();
-        const int64_t wave = part_row<G, BLOCK>();
-        double* row = p.grad_part + (size_t)wave * p.n_param;
-        for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = slots[i];
-    }
-    if constexpr (!Model::SLOTS_IN_LDS && !pow2_group<G>()) {
+    if constexpr (!pow2_group<G>()) {
         // mu already sits in LDS ([slot][thread]): lane r of group 0 adds the r-th lanes of all groups in ascending
         // group order and writes the wave's partial row (runtime loops: this tail must not inflate the register peak)
         __syncthreads();
@@ -1072,7 +984,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
             if (idx >= 0) row[idx] = mu_final[(size_t)c * MS];
         });
     }
-    if constexpr (!SG && !Model::SLOTS_IN_LDS && pow2_group<G>()) {
+    if constexpr (!SG && pow2_group<G>()) {
     double mu[NSLA];
     static_for<0, NSL>([&](auto c) { mu[c] = mu_lds[c * BLOCK]; });
     // ---- deterministic reduction: groups of a wave (xor butterfly), then one partial row per wave ----
@@ -1120,9 +1032,6 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     double* slots = kbbase + L::K_DOUBLES;
     const int np_pad = L::np_pad(p.n_param);
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
-    if constexpr (Model::SLOTS_IN_LDS) {
-        for (int i = threadIdx.x; i < 3 * np_pad; i += BLOCK) slots[i] = 0.0;
-    }
     constexpr bool SG = Model::SLOTS_GLOBAL;
     double* acc_lds = slots + threadIdx.x;  // register-slot models: accumulator row, element c at acc_lds[c*BLOCK]
     if constexpr (!SG) static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = 0.0; });
@@ -1167,9 +1076,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         // one VJP at stage input g with stage cotangent kbrow: w = (df/du)^T kbrow; parameter part into acc
         auto stage_vjp = [&](const double* g, const double* kbrow, double* w) {
             asm volatile("" ::: "memory");
-            if constexpr (Model::SLOTS_IN_LDS) {
-                Model::vjp_acc(mctx, g, kbrow, w, 1.0, 0.0, false);  // ab -= (df/dtheta)^T kbar (sign undone at the end)
-            } else if constexpr (Model::FUSED_ACC) {
+            if constexpr (Model::FUSED_ACC) {
                 Model::template vjp_acc<false>(mctx, g, kbrow, w, acc, acc, -1.0, 0.0);  // acc += (df/dtheta)^T kbar
             } else {
                 double gs[NSLA];
@@ -1262,9 +1169,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     __syncthreads();
     const int64_t wave = part_row<G, BLOCK>();
     double* row = p.grad_part + (size_t)wave * p.n_param;
-    if constexpr (Model::SLOTS_IN_LDS) {
-        for (int i = threadIdx.x; i < p.n_param; i += BLOCK) row[i] = -slots[np_pad + i];  // ab holds the negated sum
-    } else if constexpr (!SG) {
+    if constexpr (!SG) {
         if ((int)threadIdx.x < G) {
             for (int s = 0; s < NSL; ++s) {
                 const int idx = Model::slot_index(p.mc, (int)threadIdx.x, s);

@@ -39,7 +39,7 @@ struct LinearTheta {
 template <int G>
 struct LvTrue : LinearTheta {
     static constexpr int NS = 2, NSL = 4, NTHETA_LDS = 4;
-    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = false;
+    static constexpr bool STATE_DISTRIBUTED = false;
     struct Ctx {
         const double* th;
         int r;
@@ -80,7 +80,7 @@ struct LvUde : LinearTheta {
     static_assert(Net::dim(0) == 2 && Net::dim(Net::L) == 2, "LV UDE network maps R^2 -> R^2");
     static constexpr int NS = 2;
     static constexpr int NSL = Mlp::NSLOT + 2;  // + the two (optional) trainable diagonal coefficients
-    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = false;
+    static constexpr bool STATE_DISTRIBUTED = false;
     // weights in registers when the lane's share is small (narrow layers spread over >= 5 lanes), else read from LDS
     static constexpr bool REGW = (G >= 5) && (Net::maxdim() <= 8);
     struct Ctx {
@@ -150,7 +150,7 @@ struct LvUde : LinearTheta {
 template <int G>
 struct SeirTrue : LinearTheta {
     static constexpr int NS = 7, NSL = 0;
-    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = false;
+    static constexpr bool STATE_DISTRIBUTED = false;
     struct Ctx {
         double F, b0, al, ka, mu, sg, ga, d, la;
         int r;
@@ -196,7 +196,7 @@ struct SeirUde {
     static constexpr int NS = 7;
     static constexpr int NEXTRA = 7, XS = (NEXTRA + NW - 1) / NW;  // W1[:,0..2], b1, b2, W3, b3
     static constexpr int NSL = KB + XS;
-    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = false;
+    static constexpr bool STATE_DISTRIBUTED = false;
     // one wavefront per trajectory (G = 64): W2 is read from a padded LDS copy shared by the block's trajectories,
     // the 71 parameter-cotangent accumulators per lane stay in registers (fused accumulation: no g[] array) and mu
     // itself (touched once per step) lives in HBM.  G = 128/256: W2 slices in registers, theta read from HBM once.
@@ -539,7 +539,7 @@ template <int G, int PPL>
 struct KppTrue : LinearTheta {
     static __host__ __device__ constexpr int point(int c, int r) { return c * G + r; }  // grid point of (register slot, lane)
     static constexpr int NS = PPL, NSL = 0;
-    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = true;
+    static constexpr bool STATE_DISTRIBUTED = true;
     static constexpr int SCRATCH = G * PPL + 2;
     struct Ctx {
         double* row;
@@ -594,7 +594,7 @@ struct KppUde : LinearTheta {
     static constexpr int NS = PPL;
     static constexpr int NP = Net::nparam + 5;
     static constexpr int NSL = (NP + G - 1) / G;
-    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = true;
+    static constexpr bool STATE_DISTRIBUTED = true;
     static constexpr int L = Net::L;
     static constexpr int rows_a() { int s = 0; for (int l = 0; l < L; ++l) s += Net::dim(l); return s; }
     static constexpr int rows_d() { int s = 0; for (int l = 0; l < L; ++l) s += Net::dim(l + 1); return s; }
@@ -783,7 +783,7 @@ struct KppUdeW : LinearTheta {
     static constexpr int NS = PPL;
     static constexpr int NP = Net::nparam + 5;
     static constexpr int NSL = (NP + G - 1) / G;
-    static constexpr bool SLOTS_IN_LDS = false, STATE_DISTRIBUTED = true;
+    static constexpr bool STATE_DISTRIBUTED = true;
     static constexpr int L = Net::L;
     static constexpr int NPT = G * PPL;
     static constexpr bool acts_ok() {  // the reverse sweep rebuilds act' from the activation VALUE (tanh only)

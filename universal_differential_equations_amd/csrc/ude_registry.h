@@ -10,15 +10,14 @@ struct Launch {
     void (*dadj)(const KParams);  // discretise-then-optimise reverse sweep (a9)
     int nf;  // dense fields per step
     int G, block;
-    // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ slots: NSL*BLOCK registers-mode mu, or 3*np_pad]
+    // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
     int theta_lds, scratch, k_doubles, k_doubles_d, slots_reg;
-    bool slots_lds;
     int slot_glob;  // > 0: slot state in HBM, this many doubles per thread (SLOTS_GLOBAL models)
     size_t lds_bytes(int np, bool adjoint, bool discrete = false) const {
         const size_t np_pad = (size_t)((np + 1) & ~1);
         size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + scratch + k_doubles;
         if (discrete) d += 2 * (size_t)k_doubles_d - k_doubles;  // k and kbar in the reverse sweep's own layout
-        if (adjoint) d += slots_lds ? 3 * np_pad : (size_t)slots_reg;
+        if (adjoint) d += (size_t)slots_reg;
         return d * sizeof(double) + 16;
     }
 };
@@ -38,7 +37,6 @@ inline Launch make_launch() {
     l.k_doubles_d = Layout<Model, Tab, G, BLOCK, false>::K_DOUBLES;
     l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : (Tab::FSAL ? 3 : 2) * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
     l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL : 0;
-    l.slots_lds = Model::SLOTS_IN_LDS;
     return l;
 }
 
