@@ -148,6 +148,12 @@ int ude_loss_grad_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_
                                double* loss, double* loss_per_traj, double* grad_theta, double* grad_u0,
                                double* u_out, int64_t* stats, int32_t* retcode);
 
+/* replaces: one evaluation of the right-hand side closure, `f(u, p, t)` / `ude_dynamics!(du, u, p, t)` for a batch of states --
+ * what the scripts do with the trained UDE on the saved states before SINDy (`U(X_hat, p_trained, st)`,
+ * scenario_1.jl:152-160, applied to the whole right-hand side here).  u, du: n x N (one state per column). */
+int ude_rhs_ensemble(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const double* u_host, const double* theta_host, double* du_host);
+int ude_rhs_ensemble_dev(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const double* u, const double* theta, double* du);
+
 /* device time (ms) of the forward and backward kernels of the most recent call on this context,
  * measured with HIP events on the context's stream (valid after the stream has been synchronised) */
 int ude_last_kernel_ms(ude_ctx* ctx, float* fwd_ms, float* bwd_ms);

@@ -133,3 +133,22 @@ def test_multiple_shoot_on_device_matches_oracle_backend(golden):
     assert np.linalg.norm(g1 - g2) <= 1e-11 * np.linalg.norm(g2)
     for a, b in zip(p1, p2):
         assert (a == b).all()
+
+
+def test_rhs_ensemble_matches_oracle(golden):
+    """One right-hand-side evaluation per state (`U.rhs`): LV UDE, SEIR UDE, Fisher-KPP UDE (26 and 1024 points: VALU and
+    matrix-core forward passes) against the oracle's udeo_rhs_f64, bit for bit."""
+    rng = np.random.default_rng(9)
+    g = golden("Scenario_1_recovery_0.005")
+    th = np.array(g["trained_parameters"])
+    u = np.abs(rng.normal(size=(70, 2))) + 0.1
+    orhs = lambda m, th_, uu: np.stack([O.rhs(m, th_, row) for row in uu])
+    assert (U.rhs(models.ude_dynamics(), u, th) == orhs(O.lv_ude_s1(), th, u)).all()
+    ths = models.seir_chain().glorot_uniform(rng)
+    us = np.abs(rng.normal(size=(9, 7))) * 1e5 + 1.0
+    us[:, 4] = 14e6
+    assert (U.rhs(models.dudt_(), us, ths) == orhs(O.seir_ude(), ths, us)).all()
+    for nx in (26, 1024):
+        thk = models.kpp_theta(models.kpp_chain(), rng)
+        uk = rng.uniform(0, 1, size=(3, nx))
+        assert (U.rhs(models.nn_ode(nx), uk, thk) == orhs(O.kpp_ude(nx), thk, uk)).all()

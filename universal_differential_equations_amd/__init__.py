@@ -6,4 +6,4 @@ from ._lib import UdeError  # noqa: F401
 from .sciml import (DeviceEnsemble, Engine, EnsembleMI355, EnsembleProblem, ForwardDiffSensitivity,  # noqa: F401
                     InterpolatingAdjoint,
                     ODEProblem, ReverseDiffVJP, Tsit5, Vern7, adjoint_pullback, concrete_solve,
-                    loss_and_gradient, remake, solve)
+                    loss_and_gradient, remake, rhs, solve)

@@ -693,6 +693,31 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One evaluation of the right-hand side for a batch of states (the trained UDE on saved states: what the SINDy stage
+// of the scripts consumes, scenario_1.jl:152-160): du = f(u, theta), same lane-group layout as the solver kernels.
+// ---------------------------------------------------------------------------------------------
+template <class Model, class Tab, int G, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) rhs_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* th = reinterpret_cast<double*>(smem_raw);
+    double* scratch = th + Model::theta_lds(p.n_param);
+    Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
+    __syncthreads();
+    constexpr int GROUPS = BLOCK / G;
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
+    const int r = threadIdx.x % G;
+    if (gid >= p.N || (int)threadIdx.x >= GROUPS * G) return;  // whole groups leave together
+    using Sys = FwdSys<Model, Tab, G, BLOCK>;
+    Sys sys;
+    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, nullptr, 0, p.mc, r, p.theta);
+    sys.p = &p; sys.j = gid; sys.writer = (r == 0); sys.r = r; sys.n = p.n_state;
+    double z[Sys::NR], kr[Sys::NR];
+    static_for<0, Sys::NR>([&](auto c) { z[c] = sys.cvalid(c) ? p.u0[(size_t)gid * p.n_state + sys.comp(c)] : 0.0; });
+    Model::rhs(sys.mctx, z, kr);
+    static_for<0, Sys::NR>([&](auto c) { if (sys.cwrite(c)) p.u_out[(size_t)gid * p.n_state + sys.comp(c)] = kr[c]; });
+}
+
+// ---------------------------------------------------------------------------------------------
 // adjoint system (InterpolatingAdjoint): z = lambda (replicated), slots = mu
 //   lambda' = -(df/du)^T lambda, mu' = -(df/dtheta)^T lambda at y(t) = forward dense interpolant;
 //   save times are tstops with lambda += dL/du(t_i)            

@@ -8,6 +8,7 @@ struct Launch {
     void (*fwd)(const KParams);
     void (*adj)(const KParams);
     void (*dadj)(const KParams);  // discretise-then-optimise reverse sweep (a9)
+    void (*rhs)(const KParams);   // one right-hand-side evaluation per state
     int nf;  // dense fields per step
     int G, block;
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
@@ -28,6 +29,7 @@ inline Launch make_launch() {
     l.fwd = fwd_kernel<Model, Tab, G, BLOCK>;
     l.adj = adj_kernel<Model, Tab, G, BLOCK>;
     l.dadj = dadj_kernel<Model, Tab, G, BLOCK>;
+    l.rhs = rhs_kernel<Model, Tab, G, BLOCK>;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;

@@ -497,6 +497,36 @@ extern "C" int ude_solve_ensemble_dev(ude_ctx* c, const ude_model_desc* m, const
     return solve_dev_impl(c, m, o, N, u0, tspan, theta, saveat, ns, u_out, stats, retcode);
 }
 
+// du = f(u, theta) for N states (device buffers; u and du are n x N, one state per column)
+extern "C" int ude_rhs_ensemble_dev(ude_ctx* c, const ude_model_desc* m, int64_t N, const double* u, const double* theta, double* du) {
+    if (!c) return UDE_ERR_INVALID;
+    if (!m || !u || !du || N <= 0) return fail(c, UDE_ERR_INVALID, "null / empty argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    ude_solve_opts o{};
+    o.alg = UDE_ALG_TSIT5;
+    Launch l;
+    int G = 0, rc;
+    if ((rc = resolve(c, m, &o, l, G))) return rc;
+    KParams p{};
+    const double tspan0 = 0.0;
+    fill_params(p, m, &o, tspan0, 1.0);
+    p.tab = (const TabDev*)c->tabs.p;
+    p.N = N;
+    p.Npad = (N + 7) / 8 * 8;
+    p.u0 = u;
+    p.theta = theta;
+    p.u_out = du;
+    const int BLOCK = l.block;
+    const int64_t gpb = BLOCK / G;
+    const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
+    const size_t shmem = l.lds_bytes(m->n_param, false);
+    if (shmem > 160 * 1024) return fail(c, UDE_ERR_UNSUPPORTED, "kernel instance needs %zu bytes of LDS", shmem);
+    if (shmem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)l.rhs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(l.rhs, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
+    HIPCHK(c, hipGetLastError());
+    return UDE_OK;
+}
+
 extern "C" int ude_vjp_ensemble_dev(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
                                     const double* u0, const double* tspan, const double* theta, const double* saveat,
                                     int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
@@ -626,6 +656,22 @@ extern "C" int ude_loss_grad_ensemble(ude_ctx* c, const ude_model_desc* m, const
     if (c && !data) return fail(c, UDE_ERR_INVALID, "data is null");
     return grad_host(c, m, o, N, u0, tspan, theta, saveat, ns, nullptr, data, row_mask, loss, loss_per_traj, u_out,
                      grad_theta, grad_u0, stats, retcode);
+}
+
+extern "C" int ude_rhs_ensemble(ude_ctx* c, const ude_model_desc* m, int64_t N, const double* u, const double* theta, double* du) {
+    if (!c) return UDE_ERR_INVALID;
+    if (!m || !u || !du || N <= 0) return fail(c, UDE_ERR_INVALID, "null / empty argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    void *du0, *dth;
+    const size_t bytes = sizeof(double) * (size_t)N * m->n_state;
+    if ((rc = up(c, c->s_u0, u, bytes, &du0))) return rc;
+    if ((rc = up(c, c->s_theta, theta, sizeof(double) * (size_t)m->n_param, &dth))) return rc;
+    if ((rc = ensure(c, c->s_out, bytes))) return rc;
+    if ((rc = ude_rhs_ensemble_dev(c, m, N, (const double*)du0, (const double*)dth, (double*)c->s_out.p))) return rc;
+    if ((rc = dn(c, du, c->s_out.p, bytes))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return UDE_OK;
 }
 
 extern "C" int ude_math_dev(ude_ctx* c, int32_t op, int64_t n, const double* x, const double* y, double* out) {

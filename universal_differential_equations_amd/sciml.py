@@ -253,6 +253,22 @@ def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=
     return ODESolution(ts, out[0], stats[0], rc[0])
 
 
+def rhs(f, u, p, device=0):
+    """du = f(u, p) for a batch of states u (N, n) on the device: the right-hand side closure of the scripts
+    (`ude_dynamics!`, `dudt_`, `nn_ode`) evaluated once per state."""
+    eng = Engine.get(device)
+    eng.set_launch()
+    u = _np(u)
+    if u.ndim == 1:
+        u = u[None, :]
+    N, n = u.shape
+    assert n == f.n_state
+    p = _np(p)
+    du = np.zeros((N, n))
+    eng.check(eng.L.ude_rhs_ensemble(eng.h, C.byref(f), N, _ptr(u), _ptr(p if p.size else np.zeros(1)), _ptr(du)))
+    return du
+
+
 def concrete_solve(prob, alg, u0, p, saveat=None, sensealg=None, **kw):
     """concrete_solve(prob, alg, u0, p; saveat, abstol, reltol, sensealg)  (seir_exposure.jl:138)"""
     return solve(remake(prob, u0=u0, p=p), alg, saveat=saveat, sensealg=sensealg, **kw)
