@@ -80,6 +80,14 @@ grid(saveat::Number, tspan) = collect(tspan[1]:saveat:tspan[2])
 grid(saveat, tspan) = collect(Float64, saveat)
 
 "u0s: n x N matrix (column j = trajectory j); returns (u::Array{Float64,3} n x ns x N, stats 8 x N, retcode N)"
+"`f.(eachcol(U), Ref(θ))` on the device: the right-hand side closure evaluated once per state (columns of `U`)."
+function rhs_ensemble(m::UDEModel, U::Matrix{Float64}, θ::Vector{Float64})
+    n, N = size(U); dU = similar(U); d = Ref(m.desc)
+    GC.@preserve U θ dU check(ccall((:ude_rhs_ensemble, libudecore), Cint,
+        (Ptr{Cvoid}, Ref{ModelDesc}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx(), d, N, U, θ, dU))
+    dU
+end
+
 function solve_ensemble(m::UDEModel, alg, u0s::Matrix{Float64}, tspan, θ::Vector{Float64}, ts::Vector{Float64}; kw...)
     n, N = size(u0s); ns = length(ts)
     out = Array{Float64}(undef, n, ns, N); stats = zeros(Int64, 8, N); rc = zeros(Int32, N)
