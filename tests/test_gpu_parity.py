@@ -410,16 +410,21 @@ def test_discrete_gradient_seir_and_kpp_match_oracle():
     ref = O.loss_grad_ensemble(O.kpp_ude(26), O.opts(O.TSIT5, sensealg=1), u0, [0.0, 5.0], th, t, truth, nthreads=4)
     check_per_trajectory(r, ref)
     assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
-    # 1024 points: the 64-lane layout (16 points per lane, blocked fused parameter sums on the VALU) must agree bit for
-    # bit with the same oracle as the 4-wavefront MFMA kernels; its reverse sweep does not fit the LDS and says so
+    # 1024 points: the reverse sweep in the 4-wavefront matrix-core layout (stage derivatives read from the dense store),
+    # and the 64-lane layout (16 points per lane, blocked fused parameter sums on the VALU) against the same oracle;
+    # the 64-lane reverse sweep does not fit the LDS and says so
     th, u0, t, truth = kpp_case(1024, 3, models.kpp_chain(), None)
     f = models.nn_ode(1024)
     ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 5.0), th), u0)
+    r = U.loss_and_gradient(ens, U.Tsit5(), truth, saveat=t, sensealg=U.ForwardDiffSensitivity())
+    ref = O.loss_grad_ensemble(O.kpp_ude(1024), O.opts(O.TSIT5, sensealg=1), u0, [0.0, 5.0], th, t, truth, nthreads=3)
+    check_per_trajectory(r, ref)
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
     r64 = U.loss_and_gradient(ens, U.Tsit5(), truth, saveat=t, ensemblealg=U.EnsembleMI355(64))
     ref64 = O.loss_grad_ensemble(O.kpp_ude(1024), O.opts(O.TSIT5), u0, [0.0, 5.0], th, t, truth, nthreads=3)
     check_per_trajectory(r64, ref64)
     with pytest.raises(U.UdeError, match="LDS"):
-        U.loss_and_gradient(ens, U.Tsit5(), truth, saveat=t, sensealg=U.ForwardDiffSensitivity())
+        U.loss_and_gradient(ens, U.Tsit5(), truth, saveat=t, sensealg=U.ForwardDiffSensitivity(), ensemblealg=U.EnsembleMI355(64))
 
 
 def test_failed_trajectory_is_reported_not_summed(golden):

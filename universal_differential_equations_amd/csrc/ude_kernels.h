@@ -1052,8 +1052,11 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     constexpr bool DIST = Model::STATE_DISTRIBUTED;
     double* th = reinterpret_cast<double*>(smem_raw);
     double* scratch = th + Model::theta_lds(p.n_param);
-    double* kbase = scratch + Model::SCRATCH;  // k of the current step
-    double* kbbase = kbase + L::K_DOUBLES;      // kbar
+    // k of the current step: an LDS copy -- or, for models whose LDS is spoken for (DADJ_K_FROM_DENSE), read straight
+    // from the dense store in HBM (21 L2-resident loads per component and step)
+    constexpr bool KD = Model::DADJ_K_FROM_DENSE;
+    double* kbase = scratch + Model::SCRATCH;
+    double* kbbase = kbase + (KD ? 0 : L::K_DOUBLES);  // kbar
     double* slots = kbbase + L::K_DOUBLES;
     const int np_pad = L::np_pad(p.n_param);
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
@@ -1076,7 +1079,11 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         auto cvalid = [&](int c) { return comp(c) < n; };
         auto cwrite = [&](int c) { return DIST ? cvalid(c) : r == 0; };
         const int koff = k_offset<DIST, G>();
-        auto K = [&](int j, int c) -> double& { return kbase[(j * NR + c) * KSTRIDE + koff]; };
+        const double* kdense = nullptr;  // first stage field of the current step in the dense store (KD)
+        auto K = [&](int j, int c) -> double {
+            if constexpr (KD) return cvalid(c) ? kdense[(size_t)(j * n + comp(c)) * p.Npad] : 0.0;
+            else return kbase[(j * NR + c) * KSTRIDE + koff];
+        };
         auto KB = [&](int j, int c) -> double& { return kbbase[(j * NR + c) * KSTRIDE + koff]; };
         const TabDev* tab = p.tab;
         const double* cot;
@@ -1116,9 +1123,10 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             const double tn = base[0], tn1 = base[(size_t)1 * p.Npad], dt = base[(size_t)2 * p.Npad];
             double u_n[NR];
             static_for<0, NR>([&](auto c) { u_n[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p.Npad] : 0.0; });
+            kdense = base + (size_t)(3 + n) * p.Npad;
             for (int q = 0; q < NK; ++q)
                 static_for<0, NR>([&](auto c) {
-                    K(q, c) = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * p.Npad] : 0.0;
+                    if constexpr (!KD) kbase[(q * NR + c) * KSTRIDE + koff] = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * p.Npad] : 0.0;
                 });
             // (1) saves exactly at the step end feed the cotangent of u_{n+1}
             while (si >= 0 && p.saveat[si] >= tn1) {

@@ -30,6 +30,7 @@ struct LinearTheta {
     static constexpr bool SLOTS_GLOBAL = false;  // slot state mu in LDS (per-thread column)
     static constexpr bool CPL = false;           // component-per-lane stage storage (replicated small states, G = 64)
     static constexpr bool DEFERRED = false;      // adjoint keeps per-stage FACTORS of the parameter cotangent (see SeirUde)
+    static constexpr bool DADJ_K_FROM_DENSE = false;  // reverse sweep reads the stage derivatives from HBM (no LDS copy)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -207,6 +208,7 @@ struct SeirUde {
     // end of the step, fused with the error norm and the mu update: the identical fma chains (ascending stage
     // order), but no 2 x 71 persistent accumulators per lane and no per-evaluation broadcast of a1 for them.
     static constexpr bool DEFERRED = ONE;
+    static constexpr bool DADJ_K_FROM_DENSE = false;
     static constexpr int NSTG = 10, NFAC = 5, WPB = 4;  // stages stored (Vern7), factor fields, wavefronts per block
     static constexpr int LD = 65;  // leading dimension of the LDS copy of W2: row AND column reads conflict-free
     static constexpr int NPARAM = 3 * H + H + H * H + H + H + 1;  // 4481
@@ -778,6 +780,7 @@ struct KppUde : LinearTheta {
 template <class Net>
 struct KppUdeW : LinearTheta {
     static constexpr int G = 256, PPL = 4, NWV = 4, TP = 64, BLK = 256, NTILE = BLK / 16;
+    static constexpr bool DADJ_K_FROM_DENSE = true;  // (k and kbar of a 1024-point state do not both fit next to the tiles)
     static __host__ __device__ constexpr int point(int c, int r) { return (r >> 6) * BLK + c * TP + (r & 63); }
     static_assert(Net::dim(0) == 1 && Net::dim(Net::L) == 1, "pointwise reaction network R -> R");
     static constexpr int NS = PPL;

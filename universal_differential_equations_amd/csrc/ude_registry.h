@@ -13,11 +13,12 @@ struct Launch {
     int G, block;
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
     int theta_lds, scratch, k_doubles, k_doubles_d, slots_reg;
+    bool dadj_k_dense;  // the reverse sweep reads k from the dense store (HBM) instead of an LDS copy
     int slot_glob;  // > 0: slot state in HBM, this many doubles per thread (SLOTS_GLOBAL models)
     size_t lds_bytes(int np, bool adjoint, bool discrete = false) const {
         const size_t np_pad = (size_t)((np + 1) & ~1);
         size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + scratch + k_doubles;
-        if (discrete) d += 2 * (size_t)k_doubles_d - k_doubles;  // k and kbar in the reverse sweep's own layout
+        if (discrete) d += (dadj_k_dense ? 1 : 2) * (size_t)k_doubles_d - k_doubles;  // [k and] kbar in the reverse sweep's own layout
         if (adjoint) d += (size_t)slots_reg;
         return d * sizeof(double) + 16;
     }
@@ -37,6 +38,7 @@ inline Launch make_launch() {
     l.scratch = Model::SCRATCH;
     l.k_doubles = Layout<Model, Tab, G, BLOCK>::K_DOUBLES;
     l.k_doubles_d = Layout<Model, Tab, G, BLOCK, false>::K_DOUBLES;
+    l.dadj_k_dense = Model::DADJ_K_FROM_DENSE;
     l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : (Tab::FSAL ? 3 : 2) * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
     l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL : 0;
     return l;

@@ -190,7 +190,7 @@ static int default_lanes(int mid, bool discrete) {
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32: return 32;
         case MID_KPP_TRUE_1024: return 64;
-        case MID_KPP_UDE_1024: return discrete ? 64 : 256;  // 4 wavefronts per PDE (the reverse sweep keeps the 64-lane layout)
+        case MID_KPP_UDE_1024: return 256;  // 4 wavefronts per PDE
     }
     return 1;
 }
