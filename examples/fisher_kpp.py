@@ -38,8 +38,16 @@ def loss_rd(theta):                                                             
     return res.loss + 100.0 * abs(w.sum()), grad
 
 
-hist = []
+seen = []   # the callback's own iteration count (Fisher-KPP-CNN.jl:163-233 prints every 100th loss)
+
+
+def cb(th, l):
+    if len(seen) % 100 == 0:
+        print("iter %d loss %g" % (len(seen), l))
+    seen.append(l)
+    return False
+
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-pstar, hist = training.adam(loss_rd, p, eta=1e-3, maxiters=n,
-                            callback=lambda th, l: (len(hist) % 100 == 0 and print("loss", l)) and False)
+pstar, hist = training.adam(loss_rd, p, eta=1e-3, maxiters=n, callback=cb)
 print("loss %g -> %g ; D0 = %g, stencil = %s" % (hist[0], hist[-1], pstar[f.d0_offset], pstar[f.stencil_offset:f.stencil_offset + 3]))

@@ -89,7 +89,9 @@ typedef struct {
                                  trajectory) or 256 (four wavefronts); Fisher-KPP UDE <= 32 points: 32; 1024 points: 256
                                  (default, four wavefronts per PDE) or 64.  Every variant returns identical bits. */
     int32_t block_threads;    /* 0 = auto (64) */
-    int32_t max_dense_steps;  /* capacity of the dense forward store per trajectory, 0 = 256 */
+    int32_t max_dense_steps;  /* capacity of the dense forward store per trajectory; 0 = automatic: starts at 256 and is
+                                 re-run with 4x the capacity on UDE_RET_DENSE_OVERFLOW by the host-buffer entry points
+                                 (ude_last_failures does the same for the asynchronous _dev entry points) */
     int32_t waves_per_simd;   /* 0/1 = default; 2 = adjoint kernel variant register-bounded for 2 waves per SIMD */
 } ude_launch_opts;
 
@@ -153,6 +155,13 @@ int ude_loss_grad_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_
  * scenario_1.jl:152-160, applied to the whole right-hand side here).  u, du: n x N (one state per column). */
 int ude_rhs_ensemble(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const double* u_host, const double* theta_host, double* du_host);
 int ude_rhs_ensemble_dev(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const double* u, const double* theta, double* du);
+
+/* Failure accounting of the most recent gradient call on this context (blocks on the context's stream): the number
+ * of trajectories whose retcode is not Success.  Such trajectories contribute nothing to the gradient and the
+ * ensemble loss is +Inf (the reference's solve would abort / return an Inf loss), so a training loop can never
+ * silently optimise a partial objective.  If any of them is a UDE_RET_DENSE_OVERFLOW and max_dense_steps is
+ * automatic, *grown is set to 1 and the capacity is multiplied by 4: the caller repeats the call. */
+int ude_last_failures(ude_ctx* ctx, const int32_t* retcode_dev, int64_t N, int32_t* nfail, int32_t* grown);
 
 /* device time (ms) of the forward and backward kernels of the most recent call on this context,
  * measured with HIP events on the context's stream (valid after the stream has been synchronised) */

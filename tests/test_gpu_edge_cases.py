@@ -56,9 +56,27 @@ def test_retcodes_maxiters_and_dense_overflow(golden):
     out, st, rc = O.solve_ensemble(O.lv_ude_s1(), O.opts(O.TSIT5, 1e-10, 1e-10, maxiters=5), u0, [0.0, 3.0], th, t)
     assert sol.retcode == "MaxIters" and rc[0] == 1
     X = np.repeat(np.array(u0)[None, None], 31, axis=1)
-    r = U.loss_and_gradient(prob, U.Tsit5(), X, saveat=t, abstol=1e-12, reltol=1e-12, ensemblealg=U.EnsembleMI355(0, 8))
-    assert r.retcode[0] == 4 and np.all(r.grad_theta == 0)        # DenseOverflow: reported, gradient not polluted
-    U.Engine.get(0).set_launch(0, 0)
+    # a pinned dense-store capacity that is too small: loud by default ...
+    with pytest.raises(U.UdeError, match="retcode 4"):
+        U.loss_and_gradient(prob, U.Tsit5(), X, saveat=t, abstol=1e-12, reltol=1e-12, ensemblealg=U.EnsembleMI355(0, 8))
+    # ... and, when the caller opts in, reported with the gradient not polluted and the loss +Inf
+    r = U.loss_and_gradient(prob, U.Tsit5(), X, saveat=t, abstol=1e-12, reltol=1e-12, ensemblealg=U.EnsembleMI355(0, 8),
+                            allow_failures=True)
+    assert r.retcode[0] == 4 and np.all(r.grad_theta == 0) and r.loss == np.inf
+    # automatic capacity: the forward pass outgrows the initial 256 steps, the store grows x4 and the pass is repeated
+    r = U.loss_and_gradient(prob, U.Tsit5(), X, saveat=t, abstol=1e-12, reltol=1e-12)
+    ref = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(O.TSIT5, 1e-12, 1e-12), np.array([u0]), [0.0, 3.0], th, t, X)
+    assert r.retcode[0] == 0 and r.stats[0, 1] > 256 and bitwise(r.stats, ref["stats"]) and bitwise(r.grad_u0, ref["grad_u0"])
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < 1e-12 * np.linalg.norm(ref["grad_theta"])
+
+
+def test_scalar_saveat_ends_at_tf_and_grid_is_validated():
+    prob = U.ODEProblem(models.lotka(), [1.0, 1.0], (0.0, 1.0), [1.3, 0.9, 0.8, 1.8])
+    sol = U.solve(prob, U.Tsit5(), saveat=0.3)          # SciML: save_end = true for a Number saveat
+    assert np.allclose(sol.t, [0.0, 0.3, 0.6, 0.9, 1.0]) and np.asarray(sol).shape == (2, 5)
+    for bad in ([0.5, 0.2], [0.5, 1.5], [-0.1, 0.5], [0.2, 0.2]):
+        with pytest.raises(ValueError):
+            U.solve(prob, U.Tsit5(), saveat=bad)
 
 
 def test_invalid_arguments_fail_loudly():

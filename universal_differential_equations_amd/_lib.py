@@ -53,7 +53,8 @@ _lib = None
 EXPORTS = ["ude_version", "ude_create", "ude_destroy", "ude_last_error", "ude_set_stream", "ude_set_launch_opts",
            "ude_model_supported", "ude_solve_ensemble", "ude_solve_ensemble_dev", "ude_vjp_ensemble",
            "ude_vjp_ensemble_dev", "ude_loss_grad_ensemble", "ude_loss_grad_ensemble_dev", "ude_last_kernel_ms",
-           "ude_fastpow_dev", "ude_set_trace", "ude_get_trace", "ude_math_dev", "ude_rhs_ensemble", "ude_rhs_ensemble_dev"]
+           "ude_fastpow_dev", "ude_set_trace", "ude_get_trace", "ude_math_dev", "ude_rhs_ensemble", "ude_rhs_ensemble_dev",
+           "ude_last_failures"]
 
 
 def load():
@@ -95,6 +96,7 @@ def load():
     L.ude_math_dev.argtypes = [vp, i32, i64, vp, vp, vp]
     L.ude_rhs_ensemble.argtypes = [vp, vp, i64, vp, vp, vp]
     L.ude_rhs_ensemble_dev.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.ude_last_failures.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     L.ude_set_trace.argtypes = [vp, i64, i32]
     L.ude_get_trace.argtypes = [vp, vp]
     _lib = L

@@ -560,8 +560,9 @@ struct FwdSys {
             static_for<0, NR>([&](auto c) {
                 if (cvalid(c)) {
                     const int ci = comp(c);
-                    const double on = (p->row_mask && !p->row_mask[ci]) ? 0.0 : 1.0;
-                    const double e = on * (v[c] - d[ci]);
+                    // masked-out rows are ignored entirely (a select, not a product: NaN/Inf data there must not
+                    // reach the loss -- the reference slices those rows away, seir_exposure.jl:146)
+                    const double e = (p->row_mask && !p->row_mask[ci]) ? 0.0 : (v[c] - d[ci]);
                     loss = __builtin_fma(e, e, loss);
                     if (cwrite(c)) p->cot[((size_t)i * n + ci) * p->Npad + j] = 2.0 * e;
                 }

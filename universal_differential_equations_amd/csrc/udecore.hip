@@ -43,6 +43,25 @@ __global__ void reduce_sum_kernel(const double* v, int64_t n, double* out) {
     if (threadIdx.x == 0) out[0] = sh[0];
 }
 
+// A trajectory whose retcode is not Success contributes nothing to the gradient; the reference would see an Inf loss
+// (or an error) from such a solve, so the ensemble loss becomes +Inf and the count of failed trajectories is
+// published -- an optimiser never silently trains on a partial objective.
+__global__ void finalize_kernel(const int32_t* retcode, int64_t n, double* loss, int32_t* nfail_out) {
+    __shared__ int sh[256];
+    int c = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) c += retcode[i] != 0;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (nfail_out) *nfail_out = sh[0];
+        if (sh[0] > 0 && loss) *loss = __builtin_inf();
+    }
+}
+
 __global__ void fastpow_kernel(const double* x, const double* y, double* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fastpow(x[i], y[i]);
@@ -93,7 +112,9 @@ struct ude_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/end, bwd start/end
     bool ev_fwd = false, ev_bwd = false;
     // workspaces (grow on demand, reused across calls)
-    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs, slot_glob;
+    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs, slot_glob, nfail;
+    hipEvent_t ev_sync = nullptr;  // orders work across a change of the bound stream
+    int auto_cap = 256;  // dense-store capacity used when lo.max_dense_steps == 0; grows x4 on DenseOverflow (host-buffer path)
     int64_t trace_traj = -1;
     int32_t trace_cap = 0;
     // staging for the host-buffer entry points
@@ -119,7 +140,7 @@ static int fail(ude_ctx* c, int code, const char* fmt, ...) {
 static int ensure(ude_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return UDE_OK;
     if (b.p) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipDeviceSynchronize());  // (work queued on a previously bound stream may still use it)
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -248,6 +269,7 @@ static void fill_params(KParams& p, const ude_model_desc* m, const ude_solve_opt
 // context
 // ---------------------------------------------------------------------------------------------
 extern "C" int ude_version(void) { return UDE_VERSION; }
+extern "C" void ude_destroy(ude_ctx* c);
 
 extern "C" int ude_create(int32_t device_id, ude_ctx** out) {
     if (!out) return UDE_ERR_INVALID;
@@ -257,19 +279,17 @@ extern "C" int ude_create(int32_t device_id, ude_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess) return UDE_ERR_HIP;
     ude_ctx* c = new ude_ctx();
     c->device = device_id;
-    for (auto& e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) {
-            delete c;
-            return UDE_ERR_HIP;
-        }
-    {   // tableaux in device memory: [0] Tsit5, [1] Vern7
+    bool ok = hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming) == hipSuccess;
+    for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (ok) {   // tableaux in device memory: [0] Tsit5, [1] Vern7
         TabDev host[2] = {make_tabdev<Tsit5Tab>(), make_tabdev<Vern7Tab>()};
-        if (hipMalloc(&c->tabs.p, sizeof host) != hipSuccess ||
-            hipMemcpy(c->tabs.p, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) {
-            delete c;
-            return UDE_ERR_HIP;
-        }
+        ok = hipMalloc(&c->tabs.p, sizeof host) == hipSuccess &&
+             hipMemcpy(c->tabs.p, host, sizeof host, hipMemcpyHostToDevice) == hipSuccess;
         c->tabs.cap = sizeof host;
+    }
+    if (!ok) {  // release whatever was created
+        ude_destroy(c);
+        return UDE_ERR_HIP;
     }
     *out = c;
     return UDE_OK;
@@ -279,7 +299,9 @@ extern "C" void ude_destroy(ude_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs, &c->slot_glob,
+    (void)hipDeviceSynchronize();
+    if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
+    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs, &c->slot_glob, &c->nfail,
                       &c->s_u0, &c->s_theta, &c->s_saveat, &c->s_out, &c->s_data, &c->s_mask, &c->s_gtheta,
                       &c->s_gu0, &c->s_loss, &c->s_lpt, &c->s_stats, &c->s_ret};
     for (DevBuf* b : bufs)
@@ -293,7 +315,15 @@ extern "C" const char* ude_last_error(ude_ctx* c) { return c ? c->err.c_str() : 
 
 extern "C" int ude_set_stream(ude_ctx* c, void* s) {
     if (!c) return UDE_ERR_INVALID;
-    c->stream = (hipStream_t)s;
+    hipStream_t ns = (hipStream_t)s;
+    if (ns != c->stream) {
+        // the workspaces are shared by every call on this context: work already queued on the old stream must
+        // finish before work on the new stream may reuse them
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipEventRecord(c->ev_sync, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(ns, c->ev_sync, 0));
+        c->stream = ns;
+    }
     return UDE_OK;
 }
 
@@ -326,6 +356,27 @@ extern "C" int ude_get_trace(ude_ctx* c, double* out_host) {
     if (!c || !out_host || c->trace_cap <= 0) return UDE_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out_host, c->trace.p, sizeof(double) * 10 * (size_t)c->trace_cap, hipMemcpyDeviceToHost));
+    return UDE_OK;
+}
+
+extern "C" int ude_last_failures(ude_ctx* c, const int32_t* retcode_dev, int64_t N, int32_t* nfail, int32_t* grown) {
+    if (!c || !nfail) return UDE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *nfail = 0;
+    if (grown) *grown = 0;
+    if (!c->nfail.p) return UDE_OK;
+    HIPCHK(c, hipMemcpy(nfail, c->nfail.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (*nfail > 0 && retcode_dev && N > 0 && c->lo.max_dense_steps <= 0 && c->auto_cap < (1 << 20)) {
+        std::vector<int32_t> r(N);
+        HIPCHK(c, hipMemcpy(r.data(), retcode_dev, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+        for (int64_t j = 0; j < N; ++j)
+            if (r[j] == UDE_RET_DENSE_OVERFLOW) {
+                c->auto_cap *= 4;
+                if (grown) *grown = 1;
+                break;
+            }
+    }
     return UDE_OK;
 }
 
@@ -415,7 +466,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.tab = (const TabDev*)c->tabs.p + (o->alg == UDE_ALG_VERN7 ? 1 : 0);
     if (c->trace_cap > 0) { p.trace = (double*)c->trace.p; p.trace_traj = c->trace_traj; p.trace_cap = c->trace_cap; }
     const int n = m->n_state, np = m->n_param;
-    const int cap = c->lo.max_dense_steps > 0 ? c->lo.max_dense_steps : 256;
+    const int cap = c->lo.max_dense_steps > 0 ? c->lo.max_dense_steps : c->auto_cap;
     const int BLOCK = l.block;
     const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
@@ -487,6 +538,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)p.loss_traj, N, loss);
         HIPCHK(c, hipGetLastError());
     }
+    if ((rc = ensure(c, c->nfail, sizeof(int32_t)))) return rc;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, (const int32_t*)retcode, N,
+                       (loss && !cot_in) ? loss : (double*)nullptr, (int32_t*)c->nfail.p);
+    HIPCHK(c, hipGetLastError());
     return UDE_OK;
 }
 
@@ -618,16 +673,25 @@ static int grad_host(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* 
     if ((rc = ensure(c, c->s_gu0, sizeof(double) * n * N))) return rc;
     if ((rc = ensure(c, c->s_loss, sizeof(double)))) return rc;
     if ((rc = ensure(c, c->s_lpt, sizeof(double) * N))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->s_stats.p, 0, sizeof(int64_t) * 8 * N, c->stream));
-    rc = grad_dev_impl(c, m, o, N, (double*)du0, tspan, (double*)dth, (double*)dsv, ns, cot ? (double*)ddat : nullptr,
-                       cot ? nullptr : (double*)ddat, (uint8_t*)dmask, (double*)c->s_loss.p, (double*)c->s_lpt.p,
-                       (double*)c->s_out.p, (double*)c->s_gtheta.p, (double*)c->s_gu0.p, (int64_t*)c->s_stats.p,
-                       (int32_t*)c->s_ret.p);
-    if (rc) return rc;
     std::vector<int32_t> rtmp(N);
+    for (;;) {
+        HIPCHK(c, hipMemsetAsync(c->s_stats.p, 0, sizeof(int64_t) * 8 * N, c->stream));
+        rc = grad_dev_impl(c, m, o, N, (double*)du0, tspan, (double*)dth, (double*)dsv, ns, cot ? (double*)ddat : nullptr,
+                           cot ? nullptr : (double*)ddat, (uint8_t*)dmask, (double*)c->s_loss.p, (double*)c->s_lpt.p,
+                           (double*)c->s_out.p, (double*)c->s_gtheta.p, (double*)c->s_gu0.p, (int64_t*)c->s_stats.p,
+                           (int32_t*)c->s_ret.p);
+        if (rc) return rc;
+        if ((rc = dn(c, rtmp.data(), c->s_ret.p, sizeof(int32_t) * N))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // a forward pass that outgrew the dense store is re-run with four times the capacity (the oracle's and
+        // upstream's solution arrays simply grow) unless the caller pinned max_dense_steps
+        bool overflow = false;
+        for (int64_t j = 0; j < N; ++j) overflow = overflow || rtmp[j] == UDE_RET_DENSE_OVERFLOW;
+        if (!overflow || c->lo.max_dense_steps > 0 || c->auto_cap >= (1 << 20)) break;
+        c->auto_cap *= 4;
+    }
     if ((rc = dn(c, u_out, c->s_out.p, sizeof(double) * n * ns * N))) return rc;
     if ((rc = dn(c, stats, c->s_stats.p, sizeof(int64_t) * 8 * N))) return rc;
-    if ((rc = dn(c, rtmp.data(), c->s_ret.p, sizeof(int32_t) * N))) return rc;
     if ((rc = dn(c, grad_theta, c->s_gtheta.p, sizeof(double) * np))) return rc;
     if ((rc = dn(c, grad_u0, c->s_gu0.p, sizeof(double) * n * N))) return rc;
     if (!cot) {

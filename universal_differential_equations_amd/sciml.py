@@ -73,6 +73,7 @@ class Engine:
     """One ude_ctx (device + stream).  Created lazily per device."""
 
     _by_device = {}
+    _lock = __import__("threading").Lock()
 
     def __init__(self, device=0):
         self.L = _lib.load()
@@ -85,9 +86,31 @@ class Engine:
 
     @classmethod
     def get(cls, device=0):
-        if device not in cls._by_device:
-            cls._by_device[device] = Engine(device)
-        return cls._by_device[device]
+        """one context per (device, host thread), as include/udecore.h requires"""
+        import threading
+        key = (device, threading.get_ident())
+        with cls._lock:
+            if key not in cls._by_device:
+                cls._by_device[key] = Engine(device)
+            return cls._by_device[key]
+
+    def close(self):
+        if self.h is not None:
+            self.L.ude_destroy(self.h)
+            self.h = None
+
+    @classmethod
+    def close_all(cls):
+        with cls._lock:
+            for e in cls._by_device.values():
+                e.close()
+            cls._by_device.clear()
+
+    def failures(self, retcode_dev=None, N=0):
+        """(number of failed trajectories, capacity grown?) of the most recent gradient call; blocks on the stream"""
+        nf, gr = C.c_int32(0), C.c_int32(0)
+        self.check(self.L.ude_last_failures(self.h, _ptr(retcode_dev), N, C.byref(nf), C.byref(gr)))
+        return nf.value, bool(gr.value)
 
     def check(self, rc, allow_traj=False):
         if rc != 0 and not (allow_traj and rc == _lib.UDE_ERR_TRAJECTORY):
@@ -219,12 +242,19 @@ def _saveat_grid(saveat, tspan):
         ts = tspan[0] + saveat * np.arange(n)
         if ts[-1] < tspan[1] and abs(ts[-1] - tspan[1]) < 1e-12 * max(1.0, abs(tspan[1])):
             ts[-1] = tspan[1]
+        elif ts[-1] < tspan[1]:
+            ts = np.append(ts, tspan[1])   # SciML: save_end = true for a Number saveat -> Array(sol) ends at tf
         return ts
-    return _np(saveat)
+    ts = _np(saveat)
+    if ts.ndim != 1 or ts.size == 0 or np.any(np.diff(ts) <= 0) or ts[0] < tspan[0] or ts[-1] > tspan[1]:
+        raise ValueError("saveat must be strictly increasing and inside tspan = (%g, %g)" % (tspan[0], tspan[1]))
+    return ts
 
 
-def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=None, device=0, **kw):
-    """solve(prob, alg; saveat, abstol, reltol, ...) -> ODESolution  /  EnsembleSolution"""
+def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=None, device=0, allow_failures=True, **kw):
+    """solve(prob, alg; saveat, abstol, reltol, ...) -> ODESolution  /  EnsembleSolution.
+    Like upstream, a solve that stops early RETURNS (sol.retcode says why: "MaxIters", "Unstable", ...);
+    allow_failures=False turns any retcode other than Success into a UdeError."""
     ens = isinstance(prob, EnsembleProblem)
     base = prob.prob if ens else prob
     saveat = base.kwargs.get("saveat") if saveat is None else saveat
@@ -247,7 +277,7 @@ def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=
     stats = np.zeros((N, NSTATS), dtype=np.int64)
     rc = np.zeros(N, dtype=np.int32)
     eng.check(eng.L.ude_solve_ensemble(eng.h, C.byref(base.f), C.byref(o), N, _ptr(u0), _ptr(tspan), _ptr(theta),
-                                       _ptr(ts), len(ts), _ptr(out), _ptr(stats), _ptr(rc)), allow_traj=True)
+                                       _ptr(ts), len(ts), _ptr(out), _ptr(stats), _ptr(rc)), allow_traj=allow_failures)
     if ens:
         return EnsembleSolution(ts, out, stats, rc)
     return ODESolution(ts, out[0], stats[0], rc[0])
@@ -278,7 +308,7 @@ class GradResult:
     pass
 
 
-def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblealg, kw, sensealg=None):
+def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblealg, kw, sensealg=None, allow_failures=False):
     ens = isinstance(prob, EnsembleProblem)
     base = prob.prob if ens else prob
     saveat = base.kwargs.get("saveat") if saveat is None else saveat
@@ -320,22 +350,24 @@ def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblea
                                           _ptr(r.grad_theta), _ptr(r.grad_u0), _ptr(r.u), _ptr(r.stats),
                                           _ptr(r.retcode))
         r.loss = loss.value
-    eng.check(rc, allow_traj=True)
+    # a failed trajectory is dropped from the gradient and the loss is +Inf: never train on a partial objective silently
+    eng.check(rc, allow_traj=allow_failures)
     r.kernel_ms = eng.kernel_ms()
     return r
 
 
-def loss_and_gradient(prob, alg, data, row_mask=None, saveat=None, sensealg=None, ensemblealg=None, device=0, **kw):
+def loss_and_gradient(prob, alg, data, row_mask=None, saveat=None, sensealg=None, ensemblealg=None, device=0,
+                      allow_failures=False, **kw):
     """loss(theta) = sum(abs2, data[rows,:] .- Array(solve(...))[rows,:]) and dloss/dtheta by the
     interpolating adjoint (seir_exposure.jl:137-147; Fisher-KPP-CNN.jl:134-143; scenario_1.jl:82-94),
     summed over an ensemble.  data: (N, ns, n)."""
-    return _grad_common(prob, alg, data, None, row_mask, saveat, device, ensemblealg, kw, sensealg)
+    return _grad_common(prob, alg, data, None, row_mask, saveat, device, ensemblealg, kw, sensealg, allow_failures)
 
 
-def adjoint_pullback(prob, alg, cotangent, saveat=None, sensealg=None, ensemblealg=None, device=0, **kw):
+def adjoint_pullback(prob, alg, cotangent, saveat=None, sensealg=None, ensemblealg=None, device=0, allow_failures=False, **kw):
     """The ChainRules pullback of concrete_solve under InterpolatingAdjoint: cotangent (N, ns, n) of
     Array(sol) -> (grad_theta, grad_u0)."""
-    return _grad_common(prob, alg, None, cotangent, None, saveat, device, ensemblealg, kw, sensealg)
+    return _grad_common(prob, alg, None, cotangent, None, saveat, device, ensemblealg, kw, sensealg, allow_failures)
 
 
 # ---- device-resident path (torch CUDA tensors; used by bench.py and the training loop) -------------------
@@ -378,8 +410,25 @@ class DeviceEnsemble:
                                          _ptr(self.retcode)))
         return self.u
 
-    def loss_grad(self, theta):
-        """returns a view: grad[:np] = dloss/dtheta, grad[np] = loss (one buffer so a single all-reduce moves both)"""
+    def check(self):
+        """Blocks on the stream: number of failed trajectories of the last loss_grad call.  A DenseOverflow grows
+        the dense store (automatic capacity) and returns -1: repeat the call."""
+        nfail, grown = self.eng.failures(self.retcode, self.N)
+        return -1 if grown else nfail
+
+    def loss_grad(self, theta, check=None):
+        """returns a view: grad[:np] = dloss/dtheta, grad[np] = loss (one buffer so a single all-reduce moves both).
+        Failed trajectories are dropped from the gradient and make the loss +Inf (nothing is silent).  The FIRST call
+        (or check=True) also blocks once to size the dense store: on DenseOverflow the capacity grows x4 and the pass
+        is repeated, as the oracle's / upstream's growing solution arrays do."""
+        check = (not getattr(self, "_sized", False)) if check is None else check
+        if check:
+            for _ in range(8):
+                g = self.loss_grad(theta, check=False)
+                if self.check() >= 0:
+                    break
+            self._sized = True
+            return g
         self._bind()
         L, e = self.eng.L, self.eng
         np_ = self.f.n_param
