@@ -156,6 +156,64 @@ int ude_loss_grad_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_
 int ude_rhs_ensemble(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const double* u_host, const double* theta_host, double* du_host);
 int ude_rhs_ensemble_dev(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const double* u, const double* theta, double* du);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * SURVEY.md 8(f) N1 / BASELINE configs[4]: highdim_pde/lambaem.jl -- the deep-BSDE solver NNPDENS (NeuralNetDiffEq
+ * 1.1.0) for a 100-dimensional Hamilton-Jacobi-Bellman equation: an ensemble of `trajectories` adaptive
+ * Euler-Maruyama (StochasticDiffEq `LambaEM()`) solves of the (d+1)-dimensional SDE
+ *   dX = sigma dW,   du = lambda |z|^2 dt + z . dW,   z = sigma^T grad u net([X; t]),   u(0) = u0 net(x0),
+ * loss = mean_j (g(X_T) - u_T)^2 with g(X) = log(0.5 + 0.5 |X|^2), differentiated through the stepper (Tracker
+ * upstream; here the reverse sweep over the recorded accepted steps).  Float32 throughout (lambaem.jl:9-10).
+ * ude_hjb_desc replaces: TerminalPDEProblem(g, f, mu, sigma, x0, tspan) + NNPDENS(u0, sigma^T grad u) + the solve
+ * keywords alg = LambaEM(), abstol, reltol (lambaem.jl:14-34) -- a declarative descriptor of THIS problem family
+ * (g, f, mu = 0 and the constant diagonal sigma of lambaem.jl:14-17); the chains are Flux.Chain(Dense(d,hls,relu),
+ * Dense(hls,hls,relu), Dense(hls,1)) and Chain(Dense(d+1,hls,relu), Dense(hls,hls,relu), Dense(hls,hls,relu),
+ * Dense(hls,d)) (lambaem.jl:23-30), theta = Flux.params order [u0 chain; sigma^T grad u chain], per Dense layer W
+ * (out x in, column-major) then b.  Compiled instance: d = 100, hls = 110.
+ * Random numbers: counter-based Philox4x32-10, key = seed, counter = (chunk, draw event, trajectory, iteration) --
+ * Julia's MersenneTwister stream (Random.seed!(0), lambaem.jl:7) is not reproducible outside Julia. */
+typedef struct {
+    int32_t d;          /* 100 (lambaem.jl:8) */
+    int32_t hls;        /* 10 + d (lambaem.jl:20) */
+    int32_t adaptive;   /* 1 = LambaEM with error control (lambaem.jl:33); 0 = fixed-step Euler-Maruyama with `dt` */
+    int32_t maxiters;   /* step attempts per trajectory, <= 0 -> 1000000 */
+    int32_t max_steps;  /* capacity of the accepted-step store per trajectory, <= 0 -> 512 */
+    int32_t reserved;
+    uint64_t seed;      /* Philox key */
+    double lambda;      /* lambaem.jl:12 */
+    double sigma;       /* diagonal of sigma: sqrt(2f0) (lambaem.jl:17) */
+    double t0, t1;      /* tspan (lambaem.jl:10) */
+    double abstol, reltol; /* lambaem.jl:34 */
+    double dt;          /* adaptive = 0: the step; adaptive = 1: > 0 overrides the initial-dt heuristic */
+    double qmin, qmax, gamma, qoldinit, beta1, beta2, dtmax; /* <= 0 -> StochasticDiffEq defaults 1/5, 9/8, 9/10, 1e-4, 7/10, 2/5, t1 - t0 */
+} ude_hjb_desc;
+enum { UDE_HJB_NSTATS = 4 }; /* per trajectory: 0 network evaluations, 1 naccept, 2 nreject, 3 random draw events */
+enum { UDE_RET_STACK_OVERFLOW = 5 /* more than 32 unconsumed rejected increments (RSwM stack) */ };
+
+int ude_hjb_num_params(int32_t d, int32_t hls, int32_t* np_u0, int32_t* np_sg);
+/* replaces: one evaluation of loss_n_sde() and its Tracker gradient inside Flux.train!(loss_n_sde, ps, data, opt)
+ * of solve(prob::TerminalPDEProblem, pdealg::NNPDENS; trajectories = M, alg = LambaEM(), abstol, reltol)
+ * (lambaem.jl:33-34).  iter = the training iteration (a Philox counter word: fresh noise per iteration).
+ * Device pointers: x0 (d), theta (np_u0 + np_sg), loss (1 double), grad (np floats, or NULL = loss only),
+ * u0_out (1 float = u0 net(x0), the PDE solution estimate the script returns, or NULL), uT (M or NULL), XT (d x M or NULL),
+ * loss_traj (M doubles or NULL), stats (UDE_HJB_NSTATS x M int64 or NULL), retcode (M int32 or NULL).
+ * Failed trajectories are left out of the gradient and make the loss +Inf.  Asynchronous on the context's stream. */
+int ude_hjb_loss_grad_dev(ude_ctx* ctx, const ude_hjb_desc* D, int64_t M, const float* x0, const float* theta, uint32_t iter,
+                          double* loss, float* grad, float* u0_out, float* uT, float* XT, double* loss_traj,
+                          int64_t* stats, int32_t* retcode);
+/* the same with host buffers (what a Julia ccall binds); blocks; UDE_ERR_TRAJECTORY if a trajectory failed */
+int ude_hjb_loss_grad(ude_ctx* ctx, const ude_hjb_desc* D, int64_t M, const float* x0, const float* theta, uint32_t iter,
+                      double* loss, float* grad, float* u0_out, float* uT, float* XT, double* loss_traj,
+                      int64_t* stats, int32_t* retcode);
+/* parity aids: the d standard normals of one draw event as the kernels generate them (host out, d doubles);
+ * one evaluation of the sigma^T grad u chain on the FP32 matrix cores for n input columns (x_in: (d+1) x n, z: d x n, host) */
+int ude_hjb_normals(ude_ctx* ctx, uint64_t seed, uint32_t iter, uint32_t traj, uint32_t event, int32_t d, double* out_host);
+int ude_hjb_net(ude_ctx* ctx, int32_t d, int32_t hls, const float* theta_sg_host, int64_t n, const float* x_in_host, float* z_host);
+/* debugging aid for parity work: raw float copy out of a workspace of the most recent call (0: [u0, initial dt, ...],
+ * 1: the accepted-step records [trajectory][step][104] = X_n (100), t_n; 5: [trajectory][step][100] = 2 lambda dt z + dW) */
+int ude_hjb_debug_read(ude_ctx* ctx, int32_t which, int64_t offset_floats, int64_t n_floats, float* out_host);
+/* device time (ms) of the forward and backward kernels of the most recent ude_hjb_loss_grad* call (HIP events on the stream) */
+int ude_hjb_last_kernel_ms(ude_ctx* ctx, float* fwd_ms, float* bwd_ms);
+
 /* Failure accounting of the most recent gradient call on this context (blocks on the context's stream): the number
  * of trajectories whose retcode is not Success.  Such trajectories contribute nothing to the gradient and the
  * ensemble loss is +Inf (the reference's solve would abort / return an Inf loss), so a training loop can never

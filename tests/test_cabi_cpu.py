@@ -36,6 +36,10 @@ def test_struct_sizes_match_header():
     import _oracle as O
     assert C.sizeof(O.ModelDesc) == C.sizeof(_lib.ModelDesc)
     assert C.sizeof(O.SolveOpts) == C.sizeof(_lib.SolveOpts)
+    # ude_hjb_desc: 6 int32 + uint64 + 14 doubles
+    import _sde_oracle as S
+    assert C.sizeof(_lib.HjbDesc) == 24 + 8 + 14 * 8 == C.sizeof(S.HjbDesc)
+    assert [f[0] for f in _lib.HjbDesc._fields_] == [f[0] for f in S.HjbDesc._fields_]
 
 
 def test_no_gpu_fails_loudly():

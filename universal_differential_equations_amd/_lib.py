@@ -42,6 +42,16 @@ class LaunchOpts(C.Structure):
                 ("waves_per_simd", C.c_int32)]
 
 
+class HjbDesc(C.Structure):
+    """ude_hjb_desc (highdim_pde/lambaem.jl:8-34)"""
+    _fields_ = [("d", C.c_int32), ("hls", C.c_int32), ("adaptive", C.c_int32), ("maxiters", C.c_int32),
+                ("max_steps", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
+                ("lam", C.c_double), ("sigma", C.c_double), ("t0", C.c_double), ("t1", C.c_double),
+                ("abstol", C.c_double), ("reltol", C.c_double), ("dt", C.c_double),
+                ("qmin", C.c_double), ("qmax", C.c_double), ("gamma", C.c_double), ("qoldinit", C.c_double),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("dtmax", C.c_double)]
+
+
 class UdeError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("udecore error %d: %s" % (code, msg))
@@ -54,7 +64,8 @@ EXPORTS = ["ude_version", "ude_create", "ude_destroy", "ude_last_error", "ude_se
            "ude_model_supported", "ude_solve_ensemble", "ude_solve_ensemble_dev", "ude_vjp_ensemble",
            "ude_vjp_ensemble_dev", "ude_loss_grad_ensemble", "ude_loss_grad_ensemble_dev", "ude_last_kernel_ms",
            "ude_fastpow_dev", "ude_set_trace", "ude_get_trace", "ude_math_dev", "ude_rhs_ensemble", "ude_rhs_ensemble_dev",
-           "ude_last_failures"]
+           "ude_last_failures", "ude_hjb_num_params", "ude_hjb_loss_grad_dev", "ude_hjb_loss_grad", "ude_hjb_normals",
+           "ude_hjb_net", "ude_hjb_last_kernel_ms", "ude_hjb_debug_read"]
 
 
 def load():
@@ -97,6 +108,14 @@ def load():
     L.ude_rhs_ensemble.argtypes = [vp, vp, i64, vp, vp, vp]
     L.ude_rhs_ensemble_dev.argtypes = [vp, vp, i64, vp, vp, vp]
     L.ude_last_failures.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
+    u32, u64 = C.c_uint32, C.c_uint64
+    L.ude_hjb_num_params.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    for name in ("ude_hjb_loss_grad_dev", "ude_hjb_loss_grad"):
+        getattr(L, name).argtypes = [vp, C.POINTER(HjbDesc), i64, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ude_hjb_normals.argtypes = [vp, u64, u32, u32, u32, i32, vp]
+    L.ude_hjb_net.argtypes = [vp, i32, i32, vp, i64, vp, vp]
+    L.ude_hjb_debug_read.argtypes = [vp, i32, i64, i64, vp]
+    L.ude_hjb_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ude_set_trace.argtypes = [vp, i64, i32]
     L.ude_get_trace.argtypes = [vp, vp]
     _lib = L

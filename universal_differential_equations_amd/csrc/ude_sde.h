@@ -1,0 +1,873 @@
+// ude_sde.h -- SURVEY.md 8(f) N1 / BASELINE configs[4]: the deep-BSDE training step of highdim_pde/lambaem.jl:8-48 as fused
+// gfx950 kernels.  An ensemble of adaptive Euler-Maruyama (StochasticDiffEq LambaEM) solves of
+//     dX = sigma dW,   du = lambda |z|^2 dt + z . dW,   z = sigma^T grad u net([X; t])          (NNPDENS: F, G)
+// steps in lock-step per block of 32 trajectories; the three network evaluations of a step attempt (drift/diffusion at
+// (X, t), drift at (X, t + dt), diffusion at the Lamba probe point) are batched as columns of FP32 matrix-core GEMMs
+// (v_mfma_f32_32x32x2_f32: bit for bit an fmaf chain over k ascending with the bias as C operand, i.e. exactly the
+// oracle's Dense layer).  Each of the block's four wavefronts owns a 32-row slab of every layer's output and keeps
+// ITS weights in registers for the whole solve (216 VGPR/AGPR): the weights never touch LDS; activations ping-pong
+// between two LDS tiles.  The per-trajectory scalar work (tree sums over the 100 components, error estimate, PI
+// controller, rejection sampling with memory, Philox/Box-Muller normals) runs one trajectory per wavefront at a time
+// with components 2l, 2l+1 on lane l.  Algorithm and arithmetic order: oracle/sde_oracle_impl.h (the restatement;
+// parity with upstream itself is unpinned, see oracle/sde_oracle.h).
+#pragma once
+#include "ude_math.h"
+
+namespace ude {
+namespace hjb {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+enum { RET_SUCCESS = 0, RET_MAXITERS = 1, RET_UNSTABLE = 3, RET_STORE_OVERFLOW = 4, RET_STACK_OVERFLOW = 5 };
+constexpr int NT = 32;      // trajectories per block (one N-tile per evaluation kind)
+constexpr int LDA = 97;     // leading dimension of the [row][column] activation tiles (odd: row and column walks conflict-free)
+constexpr int XLD = 128;    // per-trajectory row of the state / increment arrays
+constexpr int STACK = 32;   // RSwM stack depth
+constexpr int LDT = 33;     // leading dimension of the backward kernel's [row][column] tiles
+
+template <int D, int H>
+struct Cfg {
+    static_assert(D % 2 == 0 && D <= 126 && H <= 127, "components 2l, 2l+1 per lane; one 128-row tile per layer");
+    static constexpr int DIN = D + 1;
+    static constexpr int KS1 = (DIN + 1) / 2, KSH = (H + 1) / 2, KS4T = (D + 1) / 2;  // k-steps (K = 2 per MFMA)
+    static constexpr int RX = (D + 2 + 3) & ~3, RA = (H + 1 + 3) & ~3, RE = (D + 3) & ~3;  // record strides (floats)
+    // theta_sg offsets (Flux.params order: W (out x in, column-major), b per Dense layer; lambaem.jl:27-30)
+    static constexpr int W1 = 0, B1 = H * DIN, W2 = B1 + H, B2 = W2 + H * H, W3 = B2 + H, B3 = W3 + H * H, W4 = B3 + H,
+                         B4 = W4 + D * H, NP = B4 + D;
+    // theta_u0 offsets (lambaem.jl:23-25)
+    static constexpr int U1 = 0, C1 = H * D, U2 = C1 + H, C2 = U2 + H * H, U3 = C2 + H, C3 = U3 + H, NPU = C3 + 1;
+};
+
+struct HjbParams {
+    int64_t M;
+    int32_t cap, maxiters, adaptive, record;
+    uint32_t iter;
+    uint64_t seed;
+    float lam, sig, t0, t1, abstol, reltol, qmin, qmax, gamma, qoldinit, beta1, beta2, dtmax, dt_user;
+    const float* x0;
+    const float* theta;   // [theta_u0; theta_sg]
+    float* prep;          // [0] u0, [1] initial dt, [2 .. 2+H) a1 of the u0 chain, [2+H .. 2+2H) a2
+    float *rXin, *rA1, *rA2, *rA3, *rE4;  // accepted-step records, column = traj * cap + step
+    int32_t* nacc;        // accepted steps per trajectory
+    float* stackW;        // RSwM stack increments [trajectory][depth][XLD]
+    float* uT;
+    float* XT;
+    double* loss_traj;
+    float* ubar;
+    int64_t* stats;
+    int32_t* retcode;
+    float* part;          // backward: per-block partial gradients of theta_sg
+    float* grad;          // np floats
+    double* loss;
+    int32_t* nfail;
+};
+
+// ---- Philox4x32-10 + Box-Muller (oracle/sde_oracle.c restates the same sequences) ----------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double sincos2pi(double u, double& cosout) {
+    const double v = u * 4.0;
+    const int q = (int)v;
+    const double x = (v - (double)q) * 1.5707963267948966;
+    const double x2 = x * x;
+    double ps = -1.0 / 51090942171709440000.0;
+    ps = __builtin_fma(ps, x2, 1.0 / 121645100408832000.0);
+    ps = __builtin_fma(ps, x2, -1.0 / 355687428096000.0);
+    ps = __builtin_fma(ps, x2, 1.0 / 1307674368000.0);
+    ps = __builtin_fma(ps, x2, -1.0 / 6227020800.0);
+    ps = __builtin_fma(ps, x2, 1.0 / 39916800.0);
+    ps = __builtin_fma(ps, x2, -1.0 / 362880.0);
+    ps = __builtin_fma(ps, x2, 1.0 / 5040.0);
+    ps = __builtin_fma(ps, x2, -1.0 / 120.0);
+    ps = __builtin_fma(ps, x2, 1.0 / 6.0);
+    const double s = __builtin_fma(-(x * x2), ps, x);
+    double pc = 1.0 / 2432902008176640000.0;
+    pc = __builtin_fma(pc, x2, -1.0 / 6402373705728000.0);
+    pc = __builtin_fma(pc, x2, 1.0 / 20922789888000.0);
+    pc = __builtin_fma(pc, x2, -1.0 / 87178291200.0);
+    pc = __builtin_fma(pc, x2, 1.0 / 479001600.0);
+    pc = __builtin_fma(pc, x2, -1.0 / 3628800.0);
+    pc = __builtin_fma(pc, x2, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, x2, -1.0 / 720.0);
+    pc = __builtin_fma(pc, x2, 1.0 / 24.0);
+    pc = __builtin_fma(pc, x2, -0.5);
+    const double c = __builtin_fma(pc, x2, 1.0);
+    const int qq = q & 3;
+    const double so = qq == 0 ? s : qq == 1 ? c : qq == 2 ? -s : -c;
+    cosout = qq == 0 ? c : qq == 1 ? -s : qq == 2 ? -c : s;
+    return so;
+}
+
+// the two standard normals of lane l (components 2l, 2l+1) of draw event `ev`: chunk l/2, Box-Muller pair l%2
+__device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t iter, uint32_t traj, uint32_t ev, int l, double& n0, double& n1) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)(l >> 1), ev, traj, iter, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const int h = l & 1;
+    const uint32_t a = h ? r[2] : r[0], b = h ? r[3] : r[1];
+    const double u1 = ((double)a + 0.5) * 2.3283064365386963e-10;
+    const double u2 = (double)b * 2.3283064365386963e-10;
+    const double rad = sqrt(-2.0 * dlog(u1));
+    double co;
+    const double si = sincos2pi(u2, co);
+    n0 = rad * co;
+    n1 = rad * si;
+}
+
+// ---- wavefront tree sum (binary tree over adjacent index pairs; every lane receives the total) ---------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_tree_sum_f32(float x) {
+    x += dpp_f32<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_f32<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_f32<0x141>(x);  // row_half_mirror
+    x += dpp_f32<0x140>(x);  // row_mirror
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+// tsum of a vector whose components 2l, 2l+1 sit on lane l (zeros beyond the vector)
+__device__ __forceinline__ float tsum2(float v0, float v1) { return wave_tree_sum_f32(v0 + v1); }
+
+// ---- one Dense layer on the matrix cores: out[32w .. 32w+31][columns of tiles nt0..nt1) = act(W in + b) -----------------
+// wf: this lane's weight fragments (A operand: row 32w + (l&31), k = 2s + (l>>5)); in/out: LDS tiles [row][LDA]
+template <int KS, bool RELU>
+__device__ __forceinline__ void layer(const float (&wf)[KS], const float* in, float* out, const float* bias, int nt0, int nt1, int w,
+                                      int l, float* rec, int recLD, const int* naccS, const int* doneS, int64_t jbase, int cap) {
+    const int rbase = 32 * w + 4 * (l >> 5);
+    for (int nt = nt0; nt < nt1; ++nt) {
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias[rbase + (r & 3) + 8 * (r >> 2)];
+        const float* bp = in + (l >> 5) * LDA + nt * 32 + (l & 31);
+        static_for<0, KS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s], bp[2 * s * LDA], acc, 0, 0, 0);
+        });
+        if constexpr (RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+        }
+        float* op = out + rbase * LDA + nt * 32 + (l & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) op[((r & 3) + 8 * (r >> 2)) * LDA] = acc[r];
+        if (rec && nt == 0) {  // activations of the (X, t) evaluation: speculative record of the step under way
+            const int tr = l & 31;
+            const int slot = naccS[tr];
+            if (!doneS[tr] && slot < cap) {
+                float* rp = rec + ((size_t)(jbase + tr) * cap + slot) * recLD;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row0 = rbase + 8 * g;
+                    if (row0 < recLD) {
+                        float4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                        *reinterpret_cast<float4*>(rp + row0) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int D, int H>
+__device__ __forceinline__ void load_fwd_weights(const float* th, int w, int l, float (&wf1)[Cfg<D, H>::KS1], float (&wf2)[Cfg<D, H>::KSH],
+                                                 float (&wf3)[Cfg<D, H>::KSH], float (&wf4)[Cfg<D, H>::KSH]) {
+    using C = Cfg<D, H>;
+    const int row = 32 * w + (l & 31), kk = l >> 5;
+    static_for<0, C::KS1>([&](auto sc) {
+        const int k = 2 * decltype(sc)::value + kk;
+        wf1[sc] = (row < H && k < C::DIN) ? th[C::W1 + row + k * H] : 0.0f;
+    });
+    static_for<0, C::KSH>([&](auto sc) {
+        const int k = 2 * decltype(sc)::value + kk;
+        const bool in = row < H && k < H;
+        wf2[sc] = in ? th[C::W2 + row + k * H] : 0.0f;
+        wf3[sc] = in ? th[C::W3 + row + k * H] : 0.0f;
+        wf4[sc] = (row < D && k < H) ? th[C::W4 + row + k * D] : 0.0f;
+    });
+}
+
+template <int D, int H>
+__device__ __forceinline__ void load_bias_table(const float* th, float* biasS, int tid, int nthreads) {
+    using C = Cfg<D, H>;
+    for (int i = tid; i < 4 * 128; i += nthreads) {
+        const int L = i >> 7, r = i & 127;
+        float v = 0.0f;
+        if (L == 0 && r < H) v = th[C::B1 + r];
+        if (L == 1 && r < H) v = th[C::B2 + r];
+        if (L == 2 && r < H) v = th[C::B3 + r];
+        if (L == 3 && r < D) v = th[C::B4 + r];
+        biasS[i] = v;
+    }
+}
+
+// LDS of the forward kernel (floats)
+template <int D, int H>
+constexpr int fwd_lds_floats() { return 2 * 128 * LDA + 2 * NT * XLD + 4 * 128 + 16 * NT + NT * STACK; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: the whole adaptive solve of 32 trajectories per block
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int H>
+__global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
+    using C = Cfg<D, H>;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* bufA = sm;
+    float* bufB = bufA + 128 * LDA;
+    float* Xs = bufB + 128 * LDA;
+    float* dWs = Xs + NT * XLD;
+    float* biasS = dWs + NT * XLD;
+    float* fT = biasS + 4 * 128;  // per-trajectory float state: t, dt, u, qold, q11
+    float* fDt = fT + NT;
+    float* fU = fDt + NT;
+    float* fQold = fU + NT;
+    float* fQ11 = fQold + NT;
+    int* iLast = reinterpret_cast<int*>(fQ11 + NT);
+    int* iDone = iLast + NT;
+    int* iNacc = iDone + NT;
+    int* iNrej = iNacc + NT;
+    int* iNstack = iNrej + NT;
+    int* iIter = iNstack + NT;
+    int* iEv = iIter + NT;
+    int* iNdraw = iEv + NT;
+    float* sLs = fT + 16 * NT;  // lengths of the RSwM stack pieces [trajectory][depth] (the increments themselves: HBM)
+
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const float* thsg = p.theta + C::NPU;
+    float wf1[C::KS1], wf2[C::KSH], wf3[C::KSH], wf4[C::KSH];
+    load_fwd_weights<D, H>(thsg, w, l, wf1, wf2, wf3, wf4);
+    load_bias_table<D, H>(thsg, biasS, tid, 256);
+    for (int i = tid; i < 2 * 128 * LDA; i += 256) bufA[i] = 0.0f;  // (bufA and bufB are contiguous)
+    const int64_t jbase = (int64_t)blockIdx.x * NT;
+    const int c0 = 2 * l, c1 = 2 * l + 1;
+    const bool v0 = c0 < D, v1 = c1 < D;
+    const float u0 = p.prep[0];
+    const float dt_init = p.prep[1];
+
+    // ---- initial state and first increment ----
+    for (int q = 0; q < NT / 4; ++q) {
+        const int tr = w * (NT / 4) + q;
+        const int64_t j = jbase + tr;
+        const bool valid = j < p.M;
+        float dt = dt_init;
+        int last = 0;
+        const float rem = p.t1 - p.t0;
+        if (dt >= rem) { dt = rem; last = 1; }
+        double n0, n1;
+        normal_pair(p.seed, p.iter, (uint32_t)j, 0u, l, n0, n1);
+        const float s = __builtin_sqrtf(dt);
+        if (v0) { Xs[tr * XLD + c0] = p.x0[c0]; dWs[tr * XLD + c0] = s * (float)n0; }
+        if (v1) { Xs[tr * XLD + c1] = p.x0[c1]; dWs[tr * XLD + c1] = s * (float)n1; }
+        if (l == 0) {
+            fT[tr] = p.t0; fDt[tr] = dt; fU[tr] = u0; fQold[tr] = p.qoldinit; fQ11[tr] = 1.0f;
+            iLast[tr] = last; iDone[tr] = valid ? 0 : 1; iNacc[tr] = 0; iNrej[tr] = 0; iNstack[tr] = 0; iIter[tr] = 0;
+            iEv[tr] = 1; iNdraw[tr] = 1;
+        }
+    }
+    __syncthreads();
+
+    const int nA = p.adaptive ? 2 : 1;
+    for (;;) {
+        // ---- S0: input columns of the (X, t) and (X, t + dt) evaluations ----
+        for (int q = 0; q < NT / 4; ++q) {
+            const int tr = w * (NT / 4) + q;
+            if (iDone[tr]) continue;
+            const float t = fT[tr], dt = fDt[tr];
+            if (v0) { const float x = Xs[tr * XLD + c0]; bufA[c0 * LDA + tr] = x; bufA[c0 * LDA + 32 + tr] = x; }
+            if (v1) { const float x = Xs[tr * XLD + c1]; bufA[c1 * LDA + tr] = x; bufA[c1 * LDA + 32 + tr] = x; }
+            if (c0 == D) {
+                bufA[D * LDA + tr] = t; bufA[D * LDA + 32 + tr] = t + dt;
+                bufA[(D + 1) * LDA + tr] = 0.0f; bufA[(D + 1) * LDA + 32 + tr] = 0.0f;
+            }
+        }
+        __syncthreads();
+        layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, nA, w, l, p.record ? p.rA1 : nullptr, C::RA, iNacc, iDone, jbase, p.cap);
+        __syncthreads();
+        layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 0, nA, w, l, p.record ? p.rA2 : nullptr, C::RA, iNacc, iDone, jbase, p.cap);
+        __syncthreads();
+        layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 0, nA, w, l, p.record ? p.rA3 : nullptr, C::RA, iNacc, iDone, jbase, p.cap);
+        __syncthreads();
+        layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 0, nA, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+        __syncthreads();
+        if (p.adaptive) {
+            // ---- S1: the Lamba probe point utilde = K + ||G||_F sqrt(dt): input column of the third evaluation ----
+            for (int q = 0; q < NT / 4; ++q) {
+                const int tr = w * (NT / 4) + q;
+                if (iDone[tr]) continue;
+                const float t = fT[tr], dt = fDt[tr];
+                const float z0 = v0 ? bufA[c0 * LDA + tr] : 0.0f, z1 = v1 ? bufA[c1 * LDA + tr] : 0.0f;
+                const float Sz = tsum2(z0 * z0, z1 * z1);
+                const float gs = __builtin_sqrtf(__builtin_fmaf((float)D * p.sig, p.sig, Sz));
+                const float cc = gs * __builtin_sqrtf(dt);
+                if (v0) bufA[c0 * LDA + 64 + tr] = Xs[tr * XLD + c0] + cc;
+                if (v1) bufA[c1 * LDA + 64 + tr] = Xs[tr * XLD + c1] + cc;
+                if (c0 == D) { bufA[D * LDA + 64 + tr] = t; bufA[(D + 1) * LDA + 64 + tr] = 0.0f; }
+            }
+            __syncthreads();
+            layer<C::KS1, true>(wf1, bufA, bufB, biasS, 2, 3, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+            __syncthreads();
+            layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 2, 3, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+            __syncthreads();
+            layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 2, 3, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+            __syncthreads();
+            layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 2, 3, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+            __syncthreads();
+        }
+        // ---- S2: the step of every live trajectory of this wavefront ----
+        int alldone = 1;
+        for (int q = 0; q < NT / 4; ++q) {
+            const int tr = w * (NT / 4) + q;
+            if (iDone[tr]) continue;
+            const int64_t j = jbase + tr;
+            float t = fT[tr], dt = fDt[tr], u = fU[tr], qold = fQold[tr], q11 = fQ11[tr];
+            int last = iLast[tr], nacc = iNacc[tr], nrej = iNrej[tr], nstack = iNstack[tr], it = iIter[tr], ndraw = iNdraw[tr];
+            uint32_t ev = (uint32_t)iEv[tr];
+            int ret = RET_SUCCESS;
+            bool fin = false;
+            float X0 = v0 ? Xs[tr * XLD + c0] : 0.0f, X1 = v1 ? Xs[tr * XLD + c1] : 0.0f;
+            float dW0 = v0 ? dWs[tr * XLD + c0] : 0.0f, dW1 = v1 ? dWs[tr * XLD + c1] : 0.0f;
+            if (it + 1 > p.maxiters) {
+                ret = RET_MAXITERS;
+                fin = true;
+            } else {
+                it += 1;
+                const float sq = __builtin_sqrtf(dt);
+                const float z0 = v0 ? bufA[c0 * LDA + tr] : 0.0f, z1 = v1 ? bufA[c1 * LDA + tr] : 0.0f;
+                const float Sz = tsum2(z0 * z0, z1 * z1);
+                const float F = p.lam * Sz;
+                const float zdW = tsum2(z0 * dW0, z1 * dW1);
+                const float Xn0 = __builtin_fmaf(p.sig, dW0, X0), Xn1 = __builtin_fmaf(p.sig, dW1, X1);
+                const float un = __builtin_fmaf(dt, F, u) + zdW;
+                float EE = 0.0f, qq = 1.0f;
+                bool accept = true;
+                if (p.adaptive) {
+                    const float y0 = v0 ? bufA[c0 * LDA + 32 + tr] : 0.0f, y1 = v1 ? bufA[c1 * LDA + 32 + tr] : 0.0f;
+                    const float F2 = p.lam * tsum2(y0 * y0, y1 * y1);
+                    const float Ed = (dt * (F2 - F)) * 0.5f;
+                    const float p0 = v0 ? bufA[c0 * LDA + 64 + tr] : 0.0f, p1 = v1 ? bufA[c1 * LDA + 64 + tr] : 0.0f;
+                    const float EnS = tsum2((p0 - z0) * (dW0 * dW0), (p1 - z1) * (dW1 * dW1));
+                    const float En = __fdiv_rn(EnS, sq) * 0.5f;
+                    const float au = fabsf(u), aun = fabsf(un);
+                    const float res = __fdiv_rn(Ed + En, __builtin_fmaf((au > aun ? au : aun), p.reltol, p.abstol));
+                    EE = __builtin_sqrtf(__fdiv_rn(res * res, (float)(D + 1)));
+                    if (EE == 0.0f) {
+                        qq = __fdiv_rn(1.0f, p.qmax);
+                        q11 = 1.0f;
+                    } else {
+                        q11 = (float)fastpow((double)EE, (double)p.beta1);
+                        qq = __fdiv_rn(q11, (float)fastpow((double)qold, (double)p.beta2));
+                        qq = __fdiv_rn(qq, p.gamma);
+                        const float lo = __fdiv_rn(1.0f, p.qmax), hi = __fdiv_rn(1.0f, p.qmin);
+                        if (qq > hi) qq = hi;
+                        if (qq < lo) qq = lo;
+                    }
+                    accept = EE <= 1.0f;
+                    if (EE != EE) { ret = RET_UNSTABLE; fin = true; }
+                }
+                if (!fin && accept) {
+                    if (nacc >= p.cap) {
+                        ret = RET_STORE_OVERFLOW;
+                        fin = true;
+                    } else {
+                        if (p.record) {
+                            const size_t col = (size_t)j * p.cap + nacc;
+                            float* rx = p.rXin + col * C::RX;
+                            float* re = p.rE4 + col * C::RE;
+                            const float coef = (2.0f * p.lam) * dt;
+                            if (v0) {  // (v1 == v0: D is even)
+                                *reinterpret_cast<float2*>(rx + c0) = float2{X0, X1};
+                                *reinterpret_cast<float2*>(re + c0) = float2{__builtin_fmaf(coef, z0, dW0), __builtin_fmaf(coef, z1, dW1)};
+                            }
+                            if (c0 == D) rx[D] = t;
+                        }
+                        nacc += 1;
+                        t = last ? p.t1 : t + dt;
+                        u = un;
+                        X0 = Xn0; X1 = Xn1;
+                        const bool bad = __any((un != un) || (Xn0 != Xn0) || (Xn1 != Xn1));
+                        if (bad) {
+                            ret = RET_UNSTABLE;
+                            fin = true;
+                        } else if (t >= p.t1) {
+                            fin = true;
+                        } else {
+                            float dtn = dt;
+                            if (p.adaptive) {
+                                qold = EE > p.qoldinit ? EE : p.qoldinit;
+                                dtn = __fdiv_rn(dt, qq);
+                                if (dtn > p.dtmax) dtn = p.dtmax;
+                            }
+                            const float rem = p.t1 - t;
+                            last = 0;
+                            if (dtn >= rem) { dtn = rem; last = 1; }
+                            // the increment over [t, t + dtn]: whole stack pieces, the last one bridged, the rest fresh
+                            float acch = 0.0f;
+                            dW0 = 0.0f; dW1 = 0.0f;
+                            float* sW = p.stackW + ((size_t)j * STACK) * XLD;
+                            float* sL = sLs + tr * STACK;
+                            while (nstack > 0 && acch < dtn) {
+                                float* top = sW + (size_t)(nstack - 1) * XLD;
+                                const float L = sL[nstack - 1];
+                                float2 tw = v0 ? *reinterpret_cast<float2*>(top + c0) : float2{0.0f, 0.0f};
+                                if (acch + L <= dtn) {
+                                    acch = acch + L;
+                                    dW0 = dW0 + tw.x; dW1 = dW1 + tw.y;
+                                    nstack -= 1;
+                                } else {
+                                    const float rl = dtn - acch, fr = __fdiv_rn(rl, L);
+                                    double n0, n1;
+                                    normal_pair(p.seed, p.iter, (uint32_t)j, ev, l, n0, n1);
+                                    ev += 1; ndraw += 1;
+                                    const float sd = __builtin_sqrtf((1.0f - fr) * rl);
+                                    const float w0 = __builtin_fmaf(fr, tw.x, sd * (float)n0), w1 = __builtin_fmaf(fr, tw.y, sd * (float)n1);
+                                    if (v0) *reinterpret_cast<float2*>(top + c0) = float2{tw.x - w0, tw.y - w1};
+                                    dW0 = dW0 + w0; dW1 = dW1 + w1;
+                                    if (l == 0) sL[nstack - 1] = L - rl;
+                                    acch = dtn;
+                                }
+                            }
+                            if (acch < dtn) {
+                                double n0, n1;
+                                normal_pair(p.seed, p.iter, (uint32_t)j, ev, l, n0, n1);
+                                ev += 1; ndraw += 1;
+                                const float sd = __builtin_sqrtf(dtn - acch);
+                                dW0 = __builtin_fmaf(sd, (float)n0, dW0);
+                                dW1 = __builtin_fmaf(sd, (float)n1, dW1);
+                            }
+                            if (!v0) { dW0 = 0.0f; dW1 = 0.0f; }
+                            dt = dtn;
+                        }
+                    }
+                } else if (!fin) {
+                    nrej += 1;
+                    float den = __fdiv_rn(q11, p.gamma);
+                    const float iq = __fdiv_rn(1.0f, p.qmin);
+                    if (iq < den) den = iq;
+                    const float dtn = __fdiv_rn(dt, den), fr = __fdiv_rn(dtn, dt);
+                    if (nstack >= STACK) {
+                        ret = RET_STACK_OVERFLOW;
+                        fin = true;
+                    } else {
+                        double n0, n1;
+                        normal_pair(p.seed, p.iter, (uint32_t)j, ev, l, n0, n1);
+                        ev += 1; ndraw += 1;
+                        const float sd = __builtin_sqrtf((1.0f - fr) * dtn);
+                        const float w0 = __builtin_fmaf(fr, dW0, sd * (float)n0), w1 = __builtin_fmaf(fr, dW1, sd * (float)n1);
+                        float* top = p.stackW + ((size_t)j * STACK + nstack) * XLD;
+                        if (v0) *reinterpret_cast<float2*>(top + c0) = float2{dW0 - w0, dW1 - w1};
+                        if (l == 0) sLs[tr * STACK + nstack] = dt - dtn;
+                        dW0 = v0 ? w0 : 0.0f; dW1 = v0 ? w1 : 0.0f;
+                        nstack += 1;
+                        dt = dtn;
+                        last = 0;
+                    }
+                }
+            }
+            if (v0) {
+                Xs[tr * XLD + c0] = X0; Xs[tr * XLD + c1] = X1;
+                dWs[tr * XLD + c0] = dW0; dWs[tr * XLD + c1] = dW1;
+            }
+            if (fin) {
+                // loss term of this trajectory: (g(X_T) - u_T)^2, g(X) = log(0.5 + 0.5 |X|^2)  (lambaem.jl:14)
+                float lj = 0.0f, ub = 0.0f;
+                if (ret == RET_SUCCESS) {
+                    const float S = tsum2(X0 * X0, X1 * X1);
+                    const float g = (float)dlog((double)__builtin_fmaf(0.5f, S, 0.5f));
+                    const float e = g - u;
+                    lj = e * e;
+                    ub = __fdiv_rn(-2.0f * e, (float)p.M);
+                }
+                if (p.XT && v0) *reinterpret_cast<float2*>(p.XT + (size_t)j * D + c0) = float2{X0, X1};
+                if (l == 0) {
+                    if (p.uT) p.uT[j] = u;
+                    p.loss_traj[j] = (double)lj;
+                    p.ubar[j] = ub;
+                    p.retcode[j] = ret;
+                    p.nacc[j] = nacc;
+                    if (p.stats) {
+                        int64_t* s = p.stats + (size_t)j * 4;
+                        s[0] = (int64_t)it * (p.adaptive ? 3 : 1); s[1] = nacc; s[2] = nrej; s[3] = ndraw;
+                    }
+                }
+            } else {
+                alldone = 0;
+            }
+            if (l == 0) {
+                fT[tr] = t; fDt[tr] = dt; fU[tr] = u; fQold[tr] = qold; fQ11[tr] = q11;
+                iLast[tr] = last; iDone[tr] = fin ? 1 : 0; iNacc[tr] = nacc; iNrej[tr] = nrej; iNstack[tr] = nstack; iIter[tr] = it;
+                iEv[tr] = (int)ev; iNdraw[tr] = ndraw;
+            }
+        }
+        if (__syncthreads_and(alldone)) break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sigma^T grad u chain for n input columns (parity aid: the matrix-core layers against the oracle's fmaf chains)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int H>
+__global__ void __launch_bounds__(256) hjb_net_kernel(const float* thsg, int64_t n, const float* xin, float* z) {
+    using C = Cfg<D, H>;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* bufA = sm;
+    float* bufB = bufA + 128 * LDA;
+    float* biasS = bufB + 128 * LDA;
+    __shared__ int zero32[32];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    float wf1[C::KS1], wf2[C::KSH], wf3[C::KSH], wf4[C::KSH];
+    load_fwd_weights<D, H>(thsg, w, l, wf1, wf2, wf3, wf4);
+    load_bias_table<D, H>(thsg, biasS, tid, 256);
+    if (tid < 32) zero32[tid] = 0;
+    for (int64_t base = (int64_t)blockIdx.x * 32; base < n; base += (int64_t)gridDim.x * 32) {
+        __syncthreads();
+        for (int i = tid; i < 128 * 32; i += 256) {
+            const int k = i >> 5, c = i & 31;
+            bufA[k * LDA + c] = (k < C::DIN && base + c < n) ? xin[(size_t)(base + c) * C::DIN + k] : 0.0f;
+        }
+        __syncthreads();
+        layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, 1, w, l, nullptr, 0, zero32, zero32, 0, 0);
+        __syncthreads();
+        layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 0, 1, w, l, nullptr, 0, zero32, zero32, 0, 0);
+        __syncthreads();
+        layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 0, 1, w, l, nullptr, 0, zero32, zero32, 0, 0);
+        __syncthreads();
+        layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 0, 1, w, l, nullptr, 0, zero32, zero32, 0, 0);
+        __syncthreads();
+        for (int i = tid; i < D * 32; i += 256) {
+            const int k = i >> 5, c = i & 31;
+            if (base + c < n) z[(size_t)(base + c) * D + k] = bufA[k * LDA + c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// prep: u0 = u0 net(x0) and the initial dt (sde_determine_initdt), one block of 128 threads, thread j = neuron j
+// (VALU fmaf chains: the same operation sequence as the matrix cores and the oracle)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int IN, int OUT, bool RELU>
+__device__ __forceinline__ void dense_valu(const float* W, const float* b, const float* a, float* o, int j) {
+    if (j < OUT) {
+        float acc = b[j];
+        for (int k = 0; k < IN; ++k) acc = __builtin_fmaf(W[j + (size_t)k * OUT], a[k], acc);
+        o[j] = RELU ? (acc > 0.0f ? acc : 0.0f) : acc;
+    }
+}
+
+template <int D, int H>
+__device__ __forceinline__ void sg_valu(const float* th, const float* xin, float* a1, float* a2, float* a3, float* z, int j) {
+    using C = Cfg<D, H>;
+    dense_valu<C::DIN, H, true>(th + C::W1, th + C::B1, xin, a1, j);
+    __syncthreads();
+    dense_valu<H, H, true>(th + C::W2, th + C::B2, a1, a2, j);
+    __syncthreads();
+    dense_valu<H, H, true>(th + C::W3, th + C::B3, a2, a3, j);
+    __syncthreads();
+    dense_valu<H, D, false>(th + C::W4, th + C::B4, a3, z, j);
+    __syncthreads();
+}
+
+template <int D, int H>
+__global__ void __launch_bounds__(128) hjb_prep_kernel(const HjbParams p) {
+    using C = Cfg<D, H>;
+    __shared__ float xin[128], a1[128], a2[128], a3[128], z0[128], zB[128], x0s[128], sc[4];
+    const int j = threadIdx.x;
+    const float* thu = p.theta;
+    const float* thsg = p.theta + C::NPU;
+    if (j < D) x0s[j] = p.x0[j];
+    __syncthreads();
+    dense_valu<D, H, true>(thu + C::U1, thu + C::C1, x0s, a1, j);
+    __syncthreads();
+    dense_valu<H, H, true>(thu + C::U2, thu + C::C2, a1, a2, j);
+    __syncthreads();
+    if (j == 0) {
+        float acc = thu[C::C3];
+        for (int k = 0; k < H; ++k) acc = __builtin_fmaf(thu[C::U3 + k], a2[k], acc);
+        sc[0] = acc;
+        p.prep[0] = acc;
+    }
+    if (j < H) { p.prep[2 + j] = a1[j]; p.prep[2 + H + j] = a2[j]; }
+    __syncthreads();
+    if (!(p.adaptive && !(p.dt_user > 0.0f))) {
+        if (j == 0) p.prep[1] = p.dt_user;
+        return;
+    }
+    const float u0 = sc[0];
+    if (j < D) xin[j] = x0s[j];
+    if (j == D) xin[D] = p.t0;
+    __syncthreads();
+    sg_valu<D, H>(thsg, xin, a1, a2, a3, z0, j);
+    // wave 0: lanes hold components 2l, 2l+1
+    const int l = j & 63, c0 = 2 * l, c1 = 2 * l + 1;
+    const bool v0 = c0 < D, v1 = c1 < D;
+    const float sku = __builtin_fmaf(fabsf(u0), p.reltol, p.abstol);
+    float dt0 = 0.0f, d1 = 0.0f, F0 = 0.0f;
+    if (j < 64) {
+        const float xa = v0 ? x0s[c0] : 0.0f, xb = v1 ? x0s[c1] : 0.0f;
+        const float ska = __builtin_fmaf(fabsf(xa), p.reltol, p.abstol), skb = __builtin_fmaf(fabsf(xb), p.reltol, p.abstol);
+        const float qa = __fdiv_rn(xa, ska), qb = __fdiv_rn(xb, skb);
+        const float qu = __fdiv_rn(u0, sku);
+        const float d0 = __builtin_sqrtf(__fdiv_rn(tsum2(v0 ? qa * qa : 0.0f, v1 ? qb * qb : 0.0f) + qu * qu, (float)(D + 1)));
+        const float za = v0 ? z0[c0] : 0.0f, zb = v1 ? z0[c1] : 0.0f;
+        F0 = p.lam * tsum2(za * za, zb * zb);
+        const float s3 = 3.0f * p.sig;
+        const float ra = __fdiv_rn(s3, ska), rb = __fdiv_rn(s3, skb);
+        const float sA = tsum2(v0 ? ra * ra : 0.0f, v1 ? rb * rb : 0.0f);
+        const float ga = __fdiv_rn(fabsf(F0) + 3.0f * fabsf(za), sku), gb = __fdiv_rn(fabsf(F0) + 3.0f * fabsf(zb), sku);
+        d1 = __builtin_sqrtf(__fdiv_rn(sA + tsum2(v0 ? ga * ga : 0.0f, v1 ? gb * gb : 0.0f), (float)((D + 1) * D)));
+        dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : __fdiv_rn(__fdiv_rn(d0, d1), 100.0f);
+        if (dt0 > p.dtmax) dt0 = p.dtmax;
+        if (j == 0) { sc[1] = dt0; sc[2] = d1; sc[3] = F0; }
+    }
+    __syncthreads();
+    dt0 = sc[1]; d1 = sc[2]; F0 = sc[3];
+    if (j == D) xin[D] = p.t0 + dt0;
+    __syncthreads();
+    sg_valu<D, H>(thsg, xin, a1, a2, a3, zB, j);
+    if (j < 64) {
+        const float xa = v0 ? x0s[c0] : 0.0f, xb = v1 ? x0s[c1] : 0.0f;
+        const float ska = __builtin_fmaf(fabsf(xa), p.reltol, p.abstol), skb = __builtin_fmaf(fabsf(xb), p.reltol, p.abstol);
+        const float za = v0 ? z0[c0] : 0.0f, zb = v1 ? z0[c1] : 0.0f;
+        const float ya = v0 ? zB[c0] : 0.0f, yb = v1 ? zB[c1] : 0.0f;
+        const float F1 = p.lam * tsum2(ya * ya, yb * yb);
+        const float s6 = 6.0f * p.sig;
+        const float ra = __fdiv_rn(s6, ska), rb = __fdiv_rn(s6, skb);
+        const float sA = tsum2(v0 ? ra * ra : 0.0f, v1 ? rb * rb : 0.0f);
+        const float dF = fabsf(F1 - F0);
+        auto gk = [&](float zz, float yy) {
+            const float g0 = 3.0f * zz, g1 = 3.0f * yy;
+            const float m1 = fabsf(g0 - g1), m2 = fabsf(g0 + g1);
+            return __fdiv_rn(dF + (m1 > m2 ? m1 : m2), sku);
+        };
+        const float ga = gk(za, ya), gb = gk(zb, yb);
+        const float d2 = __fdiv_rn(__builtin_sqrtf(__fdiv_rn(sA + tsum2(v0 ? ga * ga : 0.0f, v1 ? gb * gb : 0.0f), (float)((D + 1) * D))), dt0);
+        const float mx = d1 > d2 ? d1 : d2;
+        float dt1;
+        if (mx <= 1e-15f) {
+            dt1 = dt0 * 1e-3f;
+            if (dt1 < 1e-6f) dt1 = 1e-6f;
+        } else {
+            dt1 = (float)dpow10(-(2.0 + dlog10((double)mx)) / 1.0);
+        }
+        float r = 100.0f * dt0;
+        if (dt1 < r) r = dt1;
+        if (p.dtmax < r) r = p.dtmax;
+        if (j == 0) p.prep[1] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward: the columns (trajectory, accepted step) are independent (X never depends on theta): per tile of 32 columns
+//   delta4 = ubar (2 lambda dt z + dW), delta_l = relu'(a_l) .* (W_{l+1}^T delta_{l+1})  (matrix cores, transposed weight
+//   fragments in registers), then dW_l += delta_l [a_{l-1}; 1]^T with the columns along K (accumulators live in
+//   registers across all the block's tiles); per-block partial gradients are summed by hjb_reduce_kernel in block order.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int H>
+constexpr int bwd_lds_floats() { return 8 * 128 * LDT; }
+
+template <int KS>
+__device__ __forceinline__ void layer_bwd(const float (&wt)[KS], const float* din, float* dout, const float* mask, int w, int l) {
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float* bp = din + (l >> 5) * LDT + (l & 31);
+    static_for<0, KS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[s], bp[2 * s * LDT], acc, 0, 0, 0);
+    });
+    const int rbase = 32 * w + 4 * (l >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int idx = (rbase + (r & 3) + 8 * (r >> 2)) * LDT + (l & 31);
+        dout[idx] = mask[idx] > 0.0f ? acc[r] : 0.0f;
+    }
+}
+
+// G[nt] += delta (rows 32w.., columns as K) x act^T (rows nt*32.., columns as K)
+__device__ __forceinline__ void outer_acc(v16f (&G)[4], const float* dl, const float* act, int w, int l) {
+    const float* ap = dl + (32 * w + (l & 31)) * LDT + (l >> 5);
+    const float* bp = act + (l & 31) * LDT + (l >> 5);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float a = ap[2 * s];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) G[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[nt * 32 * LDT + 2 * s], G[nt], 0, 0, 0);
+    }
+}
+
+template <int D, int H>
+__global__ void __launch_bounds__(256) hjb_bwd_kernel(const HjbParams p) {
+    using C = Cfg<D, H>;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xinT = sm;
+    float* a1T = xinT + 128 * LDT;
+    float* a2T = a1T + 128 * LDT;
+    float* a3T = a2T + 128 * LDT;
+    float* d4T = a3T + 128 * LDT;
+    float* d3T = d4T + 128 * LDT;
+    float* d2T = d3T + 128 * LDT;
+    float* d1T = d2T + 128 * LDT;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const float* th = p.theta + C::NPU;
+    float wt4[C::KS4T], wt3[C::KSH], wt2[C::KSH];
+    {
+        const int i = 32 * w + (l & 31), kk = l >> 5;
+        static_for<0, C::KS4T>([&](auto sc) {
+            const int k = 2 * decltype(sc)::value + kk;
+            wt4[sc] = (i < H && k < D) ? th[C::W4 + k + i * D] : 0.0f;
+        });
+        static_for<0, C::KSH>([&](auto sc) {
+            const int k = 2 * decltype(sc)::value + kk;
+            const bool in = i < H && k < H;
+            wt3[sc] = in ? th[C::W3 + k + i * H] : 0.0f;
+            wt2[sc] = in ? th[C::W2 + k + i * H] : 0.0f;
+        });
+    }
+    v16f G1[4], G2[4], G3[4], G4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { G1[nt][r] = 0.0f; G2[nt][r] = 0.0f; G3[nt][r] = 0.0f; G4[nt][r] = 0.0f; }
+    for (int i = tid; i < 8 * 128 * LDT; i += 256) sm[i] = 0.0f;
+    __syncthreads();
+
+    for (int64_t j = blockIdx.x; j < p.M; j += gridDim.x) {
+        if (p.retcode[j] != RET_SUCCESS) continue;
+        const int nacc = p.nacc[j];
+        const float ub = p.ubar[j];
+        for (int t0 = 0; t0 < nacc; t0 += 32) {
+            const int nv = nacc - t0 < 32 ? nacc - t0 : 32;
+            const size_t col0 = (size_t)j * p.cap + t0;
+            __syncthreads();  // the previous tile's readers are done
+            // tiles [k][column]: thread walks k (coalesced in HBM), one column per pass
+            for (int i = tid; i < 32 * 128; i += 256) {
+                const int c = i >> 7, k = i & 127;
+                const bool on = c < nv;
+                float vx = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;
+                if (on) {
+                    if (k < C::DIN) vx = p.rXin[(col0 + c) * C::RX + k];
+                    else if (k == C::DIN) vx = 1.0f;  // bias slot
+                    if (k < H) {
+                        v1 = p.rA1[(col0 + c) * C::RA + k]; v2 = p.rA2[(col0 + c) * C::RA + k]; v3 = p.rA3[(col0 + c) * C::RA + k];
+                    } else if (k == H) {
+                        v1 = 1.0f; v2 = 1.0f; v3 = 1.0f;
+                    }
+                    if (k < D) v4 = ub * p.rE4[(col0 + c) * C::RE + k];
+                }
+                xinT[k * LDT + c] = vx; a1T[k * LDT + c] = v1; a2T[k * LDT + c] = v2; a3T[k * LDT + c] = v3; d4T[k * LDT + c] = v4;
+            }
+            __syncthreads();
+            layer_bwd<C::KS4T>(wt4, d4T, d3T, a3T, w, l);
+            __syncthreads();
+            layer_bwd<C::KSH>(wt3, d3T, d2T, a2T, w, l);
+            __syncthreads();
+            layer_bwd<C::KSH>(wt2, d2T, d1T, a1T, w, l);
+            __syncthreads();
+            // (rows H.. of the delta tiles: the transposed fragments are zero there, so the masked value is 0)
+            outer_acc(G1, d1T, xinT, w, l);
+            outer_acc(G2, d2T, a1T, w, l);
+            outer_acc(G3, d3T, a2T, w, l);
+            outer_acc(G4, d4T, a3T, w, l);
+        }
+    }
+    // ---- this block's partial gradient of theta_sg ----
+    float* row = p.part + (size_t)blockIdx.x * C::NP;
+    const int rbase = 32 * w + 4 * (l >> 5);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int k = nt * 32 + (l & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jr = rbase + (r & 3) + 8 * (r >> 2);
+            if (jr < H) {
+                if (k < C::DIN) row[C::W1 + jr + k * H] = G1[nt][r];
+                else if (k == C::DIN) row[C::B1 + jr] = G1[nt][r];
+                if (k < H) { row[C::W2 + jr + k * H] = G2[nt][r]; row[C::W3 + jr + k * H] = G3[nt][r]; }
+                else if (k == H) { row[C::B2 + jr] = G2[nt][r]; row[C::B3 + jr] = G3[nt][r]; }
+            }
+            if (jr < D) {
+                if (k < H) row[C::W4 + jr + k * D] = G4[nt][r];
+                else if (k == H) row[C::B4 + jr] = G4[nt][r];
+            }
+        }
+    }
+}
+
+// grad_sg[i] = sum over blocks (fixed order, double accumulation); loss = mean_j loss_traj (Inf if a trajectory failed);
+// the u0 chain's gradient from U = sum_j ubar_j (one extra block)
+template <int D, int H>
+__global__ void __launch_bounds__(256) hjb_reduce_kernel(const HjbParams p, int nblocks) {
+    using C = Cfg<D, H>;
+    __shared__ double shd[256];
+    __shared__ int shi[256];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < (int)gridDim.x - 1) {
+        const int i = blockIdx.x * 256 + tid;
+        if (p.grad && i < C::NP) {
+            double s = 0.0;
+            for (int b = 0; b < nblocks; ++b) s += (double)p.part[(size_t)b * C::NP + i];
+            p.grad[C::NPU + i] = (float)s;
+        }
+        return;
+    }
+    // last block: loss, failure count, U, and the u0 chain's gradient
+    double ls = 0.0, us = 0.0;
+    int nf = 0;
+    for (int64_t j = tid; j < p.M; j += 256) {
+        ls += p.loss_traj[j];
+        us += (double)p.ubar[j];
+        nf += p.retcode[j] != RET_SUCCESS;
+    }
+    shd[tid] = ls; shi[tid] = nf;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if (tid < m) { shd[tid] += shd[tid + m]; shi[tid] += shi[tid + m]; }
+        __syncthreads();
+    }
+    const double lsum = shd[0];
+    const int nfail = shi[0];
+    __syncthreads();
+    shd[tid] = us;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if (tid < m) shd[tid] += shd[tid + m];
+        __syncthreads();
+    }
+    const float U = (float)shd[0];
+    if (tid == 0) {
+        *p.loss = nfail ? __builtin_inf() : lsum / (double)p.M;
+        if (p.nfail) *p.nfail = nfail;
+    }
+    if (!p.grad) return;
+    __shared__ float d2[128], d1[128];
+    const float* thu = p.theta;
+    const float* a1 = p.prep + 2;
+    const float* a2 = p.prep + 2 + H;
+    if (tid < H) d2[tid] = a2[tid] > 0.0f ? thu[C::U3 + tid] * U : 0.0f;
+    __syncthreads();
+    if (tid < H) {
+        float acc = 0.0f;
+        for (int k = 0; k < H; ++k) acc = __builtin_fmaf(thu[C::U2 + k + (size_t)tid * H], d2[k], acc);
+        d1[tid] = a1[tid] > 0.0f ? acc : 0.0f;
+    }
+    __syncthreads();
+    float* g = p.grad;
+    for (int i = tid; i < H * D; i += 256) g[C::U1 + i] = d1[i % H] * p.x0[i / H];
+    for (int i = tid; i < H * H; i += 256) g[C::U2 + i] = d2[i % H] * a1[i / H];
+    if (tid < H) { g[C::C1 + tid] = d1[tid]; g[C::C2 + tid] = d2[tid]; g[C::U3 + tid] = U * a2[tid]; }
+    if (tid == 0) g[C::C3] = U;
+}
+
+}  // namespace hjb
+}  // namespace ude

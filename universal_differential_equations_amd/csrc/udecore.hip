@@ -99,58 +99,7 @@ __global__ void mfma_probe_kernel(const double* x, const double* y, double* out)
 
 }  // namespace ude
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-};
-
-struct ude_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    ude_launch_opts lo{};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/end, bwd start/end
-    bool ev_fwd = false, ev_bwd = false;
-    // workspaces (grow on demand, reused across calls)
-    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs, slot_glob, nfail;
-    hipEvent_t ev_sync = nullptr;  // orders work across a change of the bound stream
-    int auto_cap = 256;  // dense-store capacity used when lo.max_dense_steps == 0; grows x4 on DenseOverflow (host-buffer path)
-    int64_t trace_traj = -1;
-    int32_t trace_cap = 0;
-    // staging for the host-buffer entry points
-    DevBuf s_u0, s_theta, s_saveat, s_out, s_data, s_mask, s_gtheta, s_gu0, s_loss, s_lpt, s_stats, s_ret;
-};
-
-static int fail(ude_ctx* c, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf;
-    return code;
-}
-
-#define HIPCHK(c, call)                                                                              \
-    do {                                                                                             \
-        hipError_t e_ = (call);                                                                      \
-        if (e_ != hipSuccess) return fail(c, UDE_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
-    } while (0)
-
-static int ensure(ude_ctx* c, DevBuf& b, size_t bytes) {
-    if (bytes <= b.cap) return UDE_OK;
-    if (b.p) {
-        HIPCHK(c, hipDeviceSynchronize());  // (work queued on a previously bound stream may still use it)
-        HIPCHK(c, hipFree(b.p));
-        b.p = nullptr;
-        b.cap = 0;
-    }
-    size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) return fail(c, UDE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-    b.cap = want;
-    return UDE_OK;
-}
+#include "ude_ctx.h"
 
 // ---------------------------------------------------------------------------------------------
 // compiled model table (instances live in their own translation units, see build.py)
@@ -306,6 +255,10 @@ extern "C" void ude_destroy(ude_ctx* c) {
                       &c->s_gu0, &c->s_loss, &c->s_lpt, &c->s_stats, &c->s_ret};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (DevBuf& b : c->hj)
+        if (b.p) (void)hipFree(b.p);
+    for (auto& e : c->hj_ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     delete c;

@@ -246,6 +246,8 @@ def _saveat_grid(saveat, tspan):
             ts = np.append(ts, tspan[1])   # SciML: save_end = true for a Number saveat -> Array(sol) ends at tf
         return ts
     ts = _np(saveat)
+    if tspan[1] <= tspan[0]:
+        return ts   # (the library rejects a non-increasing tspan itself)
     if ts.ndim != 1 or ts.size == 0 or np.any(np.diff(ts) <= 0) or ts[0] < tspan[0] or ts[-1] > tspan[1]:
         raise ValueError("saveat must be strictly increasing and inside tspan = (%g, %g)" % (tspan[0], tspan[1]))
     return ts
