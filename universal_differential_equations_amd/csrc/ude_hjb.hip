@@ -12,7 +12,7 @@
 using namespace ude::hjb;
 
 namespace {
-enum { B_PREP = 0, B_XIN, B_A1, B_A2, B_A3, B_E4, B_NACC, B_STACKW, B_LT, B_UBAR, B_RET, B_PART, B_LOSS, B_STATS,
+enum { B_PREP = 0, B_XIN, B_A1, B_A2, B_A3, B_E4, B_NACC, B_STACKW, B_LT, B_UBAR, B_RET, B_PART, B_LOSS, B_QUEUE,
        S_X0, S_TH, S_GRAD, S_U0, S_UT, S_XT, S_LT, S_STATS, S_RET, S_NIN, S_NOUT };
 constexpr int KD = 100, KH = 110;  // the compiled instance (lambaem.jl:8,20)
 
@@ -95,6 +95,7 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
     if ((rc = ensure(c, c->hj[B_UBAR], sizeof(float) * M))) return rc;
     if ((rc = ensure(c, c->hj[B_RET], sizeof(int32_t) * M))) return rc;
     if ((rc = ensure(c, c->nfail, sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->hj[B_QUEUE], sizeof(int32_t)))) return rc;
     const int nblk = (int)(M < 256 ? M : 256);
     if (grad && (rc = ensure(c, c->hj[B_PART], sizeof(float) * (size_t)nblk * C::NP))) return rc;
     p.prep = (float*)c->hj[B_PREP].p;
@@ -120,7 +121,18 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
     hipLaunchKernelGGL((hjb_prep_kernel<KD, KH>), dim3(1), dim3(128), 0, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->hj_ev[0], c->stream));
-    hipLaunchKernelGGL((hjb_fwd_kernel<KD, KH>), dim3((unsigned)((M + NT - 1) / NT)), dim3(256), sh_f, c->stream, p);
+    // one block of 32 trajectory slots per CU at most; the remaining trajectories are handed out through the queue
+    int ncu = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    }
+    int64_t nblk_f = (M + NT - 1) / NT;
+    if (nblk_f > ncu) nblk_f = ncu;
+    const int32_t qstart = (int32_t)(nblk_f * NT);
+    p.queue = (int32_t*)c->hj[B_QUEUE].p;
+    HIPCHK(c, hipMemcpyAsync(p.queue, &qstart, sizeof qstart, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL((hjb_fwd_kernel<KD, KH>), dim3((unsigned)nblk_f), dim3(256), sh_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->hj_ev[1], c->stream));
     HIPCHK(c, hipEventRecord(c->hj_ev[2], c->stream));

@@ -60,6 +60,7 @@ struct HjbParams {
     float* grad;          // np floats
     double* loss;
     int32_t* nfail;
+    int32_t* queue;       // next trajectory of the ensemble (forward kernel's slot queue)
 };
 
 // ---- Philox4x32-10 + Box-Muller (oracle/sde_oracle.c restates the same sequences) ----------------------------------
@@ -145,7 +146,7 @@ __device__ __forceinline__ float tsum2(float v0, float v1) { return wave_tree_su
 // wf: this lane's weight fragments (A operand: row 32w + (l&31), k = 2s + (l>>5)); in/out: LDS tiles [row][LDA]
 template <int KS, bool RELU>
 __device__ __forceinline__ void layer(const float (&wf)[KS], const float* in, float* out, const float* bias, int nt0, int nt1, int w,
-                                      int l, float* rec, int recLD, const int* naccS, const int* doneS, int64_t jbase, int cap) {
+                                      int l, float* rec, int recLD, const int* naccS, const int* doneS, const int* jS, int cap) {
     const int rbase = 32 * w + 4 * (l >> 5);
     for (int nt = nt0; nt < nt1; ++nt) {
         v16f acc;
@@ -167,7 +168,7 @@ __device__ __forceinline__ void layer(const float (&wf)[KS], const float* in, fl
             const int tr = l & 31;
             const int slot = naccS[tr];
             if (!doneS[tr] && slot < cap) {
-                float* rp = rec + ((size_t)(jbase + tr) * cap + slot) * recLD;
+                float* rp = rec + ((size_t)jS[tr] * cap + slot) * recLD;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row0 = rbase + 8 * g;
@@ -217,19 +218,54 @@ __device__ __forceinline__ void load_bias_table(const float* th, float* biasS, i
 template <int D, int H>
 constexpr int fwd_lds_floats() { return 2 * 128 * LDA + 2 * NT * XLD + 4 * 128 + 16 * NT + NT * STACK; }
 
+// sum over the 128-padded component vector when lane m of a 16-lane row holds components 8m .. 8m+7: three in-lane
+// levels of the adjacent-pair tree, four DPP levels inside the row (every lane of the row receives the total)
+__device__ __forceinline__ float row_tree_sum(float x) {
+    x += dpp_f32<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_f32<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_f32<0x141>(x);  // row_half_mirror
+    x += dpp_f32<0x140>(x);  // row_mirror
+    return x;
+}
+__device__ __forceinline__ float tsum8(const float (&v)[8]) {
+    return row_tree_sum(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+}
+// the 8 standard normals of lane m (components 8m .. 8m+7) of a draw event: Philox chunks 2m, 2m+1
+__device__ __forceinline__ void normals8(uint64_t seed, uint32_t iter, uint32_t traj, uint32_t ev, int m, float (&n)[8]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)(2 * m + h), ev, traj, iter, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const double u1 = ((double)r[2 * g] + 0.5) * 2.3283064365386963e-10;
+            const double u2 = (double)r[2 * g + 1] * 2.3283064365386963e-10;
+            const double rad = sqrt(-2.0 * dlog(u1));
+            double co;
+            const double si = sincos2pi(u2, co);
+            n[4 * h + 2 * g] = (float)(rad * co);
+            n[4 * h + 2 * g + 1] = (float)(rad * si);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// forward: the whole adaptive solve of 32 trajectories per block
+// forward: adaptive solves in lock-step, 32 trajectory slots per block; a slot whose trajectory has finished takes the
+// next one from a global queue (atomic counter), so the block's columns stay busy until the ensemble is exhausted.
+// Scalar phases: a wavefront handles four of its eight slots at a time, one per 16-lane row, lane m of the row holding
+// components 8m .. 8m+7 (reductions = 3 in-lane + 4 DPP levels of the adjacent-pair tree; no LDS shuffles).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int D, int H>
 __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
     using C = Cfg<D, H>;
+    static_assert(D % 4 == 0 && D + 2 <= 128, "component octets per lane");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* bufA = sm;
     float* bufB = bufA + 128 * LDA;
     float* Xs = bufB + 128 * LDA;
     float* dWs = Xs + NT * XLD;
     float* biasS = dWs + NT * XLD;
-    float* fT = biasS + 4 * 128;  // per-trajectory float state: t, dt, u, qold, q11
+    float* fT = biasS + 4 * 128;  // per-slot float state: t, dt, u, qold, q11
     float* fDt = fT + NT;
     float* fU = fDt + NT;
     float* fQold = fU + NT;
@@ -242,7 +278,8 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
     int* iIter = iNstack + NT;
     int* iEv = iIter + NT;
     int* iNdraw = iEv + NT;
-    float* sLs = fT + 16 * NT;  // lengths of the RSwM stack pieces [trajectory][depth] (the increments themselves: HBM)
+    int* iJ = iNdraw + NT;        // trajectory of the slot
+    float* sLs = fT + 16 * NT;    // lengths of the RSwM stack pieces [slot][depth] (the increments themselves: HBM)
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const float* thsg = p.theta + C::NPU;
@@ -250,126 +287,165 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
     load_fwd_weights<D, H>(thsg, w, l, wf1, wf2, wf3, wf4);
     load_bias_table<D, H>(thsg, biasS, tid, 256);
     for (int i = tid; i < 2 * 128 * LDA; i += 256) bufA[i] = 0.0f;  // (bufA and bufB are contiguous)
-    const int64_t jbase = (int64_t)blockIdx.x * NT;
-    const int c0 = 2 * l, c1 = 2 * l + 1;
-    const bool v0 = c0 < D, v1 = c1 < D;
+    const int rr = l >> 4, m = l & 15, cb = 8 * m;
+    const bool lane_on = cb < D + 2;  // lane 12 (D = 100) also carries the time row D and the zero pad row D + 1
     const float u0 = p.prep[0];
     const float dt_init = p.prep[1];
+    __syncthreads();
 
-    // ---- initial state and first increment ----
-    for (int q = 0; q < NT / 4; ++q) {
-        const int tr = w * (NT / 4) + q;
-        const int64_t j = jbase + tr;
-        const bool valid = j < p.M;
+    // (re)start slot tr with trajectory j: state, first increment, input columns of the first attempt
+    auto start_slot = [&](int tr, int64_t j) {
         float dt = dt_init;
         int last = 0;
         const float rem = p.t1 - p.t0;
         if (dt >= rem) { dt = rem; last = 1; }
-        double n0, n1;
-        normal_pair(p.seed, p.iter, (uint32_t)j, 0u, l, n0, n1);
-        const float s = __builtin_sqrtf(dt);
-        if (v0) { Xs[tr * XLD + c0] = p.x0[c0]; dWs[tr * XLD + c0] = s * (float)n0; }
-        if (v1) { Xs[tr * XLD + c1] = p.x0[c1]; dWs[tr * XLD + c1] = s * (float)n1; }
-        if (l == 0) {
-            fT[tr] = p.t0; fDt[tr] = dt; fU[tr] = u0; fQold[tr] = p.qoldinit; fQ11[tr] = 1.0f;
-            iLast[tr] = last; iDone[tr] = valid ? 0 : 1; iNacc[tr] = 0; iNrej[tr] = 0; iNstack[tr] = 0; iIter[tr] = 0;
-            iEv[tr] = 1; iNdraw[tr] = 1;
+        if (lane_on) {
+            float nrm[8];
+            normals8(p.seed, p.iter, (uint32_t)j, 0u, m, nrm);
+            const float s = __builtin_sqrtf(dt);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = cb + i;
+                if (c < D) {
+                    const float x = p.x0[c];
+                    Xs[tr * XLD + c] = x;
+                    dWs[tr * XLD + c] = s * nrm[i];
+                    bufA[c * LDA + tr] = x;
+                    bufA[c * LDA + 32 + tr] = x;
+                } else if (c == D) {
+                    bufA[c * LDA + tr] = p.t0;
+                    bufA[c * LDA + 32 + tr] = p.t0 + dt;
+                } else if (c == D + 1) {
+                    bufA[c * LDA + tr] = 0.0f;
+                    bufA[c * LDA + 32 + tr] = 0.0f;
+                }
+            }
         }
+        if (m == 0) {
+            fT[tr] = p.t0; fDt[tr] = dt; fU[tr] = u0; fQold[tr] = p.qoldinit; fQ11[tr] = 1.0f;
+            iLast[tr] = last; iDone[tr] = 0; iNacc[tr] = 0; iNrej[tr] = 0; iNstack[tr] = 0; iIter[tr] = 0;
+            iEv[tr] = 1; iNdraw[tr] = 1; iJ[tr] = (int)j;
+        }
+    };
+
+    for (int ps = 0; ps < 2; ++ps) {
+        const int tr = w * 8 + ps * 4 + rr;
+        const int64_t j = (int64_t)blockIdx.x * NT + tr;
+        if (j < p.M) start_slot(tr, j);
+        else if (m == 0) { iDone[tr] = 1; iJ[tr] = 0; iNacc[tr] = 0; }
     }
     __syncthreads();
 
     const int nA = p.adaptive ? 2 : 1;
     for (;;) {
-        // ---- S0: input columns of the (X, t) and (X, t + dt) evaluations ----
-        for (int q = 0; q < NT / 4; ++q) {
-            const int tr = w * (NT / 4) + q;
-            if (iDone[tr]) continue;
-            const float t = fT[tr], dt = fDt[tr];
-            if (v0) { const float x = Xs[tr * XLD + c0]; bufA[c0 * LDA + tr] = x; bufA[c0 * LDA + 32 + tr] = x; }
-            if (v1) { const float x = Xs[tr * XLD + c1]; bufA[c1 * LDA + tr] = x; bufA[c1 * LDA + 32 + tr] = x; }
-            if (c0 == D) {
-                bufA[D * LDA + tr] = t; bufA[D * LDA + 32 + tr] = t + dt;
-                bufA[(D + 1) * LDA + tr] = 0.0f; bufA[(D + 1) * LDA + 32 + tr] = 0.0f;
-            }
-        }
+        layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, nA, w, l, p.record ? p.rA1 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
         __syncthreads();
-        layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, nA, w, l, p.record ? p.rA1 : nullptr, C::RA, iNacc, iDone, jbase, p.cap);
+        layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 0, nA, w, l, p.record ? p.rA2 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
         __syncthreads();
-        layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 0, nA, w, l, p.record ? p.rA2 : nullptr, C::RA, iNacc, iDone, jbase, p.cap);
+        layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 0, nA, w, l, p.record ? p.rA3 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
         __syncthreads();
-        layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 0, nA, w, l, p.record ? p.rA3 : nullptr, C::RA, iNacc, iDone, jbase, p.cap);
-        __syncthreads();
-        layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 0, nA, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+        layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 0, nA, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
         __syncthreads();
         if (p.adaptive) {
             // ---- S1: the Lamba probe point utilde = K + ||G||_F sqrt(dt): input column of the third evaluation ----
-            for (int q = 0; q < NT / 4; ++q) {
-                const int tr = w * (NT / 4) + q;
-                if (iDone[tr]) continue;
-                const float t = fT[tr], dt = fDt[tr];
-                const float z0 = v0 ? bufA[c0 * LDA + tr] : 0.0f, z1 = v1 ? bufA[c1 * LDA + tr] : 0.0f;
-                const float Sz = tsum2(z0 * z0, z1 * z1);
-                const float gs = __builtin_sqrtf(__builtin_fmaf((float)D * p.sig, p.sig, Sz));
-                const float cc = gs * __builtin_sqrtf(dt);
-                if (v0) bufA[c0 * LDA + 64 + tr] = Xs[tr * XLD + c0] + cc;
-                if (v1) bufA[c1 * LDA + 64 + tr] = Xs[tr * XLD + c1] + cc;
-                if (c0 == D) { bufA[D * LDA + 64 + tr] = t; bufA[(D + 1) * LDA + 64 + tr] = 0.0f; }
+            for (int ps = 0; ps < 2; ++ps) {
+                const int tr = w * 8 + ps * 4 + rr;
+                if (!iDone[tr]) {
+                    const float t = fT[tr], dt = fDt[tr];
+                    float zz[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float z = (cb + i < D) ? bufA[(cb + i) * LDA + tr] : 0.0f;
+                        zz[i] = z * z;
+                    }
+                    const float Sz = tsum8(zz);
+                    const float gs = __builtin_sqrtf(__builtin_fmaf((float)D * p.sig, p.sig, Sz));
+                    const float cc = gs * __builtin_sqrtf(dt);
+                    if (lane_on) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int c = cb + i;
+                            if (c < D) bufA[c * LDA + 64 + tr] = Xs[tr * XLD + c] + cc;
+                            else if (c == D) bufA[c * LDA + 64 + tr] = t;
+                            else if (c == D + 1) bufA[c * LDA + 64 + tr] = 0.0f;
+                        }
+                    }
+                }
             }
             __syncthreads();
-            layer<C::KS1, true>(wf1, bufA, bufB, biasS, 2, 3, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+            layer<C::KS1, true>(wf1, bufA, bufB, biasS, 2, 3, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
             __syncthreads();
-            layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 2, 3, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+            layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 2, 3, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
             __syncthreads();
-            layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 2, 3, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+            layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 2, 3, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
             __syncthreads();
-            layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 2, 3, w, l, nullptr, 0, iNacc, iDone, jbase, p.cap);
+            layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 2, 3, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
             __syncthreads();
         }
-        // ---- S2: the step of every live trajectory of this wavefront ----
+        // ---- S2: the step of every live slot (four per wavefront pass); writes the next attempt's input columns ----
         int alldone = 1;
-        for (int q = 0; q < NT / 4; ++q) {
-            const int tr = w * (NT / 4) + q;
+        for (int ps = 0; ps < 2; ++ps) {
+            const int tr = w * 8 + ps * 4 + rr;
             if (iDone[tr]) continue;
-            const int64_t j = jbase + tr;
+            const int64_t j = iJ[tr];
             float t = fT[tr], dt = fDt[tr], u = fU[tr], qold = fQold[tr], q11 = fQ11[tr];
             int last = iLast[tr], nacc = iNacc[tr], nrej = iNrej[tr], nstack = iNstack[tr], it = iIter[tr], ndraw = iNdraw[tr];
             uint32_t ev = (uint32_t)iEv[tr];
             int ret = RET_SUCCESS;
             bool fin = false;
-            float X0 = v0 ? Xs[tr * XLD + c0] : 0.0f, X1 = v1 ? Xs[tr * XLD + c1] : 0.0f;
-            float dW0 = v0 ? dWs[tr * XLD + c0] : 0.0f, dW1 = v1 ? dWs[tr * XLD + c1] : 0.0f;
+            float X[8], dW[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool on = cb + i < D;
+                X[i] = on ? Xs[tr * XLD + cb + i] : 0.0f;
+                dW[i] = on ? dWs[tr * XLD + cb + i] : 0.0f;
+            }
             if (it + 1 > p.maxiters) {
                 ret = RET_MAXITERS;
                 fin = true;
             } else {
                 it += 1;
                 const float sq = __builtin_sqrtf(dt);
-                const float z0 = v0 ? bufA[c0 * LDA + tr] : 0.0f, z1 = v1 ? bufA[c1 * LDA + tr] : 0.0f;
-                const float Sz = tsum2(z0 * z0, z1 * z1);
+                float z[8], tmp[8], Xn[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) z[i] = (cb + i < D) ? bufA[(cb + i) * LDA + tr] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tmp[i] = z[i] * z[i];
+                const float Sz = tsum8(tmp);
                 const float F = p.lam * Sz;
-                const float zdW = tsum2(z0 * dW0, z1 * dW1);
-                const float Xn0 = __builtin_fmaf(p.sig, dW0, X0), Xn1 = __builtin_fmaf(p.sig, dW1, X1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tmp[i] = z[i] * dW[i];
+                const float zdW = tsum8(tmp);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) Xn[i] = __builtin_fmaf(p.sig, dW[i], X[i]);
                 const float un = __builtin_fmaf(dt, F, u) + zdW;
                 float EE = 0.0f, qq = 1.0f;
                 bool accept = true;
                 if (p.adaptive) {
-                    const float y0 = v0 ? bufA[c0 * LDA + 32 + tr] : 0.0f, y1 = v1 ? bufA[c1 * LDA + 32 + tr] : 0.0f;
-                    const float F2 = p.lam * tsum2(y0 * y0, y1 * y1);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float y = (cb + i < D) ? bufA[(cb + i) * LDA + 32 + tr] : 0.0f;
+                        tmp[i] = y * y;
+                    }
+                    const float F2 = p.lam * tsum8(tmp);
                     const float Ed = (dt * (F2 - F)) * 0.5f;
-                    const float p0 = v0 ? bufA[c0 * LDA + 64 + tr] : 0.0f, p1 = v1 ? bufA[c1 * LDA + 64 + tr] : 0.0f;
-                    const float EnS = tsum2((p0 - z0) * (dW0 * dW0), (p1 - z1) * (dW1 * dW1));
-                    const float En = __fdiv_rn(EnS, sq) * 0.5f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float y = (cb + i < D) ? bufA[(cb + i) * LDA + 64 + tr] : 0.0f;
+                        tmp[i] = (y - z[i]) * (dW[i] * dW[i]);
+                    }
+                    const float En = (tsum8(tmp) / sq) * 0.5f;
                     const float au = fabsf(u), aun = fabsf(un);
-                    const float res = __fdiv_rn(Ed + En, __builtin_fmaf((au > aun ? au : aun), p.reltol, p.abstol));
-                    EE = __builtin_sqrtf(__fdiv_rn(res * res, (float)(D + 1)));
+                    const float res = (Ed + En) / __builtin_fmaf((au > aun ? au : aun), p.reltol, p.abstol);
+                    EE = __builtin_sqrtf((res * res) / (float)(D + 1));
                     if (EE == 0.0f) {
-                        qq = __fdiv_rn(1.0f, p.qmax);
+                        qq = 1.0f / p.qmax;
                         q11 = 1.0f;
                     } else {
                         q11 = (float)fastpow((double)EE, (double)p.beta1);
-                        qq = __fdiv_rn(q11, (float)fastpow((double)qold, (double)p.beta2));
-                        qq = __fdiv_rn(qq, p.gamma);
-                        const float lo = __fdiv_rn(1.0f, p.qmax), hi = __fdiv_rn(1.0f, p.qmin);
+                        qq = q11 / (float)fastpow((double)qold, (double)p.beta2);
+                        qq = qq / p.gamma;
+                        const float lo = 1.0f / p.qmax, hi = 1.0f / p.qmin;
                         if (qq > hi) qq = hi;
                         if (qq < lo) qq = lo;
                     }
@@ -381,22 +457,34 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                         ret = RET_STORE_OVERFLOW;
                         fin = true;
                     } else {
-                        if (p.record) {
+                        if (p.record && lane_on) {
                             const size_t col = (size_t)j * p.cap + nacc;
-                            float* rx = p.rXin + col * C::RX;
-                            float* re = p.rE4 + col * C::RE;
+                            float* rx = p.rXin + col * C::RX + cb;
                             const float coef = (2.0f * p.lam) * dt;
-                            if (v0) {  // (v1 == v0: D is even)
-                                *reinterpret_cast<float2*>(rx + c0) = float2{X0, X1};
-                                *reinterpret_cast<float2*>(re + c0) = float2{__builtin_fmaf(coef, z0, dW0), __builtin_fmaf(coef, z1, dW1)};
+                            if (cb + 8 <= D) {
+                                *reinterpret_cast<float4*>(rx) = float4{X[0], X[1], X[2], X[3]};
+                                *reinterpret_cast<float4*>(rx + 4) = float4{X[4], X[5], X[6], X[7]};
+                                float* re = p.rE4 + col * C::RE + cb;
+                                *reinterpret_cast<float4*>(re) = float4{__builtin_fmaf(coef, z[0], dW[0]), __builtin_fmaf(coef, z[1], dW[1]),
+                                                                        __builtin_fmaf(coef, z[2], dW[2]), __builtin_fmaf(coef, z[3], dW[3])};
+                                *reinterpret_cast<float4*>(re + 4) = float4{__builtin_fmaf(coef, z[4], dW[4]), __builtin_fmaf(coef, z[5], dW[5]),
+                                                                            __builtin_fmaf(coef, z[6], dW[6]), __builtin_fmaf(coef, z[7], dW[7])};
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const int c = cb + i;
+                                    if (c < D) { rx[i] = X[i]; p.rE4[col * C::RE + c] = __builtin_fmaf(coef, z[i], dW[i]); }
+                                    else if (c == D) rx[i] = t;
+                                }
                             }
-                            if (c0 == D) rx[D] = t;
                         }
                         nacc += 1;
                         t = last ? p.t1 : t + dt;
                         u = un;
-                        X0 = Xn0; X1 = Xn1;
-                        const bool bad = __any((un != un) || (Xn0 != Xn0) || (Xn1 != Xn1));
+                        float badf = (un != un) ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { X[i] = Xn[i]; badf += (Xn[i] != Xn[i]) ? 1.0f : 0.0f; }
+                        const bool bad = row_tree_sum(badf) > 0.0f;
                         if (bad) {
                             ret = RET_UNSTABLE;
                             fin = true;
@@ -406,7 +494,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                             float dtn = dt;
                             if (p.adaptive) {
                                 qold = EE > p.qoldinit ? EE : p.qoldinit;
-                                dtn = __fdiv_rn(dt, qq);
+                                dtn = dt / qq;
                                 if (dtn > p.dtmax) dtn = p.dtmax;
                             }
                             const float rem = p.t1 - t;
@@ -414,83 +502,107 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                             if (dtn >= rem) { dtn = rem; last = 1; }
                             // the increment over [t, t + dtn]: whole stack pieces, the last one bridged, the rest fresh
                             float acch = 0.0f;
-                            dW0 = 0.0f; dW1 = 0.0f;
-                            float* sW = p.stackW + ((size_t)j * STACK) * XLD;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) dW[i] = 0.0f;
+                            float* sW = p.stackW + ((size_t)j * STACK) * XLD + cb;
                             float* sL = sLs + tr * STACK;
                             while (nstack > 0 && acch < dtn) {
                                 float* top = sW + (size_t)(nstack - 1) * XLD;
                                 const float L = sL[nstack - 1];
-                                float2 tw = v0 ? *reinterpret_cast<float2*>(top + c0) : float2{0.0f, 0.0f};
+                                float tw[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) tw[i] = 0.0f;
+                                if (cb < D) {
+                                    const float4 a = *reinterpret_cast<float4*>(top), b = *reinterpret_cast<float4*>(top + 4);
+                                    tw[0] = a.x; tw[1] = a.y; tw[2] = a.z; tw[3] = a.w; tw[4] = b.x; tw[5] = b.y; tw[6] = b.z; tw[7] = b.w;
+                                }
                                 if (acch + L <= dtn) {
                                     acch = acch + L;
-                                    dW0 = dW0 + tw.x; dW1 = dW1 + tw.y;
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) dW[i] = dW[i] + tw[i];
                                     nstack -= 1;
                                 } else {
-                                    const float rl = dtn - acch, fr = __fdiv_rn(rl, L);
-                                    double n0, n1;
-                                    normal_pair(p.seed, p.iter, (uint32_t)j, ev, l, n0, n1);
+                                    const float rl = dtn - acch, fr = rl / L;
+                                    float nrm[8];
+                                    if (cb < D) normals8(p.seed, p.iter, (uint32_t)j, ev, m, nrm);
                                     ev += 1; ndraw += 1;
                                     const float sd = __builtin_sqrtf((1.0f - fr) * rl);
-                                    const float w0 = __builtin_fmaf(fr, tw.x, sd * (float)n0), w1 = __builtin_fmaf(fr, tw.y, sd * (float)n1);
-                                    if (v0) *reinterpret_cast<float2*>(top + c0) = float2{tw.x - w0, tw.y - w1};
-                                    dW0 = dW0 + w0; dW1 = dW1 + w1;
-                                    if (l == 0) sL[nstack - 1] = L - rl;
+                                    if (cb < D) {
+                                        float wv[8];
+#pragma unroll
+                                        for (int i = 0; i < 8; ++i) {
+                                            wv[i] = __builtin_fmaf(fr, tw[i], sd * nrm[i]);
+                                            dW[i] = dW[i] + wv[i];
+                                        }
+                                        *reinterpret_cast<float4*>(top) = float4{tw[0] - wv[0], tw[1] - wv[1], tw[2] - wv[2], tw[3] - wv[3]};
+                                        *reinterpret_cast<float4*>(top + 4) = float4{tw[4] - wv[4], tw[5] - wv[5], tw[6] - wv[6], tw[7] - wv[7]};
+                                    }
+                                    if (m == 0) sL[nstack - 1] = L - rl;
                                     acch = dtn;
                                 }
                             }
                             if (acch < dtn) {
-                                double n0, n1;
-                                normal_pair(p.seed, p.iter, (uint32_t)j, ev, l, n0, n1);
-                                ev += 1; ndraw += 1;
                                 const float sd = __builtin_sqrtf(dtn - acch);
-                                dW0 = __builtin_fmaf(sd, (float)n0, dW0);
-                                dW1 = __builtin_fmaf(sd, (float)n1, dW1);
+                                if (cb < D) {
+                                    float nrm[8];
+                                    normals8(p.seed, p.iter, (uint32_t)j, ev, m, nrm);
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) dW[i] = __builtin_fmaf(sd, nrm[i], dW[i]);
+                                }
+                                ev += 1; ndraw += 1;
                             }
-                            if (!v0) { dW0 = 0.0f; dW1 = 0.0f; }
                             dt = dtn;
                         }
                     }
                 } else if (!fin) {
                     nrej += 1;
-                    float den = __fdiv_rn(q11, p.gamma);
-                    const float iq = __fdiv_rn(1.0f, p.qmin);
+                    float den = q11 / p.gamma;
+                    const float iq = 1.0f / p.qmin;
                     if (iq < den) den = iq;
-                    const float dtn = __fdiv_rn(dt, den), fr = __fdiv_rn(dtn, dt);
+                    const float dtn = dt / den, fr = dtn / dt;
                     if (nstack >= STACK) {
                         ret = RET_STACK_OVERFLOW;
                         fin = true;
                     } else {
-                        double n0, n1;
-                        normal_pair(p.seed, p.iter, (uint32_t)j, ev, l, n0, n1);
-                        ev += 1; ndraw += 1;
                         const float sd = __builtin_sqrtf((1.0f - fr) * dtn);
-                        const float w0 = __builtin_fmaf(fr, dW0, sd * (float)n0), w1 = __builtin_fmaf(fr, dW1, sd * (float)n1);
-                        float* top = p.stackW + ((size_t)j * STACK + nstack) * XLD;
-                        if (v0) *reinterpret_cast<float2*>(top + c0) = float2{dW0 - w0, dW1 - w1};
-                        if (l == 0) sLs[tr * STACK + nstack] = dt - dtn;
-                        dW0 = v0 ? w0 : 0.0f; dW1 = v0 ? w1 : 0.0f;
+                        if (cb < D) {
+                            float nrm[8], wv[8];
+                            normals8(p.seed, p.iter, (uint32_t)j, ev, m, nrm);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) wv[i] = __builtin_fmaf(fr, dW[i], sd * nrm[i]);
+                            float* top = p.stackW + ((size_t)j * STACK + nstack) * XLD + cb;
+                            *reinterpret_cast<float4*>(top) = float4{dW[0] - wv[0], dW[1] - wv[1], dW[2] - wv[2], dW[3] - wv[3]};
+                            *reinterpret_cast<float4*>(top + 4) = float4{dW[4] - wv[4], dW[5] - wv[5], dW[6] - wv[6], dW[7] - wv[7]};
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) dW[i] = wv[i];
+                        }
+                        ev += 1; ndraw += 1;
+                        if (m == 0) sLs[tr * STACK + nstack] = dt - dtn;
                         nstack += 1;
                         dt = dtn;
                         last = 0;
                     }
                 }
             }
-            if (v0) {
-                Xs[tr * XLD + c0] = X0; Xs[tr * XLD + c1] = X1;
-                dWs[tr * XLD + c0] = dW0; dWs[tr * XLD + c1] = dW1;
-            }
             if (fin) {
                 // loss term of this trajectory: (g(X_T) - u_T)^2, g(X) = log(0.5 + 0.5 |X|^2)  (lambaem.jl:14)
                 float lj = 0.0f, ub = 0.0f;
                 if (ret == RET_SUCCESS) {
-                    const float S = tsum2(X0 * X0, X1 * X1);
+                    float tmp[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) tmp[i] = X[i] * X[i];
+                    const float S = tsum8(tmp);
                     const float g = (float)dlog((double)__builtin_fmaf(0.5f, S, 0.5f));
                     const float e = g - u;
                     lj = e * e;
-                    ub = __fdiv_rn(-2.0f * e, (float)p.M);
+                    ub = (-2.0f * e) / (float)p.M;
                 }
-                if (p.XT && v0) *reinterpret_cast<float2*>(p.XT + (size_t)j * D + c0) = float2{X0, X1};
-                if (l == 0) {
+                if (p.XT && cb < D) {
+                    float* xo = p.XT + (size_t)j * D + cb;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) if (cb + i < D) xo[i] = X[i];
+                }
+                if (m == 0) {
                     if (p.uT) p.uT[j] = u;
                     p.loss_traj[j] = (double)lj;
                     p.ubar[j] = ub;
@@ -501,13 +613,41 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                         s[0] = (int64_t)it * (p.adaptive ? 3 : 1); s[1] = nacc; s[2] = nrej; s[3] = ndraw;
                     }
                 }
+                // the slot takes the next trajectory of the ensemble, if any
+                int jn = 0;
+                if (m == 0) jn = atomicAdd(p.queue, 1);
+                jn = __shfl(jn, l & 48, 64);
+                if (jn < p.M) {
+                    start_slot(tr, jn);
+                    alldone = 0;
+                } else if (m == 0) {
+                    iDone[tr] = 1;
+                }
             } else {
                 alldone = 0;
-            }
-            if (l == 0) {
-                fT[tr] = t; fDt[tr] = dt; fU[tr] = u; fQold[tr] = qold; fQ11[tr] = q11;
-                iLast[tr] = last; iDone[tr] = fin ? 1 : 0; iNacc[tr] = nacc; iNrej[tr] = nrej; iNstack[tr] = nstack; iIter[tr] = it;
-                iEv[tr] = (int)ev; iNdraw[tr] = ndraw;
+                if (lane_on) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = cb + i;
+                        if (c < D) {
+                            Xs[tr * XLD + c] = X[i];
+                            dWs[tr * XLD + c] = dW[i];
+                            bufA[c * LDA + tr] = X[i];
+                            bufA[c * LDA + 32 + tr] = X[i];
+                        } else if (c == D) {
+                            bufA[c * LDA + tr] = t;
+                            bufA[c * LDA + 32 + tr] = t + dt;
+                        } else if (c == D + 1) {
+                            bufA[c * LDA + tr] = 0.0f;
+                            bufA[c * LDA + 32 + tr] = 0.0f;
+                        }
+                    }
+                }
+                if (m == 0) {
+                    fT[tr] = t; fDt[tr] = dt; fU[tr] = u; fQold[tr] = qold; fQ11[tr] = q11;
+                    iLast[tr] = last; iNacc[tr] = nacc; iNrej[tr] = nrej; iNstack[tr] = nstack; iIter[tr] = it;
+                    iEv[tr] = (int)ev; iNdraw[tr] = ndraw;
+                }
             }
         }
         if (__syncthreads_and(alldone)) break;
@@ -537,13 +677,13 @@ __global__ void __launch_bounds__(256) hjb_net_kernel(const float* thsg, int64_t
             bufA[k * LDA + c] = (k < C::DIN && base + c < n) ? xin[(size_t)(base + c) * C::DIN + k] : 0.0f;
         }
         __syncthreads();
-        layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, 1, w, l, nullptr, 0, zero32, zero32, 0, 0);
+        layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, 1, w, l, nullptr, 0, zero32, zero32, zero32, 0);
         __syncthreads();
-        layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 0, 1, w, l, nullptr, 0, zero32, zero32, 0, 0);
+        layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 0, 1, w, l, nullptr, 0, zero32, zero32, zero32, 0);
         __syncthreads();
-        layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 0, 1, w, l, nullptr, 0, zero32, zero32, 0, 0);
+        layer<C::KSH, true>(wf3, bufA, bufB, biasS + 256, 0, 1, w, l, nullptr, 0, zero32, zero32, zero32, 0);
         __syncthreads();
-        layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 0, 1, w, l, nullptr, 0, zero32, zero32, 0, 0);
+        layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 0, 1, w, l, nullptr, 0, zero32, zero32, zero32, 0);
         __syncthreads();
         for (int i = tid; i < D * 32; i += 256) {
             const int k = i >> 5, c = i & 31;
