@@ -276,6 +276,8 @@ def main():
     ap.add_argument("--net", default="s1", choices=["s1", "tanh32"],
                     help="lv workload: s1 = the reference 2-5-5-5-2 rbf chain (headline), tanh32 = BASELINE's '2-layer tanh' 2-32-2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allreduce", default="torch", choices=["torch", "udecore"],
+                    help="N > 1: transport of the one all-reduce per gradient (torch.distributed nccl, or libudecore's RCCL binding)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -293,7 +295,7 @@ def main():
         return run_hjb(a, rank, world, local, device, dist)
     import universal_differential_equations_amd as U
     from universal_differential_equations_amd import models
-    from universal_differential_equations_amd.parallel import allreduce_grad
+    from universal_differential_equations_amd.parallel import Comm, allreduce_payload, pack_payload
 
     N = a.traj or {"lv": 10000, "seir": 6250, "kpp": 256}[a.workload]
     mask = None
@@ -322,10 +324,24 @@ def main():
                           "%d PDEs per GPU, Tsit5 default tol, 11 save points, loss + %s gradient"}[a.workload] % (N, SENSE_NAME[a.sensealg])
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)
 
+    # ONE collective per gradient: double[np + 4] = [grad; loss; sum nf; sum naccept; sum nreject].
+    # --allreduce udecore: libudecore's own RCCL binding (ude_allreduce_grad, what a non-Python host uses), bootstrapped
+    # over the torch.distributed group; default: torch.distributed (backend "nccl" = the same RCCL)
+    comm = None
+    if dist is not None and a.allreduce == "udecore":
+        comm = Comm.from_torch_dist(ens.eng, dist)
+
     def step():
         g = ens.loss_grad(theta)
-        allreduce_grad(g, dist)
-        return g
+        if dist is None:
+            return g
+        buf = pack_payload(g, ens.stats)
+        if comm is not None:
+            ens.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            comm.allreduce(buf)
+        else:
+            allreduce_payload(buf, dist)
+        return buf
 
     def barrier():
         if dist is not None:

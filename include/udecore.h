@@ -214,6 +214,25 @@ int ude_hjb_debug_read(ude_ctx* ctx, int32_t which, int64_t offset_floats, int64
 /* device time (ms) of the forward and backward kernels of the most recent ude_hjb_loss_grad* call (HIP events on the stream) */
 int ude_hjb_last_kernel_ms(ude_ctx* ctx, float* fwd_ms, float* bwd_ms);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Multi-GPU: trajectories shard in contiguous blocks, theta is replicated, and the ONE exchange per
+ * gradient is all-reduce(sum) of double[np + 4] = gradient (+) loss (+) (sum nf, sum naccept, sum nreject).  The
+ * reference is single-process CPU Julia: these entry points replace nothing, they are what an
+ * `EnsembleMI355(devices = 0:7)` ensemble algorithm calls after ude_loss_grad_ensemble_dev on every device.
+ *   one process per GPU:   ude_comm_unique_id on rank 0 -> share the 128 bytes -> ude_comm_create on every rank
+ *   one process, N GPUs:   ude_create per device -> ude_comm_create_local -> ude_allreduce_grad_local (RCCL, grouped)
+ *                          or ude_allreduce_grad_p2p (one-shot peer reads over xGMI, fixed rank order: deterministic
+ *                          fp64 sum, identical bits on every device)
+ * All calls enqueue on the contexts' streams. */
+typedef struct ude_comm ude_comm;
+int ude_comm_unique_id(char id[128]);
+int ude_comm_create(ude_ctx* ctx, int32_t nranks, int32_t rank, const char id[128], ude_comm** out);
+int ude_comm_create_local(int32_t ndev, ude_ctx* const* ctxs, ude_comm** out /* ndev */);
+void ude_comm_destroy(ude_comm* comm);
+int ude_allreduce_grad(ude_comm* comm, double* buf_dev, int64_t n);
+int ude_allreduce_grad_local(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n);
+int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n);
+
 /* Failure accounting of the most recent gradient call on this context (blocks on the context's stream): the number
  * of trajectories whose retcode is not Success.  Such trajectories contribute nothing to the gradient and the
  * ensemble loss is +Inf (the reference's solve would abort / return an Inf loss), so a training loop can never

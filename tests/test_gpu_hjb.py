@@ -108,14 +108,21 @@ def test_failures_are_loud_and_unsupported_sizes_rejected():
 
 def test_training_reaches_the_scripts_acceptance_gate():
     """lambaem.jl:33-48: train with ADAM(0.03), m = 100 trajectories, compare u0(x0) with the Monte-Carlo reference
-    solution, `@test error_l2 < 0.2`.  Tolerances: the script's 1e-4 make this restatement of Lamba's estimator take
-    ~4e5 steps per trajectory (oracle/sde_oracle.h); the gate is checked at abstol = reltol = 0.1 (~250 steps)."""
+    solution, `@test error_l2 < 0.2`.  Two honest deviations from the script's call, both forced by this restatement
+    (oracle/sde_oracle.h): (i) tolerances -- the script's 1e-4 make Lamba's estimator take ~4e5 steps per trajectory;
+    the gate is checked at abstol = reltol = 0.1 (~250 -> ~100 steps as the chains train); (ii) iterations -- with
+    x0 = 0 and zero-initialised biases u0(x0) moves only through the output bias, ~0.004 per ADAM step: the CPU
+    restatement crosses the gate after ~1000 iterations and converges to 4.59 (0.3 %) by ~1300, so the test trains for
+    1500 (the script's maxiters = 500 ends at u0 ~ 2.0 here).  The same run on the CPU oracle: tools/cpu_train_hjb.py."""
     alg, th, rng = setup(0)
     prob = pde.TerminalPDEProblem(pde.hjb(1.0), np.zeros(D_), (0.0, 1.0))
-    ans, theta, losses = pde.solve(prob, alg, th, maxiters=250, trajectories=100, alg=pde.LambaEM(), pabstol=1e-2,
-                                   abstol=0.1, reltol=0.1, seed=0)
+    seen = []
+    ans, theta, losses = pde.solve(prob, alg, th, maxiters=1500, trajectories=100, alg=pde.LambaEM(), pabstol=1e-2,
+                                   abstol=0.1, reltol=0.1, seed=0, callback=lambda it, l, u0: seen.append(u0) and False)
     ref = pde.u_analytical(prob.x0, 1.0, 1.0, np.random.default_rng(1))
     error_l2 = np.sqrt((ans - ref) ** 2 / ans ** 2)
-    print("u0 = %.4f analytical = %.4f error_l2 = %.4f loss %g -> %g (%d its)" % (ans, ref, error_l2, losses[0], losses[-1], len(losses)))
+    print("u0 = %.4f analytical = %.4f error_l2 = %.4f loss %g -> %g (%d its; u0 after 500 its: %.3f)"
+          % (ans, ref, error_l2, losses[0], losses[-1], len(losses), seen[min(500, len(seen) - 1)]))
     assert abs(ref - 4.59) < 0.02          # Han, Jentzen, E (2018): u(0, 0) = 4.5901
-    assert error_l2 < 0.2
+    assert error_l2 < 0.2                  # the script's gate
+    assert error_l2 < 0.03 and losses[-1] < 0.2   # and it actually converges to the reference solution

@@ -1,5 +1,6 @@
-"""N>1 path on CPU: trajectories shard by contiguous blocks, one all-reduce(sum) of [grad; loss] per gradient
-(SURVEY.md 8(e)).  world_size 2, gloo backend; the per-rank compute is the CPU oracle (tests only)."""
+"""N>1 path on CPU: trajectories shard by contiguous blocks, ONE all-reduce(sum) of double[np + 4] =
+[grad; loss; sum nf; sum naccept; sum nreject] per gradient.  world_size 2, gloo backend; the
+per-rank compute is the CPU oracle (tests only: no GPU here; the device path of the same payload is tests/test_gpu_comm.py)."""
 import os
 import socket
 import sys
@@ -39,14 +40,14 @@ def _worker(rank, world, port, n_total, q):
     import torch.distributed as dist
 
     import _oracle as O
-    from universal_differential_equations_amd.parallel import allreduce_grad, shard_bounds
+    from universal_differential_equations_amd.parallel import allreduce_payload, pack_payload, shard_bounds
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     th, u0, t, data = _inputs(n_total)
     lo, hi = shard_bounds(n_total, world, rank)
     r = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(O.TSIT5, 1e-6, 1e-6), u0[lo:hi], [t[0], t[-1]], th, t, data[lo:hi])
-    buf = torch.tensor(np.concatenate([r["grad_theta"], [r["loss"]]]))
-    allreduce_grad(buf, dist)
+    buf = torch.tensor(pack_payload(np.concatenate([r["grad_theta"], [r["loss"]]]), r["stats"]))
+    allreduce_payload(buf, dist)
     if rank == 0:
         q.put(buf.numpy().copy())
     dist.barrier()
@@ -83,4 +84,7 @@ def test_two_rank_gradient_equals_single_process():
     th, u0, t, data = _inputs(n_total)
     ref = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(O.TSIT5, 1e-6, 1e-6), u0, [t[0], t[-1]], th, t, data)
     full = np.concatenate([ref["grad_theta"], [ref["loss"]]])
-    assert np.abs(got - full).max() <= 1e-12 * np.abs(full).max()
+    assert got.shape == (full.size + 3,)
+    assert np.abs(got[:-3] - full).max() <= 1e-12 * np.abs(full).max()
+    st = ref["stats"].sum(0)
+    assert got[-3:].tolist() == [st[0] + st[4], st[1] + st[5], st[2] + st[6]]      # counters ride in the same payload, exactly

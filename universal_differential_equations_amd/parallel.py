@@ -1,7 +1,18 @@
-"""Multi-GPU: trajectories are independent units sharing theta, so an ensemble shards by contiguous
-blocks of trajectories (one process per GPU) and the only exchange per gradient is one all-reduce(sum)
-of [grad(np); loss] over RCCL.  The forward-only path has no collective."""
+"""Multi-GPU (SURVEY.md 8(e)): trajectories are independent units sharing theta, so an ensemble shards by contiguous
+blocks of trajectories and the only exchange per gradient is ONE all-reduce(sum) of double[np + 4] =
+[grad(np); loss; sum nf; sum naccept; sum nreject].  The forward-only path has no collective.
+
+Two transports behind the same payload:
+  * `Comm` -- libudecore's own RCCL binding / one-shot P2P reducer (include/udecore.h ude_comm_*, ude_allreduce_grad*):
+    what a non-Python host (the Julia shim) uses; `Comm.from_torch_dist` bootstraps the RCCL unique id over an existing
+    torch.distributed group, `Comm.local` builds the communicators of all devices of one process.
+  * torch.distributed (backend "nccl" = RCCL; "gloo" for the CPU tests) through `allreduce_payload`.
+"""
+import ctypes as C
+
 import numpy as np
+
+from . import _lib
 
 
 def shard_bounds(n_total, world, rank):
@@ -11,20 +22,77 @@ def shard_bounds(n_total, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def allreduce_grad(buf, dist=None):
-    """buf: torch tensor [grad(np); loss] on this rank's device (or CPU for gloo).  In place; sum over ranks."""
+def pack_payload(grad_loss, stats):
+    """[grad(np); loss] (np + 1 doubles) and the per-trajectory stats (N, 8) -> double[np + 4] =
+    [grad; loss; sum nf (fwd + bwd); sum naccept; sum nreject]: ONE buffer, ONE collective per gradient.
+    Works on torch tensors (device-resident) and numpy arrays alike."""
+    s = stats.sum(0)
+    if hasattr(s, "to"):      # torch
+        import torch
+        c = torch.stack([s[0] + s[4], s[1] + s[5], s[2] + s[6]]).to(grad_loss.dtype)
+        return torch.cat([grad_loss, c])
+    return np.concatenate([grad_loss, np.array([s[0] + s[4], s[1] + s[5], s[2] + s[6]], dtype=grad_loss.dtype)])
+
+
+def allreduce_payload(buf, dist=None):
+    """buf: tensor double[np + 4] on this rank's device (or CPU for gloo).  In place; sum over ranks."""
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
 
-def allreduce_counters(stats_sum, dist=None):
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(stats_sum, op=dist.ReduceOp.SUM)
-    return stats_sum
+allreduce_grad = allreduce_payload   # (name used by bench.py / examples)
 
 
-def sharded_loss_grad(local_fn, n_total, world, rank, dist=None):
-    """local_fn(lo, hi) -> torch tensor [grad; loss] for trajectories [lo, hi); returns the all-reduced tensor."""
-    lo, hi = shard_bounds(n_total, world, rank)
-    return allreduce_grad(local_fn(lo, hi), dist)
+class Comm:
+    """ude_comm handles of this process: one per device it drives"""
+
+    def __init__(self, engines, handles):
+        self.engines, self.handles = engines, handles
+        self.L = _lib.load()
+
+    @classmethod
+    def from_torch_dist(cls, engine, dist):
+        """one process per GPU: rank 0 creates the RCCL unique id, the existing process group carries it to the others"""
+        L = _lib.load()
+        ident = (C.c_char * 128)()
+        if dist.get_rank() == 0:
+            rc = L.ude_comm_unique_id(ident)
+            if rc:
+                raise _lib.UdeError(rc, "ude_comm_unique_id failed (librccl not loadable?)")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        h = C.c_void_p()
+        engine.check(L.ude_comm_create(engine.h, dist.get_world_size(), dist.get_rank(), box[0], C.byref(h)))
+        return cls([engine], [h])
+
+    @classmethod
+    def local(cls, engines):
+        """all devices of one process (what a single-threaded Julia host does)"""
+        L = _lib.load()
+        n = len(engines)
+        ctxs = (C.c_void_p * n)(*[e.h for e in engines])
+        out = (C.c_void_p * n)()
+        engines[0].check(L.ude_comm_create_local(n, ctxs, out))
+        return cls(list(engines), [C.c_void_p(out[i]) for i in range(n)])
+
+    def allreduce(self, bufs, p2p=False):
+        """bufs: one torch float64 CUDA tensor per device of this Comm (same length).  In place, on the contexts' streams."""
+        n = len(self.handles)
+        if not isinstance(bufs, (list, tuple)):
+            bufs = [bufs]
+        assert len(bufs) == n and all(b.dtype.is_floating_point and b.element_size() == 8 for b in bufs)
+        cnt = bufs[0].numel()
+        if n == 1 and not p2p:
+            self.engines[0].check(self.L.ude_allreduce_grad(self.handles[0], C.c_void_p(bufs[0].data_ptr()), cnt))
+            return bufs
+        comms = (C.c_void_p * n)(*[h.value for h in self.handles])
+        ptrs = (C.c_void_p * n)(*[b.data_ptr() for b in bufs])
+        fn = self.L.ude_allreduce_grad_p2p if p2p else self.L.ude_allreduce_grad_local
+        self.engines[0].check(fn(n, comms, ptrs, cnt))
+        return bufs
+
+    def close(self):
+        for h in self.handles:
+            self.L.ude_comm_destroy(h)
+        self.handles = []
