@@ -256,3 +256,107 @@ def test_adam_trajectory_with_discrete_gradient(golden):
         th = th - eta * (mt / (1 - b1t)) / (np.sqrt(vt / (1 - b2t)) + eps)
         b1t *= b1
         b2t *= b2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-loss pins where the reference is silent (it ships no SEIR / Fisher-KPP artifact): the interpolating-adjoint
+# gradient of the WHOLE loss (row mask, S0 = 14e6 state scaling, periodic stencil) against central finite differences of
+# tight-tolerance forward solves.  GPU == oracle bitwise proves agreement; this proves the restatement itself.
+# ---------------------------------------------------------------------------------------------------------------------
+def _fd_directional(loss, th, dirs, h):
+    return np.array([(loss(th + h * d) - loss(th - h * d)) / (2 * h) for d in dirs])
+
+
+def test_seir_full_loss_adjoint_vs_finite_differences():
+    """seir_exposure.jl:137-147 at the script's scale: u0 = (0.9 S0, 0, 0, 0, S0, 0, 0), S0 = 14e6, loss rows 2:4."""
+    rng = np.random.default_rng(5)
+    m = O.seir_ude()
+    S0 = 14e6
+    u0 = np.array([0.9 * S0, 10.0, 5.0, 0.0, S0, 0.0, 0.0])       # a few exposed/infected so the dynamics are alive
+    t = np.arange(0.0, 8.0, 1.0)
+    lim = lambda fin, fout: np.sqrt(6.0 / (fin + fout))
+    th = np.concatenate([rng.uniform(-lim(3, 64), lim(3, 64), 192), np.zeros(64), rng.uniform(-lim(64, 64), lim(64, 64), 4096),
+                         np.zeros(64), rng.uniform(-lim(64, 1), lim(64, 1), 64), np.zeros(1)])
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [t[0], t[-1]], np.zeros(0), t)
+    assert rc[0] == 0
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    data = truth.copy()
+    data[:, :, [0, 4, 5, 6]] = np.nan        # masked rows must never be read
+
+    def loss(theta):
+        out, _, r = O.solve_ensemble(m, O.opts(O.VERN7, 1e-12, 1e-12), u0, [t[0], t[-1]], theta, t)
+        assert r[0] == 0
+        return float(((out[0][:, 1:4] - truth[0][:, 1:4]) ** 2).sum())
+
+    r = O.loss_grad_ensemble(m, O.opts(O.VERN7, 1e-9, 1e-9), u0, [t[0], t[-1]], th, t, data, row_mask=mask)
+    assert r["retcode"][0] == 0 and np.isfinite(r["loss"]) and abs(r["loss"] - loss(th)) < 1e-6 * r["loss"]
+    dirs = [rng.standard_normal(th.size) / np.sqrt(th.size) for _ in range(6)]
+    fd = _fd_directional(loss, th, dirs, 1e-5)
+    an = np.array([r["grad_theta"] @ d for d in dirs])
+    assert np.allclose(an, fd, rtol=2e-5, atol=1e-7 * np.abs(fd).max()), (an, fd)
+
+
+def test_fisher_kpp_full_loss_adjoint_vs_finite_differences():
+    """Fisher-KPP-CNN.jl:134-143 on the reference's 26-point grid (periodic stencil, D0, pointwise 1-10-20-10-1 tanh)."""
+    rng = np.random.default_rng(6)
+    nx = 26
+    m = O.kpp_ude(nx)
+    x = np.arange(nx) * 0.04
+    u0 = 0.5 * (np.tanh((x - 0.3) / 0.2) - np.tanh((x - 0.7) / 0.2))
+    t = np.arange(0.0, 2.01, 0.5)
+    th = np.concatenate([rng.uniform(-0.4, 0.4, 461), [1.1, -2.5, 1.0, 0.0, 6.5]])
+    truth, _, rc = O.solve_ensemble(O.kpp_true(nx), O.opts(O.TSIT5, 1e-12, 1e-12), u0, [t[0], t[-1]], np.zeros(0), t)
+    assert rc[0] == 0
+
+    def loss(theta):
+        out, _, r = O.solve_ensemble(m, O.opts(O.VERN7, 1e-12, 1e-12), u0, [t[0], t[-1]], theta, t)
+        assert r[0] == 0
+        return float(((out[0] - truth[0]) ** 2).sum())
+
+    r = O.loss_grad_ensemble(m, O.opts(O.TSIT5, 1e-9, 1e-9), u0, [t[0], t[-1]], th, t, truth)
+    assert r["retcode"][0] == 0
+    # every parameter class: NN weights/biases, the three stencil weights, the unused conv bias (zero gradient), D0
+    fd = np.zeros(th.size)
+    idx = list(rng.choice(461, 12, replace=False)) + [461, 462, 463, 464, 465]
+    for i in idx:
+        e = np.zeros(th.size)
+        e[i] = 1e-6
+        fd[i] = (loss(th + e) - loss(th - e)) / 2e-6
+    g = r["grad_theta"]
+    assert g[464] == 0.0 and fd[464] == 0.0
+    assert np.allclose(g[idx], fd[idx], rtol=1e-5, atol=1e-7 * np.abs(fd[idx]).max()), (g[idx], fd[idx])
+
+
+def test_scalar_kernels_within_a_few_ulp_of_libm():
+    """ARITH-SPEC elementary functions (oracle/ude_oracle.c, restated in csrc/ude_math.h) against 80-bit libm"""
+    L = O.lib()
+    import ctypes as C
+    for name in ("udeo_exp", "udeo_tanh", "udeo_log10", "udeo_pow10", "udeo_log"):
+        getattr(L, name).restype = C.c_double
+        getattr(L, name).argtypes = [C.c_double]
+    L.udeo_pow.restype = C.c_double
+    L.udeo_pow.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(7)
+    ld = np.longdouble
+
+    def ulps(got, ref):
+        ref64 = np.float64(ref)
+        return abs(float((ld(got) - ref) / ld(np.spacing(abs(ref64)) if ref64 != 0 else 5e-324)))
+
+    worst = {}
+    for x in np.concatenate([rng.uniform(-30, 30, 4000), rng.uniform(-1e-3, 1e-3, 500), [0.0, 1.0, -1.0, 700.0, -700.0]]):
+        worst["exp"] = max(worst.get("exp", 0), ulps(L.udeo_exp(x), np.exp(ld(x))))
+    for x in np.concatenate([rng.uniform(-6, 6, 4000), rng.uniform(-1e-4, 1e-4, 500), [0.0, 19.9, 25.0, -25.0]]):
+        worst["tanh"] = max(worst.get("tanh", 0), ulps(L.udeo_tanh(x), np.tanh(ld(x))))
+    for x in np.concatenate([10.0 ** rng.uniform(-12, 12, 4000), [1.0, 0.5, 2.0]]):
+        worst["log10"] = max(worst.get("log10", 0), ulps(L.udeo_log10(x), np.log10(ld(x))) if x != 1.0 else 0)
+        worst["log"] = max(worst.get("log", 0), ulps(L.udeo_log(x), np.log(ld(x))) if x != 1.0 else 0)
+    for x in rng.uniform(-12, 12, 3000):
+        worst["pow10"] = max(worst.get("pow10", 0), ulps(L.udeo_pow10(x), ld(10) ** ld(x)))
+    for x, y in zip(rng.uniform(0.05, 1.0, 3000), rng.uniform(0.0, 1200.0, 3000)):      # corona!'s (1 - D/N)^kappa, kappa = 1117.3
+        ref = ld(x) ** ld(y)
+        if float(ref) > 1e-290:
+            worst["pow"] = max(worst.get("pow", 0), ulps(L.udeo_pow(x, y), ref))
+    assert worst["exp"] <= 2 and worst["tanh"] <= 4 and worst["log"] <= 2 and worst["log10"] <= 3, worst
+    assert worst["pow10"] <= 40 and worst["pow"] <= 2000, worst   # exp(y log x): the argument's rounding is amplified by |y log x|
+    assert L.udeo_log(1.0) == 0.0 and L.udeo_log10(1.0) == 0.0 and L.udeo_tanh(0.0) == 0.0 and L.udeo_exp(0.0) == 1.0
