@@ -2,7 +2,7 @@
 """LotkaVolterra/scenario_2.jl, lines 57-148: partial observations, 5 shooting segments sharing theta = [delta; ude].
 
 The five `predict(theta, [XS[i,1], YS[i,1]], TS[i,:])` calls of the loss (scenario_2.jl:113-124) are ONE 5-trajectory
-ensemble here; the segment time windows are shifted to a common [0, 1.2] (the right-hand side is autonomous).  The loss
+ensemble here, every member on its own tspan = (T[1], T[end]) and save grid T (per-trajectory time grids of the boundary).  The loss
 mixes abs2 on x with abs on the last y, so the gradient goes through the generic pullback (user cotangent) instead of the
 built-in sum-of-squares loss; the regulariser stays on the host.  Data X, t and the initial theta come from the
 reference's artifact (tests/golden/Scenario_2_recovery_0.005.json).   Needs a GPU."""
@@ -36,12 +36,14 @@ def build(golden_path=os.path.join(ROOT, "tests", "golden", "Scenario_2_recovery
 def make_loss(XS, TS, YS):
     f = models.ude_dynamics(trainable="delta")                       # scenario_2.jl:87-95
     u0s = np.stack([XS[:, 0], YS[:, 0]], axis=1)
-    tau = TS[0] - TS[0, 0]                                           # common relative save grid (0:0.1:1.2)
+    tspans = np.stack([TS[:, 0], TS[:, -1]], axis=1)                 # remake(prob; tspan = (T[1], T[end])), scenario_2.jl:105
+    tau = TS                                                         # saveat = T per segment, scenario_2.jl:107
     nseg, npts = XS.shape
 
     def loss_grad(theta):
         theta = np.asarray(theta, dtype=float)
-        ens = U.EnsembleProblem(U.ODEProblem(f, u0s[0], (0.0, float(tau[-1])), theta), u0s)
+        # the 5 segments as ONE ensemble, every member on its own tspan / save grid (no time shift)
+        ens = U.EnsembleProblem(U.ODEProblem(f, u0s[0], tuple(tspans[0]), theta), u0s, tspans=tspans)
         sol = U.solve(ens, U.Vern7(), saveat=tau, abstol=1e-6, reltol=1e-6)
         Xh = sol.u                                                   # (5, 13, 2)
         reg = 1e-3 * np.sum(theta[1:] ** 2) / (theta.size - 1)       # scenario_2.jl:115

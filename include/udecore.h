@@ -79,8 +79,11 @@ typedef struct {
     double qmin, qmax, gamma, qoldinit; /* <=0 -> 0.2, 10, 0.9, 1e-4 */
     double beta1, beta2;                /* <=0 -> 7/(10 order), 2/(5 order) */
     int32_t sensealg;   /* UDE_SENSE_*: how ude_vjp / ude_loss_grad differentiate */
-    int32_t reserved;
+    int32_t per_trajectory; /* UDE_PT_* flags: every ensemble member has its own tspan (2 x N) and / or save grid (ns x N,
+                               strictly increasing inside its tspan) -- remake(prob; tspan = (T[1], T[end])) + saveat = T per
+                               segment, scenario_2.jl:104-124; 0 = one shared pair / grid */
 } ude_solve_opts;
+enum { UDE_PT_TSPAN = 1, UDE_PT_SAVEAT = 2 };
 
 /* launch/tuning knobs of the HIP back end (not part of the reference surface) */
 typedef struct {
@@ -116,8 +119,9 @@ int ude_model_supported(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_o
  * member of an ensemble sharing theta (predict: scenario_1.jl:82-88; scenario_2.jl:113-124 segments;
  * EnsembleProblem slot: SciMLBase.__solve(::EnsembleProblem, alg, ::EnsembleAlgorithm)). */
 int ude_solve_ensemble(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                       const double* u0, const double* tspan, const double* theta,
-                       const double* saveat, int32_t ns, double* u_out, int64_t* stats, int32_t* retcode);
+                       const double* u0, const double* tspan /* 2, or 2 x N with UDE_PT_TSPAN; always a HOST pointer */,
+                       const double* theta, const double* saveat /* ns, or ns x N with UDE_PT_SAVEAT */, int32_t ns,
+                       double* u_out, int64_t* stats, int32_t* retcode);
 int ude_solve_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
                            const double* u0, const double* tspan, const double* theta,
                            const double* saveat, int32_t ns, double* u_out, int64_t* stats, int32_t* retcode);

@@ -33,7 +33,7 @@ class SolveOpts(C.Structure):
         ("alg", C.c_int32), ("maxiters", C.c_int32), ("abstol", C.c_double), ("reltol", C.c_double),
         ("dtmax", C.c_double), ("dt0", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double),
         ("gamma", C.c_double), ("qoldinit", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
-        ("sensealg", C.c_int32), ("reserved", C.c_int32),
+        ("sensealg", C.c_int32), ("per_trajectory", C.c_int32),
     ]
 
 

@@ -170,3 +170,42 @@ def test_rhs_ensemble_matches_oracle(golden):
         thk = models.kpp_theta(models.kpp_chain(), rng)
         uk = rng.uniform(0, 1, size=(3, nx))
         assert (U.rhs(models.nn_ode(nx), uk, thk) == orhs(O.kpp_ude(nx), thk, uk)).all()
+
+
+def test_per_trajectory_tspan_and_save_grids(golden):
+    """scenario_2.jl:104-124: every shooting segment is solved on ITS OWN tspan = (T[1], T[end]) with saveat = T -- as one
+    ensemble through the boundary's per-trajectory grids (no caller-side time shift); per member bit-identical to the
+    oracle solving that member alone, for the plain solve, the interpolating adjoint and the discrete sweep."""
+    g = golden("Scenario_2_recovery_0.005")
+    X = np.array(g["X"]["data_colmajor"]).reshape(61, 2)
+    t = np.array(g["t"]["data_colmajor"]) if isinstance(g["t"], dict) else np.array(g["t"])
+    th = np.array(g["initial_parameters"])
+    idx = [np.arange(12 * k, 12 * k + 13) for k in range(5)]           # 5 segments of 13 points sharing their end points
+    u0 = np.stack([X[i[0]] for i in idx])
+    tspans = np.stack([[t[i[0]], t[i[-1]]] for i in idx])
+    grids = np.stack([t[i] for i in idx])
+    data = np.stack([X[i] for i in idx])
+    f = models.ude_dynamics(trainable="delta")
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], tuple(tspans[0]), th), u0, tspans=tspans)
+    sol = U.solve(ens, U.Vern7(), saveat=grids, abstol=1e-6, reltol=1e-6)
+    assert np.array_equal(sol[3].t, grids[3])
+    for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1)):
+        r = U.loss_and_gradient(ens, U.Vern7(), data, row_mask=[1, 0], saveat=grids, abstol=1e-6, reltol=1e-6, sensealg=sense)
+        tot, gsum = 0.0, np.zeros(th.size)
+        for k in range(5):
+            o = O.opts(O.VERN7, 1e-6, 1e-6, sensealg=osense)
+            out, st, rc = O.solve_ensemble(O.lv_ude_s2(), o, u0[k], tspans[k], th, grids[k])
+            ref = O.loss_grad_ensemble(O.lv_ude_s2(), o, u0[k], tspans[k], th, grids[k], data[k][None], row_mask=[1, 0])
+            assert bitwise(sol.u[k], out[0]) and bitwise(sol.stats[k, :4], st[0, :4])
+            assert bitwise(r.u[k], ref["u"][0]) and bitwise(r.stats[k], ref["stats"][0]) and bitwise(r.grad_u0[k], ref["grad_u0"][0])
+            assert r.loss_per_traj[k] == ref["loss"]
+            tot += ref["loss"]
+            gsum += ref["grad_theta"]
+        assert abs(r.loss - tot) < 1e-12 * tot and np.linalg.norm(r.grad_theta - gsum) < 1e-12 * np.linalg.norm(gsum)
+    # one shared grid with per-member spans is refused unless it lies inside every span; a bad member grid is refused
+    with pytest.raises(ValueError):
+        U.solve(ens, U.Vern7(), saveat=0.1)
+    bad = grids.copy()
+    bad[2, 5] = bad[2, 4]
+    with pytest.raises(ValueError):
+        U.solve(ens, U.Vern7(), saveat=bad)

@@ -551,3 +551,28 @@ def test_tanh32_wide_lane_group_variant():
         r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, abstol=1e-6, reltol=1e-6,
                                 **({"ensemblealg": U.EnsembleMI355(lanes)} if lanes else {}))
         check_per_trajectory(r, ref)
+
+
+def test_fisher_kpp_small_variant_matches_oracle():
+    """Fisher-KPP-CNN-Small.jl:89-124: the 15-parameter variant (1-3-1 tanh), the only one the reference publishes timings for"""
+    rng = np.random.default_rng(8)
+    nx = 26
+    chain = models.kpp_small_chain(3)
+    th = models.kpp_theta(chain, rng)
+    assert th.size == 15
+    u0 = np.stack([models.rho0(nx) * s for s in (1.0, 0.8, 0.6)])
+    t = np.arange(11) * 0.5
+    truth = U.solve(U.EnsembleProblem(U.ODEProblem(models.rc_ode(nx), u0[0], (0.0, 5.0), []), u0), U.Tsit5(), saveat=t).u
+    f = models.nn_ode(nx, chain)
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 5.0), th), u0)
+    mo = O.kpp_ude(nx, (1, 3, 1), ("tanh", "identity"))
+    for alg, oalg in ((U.Tsit5(), O.TSIT5), (U.Vern7(), O.VERN7)):
+        r = U.loss_and_gradient(ens, alg, truth, saveat=t)
+        ref = O.loss_grad_ensemble(mo, O.opts(oalg), u0, [0.0, 5.0], th, t, truth, nthreads=3)
+        assert_bitwise(r.stats, ref["stats"], "stats")
+        assert_bitwise(r.u, ref["u"], "u")
+        assert_bitwise(r.grad_u0, ref["grad_u0"], "grad_u0")
+        assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+        rd = U.loss_and_gradient(ens, alg, truth, saveat=t, sensealg=U.ForwardDiffSensitivity())
+        refd = O.loss_grad_ensemble(mo, O.opts(oalg, sensealg=1), u0, [0.0, 5.0], th, t, truth, nthreads=3)
+        assert np.linalg.norm(rd.grad_theta - refd["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(refd["grad_theta"])

@@ -55,6 +55,9 @@ struct KParams {
     int64_t trace_traj;
     int32_t trace_cap;
     const struct TabDev* tab;  // tableau of the algorithm (device memory)
+    // per-trajectory time grids (kernels instantiated with PT = true): tspan_pt = 2 x N, saveat = ns x N when saveat_pt
+    const double* tspan_pt;
+    int32_t saveat_pt, dtmax_auto;
 };
 
 __device__ __forceinline__ double ulp_of(double x) {
@@ -171,6 +174,7 @@ struct Driver {
         // by the initial-dt heuristic, and -- FSAL tableaux -- handed over from the last stage of an accepted step
         // (gtmp2 receives the last stage's slot derivative; the two rows swap on acceptance)
         double accb[NSLA], acce[NSLA];
+        const double dtmax = sys.dtmax(o);  // (per-trajectory when the time grids are)
         double t = t0, dt, qold = o.qoldinit, q11 = 1.0;
         bool accept = true, done = false;
         int iter = 0, ret = RET_SUCCESS;
@@ -242,7 +246,7 @@ struct Driver {
                 done = true;
             }
             double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : (d0 / d1) / 100.0;
-            if (dt0 > o.dtmax) dt0 = o.dtmax;
+            if (dt0 > dtmax) dt0 = dtmax;
             if (dt0 < 10.0 * 2.220446049250313e-16) {
                 dt = tdir * 1e-6;
             } else {
@@ -291,7 +295,7 @@ struct Driver {
                 }
                 double d = 100.0 * dt0;
                 if (dt1 < d) d = dt1;
-                if (o.dtmax < d) d = o.dtmax;
+                if (dtmax < d) d = dtmax;
                 dt = tdir * d;
             }
             st.nf += 2;
@@ -307,7 +311,7 @@ struct Driver {
                 dt = dt / den;
             }
             iter += 1;
-            if (fabs(dt) > o.dtmax) dt = tdir * o.dtmax;
+            if (fabs(dt) > dtmax) dt = tdir * dtmax;
             {
                 const double rem = fabs(tstop - t);  // modify_dt_for_tstops!
                 if (fabs(dt) > rem) dt = tdir * rem;
@@ -441,7 +445,7 @@ struct Driver {
                     const double mxt = t > tstop ? t : tstop;
                     t = fabs(ttmp - tstop) < 100.0 * ulp_of(mxt) ? tstop : ttmp;
                 }
-                if (fabs(dtnew) > o.dtmax) dtnew = tdir * o.dtmax;
+                if (fabs(dtnew) > dtmax) dtnew = tdir * dtmax;
                 // hook: saveat interpolation / dense store (forward); may build the lazy stages
                 {
                     bool lazy_done = false;
@@ -517,8 +521,29 @@ struct Driver {
 // forward system: model RHS + saveat (savevalues!) + dense store + loss/cotangent
 // dense field layout per step: 0 t_start, 1 t_end, 2 dt (the step size used), 3..3+n u_start, then k[q][c]
 // ---------------------------------------------------------------------------------------------
-template <class Model, class Tab, int G, int BLOCKDIM>
+// time grid of a trajectory: shared (kernel parameters, wave-uniform scalars) or its own (PT: registers)
+template <bool PT>
+struct TimeGrid {
+    double t0_, tf_, dtmax_;
+    const double* sv_;
+    __device__ __forceinline__ void init(const KParams& p, int64_t j) {
+        if constexpr (PT) {
+            t0_ = p.tspan_pt ? p.tspan_pt[2 * j] : p.t0;
+            tf_ = p.tspan_pt ? p.tspan_pt[2 * j + 1] : p.tf;
+            dtmax_ = p.dtmax_auto ? tf_ - t0_ : p.o.dtmax;
+            sv_ = p.saveat + (p.saveat_pt ? (size_t)j * p.ns : 0);
+        }
+    }
+    __device__ __forceinline__ double T0(const KParams& p) const { if constexpr (PT) return t0_; else return p.t0; }
+    __device__ __forceinline__ double TF(const KParams& p) const { if constexpr (PT) return tf_; else return p.tf; }
+    __device__ __forceinline__ double SV(const KParams& p, int i) const { if constexpr (PT) return sv_[i]; else return p.saveat[i]; }
+    __device__ __forceinline__ double DTMAX(const Opts& o) const { if constexpr (PT) return dtmax_; else return o.dtmax; }
+};
+
+template <class Model, class Tab, int G, int BLOCKDIM, bool PT = false>
 struct FwdSys {
+    TimeGrid<PT> tg;
+    __device__ __forceinline__ double dtmax(const Opts& o) const { return tg.DTMAX(o); }
     static constexpr int NR = Model::NS, NSL = 0;
     static constexpr bool ALWAYS_K0 = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     static constexpr bool SLOTS_GLOBAL = false, CPL = Model::CPL, DEFERRED = false;
@@ -536,7 +561,7 @@ struct FwdSys {
     __device__ __forceinline__ bool cwrite(int c) const { return STATE_DISTRIBUTED ? cvalid(c) : writer; }
     __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
 
-    __device__ __forceinline__ double first_tstop() const { return p->tf; }
+    __device__ __forceinline__ double first_tstop() const { return tg.TF(*p); }
     __device__ __forceinline__ bool next_tstop(double&) const { return false; }
     __device__ __forceinline__ bool at_tstop(double, double*) const { return false; }
     __device__ __forceinline__ void eval(double, const double* z, double* kr, double*) {
@@ -575,8 +600,8 @@ struct FwdSys {
                                             const double* kl, Lazy& lazy) {
         auto k = [&](int q, int c) { return kl[(q * NR + c) * k_stride<STATE_DISTRIBUTED, G, BLOCKDIM>()]; };
         auto k1 = [&](int q) { return kl[q * KCP]; };  // CPL: this lane's component
-        while (si < p->ns && p->saveat[si] <= t) {
-            const double curt = p->saveat[si];
+        while (si < p->ns && tg.SV(*p, si) <= t) {
+            const double curt = tg.SV(*p, si);
             if (curt != t) {
                 lazy();
                 const double th = (curt - tprev) / dt;
@@ -642,7 +667,7 @@ struct Layout {
     static __host__ __device__ constexpr int np_pad(int np) { return (np + 1) & ~1; }
 };
 
-template <class Model, class Tab, int G, int BLOCK>
+template <class Model, class Tab, int G, int BLOCK, bool PT = false>
 __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK>;
@@ -657,11 +682,12 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
     const int r = threadIdx.x % G;
     if (gid >= p.N || (int)threadIdx.x >= GROUPS * G) return;  // whole groups leave together
-    using Sys = FwdSys<Model, Tab, G, BLOCK>;
+    using Sys = FwdSys<Model, Tab, G, BLOCK, PT>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
     Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, nullptr, 0, p.mc, r, p.theta);
     sys.p = &p;
+    sys.tg.init(p, gid);
     sys.j = gid;
     sys.writer = (r == 0);
     sys.si = 0;
@@ -673,12 +699,12 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>(Tab::NK);
     double* mu = nullptr;  // no slot state in the forward pass
     static_for<0, Sys::NR>([&](auto c) { z[c] = sys.cvalid(c) ? p.u0[(size_t)gid * p.n_state + sys.comp(c)] : 0.0; });
-    while (sys.si < p.ns && p.saveat[sys.si] <= p.t0) {  // save_start
+    while (sys.si < p.ns && sys.tg.SV(p, sys.si) <= sys.tg.T0(p)) {  // save_start
         sys.save_point(sys.si, z);
         sys.si += 1;
     }
     typename Drv::Stats st;
-    const int ret = Drv::run(sys, p.o, p.tab, z, kl, mu, p.t0, 1.0, (double)p.n_state, st);
+    const int ret = Drv::run(sys, p.o, p.tab, z, kl, mu, sys.tg.T0(p), 1.0, (double)p.n_state, st);
     if constexpr (Model::STATE_DISTRIBUTED) sys.loss = group_sum<G>(sys.loss);  // per-lane partial sums of the loss
     if (sys.writer) {
         if (p.stats) {
@@ -723,8 +749,10 @@ __global__ void __launch_bounds__(BLOCK) rhs_kernel(const KParams p) {
 //   lambda' = -(df/du)^T lambda, mu' = -(df/dtheta)^T lambda at y(t) = forward dense interpolant;
 //   save times are tstops with lambda += dL/du(t_i)            
 // ---------------------------------------------------------------------------------------------
-template <class Model, class Tab, int G>
+template <class Model, class Tab, int G, bool PT = false>
 struct AdjSys {
+    TimeGrid<PT> tg;
+    __device__ __forceinline__ double dtmax(const Opts& o) const { return tg.DTMAX(o); }
     static constexpr bool DEFERRED = Model::DEFERRED;
     static constexpr int NR = Model::NS, NSL = DEFERRED ? 0 : Model::NSL;
     static constexpr bool STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
@@ -873,13 +901,13 @@ struct AdjSys {
 
     __device__ __forceinline__ double tstop_from_cur() const {
         // next save time strictly inside (t0, t) in descending order, else t0
-        return (cur >= 0 && p->saveat[cur] > p->t0) ? p->saveat[cur] : p->t0;
+        return (cur >= 0 && tg.SV(*p, cur) > tg.T0(*p)) ? tg.SV(*p, cur) : tg.T0(*p);
     }
     __device__ __forceinline__ double first_tstop() const { return tstop_from_cur(); }
     __device__ __forceinline__ bool at_tstop(double t, double* lam) {
         bool mod = false;
-        while (cur >= 0 && p->saveat[cur] >= t) {
-            if (p->saveat[cur] == t) {
+        while (cur >= 0 && tg.SV(*p, cur) >= t) {
+            if (tg.SV(*p, cur) == t) {
                 static_for<0, NR>([&](auto c) {
                     if (cvalid(c)) lam[c] += cot[(size_t)cur * cot_si + (size_t)comp(c) * cot_sc];
                 });
@@ -890,7 +918,7 @@ struct AdjSys {
         return mod;
     }
     __device__ __forceinline__ bool next_tstop(double& tstop) {
-        if (tstop == p->t0) return false;
+        if (tstop == tg.T0(*p)) return false;
         tstop = tstop_from_cur();
         return true;
     }
@@ -903,7 +931,7 @@ struct AdjSys {
 #ifndef UDE_ADJ_MIN_WAVES
 #define UDE_ADJ_MIN_WAVES 1
 #endif
-template <class Model, class Tab, int G, int BLOCK>
+template <class Model, class Tab, int G, int BLOCK, bool PT = false>
 __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK>;
@@ -919,7 +947,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     constexpr int GROUPS = BLOCK / G;
     const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
     const int r = threadIdx.x % G;
-    using Sys = AdjSys<Model, Tab, G>;
+    using Sys = AdjSys<Model, Tab, G, PT>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     constexpr int NSL = Sys::NSL;
     constexpr int NSLA = NSL > 0 ? NSL : 1;
@@ -944,6 +972,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         Sys sys;
         Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
         sys.p = &p;
+        sys.tg.init(p, gid);
         sys.j = gid;
         sys.n = p.n_state;
         if constexpr (Model::DEFERRED) sys.load_bth_table();
@@ -964,9 +993,9 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
         }
         sys.cur = p.ns - 1;
         sys.load_interval(sys.nsteps - 1);
-        sys.at_tstop(p.tf, lam);  // init_cb: the jump at t = tf precedes the first step
+        sys.at_tstop(sys.tg.TF(p), lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
-        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, p.tf, -1.0, (double)(p.n_state + p.n_param), st, gtmp, gtmp2, MS);
+        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, sys.tg.TF(p), -1.0, (double)(p.n_state + p.n_param), st, gtmp, gtmp2, MS);
         if constexpr (Model::DEFERRED) mu_final = sys.mu_cur;
         if (r == 0) {
             if (p.stats) {
@@ -1044,7 +1073,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
 // divisions.  Accumulation order = oracle/ude_oracle_impl.h: discrete_sweep (ARITH-SPEC), so per-trajectory
 // results are bit-identical to the oracle.
 // ---------------------------------------------------------------------------------------------
-template <class Model, class Tab, int G, int BLOCK>
+template <class Model, class Tab, int G, int BLOCK, bool PT = false>
 __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK, false>;  // (the reverse sweep keeps the replicated stage layout)
@@ -1080,6 +1109,8 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         auto cvalid = [&](int c) { return comp(c) < n; };
         auto cwrite = [&](int c) { return DIST ? cvalid(c) : r == 0; };
         const int koff = k_offset<DIST, G>();
+        TimeGrid<PT> tg;
+        tg.init(p, gid);
         const double* kdense = nullptr;  // first stage field of the current step in the dense store (KD)
         auto K = [&](int j, int c) -> double {
             if constexpr (KD) return cvalid(c) ? kdense[(size_t)(j * n + comp(c)) * p.Npad] : 0.0;
@@ -1130,8 +1161,8 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
                     if constexpr (!KD) kbase[(q * NR + c) * KSTRIDE + koff] = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * p.Npad] : 0.0;
                 });
             // (1) saves exactly at the step end feed the cotangent of u_{n+1}
-            while (si >= 0 && p.saveat[si] >= tn1) {
-                if (p.saveat[si] == tn1) static_for<0, NR>([&](auto c) { if (cvalid(c)) ubar[c] += COT(si, c); });
+            while (si >= 0 && tg.SV(p, si) >= tn1) {
+                if (tg.SV(p, si) == tn1) static_for<0, NR>([&](auto c) { if (cvalid(c)) ubar[c] += COT(si, c); });
                 si -= 1;
             }
             // (2) u_{n+1} = u_n + dt*sum B_j k_j
@@ -1143,8 +1174,8 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             if constexpr (Tab::FSAL) static_for<0, NR>([&](auto c) { KB(S - 1, c) += carry[c]; });
             // (3) saves strictly inside the step, descending: y = u_n + dt*sum b_j(theta) k_j
             bool interior = false;
-            while (si >= 0 && p.saveat[si] > tn) {
-                const double thv = (p.saveat[si] - tn) / dt;
+            while (si >= 0 && tg.SV(p, si) > tn) {
+                const double thv = (tg.SV(p, si) - tn) / dt;
                 double bw[NK];
                 Tab::bth(thv, bw);
                 static_for<0, NR>([&](auto c) {
@@ -1183,7 +1214,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             static_for<0, NR>([&](auto c) { ubar[c] = un[c]; });
         }
         while (si >= 0) {  // saves at t0 (save_start)
-            if (p.saveat[si] == p.t0) static_for<0, NR>([&](auto c) { if (cvalid(c)) ubar[c] += COT(si, c); });
+            if (tg.SV(p, si) == tg.T0(p)) static_for<0, NR>([&](auto c) { if (cvalid(c)) ubar[c] += COT(si, c); });
             si -= 1;
         }
         if (r == 0 && p.stats) p.stats[(size_t)gid * 8 + 4] = nvjp;

@@ -9,6 +9,7 @@ struct Launch {
     void (*adj)(const KParams);
     void (*dadj)(const KParams);  // discretise-then-optimise reverse sweep (a9)
     void (*rhs)(const KParams);   // one right-hand-side evaluation per state
+    void (*fwd_pt)(const KParams), (*adj_pt)(const KParams), (*dadj_pt)(const KParams);  // per-trajectory tspan / saveat
     int nf;  // dense fields per step
     int G, block;
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
@@ -31,6 +32,9 @@ inline Launch make_launch() {
     l.adj = adj_kernel<Model, Tab, G, BLOCK>;
     l.dadj = dadj_kernel<Model, Tab, G, BLOCK>;
     l.rhs = rhs_kernel<Model, Tab, G, BLOCK>;
+    l.fwd_pt = fwd_kernel<Model, Tab, G, BLOCK, true>;
+    l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true>;
+    l.dadj_pt = dadj_kernel<Model, Tab, G, BLOCK, true>;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;
@@ -50,9 +54,10 @@ using NetHudson = NetCfg<IntList<2, 5, 5, 5, 2>, IntList<ACT_RBF, ACT_RBF, ACT_T
 using NetTanh32 = NetCfg<IntList<2, 32, 2>, IntList<ACT_TANH, ACT_IDENTITY>>;                         // BASELINE C2 "2-layer tanh"
 
 enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, MID_SEIR_TRUE, MID_SEIR_UDE,
-       MID_KPP_TRUE_32, MID_KPP_TRUE_1024, MID_KPP_UDE_32, MID_KPP_UDE_1024, MID_KPP_S3_32 };
+       MID_KPP_TRUE_32, MID_KPP_TRUE_1024, MID_KPP_UDE_32, MID_KPP_UDE_1024, MID_KPP_S3_32, MID_KPP_SMALL_32 };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88
+using NetKppSmall = NetCfg<IntList<1, 3, 1>, IntList<ACT_TANH, ACT_IDENTITY>>;                        // Fisher-KPP-CNN-Small.jl:89-94 (15 parameters)
 
 }  // namespace ude

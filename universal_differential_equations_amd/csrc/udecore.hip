@@ -137,6 +137,9 @@ static int model_id(const ude_model_desc* m) {
         if (dims_are(m, {1, 10, 20, 10, 1}, {ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY}) && m->n_param == 466 &&
             m->stencil_offset == 461 && m->d0_offset == 465)
             return m->n_state <= 32 ? MID_KPP_UDE_32 : m->n_state <= 1024 ? MID_KPP_UDE_1024 : MID_NONE;
+        if (dims_are(m, {1, 3, 1}, {ACT_TANH, ACT_IDENTITY}) && m->n_param == 15 && m->stencil_offset == 10 && m->d0_offset == 14 &&
+            m->n_state <= 32)
+            return MID_KPP_SMALL_32;  // the only variant the reference publishes timings for (Fisher-KPP-CNN-Small.jl:319-341)
         if (dims_are(m, {1, 5, 5, 5, 1}, {ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY}) && m->n_param == 81 &&
             m->stencil_offset == 76 && m->d0_offset == 80 && m->n_state <= 32)
             return MID_KPP_S3_32;
@@ -158,7 +161,8 @@ static int default_lanes(int mid, bool discrete) {
         case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
-        case MID_KPP_S3_32: return 32;
+        case MID_KPP_S3_32:
+        case MID_KPP_SMALL_32: return 32;
         case MID_KPP_TRUE_1024: return 64;
         case MID_KPP_UDE_1024: return 256;  // 4 wavefronts per PDE
     }
@@ -250,7 +254,7 @@ extern "C" void ude_destroy(ude_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
-    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs, &c->slot_glob, &c->nfail,
+    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs, &c->slot_glob, &c->nfail, &c->tspan_pt,
                       &c->s_u0, &c->s_theta, &c->s_saveat, &c->s_out, &c->s_data, &c->s_mask, &c->s_gtheta,
                       &c->s_gu0, &c->s_loss, &c->s_lpt, &c->s_stats, &c->s_ret};
     for (DevBuf* b : bufs)
@@ -354,7 +358,23 @@ static int common_checks(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if (!c) return UDE_ERR_INVALID;
     if (!m || !o || !u0 || !tspan_host || !saveat || N <= 0 || ns <= 0) return fail(c, UDE_ERR_INVALID, "null argument or empty ensemble");
     if (m->n_param > 0 && !theta) return fail(c, UDE_ERR_INVALID, "theta is null");
-    if (!(tspan_host[1] > tspan_host[0])) return fail(c, UDE_ERR_INVALID, "tspan must be increasing");
+    const int64_t npairs = (o->per_trajectory & UDE_PT_TSPAN) ? N : 1;
+    for (int64_t j = 0; j < npairs; ++j)
+        if (!(tspan_host[2 * j + 1] > tspan_host[2 * j])) return fail(c, UDE_ERR_INVALID, "tspan must be increasing");
+    return UDE_OK;
+}
+
+// per-trajectory time grids (o->per_trajectory): tspan pairs to the device, kernel variants with their own grid
+static int setup_time_grids(ude_ctx* c, const ude_solve_opts* o, int64_t N, const double* tspan_host, KParams& p) {
+    p.tspan_pt = nullptr;
+    p.saveat_pt = (o->per_trajectory & UDE_PT_SAVEAT) ? 1 : 0;
+    p.dtmax_auto = o->dtmax > 0 ? 0 : 1;
+    if (o->per_trajectory & UDE_PT_TSPAN) {
+        int rc = ensure(c, c->tspan_pt, sizeof(double) * 2 * N);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->tspan_pt.p, tspan_host, sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
+        p.tspan_pt = (const double*)c->tspan_pt.p;
+    }
     return UDE_OK;
 }
 
@@ -389,10 +409,12 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const size_t shmem = l.lds_bytes(m->n_param, false);
+    if ((rc = setup_time_grids(c, o, N, tspan, p))) return rc;
+    void (*kfwd)(const KParams) = o->per_trajectory ? l.fwd_pt : l.fwd;
     if (shmem > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute((const void*)l.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
+    hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     c->ev_fwd = true;
@@ -464,7 +486,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.grad_u0 = grad_u0;
     const bool discrete = o->sensealg == UDE_SENSE_DISCRETE;
     if (o->sensealg != UDE_SENSE_INTERPOLATING_ADJOINT && !discrete) return fail(c, UDE_ERR_INVALID, "unknown sensealg %d", o->sensealg);
-    void (*bwd)(const KParams) = discrete ? l.dadj : l.adj;
+    if ((rc = setup_time_grids(c, o, N, tspan, p))) return rc;
+    const bool pt = o->per_trajectory != 0;
+    void (*bwd)(const KParams) = discrete ? (pt ? l.dadj_pt : l.dadj) : (pt ? l.adj_pt : l.adj);
+    void (*kfwd)(const KParams) = pt ? l.fwd_pt : l.fwd;
     const size_t shmem_f = l.lds_bytes(np, false);
     const size_t shmem_a = l.lds_bytes(np, true, discrete);
     if (shmem_a > 160 * 1024 || shmem_f > 160 * 1024)
@@ -473,10 +498,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if (shmem_a > 64 * 1024)  // more than the default dynamic-LDS limit: opt in (MI355X has 160 KiB per CU)
         HIPCHK(c, hipFuncSetAttribute((const void*)bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
     if (shmem_f > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute((const void*)l.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
+        HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, sizeof(double) * (size_t)nwaves * np, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(l.fwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
+    hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -589,7 +614,7 @@ extern "C" int ude_solve_ensemble(ude_ctx* c, const ude_model_desc* m, const ude
     void *du0, *dth, *dsv;
     if ((rc = up(c, c->s_u0, u0, sizeof(double) * n * N, &du0))) return rc;
     if ((rc = up(c, c->s_theta, theta, sizeof(double) * m->n_param, &dth))) return rc;
-    if ((rc = up(c, c->s_saveat, saveat, sizeof(double) * ns, &dsv))) return rc;
+    if ((rc = up(c, c->s_saveat, saveat, sizeof(double) * ns * ((o->per_trajectory & UDE_PT_SAVEAT) ? N : 1), &dsv))) return rc;
     if ((rc = ensure(c, c->s_out, sizeof(double) * n * ns * N))) return rc;
     if ((rc = ensure(c, c->s_stats, sizeof(int64_t) * 8 * N))) return rc;
     if ((rc = ensure(c, c->s_ret, sizeof(int32_t) * N))) return rc;
@@ -616,7 +641,7 @@ static int grad_host(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* 
     void *du0, *dth, *dsv, *ddat, *dmask;
     if ((rc = up(c, c->s_u0, u0, sizeof(double) * n * N, &du0))) return rc;
     if ((rc = up(c, c->s_theta, theta, sizeof(double) * np, &dth))) return rc;
-    if ((rc = up(c, c->s_saveat, saveat, sizeof(double) * ns, &dsv))) return rc;
+    if ((rc = up(c, c->s_saveat, saveat, sizeof(double) * ns * ((o->per_trajectory & UDE_PT_SAVEAT) ? N : 1), &dsv))) return rc;
     if ((rc = up(c, c->s_data, cot ? cot : data, sizeof(double) * n * ns * N, &ddat))) return rc;
     if ((rc = up(c, c->s_mask, row_mask, n, &dmask))) return rc;
     if ((rc = ensure(c, c->s_out, sizeof(double) * n * ns * N))) return rc;

@@ -131,6 +131,11 @@ def kpp_chain():
     return Chain(Dense(1, 10, "tanh"), Dense(10, 20, "tanh"), Dense(20, 10, "tanh"), Dense(10, 1))
 
 
+def kpp_small_chain(n_weights=3):
+    """rx_nn = Chain(Dense(1, n_weights, tanh), Dense(n_weights, 1))  Fisher-KPP-CNN-Small.jl:89-94 (15 parameters in all)"""
+    return Chain(Dense(1, n_weights, "tanh"), Dense(n_weights, 1))
+
+
 def kpp_s3_chain():
     """rx_nn = Lux.Chain(Dense(1,5,rbf), Dense(5,5,rbf), Dense(5,5,rbf), Dense(5,1))  LotkaVolterra/scenario_3.jl:83-88"""
     return Chain(Dense(1, 5, "rbf"), Dense(5, 5, "rbf"), Dense(5, 5, "rbf"), Dense(5, 1))

@@ -202,10 +202,12 @@ def remake(prob, u0=None, tspan=None, p=None):
 
 
 class EnsembleProblem:
-    """EnsembleProblem(prob; u0s): N trajectories sharing prob.p (theta); u0s is (N, n)."""
+    """EnsembleProblem(prob; u0s[, tspans]): N trajectories sharing prob.p (theta); u0s is (N, n).
+    tspans (N, 2): every member has its own time span -- prob_func = remake(prob; u0 = X[:, i0], tspan = (T[1], T[end]))
+    per shooting segment (scenario_2.jl:104-124); pass the members' save grids as a 2-D saveat (N, ns)."""
 
-    def __init__(self, prob, u0s):
-        self.prob, self.u0s = prob, u0s
+    def __init__(self, prob, u0s, tspans=None):
+        self.prob, self.u0s, self.tspans = prob, u0s, tspans
 
 
 class ODESolution:
@@ -228,10 +230,41 @@ class EnsembleSolution:
         self.t, self.u, self.stats, self.retcodes = t, u, stats, retcode   # u: (N, ns, n)
 
     def __getitem__(self, j):
-        return ODESolution(self.t, self.u[j], self.stats[j], self.retcodes[j])
+        t = self.t[j] if getattr(self.t, "ndim", 1) == 2 else self.t     # per-trajectory save grids
+        return ODESolution(t, self.u[j], self.stats[j], self.retcodes[j])
 
     def __len__(self):
         return self.u.shape[0]
+
+
+def _time_grids(prob, saveat, o):
+    """(tspan array, save grid array, ns) for the C ABI; sets o.per_trajectory for per-member spans / grids"""
+    ens = isinstance(prob, EnsembleProblem)
+    base = prob.prob if ens else prob
+    saveat = base.kwargs.get("saveat") if saveat is None else saveat
+    tspans = getattr(prob, "tspans", None) if ens else None
+    flags = 0
+    if tspans is not None:
+        tspan = _np(tspans)
+        assert tspan.ndim == 2 and tspan.shape[1] == 2
+        flags |= 1
+    else:
+        tspan = _np(base.tspan)
+    if saveat is not None and not np.isscalar(saveat) and np.ndim(saveat) == 2:
+        ts = _np(saveat)
+        spans = tspan if tspan.ndim == 2 else np.repeat(tspan[None], ts.shape[0], axis=0)
+        for j in range(ts.shape[0]):
+            if spans[j, 1] > spans[j, 0] and (np.any(np.diff(ts[j]) <= 0) or ts[j, 0] < spans[j, 0] or ts[j, -1] > spans[j, 1]):
+                raise ValueError("saveat[%d] must be strictly increasing and inside its tspan" % j)
+        flags |= 2
+        ns = ts.shape[1]
+    else:
+        if tspan.ndim == 2 and (saveat is None or np.isscalar(saveat)):
+            raise ValueError("per-trajectory tspans need explicit save grids (2-D saveat, or one shared grid inside every span)")
+        ts = _saveat_grid(saveat, (float(tspan[0]), float(tspan[1])) if tspan.ndim == 1 else (float(tspan[:, 0].max()), float(tspan[:, 1].min())))
+        ns = len(ts)
+    o.per_trajectory = flags
+    return tspan, ts, ns
 
 
 def _saveat_grid(saveat, tspan):
@@ -259,14 +292,13 @@ def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=
     allow_failures=False turns any retcode other than Success into a UdeError."""
     ens = isinstance(prob, EnsembleProblem)
     base = prob.prob if ens else prob
-    saveat = base.kwargs.get("saveat") if saveat is None else saveat
-    ts = _saveat_grid(saveat, base.tspan)
     eng = Engine.get(device)
     if isinstance(ensemblealg, EnsembleMI355):
         eng.set_launch(ensemblealg.lanes_per_traj, ensemblealg.max_dense_steps)
     else:
         eng.set_launch()  # library defaults (the engine is shared: do not inherit another call's launch options)
     o = _opts(alg, **kw)
+    tspan, ts, ns = _time_grids(prob, saveat, o)
     u0 = _np(prob.u0s if ens else base.u0)
     if u0.ndim == 1:
         u0 = u0[None, :]
@@ -274,12 +306,11 @@ def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=
     assert n == base.f.n_state
     theta = _np(base.p if base.p is not None else [])
     assert theta.size == base.f.n_param, "theta has %d entries, model expects %d" % (theta.size, base.f.n_param)
-    tspan = _np(base.tspan)
-    out = np.empty((N, len(ts), n))
+    out = np.zeros((N, ns, n))
     stats = np.zeros((N, NSTATS), dtype=np.int64)
     rc = np.zeros(N, dtype=np.int32)
     eng.check(eng.L.ude_solve_ensemble(eng.h, C.byref(base.f), C.byref(o), N, _ptr(u0), _ptr(tspan), _ptr(theta),
-                                       _ptr(ts), len(ts), _ptr(out), _ptr(stats), _ptr(rc)), allow_traj=allow_failures)
+                                       _ptr(ts), ns, _ptr(out), _ptr(stats), _ptr(rc)), allow_traj=allow_failures)
     if ens:
         return EnsembleSolution(ts, out, stats, rc)
     return ODESolution(ts, out[0], stats[0], rc[0])
@@ -313,25 +344,22 @@ class GradResult:
 def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblealg, kw, sensealg=None, allow_failures=False):
     ens = isinstance(prob, EnsembleProblem)
     base = prob.prob if ens else prob
-    saveat = base.kwargs.get("saveat") if saveat is None else saveat
-    ts = _saveat_grid(saveat, base.tspan)
     eng = Engine.get(device)
     if isinstance(ensemblealg, EnsembleMI355):
         eng.set_launch(ensemblealg.lanes_per_traj, ensemblealg.max_dense_steps)
     else:
         eng.set_launch()  # library defaults (the engine is shared: do not inherit another call's launch options)
     o = _opts(alg, sensealg=sensealg, **kw)
+    tspan, ts, ns = _time_grids(prob, saveat, o)
     u0 = _np(prob.u0s if ens else base.u0)
     if u0.ndim == 1:
         u0 = u0[None, :]
     N, n = u0.shape
     theta = _np(base.p)
     assert theta.size == base.f.n_param
-    tspan = _np(base.tspan)
-    ns = len(ts)
     r = GradResult()
     r.t = ts
-    r.u = np.empty((N, ns, n))
+    r.u = np.zeros((N, ns, n))
     r.grad_theta = np.zeros(theta.size)
     r.grad_u0 = np.zeros((N, n))
     r.stats = np.zeros((N, NSTATS), dtype=np.int64)
