@@ -115,27 +115,13 @@ def cpu_baseline(theta, u0, t, data, seconds_target=15.0, workload="lv", mask=No
 
 
 def pmc_traffic(a):
-    """HBM bytes per adj_kernel launch of the default C2 command, as collected by `rocprofv3 --pmc FETCH_SIZE` /
-    `--pmc WRITE_SIZE` (tools/prof_pass.sh; counters in KB) and committed under profiles/ -- PMC passes cannot run
-    inside the timed bench itself.  None when the run is not that command or the summary is absent."""
-    if a.workload != "lv" or a.net != "s1" or a.alg != "tsit5" or a.sensealg != "adjoint" or a.lanes or a.waves or a.traj:
+    """HBM bytes per launch of the dominant backward kernel of the default command of each workload, as collected by
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (tools/prof_r02.sh; counters in KB) and committed under profiles/ --
+    PMC passes cannot run inside the timed bench itself.  None when the run is not that command or the summary is absent."""
+    if a.net != "s1" or a.alg != "tsit5" or a.lanes or a.waves or a.traj:
         return None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v4_pmc.md")
-    try:
-        txt = open(path).read()
-    except OSError:
-        return None
-    sec = txt.split("### ")
-    for blk in sec:
-        if blk.startswith("`void adj_kernel<LvUde"):
-            vals = {}
-            for line in blk.splitlines():
-                c = [x.strip() for x in line.split("|")]
-                if len(c) >= 5 and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-                    vals[c[1]] = float(c[4])
-            if len(vals) == 2:
-                return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    return None
+    kern = "adj_kernel<" if a.sensealg == "adjoint" else "dadj_kernel<"
+    return pmc_traffic_file("r02_pmc_%s.md" % a.workload, "`void " + kern)
 
 
 def run_hjb(a, rank, world, local, device, dist):
@@ -410,7 +396,7 @@ def main():
                          "note": "FP64 vector/matrix peak (both 78.6 TF); algorithmic %g flop per adjoint eval; "
                                  "the path is FP64-ALU/latency bound, not HBM bound (DESIGN.md); traffic = FETCH_SIZE + "
                                  "WRITE_SIZE bytes per adj_kernel launch from the separate rocprofv3 --pmc passes of this "
-                                 "command (profiles/r01_v4_pmc.md), null for other workloads" % FLOPS[a.workload][1]},
+                                 "command (profiles/r02_pmc_<workload>.md, tools/prof_r02.sh), null for non-default commands" % FLOPS[a.workload][1]},
         }
         if not a.no_cpu_baseline and world == 1:  # (the CPU leg is a rank-0, N=1 measurement)
             out["cpu_baseline"] = cpu_baseline(theta_h, u0_d.cpu().numpy(), t, data.cpu().numpy(), workload=a.workload, mask=mask)

@@ -29,7 +29,8 @@ struct SolveOpts
     alg::Int32; maxiters::Int32
     abstol::Float64; reltol::Float64; dtmax::Float64; dt0::Float64
     qmin::Float64; qmax::Float64; gamma::Float64; qoldinit::Float64; beta1::Float64; beta2::Float64
-    sensealg::Int32; reserved::Int32   # 0 InterpolatingAdjoint, 1 discretise-then-optimise (ForwardDiffSensitivity)
+    sensealg::Int32        # 0 InterpolatingAdjoint, 1 discretise-then-optimise (ForwardDiffSensitivity)
+    per_trajectory::Int32  # UDE_PT_TSPAN = 1 (tspan is 2 x N), UDE_PT_SAVEAT = 2 (saveat is ns x N)
 end
 
 const KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE = Int32.(0:5)
@@ -55,28 +56,50 @@ seir_ude(p_) = UDEModel(ModelDesc(KIND_SEIR_UDE, 0, 7, 4481, 3, pad((3, 64, 64, 
 kpp_ude(Nx) = UDEModel(ModelDesc(KIND_KPP_UDE, 0, Nx, 466, 4, pad((1, 10, 20, 10, 1), 9, Int32(0)), pad((1, 1, 1, 0), 8, Int32(0)),
                                  0, (Int32(-1), Int32(-1)), 461, 465, 0, (1.0, 1.0), (0.0, 0.0), pad((), 16, 0.0)))
 
+"`nn_ode` of Fisher-KPP-CNN-Small.jl:89-124 (15 parameters: rx_nn 1-3-1 tanh; w1 w2 w3; conv bias; D0)"
+kpp_small_ude(Nx) = UDEModel(ModelDesc(KIND_KPP_UDE, 0, Nx, 15, 2, pad((1, 3, 1), 9, Int32(0)), pad((1, 0), 8, Int32(0)),
+                                       0, (Int32(-1), Int32(-1)), 10, 14, 0, (1.0, 1.0), (0.0, 0.0), pad((), 16, 0.0)))
+"`ude_dynamics!` of scenario_2.jl:90-95: theta = [delta; ude(87)], du2 = -delta u2 + NN2"
+lv_ude_s2(; alpha = 1.3) = UDEModel(ModelDesc(KIND_LV_UDE, 0, 2, 88, 4, pad((2, 5, 5, 5, 2), 9, Int32(0)), pad((2, 2, 2, 0), 8, Int32(0)),
+                                              1, (Int32(-1), Int32(0)), 0, 0, 0, (1.0, -1.0), (alpha, 0.0), pad((), 16, 0.0)))
+"`ude_dynamics!` of hudson_bay.jl:85-91: theta = [p1; p2; FastChain(87)], third layer tanh"
+lv_ude_hudson() = UDEModel(ModelDesc(KIND_LV_UDE, 0, 2, 89, 4, pad((2, 5, 5, 5, 2), 9, Int32(0)), pad((2, 2, 1, 0), 8, Int32(0)),
+                                     2, (Int32(0), Int32(1)), 0, 0, 0, (1.0, -1.0), (0.0, 0.0), pad((), 16, 0.0)))
+
 # ---- context ----------------------------------------------------------------------------------------------------
-const CTX = Ref{Ptr{Cvoid}}(C_NULL)
-function ctx()
-    if CTX[] == C_NULL
+const CTXS = Dict{Int,Ptr{Cvoid}}()      # one context per device (and host thread: this shim is single-threaded)
+function ctx(dev::Integer = 0)
+    get!(CTXS, dev) do
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:ude_create, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}), 0, h)
-        rc == 0 || error("ude_create failed ($rc)")
-        CTX[] = h[]
+        rc = ccall((:ude_create, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}), dev, h)
+        rc == 0 || error("ude_create(device = $dev) failed ($rc)")
+        h[]
     end
-    CTX[]
 end
-check(rc) = (rc == 0 || rc == -5) ? rc : error(unsafe_string(ccall((:ude_last_error, libudecore), Cstring, (Ptr{Cvoid},), ctx())))
+# UDE_ERR_TRAJECTORY (-5): a member stopped early; like upstream the solution RETURNS and its retcode says why, but a
+# gradient over a partial ensemble is an error unless the caller opted in (the loss is +Inf in that case)
+function check(rc, dev = 0; allow_failures = false)
+    (rc == 0 || (rc == -5 && allow_failures)) && return rc
+    error(unsafe_string(ccall((:ude_last_error, libudecore), Cstring, (Ptr{Cvoid},), ctx(dev))))
+end
 
 # ---- algorithm types ---------------------------------------------------------------------------------------------
 struct MI355Tsit5 <: SciMLBase.AbstractODEAlgorithm end
 struct MI355Vern7 <: SciMLBase.AbstractODEAlgorithm end
-struct EnsembleMI355 <: SciMLBase.EnsembleAlgorithm end
+"ensemble algorithm: trajectories run as lane groups of the fused HIP kernels, sharded in contiguous blocks over `devices`"
+struct EnsembleMI355 <: SciMLBase.EnsembleAlgorithm
+    devices::Vector{Int}
+end
+EnsembleMI355(; devices = [0]) = EnsembleMI355(collect(Int, devices))
 algcode(::MI355Tsit5) = Int32(0)
 algcode(::MI355Vern7) = Int32(1)
-opts(alg; abstol = 0.0, reltol = 0.0, dtmax = 0.0, dt = 0.0, maxiters = 0, discrete = false, kw...) =
-    SolveOpts(algcode(alg), maxiters, abstol, reltol, dtmax, dt, 0, 0, 0, 0, 0, 0, discrete ? 1 : 0, 0)
-grid(saveat::Number, tspan) = collect(tspan[1]:saveat:tspan[2])
+opts(alg; abstol = 0.0, reltol = 0.0, dtmax = 0.0, dt = 0.0, maxiters = 0, discrete = false, per_trajectory = 0, kw...) =
+    SolveOpts(algcode(alg), maxiters, abstol, reltol, dtmax, dt, 0, 0, 0, 0, 0, 0, discrete ? 1 : 0, per_trajectory)
+function grid(saveat::Number, tspan)      # SciML: save_end = true for a Number saveat
+    ts = collect(tspan[1]:saveat:tspan[2])
+    ts[end] < tspan[2] && push!(ts, tspan[2])
+    ts
+end
 grid(saveat, tspan) = collect(Float64, saveat)
 
 "u0s: n x N matrix (column j = trajectory j); returns (u::Array{Float64,3} n x ns x N, stats 8 x N, retcode N)"
@@ -94,8 +117,68 @@ function solve_ensemble(m::UDEModel, alg, u0s::Matrix{Float64}, tspan, θ::Vecto
     d = Ref(m.desc); o = Ref(opts(alg; kw...)); tsp = Float64[tspan[1], tspan[2]]
     GC.@preserve u0s θ ts out stats rc tsp check(ccall((:ude_solve_ensemble, libudecore), Cint,
         (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
-         Ptr{Float64}, Ptr{Int64}, Ptr{Int32}), ctx(), d, o, N, u0s, tsp, θ, ts, ns, out, stats, rc))
+         Ptr{Float64}, Ptr{Int64}, Ptr{Int32}), ctx(), d, o, N, u0s, tsp, θ, ts, ns, out, stats, rc); allow_failures = true)
     out, stats, rc
+end
+
+"loss(θ) = sum(abs2, data[rows, :] .- Array(solve(...))[rows, :]) over the ensemble and its gradient in ONE call
+(seir_exposure.jl:144-147 with `rows` = 2:4; Fisher-KPP-CNN.jl:140-143; scenario_1.jl:91-94).  `tspans` (2 x N) /
+`tss` (ns x N) give every member its own span and save grid (the segments of scenario_2.jl:104-124)."
+function loss_grad_ensemble(m::UDEModel, alg, u0s::Matrix{Float64}, tspan, θ::Vector{Float64}, ts::AbstractVecOrMat{Float64},
+                            data::Array{Float64,3}; rows = nothing, dev = 0, kw...)
+    n, N = size(u0s); ns = size(ts, 1)
+    flags = (tspan isa AbstractMatrix ? 1 : 0) | (ts isa AbstractMatrix ? 2 : 0)
+    mask = rows === nothing ? C_NULL : UInt8[i in rows for i in 1:n]
+    loss = Ref(0.0); lpt = zeros(N); gθ = zeros(length(θ)); gu0 = zeros(n, N); u = Array{Float64}(undef, n, ns, N)
+    stats = zeros(Int64, 8, N); rc = zeros(Int32, N)
+    d = Ref(m.desc); o = Ref(opts(alg; per_trajectory = flags, kw...)); tsp = collect(Float64, vec(tspan isa Tuple ? [tspan...] : tspan)); tsa = collect(Float64, ts)
+    GC.@preserve u0s θ tsa data mask lpt gθ gu0 u stats rc tsp check(ccall((:ude_loss_grad_ensemble, libudecore), Cint,
+        (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
+         Ptr{Float64}, Ptr{UInt8}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
+        ctx(dev), d, o, N, u0s, tsp, θ, tsa, ns, data, mask, loss, lpt, gθ, gu0, u, stats, rc), dev)
+    loss[], gθ, gu0, u, stats, rc
+end
+
+# ---- multi-GPU (SURVEY.md 8(e)): contiguous blocks of trajectories per device, ONE all-reduce of [grad; loss; counters] ----
+"`_dev` entry points take HBM pointers; the shim keeps each device's buffers in plain hipMalloc'ed memory owned by
+the caller's GPU array package (AMDGPU.jl `ROCArray` pointers) -- shown here with `Ptr{Float64}` arguments."
+function loss_grad_multi(m::UDEModel, alg, devs::Vector{Int}, dptr::Vector{NamedTuple}, tspan, ts::Vector{Float64}; p2p = true, kw...)
+    np = Int(m.desc.n_param); nd = length(devs)
+    ctxs = [ctx(dv) for dv in devs]
+    comms = Vector{Ptr{Cvoid}}(undef, nd)
+    check(ccall((:ude_comm_create_local, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), nd, ctxs, comms))
+    d = Ref(m.desc); o = Ref(opts(alg; kw...)); tsp = Float64[tspan[1], tspan[2]]
+    for (k, dv) in enumerate(devs)       # enqueue on every device; nothing blocks
+        b = dptr[k]                      # (N, u0, theta, saveat, data, mask, payload = [grad(np); loss; counters(3)], gu0, u, stats, rc)
+        check(ccall((:ude_loss_grad_ensemble_dev, libudecore), Cint,
+            (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
+             Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
+            ctxs[k], d, o, b.N, b.u0, tsp, b.theta, b.saveat, length(ts), b.data, b.mask, b.payload + 8np, C_NULL, b.payload, b.gu0, b.u,
+            b.stats, b.rc), dv)
+    end
+    bufs = [b.payload for b in dptr]
+    f = p2p ? :ude_allreduce_grad_p2p : :ude_allreduce_grad_local      # fixed-rank-order peer reads, or RCCL (grouped)
+    check(ccall((f, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Int64), nd, comms, bufs, np + 4))
+    foreach(c -> ccall((:ude_comm_destroy, libudecore), Cvoid, (Ptr{Cvoid},), c), comms)
+    nothing                              # every device's payload now holds the ensemble-wide [grad; loss; counters]
+end
+
+# ---- highdim_pde/lambaem.jl: NNPDENS + LambaEM (SURVEY.md 8(f) N1) ---------------------------------------------------
+struct HjbDesc
+    d::Int32; hls::Int32; adaptive::Int32; maxiters::Int32; max_steps::Int32; reserved::Int32; seed::UInt64
+    lambda::Float64; sigma::Float64; t0::Float64; t1::Float64; abstol::Float64; reltol::Float64; dt::Float64
+    qmin::Float64; qmax::Float64; gamma::Float64; qoldinit::Float64; beta1::Float64; beta2::Float64; dtmax::Float64
+end
+"one evaluation of loss_n_sde() and its gradient w.r.t. Flux.params(u0, σᵀ∇u) (flattened) for `trajectories` LambaEM solves
+(lambaem.jl:33-34); `iter` = the training iteration (fresh Philox noise per iteration)"
+function hjb_loss_grad(x0::Vector{Float32}, θ::Vector{Float32}, trajectories::Integer, iter::Integer; d = 100, hls = 110, λ = 1.0,
+                       tspan = (0.0, 1.0), abstol = 1e-4, reltol = 1e-4, seed = 0, adaptive = true, dt = 0.0)
+    D = Ref(HjbDesc(d, hls, adaptive, 0, 0, 0, seed, λ, sqrt(2.0f0), tspan[1], tspan[2], abstol, reltol, dt, 0, 0, 0, 0, 0, 0, 0))
+    loss = Ref(0.0); g = zeros(Float32, length(θ)); u0 = Ref(0.0f0); M = Int64(trajectories)
+    GC.@preserve x0 θ g check(ccall((:ude_hjb_loss_grad, libudecore), Cint,
+        (Ptr{Cvoid}, Ref{HjbDesc}, Int64, Ptr{Float32}, Ptr{Float32}, UInt32, Ref{Float64}, Ptr{Float32}, Ref{Float32}, Ptr{Float32},
+         Ptr{Float32}, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}), ctx(), D, M, x0, θ, iter, loss, g, u0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+    loss[], g, u0[]
 end
 
 "cotangent Δ (n x ns x N) of the saved states -> (dθ summed over the ensemble, du0 n x N)"
@@ -117,9 +200,10 @@ function DiffEqBase.__solve(prob::SciMLBase.AbstractODEProblem, alg::Union{MI355
     ts = grid(saveat, prob.tspan)
     u, stats, rc = solve_ensemble(m, alg, reshape(Vector{Float64}(prob.u0), :, 1), prob.tspan, Vector{Float64}(prob.p), ts; kw...)
     retcode = rc[1] == 0 ? :Success : rc[1] == 1 ? :MaxIters : rc[1] == 2 ? :DtLessThanMin : :Unstable
-    sol = DiffEqBase.build_solution(prob, alg, ts, [u[:, i, 1] for i in 1:length(ts)]; retcode = retcode)
-    sol.destats.nf = stats[1, 1]; sol.destats.naccept = stats[2, 1]; sol.destats.nreject = stats[3, 1]
-    sol
+    destats = DiffEqBase.DEStats(0)      # (a mutable struct in DiffEqBase 6.94 / SciMLBase 1.45, LotkaVolterra/Manifest.toml:390,1723)
+    destats.nf = stats[1, 1]; destats.naccept = stats[2, 1]; destats.nreject = stats[3, 1]
+    # dense = false: like upstream's saveat-only solutions, sol(t, Val{1}) interpolates linearly (scenario_1.jl:46)
+    DiffEqBase.build_solution(prob, alg, ts, [u[:, i, 1] for i in 1:length(ts)]; retcode = retcode, destats = destats, dense = false)
 end
 
 # Zygote: Array(solve(remake(prob; u0, p = θ), alg; saveat, ...)) differentiated by the interpolating adjoint on the GPU
@@ -135,7 +219,7 @@ function ChainRulesCore.rrule(::typeof(DiffEqBase.solve_up), prob, sensealg, u0,
 end
 
 # ensembles: solve(EnsembleProblem(prob; prob_func = (prob,i,_) -> remake(prob; u0 = u0s[:, i])), alg, EnsembleMI355(); trajectories = N)
-function SciMLBase.__solve(ens::SciMLBase.AbstractEnsembleProblem, alg::Union{MI355Tsit5,MI355Vern7}, ::EnsembleMI355;
+function SciMLBase.__solve(ens::SciMLBase.AbstractEnsembleProblem, alg::Union{MI355Tsit5,MI355Vern7}, ea::EnsembleMI355;
                            trajectories, saveat, kw...)
     probs = [ens.prob_func(ens.prob, i, 1) for i in 1:trajectories]
     u0s = reduce(hcat, [Vector{Float64}(p.u0) for p in probs])

@@ -224,6 +224,35 @@ class ODESolution:
         a = self._u.T                    # Array(sol) is n x ns
         return a.astype(dtype) if dtype else a
 
+    def __call__(self, tvals, deriv=0):
+        """sol(t) / sol(t, Val{1})  (scenario_1.jl:46, scenario_2.jl:48, seir_exposure.jl:176: `DX = Array(solution(solution.t, Val{1}))`).
+        A solve with `saveat` keeps no dense output upstream (dense = false), so the solution interpolates LINEARLY between
+        the saved points [UP: SciMLBase LinearInterpolation, continuity = :left]: the value at t in (t[i-1], t[i]] is
+        u[i-1] + theta (u[i] - u[i-1]); Val{1} is the slope (u[i] - u[i-1]) / (t[i] - t[i-1]) of that interval, the first
+        interval serving t = t[1].  Returns n x len(tvals) like Array(sol(ts)).  (The model's exact derivative at the saved
+        states is `rhs(f, Array(sol)', p)`.)"""
+        t = np.asarray(self.t, dtype=float)
+        u = self._u
+        scalar = np.isscalar(tvals)
+        tv = np.atleast_1d(np.asarray(tvals, dtype=float))
+        if tv.min() < t[0] or tv.max() > t[-1]:
+            raise ValueError("Solution interpolation cannot extrapolate past the saved time points")
+        if len(t) < 2:
+            raise ValueError("interpolation needs at least two saved points")
+        out = np.empty((u.shape[1], tv.size))
+        for k, x in enumerate(tv):
+            i = int(np.searchsorted(t, x, side="left"))     # first index with t[i] >= x
+            i = max(i, 1)
+            dt = t[i] - t[i - 1]
+            if deriv == 0:
+                th = (x - t[i - 1]) / dt
+                out[:, k] = u[i] if x == t[i] else u[i - 1] + th * (u[i] - u[i - 1])
+            elif deriv == 1:
+                out[:, k] = (u[i] - u[i - 1]) / dt
+            else:
+                raise ValueError("a linear interpolant has derivatives of order 0 and 1 only")
+        return out[:, 0] if scalar else out
+
 
 class EnsembleSolution:
     def __init__(self, t, u, stats, retcode):
