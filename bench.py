@@ -130,7 +130,7 @@ def run_hjb(a, rank, world, local, device, dist):
     `--traj` trajectories per GPU.  Tolerances: the script's 1e-4 would take ~4e5 steps per trajectory under this
     restatement of Lamba's estimator (oracle/sde_oracle.h); the bench uses abstol = reltol = --tol (default 0.1, ~250 steps; 1e-2: ~1200 steps, pass --max-steps 2048)."""
     from universal_differential_equations_amd import pde
-    M = a.traj or 8192
+    M = a.traj or 16384     # 64 slots per CU: every slot serves two trajectories on average through the queue
     alg = pde.NNPDENS(100, 110, opt=pde.ADAM(0.03))
     theta_h = alg.init_params(np.random.default_rng(0))
     prob = pde.TerminalPDEProblem(pde.hjb(1.0), np.zeros(100), (0.0, 1.0))

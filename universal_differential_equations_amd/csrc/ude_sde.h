@@ -153,9 +153,19 @@ __device__ __forceinline__ void layer(const float (&wf)[KS], const float* in, fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bias[rbase + (r & 3) + 8 * (r >> 2)];
         const float* bp = in + (l >> 5) * LDA + nt * 32 + (l & 31);
+        // B operands are fetched PF k-steps ahead of the matrix-core instruction that consumes them: the dependent MFMA
+        // chain (64 cycles per instruction) then never waits for an LDS round trip
+        // (sched_barrier: the machine scheduler otherwise sinks every load next to its use to save registers)
+        constexpr int PF = KS < 6 ? KS : 6;
+        float bq[PF];
+        static_for<0, PF>([&](auto ic) { bq[ic] = bp[2 * decltype(ic)::value * LDA]; });
+        __builtin_amdgcn_sched_barrier(0);
         static_for<0, KS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s], bp[2 * s * LDA], acc, 0, 0, 0);
+            const float b = bq[s % PF];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s], b, acc, 0, 0, 0);
+            if constexpr (s + PF < KS) bq[s % PF] = bp[2 * (s + PF) * LDA];
+            __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (RELU) {
 #pragma unroll
@@ -822,9 +832,16 @@ __device__ __forceinline__ void layer_bwd(const float (&wt)[KS], const float* di
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const float* bp = din + (l >> 5) * LDT + (l & 31);
+    constexpr int PF = KS < 6 ? KS : 6;   // operand prefetch distance (see layer())
+    float bq[PF];
+    static_for<0, PF>([&](auto ic) { bq[ic] = bp[2 * decltype(ic)::value * LDT]; });
+    __builtin_amdgcn_sched_barrier(0);
     static_for<0, KS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[s], bp[2 * s * LDT], acc, 0, 0, 0);
+        const float b = bq[s % PF];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[s], b, acc, 0, 0, 0);
+        if constexpr (s + PF < KS) bq[s % PF] = bp[2 * (s + PF) * LDT];
+        __builtin_amdgcn_sched_barrier(0);
     });
     const int rbase = 32 * w + 4 * (l >> 5);
 #pragma unroll
@@ -838,11 +855,18 @@ __device__ __forceinline__ void layer_bwd(const float (&wt)[KS], const float* di
 __device__ __forceinline__ void outer_acc(v16f (&G)[4], const float* dl, const float* act, int w, int l) {
     const float* ap = dl + (32 * w + (l & 31)) * LDT + (l >> 5);
     const float* bp = act + (l & 31) * LDT + (l >> 5);
+    // all operands of the tile's 16 k-steps are fetched first (4 independent accumulator chains keep the pipe full)
+    float av[16], bv[4][16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const float a = ap[2 * s];
+        av[s] = ap[2 * s];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) G[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[nt * 32 * LDT + 2 * s], G[nt], 0, 0, 0);
+        for (int nt = 0; nt < 4; ++nt) bv[nt][s] = bp[nt * 32 * LDT + 2 * s];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) G[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[nt][s], G[nt], 0, 0, 0);
     }
 }
 
