@@ -54,5 +54,5 @@ print("reference final loss %g after %d iterations" % (gold[-1], len(gold)))
 # Save the results (scenario_1.jl:210-213) in the reference's own file format: the arrays of its `save(...)` call
 from universal_differential_equations_amd import io                                   # noqa: E402
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "Scenario_1_recovery_0.005_mi355x.jld2")
-io.save_jld2(out, X=X, t=t, initial_parameters=p0, trained_parameters=np.asarray(p2), losses=np.asarray(losses))
+io.save_jld2(out, X=Xn, t=t, initial_parameters=p0, trained_parameters=np.asarray(p2), losses=np.asarray(losses))
 print("saved", out)
