@@ -95,7 +95,8 @@ typedef struct {
     int32_t max_dense_steps;  /* capacity of the dense forward store per trajectory; 0 = automatic: starts at 256 and is
                                  re-run with 4x the capacity on UDE_RET_DENSE_OVERFLOW by the host-buffer entry points
                                  (ude_last_failures does the same for the asynchronous _dev entry points) */
-    int32_t waves_per_simd;   /* 0/1 = default; 2 = adjoint kernel variant register-bounded for 2 waves per SIMD */
+    int32_t waves_per_simd;   /* kernel variant of the adjoint kernel: 0/1 = default (the only compiled one; the 2-waves-per-SIMD
+                                 builds of the 4- and 8-lane LV kernels spill to scratch and were measured 5x slower) */
 } ude_launch_opts;
 
 /* per-trajectory stats, int64[UDE_NSTATS]:

@@ -10,4 +10,7 @@ using InstModel = INST_MODEL;
 #ifndef INST_BLOCK
 #define INST_BLOCK 64
 #endif
-extern "C" void INST_NAME(Launch* out) { *out = make_launch<InstModel, INST_TAB, INST_G, INST_BLOCK>(); }
+#ifndef INST_VAR
+#define INST_VAR 1
+#endif
+extern "C" void INST_NAME(Launch* out) { *out = make_launch<InstModel, INST_TAB, INST_G, INST_BLOCK, INST_VAR>(); }

@@ -749,12 +749,15 @@ __global__ void __launch_bounds__(BLOCK) rhs_kernel(const KParams p) {
 //   lambda' = -(df/du)^T lambda, mu' = -(df/dtheta)^T lambda at y(t) = forward dense interpolant;
 //   save times are tstops with lambda += dL/du(t_i)            
 // ---------------------------------------------------------------------------------------------
-template <class Model, class Tab, int G, bool PT = false>
+// VAR: kernel variant of the instance (build.py's waves column).  It is a template parameter so that variants of one
+// (model, algorithm, lanes) are DIFFERENT kernels: a macro-only difference gives the same mangled name in several
+// translation units and the linker keeps one of them.  VAR == 9: timing experiment, lambda only (no mu work at all).
+template <class Model, class Tab, int G, bool PT = false, int VAR = 1>
 struct AdjSys {
     TimeGrid<PT> tg;
     __device__ __forceinline__ double dtmax(const Opts& o) const { return tg.DTMAX(o); }
     static constexpr bool DEFERRED = Model::DEFERRED;
-    static constexpr int NR = Model::NS, NSL = DEFERRED ? 0 : Model::NSL;
+    static constexpr int NR = Model::NS, NSL = (DEFERRED || VAR == 9) ? 0 : Model::NSL;
     static constexpr bool STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     // LDS-slot models re-evaluate stage 0 every step (its parameter cotangent is folded straight into the shared
     // accumulators); register-slot models hand k_S -> k_0 AND its slot derivative over (FSAL, as upstream)
@@ -887,7 +890,7 @@ struct AdjSys {
             const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
             y[c] = __builtin_fma(dtf, acc, US(c));
         });
-        Model::template vjp<true>(mctx, y, lam, dl, g);
+        Model::template vjp<(NSL > 0)>(mctx, y, lam, dl, g);
         static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
         static_for<0, NSL>([&](auto c) { g[c] = -g[c]; });
       }
@@ -928,11 +931,8 @@ struct AdjSys {
     }
 };
 
-#ifndef UDE_ADJ_MIN_WAVES
-#define UDE_ADJ_MIN_WAVES 1
-#endif
-template <class Model, class Tab, int G, int BLOCK, bool PT = false>
-__global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KParams p) {
+template <class Model, class Tab, int G, int BLOCK, bool PT = false, int VAR = 1>
+__global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK>;
     double* th = reinterpret_cast<double*>(smem_raw);
@@ -947,7 +947,7 @@ __global__ void __launch_bounds__(BLOCK, UDE_ADJ_MIN_WAVES) adj_kernel(const KPa
     constexpr int GROUPS = BLOCK / G;
     const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
     const int r = threadIdx.x % G;
-    using Sys = AdjSys<Model, Tab, G, PT>;
+    using Sys = AdjSys<Model, Tab, G, PT, VAR>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     constexpr int NSL = Sys::NSL;
     constexpr int NSLA = NSL > 0 ? NSL : 1;

@@ -25,15 +25,15 @@ struct Launch {
     }
 };
 
-template <class Model, class Tab, int G, int BLOCK = 64>
+template <class Model, class Tab, int G, int BLOCK = 64, int VAR = 1>
 inline Launch make_launch() {
     Launch l;
     l.fwd = fwd_kernel<Model, Tab, G, BLOCK>;
-    l.adj = adj_kernel<Model, Tab, G, BLOCK>;
+    l.adj = adj_kernel<Model, Tab, G, BLOCK, false, VAR>;
     l.dadj = dadj_kernel<Model, Tab, G, BLOCK>;
     l.rhs = rhs_kernel<Model, Tab, G, BLOCK>;
     l.fwd_pt = fwd_kernel<Model, Tab, G, BLOCK, true>;
-    l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true>;
+    l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true, VAR>;
     l.dadj_pt = dadj_kernel<Model, Tab, G, BLOCK, true>;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
