@@ -218,9 +218,16 @@ template <class N, int G>
 struct CoopMlp {
     static constexpr int L = N::L;
     static constexpr int own(int l) { return (N::dim(l + 1) + G - 1) / G; }  // neurons of layer l per lane
+    // Parameter-cotangent slots of a layer normally follow its neurons (lane r: the rows of its own(l) neurons).  The narrow
+    // LAST layer (out = 2 of 5 lanes) would leave most lanes with padding slots, so when its inputs are spread one per lane
+    // (in <= G, one neuron of the layer below per lane) its slots go by INPUT instead: lane r owns W[:, r] (out slots) and,
+    // for r < out, the bias b[r] -- out + 1 slots per lane instead of in + 1 (LV 2-5-5-5-2 on 5 lanes: 21 -> 18 slots).
+    // Every slot value is the same product as before (delta_j * a_r with delta replicated, a_r the lane's own activation).
+    static constexpr bool KMAJ = (G > 1) && (L >= 2) && (N::dim(L - 1) <= G) && (own(L - 2 >= 0 ? L - 2 : 0) == 1);
+    static constexpr int layer_slots(int l) { return (KMAJ && l == L - 1) ? N::dim(L) + 1 : own(l) * (N::dim(l) + 1); }
     static constexpr int slot_off(int l) {
         int o = 0;
-        for (int i = 0; i < l; ++i) o += own(i) * (N::dim(i) + 1);
+        for (int i = 0; i < l; ++i) o += layer_slots(i);
         return o;
     }
     static constexpr int NSLOT = slot_off(L);
@@ -363,12 +370,21 @@ struct CoopMlp {
                 const double d = valid ? gp * act_bwd<N::act(l)>(c.z[l][m], c.ao[l][m]) : 0.0;
                 down[m] = d;
                 sink(l, m, d);
-                if constexpr (WANT_PARAM) {
+                if constexpr (WANT_PARAM && !(KMAJ && l == L - 1)) {
                     constexpr int s0 = slot_off(l) + m * (in + 1);
                     static_for<0, in>([&](auto k) { g[s0 + k] = d * c.a[l][k]; });
                     g[s0 + in] = d;
                 }
             });
+            if constexpr (WANT_PARAM && KMAJ && l == L - 1) {
+                // slots by input: dall still holds the (replicated) deltas of this linear layer = gy
+                constexpr int s0 = slot_off(L - 1);
+                const double ak = c.ao[L - 2][0];  // this lane's own activation below = a_{L-1}[r] (0 on lanes without a neuron)
+                static_for<0, out>([&](auto j) { g[s0 + j] = dall[j] * ak; });
+                double gb = dall[0];
+                static_for<1, out>([&](auto i) { gb = (r == i) ? dall[i] : gb; });
+                g[s0 + out] = r < out ? gb : 0.0;
+            }
             if constexpr (l > 0) {
                 allgather<out>(c.gb, r, down, dall);
             } else {
@@ -394,7 +410,14 @@ struct CoopMlp {
         static_for<0, L>([&](auto lc) {
             constexpr int l = lc;
             constexpr int in = N::dim(l), out = N::dim(l + 1);
-            constexpr int lo = slot_off(l), hi = slot_off(l) + own(l) * (in + 1);
+            constexpr int lo = slot_off(l), hi = slot_off(l) + layer_slots(l);
+            if constexpr (KMAJ && l == L - 1) {
+                if (s >= lo && s < hi) {
+                    const int q = s - lo;
+                    if (q < out) { if (r < in) res = N::off(l) + q + r * out; }
+                    else if (r < out) res = N::off(l) + in * out + r;
+                }
+            } else
             if (s >= lo && s < hi) {
                 const int m = (s - lo) / (in + 1), k = (s - lo) % (in + 1);
                 const int j = r + m * G;
