@@ -75,12 +75,15 @@ struct LvTrue : LinearTheta {
 // ude_dynamics!  (scenario_1.jl:69-73; scenario_2.jl:90-95 trainable delta; hudson_bay.jl:85-91
 // trainable p1,p2):  du_i = lin_i * u_i + NN_i(u),  lin_i = lin_const_i or lin_sign_i*theta[lin_idx_i]
 // ---------------------------------------------------------------------------------------------
-template <class Net, int G>
+// NLIN: slots for trainable diagonal coefficients (2: scenario_2's delta / hudson_bay's p1, p2 may be trained; 0: both
+// diagonal coefficients are constants as in scenario_1.jl:69-73 -- no slots, no accumulators, no divisions for them)
+template <class Net, int G, int NLIN = 2>
 struct LvUde : LinearTheta {
     using Mlp = CoopMlp<Net, G>;
     static_assert(Net::dim(0) == 2 && Net::dim(Net::L) == 2, "LV UDE network maps R^2 -> R^2");
+    static_assert(NLIN == 0 || NLIN == 2, "none or both diagonal slots");
     static constexpr int NS = 2;
-    static constexpr int NSL = Mlp::NSLOT + 2;  // + the two (optional) trainable diagonal coefficients
+    static constexpr int NSL = Mlp::NSLOT + NLIN;  // + the two (optional) trainable diagonal coefficients
     static constexpr bool STATE_DISTRIBUTED = false;
     // weights in registers when the lane's share is small (narrow layers spread over >= 5 lanes), else read from LDS
     static constexpr bool REGW = (G >= 5) && (Net::maxdim() <= 8);
@@ -129,7 +132,7 @@ struct LvUde : LinearTheta {
         }
         dlam[0] = __builtin_fma(c.lin[0], lam[0], gx[0]);
         dlam[1] = __builtin_fma(c.lin[1], lam[1], gx[1]);
-        if constexpr (WANT_PARAM) {
+        if constexpr (WANT_PARAM && NLIN == 2) {
             g[Mlp::NSLOT + 0] = (c.lead_on[0] * u[0]) * lam[0];
             g[Mlp::NSLOT + 1] = (c.lead_on[1] * u[1]) * lam[1];
         }

@@ -177,12 +177,17 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
     const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
     bool ok = false;
-    for (const InstanceRow& row : kInstances)
-        if (row.mid == mid && row.alg == o->alg && row.G == G && row.W == W) {
-            row.get(&l);
-            ok = true;
-            break;
-        }
+    // scenario_1's chain with both diagonal coefficients constant has a leaner instance (no slots for them) where compiled
+    const int mid_first = (mid == MID_LV_S1 && m->lin_idx[0] < 0 && m->lin_idx[1] < 0) ? MID_LV_S1N : mid;
+    for (int pass = 0; pass < 2 && !ok; ++pass) {
+        const int want = pass == 0 ? mid_first : mid;
+        for (const InstanceRow& row : kInstances)
+            if (row.mid == want && row.alg == o->alg && row.G == G && row.W == W) {
+                row.get(&l);
+                ok = true;
+                break;
+            }
+    }
     if (!ok) return fail(c, UDE_ERR_UNSUPPORTED, "no kernel instance for model %d alg %d lanes_per_traj %d waves_per_simd %d", mid, o->alg, G, W);
     return UDE_OK;
 }
