@@ -51,7 +51,11 @@ enum { UDE_OK = 0, UDE_ERR_INVALID = -1, UDE_ERR_UNSUPPORTED = -2, UDE_ERR_HIP =
  * (scenario_1.jl:62-78, seir_exposure.jl:114-131, Fisher-KPP-CNN.jl:92-131) */
 typedef struct {
     int32_t kind;
-    int32_t dtype;                     /* 0 = f64 (f32 problems are not built yet: UDE_ERR_UNSUPPORTED) */
+    int32_t dtype;                     /* 0 = Float64; 1 = Float32 (scenario_3.jl:26-57,121-126; hudson_bay.jl:77-104): EVERY real-valued
+                                          array argument of the call (u0, theta, saveat, u_out, data, cotangent, grad_*, loss,
+                                          loss_per_traj) is then float behind the same pointers; tspan stays a pair of host doubles.
+                                          Compiled Float32 instances: LV UDE 2-5-5-5-2 rbf/rbf/tanh (hudson), Fisher-KPP true and
+                                          its 1-5-5-5-1 rbf UDE on <= 32 points; anything else: UDE_ERR_UNSUPPORTED */
     int32_t n_state;
     int32_t n_param;                   /* length of theta */
     int32_t n_layers;                  /* number of Dense layers (0 for mechanistic kinds) */

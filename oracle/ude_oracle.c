@@ -189,7 +189,9 @@ static float ulp_f32(float x) { x = fabsf(x); return nextafterf(x, INFINITY) - x
 #define R_FMA fma
 #define R_EPS 2.220446049250313e-16
 #include "ude_oracle_impl.h"
+#define UDEO_ADJ_F64_ONLY 1
 #include "ude_oracle_adj.h"
+#undef UDEO_ADJ_F64_ONLY
 #undef REAL
 #undef FN
 #undef R_EXP
@@ -205,15 +207,18 @@ static float ulp_f32(float x) { x = fabsf(x); return nextafterf(x, INFINITY) - x
 /* ---- f32 instantiation ---- */
 #define REAL float
 #define FN(name) name##_f32
-#define R_EXP expf
-#define R_TANH tanhf
+/* Float32 elementary functions = the ARITH-SPEC double kernels rounded once to Float32 (deterministic on every machine,
+ * and what the Float32 HIP instances evaluate); within 1 ulp of Julia's Float32 exp / tanh / log10 / ^ */
+#define R_EXP(x) ((float)udeo_exp((double)(x)))
+#define R_TANH(x) ((float)udeo_tanh((double)(x)))
 #define R_SQRT sqrtf
 #define R_FABS fabsf
-#define R_LOG10 log10f
-#define R_POW powf
-#define R_POW10(x) ((float)pow(10.0, (double)(x)))
+#define R_LOG10(x) ((float)udeo_log10((double)(x)))
+#define R_POW(x, y) ((float)udeo_pow((double)(x), (double)(y)))
+#define R_POW10(x) ((float)udeo_pow10((double)(x)))
 #define R_FMA fmaf
 #define R_EPS 1.1920929e-07f
 #include "ude_oracle_impl.h"
+#include "ude_oracle_adj.h"
 #undef REAL
 #undef FN

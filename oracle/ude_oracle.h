@@ -136,6 +136,20 @@ int udeo_solve_ensemble_f32(const udeo_model_desc* m, const udeo_solve_opts* o, 
                             const float* saveat, int32_t ns, float* u_out, int64_t* stats,
                             int32_t* retcode, int32_t nthreads);
 
+/* Float32 gradients (scenario_3.jl:121-134 and hudson_bay.jl:98-123 train in Float32 with ForwardDiffSensitivity: the
+ * discrete sweep; the interpolating adjoint is instantiated too) */
+int udeo_vjp_ensemble_f32(const udeo_model_desc* m, const udeo_solve_opts* o, int64_t N,
+                          const float* u0, const float* tspan, const float* theta,
+                          const float* saveat, int32_t ns, const float* cotangent,
+                          float* u_out, float* grad_theta, float* grad_u0, int64_t* stats,
+                          int32_t* retcode, int32_t nthreads);
+int udeo_loss_grad_ensemble_f32(const udeo_model_desc* m, const udeo_solve_opts* o, int64_t N,
+                                const float* u0, const float* tspan, const float* theta,
+                                const float* saveat, int32_t ns, const float* data,
+                                const uint8_t* row_mask, float* loss, float* loss_per_traj,
+                                float* grad_theta, float* grad_u0, float* u_out, int64_t* stats,
+                                int32_t* retcode, int32_t nthreads);
+
 #ifdef __cplusplus
 }
 #endif

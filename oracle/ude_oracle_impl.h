@@ -616,13 +616,15 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
                 }
             }
             /* calculate_residuals + ODE_DEFAULT_NORM (DiffEqBase) */
-            REAL s = 0;
+            /* ARITH-SPEC: the sum of squares is accumulated in double for both scalar types (Float32: order-independent after
+             * the rounding back to float -- the kernels sum over lanes in a tree; upstream's @simd sum has no fixed order) */
+            double s = 0;
             for (int i = 0; i < nz; ++i) {
                 const REAL a0 = R_FABS(uprev[i]), a1 = R_FABS(u[i]);
                 const REAL res = utilde[i] / R_FMA((a0 > a1 ? a0 : a1), r->reltol, r->abstol);
-                s = R_FMA(res, res, s);
+                s = fma((double)res, (double)res, s);
             }
-            const REAL EEst = R_SQRT(s / (REAL)nz);
+            const REAL EEst = R_SQRT((REAL)s / (REAL)nz);
             /* ---- loopfooter!: stepsize_controller! (PIController) ---- */
             REAL q;
             if (EEst == 0) {

@@ -212,28 +212,29 @@ def solve_ensemble(m, o, u0, tspan, theta, saveat, dtype=np.float64, nthreads=1)
     return out, stats, rc
 
 
-def loss_grad_ensemble(m, o, u0, tspan, theta, saveat, data, row_mask=None, nthreads=1):
+def loss_grad_ensemble(m, o, u0, tspan, theta, saveat, data, row_mask=None, nthreads=1, dtype=np.float64):
     """data: (N, ns, n).  returns dict(loss, loss_per_traj, grad_theta, grad_u0, u, stats, retcode)"""
     L = lib()
-    u0 = _arr(u0, np.float64)
+    u0 = _arr(u0, dtype)
     if u0.ndim == 1:
         u0 = u0[None, :]
     N, n = u0.shape
-    tspan, theta, saveat = _arr(tspan, np.float64), _arr(theta, np.float64), _arr(saveat, np.float64)
-    data = _arr(data, np.float64).reshape(N, len(saveat), n)
+    tspan, theta, saveat = _arr(tspan, dtype), _arr(theta, dtype), _arr(saveat, dtype)
+    data = _arr(data, dtype).reshape(N, len(saveat), n)
     ns = len(saveat)
     mask = None if row_mask is None else _arr(row_mask, np.uint8)
-    loss = C.c_double(0.0)
-    lpt = np.zeros(N)
-    g = np.zeros(m.n_param)
-    gu0 = np.zeros((N, n))
-    out = np.zeros((N, ns, n))
+    loss = np.zeros(1, dtype=dtype)
+    lpt = np.zeros(N, dtype=dtype)
+    g = np.zeros(m.n_param, dtype=dtype)
+    gu0 = np.zeros((N, n), dtype=dtype)
+    out = np.zeros((N, ns, n), dtype=dtype)
     stats = np.zeros((N, NSTATS), dtype=np.int64)
     rc = np.zeros(N, dtype=np.int32)
-    L.udeo_loss_grad_ensemble_f64(C.byref(m), C.byref(o), C.c_int64(N), _p(u0), _p(tspan), _p(theta),
-                                  _p(saveat), C.c_int32(ns), _p(data), _p(mask), C.byref(loss), _p(lpt),
-                                  _p(g), _p(gu0), _p(out), _p(stats), _p(rc), C.c_int32(nthreads))
-    return dict(loss=loss.value, loss_per_traj=lpt, grad_theta=g, grad_u0=gu0, u=out, stats=stats, retcode=rc)
+    fn = L.udeo_loss_grad_ensemble_f64 if dtype == np.float64 else L.udeo_loss_grad_ensemble_f32
+    fn(C.byref(m), C.byref(o), C.c_int64(N), _p(u0), _p(tspan), _p(theta), _p(saveat), C.c_int32(ns), _p(data), _p(mask),
+       _p(loss), _p(lpt), _p(g), _p(gu0), _p(out), _p(stats), _p(rc), C.c_int32(nthreads))
+    return dict(loss=loss[0] if dtype != np.float64 else float(loss[0]), loss_per_traj=lpt, grad_theta=g, grad_u0=gu0, u=out,
+                stats=stats, retcode=rc)
 
 
 def vjp_ensemble(m, o, u0, tspan, theta, saveat, cotangent, nthreads=1):

@@ -1,0 +1,86 @@
+"""Float32 problems on the GPU (ude_model_desc.dtype = 1): LotkaVolterra/scenario_3.jl:26-57 (true Fisher-KPP, Tsit5),
+scenario_3.jl:83-134 (its UDE: Vern7, ForwardDiffSensitivity) and hudson_bay.jl:77-123 (LV UDE, tanh third layer).
+The kernels are the Float64 ones compiled with real = float; the bar is the same: per trajectory bit-identical to the
+oracle's Float32 instantiation (step counts, saved states, dL/du0), the golden known answers of the reference's Float32
+artifacts reproduced on the device, ensemble-summed gradients to Float32 summation order."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import universal_differential_equations_amd as U
+from universal_differential_equations_amd import models
+
+pytestmark = pytest.mark.gpu
+S3 = "Scenario_3_recovery_0.005"
+HB = "Hudson_Bay_recovery"
+f32 = np.float32
+
+
+def test_true_fisher_kpp_f32_golden_destats_on_device(golden):
+    """scenario_3.jl:56-57: Tsit5, Float32, Nx = 26, saveat 0.5 -- golden DEStats 243 / 39 / 1"""
+    s = golden(S3)["solution"]
+    prob = U.ODEProblem(models.rc_ode(26, 0.01, 1.0, 0.04, dtype="float32"), np.array(s["u0"], dtype=f32), tuple(s["tspan"]), [])
+    sol = U.solve(prob, U.Tsit5(), saveat=np.array(s["t"], dtype=f32))
+    out, st, rc = O.solve_ensemble(O.kpp_true(26, 0.01, 1.0, 0.04, dtype=1), O.opts(O.TSIT5), s["u0"], s["tspan"], [], s["t"], dtype=f32)
+    assert sol.retcode == "Success" and np.asarray(sol).dtype == f32
+    assert np.array_equal(np.asarray(sol).T, out[0])                       # device == oracle, bit for bit
+    d = sol.destats
+    assert (d.nf, d.naccept, d.nreject) == tuple(st[0][:3])
+    # the reference's artifact: rejections exact, accepted steps to +-1 (the solve runs at Tsit5's stability limit,
+    # tests/test_oracle_golden.py::test_kpp_true_f32), states to Float32 rounding before that phase
+    assert d.nreject == s["destats"]["nreject"] == 1 and abs(d.naccept - s["destats"]["naccept"]) <= 1
+    Ug = np.array(s["u"], dtype=f32)
+    assert np.abs(np.asarray(sol).T[:2] - Ug[:2]).max() < 1e-6 and np.abs(np.asarray(sol).T - Ug).max() < 2e-3
+
+
+def test_scenario3_ude_f32_loss_known_answer_and_gradients(golden):
+    """scenario_3.jl:121-134: objective at theta_init = losses[0] = 2967.0867 (Float32), on the device; gradient by the
+    discrete sweep (the script's ForwardDiffSensitivity) and by the interpolating adjoint against the oracle's Float32 runs"""
+    g = golden(S3)
+    X = np.array(g["X"]["data_colmajor"], dtype=f32).reshape(11, 26)
+    t = np.array(g["t"], dtype=f32)
+    th = np.array(g["initial_parameters"], dtype=f32)
+    f = models.nn_ode(26, models.kpp_s3_chain(), dtype="float32")
+    prob = U.ODEProblem(f, X[0], (float(t[0]), float(t[-1])), th)
+    for sense, osense in ((U.ForwardDiffSensitivity(), 1), (None, 0)):
+        r = U.loss_and_gradient(prob, U.Vern7(), X[None], saveat=t, sensealg=sense)
+        ref = O.loss_grad_ensemble(O.kpp_ude_s3(1), O.opts(O.VERN7, sensealg=osense), X[0], [t[0], t[-1]], th, t, X[None], dtype=f32)
+        assert r.u.dtype == f32 and r.grad_theta.dtype == f32
+        assert np.array_equal(r.stats, ref["stats"]) and np.array_equal(r.u, ref["u"]) and np.array_equal(r.grad_u0, ref["grad_u0"])
+        assert abs(float(r.loss) - float(ref["loss"])) < 1e-5 * float(ref["loss"])     # (per-lane partial sums of the loss)
+        assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < 2e-5 * np.linalg.norm(ref["grad_theta"])
+    loss = float(r.loss) + abs(float(th[-5:-2].sum()))                               # + the script's penalty term
+    gold = g["losses"]["data_colmajor"][0]
+    assert abs(loss - gold) < 2e-5 * gold                                            # 2967.0867
+
+
+def test_hudson_bay_f32_trained_loss_and_gradient(golden):
+    """hudson_bay.jl:98-123 in Float32: loss(trained_parameters) = losses[end] = 0.00357905; gradient vs the oracle"""
+    g = golden(HB)
+    X = np.array(g["X"]["data_colmajor"], dtype=f32).reshape(21, 2)
+    t = np.array(g["t"], dtype=f32)
+    th = np.array(g["trained_parameters"], dtype=f32)
+    f = models.ude_dynamics(models.hudson_chain(), trainable="both", dtype="float32")
+    u0 = np.stack([X[0], X[0] * f32(1.05), X[0] * f32(0.9)])
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (float(t[0]), float(t[-1])), th), u0)
+    data = np.repeat(X[None], 3, axis=0)
+    for sense, osense in ((U.ForwardDiffSensitivity(), 1), (None, 0)):
+        r = U.loss_and_gradient(ens, U.Vern7(), data, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=sense)
+        ref = O.loss_grad_ensemble(O.lv_ude_hudson(1), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=osense), u0, [t[0], t[-1]], th, t, data,
+                                   dtype=f32, nthreads=3)
+        assert np.array_equal(r.stats, ref["stats"]) and np.array_equal(r.u, ref["u"]) and np.array_equal(r.grad_u0, ref["grad_u0"])
+        assert np.array_equal(r.loss_per_traj, ref["loss_per_traj"])
+        assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < 2e-6 * np.linalg.norm(ref["grad_theta"])
+    loss = float(r.loss_per_traj[0]) / 21 + 1e-3 * float(np.sum(th[2:].astype(np.float64) ** 2)) / len(th[2:])
+    gold = g["losses"]["data_colmajor"][-1]
+    assert abs(loss - gold) < 3e-5 * gold                                            # 0.00357905
+    # the right-hand side itself
+    du = U.rhs(f, X[:5], th)
+    ref_du = np.array([O.rhs(O.lv_ude_hudson(1), th, X[i], dtype=f32) for i in range(5)])
+    assert du.dtype == f32 and np.array_equal(du, ref_du)
+
+
+def test_f32_descriptor_without_instance_is_refused():
+    f = models.ude_dynamics(dtype="float32")          # scenario_1's rbf chain has no Float32 instance
+    with pytest.raises(U.UdeError, match="no compiled kernel"):
+        U.solve(U.ODEProblem(f, [1.0, 1.0], (0.0, 1.0), np.zeros(87)), U.Tsit5(), saveat=0.5)

@@ -12,13 +12,7 @@
 
 namespace ude {
 
-// ---- DPP (data-parallel primitives): cross-lane moves inside the VALU, no LDS round trip -------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
+// ---- DPP (data-parallel primitives): cross-lane moves inside the VALU, no LDS round trip (dpp_mov: ude_real.h) -----
 constexpr int DPP_QUAD(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <- lane 7-i inside each 8 lanes
 
@@ -28,15 +22,9 @@ constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane i <- lane 7-i inside each 8 
 template <int G>
 constexpr bool pow2_group() { return (G & (G - 1)) == 0; }
 
-__device__ __forceinline__ double bpermute_f64(int byte_addr, double x) {
-    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(x));
-    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-
 // value of x held by lane `src` of this lane's group (src < G is a compile-time constant)
 template <int G, int SRC>
-__device__ __forceinline__ double group_bcast(double x) {
+__device__ __forceinline__ real group_bcast(real x) {
     if constexpr (G == 1) {
         return x;
     } else if constexpr (G == 4) {
@@ -45,7 +33,7 @@ __device__ __forceinline__ double group_bcast(double x) {
         return __shfl(x, SRC, G);  // ds_bpermute
     } else {
         const int lane = threadIdx.x & 63;
-        return bpermute_f64((lane - lane % G + SRC) << 2, x);
+        return bpermute_real((lane - lane % G + SRC) << 2, x);
     }
 }
 
@@ -53,37 +41,25 @@ __device__ __forceinline__ double group_bcast(double x) {
 // the same sequential order on every lane)
 constexpr int DPP_ROW_MIRROR = 0x140;  // lane i <- lane 15-i inside each row of 16
 // scratch of the cross-wave reductions (trajectories spanning several wavefronts of one block)
-__device__ __forceinline__ double* xwave_buf() {
-    __shared__ double buf[16];
+__device__ __forceinline__ real* xwave_buf() {
+    __shared__ real buf[16];
     return buf;
-}
-// a wave-uniform value, forced into scalar registers
-__device__ __forceinline__ double uniform_f64(double x) {
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-// value of lane k (wave-uniform k) of this wavefront, as a scalar
-__device__ __forceinline__ double readlane_f64(double x, int k) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
-    return __hiloint2double(hi, lo);
 }
 // component-per-lane helpers (replicated small states, one wavefront per trajectory): lane c keeps component c
 template <int NR>
-__device__ __forceinline__ double own_of(const double (&v)[NR]) {
+__device__ __forceinline__ real own_of(const real (&v)[NR]) {
     const int lane = threadIdx.x & 63;
-    double r = 0.0;
+    real r = 0.0;
     static_for<0, NR>([&](auto c) { r = (lane == (int)decltype(c)::value) ? v[c] : r; });
     return r;
 }
 template <int NR>
-__device__ __forceinline__ void bcast_all(double own, double (&out)[NR]) {
-    static_for<0, NR>([&](auto c) { out[c] = readlane_f64(own, decltype(c)::value); });
+__device__ __forceinline__ void bcast_all(real own, real (&out)[NR]) {
+    static_for<0, NR>([&](auto c) { out[c] = readlane_real(own, decltype(c)::value); });
 }
 // ARITH-SPEC tree sum over the 64 lanes of a wavefront: binary tree over adjacent index pairs (every lane gets
 // the total; at each level both partners add the same two values, so all lanes hold identical bits)
-__device__ __forceinline__ double wave_tree_sum(double x) {
+__device__ __forceinline__ real wave_tree_sum(real x) {
     x += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x);
     x += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x);
     x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
@@ -92,15 +68,16 @@ __device__ __forceinline__ double wave_tree_sum(double x) {
     x += __shfl_xor(x, 32, 64);
     return x;
 }
-template <int G>
-__device__ __forceinline__ double group_sum(double x) {
+template <int G, class T = real>
+__device__ __forceinline__ T group_sum(T x) {
     if constexpr (G > 64) {
         // trajectory spans G/64 wavefronts: butterfly inside each, then the wave sums in ascending order through LDS
+        static_assert(G <= 64 || sizeof(T) == sizeof(real), "multi-wavefront groups exist for Float64 only");
         x = group_sum<64>(x);
-        double* buf = xwave_buf();
+        T* buf = (T*)xwave_buf();
         if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = x;
         __syncthreads();
-        double s = buf[0];
+        T s = buf[0];
 #pragma unroll
         for (int i = 1; i < G / 64; ++i) s += buf[i];
         __syncthreads();
@@ -108,9 +85,9 @@ __device__ __forceinline__ double group_sum(double x) {
     } else if constexpr (!pow2_group<G>()) {
         const int lane = threadIdx.x & 63;
         const int base = (lane - lane % G) << 2;
-        double s = bpermute_f64(base, x);
+        T s = bpermute_real(base, x);
 #pragma unroll 1
-        for (int i = 1; i < G; ++i) s += bpermute_f64(base + (i << 2), x);
+        for (int i = 1; i < G; ++i) s += bpermute_real(base + (i << 2), x);
         return s;
     } else {
         if constexpr (G >= 2) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x) : __shfl_xor(x, 1, G);
@@ -122,32 +99,32 @@ __device__ __forceinline__ double group_sum(double x) {
     }
 }
 
-// double-double accumulation (two-sum): order-independent sums for the initial-dt norms (ARITH-SPEC)
-__device__ __forceinline__ void dd_acc(double& hi, double& lo, double x) {
-    const double s = hi + x;
-    const double bb = s - hi;
-    const double e = (hi - (s - bb)) + (x - bb);
+// real-real accumulation (two-sum): order-independent sums for the initial-dt norms (ARITH-SPEC)
+__device__ __forceinline__ void dd_acc(real& hi, real& lo, real x) {
+    const real s = hi + x;
+    const real bb = s - hi;
+    const real e = (hi - (s - bb)) + (x - bb);
     hi = s;
     lo += e;
 }
 // combine the (hi, lo) pairs of the G lanes of a group; every lane ends with the same pair
 template <int G>
-__device__ __forceinline__ void group_dd_sum(double& hi, double& lo) {
+__device__ __forceinline__ void group_dd_sum(real& hi, real& lo) {
     if constexpr (G > 64) {
         group_dd_sum<64>(hi, lo);
-        double* buf = xwave_buf();
+        real* buf = xwave_buf();
         if ((threadIdx.x & 63) == 0) {
             buf[2 * (threadIdx.x >> 6)] = hi;
             buf[2 * (threadIdx.x >> 6) + 1] = lo;
         }
         __syncthreads();
-        double h = buf[0], l = buf[1];
+        real h = buf[0], l = buf[1];
 #pragma unroll
         for (int i = 1; i < G / 64; ++i) {
-            const double h2 = buf[2 * i], l2 = buf[2 * i + 1];
-            const double s = h + h2;
-            const double bb = s - h;
-            const double e = (h - (s - bb)) + (h2 - bb);
+            const real h2 = buf[2 * i], l2 = buf[2 * i + 1];
+            const real s = h + h2;
+            const real bb = s - h;
+            const real e = (h - (s - bb)) + (h2 - bb);
             l = (l + l2) + e;
             h = s;
         }
@@ -159,13 +136,13 @@ __device__ __forceinline__ void group_dd_sum(double& hi, double& lo) {
     if constexpr (!pow2_group<G>()) {
         const int lane = threadIdx.x & 63;
         const int base = (lane - lane % G) << 2;
-        double h = bpermute_f64(base, hi), l = bpermute_f64(base, lo);
+        real h = bpermute_real(base, hi), l = bpermute_real(base, lo);
 #pragma unroll 1
         for (int i = 1; i < G; ++i) {
-            const double h2 = bpermute_f64(base + (i << 2), hi), l2 = bpermute_f64(base + (i << 2), lo);
-            const double s = h + h2;
-            const double bb = s - h;
-            const double e = (h - (s - bb)) + (h2 - bb);
+            const real h2 = bpermute_real(base + (i << 2), hi), l2 = bpermute_real(base + (i << 2), lo);
+            const real s = h + h2;
+            const real bb = s - h;
+            const real e = (h - (s - bb)) + (h2 - bb);
             l = (l + l2) + e;
             h = s;
         }
@@ -175,10 +152,10 @@ __device__ __forceinline__ void group_dd_sum(double& hi, double& lo) {
     }
 #pragma unroll
     for (int m = 1; m < G; m <<= 1) {
-        const double h2 = __shfl_xor(hi, m, G), l2 = __shfl_xor(lo, m, G);
-        const double s = hi + h2;
-        const double bb = s - hi;
-        const double e = (hi - (s - bb)) + (h2 - bb);
+        const real h2 = __shfl_xor(hi, m, G), l2 = __shfl_xor(lo, m, G);
+        const real s = hi + h2;
+        const real bb = s - hi;
+        const real e = (hi - (s - bb)) + (h2 - bb);
         lo = (lo + l2) + e;
         hi = s;
     }
@@ -239,13 +216,13 @@ struct CoopMlp {
     static constexpr int MAXD = N::maxdim();
     static constexpr int MAXOWN = maxown();
 
-    typedef __attribute__((address_space(3))) double lds_t;
+    typedef __attribute__((address_space(3))) real lds_t;
     // all-gather of one value per lane inside a group.  Power-of-two groups: DPP / bpermute broadcasts.  Other groups
     // (G = 5): through the group's words of a wave-private LDS row -- one ds_write + three ds_read2 per gather instead
     // of ten ds_bpermute (LDS is in order per wavefront: no barrier; `gb` = this GROUP's first word)
     static constexpr bool LDS_GATHER = !pow2_group<G>();
     template <int CNT>
-    static __device__ __forceinline__ void allgather(lds_t* gb, int r, const double* own, double* out) {
+    static __device__ __forceinline__ void allgather(lds_t* gb, int r, const real* own, real* out) {
         if constexpr (LDS_GATHER) {
             static_assert(CNT <= G, "LDS gather: one value per lane");
             gb[r] = own[0];
@@ -259,18 +236,18 @@ struct CoopMlp {
     }
     struct Cache {
         lds_t* gb;                // LDS gather row of this group (LDS_GATHER)
-        double a[L + 1][MAXD];    // replicated activations (a[0] = input)
-        double z[L][MAXOWN];      // pre-activations of the neurons this lane owns
-        double ao[L][MAXOWN];     // their activations
+        real a[L + 1][MAXD];    // replicated activations (a[0] = input)
+        real z[L][MAXOWN];      // pre-activations of the neurons this lane owns
+        real ao[L][MAXOWN];     // their activations
     };
 
     // Register-resident copy of the weights THIS lane touches: the rows of its neurons (forward), the columns of
     // the next layer at its neurons (backward) and the first layer (input cotangent).  Loaded once per kernel; takes
     // the LDS round trips of the weight fetches out of the per-evaluation latency chain.
     struct WReg {
-        double row[L][MAXOWN][MAXD + 1];  // [l][m][k], bias at k = dim(l)
-        double col[L][MAXOWN][MAXD];      // [l][m][i] = W_{l+1}[i, j]
-        double w0[MAXD * MAXD];           // W_0[j + k*out]
+        real row[L][MAXOWN][MAXD + 1];  // [l][m][k], bias at k = dim(l)
+        real col[L][MAXOWN][MAXD];      // [l][m][i] = W_{l+1}[i, j]
+        real w0[MAXD * MAXD];           // W_0[j + k*out]
     };
     template <class P>
     static __device__ __forceinline__ void load_weights(const P* th, int r, WReg& w) {
@@ -282,16 +259,16 @@ struct CoopMlp {
                 constexpr int m = mc;
                 const int j = r + m * G;
                 const int jj = ((own(l) * G == out) || (j < out)) ? j : 0;
-                static_for<0, in>([&](auto k) { w.row[l][m][k] = (double)W[jj + k * out]; });
-                w.row[l][m][in] = (double)W[in * out + jj];
+                static_for<0, in>([&](auto k) { w.row[l][m][k] = (real)W[jj + k * out]; });
+                w.row[l][m][in] = (real)W[in * out + jj];
                 if constexpr (l + 1 < L) {
                     constexpr int out2 = N::dim(l + 2);
                     const P* W2 = th + N::off(l + 1);
-                    static_for<0, out2>([&](auto i) { w.col[l][m][i] = (double)W2[i + jj * out2]; });
+                    static_for<0, out2>([&](auto i) { w.col[l][m][i] = (real)W2[i + jj * out2]; });
                 }
             });
         });
-        static_for<0, N::dim(0) * N::dim(1)>([&](auto i) { w.w0[i] = (double)th[N::off(0) + i]; });
+        static_for<0, N::dim(0) * N::dim(1)>([&](auto i) { w.w0[i] = (real)th[N::off(0) + i]; });
     }
 
     // WS = const P* (weights read from LDS/global at every use) or WReg (register-resident copy)
@@ -300,7 +277,7 @@ struct CoopMlp {
 
     // th: NN parameters (LDS or global) or a WReg; r: lane index inside the group
     template <class WS>
-    static __device__ __forceinline__ void forward(const WS& th, int r, const double* x, Cache& c, double* y) {
+    static __device__ __forceinline__ void forward(const WS& th, int r, const real* x, Cache& c, real* y) {
         static_for<0, N::dim(0)>([&](auto k) { c.a[0][k] = x[k]; });
         static_for<0, L>([&](auto lc) {
             constexpr int l = lc;
@@ -310,13 +287,13 @@ struct CoopMlp {
                 const int j = r + m * G;
                 const bool valid = (own(l) * G == out) || (j < out);
                 const int jj = valid ? j : 0;
-                double acc = 0.0;
+                real acc = 0.0;
                 if constexpr (ws_is_reg<WS>) {
-                    static_for<0, in>([&](auto k) { acc = __builtin_fma(th.row[l][m][k], c.a[l][k], acc); });
+                    static_for<0, in>([&](auto k) { acc = rfma(th.row[l][m][k], c.a[l][k], acc); });
                     acc += th.row[l][m][in];
                 } else {
-                    static_for<0, in>([&](auto k) { acc = __builtin_fma((double)th[N::off(l) + jj + k * out], c.a[l][k], acc); });
-                    acc += (double)th[N::off(l) + in * out + jj];
+                    static_for<0, in>([&](auto k) { acc = rfma((real)th[N::off(l) + jj + k * out], c.a[l][k], acc); });
+                    acc += (real)th[N::off(l) + in * out + jj];
                 }
                 c.z[l][m] = acc;
                 c.ao[l][m] = valid ? act_fwd<N::act(l)>(acc) : 0.0;
@@ -329,30 +306,30 @@ struct CoopMlp {
     // gy: cotangent of the output (replicated).  gx: cotangent of the input (replicated).
     // g[NSLOT]: this lane's slice of (dNN/dtheta)^T gy; slot (l, m, k) = slot_off(l) + m*(in+1) + k, bias at k = in.
     struct NoSink {
-        __device__ __forceinline__ void operator()(int, int, double) const {}
+        __device__ __forceinline__ void operator()(int, int, real) const {}
     };
     template <bool WANT_PARAM, class WS>
-    static __device__ __forceinline__ void vjp(const WS& th, int r, const Cache& c, const double* gy, double* gx,
-                                               double* g) {
+    static __device__ __forceinline__ void vjp(const WS& th, int r, const Cache& c, const real* gy, real* gx,
+                                               real* g) {
         vjp_sink<WANT_PARAM>(th, r, c, gy, gx, g, NoSink{});
     }
     // sink(l, m, d): receives the delta of this lane's m-th neuron of layer l (pointwise networks export it)
     template <bool WANT_PARAM, class WS, class Sink>
-    static __device__ __forceinline__ void vjp_sink(const WS& th, int r, const Cache& c, const double* gy, double* gx,
-                                                    double* g, Sink sink) {
+    static __device__ __forceinline__ void vjp_sink(const WS& th, int r, const Cache& c, const real* gy, real* gx,
+                                                    real* g, Sink sink) {
         static_assert(N::act(L - 1) == ACT_IDENTITY, "output layer must be linear");
-        double dall[MAXD];  // replicated delta of the layer above
+        real dall[MAXD];  // replicated delta of the layer above
         static_for<0, N::dim(L)>([&](auto k) { dall[k] = gy[k]; });
         static_for<0, L>([&](auto lr) {
             constexpr int l = L - 1 - lr;
             constexpr int in = N::dim(l), out = N::dim(l + 1);
-            double down[MAXOWN];
+            real down[MAXOWN];
             static_for<0, own(l)>([&](auto mc) {
                 constexpr int m = mc;
                 const int j = r + m * G;
                 const bool valid = (own(l) * G == out) || (j < out);
                 const int jj = valid ? j : 0;
-                double gp;
+                real gp;
                 if constexpr (l == L - 1) {
                     gp = dall[0];  // pick element j of the replicated output cotangent
                     static_for<1, out>([&](auto i) { gp = (jj == i) ? dall[i] : gp; });
@@ -360,14 +337,14 @@ struct CoopMlp {
                     constexpr int out2 = N::dim(l + 2);
                     gp = 0.0;  // column jj of the next layer's W (contiguous in theta)
                     if constexpr (ws_is_reg<WS>) {
-                        static_for<0, out2>([&](auto i) { gp = __builtin_fma(th.col[l][m][i], dall[i], gp); });
+                        static_for<0, out2>([&](auto i) { gp = rfma(th.col[l][m][i], dall[i], gp); });
                     } else {
                         static_for<0, out2>([&](auto i) {
-                            gp = __builtin_fma((double)th[N::off(l + 1) + i + jj * out2], dall[i], gp);
+                            gp = rfma((real)th[N::off(l + 1) + i + jj * out2], dall[i], gp);
                         });
                     }
                 }
-                const double d = valid ? gp * act_bwd<N::act(l)>(c.z[l][m], c.ao[l][m]) : 0.0;
+                const real d = valid ? gp * act_bwd<N::act(l)>(c.z[l][m], c.ao[l][m]) : 0.0;
                 down[m] = d;
                 sink(l, m, d);
                 if constexpr (WANT_PARAM && !(KMAJ && l == L - 1)) {
@@ -379,9 +356,9 @@ struct CoopMlp {
             if constexpr (WANT_PARAM && KMAJ && l == L - 1) {
                 // slots by input: dall still holds the (replicated) deltas of this linear layer = gy
                 constexpr int s0 = slot_off(L - 1);
-                const double ak = c.ao[L - 2][0];  // this lane's own activation below = a_{L-1}[r] (0 on lanes without a neuron)
+                const real ak = c.ao[L - 2][0];  // this lane's own activation below = a_{L-1}[r] (0 on lanes without a neuron)
                 static_for<0, out>([&](auto j) { g[s0 + j] = dall[j] * ak; });
-                double gb = dall[0];
+                real gb = dall[0];
                 static_for<1, out>([&](auto i) { gb = (r == i) ? dall[i] : gb; });
                 g[s0 + out] = r < out ? gb : 0.0;
             }
@@ -389,14 +366,14 @@ struct CoopMlp {
                 allgather<out>(c.gb, r, down, dall);
             } else {
                 // input cotangent: gx[k] = sum_j W0[j,k] delta0[j]; every lane needs it, so gather delta0 too
-                double d0[MAXD];
+                real d0[MAXD];
                 allgather<out>(c.gb, r, down, d0);
                 static_for<0, in>([&](auto k) {
-                    double s = 0.0;
+                    real s = 0.0;
                     if constexpr (ws_is_reg<WS>) {
-                        static_for<0, out>([&](auto j) { s = __builtin_fma(th.w0[j + k * out], d0[j], s); });
+                        static_for<0, out>([&](auto j) { s = rfma(th.w0[j + k * out], d0[j], s); });
                     } else {
-                        static_for<0, out>([&](auto j) { s = __builtin_fma((double)th[N::off(0) + j + k * out], d0[j], s); });
+                        static_for<0, out>([&](auto j) { s = rfma((real)th[N::off(0) + j + k * out], d0[j], s); });
                     }
                     gx[k] = s;
                 });

@@ -24,6 +24,17 @@ struct Opts {
     int32_t maxiters;
 };
 
+// the solve options in the kernel's scalar type (oracle: resolve_opts casts every option to REAL)
+struct OptsR {
+    real abstol, reltol, dtmax, dt0, qmin, qmax, gamma, qoldinit, beta1, beta2;
+    int32_t maxiters;
+    __device__ OptsR(const Opts& o)
+        : abstol((real)o.abstol), reltol((real)o.reltol), dtmax((real)o.dtmax), dt0((real)o.dt0), qmin((real)o.qmin),
+          qmax((real)o.qmax), gamma((real)o.gamma), qoldinit((real)o.qoldinit), beta1((real)o.beta1), beta2((real)o.beta2),
+          maxiters(o.maxiters) {}
+};
+
+template <class T> struct TabDevT;
 struct KParams {
     int64_t N;        // trajectories
     int64_t Npad;     // stride of the SoA workspaces
@@ -31,39 +42,35 @@ struct KParams {
     double t0, tf;
     Opts o;
     ModelConsts mc;
-    const double* u0;      // n x N
-    const double* theta;   // np
-    const double* saveat;  // ns
-    double* u_out;         // n x ns x N or null
+    const real* u0;      // n x N
+    const real* theta;   // np
+    const real* saveat;  // ns
+    real* u_out;         // n x ns x N or null
     int64_t* stats;        // 8 x N or null
     int32_t* retcode;      // N
     // dense forward store (SoA, field-major: [(step*NF + field)*Npad + traj]); null for plain solves
-    double* dense;
+    real* dense;
     int32_t* dense_n;
     // loss / cotangent
-    const double* data;       // n x ns x N or null
+    const real* data;       // n x ns x N or null
     const uint8_t* row_mask;  // n or null
-    const double* cot_in;     // n x ns x N user cotangent or null
-    double* cot;              // SoA [(i*n + c)*Npad + traj] written by the forward kernel when data != null
-    double* loss_traj;        // N
+    const real* cot_in;     // n x ns x N user cotangent or null
+    real* cot;              // SoA [(i*n + c)*Npad + traj] written by the forward kernel when data != null
+    real* loss_traj;        // N
     // backward outputs
-    double* grad_part;  // [nwaves_total][np] per-wave partial gradients
-    double* slot_glob;  // SLOTS_GLOBAL models: slot state mu in HBM, element c of thread g at slot_glob[c * nthreads + g]
-    double* grad_u0;    // n x N or null
+    real* grad_part;  // [nwaves_total][np] per-wave partial gradients
+    real* slot_glob;  // SLOTS_GLOBAL models: slot state mu in HBM, element c of thread g at slot_glob[c * nthreads + g]
+    real* grad_u0;    // n x N or null
     // debugging: per-iteration trace (t, dt, EEst, q, accept) of one trajectory; fwd rows first, then bwd
-    double* trace;      // [2][trace_cap][5] or null
+    real* trace;      // [2][trace_cap][5] or null
     int64_t trace_traj;
     int32_t trace_cap;
-    const struct TabDev* tab;  // tableau of the algorithm (device memory)
+    const TabDevT<real>* tab;  // tableau of the algorithm (device memory, in the kernel's scalar type)
     // per-trajectory time grids (kernels instantiated with PT = true): tspan_pt = 2 x N, saveat = ns x N when saveat_pt
-    const double* tspan_pt;
+    const double* tspan_pt;   // (2 x N doubles, as the host holds them)
     int32_t saveat_pt, dtmax_auto;
 };
 
-__device__ __forceinline__ double ulp_of(double x) {
-    x = fabs(x);
-    return __longlong_as_double(__double_as_longlong(x) + 1) - x;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Tableau in memory: the stage loop is a RUNTIME loop (one inlined copy of the right-hand side instead
@@ -74,42 +81,44 @@ __device__ __forceinline__ double ulp_of(double x) {
 // (always nonzero) first coefficient; zero coefficients contribute fma(0, k, acc) == acc exactly, so the
 // value equals the oracle's skip-zeros chain (oracle/ude_oracle_impl.h: combine()).
 // ---------------------------------------------------------------------------------------------
-struct TabDev {
-    double A[16][16];
-    double B[16], BT[16], C[16];
-    double R[16][8];  // dense-output weights b_q(theta): 7-slot Horner tables (Tab::R), lane q of a CPL wavefront loads row q
+template <class T>
+struct TabDevT {
+    T A[16][16];
+    T B[16], BT[16], C[16];
+    T R[16][8];  // dense-output weights b_q(theta): 7-slot Horner tables (Tab::R), lane q of a CPL wavefront loads row q
 };
+using TabDev = TabDevT<real>;  // (the host uploads both the double and the float table; coefficients rounded to T)
 
-template <class Tab>
-inline TabDev make_tabdev() {
-    TabDev t{};
+template <class Tab, class T = double>
+inline TabDevT<T> make_tabdev() {
+    TabDevT<T> t{};
     for (int s = 0; s < Tab::S; ++s) {
-        for (int j = 0; j < s; ++j) t.A[s][j] = Tab::A(s, j);
-        t.B[s] = Tab::B(s);
-        t.BT[s] = Tab::BT(s);
-        t.C[s] = Tab::C(s);
+        for (int j = 0; j < s; ++j) t.A[s][j] = (T)Tab::A(s, j);
+        t.B[s] = (T)Tab::B(s);
+        t.BT[s] = (T)Tab::BT(s);
+        t.C[s] = (T)Tab::C(s);
     }
     for (int e = 0; e < Tab::NEXTRA; ++e) {
-        for (int j = 0; j < Tab::S + e; ++j) t.A[Tab::S + e][j] = Tab::AE(e, j);
-        t.C[Tab::S + e] = Tab::CE(e);
+        for (int j = 0; j < Tab::S + e; ++j) t.A[Tab::S + e][j] = (T)Tab::AE(e, j);
+        t.C[Tab::S + e] = (T)Tab::CE(e);
     }
     for (int q = 0; q < Tab::NK; ++q)
-        for (int i = 0; i < 7; ++i) t.R[q][i] = Tab::R(q, i);
+        for (int i = 0; i < 7; ++i) t.R[q][i] = (T)Tab::R(q, i);
     return t;
 }
 
 template <class Tab>
-struct RowDense { static constexpr double at(int q) { return Tab::dense_uses(q) ? 1.0 : 0.0; } };
+struct RowDense { static constexpr real at(int q) { return Tab::dense_uses(q) ? 1.0 : 0.0; } };
 
 // sum_j v1(j) * v2(j) over the j with Row::at(j) != 0, j ascending (compile-time indices)
 template <class Row, int N, class V1, class V2>
-__device__ __forceinline__ double chain2(V1 v1, V2 v2) {
-    double acc = 0.0;
+__device__ __forceinline__ real chain2(V1 v1, V2 v2) {
+    real acc = 0.0;
     bool first = true;
     static_for<0, N>([&](auto j) {
         constexpr int jj = decltype(j)::value;
-        if constexpr (Row::at(jj) != 0.0) {
-            acc = first ? v1(j) * v2(j) : __builtin_fma(v1(j), v2(j), acc);
+        if constexpr (Row::at(jj) != real(0)) {
+            acc = first ? v1(j) * v2(j) : rfma(v1(j), v2(j), acc);
             first = false;
         }
     });
@@ -166,27 +175,28 @@ struct Driver {
     //   kl: stage derivatives of the replicated part, k(j, c) = kl[(j*NR + c) * BLOCK]
     //   mu: slot state (touched once per step)
     // z: replicated state (registers).  Integrates from t0 along tdir through sys' tstops.
-    static __device__ __forceinline__ int run(Sys& sys, const Opts& o, const TabDev* __restrict__ tab, double (&z)[NR],
-                                              double* kl, double* mu, double t0, double tdir, double ntot, Stats& st,
-                                              double* gtmp = nullptr, double* gtmp2 = nullptr, int mustride = BLOCK) {
+    static __device__ __forceinline__ int run(Sys& sys, const Opts& oin, const TabDev* __restrict__ tab, real (&z)[NR],
+                                              real* kl, real* mu, real t0, real tdir, real ntot, Stats& st,
+                                              real* gtmp = nullptr, real* gtmp2 = nullptr, int mustride = BLOCK) {
         const int MS = Sys::SLOTS_GLOBAL ? mustride : BLOCK;  // element c of this thread's slot column at mu[c * MS]
         // gtmp: per-thread LDS row (element c at gtmp[c * BLOCK]) holding the slot derivative of stage 0: parked there
         // by the initial-dt heuristic, and -- FSAL tableaux -- handed over from the last stage of an accepted step
         // (gtmp2 receives the last stage's slot derivative; the two rows swap on acceptance)
-        double accb[NSLA], acce[NSLA];
-        const double dtmax = sys.dtmax(o);  // (per-trajectory when the time grids are)
-        double t = t0, dt, qold = o.qoldinit, q11 = 1.0;
+        const OptsR o(oin);
+        real accb[NSLA], acce[NSLA];
+        const real dtmax = sys.dtmax(o);  // (per-trajectory when the time grids are)
+        real t = t0, dt, qold = o.qoldinit, q11 = real(1);
         bool accept = true, done = false;
         int iter = 0, ret = RET_SUCCESS;
-        double tstop = sys.first_tstop();
-        auto K = [&](int j, int c) -> double& { return kl[(j * NR + c) * KSTRIDE]; };
-        auto K1 = [&](int j) -> double& { return kl[j * KCP]; };  // CPL: this lane's component of stage j
+        real tstop = sys.first_tstop();
+        auto K = [&](int j, int c) -> real& { return kl[(j * NR + c) * KSTRIDE]; };
+        auto K1 = [&](int j) -> real& { return kl[j * KCP]; };  // CPL: this lane's component of stage j
 
         // ---- initial dt (ode_determine_initdt), 2 evals ----
-        if (o.dt0 > 0.0) {
+        if (o.dt0 > real(0)) {
             dt = tdir * o.dt0;
             if constexpr (USE_FSAL) {
-                double kr[NR], gs[NSLA];
+                real kr[NR], gs[NSLA];
                 sys.eval(t, z, kr, gs);
                 if constexpr (CPL) K1(0) = own_of(kr);
                 else static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
@@ -194,22 +204,22 @@ struct Driver {
             }
             if constexpr (Tab::FSAL) st.nf += 1;
         } else {
-            double f0[NR], gs0[NSLA], f1[NR], gs1[NSLA], z1[NR];
+            real f0[NR], gs0[NSLA], f1[NR], gs1[NSLA], z1[NR];
             if constexpr (DEFER) sys.eval_store(t, z, f0, 0);
             else sys.eval(t, z, f0, gs0);
             if constexpr (CPL) K1(0) = own_of(f0);
             else static_for<0, NR>([&](auto c) { K(0, c) = f0[c]; });
-            // norms in double-double: slots first (lane-parallel), then the replicated components once
-            double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
+            // norms in real-real: slots first (lane-parallel), then the replicated components once
+            real h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
             if constexpr (DEFER) {
                 sys.slot_init01(o, h0, l0, h1, l1);
                 group_dd_sum<G>(h0, l0);
                 group_dd_sum<G>(h1, l1);
             } else if constexpr (NSL > 0) {
                 static_for<0, NSL>([&](auto c) {
-                    const double m = mu[c * BLOCK];
-                    const double sk = __builtin_fma(fabs(m), o.reltol, o.abstol);
-                    const double q0 = m / sk, q1 = gs0[c] / sk;
+                    const real m = mu[c * BLOCK];
+                    const real sk = rfma(rabs(m), o.reltol, o.abstol);
+                    const real q0 = m / sk, q1 = gs0[c] / sk;
                     dd_acc(h0, l0, q0 * q0);
                     dd_acc(h1, l1, q1 * q1);
                     gtmp[c * BLOCK] = gs0[c];
@@ -219,11 +229,11 @@ struct Driver {
                 asm volatile("" ::: "memory");
             }
             if constexpr (Sys::STATE_DISTRIBUTED) {
-                double hs0 = 0.0, ls0 = 0.0, hs1 = 0.0, ls1 = 0.0;
+                real hs0 = 0.0, ls0 = 0.0, hs1 = 0.0, ls1 = 0.0;
                 static_for<0, NR>([&](auto c) {
-                    const double on = sys.state_on(c);
-                    const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
-                    const double q0 = on * (z[c] / sk), q1 = on * (f0[c] / sk);
+                    const real on = sys.state_on(c);
+                    const real sk = rfma(rabs(z[c]), o.reltol, o.abstol);
+                    const real q0 = on * (z[c] / sk), q1 = on * (f0[c] / sk);
                     dd_acc(hs0, ls0, q0 * q0);
                     dd_acc(hs1, ls1, q1 * q1);
                 });
@@ -233,67 +243,68 @@ struct Driver {
                 dd_acc(h1, l1, hs1); dd_acc(h1, l1, ls1);
             } else {
                 static_for<0, NR>([&](auto c) {
-                    const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
-                    const double q0 = z[c] / sk, q1 = f0[c] / sk;
+                    const real sk = rfma(rabs(z[c]), o.reltol, o.abstol);
+                    const real q0 = z[c] / sk, q1 = f0[c] / sk;
                     dd_acc(h0, l0, q0 * q0);
                     dd_acc(h1, l1, q1 * q1);
                 });
             }
-            const double s0 = h0 + l0, s1 = h1 + l1;
-            const double d0 = sqrt(s0 / ntot), d1 = sqrt(s1 / ntot);
+            const real s0 = h0 + l0, s1 = h1 + l1;
+            const real d0 = rsqrt_ieee(s0 / ntot), d1 = rsqrt_ieee(s1 / ntot);
             if (d1 != d1) {
                 ret = RET_UNSTABLE;
                 done = true;
             }
-            double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : (d0 / d1) / 100.0;
+            real dt0 = (d0 < real(1e-5) || d1 < real(1e-5)) ? real(1e-6) : (d0 / d1) / real(100);
             if (dt0 > dtmax) dt0 = dtmax;
-            if (dt0 < 10.0 * 2.220446049250313e-16) {
-                dt = tdir * 1e-6;
+            if (dt0 < real(10) * REAL_EPS) {
+                dt = tdir * real(1e-6);
             } else {
-                const double dt0t = tdir * dt0;
-                static_for<0, NR>([&](auto c) { z1[c] = __builtin_fma(dt0t, f0[c], z[c]); });
+                const real dt0t = tdir * dt0;
+                static_for<0, NR>([&](auto c) { z1[c] = rfma(dt0t, f0[c], z[c]); });
                 // (the slot part of u1 does not enter f: mu' is independent of mu)
                 if constexpr (DEFER) sys.eval_store(t + dt0t, z1, f1, 1);
                 else sys.eval(t + dt0t, z1, f1, gs1);
-                double h2 = 0.0, l2 = 0.0;
+                real h2 = 0.0, l2 = 0.0;
                 if constexpr (DEFER) {
                     sys.slot_init2(o, h2, l2);
                     group_dd_sum<G>(h2, l2);
                 } else if constexpr (NSL > 0) {
                     static_for<0, NSL>([&](auto c) {
-                        const double sk = __builtin_fma(fabs(mu[c * BLOCK]), o.reltol, o.abstol);
-                        const double q = (gs1[c] - gtmp[c * BLOCK]) / sk;
+                        const real sk = rfma(rabs(mu[c * BLOCK]), o.reltol, o.abstol);
+                        const real q = (gs1[c] - gtmp[c * BLOCK]) / sk;
                         dd_acc(h2, l2, q * q);
                     });
                     group_dd_sum<G>(h2, l2);
                 }
                 if constexpr (Sys::STATE_DISTRIBUTED) {
-                    double hs = 0.0, ls = 0.0;
+                    real hs = 0.0, ls = 0.0;
                     static_for<0, NR>([&](auto c) {
-                        const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
-                        const double q = sys.state_on(c) * ((f1[c] - f0[c]) / sk);
+                        const real sk = rfma(rabs(z[c]), o.reltol, o.abstol);
+                        const real q = sys.state_on(c) * ((f1[c] - f0[c]) / sk);
                         dd_acc(hs, ls, q * q);
                     });
                     group_dd_sum<G>(hs, ls);
                     dd_acc(h2, l2, hs); dd_acc(h2, l2, ls);
                 } else {
                     static_for<0, NR>([&](auto c) {
-                        const double sk = __builtin_fma(fabs(z[c]), o.reltol, o.abstol);
-                        const double q = (f1[c] - f0[c]) / sk;
+                        const real sk = rfma(rabs(z[c]), o.reltol, o.abstol);
+                        const real q = (f1[c] - f0[c]) / sk;
                         dd_acc(h2, l2, q * q);
                     });
                 }
-                const double s2 = h2 + l2;
-                const double d2 = sqrt(s2 / ntot) / dt0;
-                const double mx = d1 > d2 ? d1 : d2;
-                double dt1;
-                if (mx <= 1e-15) {
-                    dt1 = dt0 * 1e-3;
-                    if (dt1 < 1e-6) dt1 = 1e-6;
+                const real s2 = h2 + l2;
+                const real d2 = rsqrt_ieee(s2 / ntot) / dt0;
+                const real mx = d1 > d2 ? d1 : d2;
+                real dt1;
+                if (mx <= real(1e-15)) {
+                    dt1 = dt0 * real(1e-3);
+                    if (dt1 < real(1e-6)) dt1 = real(1e-6);
                 } else {
-                    dt1 = dpow10(-(2.0 + dlog10(mx)) / (double)Tab::ORDER);
+                    const real ex = -(real(2) + rlog10(mx)) / (real)Tab::ORDER;
+                    dt1 = rpow10(ex);
                 }
-                double d = 100.0 * dt0;
+                real d = real(100) * dt0;
                 if (dt1 < d) d = dt1;
                 if (dtmax < d) d = dtmax;
                 dt = tdir * d;
@@ -305,49 +316,49 @@ struct Driver {
         while (!done) {
             // ---- loopheader! ----
             if (iter > 0 && !accept) {  // step_reject_controller!
-                double den = q11 / o.gamma;
-                const double iq = 1.0 / o.qmin;
+                real den = q11 / o.gamma;
+                const real iq = real(1) / o.qmin;
                 if (iq < den) den = iq;
                 dt = dt / den;
             }
             iter += 1;
-            if (fabs(dt) > dtmax) dt = tdir * dtmax;
+            if (rabs(dt) > dtmax) dt = tdir * dtmax;
             {
-                const double rem = fabs(tstop - t);  // modify_dt_for_tstops!
-                if (fabs(dt) > rem) dt = tdir * rem;
+                const real rem = rabs(tstop - t);  // modify_dt_for_tstops!
+                if (rabs(dt) > rem) dt = tdir * rem;
             }
             if (iter > o.maxiters) { ret = RET_MAXITERS; break; }
             if (dt != dt) { ret = RET_UNSTABLE; break; }
-            if (fabs(dt) <= 2.220446049250313e-16 * fabs(t) && fabs(dt) < fabs(tstop - t)) { ret = RET_DTLESSTHANMIN; break; }
+            if (rabs(dt) <= REAL_EPS * rabs(t) && rabs(dt) < rabs(tstop - t)) { ret = RET_DTLESSTHANMIN; break; }
 
             // ---- perform_step!: runtime stage loop (wave-uniform s) ----
-            double znew[NR];
-            [[maybe_unused]] const double zo = CPL ? own_of(z) : 0.0;  // this lane's component of z
+            real znew[NR];
+            [[maybe_unused]] const real zo = CPL ? own_of(z) : real(0);  // this lane's component of z
             if constexpr (SLOT_FSAL) {
-                const double bs = tab->B[0], es = tab->BT[0];
+                const real bs = tab->B[0], es = tab->BT[0];
                 static_for<0, NSL>([&](auto c) {
-                    const double g0 = gtmp[c * BLOCK];
+                    const real g0 = gtmp[c * BLOCK];
                     accb[c] = bs * g0;
                     acce[c] = es * g0;
                 });
             }
             for (int s = USE_FSAL ? 1 : 0; s < S; ++s) {
-                double zs[NR], kr[NR], gs[NSLA];
+                real zs[NR], kr[NR], gs[NSLA];
                 if (s == 0) {
                     static_for<0, NR>([&](auto c) { zs[c] = z[c]; });
                 } else if constexpr (CPL) {
-                    double acc = tab->A[s][0] * K1(0);
+                    real acc = tab->A[s][0] * K1(0);
 #pragma unroll 4
-                    for (int j = 1; j < s; ++j) acc = __builtin_fma(tab->A[s][j], K1(j), acc);  // (a_sj = 0 for j >= s)
-                    bcast_all(__builtin_fma(dt, acc, zo), zs);
+                    for (int j = 1; j < s; ++j) acc = rfma(tab->A[s][j], K1(j), acc);  // (a_sj = 0 for j >= s)
+                    bcast_all(rfma(dt, acc, zo), zs);
                 } else {
                     static_for<0, NR>([&](auto c) {
                         // all S-1 possible terms, unrolled: the coefficients of stages >= s are zero in the table and the
                         // (zero-initialised, always finite) k storage makes fma(0, k, acc) == acc exact -- one batch of
                         // scalar + LDS loads and one wait per stage instead of a load-wait-fma round trip per term
-                        double acc = tab->A[s][0] * K(0, c);
-                        static_for<1, S - 1>([&](auto j) { acc = __builtin_fma(tab->A[s][j], K(j, c), acc); });
-                        zs[c] = __builtin_fma(dt, acc, z[c]);
+                        real acc = tab->A[s][0] * K(0, c);
+                        static_for<1, S - 1>([&](auto j) { acc = rfma(tab->A[s][j], K(j, c), acc); });
+                        zs[c] = rfma(dt, acc, z[c]);
                     });
                 }
                 if (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
@@ -356,7 +367,7 @@ struct Driver {
                 if constexpr (CPL) K1(s) = own_of(kr);
                 else static_for<0, NR>([&](auto c) { K(s, c) = kr[c]; });
                 if constexpr (NSL > 0) {
-                    const double bs = tab->B[s], es = tab->BT[s];
+                    const real bs = tab->B[s], es = tab->BT[s];
                     if (s == 0) {
                         static_for<0, NSL>([&](auto c) {
                             accb[c] = bs * gs[c];
@@ -364,8 +375,8 @@ struct Driver {
                         });
                     } else {
                         static_for<0, NSL>([&](auto c) {
-                            accb[c] = __builtin_fma(bs, gs[c], accb[c]);
-                            acce[c] = __builtin_fma(es, gs[c], acce[c]);
+                            accb[c] = rfma(bs, gs[c], accb[c]);
+                            acce[c] = rfma(es, gs[c], acce[c]);
                         });
                     }
                     if constexpr (SLOT_FSAL) {
@@ -375,77 +386,77 @@ struct Driver {
             }
             st.nf += Tab::FSAL ? S - 1 : S;
             if constexpr (!Tab::FSAL && CPL) {
-                double acc = tab->B[0] * K1(0);
+                real acc = tab->B[0] * K1(0);
 #pragma unroll 3
-                for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->B[j], K1(j), acc);
-                bcast_all(__builtin_fma(dt, acc, zo), znew);
+                for (int j = 1; j < S; ++j) acc = rfma(tab->B[j], K1(j), acc);
+                bcast_all(rfma(dt, acc, zo), znew);
             } else if constexpr (!Tab::FSAL) {
                 static_for<0, NR>([&](auto c) {
-                    double acc = tab->B[0] * K(0, c);
-                    for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->B[j], K(j, c), acc);
-                    znew[c] = __builtin_fma(dt, acc, z[c]);
+                    real acc = tab->B[0] * K(0, c);
+                    for (int j = 1; j < S; ++j) acc = rfma(tab->B[j], K(j, c), acc);
+                    znew[c] = rfma(dt, acc, z[c]);
                 });
             }
             // calculate_residuals + ODE_DEFAULT_NORM
-            double ss = 0.0;
+            acc_t ss = 0.0;  // (ude_real.h: Float64 accumulation for both scalar types)
             if constexpr (CPL) {
-                double acc = tab->BT[0] * K1(0);
+                real acc = tab->BT[0] * K1(0);
 #pragma unroll 3
-                for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->BT[j], K1(j), acc);
-                const double a0 = fabs(zo), a1 = fabs(own_of(znew));
-                double res[NR];
-                bcast_all((dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
-                static_for<0, NR>([&](auto c) { ss = __builtin_fma(res[c], res[c], ss); });
+                for (int j = 1; j < S; ++j) acc = rfma(tab->BT[j], K1(j), acc);
+                const real a0 = rabs(zo), a1 = rabs(own_of(znew));
+                real res[NR];
+                bcast_all((dt * acc) / rfma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
+                static_for<0, NR>([&](auto c) { ss = afma(res[c], res[c], ss); });
             } else
             static_for<0, NR>([&](auto c) {
-                double acc = tab->BT[0] * K(0, c);
-                for (int j = 1; j < S; ++j) acc = __builtin_fma(tab->BT[j], K(j, c), acc);
-                const double a0 = fabs(z[c]), a1 = fabs(znew[c]);
-                double res = (dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
+                real acc = tab->BT[0] * K(0, c);
+                for (int j = 1; j < S; ++j) acc = rfma(tab->BT[j], K(j, c), acc);
+                const real a0 = rabs(z[c]), a1 = rabs(znew[c]);
+                real res = (dt * acc) / rfma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
                 if constexpr (Sys::STATE_DISTRIBUTED) res *= sys.state_on(c);
-                ss = __builtin_fma(res, res, ss);
+                ss = afma(res, res, ss);
             });
             if constexpr (Sys::STATE_DISTRIBUTED) ss = group_sum<G>(ss);
-            if constexpr (DEFER) ss += group_sum<G>(sys.slot_step(dt, tab, o));
+            if constexpr (DEFER) ss += group_sum<G>((acc_t)sys.slot_step(dt, tab, o));
             if constexpr (NSL > 0) {
-                double ps = 0.0;
+                acc_t ps = 0.0;
                 static_for<0, NSL>([&](auto c) {
-                    const double m0 = mu[c * MS];
-                    const double m1 = __builtin_fma(dt, accb[c], m0);
+                    const real m0 = mu[c * MS];
+                    const real m1 = rfma(dt, accb[c], m0);
                     accb[c] = m1;  // candidate new value
-                    const double a0 = fabs(m0), a1 = fabs(m1);
-                    const double res = (dt * acce[c]) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
-                    ps = __builtin_fma(res, res, ps);
+                    const real a0 = rabs(m0), a1 = rabs(m1);
+                    const real res = (dt * acce[c]) / rfma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
+                    ps = afma(res, res, ps);
                 });
                 ss += group_sum<G>(ps);
             }
-            const double EEst = sqrt(ss / ntot);
+            const real EEst = rsqrt_ieee((real)ss / ntot);
 
             // ---- loopfooter!: PIController ----
-            double q;
-            if (EEst == 0.0) {
-                q = 1.0 / o.qmax;
+            real q;
+            if (EEst == real(0)) {
+                q = real(1) / o.qmax;
             } else {
-                q11 = fastpow(EEst, o.beta1);
-                q = q11 / fastpow(qold, o.beta2);
+                q11 = (real)fastpow((double)EEst, (double)o.beta1);
+                q = q11 / (real)fastpow((double)qold, (double)o.beta2);
                 q = q / o.gamma;
-                const double lo = 1.0 / o.qmax, hi = 1.0 / o.qmin;
+                const real lo = real(1) / o.qmax, hi = real(1) / o.qmin;
                 if (q > hi) q = hi;
                 if (q < lo) q = lo;
             }
-            accept = (EEst <= 1.0);
+            accept = (EEst <= real(1));
             sys.trace(iter, t, dt, EEst, q, accept);
             if (accept) {
                 st.nacc += 1;
                 qold = EEst > o.qoldinit ? EEst : o.qoldinit;
-                double dtnew = dt / q;
-                const double tprev = t;
-                const double ttmp = t + dt;
+                real dtnew = dt / q;
+                const real tprev = t;
+                const real ttmp = t + dt;
                 {
-                    const double mxt = t > tstop ? t : tstop;
-                    t = fabs(ttmp - tstop) < 100.0 * ulp_of(mxt) ? tstop : ttmp;
+                    const real mxt = t > tstop ? t : tstop;
+                    t = rabs(ttmp - tstop) < real(100) * ulp_of(mxt) ? tstop : ttmp;
                 }
-                if (fabs(dtnew) > dtmax) dtnew = tdir * dtmax;
+                if (rabs(dtnew) > dtmax) dtnew = tdir * dtmax;
                 // hook: saveat interpolation / dense store (forward); may build the lazy stages
                 {
                     bool lazy_done = false;
@@ -453,18 +464,18 @@ struct Driver {
                         if constexpr (Tab::NEXTRA > 0) {
                             if (!lazy_done) {
                                 for (int e = 0; e < Tab::NEXTRA; ++e) {
-                                    double zs[NR], kr[NR], gs[NSLA];
+                                    real zs[NR], kr[NR], gs[NSLA];
                                     const int row = S + e;
                                     if constexpr (CPL) {
-                                        double acc = tab->A[row][0] * K1(0);
+                                        real acc = tab->A[row][0] * K1(0);
 #pragma unroll 3
-                                        for (int j = 1; j < row; ++j) acc = __builtin_fma(tab->A[row][j], K1(j), acc);
-                                        bcast_all(__builtin_fma(dt, acc, zo), zs);
+                                        for (int j = 1; j < row; ++j) acc = rfma(tab->A[row][j], K1(j), acc);
+                                        bcast_all(rfma(dt, acc, zo), zs);
                                     } else
                                     static_for<0, NR>([&](auto c) {
-                                        double acc = tab->A[row][0] * K(0, c);
-                                        for (int j = 1; j < row; ++j) acc = __builtin_fma(tab->A[row][j], K(j, c), acc);
-                                        zs[c] = __builtin_fma(dt, acc, z[c]);
+                                        real acc = tab->A[row][0] * K(0, c);
+                                        for (int j = 1; j < row; ++j) acc = rfma(tab->A[row][j], K(j, c), acc);
+                                        zs[c] = rfma(dt, acc, z[c]);
                                     });
                                     sys.eval(tprev + tab->C[row] * dt, zs, kr, gs);
                                     if constexpr (CPL) K1(row) = own_of(kr);
@@ -491,7 +502,7 @@ struct Driver {
                 if constexpr (DEFER) sys.slot_accept();
                 if constexpr (USE_FSAL && CPL) K1(0) = K1(S - 1);
                 else if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
-                if constexpr (SLOT_FSAL) { double* tsw = gtmp; gtmp = gtmp2; gtmp2 = tsw; }
+                if constexpr (SLOT_FSAL) { real* tsw = gtmp; gtmp = gtmp2; gtmp2 = tsw; }
                 if (bad) { ret = RET_UNSTABLE; done = true; }
                 if (t == tstop) {  // handle_tstop! + callbacks
                     const bool modified = sys.at_tstop(t, z);
@@ -500,7 +511,7 @@ struct Driver {
                     else if (modified) {
                         if constexpr (Tab::FSAL) st.nf += 1;  // reset_fsal! after u_modified!
                         if constexpr (USE_FSAL) {
-                            double kr[NR], gs[NSLA];
+                            real kr[NR], gs[NSLA];
                             sys.eval(t, z, kr, gs);
                             if constexpr (CPL) K1(0) = own_of(kr);
                             else static_for<0, NR>([&](auto c) { K(0, c) = kr[c]; });
@@ -524,26 +535,26 @@ struct Driver {
 // time grid of a trajectory: shared (kernel parameters, wave-uniform scalars) or its own (PT: registers)
 template <bool PT>
 struct TimeGrid {
-    double t0_, tf_, dtmax_;
-    const double* sv_;
+    real t0_, tf_, dtmax_;
+    const real* sv_;
     __device__ __forceinline__ void init(const KParams& p, int64_t j) {
         if constexpr (PT) {
-            t0_ = p.tspan_pt ? p.tspan_pt[2 * j] : p.t0;
-            tf_ = p.tspan_pt ? p.tspan_pt[2 * j + 1] : p.tf;
-            dtmax_ = p.dtmax_auto ? tf_ - t0_ : p.o.dtmax;
+            t0_ = p.tspan_pt ? (real)p.tspan_pt[2 * j] : (real)p.t0;   // (tspan pairs arrive as doubles from the host)
+            tf_ = p.tspan_pt ? (real)p.tspan_pt[2 * j + 1] : (real)p.tf;
+            dtmax_ = p.dtmax_auto ? tf_ - t0_ : (real)p.o.dtmax;
             sv_ = p.saveat + (p.saveat_pt ? (size_t)j * p.ns : 0);
         }
     }
-    __device__ __forceinline__ double T0(const KParams& p) const { if constexpr (PT) return t0_; else return p.t0; }
-    __device__ __forceinline__ double TF(const KParams& p) const { if constexpr (PT) return tf_; else return p.tf; }
-    __device__ __forceinline__ double SV(const KParams& p, int i) const { if constexpr (PT) return sv_[i]; else return p.saveat[i]; }
-    __device__ __forceinline__ double DTMAX(const Opts& o) const { if constexpr (PT) return dtmax_; else return o.dtmax; }
+    __device__ __forceinline__ real T0(const KParams& p) const { if constexpr (PT) return t0_; else return (real)p.t0; }
+    __device__ __forceinline__ real TF(const KParams& p) const { if constexpr (PT) return tf_; else return (real)p.tf; }
+    __device__ __forceinline__ real SV(const KParams& p, int i) const { if constexpr (PT) return sv_[i]; else return p.saveat[i]; }
+    __device__ __forceinline__ real DTMAX(const OptsR& o) const { if constexpr (PT) return dtmax_; else return o.dtmax; }
 };
 
 template <class Model, class Tab, int G, int BLOCKDIM, bool PT = false>
 struct FwdSys {
     TimeGrid<PT> tg;
-    __device__ __forceinline__ double dtmax(const Opts& o) const { return tg.DTMAX(o); }
+    __device__ __forceinline__ real dtmax(const OptsR& o) const { return tg.DTMAX(o); }
     static constexpr int NR = Model::NS, NSL = 0;
     static constexpr bool ALWAYS_K0 = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     static constexpr bool SLOTS_GLOBAL = false, CPL = Model::CPL, DEFERRED = false;
@@ -552,68 +563,68 @@ struct FwdSys {
     int64_t j;      // trajectory
     bool writer;    // lane 0 of the group
     int si, nsteps, r, n;
-    double loss;
+    real loss;
     // component c of this lane is state index comp(c); replicated states: every lane holds all of them
     __device__ __forceinline__ int comp(int c) const {
         if constexpr (STATE_DISTRIBUTED) return Model::point(c, r); else return c;
     }
     __device__ __forceinline__ bool cvalid(int c) const { return comp(c) < n; }
     __device__ __forceinline__ bool cwrite(int c) const { return STATE_DISTRIBUTED ? cvalid(c) : writer; }
-    __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
+    __device__ __forceinline__ real state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
 
-    __device__ __forceinline__ double first_tstop() const { return tg.TF(*p); }
-    __device__ __forceinline__ bool next_tstop(double&) const { return false; }
-    __device__ __forceinline__ bool at_tstop(double, double*) const { return false; }
-    __device__ __forceinline__ void eval(double, const double* z, double* kr, double*) {
+    __device__ __forceinline__ real first_tstop() const { return tg.TF(*p); }
+    __device__ __forceinline__ bool next_tstop(real&) const { return false; }
+    __device__ __forceinline__ bool at_tstop(real, real*) const { return false; }
+    __device__ __forceinline__ void eval(real, const real* z, real* kr, real*) {
         asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
         Model::rhs(mctx, z, kr);
     }
-    __device__ __forceinline__ void trace(int iter, double t, double dt, double e, double q, bool acc) const {
+    __device__ __forceinline__ void trace(int iter, real t, real dt, real e, real q, bool acc) const {
         if (p->trace && writer && j == p->trace_traj && iter <= p->trace_cap) {
-            double* row = p->trace + (size_t)(iter - 1) * 5;
+            real* row = p->trace + (size_t)(iter - 1) * 5;
             row[0] = t; row[1] = dt; row[2] = e; row[3] = q; row[4] = acc ? 1.0 : 0.0;
         }
     }
 
-    __device__ __forceinline__ void save_point(int i, const double* v) {
+    __device__ __forceinline__ void save_point(int i, const real* v) {
         if (p->u_out) {
-            double* dst = p->u_out + ((size_t)j * p->ns + i) * n;
+            real* dst = p->u_out + ((size_t)j * p->ns + i) * n;
             static_for<0, NR>([&](auto c) { if (cwrite(c)) dst[comp(c)] = v[c]; });
         }
         if (p->data) {
-            const double* d = p->data + ((size_t)j * p->ns + i) * n;
+            const real* d = p->data + ((size_t)j * p->ns + i) * n;
             static_for<0, NR>([&](auto c) {
                 if (cvalid(c)) {
                     const int ci = comp(c);
                     // masked-out rows are ignored entirely (a select, not a product: NaN/Inf data there must not
                     // reach the loss -- the reference slices those rows away, seir_exposure.jl:146)
-                    const double e = (p->row_mask && !p->row_mask[ci]) ? 0.0 : (v[c] - d[ci]);
-                    loss = __builtin_fma(e, e, loss);
-                    if (cwrite(c)) p->cot[((size_t)i * n + ci) * p->Npad + j] = 2.0 * e;
+                    const real e = (p->row_mask && !p->row_mask[ci]) ? real(0) : (v[c] - d[ci]);
+                    loss = rfma(e, e, loss);
+                    if (cwrite(c)) p->cot[((size_t)i * n + ci) * p->Npad + j] = real(2) * e;
                 }
             });
         }
     }
 
     template <class Lazy>
-    __device__ __forceinline__ int accepted(double tprev, double t, double dt, const double* z, const double* znew,
-                                            const double* kl, Lazy& lazy) {
+    __device__ __forceinline__ int accepted(real tprev, real t, real dt, const real* z, const real* znew,
+                                            const real* kl, Lazy& lazy) {
         auto k = [&](int q, int c) { return kl[(q * NR + c) * k_stride<STATE_DISTRIBUTED, G, BLOCKDIM>()]; };
         auto k1 = [&](int q) { return kl[q * KCP]; };  // CPL: this lane's component
         while (si < p->ns && tg.SV(*p, si) <= t) {
-            const double curt = tg.SV(*p, si);
+            const real curt = tg.SV(*p, si);
             if (curt != t) {
                 lazy();
-                const double th = (curt - tprev) / dt;
-                double b[Tab::NK], y[NR];
+                const real th = (curt - tprev) / dt;
+                real b[Tab::NK], y[NR];
                 Tab::bth(th, b);
                 if constexpr (CPL) {
-                    const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return k1(q); }, [&](auto q) { return b[q]; });
-                    bcast_all(__builtin_fma(dt, acc, own_of<NR>(reinterpret_cast<const double(&)[NR]>(*z))), y);
+                    const real acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return k1(q); }, [&](auto q) { return b[q]; });
+                    bcast_all(rfma(dt, acc, own_of<NR>(reinterpret_cast<const real(&)[NR]>(*z))), y);
                 } else
                 static_for<0, NR>([&](auto c) {
-                    const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return k(q, c); }, [&](auto q) { return b[q]; });
-                    y[c] = __builtin_fma(dt, acc, z[c]);
+                    const real acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return k(q, c); }, [&](auto q) { return b[q]; });
+                    y[c] = rfma(dt, acc, z[c]);
                 });
                 save_point(si, y);
             } else {
@@ -626,7 +637,7 @@ struct FwdSys {
             lazy();
             {
                 const int nf = 3 + n + Tab::NK * n;
-                double* base = p->dense + ((size_t)nsteps * nf) * p->Npad + j;
+                real* base = p->dense + ((size_t)nsteps * nf) * p->Npad + j;
                 if (writer) {
                     base[0] = tprev;
                     base[(size_t)1 * p->Npad] = t;
@@ -634,7 +645,7 @@ struct FwdSys {
                 }
                 if constexpr (CPL) {
                     // lane c stores component c of u and of every stage
-                    const double zo = own_of<NR>(reinterpret_cast<const double(&)[NR]>(*z));
+                    const real zo = own_of<NR>(reinterpret_cast<const real(&)[NR]>(*z));
                     if (r < n) {
                         base[(size_t)(3 + r) * p->Npad] = zo;
                         static_for<0, Tab::NK>([&](auto q) { base[(size_t)(3 + n + q * n + r) * p->Npad] = k1(q); });
@@ -667,13 +678,14 @@ struct Layout {
     static __host__ __device__ constexpr int np_pad(int np) { return (np + 1) & ~1; }
 };
 
-template <class Model, class Tab, int G, int BLOCK, bool PT = false>
+// RTag: the translation unit's scalar type in the kernel's NAME (the Float32 and Float64 builds of one instance are different symbols)
+template <class Model, class Tab, int G, int BLOCK, bool PT = false, class RTag = real>
 __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK>;
-    double* th = reinterpret_cast<double*>(smem_raw);
-    double* scratch = th + Model::theta_lds(p.n_param);
-    double* kbase = scratch + Model::SCRATCH;
+    real* th = reinterpret_cast<real*>(smem_raw);
+    real* scratch = th + Model::theta_lds(p.n_param);
+    real* kbase = scratch + Model::SCRATCH;
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     for (int i = threadIdx.x; i < L::K_DOUBLES; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
     __syncthreads();
@@ -685,7 +697,7 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     using Sys = FwdSys<Model, Tab, G, BLOCK, PT>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
-    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, nullptr, 0, p.mc, r, p.theta);
+    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, nullptr, 0, p.mc, r, p.theta);
     sys.p = &p;
     sys.tg.init(p, gid);
     sys.j = gid;
@@ -695,16 +707,16 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
     sys.loss = 0.0;
     sys.r = r;
     sys.n = p.n_state;
-    double z[Sys::NR];
-    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>(Tab::NK);
-    double* mu = nullptr;  // no slot state in the forward pass
+    real z[Sys::NR];
+    real* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>(Tab::NK);
+    real* mu = nullptr;  // no slot state in the forward pass
     static_for<0, Sys::NR>([&](auto c) { z[c] = sys.cvalid(c) ? p.u0[(size_t)gid * p.n_state + sys.comp(c)] : 0.0; });
     while (sys.si < p.ns && sys.tg.SV(p, sys.si) <= sys.tg.T0(p)) {  // save_start
         sys.save_point(sys.si, z);
         sys.si += 1;
     }
     typename Drv::Stats st;
-    const int ret = Drv::run(sys, p.o, p.tab, z, kl, mu, sys.tg.T0(p), 1.0, (double)p.n_state, st);
+    const int ret = Drv::run(sys, p.o, p.tab, z, kl, mu, sys.tg.T0(p), real(1), (real)p.n_state, st);
     if constexpr (Model::STATE_DISTRIBUTED) sys.loss = group_sum<G>(sys.loss);  // per-lane partial sums of the loss
     if (sys.writer) {
         if (p.stats) {
@@ -723,11 +735,11 @@ __global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
 // One evaluation of the right-hand side for a batch of states (the trained UDE on saved states: what the SINDy stage
 // of the scripts consumes, scenario_1.jl:152-160): du = f(u, theta), same lane-group layout as the solver kernels.
 // ---------------------------------------------------------------------------------------------
-template <class Model, class Tab, int G, int BLOCK>
+template <class Model, class Tab, int G, int BLOCK, class RTag = real>
 __global__ void __launch_bounds__(BLOCK) rhs_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* th = reinterpret_cast<double*>(smem_raw);
-    double* scratch = th + Model::theta_lds(p.n_param);
+    real* th = reinterpret_cast<real*>(smem_raw);
+    real* scratch = th + Model::theta_lds(p.n_param);
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     __syncthreads();
     constexpr int GROUPS = BLOCK / G;
@@ -736,9 +748,9 @@ __global__ void __launch_bounds__(BLOCK) rhs_kernel(const KParams p) {
     if (gid >= p.N || (int)threadIdx.x >= GROUPS * G) return;  // whole groups leave together
     using Sys = FwdSys<Model, Tab, G, BLOCK>;
     Sys sys;
-    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, nullptr, 0, p.mc, r, p.theta);
+    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, nullptr, 0, p.mc, r, p.theta);
     sys.p = &p; sys.j = gid; sys.writer = (r == 0); sys.r = r; sys.n = p.n_state;
-    double z[Sys::NR], kr[Sys::NR];
+    real z[Sys::NR], kr[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { z[c] = sys.cvalid(c) ? p.u0[(size_t)gid * p.n_state + sys.comp(c)] : 0.0; });
     Model::rhs(sys.mctx, z, kr);
     static_for<0, Sys::NR>([&](auto c) { if (sys.cwrite(c)) p.u_out[(size_t)gid * p.n_state + sys.comp(c)] = kr[c]; });
@@ -755,7 +767,7 @@ __global__ void __launch_bounds__(BLOCK) rhs_kernel(const KParams p) {
 template <class Model, class Tab, int G, bool PT = false, int VAR = 1>
 struct AdjSys {
     TimeGrid<PT> tg;
-    __device__ __forceinline__ double dtmax(const Opts& o) const { return tg.DTMAX(o); }
+    __device__ __forceinline__ real dtmax(const OptsR& o) const { return tg.DTMAX(o); }
     static constexpr bool DEFERRED = Model::DEFERRED;
     static constexpr int NR = Model::NS, NSL = (DEFERRED || VAR == 9) ? 0 : Model::NSL;
     static constexpr bool STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
@@ -772,28 +784,28 @@ struct AdjSys {
     }
     __device__ __forceinline__ bool cvalid(int c) const { return comp(c) < n; }
     __device__ __forceinline__ bool cwrite(int c) const { return STATE_DISTRIBUTED ? cvalid(c) : mctx.r == 0; }
-    __device__ __forceinline__ double state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
+    __device__ __forceinline__ real state_on(int c) const { return cvalid(c) ? 1.0 : 0.0; }
     // cached forward interval: t_start/t_end in registers; u_start and the k's either in registers (IC_LDS = false)
     // or in a group-shared LDS row (IC_LDS: saves 2*NR*(NK+1) VGPRs per lane; reads are broadcasts inside the group)
     // CPL: lane c caches component c only (u_start and the k's of the interval: 1 + NK registers)
     static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !CPL;
     static constexpr int IC_FIELDS = NR + Tab::NK * NR;
     static constexpr int IC_NR = (IC_LDS || CPL) ? 1 : NR;
-    double ts, te, us[IC_NR], ks[IC_LDS ? 1 : Tab::NK][IC_NR];
-    double* ic;      // LDS: field f of this group at ic[f * icstride]
+    real ts, te, us[IC_NR], ks[IC_LDS ? 1 : Tab::NK][IC_NR];
+    real* ic;      // LDS: field f of this group at ic[f * icstride]
     int icstride;
-    __device__ __forceinline__ double US(int c) const { if constexpr (IC_LDS) return ic[c * icstride]; else return us[c]; }
-    __device__ __forceinline__ double KS(int q, int c) const {
+    __device__ __forceinline__ real US(int c) const { if constexpr (IC_LDS) return ic[c * icstride]; else return us[c]; }
+    __device__ __forceinline__ real KS(int q, int c) const {
         if constexpr (IC_LDS) return ic[(NR + q * NR + c) * icstride]; else return ks[q][c];
     }
     // cotangent access
-    const double* cot;
+    const real* cot;
     size_t cot_si, cot_sc;  // strides of save index / component
 
     __device__ __forceinline__ void load_interval(int s) {
         sf = s;
         const int nf = 3 + n + Tab::NK * n;
-        const double* base = p->dense + ((size_t)s * nf) * p->Npad + j;
+        const real* base = p->dense + ((size_t)s * nf) * p->Npad + j;
         ts = base[0];
         te = base[(size_t)1 * p->Npad];
         if constexpr (IC_LDS) {
@@ -821,46 +833,46 @@ struct AdjSys {
         }
     }
     // sol(t, continuity = :right): interval [s, s+1] with t_s <= t, clamped to the stored range
-    __device__ __forceinline__ void locate(double t) {
+    __device__ __forceinline__ void locate(real t) {
         while (t < ts && sf > 0) load_interval(sf - 1);
         while (t >= te && sf < nsteps - 1) load_interval(sf + 1);
     }
     // ---- deferred slots: slot state in HBM, two columns (current / candidate) that swap on acceptance ----
-    double *mu_cur, *mu_new;
+    real *mu_cur, *mu_new;
     int ms;
-    double rq[7];  // CPL: lane q's Horner table of b_q(theta)
+    real rq[7];  // CPL: lane q's Horner table of b_q(theta)
     __device__ __forceinline__ void load_bth_table() {
         const int q = mctx.r < Tab::NK ? mctx.r : 0;
         static_for<0, 7>([&](auto i) { rq[i] = p->tab->R[q][i]; });
     }
     // b_q(theta) evaluated by lane q alone (bit-identical to Tab::bth), handed to the component lanes as scalars
-    __device__ __forceinline__ void bth_lanes(double th, double* b) const {
-        double h = rq[0];
-        static_for<1, 7>([&](auto i) { h = __builtin_fma(th, h, rq[i]); });
-        const double bq = (mctx.r == 0 ? th : th * th) * h;
+    __device__ __forceinline__ void bth_lanes(real th, real* b) const {
+        real h = rq[0];
+        static_for<1, 7>([&](auto i) { h = rfma(th, h, rq[i]); });
+        const real bq = (mctx.r == 0 ? th : th * th) * h;
         static_for<0, Tab::NK>([&](auto q) {
-            if constexpr (Tab::dense_uses(q)) b[q] = readlane_f64(bq, decltype(q)::value);
+            if constexpr (Tab::dense_uses(q)) b[q] = readlane_real(bq, decltype(q)::value);
         });
     }
-    __device__ __forceinline__ void eval_store(double t, const double* lam, double* klam, int s) {
+    __device__ __forceinline__ void eval_store(real t, const real* lam, real* klam, int s) {
         if constexpr (DEFERRED) {
             asm volatile("" ::: "memory");
             locate(t);
-            const double dtf = te - ts;
-            const double th = (t - ts) / dtf;
-            double b[Tab::NK], y[NR], dl[NR];
+            const real dtf = te - ts;
+            const real th = (t - ts) / dtf;
+            real b[Tab::NK], y[NR], dl[NR];
             bth_lanes(th, b);
             static_assert(!DEFERRED || CPL, "deferred slots come with component-per-lane interval caches");
-            const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][0]; }, [&](auto q) { return b[q]; });
-            bcast_all(__builtin_fma(dtf, acc, us[0]), y);
+            const real acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][0]; }, [&](auto q) { return b[q]; });
+            bcast_all(rfma(dtf, acc, us[0]), y);
             Model::vjp_store(mctx, y, lam, dl, s);
             static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
         }
     }
-    __device__ __forceinline__ void slot_init01(const Opts& o, double& h0, double& l0, double& h1, double& l1) {
+    __device__ __forceinline__ void slot_init01(const OptsR& o, real& h0, real& l0, real& h1, real& l1) {
         if constexpr (DEFERRED) Model::init_norm01(mctx, o.abstol, o.reltol, mu_cur, ms, h0, l0, h1, l1);
     }
-    __device__ __forceinline__ void slot_init2(const Opts& o, double& h2, double& l2) {
+    __device__ __forceinline__ void slot_init2(const OptsR& o, real& h2, real& l2) {
         if constexpr (DEFERRED) Model::init_norm2(mctx, o.abstol, o.reltol, mu_cur, ms, h2, l2);
     }
     // stages whose B and BT weights are both zero (Vern7: stages 2, 3) drop out of the deferred sums at compile time
@@ -870,44 +882,44 @@ struct AdjSys {
             if (Tab::B(s) != 0.0 || Tab::BT(s) != 0.0) m |= 1u << s;
         return m;
     }
-    __device__ __forceinline__ double slot_step(double dt, const TabDev* tab, const Opts& o) {
+    __device__ __forceinline__ real slot_step(real dt, const TabDev* tab, const OptsR& o) {
         if constexpr (DEFERRED)
             return Model::template step_slots<Tab::S, stage_mask()>(mctx, tab->B, tab->BT, dt, o.abstol, o.reltol, mu_cur, mu_new, ms);
         else return 0.0;
     }
     __device__ __forceinline__ void slot_accept() {
-        double* t = mu_cur; mu_cur = mu_new; mu_new = t;
+        real* t = mu_cur; mu_cur = mu_new; mu_new = t;
     }
-    __device__ __forceinline__ void eval(double t, const double* lam, double* klam, double* g) {
+    __device__ __forceinline__ void eval(real t, const real* lam, real* klam, real* g) {
       if constexpr (!DEFERRED) {
         asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
         locate(t);
-        const double dtf = te - ts;
-        const double th = (t - ts) / dtf;
-        double b[Tab::NK], y[NR], dl[NR];
+        const real dtf = te - ts;
+        const real th = (t - ts) / dtf;
+        real b[Tab::NK], y[NR], dl[NR];
         Tab::bth(th, b);
         static_for<0, NR>([&](auto c) {
-            const double acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
-            y[c] = __builtin_fma(dtf, acc, US(c));
+            const real acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
+            y[c] = rfma(dtf, acc, US(c));
         });
         Model::template vjp<(NSL > 0)>(mctx, y, lam, dl, g);
         static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
         static_for<0, NSL>([&](auto c) { g[c] = -g[c]; });
       }
     }
-    __device__ __forceinline__ void trace(int iter, double t, double dt, double e, double q, bool acc) const {
+    __device__ __forceinline__ void trace(int iter, real t, real dt, real e, real q, bool acc) const {
         if (p->trace && mctx.r == 0 && j == p->trace_traj && iter <= p->trace_cap) {
-            double* row = p->trace + ((size_t)p->trace_cap + (iter - 1)) * 5;
+            real* row = p->trace + ((size_t)p->trace_cap + (iter - 1)) * 5;
             row[0] = t; row[1] = dt; row[2] = e; row[3] = q; row[4] = acc ? 1.0 : 0.0;
         }
     }
 
-    __device__ __forceinline__ double tstop_from_cur() const {
+    __device__ __forceinline__ real tstop_from_cur() const {
         // next save time strictly inside (t0, t) in descending order, else t0
         return (cur >= 0 && tg.SV(*p, cur) > tg.T0(*p)) ? tg.SV(*p, cur) : tg.T0(*p);
     }
-    __device__ __forceinline__ double first_tstop() const { return tstop_from_cur(); }
-    __device__ __forceinline__ bool at_tstop(double t, double* lam) {
+    __device__ __forceinline__ real first_tstop() const { return tstop_from_cur(); }
+    __device__ __forceinline__ bool at_tstop(real t, real* lam) {
         bool mod = false;
         while (cur >= 0 && tg.SV(*p, cur) >= t) {
             if (tg.SV(*p, cur) == t) {
@@ -920,25 +932,25 @@ struct AdjSys {
         }
         return mod;
     }
-    __device__ __forceinline__ bool next_tstop(double& tstop) {
+    __device__ __forceinline__ bool next_tstop(real& tstop) {
         if (tstop == tg.T0(*p)) return false;
         tstop = tstop_from_cur();
         return true;
     }
     template <class Lazy>
-    __device__ __forceinline__ int accepted(double, double, double, const double*, const double*, const double*, Lazy&) {
+    __device__ __forceinline__ int accepted(real, real, real, const real*, const real*, const real*, Lazy&) {
         return RET_SUCCESS;
     }
 };
 
-template <class Model, class Tab, int G, int BLOCK, bool PT = false, int VAR = 1>
+template <class Model, class Tab, int G, int BLOCK, bool PT = false, int VAR = 1, class RTag = real>
 __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK>;
-    double* th = reinterpret_cast<double*>(smem_raw);
-    double* scratch = th + Model::theta_lds(p.n_param);
-    double* kbase = scratch + Model::SCRATCH;
-    double* slots = kbase + L::K_DOUBLES;
+    real* th = reinterpret_cast<real*>(smem_raw);
+    real* scratch = th + Model::theta_lds(p.n_param);
+    real* kbase = scratch + Model::SCRATCH;
+    real* slots = kbase + L::K_DOUBLES;
     const int np_pad = L::np_pad(p.n_param);
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     for (int i = threadIdx.x; i < L::K_DOUBLES; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
@@ -951,26 +963,26 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     constexpr int NSL = Sys::NSL;
     constexpr int NSLA = NSL > 0 ? NSL : 1;
-    double* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>(Tab::NK);
+    real* kl = kbase + k_offset<Model::STATE_DISTRIBUTED, G, Model::CPL>(Tab::NK);
     // register-slot mode: slot state mu of thread tid, element c at mu_lds[c * BLOCK]
     constexpr bool SG = Model::SLOTS_GLOBAL;  // mu in HBM (fused-accumulation models: nothing else needs a column)
     const int MS = SG ? (int)(gridDim.x * BLOCK) : BLOCK;
-    double* mu_lds = SG ? p.slot_glob + (size_t)blockIdx.x * BLOCK + threadIdx.x : slots + threadIdx.x;
-    double* gtmp = slots + (size_t)NSLA * BLOCK + threadIdx.x;        // initial-dt scratch, element c at gtmp[c * BLOCK]
-    double* gtmp2 = slots + (size_t)2 * NSLA * BLOCK + threadIdx.x;    // last-stage slot derivative (FSAL hand-over)
+    real* mu_lds = SG ? p.slot_glob + (size_t)blockIdx.x * BLOCK + threadIdx.x : slots + threadIdx.x;
+    real* gtmp = slots + (size_t)NSLA * BLOCK + threadIdx.x;        // initial-dt scratch, element c at gtmp[c * BLOCK]
+    real* gtmp2 = slots + (size_t)2 * NSLA * BLOCK + threadIdx.x;    // last-stage slot derivative (FSAL hand-over)
     // (the third column only exists for FSAL tableaux: at 4 blocks per CU every LDS kilobyte counts -- the C2 ensemble
     // must fit the chip in ONE round of blocks)
-    double* icbase = slots + (SG ? (size_t)0 : (size_t)(Tab::FSAL ? 3 : 2) * NSLA * BLOCK);  // interval cache rows (IC_LDS)
-    double lam[Sys::NR];
+    real* icbase = slots + (SG ? (size_t)0 : (size_t)(Tab::FSAL ? 3 : 2) * NSLA * BLOCK);  // interval cache rows (IC_LDS)
+    real lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
     constexpr int NSLOT = Model::DEFERRED ? Model::NSL : NSL;  // slots this thread reports (deferred: system-owned)
     static_for<0, NSLOT>([&](auto c) { mu_lds[(size_t)c * MS] = 0.0; });
-    double* mu_final = mu_lds;
+    real* mu_final = mu_lds;
     const bool in_range = gid < p.N && (int)threadIdx.x < GROUPS * G;
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         Sys sys;
-        Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
+        Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
         sys.p = &p;
         sys.tg.init(p, gid);
         sys.j = gid;
@@ -995,7 +1007,7 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         sys.load_interval(sys.nsteps - 1);
         sys.at_tstop(sys.tg.TF(p), lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
-        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, sys.tg.TF(p), -1.0, (double)(p.n_state + p.n_param), st, gtmp, gtmp2, MS);
+        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, sys.tg.TF(p), real(-1), (real)(p.n_state + p.n_param), st, gtmp, gtmp2, MS);
         if constexpr (Model::DEFERRED) mu_final = sys.mu_cur;
         if (r == 0) {
             if (p.stats) {
@@ -1018,12 +1030,12 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         __syncthreads();
         if ((int)threadIdx.x < G) {
             const int64_t wave = part_row<G, BLOCK>();
-            double* row = p.grad_part + (size_t)wave * p.n_param;
-            const double* base = slots;
+            real* row = p.grad_part + (size_t)wave * p.n_param;
+            const real* base = slots;
             for (int s = 0; s < NSL; ++s) {
                 const int idx = Model::slot_index(p.mc, (int)threadIdx.x, s);
                 if (idx >= 0) {
-                    double acc = 0.0;
+                    real acc = 0.0;
                     for (int gq = 0; gq < GROUPS; ++gq) acc += base[s * BLOCK + gq * G + (int)threadIdx.x];
                     row[idx] = acc;
                 }
@@ -1033,18 +1045,18 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     if constexpr (SG) {
         // one wavefront per trajectory, mu in HBM: the wave's partial row is its own mu, slot by slot
         static_assert(G == 64, "HBM slot state: one wavefront per trajectory");
-        double* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
+        real* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
         static_for<0, NSLOT>([&](auto c) {
             const int idx = Model::slot_index(p.mc, r, c);
             if (idx >= 0) row[idx] = mu_final[(size_t)c * MS];
         });
     }
     if constexpr (!SG && pow2_group<G>()) {
-    double mu[NSLA];
+    real mu[NSLA];
     static_for<0, NSL>([&](auto c) { mu[c] = mu_lds[c * BLOCK]; });
     // ---- deterministic reduction: groups of a wave (xor butterfly), then one partial row per wave ----
     static_for<0, NSL>([&](auto c) {
-        double v = mu[c];
+        real v = mu[c];
 #pragma unroll
         for (int m = G; m < (BLOCK < 64 ? BLOCK : 64); m <<= 1) v += __shfl_xor(v, m, 64);
         mu[c] = v;
@@ -1052,11 +1064,11 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     const int lane = G > 64 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     if (lane < G) {
         const int64_t wave = part_row<G, BLOCK>();
-        double* row = p.grad_part + (size_t)wave * p.n_param;
+        real* row = p.grad_part + (size_t)wave * p.n_param;
         for (int s = 0; s < NSL; ++s) {
             const int idx = Model::slot_index(p.mc, lane, s);
             if (idx >= 0) {
-                double v = 0.0;
+                real v = 0.0;
                 static_for<0, NSL>([&](auto c) { v = (s == c) ? mu[c] : v; });
                 row[idx] = v;
             }
@@ -1073,25 +1085,25 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
 // divisions.  Accumulation order = oracle/ude_oracle_impl.h: discrete_sweep (ARITH-SPEC), so per-trajectory
 // results are bit-identical to the oracle.
 // ---------------------------------------------------------------------------------------------
-template <class Model, class Tab, int G, int BLOCK, bool PT = false>
+template <class Model, class Tab, int G, int BLOCK, bool PT = false, class RTag = real>
 __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK, false>;  // (the reverse sweep keeps the replicated stage layout)
     constexpr int NR = Model::NS, NSL = Model::NSL, NSLA = NSL > 0 ? NSL : 1;
     constexpr int S = Tab::S, NK = Tab::NK, KSTRIDE = L::KSTRIDE, GROUPS = BLOCK / G;
     constexpr bool DIST = Model::STATE_DISTRIBUTED;
-    double* th = reinterpret_cast<double*>(smem_raw);
-    double* scratch = th + Model::theta_lds(p.n_param);
+    real* th = reinterpret_cast<real*>(smem_raw);
+    real* scratch = th + Model::theta_lds(p.n_param);
     // k of the current step: an LDS copy -- or, for models whose LDS is spoken for (DADJ_K_FROM_DENSE), read straight
     // from the dense store in HBM (21 L2-resident loads per component and step)
     constexpr bool KD = Model::DADJ_K_FROM_DENSE;
-    double* kbase = scratch + Model::SCRATCH;
-    double* kbbase = kbase + (KD ? 0 : L::K_DOUBLES);  // kbar
-    double* slots = kbbase + L::K_DOUBLES;
+    real* kbase = scratch + Model::SCRATCH;
+    real* kbbase = kbase + (KD ? 0 : L::K_DOUBLES);  // kbar
+    real* slots = kbbase + L::K_DOUBLES;
     const int np_pad = L::np_pad(p.n_param);
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     constexpr bool SG = Model::SLOTS_GLOBAL;
-    double* acc_lds = slots + threadIdx.x;  // register-slot models: accumulator row, element c at acc_lds[c*BLOCK]
+    real* acc_lds = slots + threadIdx.x;  // register-slot models: accumulator row, element c at acc_lds[c*BLOCK]
     if constexpr (!SG) static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = 0.0; });
     __syncthreads();
 
@@ -1101,7 +1113,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     const bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         typename Model::Ctx mctx;
-        Model::init(mctx, Model::THETA_GLOBAL ? const_cast<double*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
+        Model::init(mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
         const int n = p.n_state;
         auto comp = [&](int c) {
             if constexpr (DIST) return Model::point(c, r); else return c;
@@ -1111,14 +1123,14 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         const int koff = k_offset<DIST, G>();
         TimeGrid<PT> tg;
         tg.init(p, gid);
-        const double* kdense = nullptr;  // first stage field of the current step in the dense store (KD)
-        auto K = [&](int j, int c) -> double {
+        const real* kdense = nullptr;  // first stage field of the current step in the dense store (KD)
+        auto K = [&](int j, int c) -> real {
             if constexpr (KD) return cvalid(c) ? kdense[(size_t)(j * n + comp(c)) * p.Npad] : 0.0;
             else return kbase[(j * NR + c) * KSTRIDE + koff];
         };
-        auto KB = [&](int j, int c) -> double& { return kbbase[(j * NR + c) * KSTRIDE + koff]; };
+        auto KB = [&](int j, int c) -> real& { return kbbase[(j * NR + c) * KSTRIDE + koff]; };
         const TabDev* tab = p.tab;
-        const double* cot;
+        const real* cot;
         size_t cot_si, cot_sc;
         if (p.cot_in) {
             cot = p.cot_in + (size_t)gid * p.ns * n;
@@ -1132,18 +1144,18 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         auto COT = [&](int i, int c) { return cot[(size_t)i * cot_si + (size_t)comp(c) * cot_sc]; };
         const int nsteps = p.dense_n[gid];
         const int nf = 3 + n + NK * n;
-        double ubar[NR], un[NR], carry[NR], acc[NSLA];
+        real ubar[NR], un[NR], carry[NR], acc[NSLA];
         static_for<0, NR>([&](auto c) { ubar[c] = 0.0; carry[c] = 0.0; });
         static_for<0, NSL>([&](auto c) { acc[c] = 0.0; });
         int si = p.ns - 1;
         int64_t nvjp = 0;
         // one VJP at stage input g with stage cotangent kbrow: w = (df/du)^T kbrow; parameter part into acc
-        auto stage_vjp = [&](const double* g, const double* kbrow, double* w) {
+        auto stage_vjp = [&](const real* g, const real* kbrow, real* w) {
             asm volatile("" ::: "memory");
             if constexpr (Model::FUSED_ACC) {
-                Model::template vjp_acc<false>(mctx, g, kbrow, w, acc, acc, -1.0, 0.0);  // acc += (df/dtheta)^T kbar
+                Model::template vjp_acc<false>(mctx, g, kbrow, w, acc, acc, real(-1), real(0));  // acc += (df/dtheta)^T kbar
             } else {
-                double gs[NSLA];
+                real gs[NSLA];
                 Model::template vjp<true>(mctx, g, kbrow, w, gs);
                 static_for<0, NSL>([&](auto c) { acc[c] += gs[c]; });
             }
@@ -1151,9 +1163,9 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             nvjp += 1;
         };
         for (int st = nsteps - 1; st >= 0; --st) {
-            const double* base = p.dense + ((size_t)st * nf) * p.Npad + gid;
-            const double tn = base[0], tn1 = base[(size_t)1 * p.Npad], dt = base[(size_t)2 * p.Npad];
-            double u_n[NR];
+            const real* base = p.dense + ((size_t)st * nf) * p.Npad + gid;
+            const real tn = base[0], tn1 = base[(size_t)1 * p.Npad], dt = base[(size_t)2 * p.Npad];
+            real u_n[NR];
             static_for<0, NR>([&](auto c) { u_n[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p.Npad] : 0.0; });
             kdense = base + (size_t)(3 + n) * p.Npad;
             for (int q = 0; q < NK; ++q)
@@ -1168,21 +1180,21 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             // (2) u_{n+1} = u_n + dt*sum B_j k_j
             static_for<0, NR>([&](auto c) { un[c] = ubar[c]; });
             for (int j = 0; j < NK; ++j) {
-                const double bj = j < S ? tab->B[j] : 0.0;
-                static_for<0, NR>([&](auto c) { KB(j, c) = bj != 0.0 ? (dt * bj) * ubar[c] : 0.0; });
+                const real bj = j < S ? tab->B[j] : real(0);
+                static_for<0, NR>([&](auto c) { KB(j, c) = bj != real(0) ? (dt * bj) * ubar[c] : real(0); });
             }
             if constexpr (Tab::FSAL) static_for<0, NR>([&](auto c) { KB(S - 1, c) += carry[c]; });
             // (3) saves strictly inside the step, descending: y = u_n + dt*sum b_j(theta) k_j
             bool interior = false;
             while (si >= 0 && tg.SV(p, si) > tn) {
-                const double thv = (tg.SV(p, si) - tn) / dt;
-                double bw[NK];
+                const real thv = (tg.SV(p, si) - tn) / dt;
+                real bw[NK];
                 Tab::bth(thv, bw);
                 static_for<0, NR>([&](auto c) {
-                    const double dl = cvalid(c) ? COT(si, c) : 0.0;
+                    const real dl = cvalid(c) ? COT(si, c) : 0.0;
                     un[c] += dl;
                     static_for<0, NK>([&](auto j) {
-                        if constexpr (Tab::dense_uses(j)) KB(j, c) = __builtin_fma(dt * bw[j], dl, KB(j, c));
+                        if constexpr (Tab::dense_uses(j)) KB(j, c) = rfma(dt * bw[j], dl, KB(j, c));
                     });
                 });
                 interior = true;
@@ -1191,23 +1203,23 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             if constexpr (DIST) interior = __any(interior);  // wave-uniform (the save grid is shared anyway)
             // (4)+(5) lazy dense-output stages (only if a save point used them), then the main stages S-1 .. 1
             for (int row = (Tab::NEXTRA > 0 && interior) ? S + Tab::NEXTRA - 1 : S - 1; row >= 1; --row) {
-                double g[NR], kbrow[NR], w[NR];
+                real g[NR], kbrow[NR], w[NR];
                 static_for<0, NR>([&](auto c) {
-                    double a = tab->A[row][0] * K(0, c);
-                    for (int j = 1; j < row; ++j) a = __builtin_fma(tab->A[row][j], K(j, c), a);
-                    g[c] = __builtin_fma(dt, a, u_n[c]);
+                    real a = tab->A[row][0] * K(0, c);
+                    for (int j = 1; j < row; ++j) a = rfma(tab->A[row][j], K(j, c), a);
+                    g[c] = rfma(dt, a, u_n[c]);
                     kbrow[c] = KB(row, c);
                 });
                 stage_vjp(g, kbrow, w);
                 static_for<0, NR>([&](auto c) {
-                    for (int j = 0; j < row; ++j) KB(j, c) = __builtin_fma(dt * tab->A[row][j], w[c], KB(j, c));
+                    for (int j = 0; j < row; ++j) KB(j, c) = rfma(dt * tab->A[row][j], w[c], KB(j, c));
                 });
             }
             // (6) stage 0: k_0 = f(u_n); FSAL: it is the previous step's last stage -- hand kbar_0 over
             if (Tab::FSAL && st > 0) {
                 static_for<0, NR>([&](auto c) { carry[c] = KB(0, c); });
             } else {
-                double kbrow[NR], w[NR];
+                real kbrow[NR], w[NR];
                 static_for<0, NR>([&](auto c) { kbrow[c] = KB(0, c); });
                 stage_vjp(u_n, kbrow, w);
             }
@@ -1221,7 +1233,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         if (p.grad_u0)
             static_for<0, NR>([&](auto c) { if (cwrite(c)) p.grad_u0[(size_t)gid * n + comp(c)] = ubar[c]; });
         if constexpr (SG) {
-            double* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
+            real* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
             static_for<0, NSL>([&](auto c) {
                 const int idx = Model::slot_index(p.mc, r, c);
                 if (idx >= 0) row[idx] = acc[c];
@@ -1233,13 +1245,13 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     // ---- per-wave partial gradient row (fixed order) ----
     __syncthreads();
     const int64_t wave = part_row<G, BLOCK>();
-    double* row = p.grad_part + (size_t)wave * p.n_param;
+    real* row = p.grad_part + (size_t)wave * p.n_param;
     if constexpr (!SG) {
         if ((int)threadIdx.x < G) {
             for (int s = 0; s < NSL; ++s) {
                 const int idx = Model::slot_index(p.mc, (int)threadIdx.x, s);
                 if (idx >= 0) {
-                    double a = 0.0;
+                    real a = 0.0;
                     for (int gq = 0; gq < GROUPS; ++gq) a += slots[s * BLOCK + gq * G + (int)threadIdx.x];
                     row[idx] = a;
                 }

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ude_real.h"
+
 namespace ude {
 
 // ---------------------------------------------------------------------------------------------
@@ -165,20 +167,27 @@ __device__ __forceinline__ double dpow(double x, double y) { return dexp(y * dlo
 // ---------------------------------------------------------------------------------------------
 enum { ACT_IDENTITY = 0, ACT_TANH = 1, ACT_RBF = 2, ACT_RELU = 3 };
 
+// elementary functions on `real`: the double kernels above rounded once (Float64: the kernels themselves)
+__device__ __forceinline__ real rexp(real x) { return (real)dexp((double)x); }
+__device__ __forceinline__ real rtanh(real x) { return (real)dtanh((double)x); }
+__device__ __forceinline__ real rlog10(real x) { return (real)dlog10((double)x); }
+__device__ __forceinline__ real rpow10(real x) { return (real)dpow10((double)x); }
+__device__ __forceinline__ real rpow(real x, real y) { return (real)dpow((double)x, (double)y); }
+
 template <int ACT>
-__device__ __forceinline__ double act_fwd(double z) {
-    if constexpr (ACT == ACT_TANH) return dtanh(z);
-    else if constexpr (ACT == ACT_RBF) return dexp(-(z * z));
-    else if constexpr (ACT == ACT_RELU) return z > 0.0 ? z : 0.0;
+__device__ __forceinline__ real act_fwd(real z) {
+    if constexpr (ACT == ACT_TANH) return rtanh(z);
+    else if constexpr (ACT == ACT_RBF) return rexp(-(z * z));
+    else if constexpr (ACT == ACT_RELU) return z > real(0) ? z : real(0);
     else return z;
 }
 // derivative from the pre-activation z and the activation value a
 template <int ACT>
-__device__ __forceinline__ double act_bwd(double z, double a) {
-    if constexpr (ACT == ACT_TANH) return __builtin_fma(-a, a, 1.0);
-    else if constexpr (ACT == ACT_RBF) return (-2.0 * z) * a;
-    else if constexpr (ACT == ACT_RELU) return z > 0.0 ? 1.0 : 0.0;
-    else return 1.0;
+__device__ __forceinline__ real act_bwd(real z, real a) {
+    if constexpr (ACT == ACT_TANH) return rfma(-a, a, real(1));
+    else if constexpr (ACT == ACT_RBF) return (real(-2) * z) * a;
+    else if constexpr (ACT == ACT_RELU) return z > real(0) ? real(1) : real(0);
+    else return real(1);
 }
 
 // compile-time loop with integral-constant index

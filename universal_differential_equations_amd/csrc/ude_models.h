@@ -21,7 +21,7 @@ struct ModelConsts {
 // default: theta is copied linearly into LDS
 struct LinearTheta {
     static __host__ __device__ constexpr int theta_lds(int np) { return (np + 1) & ~1; }
-    static __device__ __forceinline__ void stage_theta(double* th, const double* theta, int np, int tid, int nthreads) {
+    static __device__ __forceinline__ void stage_theta(real* th, const real* theta, int np, int tid, int nthreads) {
         for (int i = tid; i < np; i += nthreads) th[i] = theta[i];
     }
     static constexpr int SCRATCH = 0;
@@ -42,26 +42,26 @@ struct LvTrue : LinearTheta {
     static constexpr int NS = 2, NSL = 4, NTHETA_LDS = 4;
     static constexpr bool STATE_DISTRIBUTED = false;
     struct Ctx {
-        const double* th;
+        const real* th;
         int r;
     };
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double*, double*, int, const ModelConsts&, int r, const double* = nullptr) {
+    static __device__ __forceinline__ void init(Ctx& c, real* th_lds, real*, real*, int, const ModelConsts&, int r, const real* = nullptr) {
         c.th = th_lds;
         c.r = r;
     }
-    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
-        const double a = c.th[0], b = c.th[1], g = c.th[2], d = c.th[3];
+    static __device__ __forceinline__ void rhs(const Ctx& c, const real* u, real* du) {
+        const real a = c.th[0], b = c.th[1], g = c.th[2], d = c.th[3];
         du[0] = a * u[0] - b * u[1] * u[0];
         du[1] = g * u[0] * u[1] - d * u[1];
     }
     template <bool WANT_PARAM>
-    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam,
-                                               double* g) {
-        const double a = c.th[0], b = c.th[1], gm = c.th[2], d = c.th[3];
+    static __device__ __forceinline__ void vjp(const Ctx& c, const real* u, const real* lam, real* dlam,
+                                               real* g) {
+        const real a = c.th[0], b = c.th[1], gm = c.th[2], d = c.th[3];
         dlam[0] = (a - b * u[1]) * lam[0] + (gm * u[1]) * lam[1];
         dlam[1] = (-b * u[0]) * lam[0] + (gm * u[0] - d) * lam[1];
         if constexpr (WANT_PARAM) {
-            const double on = c.r == 0 ? 1.0 : 0.0;
+            const real on = c.r == 0 ? 1.0 : 0.0;
             g[0] = on * (u[0] * lam[0]);
             g[1] = on * (-u[1] * u[0] * lam[0]);
             g[2] = on * (u[0] * u[1] * lam[1]);
@@ -88,41 +88,41 @@ struct LvUde : LinearTheta {
     // weights in registers when the lane's share is small (narrow layers spread over >= 5 lanes), else read from LDS
     static constexpr bool REGW = (G >= 5) && (Net::maxdim() <= 8);
     struct Ctx {
-        const double* th;   // full theta (LDS)
-        const double* nn;   // th + nn_offset
-        double lin[2];
-        double lead_on[2];  // sign if this lane owns a trainable diagonal coefficient, else 0
+        const real* th;   // full theta (LDS)
+        const real* nn;   // th + nn_offset
+        real lin[2];
+        real lead_on[2];  // sign if this lane owns a trainable diagonal coefficient, else 0
         int r;
         typename Mlp::lds_t* gb;  // LDS gather row of this lane group (non-power-of-two groups)
         typename Mlp::WReg w;  // (unused members are never materialised when REGW is false)
     };
     static constexpr int SCRATCH = 64;  // one gather word per lane (LV blocks are one wavefront; every LDS byte counts: 4 blocks per CU)
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
+    static __device__ __forceinline__ void init(Ctx& c, real* th_lds, real* scratch, real*, int, const ModelConsts& mc, int r, const real* = nullptr) {
         c.gb = (typename Mlp::lds_t*)scratch + (threadIdx.x - r);
         c.th = th_lds;
         c.nn = th_lds + mc.nn_offset;
         c.r = r;
         for (int i = 0; i < 2; ++i) {
-            c.lin[i] = mc.lin_idx[i] >= 0 ? mc.lin_sign[i] * th_lds[mc.lin_idx[i]] : mc.lin_const[i];
-            c.lead_on[i] = (mc.lin_idx[i] >= 0 && r == 0) ? mc.lin_sign[i] : 0.0;
+            c.lin[i] = mc.lin_idx[i] >= 0 ? (real)mc.lin_sign[i] * th_lds[mc.lin_idx[i]] : (real)mc.lin_const[i];
+            c.lead_on[i] = (mc.lin_idx[i] >= 0 && r == 0) ? (real)mc.lin_sign[i] : real(0);
         }
         if constexpr (REGW) Mlp::load_weights(c.nn, r, c.w);
     }
-    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
+    static __device__ __forceinline__ void rhs(const Ctx& c, const real* u, real* du) {
         typename Mlp::Cache cache;
         cache.gb = c.gb;
-        double y[2];
+        real y[2];
         if constexpr (REGW) Mlp::forward(c.w, c.r, u, cache, y);
         else Mlp::forward(c.nn, c.r, u, cache, y);
-        du[0] = __builtin_fma(c.lin[0], u[0], y[0]);
-        du[1] = __builtin_fma(c.lin[1], u[1], y[1]);
+        du[0] = rfma(c.lin[0], u[0], y[0]);
+        du[1] = rfma(c.lin[1], u[1], y[1]);
     }
     template <bool WANT_PARAM>
-    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam,
-                                               double* g) {
+    static __device__ __forceinline__ void vjp(const Ctx& c, const real* u, const real* lam, real* dlam,
+                                               real* g) {
         typename Mlp::Cache cache;
         cache.gb = c.gb;
-        double y[2], gx[2];
+        real y[2], gx[2];
         if constexpr (REGW) {
             Mlp::forward(c.w, c.r, u, cache, y);
             Mlp::template vjp<WANT_PARAM>(c.w, c.r, cache, lam, gx, g);
@@ -130,8 +130,8 @@ struct LvUde : LinearTheta {
             Mlp::forward(c.nn, c.r, u, cache, y);
             Mlp::template vjp<WANT_PARAM>(c.nn, c.r, cache, lam, gx, g);
         }
-        dlam[0] = __builtin_fma(c.lin[0], lam[0], gx[0]);
-        dlam[1] = __builtin_fma(c.lin[1], lam[1], gx[1]);
+        dlam[0] = rfma(c.lin[0], lam[0], gx[0]);
+        dlam[1] = rfma(c.lin[1], lam[1], gx[1]);
         if constexpr (WANT_PARAM && NLIN == 2) {
             g[Mlp::NSLOT + 0] = (c.lead_on[0] * u[0]) * lam[0];
             g[Mlp::NSLOT + 1] = (c.lead_on[1] * u[1]) * lam[1];
@@ -147,6 +147,7 @@ struct LvUde : LinearTheta {
     }
 };
 
+#ifndef UDE_F32  // Float64-only models (no Float32 problem of the reference uses them): absent from -DUDE_F32 translation units
 // ---------------------------------------------------------------------------------------------
 // corona!  (SEIR_exposure/seir_exposure.jl:16-30): mechanistic 7-state model, consts = p_[0..8] =
 // F, beta0, alpha, kappa, mu, sigma, gamma, d, lambda.  No trainable parameters (data generation).
@@ -287,7 +288,7 @@ struct SeirUde {
                 double acc = 0.0;
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = b * 16 + ic;
-                    const double x = readlane_f64(v, c.w * KB + i);
+                    const double x = readlane_real(v, c.w * KB + i);
                     if (vk) vk[i] = x;
                     acc = __builtin_fma(TRANSPOSED ? c.w2col[i] : c.w2row[i], x, acc);
                 });
@@ -394,7 +395,7 @@ struct SeirUde {
             ab[s] = __builtin_fma(bs, -gpos, ab[s]);
             if constexpr (WANT_E) ae[s] = __builtin_fma(es, -gpos, ae[s]);
         };
-        static_for<0, H>([&](auto k) { upd(k, q.d2 * readlane_f64(q.a1, decltype(k)::value)); });
+        static_for<0, H>([&](auto k) { upd(k, q.d2 * readlane_real(q.a1, decltype(k)::value)); });
         static_for<0, NEXTRA>([&](auto e) { upd(std::integral_constant<int, H + decltype(e)::value>{}, extra_value(c, q, decltype(e)::value)); });
     }
     // ---- deferred parameter cotangent (ONE) ----
@@ -486,7 +487,7 @@ struct SeirUde {
         Fac f;
         load_factors<NST, MASK>(c, f);
         double bb[NST], bt[NST];  // tableau weights as scalars (one load per step, not per slot)
-        static_for<0, NST>([&](auto s) { bb[s] = uniform_f64(B[s]); bt[s] = uniform_f64(BT[s]); });
+        static_for<0, NST>([&](auto s) { bb[s] = uniform_real(B[s]); bt[s] = uniform_real(BT[s]); });
         double ps = 0.0;
         for_each_slot<NST, MASK>(c, f, mu, ms, [&](int slot, const double* g, double m0) {
             double ab = bb[0] * g[0], ae = bt[0] * g[0];
@@ -534,6 +535,8 @@ struct SeirUde {
     }
 };
 
+#endif  // UDE_F32
+
 // ---------------------------------------------------------------------------------------------
 // Fisher-KPP (FisherKPP/Fisher-KPP-CNN.jl, LotkaVolterra/scenario_3.jl): 1-D reaction-diffusion on a periodic
 // grid of n_state points.  The STATE is distributed: point i = c*G + r lives on lane r (register slot c);
@@ -547,16 +550,16 @@ struct KppTrue : LinearTheta {
     static constexpr bool STATE_DISTRIBUTED = true;
     static constexpr int SCRATCH = G * PPL + 2;
     struct Ctx {
-        double* row;
-        double coff, cdiag, rr;
+        real* row;
+        real coff, cdiag, rr;
         int r, n;
     };
-    static __device__ __forceinline__ void init(Ctx& c, double*, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
+    static __device__ __forceinline__ void init(Ctx& c, real*, real* scratch, real*, int, const ModelConsts& mc, int r, const real* = nullptr) {
         c.row = scratch;
         c.coff = mc.consts[0]; c.cdiag = mc.consts[1]; c.rr = mc.consts[2];
         c.r = r; c.n = mc.n_state;
     }
-    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
+    static __device__ __forceinline__ void rhs(const Ctx& c, const real* u, real* du) {
         const int n = c.n;
         __syncthreads();
         static_for<0, PPL>([&](auto cc) { const int i = cc * G + c.r; if (i < n) c.row[i] = u[cc]; });
@@ -566,7 +569,7 @@ struct KppTrue : LinearTheta {
             if (i < n) {
                 const int im = (i + n - 1) % n, ip = (i + 1) % n;
                 // dense mat-vec row: the three nonzeros in ascending column order (oracle: same order)
-                double acc = 0.0;
+                real acc = 0.0;
                 if (i == 0) {
                     acc += c.cdiag * c.row[i]; acc += c.coff * c.row[ip]; acc += c.coff * c.row[im];
                 } else if (i == n - 1) {
@@ -574,14 +577,14 @@ struct KppTrue : LinearTheta {
                 } else {
                     acc += c.coff * c.row[im]; acc += c.cdiag * c.row[i]; acc += c.coff * c.row[ip];
                 }
-                du[cc] = acc + (c.rr * u[cc]) * (1.0 - u[cc]);
+                du[cc] = acc + (c.rr * u[cc]) * (real(1) - u[cc]);
             } else {
                 du[cc] = 0.0;
             }
         });
     }
     template <bool WANT_PARAM>
-    static __device__ __forceinline__ void vjp(const Ctx&, const double*, const double*, double*, double*) {}
+    static __device__ __forceinline__ void vjp(const Ctx&, const real*, const real*, real*, real*) {}
     static __device__ __forceinline__ int slot_index(const ModelConsts&, int, int) { return -1; }
 };
 
@@ -609,15 +612,15 @@ struct KppUde : LinearTheta {
     static constexpr int RA = rows_a() | 1, RD = rows_d() | 1;                // odd row strides of the [point][row] tiles
     static constexpr int SCRATCH = 2 * NPT + 4 + (RA + RD) * G;               // u row, lambda row, A tile, D tile
     struct Ctx {
-        const double* th;
-        const double* nn;
-        double *urow, *lrow, *A, *Dt;
-        double w1, w2, w3, D0;
+        const real* th;
+        const real* nn;
+        real *urow, *lrow, *A, *Dt;
+        real w1, w2, w3, D0;
         int r, n, so, d0o, nno;
         int a_row[NSL], d_row[NSL];  // per owned parameter: LDS row of its a factor (-1: bias) and of its delta (-1: not NN)
         int kind[NSL];               // 0 NN weight/bias, 1 w1, 2 w2, 3 w3, 4 D0, -1 padding / unused slot
     };
-    static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
+    static __device__ __forceinline__ void init(Ctx& c, real* th_lds, real* scratch, real*, int, const ModelConsts& mc, int r, const real* = nullptr) {
         c.th = th_lds;
         c.nn = th_lds + mc.nn_offset;
         c.urow = scratch; c.lrow = scratch + NPT + 2; c.A = scratch + 2 * NPT + 4; c.Dt = c.A + RA * G;
@@ -646,28 +649,28 @@ struct KppUde : LinearTheta {
             }
         }
     }
-    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
+    static __device__ __forceinline__ void rhs(const Ctx& c, const real* u, real* du) {
         const int n = c.n;
         __syncthreads();
         static_for<0, PPL>([&](auto cc) { const int i = cc * G + c.r; if (i < n) c.urow[i] = u[cc]; });
         __syncthreads();
         for (int cc = 0; cc < PPL; ++cc) {
             const int i = cc * G + c.r;
-            double out = 0.0;
+            real out = 0.0;
             if (i < n) {
                 const int im = (i + n - 1) % n, ip = (i + 1) % n;
                 typename Mlp::Cache cache;
-                double y[1];
-                const double ui = c.urow[i];
+                real y[1];
+                const real ui = c.urow[i];
                 Mlp::forward(c.nn, 0, &ui, cache, y);
-                const double cnn = c.w1 * c.urow[im] + c.w2 * ui + c.w3 * c.urow[ip];
+                const real cnn = c.w1 * c.urow[im] + c.w2 * ui + c.w3 * c.urow[ip];
                 out = y[0] + c.D0 * cnn;
             }
             du[cc] = out;
         }
     }
     template <bool WANT_PARAM>
-    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam, double* g) {
+    static __device__ __forceinline__ void vjp(const Ctx& c, const real* u, const real* lam, real* dlam, real* g) {
         const int n = c.n;
         __syncthreads();
         static_for<0, PPL>([&](auto cc) {
@@ -677,22 +680,22 @@ struct KppUde : LinearTheta {
         __syncthreads();
         // ARITH-SPEC: fused chains over blocks of 256 consecutive points, block sums added left to right
         static_assert(256 % G == 0, "a 256-point block is a whole number of tiles");
-        double acc[NSL], tot[NSL];
+        real acc[NSL], tot[NSL];
         static_for<0, NSL>([&](auto m) { acc[m] = 0.0; tot[m] = 0.0; });
         for (int cc = 0; cc < PPL; ++cc) {  // tile cc = points cc*G .. cc*G + G-1 (ascending)
             const int i = cc * G + c.r;
-            double gxi = 0.0;
+            real gxi = 0.0;
             if (i < n) {
                 typename Mlp::Cache cache;
-                double y[1], gx[1];
-                const double ui = c.urow[i], li = c.lrow[i];
+                real y[1], gx[1];
+                const real ui = c.urow[i], li = c.lrow[i];
                 Mlp::forward(c.nn, 0, &ui, cache, y);
                 static_for<0, L>([&](auto lc) {
                     constexpr int l = lc;
                     static_for<0, Net::dim(l)>([&](auto k) { c.A[c.r * RA + (a_off(l) + k)] = cache.a[l][k]; });
                 });
-                Mlp::template vjp_sink<false>(c.nn, 0, cache, &li, gx, (double*)nullptr,
-                                              [&](int l, int m, double d) { c.Dt[c.r * RD + (d_off_rt(l) + m)] = d; });
+                Mlp::template vjp_sink<false>(c.nn, 0, cache, &li, gx, (real*)nullptr,
+                                              [&](int l, int m, real d) { c.Dt[c.r * RD + (d_off_rt(l) + m)] = d; });
                 gxi = gx[0];
             }
             // transpose of the periodic stencil (the oracle's expression)
@@ -710,10 +713,10 @@ struct KppUde : LinearTheta {
                     if (c.kind[m] == 0) {
                         // tiles are [point][row] (row stride odd): the owners of different parameters read different
                         // banks of the same point's row block -- no bank conflicts in this (dominant) loop
-                        const double* dr = c.Dt + c.d_row[m];
+                        const real* dr = c.Dt + c.d_row[m];
                         if (c.a_row[m] >= 0) {
-                            const double* ar = c.A + c.a_row[m];
-                            for (int q = 0; q < npts; ++q) acc[m] = __builtin_fma(dr[q * RD], ar[q * RA], acc[m]);  // ARITH-SPEC: fused chain
+                            const real* ar = c.A + c.a_row[m];
+                            for (int q = 0; q < npts; ++q) acc[m] = rfma(dr[q * RD], ar[q * RA], acc[m]);  // ARITH-SPEC: fused chain
                         } else {
                             for (int q = 0; q < npts; ++q) acc[m] += dr[q * RD];
                         }
@@ -735,14 +738,14 @@ struct KppUde : LinearTheta {
                 constexpr int m = mc;
                 const int kd = c.kind[m];
                 if (kd >= 1) {
-                    double s = 0.0, st = 0.0;
+                    real s = 0.0, st = 0.0;
                     for (int i = 0; i < n; ++i) {
                         if (i > 0 && i % 256 == 0) { st = i == 256 ? s : st + s; s = 0.0; }
                         const int im = (i + n - 1) % n, ip = (i + 1) % n;
-                        if (kd == 1) s = __builtin_fma(c.lrow[i], c.urow[im], s);
-                        else if (kd == 2) s = __builtin_fma(c.lrow[i], c.urow[i], s);
-                        else if (kd == 3) s = __builtin_fma(c.lrow[i], c.urow[ip], s);
-                        else s = __builtin_fma(c.lrow[i], c.w1 * c.urow[im] + c.w2 * c.urow[i] + c.w3 * c.urow[ip], s);
+                        if (kd == 1) s = rfma(c.lrow[i], c.urow[im], s);
+                        else if (kd == 2) s = rfma(c.lrow[i], c.urow[i], s);
+                        else if (kd == 3) s = rfma(c.lrow[i], c.urow[ip], s);
+                        else s = rfma(c.lrow[i], c.w1 * c.urow[im] + c.w2 * c.urow[i] + c.w3 * c.urow[ip], s);
                     }
                     s = n > 256 ? st + s : s;
                     acc[m] = kd == 4 ? s : c.D0 * s;
@@ -762,6 +765,7 @@ struct KppUde : LinearTheta {
 };
 
 
+#ifndef UDE_F32  // (FP64 matrix-core kernel: Float64 only)
 // ---------------------------------------------------------------------------------------------
 // nn_ode on LARGE grids (BASELINE configs[3]: 1024 points): one trajectory per block of 4 wavefronts, the pointwise
 // network AND its parameter contraction on the FP64 matrix cores.
@@ -1076,5 +1080,7 @@ struct KppUdeW : LinearTheta {
         return p;
     }
 };
+
+#endif  // UDE_F32
 
 }  // namespace ude

@@ -15,17 +15,18 @@ struct Launch {
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
     int theta_lds, scratch, k_doubles, k_doubles_d, slots_reg;
     bool dadj_k_dense;  // the reverse sweep reads k from the dense store (HBM) instead of an LDS copy
-    int slot_glob;  // > 0: slot state in HBM, this many doubles per thread (SLOTS_GLOBAL models)
+    int slot_glob;  // > 0: slot state in HBM, this many elements per thread (SLOTS_GLOBAL models)
+    int elem;       // bytes of the instance's scalar type (8: Float64, 4: Float32)
     size_t lds_bytes(int np, bool adjoint, bool discrete = false) const {
         const size_t np_pad = (size_t)((np + 1) & ~1);
         size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + scratch + k_doubles;
         if (discrete) d += (dadj_k_dense ? 1 : 2) * (size_t)k_doubles_d - k_doubles;  // [k and] kbar in the reverse sweep's own layout
         if (adjoint) d += (size_t)slots_reg;
-        return d * sizeof(double) + 16;
+        return d * (size_t)elem + 16;
     }
 };
 
-template <class Model, class Tab, int G, int BLOCK = 64, int VAR = 1>
+template <class Model, class Tab, int G, int BLOCK = 64, int VAR = 1, class RTag = real>
 inline Launch make_launch() {
     Launch l;
     l.fwd = fwd_kernel<Model, Tab, G, BLOCK>;
@@ -45,6 +46,7 @@ inline Launch make_launch() {
     l.dadj_k_dense = Model::DADJ_K_FROM_DENSE;
     l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : (Tab::FSAL ? 3 : 2) * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
     l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL : 0;
+    l.elem = (int)sizeof(real);
     return l;
 }
 
@@ -55,7 +57,9 @@ using NetTanh32 = NetCfg<IntList<2, 32, 2>, IntList<ACT_TANH, ACT_IDENTITY>>;   
 
 enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, MID_SEIR_TRUE, MID_SEIR_UDE,
        MID_KPP_TRUE_32, MID_KPP_TRUE_1024, MID_KPP_UDE_32, MID_KPP_UDE_1024, MID_KPP_S3_32, MID_KPP_SMALL_32,
-       MID_LV_S1N /* scenario_1's chain with CONSTANT diagonal coefficients: no slots for them */ };
+       MID_LV_S1N /* scenario_1's chain with CONSTANT diagonal coefficients: no slots for them */,
+       // Float32 problems (ude_model_desc.dtype = 1): hudson_bay.jl:77-104, scenario_3.jl:26-57 (true Fisher-KPP) and :83-126 (its UDE)
+       MID_LV_HUDSON_F32, MID_KPP_TRUE_32_F32, MID_KPP_S3_32_F32 };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88

@@ -3,6 +3,7 @@
 // Stage convention: k[0] = f(uprev); k[s] = f(uprev + dt * sum_{j<s} A(s,j) k[j]) for s = 1..S-1;
 // u_new = uprev + dt * sum_j B(j) k[j]; err = dt * sum_j BT(j) k[j].
 #pragma once
+#include "ude_real.h"
 #include "ude_tableaux_gen.h"
 
 namespace ude {
@@ -34,11 +35,12 @@ struct Tsit5Tab {  // Tsit5(): LotkaVolterra/scenario_1.jl:191,202,206; FisherKP
     static constexpr double AE(int, int) { return 0; }
     static constexpr double CE(int) { return 0; }
     // dense-output weights b_j(theta), j = 0..6 (free 4th-order interpolant)
-    static __device__ __forceinline__ void bth(double th, double* b) {
-        // ARITH-SPEC: Horner with fma (upstream @evalpoly uses muladd)
-#define H3_(p) (th2 * __builtin_fma(th, __builtin_fma(th, T_(p##4), T_(p##3)), T_(p##2)))
-        const double th2 = th * th;
-        b[0] = th * __builtin_fma(th, __builtin_fma(th, __builtin_fma(th, T_(r14), T_(r13)), T_(r12)), T_(r11));
+    static __device__ __forceinline__ void bth(real th, real* b) {
+        // ARITH-SPEC: Horner with fma (upstream @evalpoly uses muladd); coefficients rounded to `real` (the Float32
+        // tableaux upstream are the rounded Float64 ones)
+#define H3_(p) (th2 * rfma(th, rfma(th, (real)T_(p##4), (real)T_(p##3)), (real)T_(p##2)))
+        const real th2 = th * th;
+        b[0] = th * rfma(th, rfma(th, rfma(th, (real)T_(r14), (real)T_(r13)), (real)T_(r12)), (real)T_(r11));
         b[1] = H3_(r2);
         b[2] = H3_(r3);
         b[3] = H3_(r4);
@@ -107,15 +109,17 @@ struct Vern7Tab {  // Vern7(): scenario_1.jl:41,84; SEIR_exposure/seir_exposure.
         constexpr double c[6] = {V_(c11), V_(c12), V_(c13), V_(c14), V_(c15), V_(c16)};
         return c[e];
     }
-#define F_ __builtin_fma
-#define P6_(p) (th2 * F_(th, F_(th, F_(th, F_(th, F_(th, V_(p##7), V_(p##6)), V_(p##5)), V_(p##4)), V_(p##3)), V_(p##2)))
-    static __device__ __forceinline__ void bth(double th, double* b) {
-        const double th2 = th * th;
-        b[0] = th * F_(th, F_(th, F_(th, F_(th, F_(th, F_(th, V_(r017), V_(r016)), V_(r015)), V_(r014)), V_(r013)), V_(r012)), V_(r011));
+#define F_ rfma
+#define W_(x) ((real)V_(x))
+#define P6_(p) (th2 * F_(th, F_(th, F_(th, F_(th, F_(th, W_(p##7), W_(p##6)), W_(p##5)), W_(p##4)), W_(p##3)), W_(p##2)))
+    static __device__ __forceinline__ void bth(real th, real* b) {
+        const real th2 = th * th;
+        b[0] = th * F_(th, F_(th, F_(th, F_(th, F_(th, F_(th, W_(r017), W_(r016)), W_(r015)), W_(r014)), W_(r013)), W_(r012)), W_(r011));
         b[1] = 0; b[2] = 0; b[9] = 0;
         b[3] = P6_(r04); b[4] = P6_(r05); b[5] = P6_(r06); b[6] = P6_(r07); b[7] = P6_(r08); b[8] = P6_(r09);
         b[10] = P6_(r11); b[11] = P6_(r12); b[12] = P6_(r13); b[13] = P6_(r14); b[14] = P6_(r15); b[15] = P6_(r16);
     }
+#undef W_
 #undef P6_
 #undef F_
     static constexpr bool dense_uses(int j) { return !(j == 1 || j == 2 || j == 9); }

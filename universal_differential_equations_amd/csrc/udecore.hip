@@ -13,40 +13,43 @@
 using namespace ude;
 
 namespace ude {
-// out[i] = sum_w part[w][i]: one block per column, fixed strided partial sums + fixed LDS tree
-// (deterministic for a given launch shape; the order is independent of timing)
-__global__ void reduce_rows_kernel(const double* part, int64_t nrows, int32_t ncols, double* out) {
+// out[i] = sum_w part[w][i]: one block per column, fixed strided partial sums + fixed LDS tree (accumulated in double for
+// both scalar types; deterministic for a given launch shape; the order is independent of timing)
+template <class T>
+__global__ void reduce_rows_kernel(const T* part, int64_t nrows, int32_t ncols, T* out) {
     __shared__ double sh[256];
     const int i = blockIdx.x;
     double s = 0.0;
-    for (int64_t w = threadIdx.x; w < nrows; w += 256) s += part[(size_t)w * ncols + i];
+    for (int64_t w = threadIdx.x; w < nrows; w += 256) s += (double)part[(size_t)w * ncols + i];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int m = 128; m > 0; m >>= 1) {
         if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[i] = sh[0];
+    if (threadIdx.x == 0) out[i] = (T)sh[0];
 }
 
 // total = sum_j v[j], fixed tree
-__global__ void reduce_sum_kernel(const double* v, int64_t n, double* out) {
+template <class T>
+__global__ void reduce_sum_kernel(const T* v, int64_t n, T* out) {
     __shared__ double sh[256];
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)v[i];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int m = 128; m > 0; m >>= 1) {
         if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = sh[0];
+    if (threadIdx.x == 0) out[0] = (T)sh[0];
 }
 
 // A trajectory whose retcode is not Success contributes nothing to the gradient; the reference would see an Inf loss
 // (or an error) from such a solve, so the ensemble loss becomes +Inf and the count of failed trajectories is
 // published -- an optimiser never silently trains on a partial objective.
-__global__ void finalize_kernel(const int32_t* retcode, int64_t n, double* loss, int32_t* nfail_out) {
+template <class T>
+__global__ void finalize_kernel(const int32_t* retcode, int64_t n, T* loss, int32_t* nfail_out) {
     __shared__ int sh[256];
     int c = 0;
     for (int64_t i = threadIdx.x; i < n; i += 256) c += retcode[i] != 0;
@@ -58,7 +61,7 @@ __global__ void finalize_kernel(const int32_t* retcode, int64_t n, double* loss,
     }
     if (threadIdx.x == 0) {
         if (nfail_out) *nfail_out = sh[0];
-        if (sh[0] > 0 && loss) *loss = __builtin_inf();
+        if (sh[0] > 0 && loss) *loss = (T)__builtin_inf();
     }
 }
 
@@ -124,6 +127,17 @@ static bool dims_are(const ude_model_desc* m, std::initializer_list<int> d, std:
 }
 
 static int model_id(const ude_model_desc* m) {
+    if (m->dtype == 1) {  // Float32 problems: hudson_bay.jl:77-104, scenario_3.jl:26-57 and :83-126
+        if (m->kind == UDE_KIND_LV_UDE && m->n_state == 2 &&
+            dims_are(m, {2, 5, 5, 5, 2}, {ACT_RBF, ACT_RBF, ACT_TANH, ACT_IDENTITY}))
+            return MID_LV_HUDSON_F32;
+        if (m->kind == UDE_KIND_KPP_TRUE && m->n_param == 0 && m->n_state >= 3 && m->n_state <= 32) return MID_KPP_TRUE_32_F32;
+        if (m->kind == UDE_KIND_KPP_UDE && m->nn_offset == 0 && m->n_state >= 3 && m->n_state <= 32 &&
+            dims_are(m, {1, 5, 5, 5, 1}, {ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY}) && m->n_param == 81 && m->stencil_offset == 76 &&
+            m->d0_offset == 80)
+            return MID_KPP_S3_32_F32;
+        return MID_NONE;
+    }
     if (m->dtype != 0) return MID_NONE;
     if (m->kind == UDE_KIND_LV_TRUE && m->n_state == 2 && m->n_param == 4) return MID_LV_TRUE;
     if (m->kind == UDE_KIND_LV_UDE && m->n_state == 2) {
@@ -155,14 +169,17 @@ static int default_lanes(int mid, bool discrete) {
     switch (mid) {
         case MID_LV_TRUE: return 1;
         case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
-        case MID_LV_HUDSON: return 8;
+        case MID_LV_HUDSON:
+        case MID_LV_HUDSON_F32: return 8;
         case MID_LV_TANH32: return 8;  // (32 lanes = 5000 wavefronts = five rounds for 10k trajectories: 16.5 ms vs 7.6 ms per gradient)
         case MID_SEIR_TRUE: return 1;
         case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32:
-        case MID_KPP_SMALL_32: return 32;
+        case MID_KPP_SMALL_32:
+        case MID_KPP_TRUE_32_F32:
+        case MID_KPP_S3_32_F32: return 32;
         case MID_KPP_TRUE_1024: return 64;
         case MID_KPP_UDE_1024: return 256;  // 4 wavefronts per PDE
     }
@@ -190,6 +207,14 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
     }
     if (!ok) return fail(c, UDE_ERR_UNSUPPORTED, "no kernel instance for model %d alg %d lanes_per_traj %d waves_per_simd %d", mid, o->alg, G, W);
     return UDE_OK;
+}
+
+// the algorithm's tableau in the problem's scalar type (the kernels of a Float32 instance read it as TabDevT<float>)
+static const TabDev* tab_for(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o) {
+    const int a = o->alg == UDE_ALG_VERN7 ? 1 : 0;
+    const char* base = (const char*)c->tabs.p;
+    if (m->dtype == 1) return (const TabDev*)(base + 2 * sizeof(TabDevT<double>) + a * sizeof(TabDevT<float>));
+    return (const TabDev*)(base + a * sizeof(TabDevT<double>));
 }
 
 static void fill_params(KParams& p, const ude_model_desc* m, const ude_solve_opts* o, double t0, double tf) {
@@ -240,9 +265,10 @@ extern "C" int ude_create(int32_t device_id, ude_ctx** out) {
     bool ok = hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming) == hipSuccess;
     for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (ok) {   // tableaux in device memory: [0] Tsit5, [1] Vern7
-        TabDev host[2] = {make_tabdev<Tsit5Tab>(), make_tabdev<Vern7Tab>()};
+        struct { TabDevT<double> d[2]; TabDevT<float> f[2]; } host = {{make_tabdev<Tsit5Tab, double>(), make_tabdev<Vern7Tab, double>()},
+                                                                      {make_tabdev<Tsit5Tab, float>(), make_tabdev<Vern7Tab, float>()}};
         ok = hipMalloc(&c->tabs.p, sizeof host) == hipSuccess &&
-             hipMemcpy(c->tabs.p, host, sizeof host, hipMemcpyHostToDevice) == hipSuccess;
+             hipMemcpy(c->tabs.p, &host, sizeof host, hipMemcpyHostToDevice) == hipSuccess;
         c->tabs.cap = sizeof host;
     }
     if (!ok) {  // release whatever was created
@@ -395,7 +421,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
-    p.tab = (const TabDev*)c->tabs.p + (o->alg == UDE_ALG_VERN7 ? 1 : 0);
+    p.tab = tab_for(c, m, o);
     if (c->trace_cap > 0) { p.trace = (double*)c->trace.p; p.trace_traj = c->trace_traj; p.trace_cap = c->trace_cap; }
     p.N = N;
     p.Npad = N;
@@ -443,9 +469,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
-    p.tab = (const TabDev*)c->tabs.p + (o->alg == UDE_ALG_VERN7 ? 1 : 0);
+    p.tab = tab_for(c, m, o);
     if (c->trace_cap > 0) { p.trace = (double*)c->trace.p; p.trace_traj = c->trace_traj; p.trace_cap = c->trace_cap; }
     const int n = m->n_state, np = m->n_param;
+    const size_t es = m->dtype == 1 ? sizeof(float) : sizeof(double);  // bytes of the problem's scalar type
     const int cap = c->lo.max_dense_steps > 0 ? c->lo.max_dense_steps : c->auto_cap;
     const int BLOCK = l.block;
     const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
@@ -463,14 +490,14 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.data = cot_in ? nullptr : data;
     p.row_mask = row_mask;
     p.cot_in = cot_in;
-    if ((rc = ensure(c, c->dense, sizeof(double) * (size_t)cap * nf * p.Npad))) return rc;
+    if ((rc = ensure(c, c->dense, es * (size_t)cap * nf * p.Npad))) return rc;
     if ((rc = ensure(c, c->dense_n, sizeof(int32_t) * N))) return rc;
-    if ((rc = ensure(c, c->cot, sizeof(double) * (size_t)ns * n * p.Npad))) return rc;
-    if ((rc = ensure(c, c->loss_traj, sizeof(double) * N))) return rc;
-    if ((rc = ensure(c, c->grad_part, sizeof(double) * (size_t)nwaves * np))) return rc;
+    if ((rc = ensure(c, c->cot, es * (size_t)ns * n * p.Npad))) return rc;
+    if ((rc = ensure(c, c->loss_traj, es * N))) return rc;
+    if ((rc = ensure(c, c->grad_part, es * (size_t)nwaves * np))) return rc;
     p.slot_glob = nullptr;
     if (l.slot_glob > 0) {  // slot state mu of the adjoint in HBM: [slot][thread]
-        if ((rc = ensure(c, c->slot_glob, sizeof(double) * (size_t)l.slot_glob * grid * BLOCK))) return rc;
+        if ((rc = ensure(c, c->slot_glob, es * (size_t)l.slot_glob * grid * BLOCK))) return rc;
         p.slot_glob = (double*)c->slot_glob.p;
     }
     if (!retcode) {
@@ -504,7 +531,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         HIPCHK(c, hipFuncSetAttribute((const void*)bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
     if (shmem_f > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
-    HIPCHK(c, hipMemsetAsync(p.grad_part, 0, sizeof(double) * (size_t)nwaves * np, c->stream));
+    HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)nwaves * np, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
@@ -514,16 +541,20 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->ev_fwd = c->ev_bwd = true;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(np), dim3(256), 0, c->stream, (const double*)p.grad_part,
-                       nwaves, (int32_t)np, grad_theta);
-    HIPCHK(c, hipGetLastError());
-    if (loss && !cot_in) {
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)p.loss_traj, N, loss);
-        HIPCHK(c, hipGetLastError());
-    }
     if ((rc = ensure(c, c->nfail, sizeof(int32_t)))) return rc;
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, c->stream, (const int32_t*)retcode, N,
-                       (loss && !cot_in) ? loss : (double*)nullptr, (int32_t*)c->nfail.p);
+    double* lossp = (loss && !cot_in) ? loss : (double*)nullptr;
+    if (m->dtype == 1) {  // Float32 problem: every real-valued array behind these pointers is float
+        hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(np), dim3(256), 0, c->stream, (const float*)p.grad_part, nwaves, (int32_t)np,
+                           (float*)grad_theta);
+        if (lossp) hipLaunchKernelGGL(reduce_sum_kernel<float>, dim3(1), dim3(256), 0, c->stream, (const float*)p.loss_traj, N, (float*)lossp);
+        hipLaunchKernelGGL(finalize_kernel<float>, dim3(1), dim3(256), 0, c->stream, (const int32_t*)retcode, N, (float*)lossp,
+                           (int32_t*)c->nfail.p);
+    } else {
+        hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(np), dim3(256), 0, c->stream, (const double*)p.grad_part, nwaves, (int32_t)np,
+                           grad_theta);
+        if (lossp) hipLaunchKernelGGL(reduce_sum_kernel<double>, dim3(1), dim3(256), 0, c->stream, (const double*)p.loss_traj, N, lossp);
+        hipLaunchKernelGGL(finalize_kernel<double>, dim3(1), dim3(256), 0, c->stream, (const int32_t*)retcode, N, lossp, (int32_t*)c->nfail.p);
+    }
     HIPCHK(c, hipGetLastError());
     return UDE_OK;
 }
@@ -548,7 +579,7 @@ extern "C" int ude_rhs_ensemble_dev(ude_ctx* c, const ude_model_desc* m, int64_t
     KParams p{};
     const double tspan0 = 0.0;
     fill_params(p, m, &o, tspan0, 1.0);
-    p.tab = (const TabDev*)c->tabs.p;
+    p.tab = tab_for(c, m, &o);
     p.N = N;
     p.Npad = (N + 7) / 8 * 8;
     p.u0 = u;
@@ -616,18 +647,19 @@ extern "C" int ude_solve_ensemble(ude_ctx* c, const ude_model_desc* m, const ude
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = m->n_state;
+    const size_t es = m->dtype == 1 ? sizeof(float) : sizeof(double);
     void *du0, *dth, *dsv;
-    if ((rc = up(c, c->s_u0, u0, sizeof(double) * n * N, &du0))) return rc;
-    if ((rc = up(c, c->s_theta, theta, sizeof(double) * m->n_param, &dth))) return rc;
-    if ((rc = up(c, c->s_saveat, saveat, sizeof(double) * ns * ((o->per_trajectory & UDE_PT_SAVEAT) ? N : 1), &dsv))) return rc;
-    if ((rc = ensure(c, c->s_out, sizeof(double) * n * ns * N))) return rc;
+    if ((rc = up(c, c->s_u0, u0, es * n * N, &du0))) return rc;
+    if ((rc = up(c, c->s_theta, theta, es * m->n_param, &dth))) return rc;
+    if ((rc = up(c, c->s_saveat, saveat, es * ns * ((o->per_trajectory & UDE_PT_SAVEAT) ? N : 1), &dsv))) return rc;
+    if ((rc = ensure(c, c->s_out, es * n * ns * N))) return rc;
     if ((rc = ensure(c, c->s_stats, sizeof(int64_t) * 8 * N))) return rc;
     if ((rc = ensure(c, c->s_ret, sizeof(int32_t) * N))) return rc;
     rc = solve_dev_impl(c, m, o, N, (double*)du0, tspan, (double*)dth, (double*)dsv, ns, (double*)c->s_out.p,
                         (int64_t*)c->s_stats.p, (int32_t*)c->s_ret.p);
     if (rc) return rc;
     std::vector<int32_t> rtmp(N);
-    if ((rc = dn(c, u_out, c->s_out.p, sizeof(double) * n * ns * N))) return rc;
+    if ((rc = dn(c, u_out, c->s_out.p, es * n * ns * N))) return rc;
     if ((rc = dn(c, stats, c->s_stats.p, sizeof(int64_t) * 8 * N))) return rc;
     if ((rc = dn(c, rtmp.data(), c->s_ret.p, sizeof(int32_t) * N))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -643,19 +675,20 @@ static int grad_host(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* 
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = m->n_state, np = m->n_param;
+    const size_t es = m->dtype == 1 ? sizeof(float) : sizeof(double);
     void *du0, *dth, *dsv, *ddat, *dmask;
-    if ((rc = up(c, c->s_u0, u0, sizeof(double) * n * N, &du0))) return rc;
-    if ((rc = up(c, c->s_theta, theta, sizeof(double) * np, &dth))) return rc;
-    if ((rc = up(c, c->s_saveat, saveat, sizeof(double) * ns * ((o->per_trajectory & UDE_PT_SAVEAT) ? N : 1), &dsv))) return rc;
-    if ((rc = up(c, c->s_data, cot ? cot : data, sizeof(double) * n * ns * N, &ddat))) return rc;
+    if ((rc = up(c, c->s_u0, u0, es * n * N, &du0))) return rc;
+    if ((rc = up(c, c->s_theta, theta, es * np, &dth))) return rc;
+    if ((rc = up(c, c->s_saveat, saveat, es * ns * ((o->per_trajectory & UDE_PT_SAVEAT) ? N : 1), &dsv))) return rc;
+    if ((rc = up(c, c->s_data, cot ? cot : data, es * n * ns * N, &ddat))) return rc;
     if ((rc = up(c, c->s_mask, row_mask, n, &dmask))) return rc;
-    if ((rc = ensure(c, c->s_out, sizeof(double) * n * ns * N))) return rc;
+    if ((rc = ensure(c, c->s_out, es * n * ns * N))) return rc;
     if ((rc = ensure(c, c->s_stats, sizeof(int64_t) * 8 * N))) return rc;
     if ((rc = ensure(c, c->s_ret, sizeof(int32_t) * N))) return rc;
-    if ((rc = ensure(c, c->s_gtheta, sizeof(double) * np))) return rc;
-    if ((rc = ensure(c, c->s_gu0, sizeof(double) * n * N))) return rc;
-    if ((rc = ensure(c, c->s_loss, sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->s_lpt, sizeof(double) * N))) return rc;
+    if ((rc = ensure(c, c->s_gtheta, es * np))) return rc;
+    if ((rc = ensure(c, c->s_gu0, es * n * N))) return rc;
+    if ((rc = ensure(c, c->s_loss, es))) return rc;
+    if ((rc = ensure(c, c->s_lpt, es * N))) return rc;
     std::vector<int32_t> rtmp(N);
     for (;;) {
         HIPCHK(c, hipMemsetAsync(c->s_stats.p, 0, sizeof(int64_t) * 8 * N, c->stream));
@@ -673,13 +706,13 @@ static int grad_host(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* 
         if (!overflow || c->lo.max_dense_steps > 0 || c->auto_cap >= (1 << 20)) break;
         c->auto_cap *= 4;
     }
-    if ((rc = dn(c, u_out, c->s_out.p, sizeof(double) * n * ns * N))) return rc;
+    if ((rc = dn(c, u_out, c->s_out.p, es * n * ns * N))) return rc;
     if ((rc = dn(c, stats, c->s_stats.p, sizeof(int64_t) * 8 * N))) return rc;
-    if ((rc = dn(c, grad_theta, c->s_gtheta.p, sizeof(double) * np))) return rc;
-    if ((rc = dn(c, grad_u0, c->s_gu0.p, sizeof(double) * n * N))) return rc;
+    if ((rc = dn(c, grad_theta, c->s_gtheta.p, es * np))) return rc;
+    if ((rc = dn(c, grad_u0, c->s_gu0.p, es * n * N))) return rc;
     if (!cot) {
-        if ((rc = dn(c, loss, c->s_loss.p, sizeof(double)))) return rc;
-        if ((rc = dn(c, loss_per_traj, c->s_lpt.p, sizeof(double) * N))) return rc;
+        if ((rc = dn(c, loss, c->s_loss.p, es))) return rc;
+        if ((rc = dn(c, loss_per_traj, c->s_lpt.p, es * N))) return rc;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (retcode) memcpy(retcode, rtmp.data(), sizeof(int32_t) * N);
@@ -711,9 +744,10 @@ extern "C" int ude_rhs_ensemble(ude_ctx* c, const ude_model_desc* m, int64_t N, 
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     void *du0, *dth;
-    const size_t bytes = sizeof(double) * (size_t)N * m->n_state;
+    const size_t es = m->dtype == 1 ? sizeof(float) : sizeof(double);
+    const size_t bytes = es * (size_t)N * m->n_state;
     if ((rc = up(c, c->s_u0, u, bytes, &du0))) return rc;
-    if ((rc = up(c, c->s_theta, theta, sizeof(double) * (size_t)m->n_param, &dth))) return rc;
+    if ((rc = up(c, c->s_theta, theta, es * (size_t)m->n_param, &dth))) return rc;
     if ((rc = ensure(c, c->s_out, bytes))) return rc;
     if ((rc = ude_rhs_ensemble_dev(c, m, N, (const double*)du0, (const double*)dth, (double*)c->s_out.p))) return rc;
     if ((rc = dn(c, du, c->s_out.p, bytes))) return rc;

@@ -48,9 +48,9 @@ class Chain:
 
 
 def _desc(kind, n_state, chain=None, nn_offset=0, n_param=None, lin_idx=(-1, -1), lin_sign=(1.0, 1.0),
-          lin_const=(0.0, 0.0), stencil_offset=0, d0_offset=0, consts=()):
+          lin_const=(0.0, 0.0), stencil_offset=0, d0_offset=0, consts=(), dtype="float64"):
     m = ModelDesc()
-    m.kind, m.dtype, m.n_state = kind, 0, n_state
+    m.kind, m.dtype, m.n_state = kind, {"float64": 0, "float32": 1}[str(dtype)], n_state
     if chain is not None:
         m.n_layers = len(chain.layers)
         for i, d in enumerate(chain.dims):
@@ -77,18 +77,19 @@ def lv_chain():
     return Chain(Dense(2, 5, "rbf"), Dense(5, 5, "rbf"), Dense(5, 5, "rbf"), Dense(5, 2))
 
 
-def ude_dynamics(chain=None, p_true=(1.3, 0.9, 0.8, 1.8), trainable=None):
+def ude_dynamics(chain=None, p_true=(1.3, 0.9, 0.8, 1.8), trainable=None, dtype="float64"):
     """ude_dynamics!  du1 = p_true[1]*u1 + U(u)[1];  du2 = -p_true[4]*u2 + U(u)[2]   (scenario_1.jl:69-73).
 
     trainable: None (scenario_1), "delta" (scenario_2.jl:87-95: theta = [delta; ude], du2 = -delta*u2 + ...),
-    "both" (hudson_bay.jl:82-91: theta = [p1, p2, ude], du1 = p1*u1 + ..., du2 = -p2*u2 + ...)."""
+    "both" (hudson_bay.jl:82-91: theta = [p1, p2, ude], du1 = p1*u1 + ..., du2 = -p2*u2 + ...).
+    dtype="float32": the Float32 problem of hudson_bay.jl:77-104 (compiled: hudson_chain(), trainable="both")."""
     chain = chain or lv_chain()
     if trainable is None:
-        return _desc(KIND_LV_UDE, 2, chain, lin_const=(p_true[0], -p_true[3]))
+        return _desc(KIND_LV_UDE, 2, chain, lin_const=(p_true[0], -p_true[3]), dtype=dtype)
     if trainable == "delta":
-        return _desc(KIND_LV_UDE, 2, chain, nn_offset=1, lin_idx=(-1, 0), lin_sign=(1.0, -1.0), lin_const=(p_true[0], 0.0))
+        return _desc(KIND_LV_UDE, 2, chain, nn_offset=1, lin_idx=(-1, 0), lin_sign=(1.0, -1.0), lin_const=(p_true[0], 0.0), dtype=dtype)
     if trainable == "both":
-        return _desc(KIND_LV_UDE, 2, chain, nn_offset=2, lin_idx=(0, 1), lin_sign=(1.0, -1.0))
+        return _desc(KIND_LV_UDE, 2, chain, nn_offset=2, lin_idx=(0, 1), lin_sign=(1.0, -1.0), dtype=dtype)
     raise ValueError(trainable)
 
 
@@ -120,9 +121,16 @@ def dudt_(chain=None, p_=SEIR_P):
     return _desc(KIND_SEIR_UDE, 7, chain or seir_chain(), consts=p_)
 
 
-def rc_ode(nx=26, D=0.01, r=1.0, dx=0.04):
-    """rc_ode(rho,p,t) = D*lap*rho + reaction.(rho)  FisherKPP/Fisher-KPP-CNN.jl:51-63 (periodic)"""
+def rc_ode(nx=26, D=0.01, r=1.0, dx=0.04, dtype="float64"):
+    """rc_ode(rho,p,t) = D*lap*rho + reaction.(rho)  FisherKPP/Fisher-KPP-CNN.jl:51-63 (periodic);
+    dtype="float32": LotkaVolterra/scenario_3.jl:43-53 (the matrix entries formed in Float32 the way the script forms them)"""
     # D * lap with lap = diagm(-2, 1, 1) ./ dx^2: the entries Julia forms are D*(1/dx^2) and D*(-2/dx^2)
+    if str(dtype) == "float32":
+        import numpy as np
+        f = np.float32
+        dx2 = f(f(dx) * f(dx))
+        off, dia = f(np.float64(1.0) / np.float64(dx2)), f(np.float64(-2.0) / np.float64(dx2))     # Float32.(diagm(...) ./ dx^2)
+        return _desc(KIND_KPP_TRUE, nx, n_param=0, consts=(float(f(f(D) * off)), float(f(f(D) * dia)), float(f(r))), dtype=dtype)
     return _desc(KIND_KPP_TRUE, nx, n_param=0, consts=(D * (1.0 / dx ** 2), D * (-2.0 / dx ** 2), r))
 
 
@@ -154,8 +162,9 @@ def rho0(nx=26, dx=0.04, amp=1.0, delta=0.2):
     return amp * (np.tanh((x - (0.5 - delta / 2)) / (delta / 10)) - np.tanh((x - (0.5 + delta / 2)) / (delta / 10))) / 2
 
 
-def nn_ode(nx=26, chain=None):
-    """nn_ode(u,p,t)  Fisher-KPP-CNN.jl:111-126; theta = [rx_nn params; w1 w2 w3; unused conv bias; D0]"""
+def nn_ode(nx=26, chain=None, dtype="float64"):
+    """nn_ode(u,p,t)  Fisher-KPP-CNN.jl:111-126; theta = [rx_nn params; w1 w2 w3; unused conv bias; D0];
+    dtype="float32" with kpp_s3_chain(): scenario_3.jl:103-114"""
     chain = chain or kpp_chain()
     nn = chain.n_param
-    return _desc(KIND_KPP_UDE, nx, chain, nn_offset=0, n_param=nn + 5, stencil_offset=nn, d0_offset=nn + 4)
+    return _desc(KIND_KPP_UDE, nx, chain, nn_offset=0, n_param=nn + 5, stencil_offset=nn, d0_offset=nn + 4, dtype=dtype)

@@ -186,6 +186,12 @@ def _np(x, dtype=np.float64):
     return np.ascontiguousarray(np.asarray(x, dtype=dtype))
 
 
+def _rt(f):
+    """numpy scalar type of a problem: ude_model_desc.dtype = 1 -> every real-valued array of the call is Float32
+    (scenario_3.jl:26-57,121-126; hudson_bay.jl:77-104); tspan stays a pair of host doubles"""
+    return np.float32 if f.dtype == 1 else np.float64
+
+
 # ---- problems and solutions ------------------------------------------------------------------------------
 class ODEProblem:
     """ODEProblem(f, u0, tspan, p; saveat=...) -- f is a ModelDesc from .models"""
@@ -328,14 +334,16 @@ def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=
         eng.set_launch()  # library defaults (the engine is shared: do not inherit another call's launch options)
     o = _opts(alg, **kw)
     tspan, ts, ns = _time_grids(prob, saveat, o)
-    u0 = _np(prob.u0s if ens else base.u0)
+    rt = _rt(base.f)
+    ts = _np(ts, rt)
+    u0 = _np(prob.u0s if ens else base.u0, rt)
     if u0.ndim == 1:
         u0 = u0[None, :]
     N, n = u0.shape
     assert n == base.f.n_state
-    theta = _np(base.p if base.p is not None else [])
+    theta = _np(base.p if base.p is not None else [], rt)
     assert theta.size == base.f.n_param, "theta has %d entries, model expects %d" % (theta.size, base.f.n_param)
-    out = np.zeros((N, ns, n))
+    out = np.zeros((N, ns, n), dtype=rt)
     stats = np.zeros((N, NSTATS), dtype=np.int64)
     rc = np.zeros(N, dtype=np.int32)
     eng.check(eng.L.ude_solve_ensemble(eng.h, C.byref(base.f), C.byref(o), N, _ptr(u0), _ptr(tspan), _ptr(theta),
@@ -350,14 +358,15 @@ def rhs(f, u, p, device=0):
     (`ude_dynamics!`, `dudt_`, `nn_ode`) evaluated once per state."""
     eng = Engine.get(device)
     eng.set_launch()
-    u = _np(u)
+    rt = _rt(f)
+    u = _np(u, rt)
     if u.ndim == 1:
         u = u[None, :]
     N, n = u.shape
     assert n == f.n_state
-    p = _np(p)
-    du = np.zeros((N, n))
-    eng.check(eng.L.ude_rhs_ensemble(eng.h, C.byref(f), N, _ptr(u), _ptr(p if p.size else np.zeros(1)), _ptr(du)))
+    p = _np(p, rt)
+    du = np.zeros((N, n), dtype=rt)
+    eng.check(eng.L.ude_rhs_ensemble(eng.h, C.byref(f), N, _ptr(u), _ptr(p if p.size else np.zeros(1, dtype=rt)), _ptr(du)))
     return du
 
 
@@ -380,35 +389,37 @@ def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblea
         eng.set_launch()  # library defaults (the engine is shared: do not inherit another call's launch options)
     o = _opts(alg, sensealg=sensealg, **kw)
     tspan, ts, ns = _time_grids(prob, saveat, o)
-    u0 = _np(prob.u0s if ens else base.u0)
+    rt = _rt(base.f)
+    ts = _np(ts, rt)
+    u0 = _np(prob.u0s if ens else base.u0, rt)
     if u0.ndim == 1:
         u0 = u0[None, :]
     N, n = u0.shape
-    theta = _np(base.p)
+    theta = _np(base.p, rt)
     assert theta.size == base.f.n_param
     r = GradResult()
     r.t = ts
-    r.u = np.zeros((N, ns, n))
-    r.grad_theta = np.zeros(theta.size)
-    r.grad_u0 = np.zeros((N, n))
+    r.u = np.zeros((N, ns, n), dtype=rt)
+    r.grad_theta = np.zeros(theta.size, dtype=rt)
+    r.grad_u0 = np.zeros((N, n), dtype=rt)
     r.stats = np.zeros((N, NSTATS), dtype=np.int64)
     r.retcode = np.zeros(N, dtype=np.int32)
     if cotangent is not None:
-        cot = _np(cotangent).reshape(N, ns, n)
+        cot = _np(cotangent, rt).reshape(N, ns, n)
         rc = eng.L.ude_vjp_ensemble(eng.h, C.byref(base.f), C.byref(o), N, _ptr(u0), _ptr(tspan), _ptr(theta),
                                     _ptr(ts), ns, _ptr(cot), _ptr(r.u), _ptr(r.grad_theta), _ptr(r.grad_u0),
                                     _ptr(r.stats), _ptr(r.retcode))
         r.loss = None
     else:
-        dat = _np(data).reshape(N, ns, n)
+        dat = _np(data, rt).reshape(N, ns, n)
         mask = None if row_mask is None else _np(row_mask, np.uint8)
-        loss = C.c_double(0.0)
-        r.loss_per_traj = np.zeros(N)
+        loss = np.zeros(1, dtype=rt)
+        r.loss_per_traj = np.zeros(N, dtype=rt)
         rc = eng.L.ude_loss_grad_ensemble(eng.h, C.byref(base.f), C.byref(o), N, _ptr(u0), _ptr(tspan), _ptr(theta),
-                                          _ptr(ts), ns, _ptr(dat), _ptr(mask), C.byref(loss), _ptr(r.loss_per_traj),
+                                          _ptr(ts), ns, _ptr(dat), _ptr(mask), _ptr(loss), _ptr(r.loss_per_traj),
                                           _ptr(r.grad_theta), _ptr(r.grad_u0), _ptr(r.u), _ptr(r.stats),
                                           _ptr(r.retcode))
-        r.loss = loss.value
+        r.loss = float(loss[0]) if rt is np.float64 else loss[0]
     # a failed trajectory is dropped from the gradient and the loss is +Inf: never train on a partial objective silently
     eng.check(rc, allow_traj=allow_failures)
     r.kernel_ms = eng.kernel_ms()
