@@ -34,7 +34,8 @@ enum {
     UDE_KIND_SEIR_TRUE = 2, /* corona!       SEIR_exposure/seir_exposure.jl:16-30 */
     UDE_KIND_SEIR_UDE = 3,  /* dudt_         seir_exposure.jl:117-130 */
     UDE_KIND_KPP_TRUE = 4,  /* rc_ode        FisherKPP/Fisher-KPP-CNN.jl:51-63, LotkaVolterra/scenario_3.jl:43-53 */
-    UDE_KIND_KPP_UDE = 5    /* nn_ode        Fisher-KPP-CNN.jl:111-126, scenario_3.jl:103-114 */
+    UDE_KIND_KPP_UDE = 5,   /* nn_ode        Fisher-KPP-CNN.jl:111-126, scenario_3.jl:103-114 */
+    UDE_KIND_SEIR_NODE = 6  /* dudt_node     seir_exposure.jl:53-66: pure neural ODE 7-64-64-64-7 tanh, first five outputs = dS,dE,dI,dR,dD */
 };
 enum { UDE_ACT_IDENTITY = 0, UDE_ACT_TANH = 1, UDE_ACT_RBF = 2 /* scenario_1.jl:59 */, UDE_ACT_RELU = 3 };
 /* sensealg: InterpolatingAdjoint(autojacvec=ReverseDiffVJP()) seir_exposure.jl:140, Fisher-KPP-CNN.jl:136;

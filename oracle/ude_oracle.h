@@ -35,7 +35,8 @@ enum {
     UDEO_KIND_SEIR_TRUE = 2, /* corona!           SEIR_exposure/seir_exposure.jl:16-30    consts = p_[9] */
     UDEO_KIND_SEIR_UDE = 3,  /* dudt_             seir_exposure.jl:117-130 */
     UDEO_KIND_KPP_TRUE = 4,  /* rc_ode            FisherKPP/Fisher-KPP-CNN.jl:51-63, scenario_3.jl:43-53  consts = D/dx^2, -2D/dx^2, r */
-    UDEO_KIND_KPP_UDE = 5    /* nn_ode            Fisher-KPP-CNN.jl:111-126, scenario_3.jl:103-114 */
+    UDEO_KIND_KPP_UDE = 5,   /* nn_ode            Fisher-KPP-CNN.jl:111-126, scenario_3.jl:103-114 */
+    UDEO_KIND_SEIR_NODE = 6  /* dudt_node         SEIR_exposure/seir_exposure.jl:53-66   consts as SEIR (mu, sigma used) */
 };
 enum { UDEO_ACT_IDENTITY = 0, UDEO_ACT_TANH = 1, UDEO_ACT_RBF = 2, UDEO_ACT_RELU = 3 };
 enum { UDEO_ALG_TSIT5 = 0, UDEO_ALG_VERN7 = 1 };

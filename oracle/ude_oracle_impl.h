@@ -175,6 +175,18 @@ void FN(udeo_rhs)(const udeo_model_desc* m, const REAL* th, const REAL* u, REAL 
             du[5] = d * ga * I - la * D;
             du[6] = sg * E;
         } break;
+        case UDEO_KIND_SEIR_NODE: { /* dudt_node, seir_exposure.jl:55-66: the pure neural ODE 7 -> 64 -> 64 -> 64 -> 7 (tanh);
+                                     * the script destructures the FIRST FIVE outputs into dS,dE,dI,dR,dD */
+            const REAL S = u[0], N = u[4], D = u[5];
+            const REAL mu = (REAL)m->consts[4], sg = (REAL)m->consts[5];
+            REAL x[7] = {S / N, u[1], u[2], u[3], N, D / N, u[6]};
+            FN(mlp_forward)(m, th + m->nn_offset, x, zs, as);
+            const REAL* o = as[m->n_layers];
+            du[0] = o[0]; du[1] = o[1]; du[2] = o[2]; du[3] = o[3];
+            du[4] = -mu * N;
+            du[5] = o[4];
+            du[6] = sg * u[1];
+        } break;
         case UDEO_KIND_KPP_TRUE: { /* Fisher-KPP-CNN.jl:51-63: (D*lap)*rho + r*rho*(1-rho), periodic */
             /* consts = (D/dx^2, -2D/dx^2, r): the entries of the matrix D*lap as Julia forms them */
             const int n = m->n_state;
@@ -254,6 +266,21 @@ int FN(udeo_rhs_vjp)(const udeo_model_desc* m, const REAL* th, const REAL* u, RE
             dlam[4] = cN * lam[0] - cN * lam[1] - mu * lam[4] - gx[0] * S / (N * N) - gx[2] * D / (N * N);
             dlam[5] = -la * lam[5] + gx[2] / N;
             dlam[6] = 0;
+        } return 0;
+        case UDEO_KIND_SEIR_NODE: {
+            const REAL S = u[0], N = u[4], D = u[5];
+            const REAL mu = (REAL)m->consts[4], sg = (REAL)m->consts[5];
+            REAL x[7] = {S / N, u[1], u[2], u[3], N, D / N, u[6]};
+            REAL gy[7] = {lam[0], lam[1], lam[2], lam[3], lam[5], 0, 0}, gx[7];
+            FN(mlp_forward)(m, th + m->nn_offset, x, zs, as);
+            FN(mlp_vjp)(m, th + m->nn_offset, zs, as, gy, gx, dth ? dth + m->nn_offset : 0);
+            dlam[0] = gx[0] / N;
+            dlam[1] = R_FMA(sg, lam[6], gx[1]);
+            dlam[2] = gx[2];
+            dlam[3] = gx[3];
+            dlam[4] = ((gx[4] - gx[0] * S / (N * N)) - gx[5] * D / (N * N)) - mu * lam[4];
+            dlam[5] = gx[5] / N;
+            dlam[6] = gx[6];
         } return 0;
         case UDEO_KIND_KPP_UDE: {
             const int n = m->n_state;

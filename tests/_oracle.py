@@ -13,7 +13,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 MAX_LAYERS = 8
 NSTATS = 8
 
-KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE = range(6)
+KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE, KIND_SEIR_NODE = range(7)
 ACT = {"identity": 0, "tanh": 1, "rbf": 2, "relu": 3}
 TSIT5, VERN7 = 0, 1
 
@@ -102,6 +102,11 @@ def seir_true(p=SEIR_P):
 def seir_ude(p=SEIR_P):
     """seir_exposure.jl:114-130: NN 3-64-64-1 tanh (4481 params)"""
     return make_model(KIND_SEIR_UDE, 7, (3, 64, 64, 1), ("tanh", "tanh", "identity"), consts=p)
+
+
+def seir_node(p=SEIR_P):
+    """seir_exposure.jl:53-66: the pure neural ODE, FastChain 7-64-64-64-7 tanh (9287 params)"""
+    return make_model(KIND_SEIR_NODE, 7, (7, 64, 64, 64, 7), ("tanh", "tanh", "tanh", "identity"), consts=p)
 
 
 def kpp_true(nx=26, D=0.01, r=1.0, dx=0.04, dtype=0):

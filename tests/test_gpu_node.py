@@ -1,0 +1,78 @@
+"""The pure neural ODE of the SEIR script on the GPU: dudt_node, FastChain 7-64-64-64-7 tanh, 9287 parameters
+(/root/reference/SEIR_exposure/seir_exposure.jl:53-83; the call site of InterpolatingAdjoint at :69-73).
+Device (SeirNode<64>: one wavefront per trajectory, two 64x64 layers in LDS, deferred parameter cotangent) against the
+oracle's generic dense-chain restatement: per trajectory bit-identical, ensemble sums to summation order."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import universal_differential_equations_amd as U
+from universal_differential_equations_amd import models
+from test_gpu_parity import REL_GRAD_SUM, assert_bitwise, check_per_trajectory
+
+pytestmark = pytest.mark.gpu
+MASK = [0, 1, 1, 1, 0, 0, 0]
+
+
+def node_case(N, S0, seed=21):
+    rng = np.random.default_rng(seed)
+    u0 = np.zeros((N, 7))
+    u0[:, 0] = rng.uniform(0.8, 0.95, N) * S0
+    u0[:, 1] = rng.uniform(0.5, 2.0, N)
+    u0[:, 2] = rng.uniform(0.2, 1.0, N)
+    u0[:, 4] = S0
+    th = models.seir_node_chain().glorot_uniform(rng)
+    return u0, th
+
+
+def test_node_rhs_matches_oracle():
+    u0, th = node_case(9, 100.0)
+    f = models.dudt_node()
+    assert f.n_param == 9287
+    du = U.rhs(f, u0, th)
+    ref = np.array([O.rhs(O.seir_node(), th, u) for u in u0])
+    assert_bitwise(du, ref, "dudt_node")
+    assert np.abs(ref[:, :4]).min() > 0 and np.array_equal(ref[:, 4], -0.02 * u0[:, 4])
+
+
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+@pytest.mark.parametrize("S0,tf", [(100.0, 6.0), (14e6, 21.0)])
+def test_node_forward_and_adjoint_match_oracle(alg, oalg, S0, tf):
+    """S0 = 100: every layer alive, > 8000 of the 9287 parameter cotangents nonzero (the two unused output rows and the
+    rows of saturated first-layer neurons are exactly zero); S0 = 14e6: the script's own scale (N enters the first layer unscaled and saturates it)."""
+    N = 6
+    u0, th = node_case(N, S0)
+    t = np.arange(0.0, tf + 0.5, 1.0)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, tf], [], t)
+    f = models.dudt_node()
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, tf), th), u0)
+    sol = U.solve(ens, alg(), saveat=t, abstol=1e-6, reltol=1e-6)
+    out, st, rc = O.solve_ensemble(O.seir_node(), O.opts(oalg, 1e-6, 1e-6), u0, [0.0, tf], th, t)
+    assert (rc == 0).all()
+    assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts")
+    assert_bitwise(sol.u, out, "forward states")
+    r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
+    ref = O.loss_grad_ensemble(O.seir_node(), O.opts(oalg, 1e-6, 1e-6), u0, [0.0, tf], th, t, truth, row_mask=MASK, nthreads=6)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
+    gn = np.linalg.norm(ref["grad_theta"])
+    assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
+    W4g = r.grad_theta[-455:-7].reshape(64, 7)
+    assert np.all(W4g[:, 5:] == 0) and np.all(r.grad_theta[-2:] == 0) and np.abs(W4g[:, 1:4]).min() > 0   # rows of dE, dI, dR: the masked loss rows
+    if S0 == 100.0:
+        assert np.count_nonzero(r.grad_theta) > 8000       # (first-layer neurons saturated by N = 100 have exactly zero rows)
+
+
+def test_node_single_trajectory_gradient_is_bitwise():
+    """one trajectory: no sum over trajectories, so every one of the 9287 slots must carry the oracle's bits"""
+    u0, th = node_case(1, 100.0, seed=5)
+    t = np.arange(0.0, 4.5, 1.0)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 4.0], [], t)
+    prob = U.ODEProblem(models.dudt_node(), u0[0], (0.0, 4.0), th)
+    for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1)):
+        r = U.loss_and_gradient(prob, U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=sense)
+        ref = O.loss_grad_ensemble(O.seir_node(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=osense), u0, [0.0, 4.0], th, t, truth, row_mask=MASK)
+        assert_bitwise(r.stats, ref["stats"], "stats")
+        assert_bitwise(r.grad_u0, ref["grad_u0"], "dL/du0")
+        assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta")

@@ -29,6 +29,7 @@ MODELS = [
     ("lv_true", O.lv_true, [0.4, 1.2]),
     # population scaled to O(100) so finite differences resolve the NN term next to beta0*S*F/N
     ("seir", O.seir_ude, [90.0, 1.0, 2.0, 0.3, 100.0, 0.5, 3.0]),
+    ("seir_node", O.seir_node, [90.0, 1.0, 2.0, 0.3, 100.0, 0.5, 3.0]),
     ("kpp", lambda: O.kpp_ude(12), list(np.linspace(0.05, 0.9, 12))),
     ("kpp_s3", lambda: O.kpp_ude_s3(0), list(np.linspace(0.05, 0.9, 26))),
 ]
@@ -39,6 +40,8 @@ def test_rhs_vjp_matches_finite_differences(name, mk, u):
     m = mk()
     rng = np.random.default_rng(3)
     th = rng.uniform(-0.5, 0.5, m.n_param)
+    if name == "seir_node":
+        th *= 0.2                                  # keep the three 64-wide tanh layers out of saturation
     if name == "lv_true":
         th = np.array([1.3, 0.9, 0.8, 1.8])
     if name.startswith("kpp"):
@@ -294,6 +297,45 @@ def test_seir_full_loss_adjoint_vs_finite_differences():
     fd = _fd_directional(loss, th, dirs, 1e-5)
     an = np.array([r["grad_theta"] @ d for d in dirs])
     assert np.allclose(an, fd, rtol=2e-5, atol=1e-7 * np.abs(fd).max()), (an, fd)
+
+
+def glorot_chain(rng, dims):
+    """initial_params(FastChain): glorot_uniform weights, zero biases, [vec(W); b] per layer"""
+    parts = []
+    for fin, fout in zip(dims[:-1], dims[1:]):
+        lim = np.sqrt(6.0 / (fin + fout))
+        parts += [rng.uniform(-lim, lim, fin * fout), np.zeros(fout)]
+    return np.concatenate(parts)
+
+
+def test_seir_neural_ode_full_loss_adjoint_vs_finite_differences():
+    """seir_exposure.jl:53-83 (the pure neural ODE 7-64-64-64-7): loss rows 2:4, state at the script's scale (S0 = 14e6
+    enters the network unscaled through E, I, R, N, C -- the script's own formulation), interpolating adjoint vs central FD."""
+    rng = np.random.default_rng(7)
+    m = O.seir_node()
+    assert m.n_param == 9287
+    S0 = 14e6
+    u0 = np.array([0.9 * S0, 10.0, 5.0, 0.0, S0, 0.0, 0.0])
+    t = np.arange(0.0, 4.0, 1.0)
+    th = glorot_chain(rng, (7, 64, 64, 64, 7))
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [t[0], t[-1]], np.zeros(0), t)
+    mask = [0, 1, 1, 1, 0, 0, 0]
+
+    def loss(theta):
+        out, _, r = O.solve_ensemble(m, O.opts(O.VERN7, 1e-12, 1e-12), u0, [t[0], t[-1]], theta, t)
+        assert r[0] == 0
+        return float(((out[0][:, 1:4] - truth[0][:, 1:4]) ** 2).sum())
+
+    r = O.loss_grad_ensemble(m, O.opts(O.VERN7, 1e-9, 1e-9), u0, [t[0], t[-1]], th, t, truth, row_mask=mask)
+    assert r["retcode"][0] == 0 and abs(r["loss"] - loss(th)) < 1e-6 * r["loss"]
+    # rows 6, 7 of the output layer and their biases never reach the loss (the script destructures five outputs)
+    g4 = r["grad_theta"][-(64 * 7 + 7):]
+    W4g, b4g = g4[:448].reshape(64, 7), g4[448:]
+    assert np.all(W4g[:, 5:] == 0.0) and np.all(b4g[5:] == 0.0) and np.abs(W4g[:, :5]).max() > 0
+    dirs = [rng.standard_normal(th.size) / np.sqrt(th.size) for _ in range(5)]
+    fd = _fd_directional(loss, th, dirs, 1e-5)
+    an = np.array([r["grad_theta"] @ d for d in dirs])
+    assert np.allclose(an, fd, rtol=5e-5, atol=1e-7 * np.abs(fd).max()), (an, fd)
 
 
 def test_fisher_kpp_full_loss_adjoint_vs_finite_differences():

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libudecore.so")
 MAX_LAYERS = 8
 NSTATS = 8
 
-KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE = range(6)
+KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE, KIND_SEIR_NODE = range(7)
 ACT = {"identity": 0, "tanh": 1, "rbf": 2, "relu": 3}
 ALG_TSIT5, ALG_VERN7 = 0, 1
 RETCODES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable", 4: "DenseOverflow"}

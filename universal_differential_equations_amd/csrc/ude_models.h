@@ -535,6 +535,9 @@ struct SeirUde {
     }
 };
 
+}  // namespace ude
+#include "ude_model_node.h"
+namespace ude {
 #endif  // UDE_F32
 
 // ---------------------------------------------------------------------------------------------

@@ -59,7 +59,8 @@ enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, 
        MID_KPP_TRUE_32, MID_KPP_TRUE_1024, MID_KPP_UDE_32, MID_KPP_UDE_1024, MID_KPP_S3_32, MID_KPP_SMALL_32,
        MID_LV_S1N /* scenario_1's chain with CONSTANT diagonal coefficients: no slots for them */,
        // Float32 problems (ude_model_desc.dtype = 1): hudson_bay.jl:77-104, scenario_3.jl:26-57 (true Fisher-KPP) and :83-126 (its UDE)
-       MID_LV_HUDSON_F32, MID_KPP_TRUE_32_F32, MID_KPP_S3_32_F32 };
+       MID_LV_HUDSON_F32, MID_KPP_TRUE_32_F32, MID_KPP_S3_32_F32,
+       MID_SEIR_NODE /* the pure neural ODE 7-64-64-64-7 of seir_exposure.jl:53-73 */ };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88

@@ -162,6 +162,9 @@ static int model_id(const ude_model_desc* m) {
     if (m->kind == UDE_KIND_SEIR_UDE && m->n_state == 7 && m->nn_offset == 0 && m->n_param == 4481 &&
         dims_are(m, {3, 64, 64, 1}, {ACT_TANH, ACT_TANH, ACT_IDENTITY}))
         return MID_SEIR_UDE;
+    if (m->kind == UDE_KIND_SEIR_NODE && m->n_state == 7 && m->nn_offset == 0 && m->n_param == 9287 &&
+        dims_are(m, {7, 64, 64, 64, 7}, {ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY}))
+        return MID_SEIR_NODE;
     return MID_NONE;
 }
 
@@ -174,6 +177,7 @@ static int default_lanes(int mid, bool discrete) {
         case MID_LV_TANH32: return 8;  // (32 lanes = 5000 wavefronts = five rounds for 10k trajectories: 16.5 ms vs 7.6 ms per gradient)
         case MID_SEIR_TRUE: return 1;
         case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
+        case MID_SEIR_NODE: return 64;  // wavefront per trajectory, 2 per block (two 64x64 layers + the stage factors fill the LDS)
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32:

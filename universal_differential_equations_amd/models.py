@@ -3,7 +3,7 @@
 A Julia (or Python) closure cannot cross the C ABI, so each RHS family of the reference is a
 descriptor (include/udecore.h:ude_model_desc).  Constructors are named after the reference functions.
 """
-from ._lib import (ACT, KIND_KPP_TRUE, KIND_KPP_UDE, KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE,
+from ._lib import (ACT, KIND_KPP_TRUE, KIND_KPP_UDE, KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_NODE, KIND_SEIR_TRUE, KIND_SEIR_UDE,
                    ModelDesc)
 
 
@@ -119,6 +119,16 @@ def seir_chain():
 def dudt_(chain=None, p_=SEIR_P):
     """dudt_(u,p,t)  seir_exposure.jl:117-130"""
     return _desc(KIND_SEIR_UDE, 7, chain or seir_chain(), consts=p_)
+
+
+def seir_node_chain():
+    """ann_node = FastChain(FastDense(7,64,tanh), FastDense(64,64,tanh), FastDense(64,64,tanh), FastDense(64,7))  seir_exposure.jl:53"""
+    return Chain(Dense(7, 64, "tanh"), Dense(64, 64, "tanh"), Dense(64, 64, "tanh"), Dense(64, 7))
+
+
+def dudt_node(chain=None, p_=SEIR_P):
+    """dudt_node(u,p,t)  seir_exposure.jl:55-66: the pure neural ODE; dS,dE,dI,dR,dD = the first five network outputs"""
+    return _desc(KIND_SEIR_NODE, 7, chain or seir_node_chain(), consts=p_)
 
 
 def rc_ode(nx=26, D=0.01, r=1.0, dx=0.04, dtype="float64"):
