@@ -25,7 +25,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 (MI355X guide: 64 FLOP/c
 HJB_FLOP_PER_EVAL = 2.0 * (101 * 110 + 110 * 110 * 2 + 110 * 100)   # one sigma^T grad u chain evaluation (lambaem.jl:27-30)
 HJB_FLOP_PER_BWD_COL = 2.0 * (100 * 110 + 110 * 110 * 2) + 2.0 * (102 * 110 + 111 * 110 * 2 + 111 * 100)  # delta chain + outer products
 # algorithmic flop per work unit (forward RHS eval, adjoint eval): SURVEY.md 8(d) roofline table
-FLOPS = {"lv": (160.0, 550.0), "seir": (8744.0, 26000.0), "kpp": (0.87e6, 2.6e6)}
+FLOPS = {"lv": (160.0, 550.0), "seir": (8744.0, 26000.0), "kpp": (0.87e6, 2.6e6),
+         # neural ODE 7-64-64-64-7: forward 2*(7*64 + 2*64*64 + 64*7) = 18.2 kflop; adjoint = forward + transposed products + outer products
+         "node": (18176.0, 54500.0)}
 
 
 SENSE_NAME = {"adjoint": "InterpolatingAdjoint", "discrete": "discretise-then-optimise (ForwardDiffSensitivity-equivalent)"}
@@ -39,14 +41,16 @@ def synth_inputs_other(workload, N, rank, device):
     import universal_differential_equations_amd as U
     from universal_differential_equations_amd import models
     rng = np.random.default_rng(1234 + rank)
-    if workload == "seir":
+    if workload in ("seir", "node"):
         S0 = 14e6
         u0 = np.zeros((N, 7))
         u0[:, 0] = rng.uniform(0.8, 0.95, N) * S0
         u0[:, 4] = S0
         t = np.arange(22.0)
-        tspan, f_true, f_ude = (0.0, 21.0), models.corona(), models.dudt_()
-        theta = models.seir_chain().glorot_uniform(rng)
+        tspan, f_true, f_ude = (0.0, 21.0), models.corona(), models.dudt_() if workload == "seir" else models.dudt_node()
+        theta = (models.seir_chain() if workload == "seir" else models.seir_node_chain()).glorot_uniform(rng)
+        if workload == "node":
+            u0[:, 1] = rng.uniform(5.0, 20.0, N)      # a few exposed, so that the data rows 2:4 are not identically zero
         mask, alg, tol = [0, 1, 1, 1, 0, 0, 0], U.Vern7(), dict(abstol=1e-6, reltol=1e-6)
         true_alg, true_tol = U.Vern7(), dict(abstol=1e-12, reltol=1e-12)
     else:
@@ -94,8 +98,8 @@ def cpu_baseline(theta, u0, t, data, seconds_target=15.0, workload="lv", mask=No
     cores = os.cpu_count() or 1
     if workload == "lv":
         m, o = O.lv_ude_s1(), O.opts(O.TSIT5, 1e-6, 1e-6)
-    elif workload == "seir":
-        m, o = O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6)
+    elif workload in ("seir", "node"):
+        m, o = (O.seir_ude() if workload == "seir" else O.seir_node()), O.opts(O.VERN7, 1e-6, 1e-6)
     else:
         m, o = O.kpp_ude(u0.shape[1]), O.opts(O.TSIT5)
     n = min(len(u0), cores if workload != "lv" else 64 * cores)
@@ -250,8 +254,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--traj", type=int, default=0, help="trajectories per GPU (0 = workload default)")
-    ap.add_argument("--workload", default="lv", choices=["lv", "seir", "kpp", "hjb"],
-                    help="lv = BASELINE configs[1] (the headline); seir / kpp / hjb = configs[2] per-GPU share / configs[3] / configs[4] per-GPU share")
+    ap.add_argument("--workload", default="lv", choices=["lv", "seir", "kpp", "hjb", "node"],
+                    help="lv = BASELINE configs[1] (the headline); seir / kpp / hjb = configs[2] per-GPU share / configs[3] / configs[4] per-GPU share; "
+                         "node = the script's pure neural ODE 7-64-64-64-7 (seir_exposure.jl:53-83) on the configs[2] ensemble")
     ap.add_argument("--tol", type=float, default=0.1, help="hjb workload: abstol = reltol of the adaptive LambaEM solves")
     ap.add_argument("--max-steps", type=int, default=0, help="hjb workload: accepted-step store per trajectory (0 = library default 512)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = library default)")
@@ -283,7 +288,7 @@ def main():
     from universal_differential_equations_amd import models
     from universal_differential_equations_amd.parallel import Comm, allreduce_payload, pack_payload
 
-    N = a.traj or {"lv": 10000, "seir": 6250, "kpp": 256}[a.workload]
+    N = a.traj or {"lv": 10000, "seir": 6250, "kpp": 256, "node": 6250}[a.workload]
     mask = None
     if a.workload == "lv":
         theta_h, u0_d, t, data = synth_inputs(N, rank, device)
@@ -306,6 +311,8 @@ def main():
                                sensealg=U.ForwardDiffSensitivity() if a.sensealg == "discrete" else None, **w["tol"])
         wl_name = {"seir": "BASELINE configs[2] per-GPU share: SEIR exposure UDE (7 states, NN 3-64-64-1 tanh, 4481 params), %d trajectories "
                            "per GPU, Vern7 abstol=reltol=1e-6, 22 save points, loss rows 2:4 + %s gradient",
+                   "node": "SEIR neural ODE (seir_exposure.jl:53-83: 7 states, FastChain 7-64-64-64-7 tanh, 9287 params) on the configs[2] ensemble, %d "
+                           "trajectories per GPU, Vern7 abstol=reltol=1e-6, 22 save points, loss rows 2:4 + %s gradient",
                    "kpp": "BASELINE configs[3]: Fisher-KPP UDE, 1024 points (dx = 0.04), NN 1-10-20-10-1 tanh + 3-tap stencil (466 params), "
                           "%d PDEs per GPU, Tsit5 default tol, 11 save points, loss + %s gradient"}[a.workload] % (N, SENSE_NAME[a.sensealg])
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)

@@ -195,39 +195,37 @@ struct SeirNode {
         static_for<0, NOUT>([&](auto i) { sh = (c.j == NIN + (int)decltype(i)::value) ? q.d4[i] : sh; });
         f[6 * H] = sh;
     }
-    struct Fac {  // this lane's factors of all stages (registers)
-        double a3[NSTG], d1[NSTG], d2[NSTG], d3[NSTG];
+    // this lane's delta of ONE layer at all stages (registers): the 64 slots of a weight block share it; the 18 extras
+    // read their factors straight from the lane's own LDS words (one use each -- keeping all four per-lane factor sets
+    // of ten stages in registers next to the chunked mu prefetch spilled 221 VGPRs)
+    struct Fac {
+        double d[NSTG];
     };
-    template <int NST, unsigned MASK>
-    static __device__ __forceinline__ void load_factors(const Ctx& c, Fac& f) {
+    template <int NST, unsigned MASK, int FIELD>
+    static __device__ __forceinline__ void load_factor(const Ctx& c, Fac& f) {
         static_for<0, NST>([&](auto s) {
-            if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                const double* p = c.fac + decltype(s)::value * (NFAC * H) + c.j;
-                f.a3[s] = p[2 * H]; f.d1[s] = p[3 * H]; f.d2[s] = p[4 * H]; f.d3[s] = p[5 * H];
-            }
+            if constexpr ((MASK >> decltype(s)::value) & 1u) f.d[s] = c.fac[(decltype(s)::value * NFAC + FIELD) * H + c.j];
         });
     }
     // g_s (all stored stages) of slot k of the W2 block (LAYER = 0: -(delta2_j a1_k)) / the W3 block (1: -(delta3_j a2_k))
     template <int NST, unsigned MASK, int LAYER>
     static __device__ __forceinline__ void g_w(const Ctx& c, const Fac& f, int k, double* g) {
         static_for<0, NST>([&](auto s) {
-            if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                const double a = c.fac[(decltype(s)::value * NFAC + LAYER) * H + k];
-                g[s] = -((LAYER == 0 ? f.d2[s] : f.d3[s]) * a);
-            }
+            if constexpr ((MASK >> decltype(s)::value) & 1u) g[s] = -(f.d[s] * c.fac[(decltype(s)::value * NFAC + LAYER) * H + k]);
         });
     }
     template <int NST, unsigned MASK, int E>
-    static __device__ __forceinline__ void g_extra(const Ctx& c, const Fac& f, double* g) {
+    static __device__ __forceinline__ void g_extra(const Ctx& c, double* g) {
         static_for<0, NST>([&](auto s) {
             if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                const double* p = c.fac + (decltype(s)::value * NFAC + 6) * H;  // x0..x6 | delta4_0..6
+                const double* own = c.fac + decltype(s)::value * (NFAC * H) + c.j;          // a1 a2 a3 d1 d2 d3 of this lane
+                const double* p = c.fac + (decltype(s)::value * NFAC + 6) * H;              // x0..x6 | delta4_0..6
                 double v;
-                if constexpr (E < NIN) v = -(f.d1[s] * p[E]);
-                else if constexpr (E == NIN) v = -f.d1[s];
-                else if constexpr (E == NIN + 1) v = -f.d2[s];
-                else if constexpr (E == NIN + 2) v = -f.d3[s];
-                else if constexpr (E < NIN + 3 + NOUT) v = -(p[NIN + (E - NIN - 3)] * f.a3[s]);
+                if constexpr (E < NIN) v = -(own[3 * H] * p[E]);
+                else if constexpr (E == NIN) v = -own[3 * H];
+                else if constexpr (E == NIN + 1) v = -own[4 * H];
+                else if constexpr (E == NIN + 2) v = -own[5 * H];
+                else if constexpr (E < NIN + 3 + NOUT) v = -(p[NIN + (E - NIN - 3)] * own[2 * H]);
                 else v = c.j < NOUT ? -p[NIN + c.j] : -0.0;
                 g[s] = v;
             }
@@ -235,7 +233,7 @@ struct SeirNode {
     }
     // slots in order 0..145, mu read in chunks of CH (next chunk in flight while this one is processed)
     template <int NST, unsigned MASK, class Body>
-    static __device__ __forceinline__ void for_each_slot(const Ctx& c, const Fac& f, const double* mu, int ms, Body body) {
+    static __device__ __forceinline__ void for_each_slot(const Ctx& c, const double* mu, int ms, Body body) {
         constexpr int CH = 8;
         static_assert(NEXTRA > 2 * CH && NEXTRA <= 3 * CH, "three chunks of extras");
         double mcur[CH], mnext[CH];
@@ -247,26 +245,21 @@ struct SeirNode {
             });
         };
         auto roll = [&]() { static_for<0, CH>([&](auto i) { mcur[i] = mnext[i]; }); };
+        static_for<0, 2>([&](auto layer) {
+            constexpr int LAYER = decltype(layer)::value;
+            Fac f;
+            load_factor<NST, MASK, 4 + LAYER>(c, f);  // delta2 / delta3
 #pragma unroll 1
-        for (int k0 = 0; k0 < H; k0 += CH) {
-            fetch(k0 + CH);
-            static_for<0, CH>([&](auto i) {
-                double g[NST];
-                g_w<NST, MASK, 0>(c, f, k0 + decltype(i)::value, g);
-                body(k0 + decltype(i)::value, g, mcur[i]);
-            });
-            roll();
-        }
-#pragma unroll 1
-        for (int k0 = 0; k0 < H; k0 += CH) {
-            fetch(H + k0 + CH);
-            static_for<0, CH>([&](auto i) {
-                double g[NST];
-                g_w<NST, MASK, 1>(c, f, k0 + decltype(i)::value, g);
-                body(H + k0 + decltype(i)::value, g, mcur[i]);
-            });
-            roll();
-        }
+            for (int k0 = 0; k0 < H; k0 += CH) {
+                fetch(LAYER * H + k0 + CH);
+                static_for<0, CH>([&](auto i) {
+                    double g[NST];
+                    g_w<NST, MASK, LAYER>(c, f, k0 + decltype(i)::value, g);
+                    body(LAYER * H + k0 + decltype(i)::value, g, mcur[i]);
+                });
+                roll();
+            }
+        });
         static_for<0, 3>([&](auto chunk) {
             constexpr int e0 = decltype(chunk)::value * CH;
             if constexpr (e0 + CH < NEXTRA) fetch(2 * H + e0 + CH);
@@ -274,8 +267,9 @@ struct SeirNode {
                 constexpr int e = e0 + decltype(i)::value;
                 if constexpr (e < NEXTRA) {
                     double g[NST];
-                    g_extra<NST, MASK, e>(c, f, g);
+                    g_extra<NST, MASK, e>(c, g);
                     body(2 * H + e, g, mcur[i]);
+                    asm volatile("" ::: "memory");  // one extra at a time: no hoisting of all 18 x NST factor loads
                 }
             });
             if constexpr (e0 + CH < NEXTRA) roll();
@@ -285,12 +279,10 @@ struct SeirNode {
     static __device__ __forceinline__ double step_slots(const Ctx& c, const double* B, const double* BT, double dt, double abstol,
                                                         double reltol, const double* mu, double* mu_new, int ms) {
         static_assert(MASK & 1u, "the first stage starts the chains");
-        Fac f;
-        load_factors<NST, MASK>(c, f);
         double bb[NST], bt[NST];
         static_for<0, NST>([&](auto s) { bb[s] = uniform_real(B[s]); bt[s] = uniform_real(BT[s]); });
         double ps = 0.0;
-        for_each_slot<NST, MASK>(c, f, mu, ms, [&](int slot, const double* g, double m0) {
+        for_each_slot<NST, MASK>(c, mu, ms, [&](int slot, const double* g, double m0) {
             double ab = bb[0] * g[0], ae = bt[0] * g[0];
             static_for<1, NST>([&](auto s) {
                 if constexpr ((MASK >> decltype(s)::value) & 1u) {
@@ -308,9 +300,7 @@ struct SeirNode {
     }
     static __device__ __forceinline__ void init_norm01(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
                                                        double& h0, double& l0, double& h1, double& l1) {
-        Fac f;
-        load_factors<1, 1u>(c, f);
-        for_each_slot<1, 1u>(c, f, mu, ms, [&](int, const double* g, double m) {
+        for_each_slot<1, 1u>(c, mu, ms, [&](int, const double* g, double m) {
             const double sk = __builtin_fma(fabs(m), reltol, abstol);
             const double q0 = m / sk, q1 = g[0] / sk;
             dd_acc(h0, l0, q0 * q0);
@@ -319,9 +309,7 @@ struct SeirNode {
     }
     static __device__ __forceinline__ void init_norm2(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
                                                       double& h2, double& l2) {
-        Fac f;
-        load_factors<2, 3u>(c, f);
-        for_each_slot<2, 3u>(c, f, mu, ms, [&](int, const double* g, double m) {
+        for_each_slot<2, 3u>(c, mu, ms, [&](int, const double* g, double m) {
             const double sk = __builtin_fma(fabs(m), reltol, abstol);
             const double q = (g[1] - g[0]) / sk;
             dd_acc(h2, l2, q * q);
