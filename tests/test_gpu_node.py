@@ -76,3 +76,20 @@ def test_node_single_trajectory_gradient_is_bitwise():
         assert_bitwise(r.stats, ref["stats"], "stats")
         assert_bitwise(r.grad_u0, ref["grad_u0"], "dL/du0")
         assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta")
+
+
+@pytest.mark.parametrize("N", [1, 6])
+def test_node_adjoint_is_reproducible_run_to_run(N):
+    """Regression guard: an earlier build of these kernels (8 slots in flight per chunk, 250+ spilled VGPRs) produced a
+    garbage backward solve for Tsit5 depending on what had run before on the device (first call of a process, tracing
+    on/off); alternate the two algorithms several times and demand the oracle's bits every time."""
+    u0, th = node_case(N, 100.0)
+    t = np.arange(0.0, 6.5, 1.0)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 6.0], [], t)
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_node(), u0[0], (0.0, 6.0), th), u0)
+    refs = {a: O.loss_grad_ensemble(O.seir_node(), O.opts(oa, 1e-6, 1e-6), u0, [0.0, 6.0], th, t, truth, row_mask=MASK, nthreads=4)
+            for a, oa in (("t", O.TSIT5), ("v", O.VERN7))}
+    for a in "ttvttvvt":
+        r = U.loss_and_gradient(ens, U.Tsit5() if a == "t" else U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
+        assert_bitwise(r.stats, refs[a]["stats"], "stats (%s)" % a)
+        assert_bitwise(r.grad_u0, refs[a]["grad_u0"], "dL/du0 (%s)" % a)

@@ -1046,10 +1046,12 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         // one wavefront per trajectory, mu in HBM: the wave's partial row is its own mu, slot by slot
         static_assert(G == 64, "HBM slot state: one wavefront per trajectory");
         real* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
-        static_for<0, NSLOT>([&](auto c) {
+        // (a runtime loop: unrolled, the compiler keeps all NSLOT loads in flight -- 2 x 146 registers for the neural ODE)
+#pragma unroll 2
+        for (int c = 0; c < NSLOT; ++c) {
             const int idx = Model::slot_index(p.mc, r, c);
             if (idx >= 0) row[idx] = mu_final[(size_t)c * MS];
-        });
+        }
     }
     if constexpr (!SG && pow2_group<G>()) {
     real mu[NSLA];

@@ -16,6 +16,9 @@
 // sums of the 146 slots per lane are formed at the end of the step, fused with the error norm and the candidate mu
 // (mu itself in HBM, two columns that swap on acceptance).
 #pragma once
+#ifndef NODE_BARRIER
+#define NODE_BARRIER asm volatile("" ::: "memory")
+#endif
 
 namespace ude {
 
@@ -40,7 +43,7 @@ struct SeirNode {
         double w1[NIN], b1, b2, b3, w4[NOUT], b4[NOUT];
         const lds_t *W2p, *W3p;  // LDS, ld = 65
         lds_t* bc;               // two wave-private broadcast rows: lane j writes, every lane reads all 64
-        double* fac;             // stage factors of this wavefront: field f of stage s at fac[(s*NFAC + f)*H + lane]
+        lds_t* fac;              // stage factors of this wavefront: field f of stage s at fac[(s*NFAC + f)*H + lane]
         double mu_c, sg;
         int j, r;
     };
@@ -59,7 +62,7 @@ struct SeirNode {
         c.W3p = (const lds_t*)th + H * LD;
         const int wv = (threadIdx.x >> 6) % WPB;
         c.bc = (lds_t*)scratch + WPB * NSTG * NFAC * H + wv * 2 * H;
-        c.fac = scratch + wv * (NSTG * NFAC * H);
+        c.fac = (lds_t*)scratch + wv * (NSTG * NFAC * H);
         static_for<0, NIN>([&](auto m) { c.w1[m] = theta_g[OFF_W1 + j + decltype(m)::value * H]; });
         c.b1 = theta_g[OFF_B1 + j]; c.b2 = theta_g[OFF_B2 + j]; c.b3 = theta_g[OFF_B3 + j];
         static_for<0, NOUT>([&](auto i) {
@@ -188,7 +191,7 @@ struct SeirNode {
     static __device__ __forceinline__ void vjp_store(const Ctx& c, const double* u, const double* lam, double* dlam, int s) {
         Bwd q;
         sweep(c, u, lam, dlam, q);
-        double* f = c.fac + s * (NFAC * H) + c.j;
+        lds_t* f = c.fac + s * (NFAC * H) + c.j;
         f[0] = q.f.a1; f[H] = q.f.a2; f[2 * H] = q.f.a3; f[3 * H] = q.d1; f[4 * H] = q.d2; f[5 * H] = q.d3;
         double sh = 0.0;
         static_for<0, NIN>([&](auto m) { sh = (c.j == (int)decltype(m)::value) ? q.f.x[m] : sh; });
@@ -218,8 +221,8 @@ struct SeirNode {
     static __device__ __forceinline__ void g_extra(const Ctx& c, double* g) {
         static_for<0, NST>([&](auto s) {
             if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                const double* own = c.fac + decltype(s)::value * (NFAC * H) + c.j;          // a1 a2 a3 d1 d2 d3 of this lane
-                const double* p = c.fac + (decltype(s)::value * NFAC + 6) * H;              // x0..x6 | delta4_0..6
+                const lds_t* own = c.fac + decltype(s)::value * (NFAC * H) + c.j;          // a1 a2 a3 d1 d2 d3 of this lane
+                const lds_t* p = c.fac + (decltype(s)::value * NFAC + 6) * H;              // x0..x6 | delta4_0..6
                 double v;
                 if constexpr (E < NIN) v = -(own[3 * H] * p[E]);
                 else if constexpr (E == NIN) v = -own[3 * H];
@@ -234,8 +237,8 @@ struct SeirNode {
     // slots in order 0..145, mu read in chunks of CH (next chunk in flight while this one is processed)
     template <int NST, unsigned MASK, class Body>
     static __device__ __forceinline__ void for_each_slot(const Ctx& c, const double* mu, int ms, Body body) {
-        constexpr int CH = 8;
-        static_assert(NEXTRA > 2 * CH && NEXTRA <= 3 * CH, "three chunks of extras");
+        constexpr int CH = 4;  // (8 in flight made the scheduler interleave 8 x NST factor products: 250+ spilled VGPRs)
+        constexpr int NCHX = (NEXTRA + CH - 1) / CH;
         double mcur[CH], mnext[CH];
         static_for<0, CH>([&](auto i) { mcur[i] = mu[(size_t)decltype(i)::value * ms]; });
         auto fetch = [&](int first) {
@@ -260,7 +263,7 @@ struct SeirNode {
                 roll();
             }
         });
-        static_for<0, 3>([&](auto chunk) {
+        static_for<0, NCHX>([&](auto chunk) {
             constexpr int e0 = decltype(chunk)::value * CH;
             if constexpr (e0 + CH < NEXTRA) fetch(2 * H + e0 + CH);
             static_for<0, CH>([&](auto i) {
@@ -269,7 +272,7 @@ struct SeirNode {
                     double g[NST];
                     g_extra<NST, MASK, e>(c, g);
                     body(2 * H + e, g, mcur[i]);
-                    asm volatile("" ::: "memory");  // one extra at a time: no hoisting of all 18 x NST factor loads
+                    NODE_BARRIER;
                 }
             });
             if constexpr (e0 + CH < NEXTRA) roll();

@@ -225,7 +225,7 @@ struct SeirUde {
         const lds_t* W2p;   // LDS, ld = 65 (ONE)
         lds_t* bc;          // ONE: two wave-private broadcast rows (a1 / delta2): lane j writes, every lane reads all 64
         double *pf, *pb;    // LDS block-sum exchange (multi-wave)
-        double* fac;        // LDS stage factors of this wavefront: field f of stage s at fac[(s*NFAC + f)*H + lane]
+        lds_t* fac;         // LDS stage factors of this wavefront: field f of stage s at fac[(s*NFAC + f)*H + lane]
         double F, b0, mu_c, sg, ga, d, la;
         int j, w, r;
         mutable int flip;
@@ -244,7 +244,7 @@ struct SeirUde {
         c.W2p = (const lds_t*)th;
         c.bc = (lds_t*)scratch + WPB * NSTG * NFAC * H + ((threadIdx.x >> 6) % WPB) * 2 * H;
         c.pf = scratch; c.pb = scratch + 2 * NBLK * H;
-        c.fac = scratch + ((threadIdx.x >> 6) % WPB) * (NSTG * NFAC * H);
+        c.fac = (lds_t*)scratch + ((threadIdx.x >> 6) % WPB) * (NSTG * NFAC * H);
         if constexpr (!ONE)
             static_for<0, KB>([&](auto i) {
                 const int k = w * KB + i;
@@ -403,7 +403,7 @@ struct SeirUde {
     static __device__ __forceinline__ void vjp_store(const Ctx& c, const double* u, const double* lam, double* dlam, int s) {
         Bwd q;
         sweep(c, u, lam, dlam, q, nullptr);
-        double* f = c.fac + s * (NFAC * H) + c.j;
+        lds_t* f = c.fac + s * (NFAC * H) + c.j;
         f[0] = q.a1; f[H] = q.a2; f[2 * H] = q.d1; f[3 * H] = q.d2;
         f[4 * H] = c.j == 0 ? q.x[0] : c.j == 1 ? q.x[1] : c.j == 2 ? q.x[2] : q.d3;
     }
@@ -419,7 +419,7 @@ struct SeirUde {
     static __device__ __forceinline__ void load_factors(const Ctx& c, Fac& f) {
         static_for<0, NST>([&](auto s) {
             if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                const double* p = c.fac + decltype(s)::value * (NFAC * H) + c.j;
+                const lds_t* p = c.fac + decltype(s)::value * (NFAC * H) + c.j;
                 f.a2[s] = p[H]; f.d1[s] = p[2 * H]; f.d2[s] = p[3 * H];
             }
         });
@@ -435,7 +435,7 @@ struct SeirUde {
     static __device__ __forceinline__ void g_extra(const Ctx& c, const Fac& f, int e, double* g) {
         static_for<0, NST>([&](auto s) {
           if constexpr ((MASK >> decltype(s)::value) & 1u) {
-            const double* p = c.fac + decltype(s)::value * (NFAC * H) + 4 * H;  // x0 x1 x2 d3
+            const lds_t* p = c.fac + decltype(s)::value * (NFAC * H) + 4 * H;  // x0 x1 x2 d3
             double v;
             switch (e) {
                 case 0: v = -(f.d1[s] * p[0]); break;
