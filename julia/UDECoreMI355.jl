@@ -33,7 +33,10 @@ struct SolveOpts
     per_trajectory::Int32  # UDE_PT_TSPAN = 1 (tspan is 2 x N), UDE_PT_SAVEAT = 2 (saveat is ns x N)
 end
 
-const KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE = Int32.(0:5)
+const KIND_LV_TRUE, KIND_LV_UDE, KIND_SEIR_TRUE, KIND_SEIR_UDE, KIND_KPP_TRUE, KIND_KPP_UDE, KIND_SEIR_NODE = Int32.(0:6)
+const Real32or64 = Union{Float32,Float64}
+dtypecode(::Type{Float64}) = Int32(0)
+dtypecode(::Type{Float32}) = Int32(1)   # every real-valued array of a call is then Float32 (include/udecore.h: ude_model_desc.dtype)
 const ACT = Dict(identity => Int32(0), tanh => Int32(1), :rbf => Int32(2), :relu => Int32(3))
 pad(t, n, z) = ntuple(i -> i <= length(t) ? oftype(z, t[i]) : z, n)
 
@@ -52,6 +55,9 @@ end
 "`dudt_` of seir_exposure.jl:117-130 with `ann = FastChain(FastDense(3,64,tanh),FastDense(64,64,tanh),FastDense(64,1))`"
 seir_ude(p_) = UDEModel(ModelDesc(KIND_SEIR_UDE, 0, 7, 4481, 3, pad((3, 64, 64, 1), 9, Int32(0)), pad((1, 1, 0), 8, Int32(0)),
                                   0, (Int32(-1), Int32(-1)), 0, 0, 0, (1.0, 1.0), (0.0, 0.0), pad(Tuple(p_), 16, 0.0)))
+"`dudt_node` of seir_exposure.jl:53-66: the pure neural ODE, `ann_node = FastChain(FastDense(7,64,tanh), FastDense(64,64,tanh), FastDense(64,64,tanh), FastDense(64,7))`"
+seir_node(p_) = UDEModel(ModelDesc(KIND_SEIR_NODE, 0, 7, 9287, 4, pad((7, 64, 64, 64, 7), 9, Int32(0)), pad((1, 1, 1, 0), 8, Int32(0)),
+                                   0, (Int32(-1), Int32(-1)), 0, 0, 0, (1.0, 1.0), (0.0, 0.0), pad(Tuple(p_), 16, 0.0)))
 "`nn_ode` of Fisher-KPP-CNN.jl:111-126 (theta = [rx_nn; w1 w2 w3; conv bias; D0])"
 kpp_ude(Nx) = UDEModel(ModelDesc(KIND_KPP_UDE, 0, Nx, 466, 4, pad((1, 10, 20, 10, 1), 9, Int32(0)), pad((1, 1, 1, 0), 8, Int32(0)),
                                  0, (Int32(-1), Int32(-1)), 461, 465, 0, (1.0, 1.0), (0.0, 0.0), pad((), 16, 0.0)))
@@ -62,9 +68,20 @@ kpp_small_ude(Nx) = UDEModel(ModelDesc(KIND_KPP_UDE, 0, Nx, 15, 2, pad((1, 3, 1)
 "`ude_dynamics!` of scenario_2.jl:90-95: theta = [delta; ude(87)], du2 = -delta u2 + NN2"
 lv_ude_s2(; alpha = 1.3) = UDEModel(ModelDesc(KIND_LV_UDE, 0, 2, 88, 4, pad((2, 5, 5, 5, 2), 9, Int32(0)), pad((2, 2, 2, 0), 8, Int32(0)),
                                               1, (Int32(-1), Int32(0)), 0, 0, 0, (1.0, -1.0), (alpha, 0.0), pad((), 16, 0.0)))
-"`ude_dynamics!` of hudson_bay.jl:85-91: theta = [p1; p2; FastChain(87)], third layer tanh"
-lv_ude_hudson() = UDEModel(ModelDesc(KIND_LV_UDE, 0, 2, 89, 4, pad((2, 5, 5, 5, 2), 9, Int32(0)), pad((2, 2, 1, 0), 8, Int32(0)),
+"`ude_dynamics!` of hudson_bay.jl:85-91: theta = [p1; p2; FastChain(87)], third layer tanh (the script is Float32: `lv_ude_hudson(Float32)`)"
+lv_ude_hudson(::Type{T} = Float64) where {T<:Real32or64} = UDEModel(ModelDesc(KIND_LV_UDE, dtypecode(T), 2, 89, 4, pad((2, 5, 5, 5, 2), 9, Int32(0)), pad((2, 2, 1, 0), 8, Int32(0)),
                                      2, (Int32(0), Int32(1)), 0, 0, 0, (1.0, -1.0), (0.0, 0.0), pad((), 16, 0.0)))
+
+"`nn_ode` of scenario_3.jl:103-114 (Float32; ude 1-5-5-5-1 rbf, theta = [ude(76); p2s(4); D0])"
+kpp_s3_ude(::Type{T} = Float32) where {T<:Real32or64} = UDEModel(ModelDesc(KIND_KPP_UDE, dtypecode(T), 26, 81, 4, pad((1, 5, 5, 5, 1), 9, Int32(0)),
+    pad((2, 2, 2, 0), 8, Int32(0)), 0, (Int32(-1), Int32(-1)), 76, 80, 0, (1.0, 1.0), (0.0, 0.0), pad((), 16, 0.0)))
+"`rc_ode` of scenario_3.jl:43-53 / Fisher-KPP-CNN.jl:51-63: consts = the entries of D*lap and r as the script forms them in `T`"
+function kpp_true(Nx, D, r, dx, ::Type{T} = Float64) where {T<:Real32or64}
+    dx2 = T(dx) * T(dx)
+    off, dia = T(1.0 / Float64(dx2)), T(-2.0 / Float64(dx2))
+    UDEModel(ModelDesc(KIND_KPP_TRUE, dtypecode(T), Nx, 0, 0, pad((), 9, Int32(0)), pad((), 8, Int32(0)), 0, (Int32(-1), Int32(-1)), 0, 0, 0,
+                       (1.0, 1.0), (0.0, 0.0), pad((Float64(T(D) * off), Float64(T(D) * dia), Float64(T(r))), 16, 0.0)))
+end
 
 # ---- context ----------------------------------------------------------------------------------------------------
 const CTXS = Dict{Int,Ptr{Cvoid}}()      # one context per device (and host thread: this shim is single-threaded)
@@ -104,37 +121,40 @@ grid(saveat, tspan) = collect(Float64, saveat)
 
 "u0s: n x N matrix (column j = trajectory j); returns (u::Array{Float64,3} n x ns x N, stats 8 x N, retcode N)"
 "`f.(eachcol(U), Ref(θ))` on the device: the right-hand side closure evaluated once per state (columns of `U`)."
-function rhs_ensemble(m::UDEModel, U::Matrix{Float64}, θ::Vector{Float64})
+function rhs_ensemble(m::UDEModel, U::Matrix{T}, θ::Vector{T}) where {T<:Real32or64}
+    m.desc.dtype == dtypecode(T) || error("descriptor dtype and array element type differ")
     n, N = size(U); dU = similar(U); d = Ref(m.desc)
     GC.@preserve U θ dU check(ccall((:ude_rhs_ensemble, libudecore), Cint,
-        (Ptr{Cvoid}, Ref{ModelDesc}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx(), d, N, U, θ, dU))
+        (Ptr{Cvoid}, Ref{ModelDesc}, Int64, Ptr{T}, Ptr{T}, Ptr{T}), ctx(), d, N, U, θ, dU))
     dU
 end
 
-function solve_ensemble(m::UDEModel, alg, u0s::Matrix{Float64}, tspan, θ::Vector{Float64}, ts::Vector{Float64}; kw...)
+function solve_ensemble(m::UDEModel, alg, u0s::Matrix{T}, tspan, θ::Vector{T}, ts::Vector{T}; kw...) where {T<:Real32or64}
+    m.desc.dtype == dtypecode(T) || error("descriptor dtype and array element type differ")
     n, N = size(u0s); ns = length(ts)
-    out = Array{Float64}(undef, n, ns, N); stats = zeros(Int64, 8, N); rc = zeros(Int32, N)
-    d = Ref(m.desc); o = Ref(opts(alg; kw...)); tsp = Float64[tspan[1], tspan[2]]
+    out = Array{T}(undef, n, ns, N); stats = zeros(Int64, 8, N); rc = zeros(Int32, N)
+    d = Ref(m.desc); o = Ref(opts(alg; kw...)); tsp = Float64[tspan[1], tspan[2]]     # tspan: always a pair of host doubles
     GC.@preserve u0s θ ts out stats rc tsp check(ccall((:ude_solve_ensemble, libudecore), Cint,
-        (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
-         Ptr{Float64}, Ptr{Int64}, Ptr{Int32}), ctx(), d, o, N, u0s, tsp, θ, ts, ns, out, stats, rc); allow_failures = true)
+        (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{T}, Ptr{Float64}, Ptr{T}, Ptr{T}, Int32,
+         Ptr{T}, Ptr{Int64}, Ptr{Int32}), ctx(), d, o, N, u0s, tsp, θ, ts, ns, out, stats, rc); allow_failures = true)
     out, stats, rc
 end
 
 "loss(θ) = sum(abs2, data[rows, :] .- Array(solve(...))[rows, :]) over the ensemble and its gradient in ONE call
 (seir_exposure.jl:144-147 with `rows` = 2:4; Fisher-KPP-CNN.jl:140-143; scenario_1.jl:91-94).  `tspans` (2 x N) /
 `tss` (ns x N) give every member its own span and save grid (the segments of scenario_2.jl:104-124)."
-function loss_grad_ensemble(m::UDEModel, alg, u0s::Matrix{Float64}, tspan, θ::Vector{Float64}, ts::AbstractVecOrMat{Float64},
-                            data::Array{Float64,3}; rows = nothing, dev = 0, kw...)
+function loss_grad_ensemble(m::UDEModel, alg, u0s::Matrix{T}, tspan, θ::Vector{T}, ts::AbstractVecOrMat{T},
+                            data::Array{T,3}; rows = nothing, dev = 0, kw...) where {T<:Real32or64}
+    m.desc.dtype == dtypecode(T) || error("descriptor dtype and array element type differ")
     n, N = size(u0s); ns = size(ts, 1)
     flags = (tspan isa AbstractMatrix ? 1 : 0) | (ts isa AbstractMatrix ? 2 : 0)
     mask = rows === nothing ? C_NULL : UInt8[i in rows for i in 1:n]
-    loss = Ref(0.0); lpt = zeros(N); gθ = zeros(length(θ)); gu0 = zeros(n, N); u = Array{Float64}(undef, n, ns, N)
+    loss = Ref(zero(T)); lpt = zeros(T, N); gθ = zeros(T, length(θ)); gu0 = zeros(T, n, N); u = Array{T}(undef, n, ns, N)
     stats = zeros(Int64, 8, N); rc = zeros(Int32, N)
-    d = Ref(m.desc); o = Ref(opts(alg; per_trajectory = flags, kw...)); tsp = collect(Float64, vec(tspan isa Tuple ? [tspan...] : tspan)); tsa = collect(Float64, ts)
+    d = Ref(m.desc); o = Ref(opts(alg; per_trajectory = flags, kw...)); tsp = collect(Float64, vec(tspan isa Tuple ? [tspan...] : tspan)); tsa = collect(T, ts)
     GC.@preserve u0s θ tsa data mask lpt gθ gu0 u stats rc tsp check(ccall((:ude_loss_grad_ensemble, libudecore), Cint,
-        (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
-         Ptr{Float64}, Ptr{UInt8}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
+        (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{T}, Ptr{Float64}, Ptr{T}, Ptr{T}, Int32,
+         Ptr{T}, Ptr{UInt8}, Ref{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Int64}, Ptr{Int32}),
         ctx(dev), d, o, N, u0s, tsp, θ, tsa, ns, data, mask, loss, lpt, gθ, gu0, u, stats, rc), dev)
     loss[], gθ, gu0, u, stats, rc
 end

@@ -84,3 +84,26 @@ def test_f32_descriptor_without_instance_is_refused():
     f = models.ude_dynamics(dtype="float32")          # scenario_1's rbf chain has no Float32 instance
     with pytest.raises(U.UdeError, match="no compiled kernel"):
         U.solve(U.ODEProblem(f, [1.0, 1.0], (0.0, 1.0), np.zeros(87)), U.Tsit5(), saveat=0.5)
+
+
+def test_device_resident_f32_ensemble_matches_host_buffer_path(golden):
+    """DeviceEnsemble on float32 CUDA tensors (the `_dev` entry points with dtype = 1) == the host-buffer entry points"""
+    import torch
+    g = golden(S3)
+    X = np.array(g["X"]["data_colmajor"], dtype=f32).reshape(11, 26)
+    t = np.array(g["t"], dtype=f32)
+    th = np.array(g["initial_parameters"], dtype=f32)
+    f = models.nn_ode(26, models.kpp_s3_chain(), dtype="float32")
+    u0 = np.stack([X[0], X[0] * f32(0.97), X[0] * f32(1.02)])
+    data = np.repeat(X[None], 3, axis=0)
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (float(t[0]), float(t[-1])), th), u0)
+    ref = U.loss_and_gradient(ens, U.Vern7(), data, saveat=t)
+    dev = torch.device("cuda:0")
+    de = U.DeviceEnsemble(f, U.Vern7(), (float(t[0]), float(t[-1])), t, torch.tensor(u0, device=dev), data=torch.tensor(data, device=dev))
+    gd = de.loss_grad(torch.tensor(th, device=dev))
+    torch.cuda.synchronize()
+    assert gd.dtype == torch.float32 and de.u.dtype == torch.float32
+    assert np.array_equal(gd[:-1].cpu().numpy(), ref.grad_theta) and np.array_equal(de.u.cpu().numpy(), ref.u)
+    assert float(gd[-1]) == float(ref.loss) and np.array_equal(de.grad_u0.cpu().numpy(), ref.grad_u0)
+    with pytest.raises(AssertionError):
+        U.DeviceEnsemble(f, U.Vern7(), (0.0, 5.0), t, torch.tensor(u0.astype(np.float64), device=dev))

@@ -442,8 +442,9 @@ def adjoint_pullback(prob, alg, cotangent, saveat=None, sensealg=None, ensemblea
 
 # ---- device-resident path (torch CUDA tensors; used by bench.py and the training loop) -------------------
 class DeviceEnsemble:
-    """Ensemble whose u0 / data / theta already live in HBM (torch float64 CUDA tensors).  Every call
-    enqueues on torch's current stream and returns torch tensors; nothing touches the host."""
+    """Ensemble whose u0 / data / theta already live in HBM (torch CUDA tensors of the problem's scalar type: float64, or
+    float32 for a descriptor with dtype = 1).  Every call enqueues on torch's current stream and returns torch tensors;
+    nothing touches the host."""
 
     def __init__(self, f, alg, tspan, saveat, u0, data=None, row_mask=None, lanes_per_traj=0, max_dense_steps=0,
                  waves_per_simd=0, sensealg=None, **kw):
@@ -451,7 +452,10 @@ class DeviceEnsemble:
         self.torch = torch
         self.f, self.o = f, _opts(alg, sensealg=sensealg, **kw)
         dev = u0.device
-        assert dev.type == "cuda" and u0.dtype == torch.float64
+        rt = torch.float32 if f.dtype == 1 else torch.float64
+        self.rt, self.es = rt, (4 if f.dtype == 1 else 8)
+        assert dev.type == "cuda" and u0.dtype == rt, "u0 must be a CUDA tensor of the problem's scalar type (%s)" % rt
+        assert data is None or data.dtype == rt
         self.eng = Engine.get(dev.index or 0)
         self.launch = (lanes_per_traj, max_dense_steps, waves_per_simd)
         self.N, self.n = u0.shape
@@ -459,14 +463,14 @@ class DeviceEnsemble:
         self.tspan = _np(tspan)
         ts = _saveat_grid(saveat, (float(tspan[0]), float(tspan[1])))
         self.ns = len(ts)
-        self.saveat = torch.tensor(ts, dtype=torch.float64, device=dev)
+        self.saveat = torch.tensor(ts, dtype=rt, device=dev)
         self.data = None if data is None else data.contiguous()
         self.mask = None if row_mask is None else torch.tensor(list(row_mask), dtype=torch.uint8, device=dev)
-        self.u = torch.empty((self.N, self.ns, self.n), dtype=torch.float64, device=dev)
+        self.u = torch.empty((self.N, self.ns, self.n), dtype=rt, device=dev)
         self.stats = torch.zeros((self.N, NSTATS), dtype=torch.int64, device=dev)
         self.retcode = torch.zeros(self.N, dtype=torch.int32, device=dev)
-        self.grad = torch.zeros(f.n_param + 1, dtype=torch.float64, device=dev)  # [grad(np); loss]
-        self.grad_u0 = torch.zeros((self.N, self.n), dtype=torch.float64, device=dev)
+        self.grad = torch.zeros(f.n_param + 1, dtype=rt, device=dev)  # [grad(np); loss]
+        self.grad_u0 = torch.zeros((self.N, self.n), dtype=rt, device=dev)
 
     def _bind(self):
         self.eng.set_launch(*self.launch)
@@ -502,7 +506,7 @@ class DeviceEnsemble:
         self._bind()
         L, e = self.eng.L, self.eng
         np_ = self.f.n_param
-        loss_ptr = C.c_void_p(self.grad.data_ptr() + 8 * np_)
+        loss_ptr = C.c_void_p(self.grad.data_ptr() + self.es * np_)
         e.check(L.ude_loss_grad_ensemble_dev(e.h, C.byref(self.f), C.byref(self.o), self.N, _ptr(self.u0),
                                              _ptr(self.tspan), _ptr(theta), _ptr(self.saveat), self.ns,
                                              _ptr(self.data), _ptr(self.mask), loss_ptr, None, _ptr(self.grad),
