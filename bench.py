@@ -30,10 +30,16 @@ FLOPS = {"lv": (160.0, 550.0), "seir": (8744.0, 26000.0), "kpp": (0.87e6, 2.6e6)
          "node": (18176.0, 54500.0)}
 
 
-SENSE_NAME = {"adjoint": "InterpolatingAdjoint", "discrete": "discretise-then-optimise (ForwardDiffSensitivity-equivalent)"}
+SENSE_NAME = {"adjoint": "InterpolatingAdjoint", "discrete": "discretise-then-optimise (ForwardDiffSensitivity-equivalent)",
+              "fast": "InterpolatingAdjoint with lambda-only error control (SURVEY 8(b) fast mode; not the reference's step sequence)"}
 # which unit dominates each backward kernel: the LV / SEIR kernels run on the FP64 VALU, Fisher-KPP on the FP64 matrix cores
 # (both peaks are 78.6 TF; the schema's "bound" offers hbm | mfma)
-BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint)", "discrete": "dadj_kernel (frozen-step reverse sweep)"}
+BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint)", "discrete": "dadj_kernel (frozen-step reverse sweep)",
+              "fast": "adj_kernel, fast mode (lambda-only error control)"}
+
+
+def SENSE_OBJ(U, name):
+    return U.ForwardDiffSensitivity() if name == "discrete" else U.FastInterpolatingAdjoint() if name == "fast" else None
 
 
 def synth_inputs_other(workload, N, rank, device):
@@ -122,7 +128,7 @@ def pmc_traffic(a):
     """HBM bytes per launch of the dominant backward kernel of the default command of each workload, as collected by
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (tools/prof_r02.sh; counters in KB) and committed under profiles/ --
     PMC passes cannot run inside the timed bench itself.  None when the run is not that command or the summary is absent."""
-    if a.net != "s1" or a.alg != "tsit5" or a.lanes or a.waves or a.traj:
+    if a.net != "s1" or a.alg != "tsit5" or a.lanes or a.waves or a.traj or a.sensealg == "fast":
         return None
     kern = "adj_kernel<" if a.sensealg == "adjoint" else "dadj_kernel<"
     return pmc_traffic_file("r02_pmc_%s.md" % a.workload, "`void " + kern)
@@ -262,8 +268,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = library default)")
     ap.add_argument("--waves", type=int, default=0, help="adjoint kernel variant: waves per SIMD (0 = default)")
     ap.add_argument("--alg", default="tsit5")
-    ap.add_argument("--sensealg", default="adjoint", choices=["adjoint", "discrete"],
-                    help="adjoint = InterpolatingAdjoint (the north-star path); discrete = frozen-step reverse sweep (a9)")
+    ap.add_argument("--sensealg", default="adjoint", choices=["adjoint", "discrete", "fast"],
+                    help="adjoint = InterpolatingAdjoint (the north-star path); discrete = frozen-step reverse sweep (a9); "
+                         "fast = interpolating adjoint with lambda-only error control (opt-in, not the reference's step sequence)")
     ap.add_argument("--net", default="s1", choices=["s1", "tanh32"],
                     help="lv workload: s1 = the reference 2-5-5-5-2 rbf chain (headline), tanh32 = BASELINE's '2-layer tanh' 2-32-2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -299,7 +306,7 @@ def main():
             theta_h = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(7))
         ens = U.DeviceEnsemble(f_lv, alg, (0.0, 3.0), t, u0_d, data=data, lanes_per_traj=a.lanes,
                                waves_per_simd=a.waves, abstol=1e-6, reltol=1e-6,
-                               sensealg=U.ForwardDiffSensitivity() if a.sensealg == "discrete" else None)
+                               sensealg=SENSE_OBJ(U, a.sensealg))
         wl_name = ("BASELINE configs[1]: LV UDE (%s), %d trajectories per GPU, "
                    "%s abstol=reltol=1e-6, 31 save points, loss + %s gradient"
                    % ("2-5-5-5-2 rbf, 87 params, theta_init of scenario_1" if a.net == "s1" else "2-32-2 tanh, 162 params, 0.1 x glorot", N, a.alg,
@@ -308,7 +315,7 @@ def main():
         w = synth_inputs_other(a.workload, N, rank, device)
         theta_h, u0_d, t, data, mask = w["theta"], w["u0"], w["t"], w["data"], w["mask"]
         ens = U.DeviceEnsemble(w["f"], w["alg"], w["tspan"], t, u0_d, data=data, row_mask=mask, lanes_per_traj=a.lanes,
-                               sensealg=U.ForwardDiffSensitivity() if a.sensealg == "discrete" else None, **w["tol"])
+                               sensealg=SENSE_OBJ(U, a.sensealg), **w["tol"])
         wl_name = {"seir": "BASELINE configs[2] per-GPU share: SEIR exposure UDE (7 states, NN 3-64-64-1 tanh, 4481 params), %d trajectories "
                            "per GPU, Vern7 abstol=reltol=1e-6, 22 save points, loss rows 2:4 + %s gradient",
                    "node": "SEIR neural ODE (seir_exposure.jl:53-83: 7 states, FastChain 7-64-64-64-7 tanh, 9287 params) on the configs[2] ensemble, %d "

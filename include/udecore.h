@@ -40,7 +40,13 @@ enum {
 enum { UDE_ACT_IDENTITY = 0, UDE_ACT_TANH = 1, UDE_ACT_RBF = 2 /* scenario_1.jl:59 */, UDE_ACT_RELU = 3 };
 /* sensealg: InterpolatingAdjoint(autojacvec=ReverseDiffVJP()) seir_exposure.jl:140, Fisher-KPP-CNN.jl:136;
  * discretise-then-optimise = the frozen-step derivative that ForwardDiffSensitivity() requests, scenario_1.jl:86 */
-enum { UDE_SENSE_INTERPOLATING_ADJOINT = 0, UDE_SENSE_DISCRETE = 1 };
+enum { UDE_SENSE_INTERPOLATING_ADJOINT = 0, UDE_SENSE_DISCRETE = 1,
+       /* SURVEY.md 8(b) `fast` mode: the interpolating adjoint with ONLY lambda under error control.  The parameter cotangent
+        * is carried as a quadrature on the adjoint's accepted steps (mu += dt * sum_s b_s g_s): no per-parameter error
+        * estimate, no candidate/commit (cheaper steps, not fewer).  Not the step sequence of upstream's InterpolatingAdjoint
+        * (which keeps mu in the error norm) -- an opt-in; gradients agree with mode 0 to the solver tolerance.  Shared time
+        * grids only (per_trajectory = 0). */
+       UDE_SENSE_INTERPOLATING_ADJOINT_FAST = 2 };
 enum { UDE_ALG_TSIT5 = 0 /* Tsit5() scenario_1.jl:191 */, UDE_ALG_VERN7 = 1 /* Vern7() scenario_1.jl:84 */ };
 /* per-trajectory return codes mirror the SciML retcodes stored in the reference's artifacts */
 enum { UDE_RET_SUCCESS = 0, UDE_RET_MAXITERS = 1, UDE_RET_DTLESSTHANMIN = 2, UDE_RET_UNSTABLE = 3,

@@ -40,7 +40,9 @@ enum {
 };
 enum { UDEO_ACT_IDENTITY = 0, UDEO_ACT_TANH = 1, UDEO_ACT_RBF = 2, UDEO_ACT_RELU = 3 };
 enum { UDEO_ALG_TSIT5 = 0, UDEO_ALG_VERN7 = 1 };
-enum { UDEO_SENSE_INTERPOLATING_ADJOINT = 0, UDEO_SENSE_DISCRETE = 1 };
+enum { UDEO_SENSE_INTERPOLATING_ADJOINT = 0, UDEO_SENSE_DISCRETE = 1,
+       UDEO_SENSE_FAST = 2 /* interpolating adjoint with lambda-only error control (SURVEY 8(b) `fast`): the parameter
+                              cotangent rides along as a quadrature on the adjoint's own steps; not an upstream step sequence */ };
 enum { UDEO_RET_SUCCESS = 0, UDEO_RET_MAXITERS = 1, UDEO_RET_DTLESSTHANMIN = 2, UDEO_RET_UNSTABLE = 3 };
 
 /* Same field layout as include/udecore.h:ude_model_desc so one ctypes.Structure serves both. */
@@ -71,7 +73,7 @@ typedef struct {
     double dt0;         /* >0 -> use as initial dt instead of the Hairer heuristic */
     double qmin, qmax, gamma, qoldinit; /* <=0 -> 0.2, 10, 0.9, 1e-4 */
     double beta1, beta2;                /* <=0 -> 7/(10 order), 2/(5 order) */
-    int32_t sensealg;   /* UDEO_SENSE_*: 0 InterpolatingAdjoint (a10), 1 discretise-then-optimise (a9 / N2) */
+    int32_t sensealg;   /* UDEO_SENSE_*: 0 InterpolatingAdjoint (a10), 1 discretise-then-optimise (a9 / N2), 2 fast */
     int32_t reserved;
 } udeo_solve_opts;
 

@@ -488,6 +488,8 @@ static void FN(interp)(int alg, REAL th, REAL dt, const REAL* uprev, REAL* const
 typedef struct {
     REAL abstol, reltol, dtmax, qmin, qmax, gamma, qoldinit, beta1, beta2, dt0;
     int alg, order, maxiters;
+    int nerr; /* > 0: only the first nerr components enter the error norm and the initial-dt norms (the `fast` adjoint mode:
+               * lambda-only error control, the parameter cotangent is carried as a quadrature) */
 } FN(ropts);
 
 static void FN(resolve_opts)(const udeo_solve_opts* o, REAL t0, REAL tf, FN(ropts)* r) {
@@ -504,6 +506,7 @@ static void FN(resolve_opts)(const udeo_solve_opts* o, REAL t0, REAL tf, FN(ropt
     r->beta2 = (REAL)(o->beta2 > 0 ? o->beta2 : 2.0 / (5.0 * r->order));
     r->beta1 = (REAL)(o->beta1 > 0 ? o->beta1 : 7.0 / (10.0 * r->order));
     r->dt0 = (REAL)o->dt0;
+    r->nerr = 0;
 }
 
 /* ARITH-SPEC: the three norms of the initial-dt heuristic enter dt at full precision (no Float32 controller
@@ -523,14 +526,15 @@ static inline void FN(dd_acc)(REAL* hi, REAL* lo, REAL x) {
 static REAL FN(initdt)(const FN(ropts)* r, FN(rhs_fn) f, void* ctx, const REAL* u0, REAL t, REAL tdir,
                        int nz, REAL* f0, REAL* w1, REAL* w2, int* nan_out) {
     REAL* sk = w1;
+    const int nn = (r->nerr > 0 && r->nerr < nz) ? r->nerr : nz; /* components under error control */
     for (int i = 0; i < nz; ++i) sk[i] = R_FMA(R_FABS(u0[i]), r->reltol, r->abstol);
     REAL hi = 0, lo = 0;
-    for (int i = 0; i < nz; ++i) { REAL q = u0[i] / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
-    const REAL d0 = R_SQRT((hi + lo) / (REAL)nz);
+    for (int i = 0; i < nn; ++i) { REAL q = u0[i] / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
+    const REAL d0 = R_SQRT((hi + lo) / (REAL)nn);
     f(ctx, t, u0, f0);
     hi = 0; lo = 0;
-    for (int i = 0; i < nz; ++i) { REAL q = f0[i] / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
-    const REAL d1 = R_SQRT((hi + lo) / (REAL)nz);
+    for (int i = 0; i < nn; ++i) { REAL q = f0[i] / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
+    const REAL d1 = R_SQRT((hi + lo) / (REAL)nn);
     if (d1 != d1) { *nan_out = 1; return (REAL)0; }
     REAL dt0 = (d0 < (REAL)1e-5 || d1 < (REAL)1e-5) ? (REAL)1e-6 : (d0 / d1) / (REAL)100;
     if (dt0 > r->dtmax) dt0 = r->dtmax;
@@ -541,8 +545,8 @@ static REAL FN(initdt)(const FN(ropts)* r, FN(rhs_fn) f, void* ctx, const REAL* 
     for (int i = 0; i < nz; ++i) u1[i] = R_FMA(dt0t, f0[i], u0[i]);
     f(ctx, t + dt0t, u1, f1);
     hi = 0; lo = 0;
-    for (int i = 0; i < nz; ++i) { REAL q = (f1[i] - f0[i]) / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
-    const REAL d2 = R_SQRT((hi + lo) / (REAL)nz) / dt0;
+    for (int i = 0; i < nn; ++i) { REAL q = (f1[i] - f0[i]) / sk[i]; FN(dd_acc)(&hi, &lo, q * q); }
+    const REAL d2 = R_SQRT((hi + lo) / (REAL)nn) / dt0;
     const REAL mx = d1 > d2 ? d1 : d2;
     REAL dt1;
     if (mx <= (REAL)1e-15) {
@@ -646,12 +650,13 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
             /* ARITH-SPEC: the sum of squares is accumulated in double for both scalar types (Float32: order-independent after
              * the rounding back to float -- the kernels sum over lanes in a tree; upstream's @simd sum has no fixed order) */
             double s = 0;
-            for (int i = 0; i < nz; ++i) {
+            const int nn = (r->nerr > 0 && r->nerr < nz) ? r->nerr : nz;
+            for (int i = 0; i < nn; ++i) {
                 const REAL a0 = R_FABS(uprev[i]), a1 = R_FABS(u[i]);
                 const REAL res = utilde[i] / R_FMA((a0 > a1 ? a0 : a1), r->reltol, r->abstol);
                 s = fma((double)res, (double)res, s);
             }
-            const REAL EEst = R_SQRT((REAL)s / (REAL)nz);
+            const REAL EEst = R_SQRT((REAL)s / (REAL)nn);
             /* ---- loopfooter!: stepsize_controller! (PIController) ---- */
             REAL q;
             if (EEst == 0) {
@@ -1041,6 +1046,7 @@ static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const
     FN(adj_tstop)(&ac, tf, z); /* init_cb: jump at t = tf before the first step */
     FN(ropts) r;
     FN(resolve_opts)(o, t0, tf, &r);
+    if (o->sensealg == UDEO_SENSE_FAST) r.nerr = n; /* lambda-only error control */
     r.dt0 = 0;
     ret = FN(integrate)(&r, nz, FN(adj_rhs), &ac, z, tf, tst, nt, 0, 0, FN(adj_tstop), &ac,
                         &stats[4], &stats[5], &stats[6], 0);

@@ -1,0 +1,90 @@
+"""UDE_SENSE_INTERPOLATING_ADJOINT_FAST (SURVEY.md 8(b) `fast` mode): the interpolating adjoint with only lambda under
+error control, the parameter cotangent a quadrature on the accepted steps.  Device against the oracle's same mode: per
+trajectory bit-identical (backward step counts, dL/du0, and for one trajectory every gradient entry); against the default
+(parity) mode: same forward pass, gradients equal to the solver tolerance."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import universal_differential_equations_amd as U
+from universal_differential_equations_amd import models
+from test_gpu_parity import REL_GRAD_SUM, assert_bitwise, check_per_trajectory, seir_inputs, kpp_case
+from test_gpu_node import node_case, MASK
+
+pytestmark = pytest.mark.gpu
+S1 = "Scenario_1_recovery_0.005"
+FAST = U.FastInterpolatingAdjoint
+
+
+@pytest.mark.parametrize("alg,oalg", [(U.Tsit5, O.TSIT5), (U.Vern7, O.VERN7)])
+def test_lv_fast_mode_matches_oracle_and_parity_mode(golden, alg, oalg):
+    g = golden(S1)
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+    t = np.array(g["solution"]["t"])
+    th = np.array(g["initial_parameters"])
+    rng = np.random.default_rng(9)
+    N = 25
+    u0 = X[0] * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))
+    data = np.repeat(X[None], N, axis=0)
+    ens = U.EnsembleProblem(U.ODEProblem(models.ude_dynamics(), u0[0], (t[0], t[-1]), th), u0)
+    r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST())
+    ref = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(oalg, 1e-6, 1e-6, sensealg=2), u0, [t[0], t[-1]], th, t, data, nthreads=8)
+    check_per_trajectory(r, ref)
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+    full = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6)
+    assert_bitwise(r.u, full.u, "forward pass") and None
+    # (not necessarily fewer backward steps: the parity mode's RMS over n + np components dilutes lambda's error, the
+    # lambda-only norm does not -- what the fast mode saves is the per-slot error estimate, its divisions and accumulators)
+    assert np.linalg.norm(r.grad_theta - full.grad_theta) < 2e-4 * np.linalg.norm(full.grad_theta)
+    # one trajectory: every entry of the gradient carries the oracle's bits
+    one = U.loss_and_gradient(U.ODEProblem(models.ude_dynamics(), u0[3], (t[0], t[-1]), th), alg(), data[:1], saveat=t,
+                              abstol=1e-6, reltol=1e-6, sensealg=FAST())
+    ref1 = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(oalg, 1e-6, 1e-6, sensealg=2), u0[3], [t[0], t[-1]], th, t, data[:1])
+    assert_bitwise(one.grad_theta, ref1["grad_theta"], "dL/dtheta")
+
+
+def test_seir_fast_mode_matches_oracle():
+    """deferred parameter cotangent: the slot sums are formed on accepted steps only (commit_slots)"""
+    N = 8
+    u0, t = seir_inputs(N)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+    th = models.seir_chain().glorot_uniform(np.random.default_rng(11))
+    th[-65:-1] *= 10.0
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 21.0), th), u0)
+    for alg, oalg in ((U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)):
+        r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST())
+        ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6, sensealg=2), u0, [0.0, 21.0], th, t, truth, row_mask=MASK, nthreads=8)
+        check_per_trajectory(r, ref)
+        assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+        full = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
+        assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
+
+
+def test_node_and_kpp_fast_mode_match_oracle():
+    u0, th = node_case(3, 100.0)
+    t = np.arange(0.0, 6.5, 1.0)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 6.0], [], t)
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_node(), u0[0], (0.0, 6.0), th), u0)
+    r = U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST())
+    ref = O.loss_grad_ensemble(O.seir_node(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=2), u0, [0.0, 6.0], th, t, truth, row_mask=MASK, nthreads=3)
+    check_per_trajectory(r, ref)
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+    # Fisher-KPP, 26 points and the 1024-point matrix-core kernels
+    for nx, N in ((26, 4), (1024, 2)):
+        thk, u0k, tk, truthk = kpp_case(nx, N, models.kpp_chain(), None)
+        ensk = U.EnsembleProblem(U.ODEProblem(models.nn_ode(nx), u0k[0], (0.0, 5.0), thk), u0k)
+        rk = U.loss_and_gradient(ensk, U.Tsit5(), truthk, saveat=tk, sensealg=FAST())
+        refk = O.loss_grad_ensemble(O.kpp_ude(nx), O.opts(O.TSIT5, sensealg=2), u0k, [0.0, 5.0], thk, tk, truthk, nthreads=4)
+        check_per_trajectory(rk, refk)
+        assert np.linalg.norm(rk.grad_theta - refk["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(refk["grad_theta"])
+
+
+def test_fast_mode_with_per_trajectory_grids_is_refused(golden):
+    g = golden(S1)
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+    t = np.array(g["solution"]["t"])
+    th = np.array(g["initial_parameters"])
+    u0 = np.stack([X[0], X[0]])
+    ens = U.EnsembleProblem(U.ODEProblem(models.ude_dynamics(), u0[0], (t[0], t[-1]), th), u0, tspans=np.array([[0.0, 3.0], [0.0, 3.0]]))
+    with pytest.raises(U.UdeError, match="per-trajectory"):
+        U.loss_and_gradient(ens, U.Tsit5(), np.repeat(X[None], 2, axis=0), saveat=t, sensealg=FAST())

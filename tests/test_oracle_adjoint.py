@@ -402,3 +402,25 @@ def test_scalar_kernels_within_a_few_ulp_of_libm():
     assert worst["exp"] <= 2 and worst["tanh"] <= 4 and worst["log"] <= 2 and worst["log10"] <= 3, worst
     assert worst["pow10"] <= 40 and worst["pow"] <= 2000, worst   # exp(y log x): the argument's rounding is amplified by |y log x|
     assert L.udeo_log(1.0) == 0.0 and L.udeo_log10(1.0) == 0.0 and L.udeo_tanh(0.0) == 0.0 and L.udeo_exp(0.0) == 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY.md 8(b) `fast` adjoint mode (sensealg = 2): lambda-only error control, the parameter cotangent as a quadrature on
+# the accepted steps.  Not an upstream step sequence -- pinned against the parity mode and finite differences.
+# ---------------------------------------------------------------------------------------------------------------------
+def test_fast_adjoint_mode_agrees_with_parity_mode_and_finite_differences(golden):
+    g, X, t = s1_setup(golden)
+    th = np.array(g["initial_parameters"])
+    m = O.lv_ude_s1()
+    full = O.loss_grad_ensemble(m, O.opts(O.TSIT5, 1e-8, 1e-8), X[0], [t[0], t[-1]], th, t, X[None])
+    fast = O.loss_grad_ensemble(m, O.opts(O.TSIT5, 1e-8, 1e-8, sensealg=2), X[0], [t[0], t[-1]], th, t, X[None])
+    assert np.array_equal(fast["stats"][:, :4], full["stats"][:, :4]) and fast["loss"] == full["loss"]     # the forward pass is the same
+    assert fast["stats"][0, 5] > 0 and fast["stats"][0, 5] != full["stats"][0, 5]     # its own backward step sequence
+    gn = np.linalg.norm(full["grad_theta"])
+    assert np.linalg.norm(fast["grad_theta"] - full["grad_theta"]) < 1e-5 * gn
+    assert np.linalg.norm(fast["grad_u0"] - full["grad_u0"]) < 1e-6 * np.linalg.norm(full["grad_u0"])
+    rng = np.random.default_rng(2)
+    dirs = [rng.standard_normal(th.size) / np.sqrt(th.size) for _ in range(4)]
+    fd = _fd_directional(lambda x: s1_loss(x, X, t, O.VERN7, 1e-12), th, dirs, 1e-6)
+    an = np.array([fast["grad_theta"] @ d for d in dirs])
+    assert np.allclose(an, fd, rtol=2e-5, atol=1e-6 * np.abs(fd).max()), (an, fd)

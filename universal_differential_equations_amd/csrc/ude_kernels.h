@@ -159,6 +159,9 @@ struct Driver {
     static constexpr bool SLOT_FSAL = USE_FSAL && NSL > 0;  // stage-0 slot derivative handed over in LDS
     // deferred slots: the system keeps per-stage factors and forms the slot sums / error norm / candidate at step end
     static constexpr bool DEFER = Sys::DEFERRED;
+    // `fast` adjoint mode (UDE_SENSE_FAST): only the replicated state (lambda) is under error control; the slot state (the
+    // parameter cotangent) is a quadrature carried along on the accepted steps -- no error accumulators, no divisions
+    static constexpr bool FAST = Sys::FAST;
     static_assert(!DEFER || (NSL == 0 && !USE_FSAL), "deferred slots: the system owns the slot state");
     // stage derivatives of a REPLICATED state are stored once per group (all lanes read/write the same word)
     // CPL: stage derivatives stored one component per lane (lane c <-> component c): the weighted stage sums are
@@ -211,10 +214,13 @@ struct Driver {
             else static_for<0, NR>([&](auto c) { K(0, c) = f0[c]; });
             // norms in real-real: slots first (lane-parallel), then the replicated components once
             real h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
-            if constexpr (DEFER) {
+            if constexpr (DEFER && !FAST) {
                 sys.slot_init01(o, h0, l0, h1, l1);
                 group_dd_sum<G>(h0, l0);
                 group_dd_sum<G>(h1, l1);
+            } else if constexpr (NSL > 0 && FAST) {
+                static_for<0, NSL>([&](auto c) { gtmp[c * BLOCK] = gs0[c]; });  // (FSAL hand-over only)
+                asm volatile("" ::: "memory");
             } else if constexpr (NSL > 0) {
                 static_for<0, NSL>([&](auto c) {
                     const real m = mu[c * BLOCK];
@@ -266,10 +272,10 @@ struct Driver {
                 if constexpr (DEFER) sys.eval_store(t + dt0t, z1, f1, 1);
                 else sys.eval(t + dt0t, z1, f1, gs1);
                 real h2 = 0.0, l2 = 0.0;
-                if constexpr (DEFER) {
+                if constexpr (DEFER && !FAST) {
                     sys.slot_init2(o, h2, l2);
                     group_dd_sum<G>(h2, l2);
-                } else if constexpr (NSL > 0) {
+                } else if constexpr (NSL > 0 && !FAST) {
                     static_for<0, NSL>([&](auto c) {
                         const real sk = rfma(rabs(mu[c * BLOCK]), o.reltol, o.abstol);
                         const real q = (gs1[c] - gtmp[c * BLOCK]) / sk;
@@ -339,7 +345,7 @@ struct Driver {
                 static_for<0, NSL>([&](auto c) {
                     const real g0 = gtmp[c * BLOCK];
                     accb[c] = bs * g0;
-                    acce[c] = es * g0;
+                    if constexpr (!FAST) acce[c] = es * g0;
                 });
             }
             for (int s = USE_FSAL ? 1 : 0; s < S; ++s) {
@@ -371,12 +377,12 @@ struct Driver {
                     if (s == 0) {
                         static_for<0, NSL>([&](auto c) {
                             accb[c] = bs * gs[c];
-                            acce[c] = es * gs[c];
+                            if constexpr (!FAST) acce[c] = es * gs[c];
                         });
                     } else {
                         static_for<0, NSL>([&](auto c) {
                             accb[c] = rfma(bs, gs[c], accb[c]);
-                            acce[c] = rfma(es, gs[c], acce[c]);
+                            if constexpr (!FAST) acce[c] = rfma(es, gs[c], acce[c]);
                         });
                     }
                     if constexpr (SLOT_FSAL) {
@@ -417,8 +423,8 @@ struct Driver {
                 ss = afma(res, res, ss);
             });
             if constexpr (Sys::STATE_DISTRIBUTED) ss = group_sum<G>(ss);
-            if constexpr (DEFER) ss += group_sum<G>((acc_t)sys.slot_step(dt, tab, o));
-            if constexpr (NSL > 0) {
+            if constexpr (DEFER && !FAST) ss += group_sum<G>((acc_t)sys.slot_step(dt, tab, o));
+            if constexpr (NSL > 0 && !FAST) {
                 acc_t ps = 0.0;
                 static_for<0, NSL>([&](auto c) {
                     const real m0 = mu[c * MS];
@@ -489,6 +495,10 @@ struct Driver {
                     const int hr = sys.accepted(tprev, t, dt, z, znew, kl, lazy);
                     if (hr != RET_SUCCESS) { ret = hr; done = true; }
                 }
+                if constexpr (FAST) {  // (with the step size this step USED)
+                    static_for<0, NSL>([&](auto c) { mu[c * MS] = rfma(dt, accb[c], mu[c * MS]); });  // the same fma as the candidate of the parity mode
+                    if constexpr (DEFER) sys.slot_commit(dt, tab);
+                }
                 dt = dtnew;
                 bool bad = false;
                 static_for<0, NR>([&](auto c) {
@@ -498,8 +508,10 @@ struct Driver {
                 if constexpr (Sys::STATE_DISTRIBUTED) {  // same decision on every lane of the trajectory
                     if constexpr (G > 64) bad = __syncthreads_or(bad); else bad = __any(bad);
                 }
-                static_for<0, NSL>([&](auto c) { mu[c * MS] = accb[c]; });
-                if constexpr (DEFER) sys.slot_accept();
+                if constexpr (!FAST) {
+                    static_for<0, NSL>([&](auto c) { mu[c * MS] = accb[c]; });
+                    if constexpr (DEFER) sys.slot_accept();
+                }
                 if constexpr (USE_FSAL && CPL) K1(0) = K1(S - 1);
                 else if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
                 if constexpr (SLOT_FSAL) { real* tsw = gtmp; gtmp = gtmp2; gtmp2 = tsw; }
@@ -556,7 +568,7 @@ struct FwdSys {
     TimeGrid<PT> tg;
     __device__ __forceinline__ real dtmax(const OptsR& o) const { return tg.DTMAX(o); }
     static constexpr int NR = Model::NS, NSL = 0;
-    static constexpr bool ALWAYS_K0 = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
+    static constexpr bool ALWAYS_K0 = false, FAST = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     static constexpr bool SLOTS_GLOBAL = false, CPL = Model::CPL, DEFERRED = false;
     typename Model::Ctx mctx;
     const KParams* p;
@@ -769,6 +781,7 @@ struct AdjSys {
     TimeGrid<PT> tg;
     __device__ __forceinline__ real dtmax(const OptsR& o) const { return tg.DTMAX(o); }
     static constexpr bool DEFERRED = Model::DEFERRED;
+    static constexpr bool FAST = (VAR == 3);  // UDE_SENSE_FAST: lambda-only error control
     static constexpr int NR = Model::NS, NSL = (DEFERRED || VAR == 9) ? 0 : Model::NSL;
     static constexpr bool STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     // LDS-slot models re-evaluate stage 0 every step (its parameter cotangent is folded straight into the shared
@@ -886,6 +899,10 @@ struct AdjSys {
         if constexpr (DEFERRED)
             return Model::template step_slots<Tab::S, stage_mask()>(mctx, tab->B, tab->BT, dt, o.abstol, o.reltol, mu_cur, mu_new, ms);
         else return 0.0;
+    }
+    // fast mode: mu += dt * sum_s B_s g_s for every slot, in place, on ACCEPTED steps only
+    __device__ __forceinline__ void slot_commit(real dt, const TabDev* tab) {
+        if constexpr (DEFERRED) Model::template commit_slots<Tab::S, stage_mask()>(mctx, tab->B, dt, mu_cur, ms);
     }
     __device__ __forceinline__ void slot_accept() {
         real* t = mu_cur; mu_cur = mu_new; mu_new = t;
@@ -1007,7 +1024,7 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         sys.load_interval(sys.nsteps - 1);
         sys.at_tstop(sys.tg.TF(p), lam);  // init_cb: the jump at t = tf precedes the first step
         typename Drv::Stats st;
-        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, sys.tg.TF(p), real(-1), (real)(p.n_state + p.n_param), st, gtmp, gtmp2, MS);
+        const int ret = Drv::run(sys, p.o, p.tab, lam, kl, mu_lds, sys.tg.TF(p), real(-1), (real)(Sys::FAST ? p.n_state : p.n_state + p.n_param), st, gtmp, gtmp2, MS);
         if constexpr (Model::DEFERRED) mu_final = sys.mu_cur;
         if (r == 0) {
             if (p.stats) {

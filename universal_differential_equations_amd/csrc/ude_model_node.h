@@ -301,6 +301,20 @@ struct SeirNode {
         });
         return ps;
     }
+    // fast adjoint mode: mu += dt * sum_s B_s g_s in place, on accepted steps only (no error half, no division)
+    template <int NST, unsigned MASK>
+    static __device__ __forceinline__ void commit_slots(const Ctx& c, const double* B, double dt, double* mu, int ms) {
+        static_assert(MASK & 1u, "the first stage starts the chains");
+        double bb[NST];
+        static_for<0, NST>([&](auto s) { bb[s] = uniform_real(B[s]); });
+        for_each_slot<NST, MASK>(c, mu, ms, [&](int slot, const double* g, double m0) {
+            double ab = bb[0] * g[0];
+            static_for<1, NST>([&](auto s) {
+                if constexpr ((MASK >> decltype(s)::value) & 1u) ab = __builtin_fma(bb[s], g[s], ab);
+            });
+            mu[(size_t)slot * ms] = __builtin_fma(dt, ab, m0);
+        });
+    }
     static __device__ __forceinline__ void init_norm01(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
                                                        double& h0, double& l0, double& h1, double& l1) {
         for_each_slot<1, 1u>(c, mu, ms, [&](int, const double* g, double m) {

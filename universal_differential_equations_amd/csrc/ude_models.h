@@ -505,6 +505,23 @@ struct SeirUde {
         });
         return ps;
     }
+    // fast adjoint mode (lambda-only error control): mu += dt * sum_s B_s g_s in place, on accepted steps only -- the
+    // same chain and the same final fma as the candidate of step_slots, without the error half and its division
+    template <int NST, unsigned MASK>
+    static __device__ __forceinline__ void commit_slots(const Ctx& c, const double* B, double dt, double* mu, int ms) {
+        static_assert(MASK & 1u, "the first stage starts the chains");
+        Fac f;
+        load_factors<NST, MASK>(c, f);
+        double bb[NST];
+        static_for<0, NST>([&](auto s) { bb[s] = uniform_real(B[s]); });
+        for_each_slot<NST, MASK>(c, f, mu, ms, [&](int slot, const double* g, double m0) {
+            double ab = bb[0] * g[0];
+            static_for<1, NST>([&](auto s) {
+                if constexpr ((MASK >> decltype(s)::value) & 1u) ab = __builtin_fma(bb[s], g[s], ab);
+            });
+            mu[(size_t)slot * ms] = __builtin_fma(dt, ab, m0);
+        });
+    }
     // initial-dt norms: stage 0 holds g0 = f0's slot part, stage 1 (second call) g1
     static __device__ __forceinline__ void init_norm01(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
                                                        double& h0, double& l0, double& h1, double& l1) {

@@ -10,6 +10,7 @@ struct Launch {
     void (*dadj)(const KParams);  // discretise-then-optimise reverse sweep (a9)
     void (*rhs)(const KParams);   // one right-hand-side evaluation per state
     void (*fwd_pt)(const KParams), (*adj_pt)(const KParams), (*dadj_pt)(const KParams);  // per-trajectory tspan / saveat
+    void (*adj_fast)(const KParams);  // UDE_SENSE_FAST: lambda-only error control (shared time grid only)
     int nf;  // dense fields per step
     int G, block;
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
@@ -36,6 +37,7 @@ inline Launch make_launch() {
     l.fwd_pt = fwd_kernel<Model, Tab, G, BLOCK, true>;
     l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true, VAR>;
     l.dadj_pt = dadj_kernel<Model, Tab, G, BLOCK, true>;
+    l.adj_fast = adj_kernel<Model, Tab, G, BLOCK, false, 3>;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;

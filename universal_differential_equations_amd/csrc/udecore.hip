@@ -521,10 +521,12 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.grad_part = (double*)c->grad_part.p;
     p.grad_u0 = grad_u0;
     const bool discrete = o->sensealg == UDE_SENSE_DISCRETE;
-    if (o->sensealg != UDE_SENSE_INTERPOLATING_ADJOINT && !discrete) return fail(c, UDE_ERR_INVALID, "unknown sensealg %d", o->sensealg);
+    const bool fast = o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST;
+    if (o->sensealg != UDE_SENSE_INTERPOLATING_ADJOINT && !discrete && !fast) return fail(c, UDE_ERR_INVALID, "unknown sensealg %d", o->sensealg);
     if ((rc = setup_time_grids(c, o, N, tspan, p))) return rc;
     const bool pt = o->per_trajectory != 0;
-    void (*bwd)(const KParams) = discrete ? (pt ? l.dadj_pt : l.dadj) : (pt ? l.adj_pt : l.adj);
+    if (fast && pt) return fail(c, UDE_ERR_UNSUPPORTED, "UDE_SENSE_INTERPOLATING_ADJOINT_FAST has no per-trajectory time-grid instances");
+    void (*bwd)(const KParams) = discrete ? (pt ? l.dadj_pt : l.dadj) : fast ? l.adj_fast : (pt ? l.adj_pt : l.adj);
     void (*kfwd)(const KParams) = pt ? l.fwd_pt : l.fwd;
     const size_t shmem_f = l.lds_bytes(np, false);
     const size_t shmem_a = l.lds_bytes(np, true, discrete);

@@ -52,6 +52,15 @@ class ForwardDiffSensitivity:
         pass
 
 
+class FastInterpolatingAdjoint:
+    """SURVEY.md 8(b) `fast` mode (UDE_SENSE_INTERPOLATING_ADJOINT_FAST): the interpolating adjoint with only lambda under
+    error control; the parameter cotangent rides along as a quadrature on the accepted steps.  NOT an upstream sensealg
+    (upstream's InterpolatingAdjoint keeps the parameter cotangent in the error norm, which is the default here): an
+    opt-in that drops the per-parameter error estimate (its accumulators and IEEE divisions): 5-12 % less time per gradient
+    on the reference's problem sizes, not fewer steps (the parity mode's RMS over n + np components dilutes lambda's error);
+    gradients agree to the tolerance."""
+
+
 class EnsembleMI355:
     """ensemble algorithm tag: trajectories run as lane groups of the fused HIP kernels"""
 
@@ -157,7 +166,7 @@ class Engine:
 def _opts(alg, abstol=None, reltol=None, dtmax=None, dt=None, maxiters=None, sensealg=None, **kw):
     o = SolveOpts()
     o.alg = alg.alg if not isinstance(alg, int) else alg
-    o.sensealg = 1 if isinstance(sensealg, ForwardDiffSensitivity) else 0
+    o.sensealg = 1 if isinstance(sensealg, ForwardDiffSensitivity) else 2 if isinstance(sensealg, FastInterpolatingAdjoint) else 0
     o.abstol = abstol or 0.0
     o.reltol = reltol or 0.0
     o.dtmax = dtmax or 0.0
