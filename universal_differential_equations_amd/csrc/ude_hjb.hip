@@ -1,5 +1,7 @@
 // ude_hjb.hip -- C ABI of the stochastic (deep-BSDE / LambaEM) path: include/udecore.h `ude_hjb_*`
 // (BASELINE configs[4], highdim_pde/lambaem.jl:8-48).  gfx950 only.
+#include <cstdlib>
+#include <cstdio>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -132,8 +134,21 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
     const int32_t qstart = (int32_t)(nblk_f * NT);
     p.queue = (int32_t*)c->hj[B_QUEUE].p;
     HIPCHK(c, hipMemcpyAsync(p.queue, &qstart, sizeof qstart, hipMemcpyHostToDevice, c->stream));
+    const bool prof = getenv("UDE_HJB_PROF") != nullptr;  // debug: phase clocks of block 0 on stderr (blocks the stream)
+    if (prof) {
+        if ((rc = ensure(c, c->hj[30], sizeof(unsigned long long) * 16))) return rc;
+        p.prof = (unsigned long long*)c->hj[30].p;
+        HIPCHK(c, hipMemsetAsync(p.prof, 0, sizeof(unsigned long long) * 16, c->stream));
+    }
     hipLaunchKernelGGL((hjb_fwd_kernel<KD, KH>), dim3((unsigned)nblk_f), dim3(256), sh_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
+    if (prof) {
+        unsigned long long h[16];
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(h, p.prof, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[hjb prof] block 0: %llu iterations; clock ticks: eval1+2 %llu | S1 %llu | eval3 %llu | S2: estimate+controller %llu, accept/reject %llu, finish/write-back %llu | end barrier %llu\n", h[8], h[0], h[1],
+                h[2], h[5], h[6], h[3], h[4]);
+    }
     HIPCHK(c, hipEventRecord(c->hj_ev[1], c->stream));
     HIPCHK(c, hipEventRecord(c->hj_ev[2], c->stream));
     if (grad) {

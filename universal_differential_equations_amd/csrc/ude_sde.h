@@ -61,6 +61,7 @@ struct HjbParams {
     double* loss;
     int32_t* nfail;
     int32_t* queue;       // next trajectory of the ensemble (forward kernel's slot queue)
+    unsigned long long* prof;  // debug (UDE_HJB_PROF=1): per-phase clock sums of block 0 [phase 0..7], iterations at [8]
 };
 
 // ---- Philox4x32-10 + Box-Muller (oracle/sde_oracle.c restates the same sequences) ----------------------------------
@@ -242,6 +243,10 @@ __device__ __forceinline__ float tsum8(const float (&v)[8]) {
 }
 // the 8 standard normals of lane m (components 8m .. 8m+7) of a draw event: Philox chunks 2m, 2m+1
 __device__ __forceinline__ void normals8(uint64_t seed, uint32_t iter, uint32_t traj, uint32_t ev, int m, float (&n)[8]) {
+#ifdef HJB_EXP_NORNG  // timing experiment only: no Philox / Box-Muller (results are NOT normals)
+    for (int i = 0; i < 8; ++i) n[i] = (float)((int)((traj * 2654435761u + ev * 40503u + (uint32_t)(8 * m + i) * 2246822519u) >> 8) - (1 << 23)) * 1.1e-7f;
+    return;
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         uint32_t r[4];
@@ -347,7 +352,18 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
     __syncthreads();
 
     const int nA = p.adaptive ? 2 : 1;
+    // debug phase clocks (s_memtime; one lane of block 0): [0] evaluations 1+2, [1] S1, [2] evaluation 3, [3] S2, [4] loop-end barrier
+    const bool prof = p.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    unsigned long long tk = prof ? __builtin_readcyclecounter() : 0ull;
+    auto tick = [&](int ph) {
+        if (prof) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            p.prof[ph] += now - tk;
+            tk = now;
+        }
+    };
     for (;;) {
+        if (prof) p.prof[8] += 1;
         layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, nA, w, l, p.record ? p.rA1 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
         __syncthreads();
         layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 0, nA, w, l, p.record ? p.rA2 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
@@ -356,6 +372,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
         __syncthreads();
         layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 0, nA, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
         __syncthreads();
+        tick(0);
         if (p.adaptive) {
             // ---- S1: the Lamba probe point utilde = K + ||G||_F sqrt(dt): input column of the third evaluation ----
             for (int ps = 0; ps < 2; ++ps) {
@@ -383,6 +400,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                 }
             }
             __syncthreads();
+            tick(1);
             layer<C::KS1, true>(wf1, bufA, bufB, biasS, 2, 3, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
             __syncthreads();
             layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 2, 3, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
@@ -391,6 +409,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
             __syncthreads();
             layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 2, 3, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
             __syncthreads();
+            tick(2);
         }
         // ---- S2: the step of every live slot (four per wavefront pass); writes the next attempt's input columns ----
         int alldone = 1;
@@ -410,6 +429,13 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                 X[i] = on ? Xs[tr * XLD + cb + i] : 0.0f;
                 dW[i] = on ? dWs[tr * XLD + cb + i] : 0.0f;
             }
+            // the ONE draw a step can consume (a bridged stack piece, OR the fresh remainder, OR the bridge of a rejected step --
+            // always with event counter ev): generated once up front, so a wavefront whose four slots take different
+            // branches does not run Philox + Box-Muller once per branch
+            float nrm[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nrm[i] = 0.0f;
+            if (cb < D) normals8(p.seed, p.iter, (uint32_t)j, ev, m, nrm);
             if (it + 1 > p.maxiters) {
                 ret = RET_MAXITERS;
                 fin = true;
@@ -462,6 +488,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                     accept = EE <= 1.0f;
                     if (EE != EE) { ret = RET_UNSTABLE; fin = true; }
                 }
+                tick(5);
                 if (!fin && accept) {
                     if (nacc >= p.cap) {
                         ret = RET_STORE_OVERFLOW;
@@ -533,8 +560,6 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                                     nstack -= 1;
                                 } else {
                                     const float rl = dtn - acch, fr = rl / L;
-                                    float nrm[8];
-                                    if (cb < D) normals8(p.seed, p.iter, (uint32_t)j, ev, m, nrm);
                                     ev += 1; ndraw += 1;
                                     const float sd = __builtin_sqrtf((1.0f - fr) * rl);
                                     if (cb < D) {
@@ -554,8 +579,6 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                             if (acch < dtn) {
                                 const float sd = __builtin_sqrtf(dtn - acch);
                                 if (cb < D) {
-                                    float nrm[8];
-                                    normals8(p.seed, p.iter, (uint32_t)j, ev, m, nrm);
 #pragma unroll
                                     for (int i = 0; i < 8; ++i) dW[i] = __builtin_fmaf(sd, nrm[i], dW[i]);
                                 }
@@ -576,8 +599,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                     } else {
                         const float sd = __builtin_sqrtf((1.0f - fr) * dtn);
                         if (cb < D) {
-                            float nrm[8], wv[8];
-                            normals8(p.seed, p.iter, (uint32_t)j, ev, m, nrm);
+                            float wv[8];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) wv[i] = __builtin_fmaf(fr, dW[i], sd * nrm[i]);
                             float* top = p.stackW + ((size_t)j * STACK + nstack) * XLD + cb;
@@ -594,6 +616,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                     }
                 }
             }
+            tick(6);
             if (fin) {
                 // loss term of this trajectory: (g(X_T) - u_T)^2, g(X) = log(0.5 + 0.5 |X|^2)  (lambaem.jl:14)
                 float lj = 0.0f, ub = 0.0f;
@@ -660,7 +683,10 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                 }
             }
         }
-        if (__syncthreads_and(alldone)) break;
+        tick(3);
+        const bool stop = __syncthreads_and(alldone);
+        tick(4);
+        if (stop) break;
     }
 }
 
