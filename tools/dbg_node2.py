@@ -1,6 +1,10 @@
 import sys, numpy as np
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import _oracle as O
+import os
+import universal_differential_equations_amd._lib as _L
+if os.environ.get('UDE_EXP_LIB'):
+    _L.LIB_PATH = os.environ['UDE_EXP_LIB']
 import universal_differential_equations_amd as U
 from universal_differential_equations_amd import models
 from test_gpu_node import node_case, MASK

@@ -969,6 +969,13 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     real* kbase = scratch + Model::SCRATCH;
     real* slots = kbase + L::K_DOUBLES;
     const int np_pad = L::np_pad(p.n_param);
+#ifdef UDE_EXP_LDS_FILL  // debugging experiment: poison (or zero) the whole dynamic LDS before anything is staged
+    {
+        const int tot = Model::theta_lds(p.n_param) + Model::SCRATCH + L::K_DOUBLES;
+        for (int i = threadIdx.x; i < tot; i += BLOCK) th[i] = UDE_EXP_LDS_FILL;
+        __syncthreads();
+    }
+#endif
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     for (int i = threadIdx.x; i < L::K_DOUBLES; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
     __syncthreads();
@@ -1064,11 +1071,18 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         static_assert(G == 64, "HBM slot state: one wavefront per trajectory");
         real* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
         // (a runtime loop: unrolled, the compiler keeps all NSLOT loads in flight -- 2 x 146 registers for the neural ODE)
+#ifdef UDE_EXP_TAIL_UNROLL
+        static_for<0, NSLOT>([&](auto c) {
+            const int idx = Model::slot_index(p.mc, r, c);
+            if (idx >= 0) row[idx] = mu_final[(size_t)c * MS];
+        });
+#else
 #pragma unroll 2
         for (int c = 0; c < NSLOT; ++c) {
             const int idx = Model::slot_index(p.mc, r, c);
             if (idx >= 0) row[idx] = mu_final[(size_t)c * MS];
         }
+#endif
     }
     if constexpr (!SG && pow2_group<G>()) {
     real mu[NSLA];

@@ -237,7 +237,10 @@ struct SeirNode {
     // slots in order 0..145, mu read in chunks of CH (next chunk in flight while this one is processed)
     template <int NST, unsigned MASK, class Body>
     static __device__ __forceinline__ void for_each_slot(const Ctx& c, const double* mu, int ms, Body body) {
-        constexpr int CH = 4;  // (8 in flight made the scheduler interleave 8 x NST factor products: 250+ spilled VGPRs)
+#ifndef NODE_CH
+#define NODE_CH 4
+#endif
+        constexpr int CH = NODE_CH;  // slots in flight per chunk (-DNODE_CH=8 is the build discussed in DESIGN 8b: wrong results on ONE GPU of the pool)
         constexpr int NCHX = (NEXTRA + CH - 1) / CH;
         double mcur[CH], mnext[CH];
         static_for<0, CH>([&](auto i) { mcur[i] = mu[(size_t)decltype(i)::value * ms]; });
