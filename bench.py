@@ -281,13 +281,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (rehearsal of the N > 1 path on a 1-GPU box: UDE_BENCH_DEVICE=0 puts every rank on that device, UDE_BENCH_BACKEND=gloo
+    #  replaces RCCL, which refuses two ranks on one device; the driver's runs use neither)
+    if os.environ.get("UDE_BENCH_DEVICE"):
+        local = int(os.environ["UDE_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("UDE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     if a.workload == "hjb":
         return run_hjb(a, rank, world, local, device, dist)
