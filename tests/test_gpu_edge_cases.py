@@ -209,3 +209,66 @@ def test_per_trajectory_tspan_and_save_grids(golden):
     bad[2, 5] = bad[2, 4]
     with pytest.raises(ValueError):
         U.solve(ens, U.Vern7(), saveat=bad)
+
+
+def test_empty_ensemble_and_nan_member(golden):
+    """an empty ensemble is refused; a member with a NaN initial state is reported (Unstable), makes the loss +Inf, and
+    leaves every other member's results and the rest of the gradient untouched"""
+    g = golden(S1)
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+    t = np.array(g["solution"]["t"])
+    th = np.array(g["initial_parameters"])
+    f = models.ude_dynamics()
+    with pytest.raises((U.UdeError, AssertionError, ValueError)):
+        U.solve(U.EnsembleProblem(U.ODEProblem(f, X[0], (t[0], t[-1]), th), np.zeros((0, 2))), U.Tsit5(), saveat=t)
+    rng = np.random.default_rng(4)
+    N = 13
+    u0 = X[0] * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))
+    data = np.repeat(X[None], N, axis=0)
+    good = U.loss_and_gradient(U.EnsembleProblem(U.ODEProblem(f, u0[0], (t[0], t[-1]), th), u0), U.Tsit5(), data, saveat=t,
+                               abstol=1e-6, reltol=1e-6)
+    bad_u0 = u0.copy()
+    bad_u0[5, 1] = np.nan
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (t[0], t[-1]), th), bad_u0)
+    with pytest.raises(U.UdeError):
+        U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, abstol=1e-6, reltol=1e-6)
+    r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, abstol=1e-6, reltol=1e-6, allow_failures=True)
+    assert r.retcode[5] == 3 and (np.delete(r.retcode, 5) == 0).all() and np.isinf(r.loss)
+    keep = np.arange(N) != 5
+    assert np.array_equal(r.stats[keep], good.stats[keep]) and np.array_equal(r.grad_u0[keep], good.grad_u0[keep])
+    assert np.array_equal(r.loss_per_traj[keep], good.loss_per_traj[keep])
+    # the failed member is left out of the parameter gradient: it equals the gradient of the 12 healthy members
+    rest = U.loss_and_gradient(U.EnsembleProblem(U.ODEProblem(f, u0[0], (t[0], t[-1]), th), u0[keep]), U.Tsit5(), data[keep], saveat=t,
+                               abstol=1e-6, reltol=1e-6)
+    assert np.isfinite(r.grad_theta).all()
+    assert np.linalg.norm(r.grad_theta - rest.grad_theta) < 1e-12 * np.linalg.norm(rest.grad_theta)
+
+
+def test_full_size_ensemble_duplicate_and_linearity_properties(golden):
+    """BASELINE configs[1] size (10 000 trajectories): size-independent properties -- a duplicated half gives duplicated
+    per-trajectory bits, the ensemble loss / gradient are the sums of the halves', the cotangent pullback is linear"""
+    g = golden(S1)
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+    t = np.array(g["solution"]["t"])
+    th = np.array(g["initial_parameters"])
+    f = models.ude_dynamics()
+    rng = np.random.default_rng(10)
+    half = X[0] * (1 + 0.2 * rng.uniform(-1, 1, (5000, 2)))
+    u0 = np.concatenate([half, half])
+    data = np.repeat(X[None], 10000, axis=0)
+    prob = U.ODEProblem(f, u0[0], (t[0], t[-1]), th)
+    full = U.loss_and_gradient(U.EnsembleProblem(prob, u0), U.Tsit5(), data, saveat=t, abstol=1e-6, reltol=1e-6)
+    assert (full.retcode == 0).all()
+    for a in (full.stats, full.u, full.grad_u0, full.loss_per_traj):
+        assert np.array_equal(a[:5000], a[5000:])
+    h = U.loss_and_gradient(U.EnsembleProblem(prob, half), U.Tsit5(), data[:5000], saveat=t, abstol=1e-6, reltol=1e-6)
+    assert abs(full.loss - 2 * h.loss) < 1e-12 * full.loss
+    assert np.linalg.norm(full.grad_theta - 2 * h.grad_theta) < 1e-12 * np.linalg.norm(full.grad_theta)
+    # linearity of the pullback in the cotangent (one trajectory, the backward step sequence depends on the cotangent only
+    # through error control: compare at the level the tolerance allows)
+    p1 = U.ODEProblem(f, half[0], (t[0], t[-1]), th)
+    c1, c2 = rng.standard_normal((1, 31, 2)), rng.standard_normal((1, 31, 2))
+    ga = U.adjoint_pullback(p1, U.Tsit5(), c1, saveat=t, abstol=1e-9, reltol=1e-9).grad_theta
+    gb = U.adjoint_pullback(p1, U.Tsit5(), c2, saveat=t, abstol=1e-9, reltol=1e-9).grad_theta
+    gab = U.adjoint_pullback(p1, U.Tsit5(), 2.0 * c1 - 0.5 * c2, saveat=t, abstol=1e-9, reltol=1e-9).grad_theta
+    assert np.linalg.norm(gab - (2.0 * ga - 0.5 * gb)) < 1e-6 * np.linalg.norm(gab)
