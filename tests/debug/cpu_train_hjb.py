@@ -2,7 +2,7 @@
 TEST INFRASTRUCTURE (imports the oracle); reference run: u0 = 1.99 after 500 iterations, 3.85 after 1000, 4.59 after 1300."""
 import sys, time
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import numpy as np
 import _sde_oracle as S

@@ -113,7 +113,7 @@ def test_training_reaches_the_scripts_acceptance_gate():
     the gate is checked at abstol = reltol = 0.1 (~250 -> ~100 steps as the chains train); (ii) iterations -- with
     x0 = 0 and zero-initialised biases u0(x0) moves only through the output bias, ~0.004 per ADAM step: the CPU
     restatement crosses the gate after ~1000 iterations and converges to 4.59 (0.3 %) by ~1300, so the test trains for
-    1500 (the script's maxiters = 500 ends at u0 ~ 2.0 here).  The same run on the CPU oracle: tools/cpu_train_hjb.py."""
+    1500 (the script's maxiters = 500 ends at u0 ~ 2.0 here).  The same run on the CPU oracle: tests/debug/cpu_train_hjb.py."""
     alg, th, rng = setup(0)
     prob = pde.TerminalPDEProblem(pde.hjb(1.0), np.zeros(D_), (0.0, 1.0))
     seen = []
