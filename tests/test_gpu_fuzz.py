@@ -142,3 +142,34 @@ def test_random_seir_and_neural_ode_match_oracle(seed):
     check_per_trajectory(r, ref)
     gn = np.linalg.norm(ref["grad_theta"])
     assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) <= REL_GRAD_SUM * max(gn, 1e-300), what
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_deep_bsde_step_matches_oracle(seed):
+    """highdim_pde/lambaem.jl: random Philox seed / training iteration / ensemble size (below, at and above one 32-slot block,
+    so the slot queue is exercised) / tolerances / controller settings / lambda / horizon / x0, adaptive LambaEM and fixed EM"""
+    import _sde_oracle as S
+    from universal_differential_equations_amd import pde
+    rng = np.random.default_rng(4000 + seed)
+    alg = pde.NNPDENS(100, 110, opt=pde.ADAM(0.03))
+    th = (alg.init_params(rng) + 0.03 * rng.standard_normal(sum(alg.num_params()))).astype(np.float32)
+    lam = float(rng.uniform(0.5, 2.0))
+    t1 = float(rng.uniform(0.3, 1.0))
+    x0 = (0.2 * rng.standard_normal(100)).astype(np.float32) if rng.random() < 0.5 else np.zeros(100, dtype=np.float32)
+    prob = pde.TerminalPDEProblem(pde.hjb(lam), x0, (0.0, t1))
+    M = int(rng.choice([3, 31, 32, 33, 70]))
+    it = int(rng.integers(0, 500))
+    pseed = int(rng.integers(0, 2 ** 62))
+    if seed % 4 == 3:
+        dt = float(rng.uniform(0.01, 0.05))
+        r = pde.loss_and_gradient(prob, alg, pde.EM(), th, M, it=it, dt=dt, seed=pseed)
+        ref = S.loss_grad(S.desc(lam=lam, tspan=(0.0, t1), adaptive=0, dt=dt, seed=pseed), M, prob.x0, th, it=it, nthreads=8)
+    else:
+        tol = float(rng.uniform(0.05, 0.3))
+        kw = dict(abstol=tol, reltol=tol, seed=pseed, qmax=float(rng.choice([1.125, 2.0, 10.0])), gamma=float(rng.uniform(0.8, 0.95)))
+        r = pde.loss_and_gradient(prob, alg, pde.LambaEM(), th, M, it=it, **kw)
+        ref = S.loss_grad(S.desc(lam=lam, tspan=(0.0, t1), **kw), M, prob.x0, th, it=it, nthreads=8)
+    assert np.array_equal(r.retcode, ref["retcode"]) and (r.retcode == 0).all()
+    assert np.array_equal(r.stats, ref["stats"]) and np.array_equal(r.XT, ref["XT"]) and np.array_equal(r.uT, ref["uT"])
+    assert np.array_equal(r.loss_traj, ref["loss_traj"]) and r.u0 == ref["u0"]
+    assert np.linalg.norm(r.grad - ref["grad"]) < 1e-5 * np.linalg.norm(ref["grad"])
