@@ -273,6 +273,8 @@ def main():
                          "fast = interpolating adjoint with lambda-only error control (opt-in, not the reference's step sequence)")
     ap.add_argument("--net", default="s1", choices=["s1", "tanh32"],
                     help="lv workload: s1 = the reference 2-5-5-5-2 rbf chain (headline), tanh32 = BASELINE's '2-layer tanh' 2-32-2")
+    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step (memset + forward + adjoint + reductions) "
+                                                         "instead of launching the six operations individually")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allreduce", default="torch", choices=["torch", "udecore"],
                     help="N > 1: transport of the one all-reduce per gradient (torch.distributed nccl, or libudecore's RCCL binding)")
@@ -339,8 +341,10 @@ def main():
     if dist is not None and a.allreduce == "udecore":
         comm = Comm.from_torch_dist(ens.eng, dist)
 
+    replay = ens.graph(theta) if a.graph else None
+
     def step():
-        g = ens.loss_grad(theta)
+        g = replay() if replay is not None else ens.loss_grad(theta)
         if dist is None:
             return g
         buf = pack_payload(g, ens.stats)
@@ -406,7 +410,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name,
-                       "trajectories_per_gpu": N, "sensealg": a.sensealg, "lanes_per_trajectory": a.lanes or "default",
+                       "trajectories_per_gpu": N, "sensealg": a.sensealg, "hip_graph": bool(a.graph), "lanes_per_trajectory": a.lanes or "default",
                        "evals_per_step_fwd": nf_fwd, "evals_per_step_bwd": nf_bwd, "failed_trajectories": int(evals[1].item()),
                        "adjoint_grad_wallclock_ms": ms_per_step, "sustained_loop": {"steps": n_sus, "ms_per_step": sustained_ms},
                        "fwd_kernel_ms": float(np.mean(fwd_ms)),

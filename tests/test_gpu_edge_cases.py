@@ -272,3 +272,29 @@ def test_full_size_ensemble_duplicate_and_linearity_properties(golden):
     gb = U.adjoint_pullback(p1, U.Tsit5(), c2, saveat=t, abstol=1e-9, reltol=1e-9).grad_theta
     gab = U.adjoint_pullback(p1, U.Tsit5(), 2.0 * c1 - 0.5 * c2, saveat=t, abstol=1e-9, reltol=1e-9).grad_theta
     assert np.linalg.norm(gab - (2.0 * ga - 0.5 * gb)) < 1e-6 * np.linalg.norm(gab)
+
+
+def test_device_gradient_is_capturable_into_a_hip_graph(golden):
+    """the `_dev` gradient call inside a hipGraph capture (torch.cuda.graph): replay == the plain call bit for bit, and an
+    in-place update of theta is seen by the next replay"""
+    import torch
+    g = golden(S1)
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+    t = np.array(g["solution"]["t"])
+    th = np.array(g["initial_parameters"])
+    rng = np.random.default_rng(12)
+    N = 300
+    dev = torch.device("cuda:0")
+    u0 = torch.tensor(X[0] * (1 + 0.2 * rng.uniform(-1, 1, (N, 2))), device=dev)
+    data = torch.tensor(np.repeat(X[None], N, axis=0), device=dev)
+    ens = U.DeviceEnsemble(models.ude_dynamics(), U.Tsit5(), (t[0], t[-1]), t, u0, data=data, abstol=1e-6, reltol=1e-6)
+    theta = torch.tensor(th, device=dev)
+    plain = ens.loss_grad(theta).clone()
+    replay = ens.graph(theta)
+    for _ in range(3):
+        assert torch.equal(replay(), plain)
+    theta.mul_(1.01)                                   # a training step updates theta in place
+    stepped = replay().clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(stepped, plain)
+    assert torch.equal(ens.loss_grad(theta), stepped)   # and the plain path agrees at the new theta

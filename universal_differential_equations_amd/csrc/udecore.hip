@@ -305,6 +305,18 @@ extern "C" void ude_destroy(ude_ctx* c) {
 
 extern "C" const char* ude_last_error(ude_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+// true while `st` is being captured into a hipGraph (torch.cuda.graph / hipStreamBeginCapture): no event records for the
+// timing hooks, no cross-stream hops, no allocation may happen inside the capture
+static bool capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st == nullptr) return false;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs == hipStreamCaptureStatusActive;
+}
+
 extern "C" int ude_set_stream(ude_ctx* c, void* s) {
     if (!c) return UDE_ERR_INVALID;
     hipStream_t ns = (hipStream_t)s;
@@ -312,8 +324,10 @@ extern "C" int ude_set_stream(ude_ctx* c, void* s) {
         // the workspaces are shared by every call on this context: work already queued on the old stream must
         // finish before work on the new stream may reuse them
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipEventRecord(c->ev_sync, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(ns, c->ev_sync, 0));
+        if (!capturing(ns) && !capturing(c->stream)) {  // (a capture starts from an idle context: the caller synchronises first)
+            HIPCHK(c, hipEventRecord(c->ev_sync, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(ns, c->ev_sync, 0));
+        }
         c->stream = ns;
     }
     return UDE_OK;
@@ -537,16 +551,21 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         HIPCHK(c, hipFuncSetAttribute((const void*)bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
     if (shmem_f > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
+    const bool cap_graph = capturing(c->stream);  // inside a hipGraph capture: the per-kernel timing events are left out
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)nwaves * np, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (!cap_graph) {
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    }
     hipLaunchKernelGGL(bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    c->ev_fwd = c->ev_bwd = true;
+    if (!cap_graph) {
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        c->ev_fwd = c->ev_bwd = true;
+    }
     if ((rc = ensure(c, c->nfail, sizeof(int32_t)))) return rc;
     double* lossp = (loss && !cot_in) ? loss : (double*)nullptr;
     if (m->dtype == 1) {  // Float32 problem: every real-valued array behind these pointers is float

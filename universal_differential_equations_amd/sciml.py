@@ -522,5 +522,24 @@ class DeviceEnsemble:
                                              _ptr(self.grad_u0), _ptr(self.u), _ptr(self.stats), _ptr(self.retcode)))
         return self.grad
 
+    def graph(self, theta):
+        """Capture ONE loss_grad(theta) -- memset, forward kernel, adjoint kernel, the three reduction kernels -- into a
+        hipGraph (torch.cuda.CUDAGraph) and return replay() -> the same [grad; loss] view.  `theta` must remain the same
+        tensor (update it in place between replays, as a training loop does).  A first, uncaptured call sizes every
+        workspace; inside the capture the library leaves out its timing events and refuses to allocate."""
+        torch = self.torch
+        self.loss_grad(theta)                    # warm-up (+ dense-store sizing): nothing may allocate during the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.loss_grad(theta, check=False)
+        torch.cuda.synchronize()
+        self._graph = g
+
+        def replay():
+            g.replay()
+            return self.grad
+        return replay
+
     def kernel_ms(self):
         return self.eng.kernel_ms()
