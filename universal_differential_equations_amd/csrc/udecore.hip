@@ -13,55 +13,44 @@
 using namespace ude;
 
 namespace ude {
-// out[i] = sum_w part[w][i]: one block per column, fixed strided partial sums + fixed LDS tree (accumulated in double for
-// both scalar types; deterministic for a given launch shape; the order is independent of timing)
+// A trajectory whose retcode is not Success contributes nothing to the gradient; the reference would see an Inf loss (or an
+// error) from such a solve, so the ensemble loss becomes +Inf and the count of failed trajectories is published -- an
+// optimiser never silently trains on a partial objective.  Column sums: fixed strided partial sums + fixed LDS tree,
+// accumulated in double for both scalar types (deterministic for a given launch shape, independent of timing).
+// the three reductions of a gradient call in ONE launch (block i < ncols: column i of the partial-gradient matrix; block
+// ncols: the loss sum, then the failure count and the +Inf rule) -- same sums, same trees, two launches less
 template <class T>
-__global__ void reduce_rows_kernel(const T* part, int64_t nrows, int32_t ncols, T* out) {
+__global__ void finish_kernel(const T* part, int64_t nrows, int32_t ncols, T* grad_out, const T* loss_traj, int64_t N, T* loss_out,
+                              const int32_t* retcode, int32_t* nfail_out) {
     __shared__ double sh[256];
+    __shared__ int shi[256];
     const int i = blockIdx.x;
-    double s = 0.0;
-    for (int64_t w = threadIdx.x; w < nrows; w += 256) s += (double)part[(size_t)w * ncols + i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int m = 128; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+    if (i < ncols) {
+        double s = 0.0;
+        for (int64_t w = threadIdx.x; w < nrows; w += 256) s += (double)part[(size_t)w * ncols + i];
+        sh[threadIdx.x] = s;
         __syncthreads();
+        for (int m = 128; m > 0; m >>= 1) {
+            if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) grad_out[i] = (T)sh[0];
+        return;
     }
-    if (threadIdx.x == 0) out[i] = (T)sh[0];
-}
-
-// total = sum_j v[j], fixed tree
-template <class T>
-__global__ void reduce_sum_kernel(const T* v, int64_t n, T* out) {
-    __shared__ double sh[256];
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)v[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int m = 128; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = (T)sh[0];
-}
-
-// A trajectory whose retcode is not Success contributes nothing to the gradient; the reference would see an Inf loss
-// (or an error) from such a solve, so the ensemble loss becomes +Inf and the count of failed trajectories is
-// published -- an optimiser never silently trains on a partial objective.
-template <class T>
-__global__ void finalize_kernel(const int32_t* retcode, int64_t n, T* loss, int32_t* nfail_out) {
-    __shared__ int sh[256];
     int c = 0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) c += retcode[i] != 0;
-    sh[threadIdx.x] = c;
+    if (loss_out) for (int64_t j = threadIdx.x; j < N; j += 256) s += (double)loss_traj[j];
+    for (int64_t j = threadIdx.x; j < N; j += 256) c += retcode[j] != 0;
+    sh[threadIdx.x] = s;
+    shi[threadIdx.x] = c;
     __syncthreads();
     for (int m = 128; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+        if ((int)threadIdx.x < m) { sh[threadIdx.x] += sh[threadIdx.x + m]; shi[threadIdx.x] += shi[threadIdx.x + m]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (nfail_out) *nfail_out = sh[0];
-        if (sh[0] > 0 && loss) *loss = (T)__builtin_inf();
+        if (nfail_out) *nfail_out = shi[0];
+        if (loss_out) *loss_out = shi[0] > 0 ? (T)__builtin_inf() : (T)sh[0];
     }
 }
 
@@ -568,18 +557,12 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     }
     if ((rc = ensure(c, c->nfail, sizeof(int32_t)))) return rc;
     double* lossp = (loss && !cot_in) ? loss : (double*)nullptr;
-    if (m->dtype == 1) {  // Float32 problem: every real-valued array behind these pointers is float
-        hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(np), dim3(256), 0, c->stream, (const float*)p.grad_part, nwaves, (int32_t)np,
-                           (float*)grad_theta);
-        if (lossp) hipLaunchKernelGGL(reduce_sum_kernel<float>, dim3(1), dim3(256), 0, c->stream, (const float*)p.loss_traj, N, (float*)lossp);
-        hipLaunchKernelGGL(finalize_kernel<float>, dim3(1), dim3(256), 0, c->stream, (const int32_t*)retcode, N, (float*)lossp,
-                           (int32_t*)c->nfail.p);
-    } else {
-        hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(np), dim3(256), 0, c->stream, (const double*)p.grad_part, nwaves, (int32_t)np,
-                           grad_theta);
-        if (lossp) hipLaunchKernelGGL(reduce_sum_kernel<double>, dim3(1), dim3(256), 0, c->stream, (const double*)p.loss_traj, N, lossp);
-        hipLaunchKernelGGL(finalize_kernel<double>, dim3(1), dim3(256), 0, c->stream, (const int32_t*)retcode, N, lossp, (int32_t*)c->nfail.p);
-    }
+    if (m->dtype == 1)  // Float32 problem: every real-valued array behind these pointers is float
+        hipLaunchKernelGGL(finish_kernel<float>, dim3(np + 1), dim3(256), 0, c->stream, (const float*)p.grad_part, nwaves, (int32_t)np,
+                           (float*)grad_theta, (const float*)p.loss_traj, N, (float*)lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
+    else
+        hipLaunchKernelGGL(finish_kernel<double>, dim3(np + 1), dim3(256), 0, c->stream, (const double*)p.grad_part, nwaves, (int32_t)np,
+                           grad_theta, (const double*)p.loss_traj, N, lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
     HIPCHK(c, hipGetLastError());
     return UDE_OK;
 }
