@@ -2,6 +2,8 @@
 // host buffers, column-major arrays, no Python, no torch.  Built and run by tests/test_gpu_cabi_harness.py (-m gpu).
 //   Array(solve(prob, Tsit5(); saveat))                               -> ude_solve_ensemble       (scenario_1.jl:40-41 shape)
 //   loss(theta) and its adjoint gradient                              -> ude_loss_grad_ensemble   (seir_exposure.jl:144-147 shape)
+//   a Float32 solve (scenario_3.jl:43-57)                             -> ude_solve_ensemble with dtype = 1
+//   one deep-BSDE loss + gradient (highdim_pde/lambaem.jl:14-34)      -> ude_hjb_loss_grad
 // Self-check: the adjoint gradient against central differences of the loss computed through ude_solve_ensemble.
 // Prints one JSON line with the numbers the Python side compares with the oracle.
 #include <cmath>
@@ -71,7 +73,63 @@ int main() {
     bad.n_layers = 2;
     bad.dims[0] = 2; bad.dims[1] = 7; bad.dims[2] = 2;
     const int rc_bad = ude_model_supported(ctx, &bad, &o, 1);
-    printf("{\"version\": %d, \"loss\": %.17g, \"loss_direct\": %.17g, \"grad\": [%.17g, %.17g, %.17g, %.17g], \"fd_worst\": %.3g, "
+    // ---- a Float32 problem through the same entry point (ude_model_desc.dtype = 1: every real array is float) ----
+    // rc_ode of LotkaVolterra/scenario_3.jl:43-57 on 26 points, Tsit5 at default tolerances
+    ude_model_desc mf;
+    memset(&mf, 0, sizeof mf);
+    mf.kind = UDE_KIND_KPP_TRUE;
+    mf.dtype = 1;
+    mf.n_state = 26;
+    mf.lin_idx[0] = mf.lin_idx[1] = -1;
+    {
+        const float dx = 0.04f, dx2 = dx * dx;
+        const float off = (float)(1.0 / (double)dx2), dia = (float)(-2.0 / (double)dx2);
+        mf.consts[0] = (double)(0.01f * off); mf.consts[1] = (double)(0.01f * dia); mf.consts[2] = 1.0;
+    }
+    ude_solve_opts of;
+    memset(&of, 0, sizeof of);
+    of.alg = UDE_ALG_TSIT5;
+    float u0f[26], satf[3] = {0.0f, 2.5f, 5.0f}, outf[26 * 3], thf[1] = {0.0f};
+    for (int i = 0; i < 26; ++i) {  // a bump from +, *, / only (no libm: the Python side must form the same bits)
+        const float xx = (float)i / 25.0f, om = 1.0f - xx;
+        u0f[i] = ((16.0f * xx) * xx) * (om * om);
+    }
+    const double tspanf[2] = {0.0, 5.0};
+    int64_t stf[UDE_NSTATS];
+    int32_t rcf = -1;
+    // (the real-valued array parameters are declared double*: with dtype = 1 the same pointers carry float data)
+    if (ude_solve_ensemble(ctx, &mf, &of, 1, (const double*)u0f, tspanf, (const double*)thf, (const double*)satf, 3, (double*)outf, stf, &rcf) != UDE_OK) {
+        fprintf(stderr, "f32 solve: %s\n", ude_last_error(ctx));
+        return 5;
+    }
+    // ---- one deep-BSDE loss + gradient (highdim_pde/lambaem.jl:14-34) with a parameter vector from a small LCG ----
+    ude_hjb_desc hd;
+    memset(&hd, 0, sizeof hd);
+    hd.d = 100; hd.hls = 110; hd.adaptive = 1; hd.seed = 77;
+    hd.lambda = 1.0; hd.sigma = (double)sqrtf(2.0f); hd.t0 = 0.0; hd.t1 = 1.0; hd.abstol = 0.1; hd.reltol = 0.1;
+    int32_t np0 = 0, np1 = 0;
+    ude_hjb_num_params(hd.d, hd.hls, &np0, &np1);
+    std::vector<float> hth((size_t)np0 + np1), hgrad((size_t)np0 + np1), hx0(100, 0.0f), huT(5), hXT(500);
+    uint32_t lcg = 12345u;
+    for (auto& v : hth) { lcg = lcg * 1664525u + 1013904223u; v = ((float)((lcg >> 8) & 0xFFFFu) / 65536.0f - 0.5f) * 0.2f; }
+    double hloss = 0.0;
+    float hu0 = 0.0f;
+    std::vector<double> hlt(5);
+    std::vector<int64_t> hst(4 * 5);
+    std::vector<int32_t> hrc(5);
+    if (ude_hjb_loss_grad(ctx, &hd, 5, hx0.data(), hth.data(), 3u, &hloss, hgrad.data(), &hu0, huT.data(), hXT.data(), hlt.data(), hst.data(),
+                          hrc.data()) != UDE_OK) {
+        fprintf(stderr, "hjb: %s\n", ude_last_error(ctx));
+        return 6;
+    }
+    double hgn = 0.0;
+    for (float v : hgrad) hgn += (double)v * (double)v;
+    printf("{\"f32_nf\": %lld, \"f32_naccept\": %lld, \"f32_nreject\": %lld, \"f32_rc\": %d, \"f32_u_end_13\": %.9g, "
+           "\"hjb_np\": %d, \"hjb_loss\": %.17g, \"hjb_u0\": %.9g, \"hjb_uT0\": %.9g, \"hjb_naccept0\": %lld, \"hjb_nreject0\": %lld, "
+           "\"hjb_grad_norm\": %.9g, ",
+           (long long)stf[0], (long long)stf[1], (long long)stf[2], (int)rcf, (double)outf[2 * 26 + 13], (int)(np0 + np1), hloss, (double)hu0,
+           (double)huT[0], (long long)hst[1], (long long)hst[2], sqrt(hgn));
+    printf("\"version\": %d, \"loss\": %.17g, \"loss_direct\": %.17g, \"grad\": [%.17g, %.17g, %.17g, %.17g], \"fd_worst\": %.3g, "
            "\"nf0\": %lld, \"naccept0\": %lld, \"rc_unsupported\": %d, \"pred00\": %.17g}\n",
            ude_version(), loss, loss_of(th2), gth[0], gth[1], gth[2], gth[3], worst, (long long)stats[0], (long long)stats[1], rc_bad,
            pred[0]);
