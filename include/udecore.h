@@ -61,6 +61,7 @@ typedef struct {
     int32_t dtype;                     /* 0 = Float64; 1 = Float32 (scenario_3.jl:26-57,121-126; hudson_bay.jl:77-104): EVERY real-valued
                                           array argument of the call (u0, theta, saveat, u_out, data, cotangent, grad_*, loss,
                                           loss_per_traj) is then float behind the same pointers; tspan stays a pair of host doubles.
+                                          (the array parameters are ude_real* = void* for that reason)
                                           Compiled Float32 instances: LV UDE 2-5-5-5-2 rbf/rbf/tanh (hudson), Fisher-KPP true and
                                           its 1-5-5-5-1 rbf UDE on <= 32 points; anything else: UDE_ERR_UNSUPPORTED */
     int32_t n_state;
@@ -127,50 +128,55 @@ int ude_set_launch_opts(ude_ctx* ctx, const ude_launch_opts* lo);
 /* 0 if this (model, alg) has a compiled kernel, UDE_ERR_UNSUPPORTED otherwise */
 int ude_model_supported(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int32_t need_adjoint);
 
+/* Real-valued arrays: `ude_real` is void -- the element type is the problem's scalar type, double for
+ * ude_model_desc.dtype == 0 and float for dtype == 1 (u0, theta, saveat, u_out, data, cotangent, grad_*, loss, loss_per_traj).
+ * tspan is always a pair (or 2 x N) of HOST doubles. */
+typedef void ude_real;
+
 /* replaces: Array(solve(remake(prob; u0, tspan, p = theta), alg; saveat, abstol, reltol)) for every
  * member of an ensemble sharing theta (predict: scenario_1.jl:82-88; scenario_2.jl:113-124 segments;
  * EnsembleProblem slot: SciMLBase.__solve(::EnsembleProblem, alg, ::EnsembleAlgorithm)). */
 int ude_solve_ensemble(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                       const double* u0, const double* tspan /* 2, or 2 x N with UDE_PT_TSPAN; always a HOST pointer */,
-                       const double* theta, const double* saveat /* ns, or ns x N with UDE_PT_SAVEAT */, int32_t ns,
-                       double* u_out, int64_t* stats, int32_t* retcode);
+                       const ude_real* u0, const double* tspan /* 2, or 2 x N with UDE_PT_TSPAN; always a HOST pointer */,
+                       const ude_real* theta, const ude_real* saveat /* ns, or ns x N with UDE_PT_SAVEAT */, int32_t ns,
+                       ude_real* u_out, int64_t* stats, int32_t* retcode);
 int ude_solve_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                           const double* u0, const double* tspan, const double* theta,
-                           const double* saveat, int32_t ns, double* u_out, int64_t* stats, int32_t* retcode);
+                           const ude_real* u0, const double* tspan, const ude_real* theta,
+                           const ude_real* saveat, int32_t ns, ude_real* u_out, int64_t* stats, int32_t* retcode);
 
 /* replaces: the Zygote pullback of concrete_solve(prob, alg, u0, theta; saveat,
  * sensealg = InterpolatingAdjoint(autojacvec = ReverseDiffVJP())) (seir_exposure.jl:138-140,
  * Fisher-KPP-CNN.jl:136): cotangent (n x ns x N) -> grad_theta (np, summed over the ensemble),
  * grad_u0 (n x N, may be NULL).  u_out (may be NULL) receives the primal sol(saveat). */
 int ude_vjp_ensemble(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                     const double* u0, const double* tspan, const double* theta, const double* saveat,
-                     int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
-                     double* grad_u0, int64_t* stats, int32_t* retcode);
+                     const ude_real* u0, const double* tspan, const ude_real* theta, const ude_real* saveat,
+                     int32_t ns, const ude_real* cotangent, ude_real* u_out, ude_real* grad_theta,
+                     ude_real* grad_u0, int64_t* stats, int32_t* retcode);
 int ude_vjp_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                         const double* u0, const double* tspan, const double* theta, const double* saveat,
-                         int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
-                         double* grad_u0, int64_t* stats, int32_t* retcode);
+                         const ude_real* u0, const double* tspan, const ude_real* theta, const ude_real* saveat,
+                         int32_t ns, const ude_real* cotangent, ude_real* u_out, ude_real* grad_theta,
+                         ude_real* grad_u0, int64_t* stats, int32_t* retcode);
 
 /* replaces: loss(theta) = sum(abs2, data[rows,:] .- predict(theta)[rows,:]) and its gradient
  * (seir_exposure.jl:144-147 rows 2:4; Fisher-KPP-CNN.jl:140-143 without the host-side penalty term;
  * scenario_1.jl:91-94), summed over the ensemble.  row_mask: n bytes (NULL = all rows).
  * loss: one double.  loss_per_traj (N doubles) may be NULL. */
 int ude_loss_grad_ensemble(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                           const double* u0, const double* tspan, const double* theta,
-                           const double* saveat, int32_t ns, const double* data, const uint8_t* row_mask,
-                           double* loss, double* loss_per_traj, double* grad_theta, double* grad_u0,
-                           double* u_out, int64_t* stats, int32_t* retcode);
+                           const ude_real* u0, const double* tspan, const ude_real* theta,
+                           const ude_real* saveat, int32_t ns, const ude_real* data, const uint8_t* row_mask,
+                           ude_real* loss, ude_real* loss_per_traj, ude_real* grad_theta, ude_real* grad_u0,
+                           ude_real* u_out, int64_t* stats, int32_t* retcode);
 int ude_loss_grad_ensemble_dev(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                               const double* u0, const double* tspan, const double* theta,
-                               const double* saveat, int32_t ns, const double* data, const uint8_t* row_mask,
-                               double* loss, double* loss_per_traj, double* grad_theta, double* grad_u0,
-                               double* u_out, int64_t* stats, int32_t* retcode);
+                               const ude_real* u0, const double* tspan, const ude_real* theta,
+                               const ude_real* saveat, int32_t ns, const ude_real* data, const uint8_t* row_mask,
+                               ude_real* loss, ude_real* loss_per_traj, ude_real* grad_theta, ude_real* grad_u0,
+                               ude_real* u_out, int64_t* stats, int32_t* retcode);
 
 /* replaces: one evaluation of the right-hand side closure, `f(u, p, t)` / `ude_dynamics!(du, u, p, t)` for a batch of states --
  * what the scripts do with the trained UDE on the saved states before SINDy (`U(X_hat, p_trained, st)`,
  * scenario_1.jl:152-160, applied to the whole right-hand side here).  u, du: n x N (one state per column). */
-int ude_rhs_ensemble(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const double* u_host, const double* theta_host, double* du_host);
-int ude_rhs_ensemble_dev(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const double* u, const double* theta, double* du);
+int ude_rhs_ensemble(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const ude_real* u_host, const ude_real* theta_host, ude_real* du_host);
+int ude_rhs_ensemble_dev(ude_ctx* ctx, const ude_model_desc* model, int64_t N, const ude_real* u, const ude_real* theta, ude_real* du);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * SURVEY.md 8(f) N1 / BASELINE configs[4]: highdim_pde/lambaem.jl -- the deep-BSDE solver NNPDENS (NeuralNetDiffEq

@@ -97,8 +97,8 @@ int main() {
     const double tspanf[2] = {0.0, 5.0};
     int64_t stf[UDE_NSTATS];
     int32_t rcf = -1;
-    // (the real-valued array parameters are declared double*: with dtype = 1 the same pointers carry float data)
-    if (ude_solve_ensemble(ctx, &mf, &of, 1, (const double*)u0f, tspanf, (const double*)thf, (const double*)satf, 3, (double*)outf, stf, &rcf) != UDE_OK) {
+    // (the real-valued array parameters are ude_real* = void*: with dtype = 1 they carry float data)
+    if (ude_solve_ensemble(ctx, &mf, &of, 1, u0f, tspanf, thf, satf, 3, outf, stf, &rcf) != UDE_OK) {
         fprintf(stderr, "f32 solve: %s\n", ude_last_error(ctx));
         return 5;
     }

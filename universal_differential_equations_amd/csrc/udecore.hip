@@ -568,14 +568,21 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
 }
 
 extern "C" int ude_solve_ensemble_dev(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                                      const double* u0, const double* tspan, const double* theta,
-                                      const double* saveat, int32_t ns, double* u_out, int64_t* stats,
+                                      const ude_real* u0_, const double* tspan, const ude_real* theta_,
+                                      const ude_real* saveat_, int32_t ns, ude_real* u_out_, int64_t* stats,
                                       int32_t* retcode) {
+    const double* u0 = (const double*)u0_;
+    const double* theta = (const double*)theta_;
+    const double* saveat = (const double*)saveat_;
+    double* u_out = (double*)u_out_;
     return solve_dev_impl(c, m, o, N, u0, tspan, theta, saveat, ns, u_out, stats, retcode);
 }
 
 // du = f(u, theta) for N states (device buffers; u and du are n x N, one state per column)
-extern "C" int ude_rhs_ensemble_dev(ude_ctx* c, const ude_model_desc* m, int64_t N, const double* u, const double* theta, double* du) {
+extern "C" int ude_rhs_ensemble_dev(ude_ctx* c, const ude_model_desc* m, int64_t N, const ude_real* u_, const ude_real* theta_, ude_real* du_) {
+    const double* u = (const double*)u_;
+    const double* theta = (const double*)theta_;
+    double* du = (double*)du_;
     if (!c) return UDE_ERR_INVALID;
     if (!m || !u || !du || N <= 0) return fail(c, UDE_ERR_INVALID, "null / empty argument");
     HIPCHK(c, hipSetDevice(c->device));
@@ -605,20 +612,36 @@ extern "C" int ude_rhs_ensemble_dev(ude_ctx* c, const ude_model_desc* m, int64_t
 }
 
 extern "C" int ude_vjp_ensemble_dev(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                                    const double* u0, const double* tspan, const double* theta, const double* saveat,
-                                    int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
-                                    double* grad_u0, int64_t* stats, int32_t* retcode) {
+                                    const ude_real* u0_, const double* tspan, const ude_real* theta_, const ude_real* saveat_,
+                                    int32_t ns, const ude_real* cotangent_, ude_real* u_out_, ude_real* grad_theta_,
+                                    ude_real* grad_u0_, int64_t* stats, int32_t* retcode) {
+    const double* u0 = (const double*)u0_;
+    const double* theta = (const double*)theta_;
+    const double* saveat = (const double*)saveat_;
+    const double* cotangent = (const double*)cotangent_;
+    double* u_out = (double*)u_out_;
+    double* grad_theta = (double*)grad_theta_;
+    double* grad_u0 = (double*)grad_u0_;
     if (c && !cotangent) return fail(c, UDE_ERR_INVALID, "cotangent is null");
     return grad_dev_impl(c, m, o, N, u0, tspan, theta, saveat, ns, cotangent, nullptr, nullptr, nullptr, nullptr, u_out,
                          grad_theta, grad_u0, stats, retcode);
 }
 
 extern "C" int ude_loss_grad_ensemble_dev(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                                          const double* u0, const double* tspan, const double* theta,
-                                          const double* saveat, int32_t ns, const double* data,
-                                          const uint8_t* row_mask, double* loss, double* loss_per_traj,
-                                          double* grad_theta, double* grad_u0, double* u_out, int64_t* stats,
+                                          const ude_real* u0_, const double* tspan, const ude_real* theta_,
+                                          const ude_real* saveat_, int32_t ns, const ude_real* data_,
+                                          const uint8_t* row_mask, ude_real* loss_, ude_real* loss_per_traj_,
+                                          ude_real* grad_theta_, ude_real* grad_u0_, ude_real* u_out_, int64_t* stats,
                                           int32_t* retcode) {
+    const double* u0 = (const double*)u0_;
+    const double* theta = (const double*)theta_;
+    const double* saveat = (const double*)saveat_;
+    const double* data = (const double*)data_;
+    double* loss = (double*)loss_;
+    double* loss_per_traj = (double*)loss_per_traj_;
+    double* grad_theta = (double*)grad_theta_;
+    double* grad_u0 = (double*)grad_u0_;
+    double* u_out = (double*)u_out_;
     if (c && !data) return fail(c, UDE_ERR_INVALID, "data is null");
     return grad_dev_impl(c, m, o, N, u0, tspan, theta, saveat, ns, nullptr, data, row_mask, loss, loss_per_traj, u_out,
                          grad_theta, grad_u0, stats, retcode);
@@ -649,8 +672,12 @@ static int any_failed(ude_ctx* c, const int32_t* rc, int64_t N) {
 }
 
 extern "C" int ude_solve_ensemble(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                                  const double* u0, const double* tspan, const double* theta, const double* saveat,
-                                  int32_t ns, double* u_out, int64_t* stats, int32_t* retcode) {
+                                  const ude_real* u0_, const double* tspan, const ude_real* theta_, const ude_real* saveat_,
+                                  int32_t ns, ude_real* u_out_, int64_t* stats, int32_t* retcode) {
+    const double* u0 = (const double*)u0_;
+    const double* theta = (const double*)theta_;
+    const double* saveat = (const double*)saveat_;
+    double* u_out = (double*)u_out_;
     int rc = common_checks(c, m, o, N, u0, tspan, theta, saveat, ns);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
@@ -728,25 +755,44 @@ static int grad_host(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* 
 }
 
 extern "C" int ude_vjp_ensemble(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                                const double* u0, const double* tspan, const double* theta, const double* saveat,
-                                int32_t ns, const double* cotangent, double* u_out, double* grad_theta,
-                                double* grad_u0, int64_t* stats, int32_t* retcode) {
+                                const ude_real* u0_, const double* tspan, const ude_real* theta_, const ude_real* saveat_,
+                                int32_t ns, const ude_real* cotangent_, ude_real* u_out_, ude_real* grad_theta_,
+                                ude_real* grad_u0_, int64_t* stats, int32_t* retcode) {
+    const double* u0 = (const double*)u0_;
+    const double* theta = (const double*)theta_;
+    const double* saveat = (const double*)saveat_;
+    const double* cotangent = (const double*)cotangent_;
+    double* u_out = (double*)u_out_;
+    double* grad_theta = (double*)grad_theta_;
+    double* grad_u0 = (double*)grad_u0_;
     if (c && !cotangent) return fail(c, UDE_ERR_INVALID, "cotangent is null");
     return grad_host(c, m, o, N, u0, tspan, theta, saveat, ns, cotangent, nullptr, nullptr, nullptr, nullptr, u_out,
                      grad_theta, grad_u0, stats, retcode);
 }
 
 extern "C" int ude_loss_grad_ensemble(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int64_t N,
-                                      const double* u0, const double* tspan, const double* theta,
-                                      const double* saveat, int32_t ns, const double* data, const uint8_t* row_mask,
-                                      double* loss, double* loss_per_traj, double* grad_theta, double* grad_u0,
-                                      double* u_out, int64_t* stats, int32_t* retcode) {
+                                      const ude_real* u0_, const double* tspan, const ude_real* theta_,
+                                      const ude_real* saveat_, int32_t ns, const ude_real* data_, const uint8_t* row_mask,
+                                      ude_real* loss_, ude_real* loss_per_traj_, ude_real* grad_theta_, ude_real* grad_u0_,
+                                      ude_real* u_out_, int64_t* stats, int32_t* retcode) {
+    const double* u0 = (const double*)u0_;
+    const double* theta = (const double*)theta_;
+    const double* saveat = (const double*)saveat_;
+    const double* data = (const double*)data_;
+    double* loss = (double*)loss_;
+    double* loss_per_traj = (double*)loss_per_traj_;
+    double* grad_theta = (double*)grad_theta_;
+    double* grad_u0 = (double*)grad_u0_;
+    double* u_out = (double*)u_out_;
     if (c && !data) return fail(c, UDE_ERR_INVALID, "data is null");
     return grad_host(c, m, o, N, u0, tspan, theta, saveat, ns, nullptr, data, row_mask, loss, loss_per_traj, u_out,
                      grad_theta, grad_u0, stats, retcode);
 }
 
-extern "C" int ude_rhs_ensemble(ude_ctx* c, const ude_model_desc* m, int64_t N, const double* u, const double* theta, double* du) {
+extern "C" int ude_rhs_ensemble(ude_ctx* c, const ude_model_desc* m, int64_t N, const ude_real* u_, const ude_real* theta_, ude_real* du_) {
+    const double* u = (const double*)u_;
+    const double* theta = (const double*)theta_;
+    double* du = (double*)du_;
     if (!c) return UDE_ERR_INVALID;
     if (!m || !u || !du || N <= 0) return fail(c, UDE_ERR_INVALID, "null / empty argument");
     HIPCHK(c, hipSetDevice(c->device));
