@@ -173,3 +173,23 @@ def test_random_deep_bsde_step_matches_oracle(seed):
     assert np.array_equal(r.stats, ref["stats"]) and np.array_equal(r.XT, ref["XT"]) and np.array_equal(r.uT, ref["uT"])
     assert np.array_equal(r.loss_traj, ref["loss_traj"]) and r.u0 == ref["u0"]
     assert np.linalg.norm(r.grad - ref["grad"]) < 1e-5 * np.linalg.norm(ref["grad"])
+
+
+@pytest.mark.parametrize("nx", [65, 257, 777, 1000])
+def test_ragged_large_fisher_kpp_grids_match_oracle(nx):
+    """grids that end inside a 16-point matrix-core tile / a wavefront's 256-point block of the 1024-point kernels"""
+    rng = np.random.default_rng(nx)
+    th = models.kpp_theta(models.kpp_chain(), rng)
+    f = models.nn_ode(nx)
+    th[f.stencil_offset:f.stencil_offset + 3] = [1.05, -2.1, 1.0]
+    x = np.arange(nx) / nx
+    u0 = (0.5 * (np.tanh((x - 0.3) / 0.05) - np.tanh((x - 0.7) / 0.05)))[None, :] * np.array([[1.0], [0.9]])
+    t = np.array([0.0, 0.4, 1.0])
+    data = rng.uniform(0, 1, (2, 3, nx))
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 1.0), th), u0)
+    for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1)):
+        r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, sensealg=sense)
+        ref = O.loss_grad_ensemble(O.kpp_ude(nx), O.opts(O.TSIT5, sensealg=osense), u0, [0.0, 1.0], th, t, data, nthreads=2)
+        assert (r.retcode == 0).all()
+        check_per_trajectory(r, ref)
+        assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) <= REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
