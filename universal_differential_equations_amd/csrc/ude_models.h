@@ -77,7 +77,8 @@ struct LvTrue : LinearTheta {
 // ---------------------------------------------------------------------------------------------
 // NLIN: slots for trainable diagonal coefficients (2: scenario_2's delta / hudson_bay's p1, p2 may be trained; 0: both
 // diagonal coefficients are constants as in scenario_1.jl:69-73 -- no slots, no accumulators, no divisions for them)
-template <class Net, int G, int NLIN = 2>
+// WREG = false: the weights stay in LDS (the register budget of the two-wavefronts-per-SIMD instances)
+template <class Net, int G, int NLIN = 2, bool WREG = true>
 struct LvUde : LinearTheta {
     using Mlp = CoopMlp<Net, G>;
     static_assert(Net::dim(0) == 2 && Net::dim(Net::L) == 2, "LV UDE network maps R^2 -> R^2");
@@ -86,7 +87,7 @@ struct LvUde : LinearTheta {
     static constexpr int NSL = Mlp::NSLOT + NLIN;  // + the two (optional) trainable diagonal coefficients
     static constexpr bool STATE_DISTRIBUTED = false;
     // weights in registers when the lane's share is small (narrow layers spread over >= 5 lanes), else read from LDS
-    static constexpr bool REGW = (G >= 5) && (Net::maxdim() <= 8);
+    static constexpr bool REGW = WREG && (G >= 5) && (Net::maxdim() <= 8);
     struct Ctx {
         const real* th;   // full theta (LDS)
         const real* nn;   // th + nn_offset
