@@ -815,7 +815,43 @@ struct AdjSys {
     const real* cot;
     size_t cot_si, cot_sc;  // strides of save index / component
 
+    // PREFETCH (IC_LDS groups): the backward solve walks the stored steps downwards, so while interval s is in use the
+    // fields of interval s - 1 are already on their way from HBM into registers (pf_*); the switch to s - 1 is then an LDS
+    // write of data that has long arrived instead of a dependent HBM round trip (~1.5 k cycles with nothing to hide it)
+    static constexpr bool IC_PREFETCH = IC_LDS && (G <= 64);
+    static constexpr int PF_N = IC_PREFETCH ? (IC_FIELDS + G - 1) / G : 1;
+    real pf_ts, pf_f[PF_N];
+    int pf_s = -1;
+    __device__ __forceinline__ void prefetch_interval(int s) {
+        if constexpr (IC_PREFETCH) {
+            pf_s = s;
+            if (s >= 0) {
+                const int nf = 3 + n + Tab::NK * n;
+                const real* base = p->dense + ((size_t)s * nf) * p->Npad + j;
+                pf_ts = base[0];
+                static_for<0, PF_N>([&](auto q) {
+                    const int f = mctx.r + (int)decltype(q)::value * G;
+                    pf_f[q] = base[(size_t)(3 + (f < IC_FIELDS ? f : 0)) * p->Npad];
+                });
+            }
+        }
+    }
     __device__ __forceinline__ void load_interval(int s) {
+        if constexpr (IC_PREFETCH) {
+            if (s == pf_s && s >= 0) {  // (group-uniform: every lane of a trajectory prefetched the same interval)
+                sf = s;
+                te = ts;                // stored steps are contiguous: t_end(s) == t_start(s + 1), the interval being left
+                ts = pf_ts;
+                asm volatile("" ::: "memory");
+                static_for<0, PF_N>([&](auto q) {
+                    const int f = mctx.r + (int)decltype(q)::value * G;
+                    if (f < IC_FIELDS) ic[f * icstride] = pf_f[q];
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                prefetch_interval(s - 1);
+                return;
+            }
+        }
         sf = s;
         const int nf = 3 + n + Tab::NK * n;
         const real* base = p->dense + ((size_t)s * nf) * p->Npad + j;
@@ -828,6 +864,7 @@ struct AdjSys {
             for (int f = mctx.r; f < IC_FIELDS; f += G) ic[f * icstride] = base[(size_t)(3 + f) * p->Npad];
             if constexpr (G > 64) __syncthreads();
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            prefetch_interval(s - 1);
         } else if constexpr (CPL) {
             const bool on = mctx.r < n;
             const int rc = on ? mctx.r : 0;
