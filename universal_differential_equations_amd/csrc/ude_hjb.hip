@@ -155,6 +155,13 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
         HIPCHK(c, hipFuncSetAttribute((const void*)hjb_bwd_kernel<KD, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b));
         hipLaunchKernelGGL((hjb_bwd_kernel<KD, KH>), dim3(nblk), dim3(256), sh_b, c->stream, p);
         HIPCHK(c, hipGetLastError());
+        if (prof) {
+            unsigned long long h[16];
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMemcpy(h, p.prof, sizeof h, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[hjb prof] backward, block 0: %llu tiles of 32 columns; clock ticks: entry barrier %llu | loads+LDS stores %llu | exit barrier %llu | transposed layers %llu | outer products %llu\n",
+                    h[13], h[9], h[15], h[10], h[11], h[12]);
+        }
     }
     HIPCHK(c, hipEventRecord(c->hj_ev[3], c->stream));
     hipLaunchKernelGGL((hjb_reduce_kernel<KD, KH>), dim3((C::NP + 255) / 256 + 1), dim3(256), 0, c->stream, p, nblk);

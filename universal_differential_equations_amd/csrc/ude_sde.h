@@ -896,6 +896,9 @@ __device__ __forceinline__ void outer_acc(v16f (&G)[4], const float* dl, const f
     }
 }
 
+#ifndef HJB_BWD_LU
+#define HJB_BWD_LU 2
+#endif
 template <int D, int H>
 __global__ void __launch_bounds__(256) hjb_bwd_kernel(const HjbParams p) {
     using C = Cfg<D, H>;
@@ -932,43 +935,79 @@ __global__ void __launch_bounds__(256) hjb_bwd_kernel(const HjbParams p) {
     for (int i = tid; i < 8 * 128 * LDT; i += 256) sm[i] = 0.0f;
     __syncthreads();
 
+    // debug phase clocks (UDE_HJB_PROF): [10] tile loads, [11] three transposed layers, [12] four outer products, [13] tiles
+    const bool prof = p.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    unsigned long long tk = prof ? __builtin_readcyclecounter() : 0ull;
+    auto tick = [&](int ph) {
+        if (prof) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            p.prof[ph] += now - tk;
+            tk = now;
+        }
+    };
     for (int64_t j = blockIdx.x; j < p.M; j += gridDim.x) {
         if (p.retcode[j] != RET_SUCCESS) continue;
         const int nacc = p.nacc[j];
         const float ub = p.ubar[j];
         for (int t0 = 0; t0 < nacc; t0 += 32) {
+            if (prof) p.prof[13] += 1;
+            tick(14);
             const int nv = nacc - t0 < 32 ? nacc - t0 : 32;
             const size_t col0 = (size_t)j * p.cap + t0;
             __syncthreads();  // the previous tile's readers are done
-            // tiles [k][column]: thread walks k (coalesced in HBM), one column per pass
-            for (int i = tid; i < 32 * 128; i += 256) {
-                const int c = i >> 7, k = i & 127;
-                const bool on = c < nv;
-                float vx = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;
-                if (on) {
-                    if (k < C::DIN) vx = p.rXin[(col0 + c) * C::RX + k];
-                    else if (k == C::DIN) vx = 1.0f;  // bias slot
-                    if (k < H) {
-                        v1 = p.rA1[(col0 + c) * C::RA + k]; v2 = p.rA2[(col0 + c) * C::RA + k]; v3 = p.rA3[(col0 + c) * C::RA + k];
-                    } else if (k == H) {
-                        v1 = 1.0f; v2 = 1.0f; v3 = 1.0f;
-                    }
-                    if (k < D) v4 = ub * p.rE4[(col0 + c) * C::RE + k];
+            tick(9);
+            // tiles [k][column]: thread walks k (coalesced in HBM), one column per pass.  LU passes are loaded together and
+            // stored together: a pass-by-pass loop waited for its five loads before the next pass could issue its own
+            // (16 dependent HBM round trips per tile = 41 % of this kernel, measured with UDE_HJB_PROF)
+            constexpr int LU = HJB_BWD_LU;
+            static_assert((32 * 128 / 256) % LU == 0, "passes per tile");
+            for (int i0 = tid; i0 < 32 * 128; i0 += 256 * LU) {
+                float vx[LU], v1[LU], v2[LU], v3[LU], v4[LU];
+#pragma unroll
+                for (int u = 0; u < LU; ++u) {  // UNCONDITIONAL loads from clamped (always valid) addresses: all 5 x LU in flight together
+                    const int i = i0 + 256 * u;
+                    const int c = i >> 7, k = i & 127;
+                    const size_t col = col0 + (c < nv ? c : 0);
+                    vx[u] = p.rXin[col * C::RX + (k < C::DIN ? k : 0)];
+                    const int kh = k < H ? k : 0;
+                    v1[u] = p.rA1[col * C::RA + kh]; v2[u] = p.rA2[col * C::RA + kh]; v3[u] = p.rA3[col * C::RA + kh];
+                    v4[u] = p.rE4[col * C::RE + (k < D ? k : 0)];
                 }
-                xinT[k * LDT + c] = vx; a1T[k * LDT + c] = v1; a2T[k * LDT + c] = v2; a3T[k * LDT + c] = v3; d4T[k * LDT + c] = v4;
+#pragma unroll
+                for (int u = 0; u < LU; ++u) {
+                    const int i = i0 + 256 * u;
+                    const int c = i >> 7, k = i & 127;
+                    const bool on = c < nv;
+                    vx[u] = !on ? 0.0f : k < C::DIN ? vx[u] : k == C::DIN ? 1.0f : 0.0f;  // (k == DIN: bias slot)
+                    const float one_h = (on && k == H) ? 1.0f : 0.0f;
+                    v1[u] = (on && k < H) ? v1[u] : one_h;
+                    v2[u] = (on && k < H) ? v2[u] : one_h;
+                    v3[u] = (on && k < H) ? v3[u] : one_h;
+                    v4[u] = (on && k < D) ? ub * v4[u] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < LU; ++u) {
+                    const int i = i0 + 256 * u;
+                    const int c = i >> 7, k = i & 127;
+                    xinT[k * LDT + c] = vx[u]; a1T[k * LDT + c] = v1[u]; a2T[k * LDT + c] = v2[u]; a3T[k * LDT + c] = v3[u]; d4T[k * LDT + c] = v4[u];
+                }
             }
+            tick(15);
             __syncthreads();
+            tick(10);
             layer_bwd<C::KS4T>(wt4, d4T, d3T, a3T, w, l);
             __syncthreads();
             layer_bwd<C::KSH>(wt3, d3T, d2T, a2T, w, l);
             __syncthreads();
             layer_bwd<C::KSH>(wt2, d2T, d1T, a1T, w, l);
             __syncthreads();
+            tick(11);
             // (rows H.. of the delta tiles: the transposed fragments are zero there, so the masked value is 0)
             outer_acc(G1, d1T, xinT, w, l);
             outer_acc(G2, d2T, a1T, w, l);
             outer_acc(G3, d3T, a2T, w, l);
             outer_acc(G4, d4T, a3T, w, l);
+            tick(12);
         }
     }
     // ---- this block's partial gradient of theta_sg ----
