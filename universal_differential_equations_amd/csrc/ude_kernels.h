@@ -1232,16 +1232,46 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             static_for<0, NR>([&](auto c) { un[c] += w[c]; });
             nvjp += 1;
         };
+        // small states: the whole record of step st - 1 (times, u_n, every stage derivative) is requested while step st is
+        // being swept, and consumed one iteration later -- no HBM round trip on the critical path of the sweep
+        constexpr bool PREF = !KD && NK * NR <= 32;
+        struct StepRec {
+            real tn, tn1, dt, u[NR], k[PREF ? NK : 1][NR];
+        };
+        auto fetch_step = [&](int st, StepRec& rec) {
+            const real* base = p.dense + ((size_t)st * nf) * p.Npad + gid;
+            rec.tn = base[0]; rec.tn1 = base[(size_t)1 * p.Npad]; rec.dt = base[(size_t)2 * p.Npad];
+            static_for<0, NR>([&](auto c) { rec.u[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p.Npad] : real(0); });
+            if constexpr (PREF)
+                static_for<0, NK>([&](auto q) {
+                    static_for<0, NR>([&](auto c) { rec.k[q][c] = cvalid(c) ? base[(size_t)(3 + n + (int)decltype(q)::value * n + comp(c)) * p.Npad] : real(0); });
+                });
+        };
+        StepRec nxt;
+        if constexpr (PREF) { if (nsteps > 0) fetch_step(nsteps - 1, nxt); }
         for (int st = nsteps - 1; st >= 0; --st) {
             const real* base = p.dense + ((size_t)st * nf) * p.Npad + gid;
-            const real tn = base[0], tn1 = base[(size_t)1 * p.Npad], dt = base[(size_t)2 * p.Npad];
+            StepRec cur;
+            if constexpr (PREF) {
+                cur = nxt;
+                if (st > 0) fetch_step(st - 1, nxt);
+            } else {
+                fetch_step(st, cur);
+            }
+            const real tn = cur.tn, tn1 = cur.tn1, dt = cur.dt;
             real u_n[NR];
-            static_for<0, NR>([&](auto c) { u_n[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p.Npad] : 0.0; });
+            static_for<0, NR>([&](auto c) { u_n[c] = cur.u[c]; });
             kdense = base + (size_t)(3 + n) * p.Npad;
+            if constexpr (PREF) {
+                static_for<0, NK>([&](auto q) {
+                    static_for<0, NR>([&](auto c) { kbase[((int)decltype(q)::value * NR + c) * KSTRIDE + koff] = cur.k[q][c]; });
+                });
+            } else {
             for (int q = 0; q < NK; ++q)
                 static_for<0, NR>([&](auto c) {
                     if constexpr (!KD) kbase[(q * NR + c) * KSTRIDE + koff] = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * p.Npad] : 0.0;
                 });
+            }
             // (1) saves exactly at the step end feed the cotangent of u_{n+1}
             while (si >= 0 && tg.SV(p, si) >= tn1) {
                 if (tg.SV(p, si) == tn1) static_for<0, NR>([&](auto c) { if (cvalid(c)) ubar[c] += COT(si, c); });
