@@ -82,6 +82,61 @@ __global__ void finish_kernel(const T* part, int64_t nrows, int32_t ncols, T* gr
     }
 }
 
+// wide partial-gradient matrices (SEIR: 6252 rows x 4481 columns, neural ODE: x 9287): the column-per-block layout above reads
+// 8 bytes per 64-byte line (224 MB of data cost 350 us).  Here a block of 1024 threads owns 32 adjacent columns: 32 lanes read
+// 256 contiguous bytes of a row, 32 row-lanes stride over the rows (eight rows requested together), partials meet in LDS and
+// are added in ascending row-lane order.  Block gridDim.x - 1 does the loss / failure bookkeeping as in finish_kernel.
+template <class T>
+__global__ void __launch_bounds__(1024) finish_wide_kernel(const T* part, int64_t nrows, int32_t ncols, T* grad_out, const T* loss_traj, int64_t N,
+                                                           T* loss_out, const int32_t* retcode, int32_t* nfail_out) {
+    __shared__ double sh[32][33];
+    __shared__ int shi[1024];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < (int)gridDim.x - 1) {
+        const int cx = tid & 31, ry = tid >> 5;
+        const int col = blockIdx.x * 32 + cx;
+        const int cc = col < ncols ? col : ncols - 1;
+        double s = 0.0;
+        for (int64_t w0 = ry; w0 < nrows; w0 += 32 * 8) {
+            double pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t w = w0 + 32 * u;
+                pv[u] = (double)part[(size_t)(w < nrows ? w : 0) * ncols + cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (w0 + 32 * u < nrows) s += pv[u];
+        }
+        sh[ry][cx] = s;
+        __syncthreads();
+        if (ry == 0 && col < ncols) {
+            double t = sh[0][cx];
+            for (int q = 1; q < 32; ++q) t += sh[q][cx];
+            grad_out[col] = (T)t;
+        }
+        return;
+    }
+    double s = 0.0;
+    int c = 0;
+    for (int64_t j = tid; j < N; j += 1024) {
+        if (loss_out) s += (double)loss_traj[j];
+        c += retcode[j] != 0;
+    }
+    double* shd = &sh[0][0];  // 1056 doubles
+    shd[tid] = s;
+    shi[tid] = c;
+    __syncthreads();
+    for (int m = 512; m > 0; m >>= 1) {
+        if (tid < m) { shd[tid] += shd[tid + m]; shi[tid] += shi[tid + m]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (nfail_out) *nfail_out = shi[0];
+        if (loss_out) *loss_out = shi[0] > 0 ? (T)__builtin_inf() : (T)shd[0];
+    }
+}
+
 __global__ void fastpow_kernel(const double* x, const double* y, double* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fastpow(x[i], y[i]);
@@ -588,6 +643,9 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if (m->dtype == 1)  // Float32 problem: every real-valued array behind these pointers is float
         hipLaunchKernelGGL(finish_kernel<float>, dim3(np + 1), dim3(256), 0, c->stream, (const float*)p.grad_part, nwaves, (int32_t)np,
                            (float*)grad_theta, (const float*)p.loss_traj, N, (float*)lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
+    else if (np >= 512 && nwaves >= 256)  // wide and tall: coalesced 32-column tiles
+        hipLaunchKernelGGL(finish_wide_kernel<double>, dim3((np + 31) / 32 + 1), dim3(1024), 0, c->stream, (const double*)p.grad_part, nwaves,
+                           (int32_t)np, grad_theta, (const double*)p.loss_traj, N, lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
     else
         hipLaunchKernelGGL(finish_kernel<double>, dim3(np + 1), dim3(256), 0, c->stream, (const double*)p.grad_part, nwaves, (int32_t)np,
                            grad_theta, (const double*)p.loss_traj, N, lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
