@@ -298,3 +298,21 @@ def test_device_gradient_is_capturable_into_a_hip_graph(golden):
     torch.cuda.synchronize()
     assert not torch.equal(stepped, plain)
     assert torch.equal(ens.loss_grad(theta), stepped)   # and the plain path agrees at the new theta
+
+
+def test_wide_gradient_matrix_reduction_path():
+    """>= 256 wavefronts x >= 512 parameters take the coalesced finishing kernel (finish_wide_kernel): the SEIR exposure UDE
+    with 300 trajectories -- ensemble gradient and loss against the oracle's sums"""
+    from test_gpu_parity import seir_inputs
+    N = 300
+    u0, t = seir_inputs(N, seed=8)
+    t = t[:8]
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 7.0], [], t, nthreads=8)
+    th = models.seir_chain().glorot_uniform(np.random.default_rng(3))
+    th[-65:-1] *= 10.0
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 7.0), th), u0)
+    r = U.loss_and_gradient(ens, U.Tsit5(), truth, row_mask=[0, 1, 1, 1, 0, 0, 0], saveat=t, abstol=1e-6, reltol=1e-6)
+    ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(O.TSIT5, 1e-6, 1e-6), u0, [0.0, 7.0], th, t, truth, row_mask=[0, 1, 1, 1, 0, 0, 0], nthreads=8)
+    assert (r.retcode == 0).all() and np.array_equal(r.stats, ref["stats"]) and np.array_equal(r.grad_u0, ref["grad_u0"])
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < 1e-12 * np.linalg.norm(ref["grad_theta"])
+    assert abs(r.loss - ref["loss"]) < 1e-12 * ref["loss"]
