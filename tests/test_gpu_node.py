@@ -80,9 +80,10 @@ def test_node_single_trajectory_gradient_is_bitwise():
 
 @pytest.mark.parametrize("N", [1, 6])
 def test_node_adjoint_is_reproducible_run_to_run(N):
-    """Regression guard: an earlier build of these kernels (8 slots in flight per chunk, 250+ spilled VGPRs) produced a
-    garbage backward solve for Tsit5 depending on what had run before on the device (first call of a process, tracing
-    on/off); alternate the two algorithms several times and demand the oracle's bits every time."""
+    """Regression guard: earlier builds of these kernels produced a garbage backward solve depending on what had run before
+    on the device (a register copy the compiler placed under a narrowed EXEC kept stale lanes: DESIGN.md 8b; the
+    deterministic check is tests/test_gpu_poison.py); alternate the two algorithms several times and demand the oracle's
+    bits every time."""
     u0, th = node_case(N, 100.0)
     t = np.arange(0.0, 6.5, 1.0)
     truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 6.0], [], t)

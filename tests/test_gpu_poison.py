@@ -1,0 +1,42 @@
+"""Stale-register check.  With UDE_EXP_POISON=3,1 the library runs, between the forward and the backward kernel of every
+gradient call, a kernel that leaves different garbage in every lane of every VGPR and AGPR of the chip (udecore.hip:
+poison_chip).  A backward kernel that reads a register lane it never wrote -- round 2 found one: a compiler-inserted
+VGPR->AGPR copy in front of the EXEC restore of a join block in the neural-ODE adjoint -- then fails this
+test on every run instead of on some runs of some GPUs; one that does not is bit-identical to the oracle as always.
+The parity tests themselves are reused; nothing here has its own expected values."""
+import pytest
+
+import _oracle as O
+import universal_differential_equations_amd as U
+import test_gpu_node as TN
+import test_gpu_parity as TP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def poison(monkeypatch):
+    monkeypatch.setenv("UDE_EXP_POISON", "3,1")
+
+
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+@pytest.mark.parametrize("S0,tf", [(100.0, 6.0), (14e6, 21.0)])
+def test_node_adjoint_with_garbage_registers(poison, alg, oalg, S0, tf):
+    TN.test_node_forward_and_adjoint_match_oracle(alg, oalg, S0, tf)
+    TN.test_node_adjoint_is_reproducible_run_to_run(1)
+
+
+@pytest.mark.parametrize("alg,oalg,lanes", [(U.Vern7, O.VERN7, 0), (U.Tsit5, O.TSIT5, 0), (U.Vern7, O.VERN7, 256)])
+def test_seir_adjoint_with_garbage_registers(poison, alg, oalg, lanes):
+    TP.test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg, lanes)
+
+
+@pytest.mark.parametrize("name,mk,omk,npar", TP.CASES)
+def test_lv_adjoint_with_garbage_registers(poison, golden, name, mk, omk, npar):
+    TP.test_adjoint_gradient_matches_oracle(golden, name, mk, omk, npar, U.Vern7, O.VERN7)
+    TP.test_discrete_gradient_seir_and_kpp_match_oracle()
+
+
+@pytest.mark.parametrize("case", [c for c in TP.KPP_CASES if c[0] in ("cnn26", "s3_26", "cnn300")], ids=lambda c: c[0])
+def test_kpp_adjoint_with_garbage_registers(poison, case):
+    TP.test_kpp_ude_forward_and_adjoint_match_oracle(*case)

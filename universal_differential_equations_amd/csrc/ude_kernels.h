@@ -169,6 +169,15 @@ struct Driver {
     static constexpr bool CPL = Sys::CPL;
     static_assert(!CPL || (G == 64 && !Sys::STATE_DISTRIBUTED && NR <= 64), "component-per-lane: one wavefront per trajectory");
     static constexpr int KSTRIDE = k_stride<Sys::STATE_DISTRIBUTED, G, BLOCK, CPL>();
+    // CPL systems run one wavefront per trajectory with the step-size state replicated in every lane: all 64 lanes take the
+    // same branches by construction.  Saying so -- a scalar condition -- keeps the compiler from lowering the control flow
+    // to EXEC-masked regions: cheaper (scalar branches, no mask bookkeeping in spilled SGPR pairs), and the masked lowering is
+    // where, under the register pressure of the neural-ODE kernels, a compiler-inserted VGPR->AGPR copy ended up in front of
+    // the EXEC restore of a join block and kept stale lanes
+    static constexpr bool UNI = CPL;
+    static __device__ __forceinline__ bool uni(bool b) {
+        if constexpr (UNI) return __builtin_amdgcn_readfirstlane((int)b) != 0; else return b;
+    }
 
     struct Stats {
         int64_t nf = 0, nacc = 0, nrej = 0, nlazy = 0;
@@ -257,13 +266,13 @@ struct Driver {
             }
             const real s0 = h0 + l0, s1 = h1 + l1;
             const real d0 = rsqrt_ieee(s0 / ntot), d1 = rsqrt_ieee(s1 / ntot);
-            if (d1 != d1) {
+            if (uni(d1 != d1)) {
                 ret = RET_UNSTABLE;
                 done = true;
             }
             real dt0 = (d0 < real(1e-5) || d1 < real(1e-5)) ? real(1e-6) : (d0 / d1) / real(100);
             if (dt0 > dtmax) dt0 = dtmax;
-            if (dt0 < real(10) * REAL_EPS) {
+            if (uni(dt0 < real(10) * REAL_EPS)) {
                 dt = tdir * real(1e-6);
             } else {
                 const real dt0t = tdir * dt0;
@@ -303,7 +312,7 @@ struct Driver {
                 const real d2 = rsqrt_ieee(s2 / ntot) / dt0;
                 const real mx = d1 > d2 ? d1 : d2;
                 real dt1;
-                if (mx <= real(1e-15)) {
+                if (uni(mx <= real(1e-15))) {
                     dt1 = dt0 * real(1e-3);
                     if (dt1 < real(1e-6)) dt1 = real(1e-6);
                 } else {
@@ -319,9 +328,9 @@ struct Driver {
             if constexpr (Tab::FSAL) st.nf += 1;  // initialize!: fsalfirst = f(u0) (same value, reused)
         }
 
-        while (!done) {
+        while (uni(!done)) {
             // ---- loopheader! ----
-            if (iter > 0 && !accept) {  // step_reject_controller!
+            if (uni(iter > 0 && !accept)) {  // step_reject_controller!
                 real den = q11 / o.gamma;
                 const real iq = real(1) / o.qmin;
                 if (iq < den) den = iq;
@@ -333,9 +342,9 @@ struct Driver {
                 const real rem = rabs(tstop - t);  // modify_dt_for_tstops!
                 if (rabs(dt) > rem) dt = tdir * rem;
             }
-            if (iter > o.maxiters) { ret = RET_MAXITERS; break; }
-            if (dt != dt) { ret = RET_UNSTABLE; break; }
-            if (rabs(dt) <= REAL_EPS * rabs(t) && rabs(dt) < rabs(tstop - t)) { ret = RET_DTLESSTHANMIN; break; }
+            if (uni(iter > o.maxiters)) { ret = RET_MAXITERS; break; }
+            if (uni(dt != dt)) { ret = RET_UNSTABLE; break; }
+            if (uni(rabs(dt) <= REAL_EPS * rabs(t) && rabs(dt) < rabs(tstop - t))) { ret = RET_DTLESSTHANMIN; break; }
 
             // ---- perform_step!: runtime stage loop (wave-uniform s) ----
             real znew[NR];
@@ -440,7 +449,7 @@ struct Driver {
 
             // ---- loopfooter!: PIController ----
             real q;
-            if (EEst == real(0)) {
+            if (uni(EEst == real(0))) {
                 q = real(1) / o.qmax;
             } else {
                 q11 = (real)fastpow((double)EEst, (double)o.beta1);
@@ -450,7 +459,7 @@ struct Driver {
                 if (q > hi) q = hi;
                 if (q < lo) q = lo;
             }
-            accept = (EEst <= real(1));
+            accept = uni(EEst <= real(1));
             sys.trace(iter, t, dt, EEst, q, accept);
             if (accept) {
                 st.nacc += 1;
@@ -493,7 +502,7 @@ struct Driver {
                         }
                     };
                     const int hr = sys.accepted(tprev, t, dt, z, znew, kl, lazy);
-                    if (hr != RET_SUCCESS) { ret = hr; done = true; }
+                    if (uni(hr != RET_SUCCESS)) { ret = hr; done = true; }
                 }
                 if constexpr (FAST) {  // (with the step size this step USED)
                     static_for<0, NSL>([&](auto c) { mu[c * MS] = rfma(dt, accb[c], mu[c * MS]); });  // the same fma as the candidate of the parity mode
@@ -515,10 +524,10 @@ struct Driver {
                 if constexpr (USE_FSAL && CPL) K1(0) = K1(S - 1);
                 else if constexpr (USE_FSAL) static_for<0, NR>([&](auto c) { K(0, c) = K(S - 1, c); });
                 if constexpr (SLOT_FSAL) { real* tsw = gtmp; gtmp = gtmp2; gtmp2 = tsw; }
-                if (bad) { ret = RET_UNSTABLE; done = true; }
-                if (t == tstop) {  // handle_tstop! + callbacks
-                    const bool modified = sys.at_tstop(t, z);
-                    bool more = sys.next_tstop(tstop);
+                if (uni(bad)) { ret = RET_UNSTABLE; done = true; }
+                if (uni(t == tstop)) {  // handle_tstop! + callbacks
+                    const bool modified = uni(sys.at_tstop(t, z));
+                    bool more = uni(sys.next_tstop(tstop));
                     if (!more) done = true;
                     else if (modified) {
                         if constexpr (Tab::FSAL) st.nf += 1;  // reset_fsal! after u_modified!
@@ -533,7 +542,7 @@ struct Driver {
                 }
             } else {
                 st.nrej += 1;
-                if (EEst != EEst) { ret = RET_UNSTABLE; done = true; }
+                if (uni(EEst != EEst)) { ret = RET_UNSTABLE; done = true; }
             }
         }
         return ret;
@@ -570,6 +579,9 @@ struct FwdSys {
     static constexpr int NR = Model::NS, NSL = 0;
     static constexpr bool ALWAYS_K0 = false, FAST = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     static constexpr bool SLOTS_GLOBAL = false, CPL = Model::CPL, DEFERRED = false;
+    static __device__ __forceinline__ bool uni(bool b) {  // (Driver::uni)
+        if constexpr (CPL) return __builtin_amdgcn_readfirstlane((int)b) != 0; else return b;
+    }
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;      // trajectory
@@ -623,9 +635,9 @@ struct FwdSys {
                                             const real* kl, Lazy& lazy) {
         auto k = [&](int q, int c) { return kl[(q * NR + c) * k_stride<STATE_DISTRIBUTED, G, BLOCKDIM>()]; };
         auto k1 = [&](int q) { return kl[q * KCP]; };  // CPL: this lane's component
-        while (si < p->ns && tg.SV(*p, si) <= t) {
+        while (uni(si < p->ns && tg.SV(*p, si) <= t)) {
             const real curt = tg.SV(*p, si);
-            if (curt != t) {
+            if (uni(curt != t)) {
                 lazy();
                 const real th = (curt - tprev) / dt;
                 real b[Tab::NK], y[NR];
@@ -645,7 +657,7 @@ struct FwdSys {
             si += 1;
         }
         if (p->dense) {
-            if (nsteps >= p->cap) return RET_DENSE_OVERFLOW;
+            if (uni(nsteps >= p->cap)) return RET_DENSE_OVERFLOW;
             lazy();
             {
                 const int nf = 3 + n + Tab::NK * n;
@@ -788,6 +800,10 @@ struct AdjSys {
     // accumulators); register-slot models hand k_S -> k_0 AND its slot derivative over (FSAL, as upstream)
     static constexpr bool SLOTS_GLOBAL = Model::SLOTS_GLOBAL, CPL = Model::CPL;
     static constexpr bool ALWAYS_K0 = DEFERRED;
+    // (Driver::uni: component-per-lane systems are wave-uniform in everything that steers control flow)
+    static __device__ __forceinline__ bool uni(bool b) {
+        if constexpr (CPL) return __builtin_amdgcn_readfirstlane((int)b) != 0; else return b;
+    }
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;
@@ -884,8 +900,8 @@ struct AdjSys {
     }
     // sol(t, continuity = :right): interval [s, s+1] with t_s <= t, clamped to the stored range
     __device__ __forceinline__ void locate(real t) {
-        while (t < ts && sf > 0) load_interval(sf - 1);
-        while (t >= te && sf < nsteps - 1) load_interval(sf + 1);
+        while (uni(t < ts && sf > 0)) load_interval(sf - 1);
+        while (uni(t >= te && sf < nsteps - 1)) load_interval(sf + 1);
     }
     // ---- deferred slots: slot state in HBM, two columns (current / candidate) that swap on acceptance ----
     real *mu_cur, *mu_new;
@@ -975,8 +991,8 @@ struct AdjSys {
     __device__ __forceinline__ real first_tstop() const { return tstop_from_cur(); }
     __device__ __forceinline__ bool at_tstop(real t, real* lam) {
         bool mod = false;
-        while (cur >= 0 && tg.SV(*p, cur) >= t) {
-            if (tg.SV(*p, cur) == t) {
+        while (uni(cur >= 0 && tg.SV(*p, cur) >= t)) {
+            if (uni(tg.SV(*p, cur) == t)) {
                 static_for<0, NR>([&](auto c) {
                     if (cvalid(c)) lam[c] += cot[(size_t)cur * cot_si + (size_t)comp(c) * cot_sc];
                 });
@@ -987,7 +1003,7 @@ struct AdjSys {
         return mod;
     }
     __device__ __forceinline__ bool next_tstop(real& tstop) {
-        if (tstop == tg.T0(*p)) return false;
+        if (uni(tstop == tg.T0(*p))) return false;
         tstop = tstop_from_cur();
         return true;
     }
@@ -1041,6 +1057,7 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     real* mu_final = mu_lds;
     const bool in_range = gid < p.N && (int)threadIdx.x < GROUPS * G;
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
+    if constexpr (Model::CPL) ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;  // one wavefront per trajectory: a scalar condition (Driver::uni)
     if (ok) {
         Sys sys;
         Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);

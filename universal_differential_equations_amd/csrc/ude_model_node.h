@@ -40,18 +40,25 @@ struct SeirNode {
     static constexpr int SCRATCH = WPB * (NSTG * NFAC + 2) * H;  // stage factors + 2 broadcast rows per wavefront
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
-        double w1[NIN], b1, b2, b3, w4[NOUT], b4[NOUT];
+        double b1, b2, b3, b4[NOUT];
         const lds_t *W2p, *W3p;  // LDS, ld = 65
+        const lds_t* wx;         // LDS: this lane's column of the narrow layers, W1[j, m] at wx[m*H] (m < 7), W4[i, j] at wx[(7+i)*H]
+                                 // (28 registers less per lane than a register copy; the adjoint kernels are at the 512-register limit)
         lds_t* bc;               // two wave-private broadcast rows: lane j writes, every lane reads all 64
         lds_t* fac;              // stage factors of this wavefront: field f of stage s at fac[(s*NFAC + f)*H + lane]
         double mu_c, sg;
         int j, r;
     };
-    static __host__ __device__ constexpr int theta_lds(int) { return 2 * H * LD; }
+    static constexpr int NWX = (NIN + NOUT) * H;  // narrow-layer table
+    static __host__ __device__ constexpr int theta_lds(int) { return 2 * H * LD + NWX; }
     static __device__ __forceinline__ void stage_theta(double* th, const double* theta, int, int tid, int nthreads) {
         for (int i = tid; i < H * H; i += nthreads) {
             th[(i % H) + (i / H) * LD] = theta[OFF_W2 + i];
             th[H * LD + (i % H) + (i / H) * LD] = theta[OFF_W3 + i];
+        }
+        for (int i = tid; i < NWX; i += nthreads) {
+            const int q = i / H, j = i % H;
+            th[2 * H * LD + i] = q < NIN ? theta[OFF_W1 + j + q * H] : theta[OFF_W4 + (q - NIN) + j * NOUT];
         }
     }
     static __device__ __forceinline__ void init(Ctx& c, double* th, double* scratch, double*, int, const ModelConsts& mc, int r,
@@ -63,12 +70,9 @@ struct SeirNode {
         const int wv = (threadIdx.x >> 6) % WPB;
         c.bc = (lds_t*)scratch + WPB * NSTG * NFAC * H + wv * 2 * H;
         c.fac = (lds_t*)scratch + wv * (NSTG * NFAC * H);
-        static_for<0, NIN>([&](auto m) { c.w1[m] = theta_g[OFF_W1 + j + decltype(m)::value * H]; });
+        c.wx = (const lds_t*)th + 2 * H * LD + j;
         c.b1 = theta_g[OFF_B1 + j]; c.b2 = theta_g[OFF_B2 + j]; c.b3 = theta_g[OFF_B3 + j];
-        static_for<0, NOUT>([&](auto i) {
-            c.w4[i] = theta_g[OFF_W4 + decltype(i)::value + j * NOUT];
-            c.b4[i] = uniform_real(theta_g[OFF_B4 + decltype(i)::value]);
-        });
+        static_for<0, NOUT>([&](auto i) { c.b4[i] = uniform_real(theta_g[OFF_B4 + decltype(i)::value]); });
         c.mu_c = mc.consts[4]; c.sg = mc.consts[5];
     }
     // 64-term hidden dot of neuron j (row j of W, or column j when TRANSPOSED): 4 blocks of 16, left to right
@@ -97,12 +101,12 @@ struct SeirNode {
     // forward network: out[0..4] (the outputs the script uses), replicated
     static __device__ __forceinline__ void net(const Ctx& c, Act& q, double* out) {
         double z1 = 0.0;
-        static_for<0, NIN>([&](auto k) { z1 = __builtin_fma(c.w1[k], q.x[k], z1); });
+        static_for<0, NIN>([&](auto k) { z1 = __builtin_fma(c.wx[(int)decltype(k)::value * H], q.x[k], z1); });
         z1 += c.b1;
         q.a1 = dtanh(z1);
         q.a2 = dtanh(hidden_dot<false>(c, c.W2p, q.a1) + c.b2);
         q.a3 = dtanh(hidden_dot<false>(c, c.W3p, q.a2) + c.b3);
-        static_for<0, 5>([&](auto i) { out[i] = wave_tree_sum(c.w4[i] * q.a3) + c.b4[i]; });
+        static_for<0, 5>([&](auto i) { out[i] = wave_tree_sum(c.wx[(NIN + (int)decltype(i)::value) * H] * q.a3) + c.b4[i]; });
     }
     static __device__ __forceinline__ void inputs(const double* u, Act& q) {
         const double S = u[0], N = u[4], D = u[5];
@@ -129,12 +133,12 @@ struct SeirNode {
         net(c, q.f, o);
         q.d4[0] = lam[0]; q.d4[1] = lam[1]; q.d4[2] = lam[2]; q.d4[3] = lam[3]; q.d4[4] = lam[5]; q.d4[5] = 0.0; q.d4[6] = 0.0;
         double s3 = 0.0;  // column j of the 7-row output layer against delta4 (7-term chain, the zero rows included)
-        static_for<0, NOUT>([&](auto i) { s3 = __builtin_fma(c.w4[i], q.d4[i], s3); });
+        static_for<0, NOUT>([&](auto i) { s3 = __builtin_fma(c.wx[(NIN + (int)decltype(i)::value) * H], q.d4[i], s3); });
         q.d3 = s3 * __builtin_fma(-q.f.a3, q.f.a3, 1.0);
         q.d2 = hidden_dot<true>(c, c.W3p, q.d3) * __builtin_fma(-q.f.a2, q.f.a2, 1.0);
         q.d1 = hidden_dot<true>(c, c.W2p, q.d2) * __builtin_fma(-q.f.a1, q.f.a1, 1.0);
         double gx[NIN];
-        static_for<0, NIN>([&](auto m) { gx[m] = wave_tree_sum(c.w1[m] * q.d1); });
+        static_for<0, NIN>([&](auto m) { gx[m] = wave_tree_sum(c.wx[(int)decltype(m)::value * H] * q.d1); });
         dlam[0] = gx[0] / N;
         dlam[1] = __builtin_fma(c.sg, lam[6], gx[1]);
         dlam[2] = gx[2];
@@ -240,7 +244,7 @@ struct SeirNode {
 #ifndef NODE_CH
 #define NODE_CH 4
 #endif
-        constexpr int CH = NODE_CH;  // slots in flight per chunk (-DNODE_CH=8 is the build discussed in DESIGN 8b: wrong results on ONE GPU of the pool)
+        constexpr int CH = NODE_CH;  // slots in flight per chunk
         constexpr int NCHX = (NEXTRA + CH - 1) / CH;
         double mcur[CH], mnext[CH];
         static_for<0, CH>([&](auto i) { mcur[i] = mu[(size_t)decltype(i)::value * ms]; });

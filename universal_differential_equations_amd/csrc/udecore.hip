@@ -175,6 +175,33 @@ __global__ void mfma_probe_kernel(const double* x, const double* y, double* out)
 }  // namespace ude
 
 #include "ude_ctx.h"
+#include "ude_poison_gen.h"
+// debugging experiment (UDE_EXP_POISON=<kind>[,<what>]): between the forward and the backward kernel every register and every LDS
+// byte of the chip is set to a known pattern -- a kernel whose result changes with the pattern reads state it never wrote
+__global__ void __launch_bounds__(256) poison_regs_kernel(unsigned pat, unsigned* sink, unsigned mask, unsigned lo, unsigned hi) {
+    if (hi > lo) { UDE_POISON_ASM_RANGE(0x9e3779b1u, lo, hi); } else if (mask) { UDE_POISON_ASM_MASK(0x9e3779b1u, mask); } else if (pat == 0x9e3779b1u) { UDE_POISON_ASM_LANES(pat); } else { UDE_POISON_ASM(pat); }
+    if (pat == 0x12345u && sink) sink[threadIdx.x] = pat;
+}
+__global__ void __launch_bounds__(256) poison_lds_kernel(unsigned pat, int words, unsigned* sink) {
+    extern __shared__ unsigned pl[];
+    for (int i = threadIdx.x; i < words; i += 256) pl[i] = pat;
+    __syncthreads();
+    if (pat == 0x12345u && sink) sink[threadIdx.x] = pl[threadIdx.x];
+}
+static void poison_chip(hipStream_t st) {
+    const char* e = getenv("UDE_EXP_POISON");
+    if (!e) return;
+    int kind = 0, what = 3;
+    unsigned mask = 0;  // kind 4: bit k < 8: v[32k, 32k+32) get lane-varying garbage, bit 8+k: a[32k, 32k+32); every other register zero
+    unsigned lo = 0, hi = 0;  // kind 5: registers [lo, hi) of v0..v255 (0..255), a0..a255 (256..511) get the garbage, the others zero
+    if (sscanf(e, "5,%d,%u,%u", &what, &lo, &hi) == 3) kind = 5; else { lo = hi = 0; sscanf(e, "%d,%d,%x", &kind, &what, &mask); }
+    const unsigned pat = kind == 0 ? 0u : kind == 1 ? 0x7ff80000u : kind == 2 ? 0x41f00000u : 0x9e3779b1u;  // 3: different garbage in every lane and register
+    if (what & 1) hipLaunchKernelGGL(poison_regs_kernel, dim3(2048), dim3(256), 0, st, pat, (unsigned*)nullptr, kind == 4 ? mask : 0u, lo, hi);
+    if (what & 2) {
+        (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 160 * 1024, st, pat, 160 * 256, (unsigned*)nullptr);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // compiled model table (instances live in their own translation units, see build.py)
@@ -624,6 +651,13 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if (shmem_f > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
     const bool cap_graph = capturing(c->stream);  // inside a hipGraph capture: the per-kernel timing events are left out
+    if (const char* fill = getenv("UDE_EXP_WS_FILL")) {  // debugging experiment: every workspace byte the kernels may read set to a known value first
+        const int v = atoi(fill);
+        HIPCHK(c, hipMemsetAsync(c->dense.p, v, c->dense.cap, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->dense_n.p, v, c->dense_n.cap, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cot.p, v, c->cot.cap, c->stream));
+        if (c->slot_glob.p) HIPCHK(c, hipMemsetAsync(c->slot_glob.p, v, c->slot_glob.cap, c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)nwaves * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
@@ -632,6 +666,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     }
+    poison_chip(c->stream);
     hipLaunchKernelGGL(bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
     HIPCHK(c, hipGetLastError());
     if (!cap_graph) {
