@@ -64,6 +64,16 @@ __device__ __forceinline__ real wave_tree_sum(real x) {
     x += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x);
     x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
     x += dpp_mov<DPP_ROW_MIRROR>(x);
+#ifndef UDE_TREE_BUTTERFLY
+    // rows 0+1 and 2+3 (row_bcast15 into rows 1 and 3), then the two halves (row_bcast31 into rows 2 and 3): lane 63 holds
+    // ((r0 + r1) + (r2 + r3)), the same tree as the xor butterfly, and the total leaves through a scalar register --
+    // two DPP moves and a v_readlane pair instead of two ds_bpermute round trips (tools/probe/tree_sum_probe.hip)
+    if constexpr (sizeof(real) == 8) {
+        x += dpp_mov_rows<0x142, 0xA>(x);
+        x += dpp_mov_rows<0x143, 0xC>(x);
+        return readlane_real(x, 63);
+    }
+#endif
     x += __shfl_xor(x, 16, 64);
     x += __shfl_xor(x, 32, 64);
     return x;

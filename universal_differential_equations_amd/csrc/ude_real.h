@@ -48,6 +48,13 @@ __device__ __forceinline__ double dpp_mov(double x) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// (row-masked form: lanes of rows outside RM receive 0)
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_mov_rows(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, RM, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, RM, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
