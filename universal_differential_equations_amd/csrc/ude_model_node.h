@@ -242,7 +242,7 @@ struct SeirNode {
     template <int NST, unsigned MASK, class Body>
     static __device__ __forceinline__ void for_each_slot(const Ctx& c, const double* mu, int ms, Body body) {
 #ifndef NODE_CH
-#define NODE_CH 4
+#define NODE_CH 8
 #endif
         constexpr int CH = NODE_CH;  // slots in flight per chunk
         constexpr int NCHX = (NEXTRA + CH - 1) / CH;
