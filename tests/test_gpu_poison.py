@@ -1,5 +1,5 @@
-"""Stale-register check.  With UDE_EXP_POISON=3,1 the library runs, between the forward and the backward kernel of every
-gradient call, a kernel that leaves different garbage in every lane of every VGPR and AGPR of the chip (udecore.hip:
+"""Stale-register check.  With UDE_EXP_POISON=3,5 the library runs, in front of the forward kernel and between the forward and
+the backward kernel of every call, a kernel that leaves different garbage in every lane of every VGPR and AGPR of the chip (udecore.hip:
 poison_chip).  A backward kernel that reads a register lane it never wrote -- round 2 found one: a compiler-inserted
 VGPR->AGPR copy in front of the EXEC restore of a join block in the neural-ODE adjoint -- then fails this
 test on every run instead of on some runs of some GPUs; one that does not is bit-identical to the oracle as always.
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def poison(monkeypatch):
-    monkeypatch.setenv("UDE_EXP_POISON", "3,1")
+    monkeypatch.setenv("UDE_EXP_POISON", "3,5")
 
 
 @pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
@@ -40,3 +40,10 @@ def test_lv_adjoint_with_garbage_registers(poison, golden, name, mk, omk, npar):
 @pytest.mark.parametrize("case", [c for c in TP.KPP_CASES if c[0] in ("cnn26", "s3_26", "cnn300")], ids=lambda c: c[0])
 def test_kpp_adjoint_with_garbage_registers(poison, case):
     TP.test_kpp_ude_forward_and_adjoint_match_oracle(*case)
+
+
+def test_forward_solves_with_garbage_registers(poison, golden):
+    TP.test_seir_true_matches_oracle()
+    TP.test_kpp_true_matches_oracle()
+    TP.test_forward_ensemble_matches_oracle(golden, *TP.CASES[0], U.Vern7, O.VERN7)
+    TN.test_node_rhs_matches_oracle()

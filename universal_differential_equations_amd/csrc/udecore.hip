@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) poison_lds_kernel(unsigned pat, int words
     __syncthreads();
     if (pat == 0x12345u && sink) sink[threadIdx.x] = pl[threadIdx.x];
 }
-static void poison_chip(hipStream_t st) {
+static void poison_chip(hipStream_t st, bool before_forward = false) {  // (what & 4: also in front of the forward kernels)
     const char* e = getenv("UDE_EXP_POISON");
     if (!e) return;
     int kind = 0, what = 3;
@@ -196,6 +196,7 @@ static void poison_chip(hipStream_t st) {
     unsigned lo = 0, hi = 0;  // kind 5: registers [lo, hi) of v0..v255 (0..255), a0..a255 (256..511) get the garbage, the others zero
     if (sscanf(e, "5,%d,%u,%u", &what, &lo, &hi) == 3) kind = 5; else { lo = hi = 0; sscanf(e, "%d,%d,%x", &kind, &what, &mask); }
     const unsigned pat = kind == 0 ? 0u : kind == 1 ? 0x7ff80000u : kind == 2 ? 0x41f00000u : 0x9e3779b1u;  // 3: different garbage in every lane and register
+    if (before_forward && !(what & 4)) return;
     if (what & 1) hipLaunchKernelGGL(poison_regs_kernel, dim3(2048), dim3(256), 0, st, pat, (unsigned*)nullptr, kind == 4 ? mask : 0u, lo, hi);
     if (what & 2) {
         (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -562,6 +563,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     if (shmem > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    poison_chip(c->stream, true);
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -660,6 +662,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     }
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)nwaves * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    poison_chip(c->stream, true);
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
     if (!cap_graph) {
