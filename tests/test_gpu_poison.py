@@ -1,6 +1,6 @@
 """Stale-register check.  With UDE_EXP_POISON=3,5 the library runs, in front of the forward kernel and between the forward and
 the backward kernel of every call, a kernel that leaves different garbage in every lane of every VGPR and AGPR of the chip (udecore.hip:
-poison_chip).  A backward kernel that reads a register lane it never wrote -- round 2 found one: a compiler-inserted
+ude_poison_chip).  A backward kernel that reads a register lane it never wrote -- round 2 found one: a compiler-inserted
 VGPR->AGPR copy in front of the EXEC restore of a join block in the neural-ODE adjoint -- then fails this
 test on every run instead of on some runs of some GPUs; one that does not is bit-identical to the oracle as always.
 The parity tests themselves are reused; nothing here has its own expected values."""
@@ -47,3 +47,9 @@ def test_forward_solves_with_garbage_registers(poison, golden):
     TP.test_kpp_true_matches_oracle()
     TP.test_forward_ensemble_matches_oracle(golden, *TP.CASES[0], U.Vern7, O.VERN7)
     TN.test_node_rhs_matches_oracle()
+
+
+def test_deep_bsde_step_with_garbage_registers(poison):
+    import test_gpu_hjb as TH
+    TH.test_adaptive_loss_and_gradient_match_oracle(5)
+    TH.test_rejections_and_stack_match_oracle()

@@ -65,3 +65,5 @@ static inline int ensure(ude_ctx* c, DevBuf& b, size_t bytes) {
     return UDE_OK;
 }
 
+// debugging hook (UDE_EXP_POISON, udecore.hip): garbage into every register / LDS byte of the chip in front of a kernel
+void ude_poison_chip(hipStream_t st, bool before_forward);

@@ -140,6 +140,7 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
         p.prof = (unsigned long long*)c->hj[30].p;
         HIPCHK(c, hipMemsetAsync(p.prof, 0, sizeof(unsigned long long) * 16, c->stream));
     }
+    ude_poison_chip(c->stream, true);
     hipLaunchKernelGGL((hjb_fwd_kernel<KD, KH>), dim3((unsigned)nblk_f), dim3(256), sh_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
     if (prof) {
@@ -153,6 +154,7 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
     HIPCHK(c, hipEventRecord(c->hj_ev[2], c->stream));
     if (grad) {
         HIPCHK(c, hipFuncSetAttribute((const void*)hjb_bwd_kernel<KD, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b));
+        ude_poison_chip(c->stream, false);
         hipLaunchKernelGGL((hjb_bwd_kernel<KD, KH>), dim3(nblk), dim3(256), sh_b, c->stream, p);
         HIPCHK(c, hipGetLastError());
         if (prof) {

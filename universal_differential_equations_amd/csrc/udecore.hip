@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) poison_lds_kernel(unsigned pat, int words
     __syncthreads();
     if (pat == 0x12345u && sink) sink[threadIdx.x] = pl[threadIdx.x];
 }
-static void poison_chip(hipStream_t st, bool before_forward = false) {  // (what & 4: also in front of the forward kernels)
+void ude_poison_chip(hipStream_t st, bool before_forward) {  // (what & 4: also in front of the forward kernels)
     const char* e = getenv("UDE_EXP_POISON");
     if (!e) return;
     int kind = 0, what = 3;
@@ -563,7 +563,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     if (shmem > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    poison_chip(c->stream, true);
+    ude_poison_chip(c->stream, true);
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -662,14 +662,14 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     }
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)nwaves * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    poison_chip(c->stream, true);
+    ude_poison_chip(c->stream, true);
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
     if (!cap_graph) {
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     }
-    poison_chip(c->stream);
+    ude_poison_chip(c->stream, false);
     hipLaunchKernelGGL(bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
     HIPCHK(c, hipGetLastError());
     if (!cap_graph) {
