@@ -174,7 +174,7 @@ struct Driver {
     // to EXEC-masked regions: cheaper (scalar branches, no mask bookkeeping in spilled SGPR pairs), and the masked lowering is
     // where, under the register pressure of the neural-ODE kernels, a compiler-inserted VGPR->AGPR copy ended up in front of
     // the EXEC restore of a join block and kept stale lanes
-    static constexpr bool UNI = CPL;
+    static constexpr bool UNI = CPL || G >= 64;  // (G >= 64: a wavefront never holds lanes of two trajectories)
     static __device__ __forceinline__ bool uni(bool b) {
         if constexpr (UNI) return __builtin_amdgcn_readfirstlane((int)b) != 0; else return b;
     }
@@ -580,7 +580,7 @@ struct FwdSys {
     static constexpr bool ALWAYS_K0 = false, FAST = false, STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     static constexpr bool SLOTS_GLOBAL = false, CPL = Model::CPL, DEFERRED = false;
     static __device__ __forceinline__ bool uni(bool b) {  // (Driver::uni)
-        if constexpr (CPL) return __builtin_amdgcn_readfirstlane((int)b) != 0; else return b;
+        if constexpr (CPL || G >= 64) return __builtin_amdgcn_readfirstlane((int)b) != 0; else return b;
     }
     typename Model::Ctx mctx;
     const KParams* p;
@@ -802,7 +802,7 @@ struct AdjSys {
     static constexpr bool ALWAYS_K0 = DEFERRED;
     // (Driver::uni: component-per-lane systems are wave-uniform in everything that steers control flow)
     static __device__ __forceinline__ bool uni(bool b) {
-        if constexpr (CPL) return __builtin_amdgcn_readfirstlane((int)b) != 0; else return b;
+        if constexpr (CPL || G >= 64) return __builtin_amdgcn_readfirstlane((int)b) != 0; else return b;
     }
     typename Model::Ctx mctx;
     const KParams* p;
@@ -1057,7 +1057,7 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     real* mu_final = mu_lds;
     const bool in_range = gid < p.N && (int)threadIdx.x < GROUPS * G;
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
-    if constexpr (Model::CPL) ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;  // one wavefront per trajectory: a scalar condition (Driver::uni)
+    if constexpr (Model::CPL || G >= 64) ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;  // one wavefront per trajectory: a scalar condition (Driver::uni)
     if (ok) {
         Sys sys;
         Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
