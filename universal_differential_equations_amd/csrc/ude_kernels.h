@@ -931,7 +931,9 @@ struct AdjSys {
             static_assert(!DEFERRED || CPL, "deferred slots come with component-per-lane interval caches");
             const real acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return ks[q][0]; }, [&](auto q) { return b[q]; });
             bcast_all(rfma(dtf, acc, us[0]), y);
-            Model::vjp_store(mctx, y, lam, dl, s);
+            int slot = s;  // where the stage's factors go: models that keep only the stages the tableau weights use get the compacted slot
+            if constexpr (Model::COMPACT_STAGES) slot = __builtin_popcount(stage_mask() & ((1u << s) - 1u));
+            Model::vjp_store(mctx, y, lam, dl, slot);
             static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
         }
     }

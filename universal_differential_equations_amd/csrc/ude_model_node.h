@@ -32,12 +32,19 @@ struct SeirNode {
     static constexpr bool STATE_DISTRIBUTED = false;
     static constexpr bool THETA_GLOBAL = false, FUSED_ACC = true, SLOTS_GLOBAL = true, CPL = true, DEFERRED = true;
     static constexpr bool DADJ_K_FROM_DENSE = false;
-    static constexpr int NSTG = 10, NFAC = 7, WPB = 2;  // stages stored (Vern7), factor fields, wavefronts per block
+    // Stage factors in LDS: only the stages whose B or BT weight is nonzero are kept (Tsit5: all 7; Vern7: 8 of 10), in
+    // COMPACTED slots (AdjSys passes popcount(mask below s); a stage nobody reads lands in the slot of the next kept stage
+    // and is overwritten by it), six full rows per stage plus one short row (x0..x6 | delta4_0..6: 14 words).  With that
+    // THREE wavefronts fit next to the 74 KB of weights: 3 x (8 x 3.1 KB + 1 KB) + 74 KB + stage storage = 157 KB of the
+    // CU's 160 KB -- three of the four SIMDs busy instead of two (the kernels use all 512 registers of a SIMD lane)
+    static constexpr bool COMPACT_STAGES = true;
+    static constexpr int NSTG = 10, NSTC = 8, NFAC = 7, WPB = 3, RX = 16;  // tableau stages, stored stages, factor fields, wavefronts per block, short row
+    static constexpr int STG = 6 * H + RX;                                 // doubles of one stored stage
     static constexpr int LD = 65;
     static constexpr int OFF_W1 = 0, OFF_B1 = NIN * H, OFF_W2 = OFF_B1 + H, OFF_B2 = OFF_W2 + H * H, OFF_W3 = OFF_B2 + H,
                          OFF_B3 = OFF_W3 + H * H, OFF_W4 = OFF_B3 + H, OFF_B4 = OFF_W4 + NOUT * H, NPARAM = OFF_B4 + NOUT;
     static_assert(NPARAM == 9287, "7-64-64-64-7");
-    static constexpr int SCRATCH = WPB * (NSTG * NFAC + 2) * H;  // stage factors + 2 broadcast rows per wavefront
+    static constexpr int SCRATCH = WPB * (NSTC * STG + 2 * H);  // stage factors + 2 broadcast rows per wavefront
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
         double b1, b2, b3, b4[NOUT];
@@ -45,7 +52,7 @@ struct SeirNode {
         const lds_t* wx;         // LDS: this lane's column of the narrow layers, W1[j, m] at wx[m*H] (m < 7), W4[i, j] at wx[(7+i)*H]
                                  // (28 registers less per lane than a register copy; the adjoint kernels are at the 512-register limit)
         lds_t* bc;               // two wave-private broadcast rows: lane j writes, every lane reads all 64
-        lds_t* fac;              // stage factors of this wavefront: field f of stage s at fac[(s*NFAC + f)*H + lane]
+        lds_t* fac;              // stage factors of this wavefront: field f < 6 of stored stage q at fac[q*STG + f*H + lane], the short row at fac[q*STG + 6*H]
         double mu_c, sg;
         int j, r;
     };
@@ -68,8 +75,8 @@ struct SeirNode {
         c.W2p = (const lds_t*)th;
         c.W3p = (const lds_t*)th + H * LD;
         const int wv = (threadIdx.x >> 6) % WPB;
-        c.bc = (lds_t*)scratch + WPB * NSTG * NFAC * H + wv * 2 * H;
-        c.fac = (lds_t*)scratch + wv * (NSTG * NFAC * H);
+        c.bc = (lds_t*)scratch + WPB * NSTC * STG + wv * 2 * H;
+        c.fac = (lds_t*)scratch + wv * (NSTC * STG);
         c.wx = (const lds_t*)th + 2 * H * LD + j;
         c.b1 = theta_g[OFF_B1 + j]; c.b2 = theta_g[OFF_B2 + j]; c.b3 = theta_g[OFF_B3 + j];
         static_for<0, NOUT>([&](auto i) { c.b4[i] = uniform_real(theta_g[OFF_B4 + decltype(i)::value]); });
@@ -195,12 +202,12 @@ struct SeirNode {
     static __device__ __forceinline__ void vjp_store(const Ctx& c, const double* u, const double* lam, double* dlam, int s) {
         Bwd q;
         sweep(c, u, lam, dlam, q);
-        lds_t* f = c.fac + s * (NFAC * H) + c.j;
+        lds_t* f = c.fac + s * STG + c.j;  // (s: compacted slot)
         f[0] = q.f.a1; f[H] = q.f.a2; f[2 * H] = q.f.a3; f[3 * H] = q.d1; f[4 * H] = q.d2; f[5 * H] = q.d3;
         double sh = 0.0;
         static_for<0, NIN>([&](auto m) { sh = (c.j == (int)decltype(m)::value) ? q.f.x[m] : sh; });
         static_for<0, NOUT>([&](auto i) { sh = (c.j == NIN + (int)decltype(i)::value) ? q.d4[i] : sh; });
-        f[6 * H] = sh;
+        c.fac[s * STG + 6 * H + (c.j < RX ? c.j : RX - 1)] = sh;  // (lanes >= 14 all carry 0.0: one word, one value)
     }
     // this lane's delta of ONE layer at all stages (registers): the 64 slots of a weight block share it; the 18 extras
     // read their factors straight from the lane's own LDS words (one use each -- keeping all four per-lane factor sets
@@ -208,25 +215,31 @@ struct SeirNode {
     struct Fac {
         double d[NSTG];
     };
+    template <unsigned MASK>
+    static constexpr int slot_of(int s) {  // compacted slot of stage s: kept stages below it
+        int q = 0;
+        for (int i = 0; i < s; ++i) q += (MASK >> i) & 1u;
+        return q;
+    }
     template <int NST, unsigned MASK, int FIELD>
     static __device__ __forceinline__ void load_factor(const Ctx& c, Fac& f) {
         static_for<0, NST>([&](auto s) {
-            if constexpr ((MASK >> decltype(s)::value) & 1u) f.d[s] = c.fac[(decltype(s)::value * NFAC + FIELD) * H + c.j];
+            if constexpr ((MASK >> decltype(s)::value) & 1u) f.d[s] = c.fac[slot_of<MASK>(decltype(s)::value) * STG + FIELD * H + c.j];
         });
     }
     // g_s (all stored stages) of slot k of the W2 block (LAYER = 0: -(delta2_j a1_k)) / the W3 block (1: -(delta3_j a2_k))
     template <int NST, unsigned MASK, int LAYER>
     static __device__ __forceinline__ void g_w(const Ctx& c, const Fac& f, int k, double* g) {
         static_for<0, NST>([&](auto s) {
-            if constexpr ((MASK >> decltype(s)::value) & 1u) g[s] = -(f.d[s] * c.fac[(decltype(s)::value * NFAC + LAYER) * H + k]);
+            if constexpr ((MASK >> decltype(s)::value) & 1u) g[s] = -(f.d[s] * c.fac[slot_of<MASK>(decltype(s)::value) * STG + LAYER * H + k]);
         });
     }
     template <int NST, unsigned MASK, int E>
     static __device__ __forceinline__ void g_extra(const Ctx& c, double* g) {
         static_for<0, NST>([&](auto s) {
             if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                const lds_t* own = c.fac + decltype(s)::value * (NFAC * H) + c.j;          // a1 a2 a3 d1 d2 d3 of this lane
-                const lds_t* p = c.fac + (decltype(s)::value * NFAC + 6) * H;              // x0..x6 | delta4_0..6
+                const lds_t* own = c.fac + slot_of<MASK>(decltype(s)::value) * STG + c.j;  // a1 a2 a3 d1 d2 d3 of this lane
+                const lds_t* p = c.fac + slot_of<MASK>(decltype(s)::value) * STG + 6 * H;  // x0..x6 | delta4_0..6
                 double v;
                 if constexpr (E < NIN) v = -(own[3 * H] * p[E]);
                 else if constexpr (E == NIN) v = -own[3 * H];

@@ -214,6 +214,7 @@ struct SeirUde {
     // order), but no 2 x 71 persistent accumulators per lane and no per-evaluation broadcast of a1 for them.
     static constexpr bool DEFERRED = ONE;
     static constexpr bool DADJ_K_FROM_DENSE = false;
+    static constexpr bool COMPACT_STAGES = false;
     static constexpr int NSTG = 10, NFAC = 5, WPB = 4;  // stages stored (Vern7), factor fields, wavefronts per block
     static constexpr int LD = 65;  // leading dimension of the LDS copy of W2: row AND column reads conflict-free
     static constexpr int NPARAM = 3 * H + H + H * H + H + H + 1;  // 4481

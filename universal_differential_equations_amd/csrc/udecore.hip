@@ -277,7 +277,7 @@ static int default_lanes(int mid, bool discrete) {
         case MID_LV_TANH32: return 8;  // (32 lanes = 5000 wavefronts = five rounds for 10k trajectories: 16.5 ms vs 7.6 ms per gradient)
         case MID_SEIR_TRUE: return 1;
         case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
-        case MID_SEIR_NODE: return 64;  // wavefront per trajectory, 2 per block (two 64x64 layers + the stage factors fill the LDS)
+        case MID_SEIR_NODE: return 64;  // wavefront per trajectory, 3 per block (two 64x64 layers + the compacted stage factors fill the LDS)
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32:
