@@ -690,6 +690,12 @@ struct FwdSys {
     }
 };
 
+#ifndef UDE_FWD_BLOCKS_CPL
+#define UDE_FWD_BLOCKS_CPL 2  // blocks per CU the component-per-lane forward kernels are compiled for (register budget 256)
+#endif
+// model scratch of the forward / rhs kernels: Model::SCRATCH_FWD where a model declares one (its adjoint-only part left out)
+template <class M, class = void> struct scratch_fwd { static constexpr int v = M::SCRATCH; };
+template <class M> struct scratch_fwd<M, std::void_t<decltype(M::SCRATCH_FWD)>> { static constexpr int v = M::SCRATCH_FWD; };
 // LDS layout of a block: [theta copy | model scratch | stage derivatives k | slot state]
 template <class Model, class Tab, int G, int BLOCK, bool CPL = Model::CPL>
 struct Layout {
@@ -704,12 +710,12 @@ struct Layout {
 
 // RTag: the translation unit's scalar type in the kernel's NAME (the Float32 and Float64 builds of one instance are different symbols)
 template <class Model, class Tab, int G, int BLOCK, bool PT = false, class RTag = real>
-__global__ void __launch_bounds__(BLOCK) fwd_kernel(const KParams p) {
+__global__ void __launch_bounds__(BLOCK, (Model::CPL ? UDE_FWD_BLOCKS_CPL : 1)) fwd_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK>;
     real* th = reinterpret_cast<real*>(smem_raw);
     real* scratch = th + Model::theta_lds(p.n_param);
-    real* kbase = scratch + Model::SCRATCH;
+    real* kbase = scratch + scratch_fwd<Model>::v;
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     for (int i = threadIdx.x; i < L::K_DOUBLES; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
     __syncthreads();

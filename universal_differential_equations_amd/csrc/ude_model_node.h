@@ -45,6 +45,7 @@ struct SeirNode {
                          OFF_B3 = OFF_W3 + H * H, OFF_W4 = OFF_B3 + H, OFF_B4 = OFF_W4 + NOUT * H, NPARAM = OFF_B4 + NOUT;
     static_assert(NPARAM == 9287, "7-64-64-64-7");
     static constexpr int SCRATCH = WPB * (NSTC * STG + 2 * H);  // stage factors + 2 broadcast rows per wavefront
+    static constexpr int SCRATCH_FWD = WPB * 2 * H;             // forward / rhs kernels: the broadcast rows only
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
         double b1, b2, b3, b4[NOUT];
@@ -75,8 +76,8 @@ struct SeirNode {
         c.W2p = (const lds_t*)th;
         c.W3p = (const lds_t*)th + H * LD;
         const int wv = (threadIdx.x >> 6) % WPB;
-        c.bc = (lds_t*)scratch + WPB * NSTC * STG + wv * 2 * H;
-        c.fac = (lds_t*)scratch + wv * (NSTC * STG);
+        c.bc = (lds_t*)scratch + wv * 2 * H;  // (the broadcast rows first: all the forward kernels need of the scratch)
+        c.fac = (lds_t*)scratch + WPB * 2 * H + wv * (NSTC * STG);
         c.wx = (const lds_t*)th + 2 * H * LD + j;
         c.b1 = theta_g[OFF_B1 + j]; c.b2 = theta_g[OFF_B2 + j]; c.b3 = theta_g[OFF_B3 + j];
         static_for<0, NOUT>([&](auto i) { c.b4[i] = uniform_real(theta_g[OFF_B4 + decltype(i)::value]); });

@@ -221,6 +221,7 @@ struct SeirUde {
     static constexpr int OFF_W1 = 0, OFF_B1 = 3 * H, OFF_W2 = 4 * H, OFF_B2 = 4 * H + H * H, OFF_W3 = OFF_B2 + H,
                          OFF_B3 = OFF_W3 + H;
     static constexpr int SCRATCH = ONE ? WPB * (NSTG * NFAC + 2) * H : 3 * NBLK * H;  // stage factors + 2 broadcast rows / block sums
+    static constexpr int SCRATCH_FWD = ONE ? WPB * 2 * H : SCRATCH;  // forward / rhs kernels: no stage factors (two blocks per CU fit)
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
         double w2row[ONE ? 1 : KB], w2col[ONE ? 1 : KB], w1[3], b1, b2, w3, b3;
@@ -244,9 +245,9 @@ struct SeirUde {
         const int w = __builtin_amdgcn_readfirstlane(r >> 6);
         c.j = j; c.w = w; c.r = r; c.flip = 0;
         c.W2p = (const lds_t*)th;
-        c.bc = (lds_t*)scratch + WPB * NSTG * NFAC * H + ((threadIdx.x >> 6) % WPB) * 2 * H;
+        c.bc = (lds_t*)scratch + ((threadIdx.x >> 6) % WPB) * 2 * H;  // (the broadcast rows first: all the forward kernels need of the scratch)
         c.pf = scratch; c.pb = scratch + 2 * NBLK * H;
-        c.fac = (lds_t*)scratch + ((threadIdx.x >> 6) % WPB) * (NSTG * NFAC * H);
+        c.fac = (lds_t*)scratch + WPB * 2 * H + ((threadIdx.x >> 6) % WPB) * (NSTG * NFAC * H);
         if constexpr (!ONE)
             static_for<0, KB>([&](auto i) {
                 const int k = w * KB + i;
