@@ -690,9 +690,9 @@ struct FwdSys {
     }
 };
 
-#ifndef UDE_FWD_BLOCKS_CPL
-#define UDE_FWD_BLOCKS_CPL 2  // blocks per CU the component-per-lane forward kernels are compiled for (register budget 256)
-#endif
+// blocks per CU a model's forward kernel is compiled for (Model::FWD_BLOCKS; register budget 512 / (waves per SIMD))
+template <class M, class = void> struct fwd_blocks { static constexpr int v = 1; };
+template <class M> struct fwd_blocks<M, std::void_t<decltype(M::FWD_BLOCKS)>> { static constexpr int v = M::FWD_BLOCKS; };
 // model scratch of the forward / rhs kernels: Model::SCRATCH_FWD where a model declares one (its adjoint-only part left out)
 template <class M, class = void> struct scratch_fwd { static constexpr int v = M::SCRATCH; };
 template <class M> struct scratch_fwd<M, std::void_t<decltype(M::SCRATCH_FWD)>> { static constexpr int v = M::SCRATCH_FWD; };
@@ -710,7 +710,7 @@ struct Layout {
 
 // RTag: the translation unit's scalar type in the kernel's NAME (the Float32 and Float64 builds of one instance are different symbols)
 template <class Model, class Tab, int G, int BLOCK, bool PT = false, class RTag = real>
-__global__ void __launch_bounds__(BLOCK, (Model::CPL ? UDE_FWD_BLOCKS_CPL : 1)) fwd_kernel(const KParams p) {
+__global__ void __launch_bounds__(BLOCK, fwd_blocks<Model>::v) fwd_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK>;
     real* th = reinterpret_cast<real*>(smem_raw);

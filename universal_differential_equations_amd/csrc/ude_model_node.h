@@ -46,6 +46,7 @@ struct SeirNode {
     static_assert(NPARAM == 9287, "7-64-64-64-7");
     static constexpr int SCRATCH = WPB * (NSTC * STG + 2 * H);  // stage factors + 2 broadcast rows per wavefront
     static constexpr int SCRATCH_FWD = WPB * 2 * H;             // forward / rhs kernels: the broadcast rows only
+    static constexpr int FWD_BLOCKS = 2;                        // 2 x 80 KB of LDS, 256 registers
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
         double b1, b2, b3, b4[NOUT];

@@ -8,6 +8,9 @@
 #pragma once
 #include "ude_coop.h"
 
+#ifndef SEIR_FWD_BLOCKS
+#define SEIR_FWD_BLOCKS 2  // (3: 3.87 instead of 3.95 ms for 552 B of scratch per lane -- not worth it)
+#endif
 namespace ude {
 
 struct ModelConsts {
@@ -221,7 +224,8 @@ struct SeirUde {
     static constexpr int OFF_W1 = 0, OFF_B1 = 3 * H, OFF_W2 = 4 * H, OFF_B2 = 4 * H + H * H, OFF_W3 = OFF_B2 + H,
                          OFF_B3 = OFF_W3 + H;
     static constexpr int SCRATCH = ONE ? WPB * (NSTG * NFAC + 2) * H : 3 * NBLK * H;  // stage factors + 2 broadcast rows / block sums
-    static constexpr int SCRATCH_FWD = ONE ? WPB * 2 * H : SCRATCH;  // forward / rhs kernels: no stage factors (two blocks per CU fit)
+    static constexpr int SCRATCH_FWD = ONE ? WPB * 2 * H : SCRATCH;  // forward / rhs kernels: no stage factors (41 KB per block)
+    static constexpr int FWD_BLOCKS = ONE ? SEIR_FWD_BLOCKS : 1;
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
         double w2row[ONE ? 1 : KB], w2col[ONE ? 1 : KB], w1[3], b1, b2, w3, b3;
