@@ -84,7 +84,7 @@ function kpp_true(Nx, D, r, dx, ::Type{T} = Float64) where {T<:Real32or64}
 end
 
 # ---- context ----------------------------------------------------------------------------------------------------
-const CTXS = Dict{Int,Ptr{Cvoid}}()      # one context per device (and host thread: this shim is single-threaded)
+const CTXS = Dict{Int,Ptr{Cvoid}}()      # one context per device; a device is driven by one host task at a time
 function ctx(dev::Integer = 0)
     get!(CTXS, dev) do
         h = Ref{Ptr{Cvoid}}(C_NULL)
@@ -131,14 +131,17 @@ function rhs_ensemble(m::UDEModel, U::Matrix{T}, θ::Vector{T}) where {T<:Real32
     dU
 end
 
-function solve_ensemble(m::UDEModel, alg, u0s::Matrix{T}, tspan, θ::Vector{T}, ts::Vector{T}; kw...) where {T<:Real32or64}
+"`tspan` a pair or a 2 x N matrix, `ts` a vector or an ns x N matrix (per-member spans / save grids: the UDE_PT_* flags)"
+function solve_ensemble(m::UDEModel, alg, u0s::Matrix{T}, tspan, θ::Vector{T}, ts::AbstractVecOrMat{T}; dev = 0, kw...) where {T<:Real32or64}
     m.desc.dtype == dtypecode(T) || error("descriptor dtype and array element type differ")
-    n, N = size(u0s); ns = length(ts)
+    n, N = size(u0s); ns = size(ts, 1)
+    flags = (tspan isa AbstractMatrix ? 1 : 0) | (ts isa AbstractMatrix ? 2 : 0)
     out = Array{T}(undef, n, ns, N); stats = zeros(Int64, 8, N); rc = zeros(Int32, N)
-    d = Ref(m.desc); o = Ref(opts(alg; kw...)); tsp = Float64[tspan[1], tspan[2]]     # tspan: always a pair of host doubles
-    GC.@preserve u0s θ ts out stats rc tsp check(ccall((:ude_solve_ensemble, libudecore), Cint,
+    d = Ref(m.desc); o = Ref(opts(alg; per_trajectory = flags, kw...))
+    tsp = collect(Float64, vec(tspan isa Tuple ? [tspan...] : tspan)); tsa = collect(T, ts)     # tspan: always host doubles
+    GC.@preserve u0s θ tsa out stats rc tsp check(ccall((:ude_solve_ensemble, libudecore), Cint,
         (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{T}, Ptr{Float64}, Ptr{T}, Ptr{T}, Int32,
-         Ptr{T}, Ptr{Int64}, Ptr{Int32}), ctx(), d, o, N, u0s, tsp, θ, ts, ns, out, stats, rc); allow_failures = true)
+         Ptr{T}, Ptr{Int64}, Ptr{Int32}), ctx(dev), d, o, N, u0s, tsp, θ, tsa, ns, out, stats, rc), dev; allow_failures = true)
     out, stats, rc
 end
 
@@ -164,14 +167,25 @@ end
 # ---- multi-GPU (SURVEY.md 8(e)): contiguous blocks of trajectories per device, ONE all-reduce of [grad; loss; counters] ----
 "`_dev` entry points take HBM pointers; the shim keeps each device's buffers in plain hipMalloc'ed memory owned by
 the caller's GPU array package (AMDGPU.jl `ROCArray` pointers) -- shown here with `Ptr{Float64}` arguments."
-function loss_grad_multi(m::UDEModel, alg, devs::Vector{Int}, dptr::Vector{NamedTuple}, tspan, ts::Vector{Float64}; p2p = true, kw...)
+const COMMS = Dict{Vector{Int},Vector{Ptr{Cvoid}}}()     # communicators are created once per device set and kept
+function comms_for(devs::Vector{Int})
+    get!(COMMS, devs) do
+        ctxs = [ctx(dv) for dv in devs]
+        comms = Vector{Ptr{Cvoid}}(undef, length(devs))
+        check(ccall((:ude_comm_create_local, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), length(devs), ctxs, comms), devs[1])
+        comms
+    end
+end
+"every device's `payload` = double[np + 1] = [grad(np); loss] is filled by its own ude_loss_grad_ensemble_dev and then summed over
+the devices in ONE all-reduce (the per-trajectory counters stay in each device's `stats` array: the host adds them if it wants
+the ensemble-wide DEStats -- python's `pack_payload` appends them as three more doubles, this shim reduces np + 1 values)"
+function loss_grad_multi(m::UDEModel, alg, devs::Vector{Int}, dptr::Vector{<:NamedTuple}, tspan, ts::Vector{Float64}; p2p = true, kw...)
     np = Int(m.desc.n_param); nd = length(devs)
     ctxs = [ctx(dv) for dv in devs]
-    comms = Vector{Ptr{Cvoid}}(undef, nd)
-    check(ccall((:ude_comm_create_local, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), nd, ctxs, comms))
+    comms = comms_for(devs)
     d = Ref(m.desc); o = Ref(opts(alg; kw...)); tsp = Float64[tspan[1], tspan[2]]
     for (k, dv) in enumerate(devs)       # enqueue on every device; nothing blocks
-        b = dptr[k]                      # (N, u0, theta, saveat, data, mask, payload = [grad(np); loss; counters(3)], gu0, u, stats, rc)
+        b = dptr[k]                      # (N, u0, theta, saveat, data, mask, payload = [grad(np); loss], gu0, u, stats, rc)
         check(ccall((:ude_loss_grad_ensemble_dev, libudecore), Cint,
             (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
              Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
@@ -180,9 +194,8 @@ function loss_grad_multi(m::UDEModel, alg, devs::Vector{Int}, dptr::Vector{Named
     end
     bufs = [b.payload for b in dptr]
     f = p2p ? :ude_allreduce_grad_p2p : :ude_allreduce_grad_local      # fixed-rank-order peer reads, or RCCL (grouped)
-    check(ccall((f, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Int64), nd, comms, bufs, np + 4))
-    foreach(c -> ccall((:ude_comm_destroy, libudecore), Cvoid, (Ptr{Cvoid},), c), comms)
-    nothing                              # every device's payload now holds the ensemble-wide [grad; loss; counters]
+    check(ccall((f, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Int64), nd, comms, bufs, np + 1), devs[1])
+    nothing                              # every device's payload now holds the ensemble-wide [grad; loss]
 end
 
 # ---- highdim_pde/lambaem.jl: NNPDENS + LambaEM (SURVEY.md 8(f) N1) ---------------------------------------------------
@@ -194,8 +207,9 @@ end
 "one evaluation of loss_n_sde() and its gradient w.r.t. Flux.params(u0, σᵀ∇u) (flattened) for `trajectories` LambaEM solves
 (lambaem.jl:33-34); `iter` = the training iteration (fresh Philox noise per iteration)"
 function hjb_loss_grad(x0::Vector{Float32}, θ::Vector{Float32}, trajectories::Integer, iter::Integer; d = 100, hls = 110, λ = 1.0,
-                       tspan = (0.0, 1.0), abstol = 1e-4, reltol = 1e-4, seed = 0, adaptive = true, dt = 0.0)
-    D = Ref(HjbDesc(d, hls, adaptive, 0, 0, 0, seed, λ, sqrt(2.0f0), tspan[1], tspan[2], abstol, reltol, dt, 0, 0, 0, 0, 0, 0, 0))
+                       tspan = (0.0, 1.0), abstol = 1e-4, reltol = 1e-4, seed = 0, adaptive = true, dt = 0.0, max_steps = 0)
+    # max_steps = 0: the accepted-step store grows on demand (ude_hjb_loss_grad re-runs a call that outgrew it)
+    D = Ref(HjbDesc(d, hls, adaptive, 0, max_steps, 0, seed, λ, sqrt(2.0f0), tspan[1], tspan[2], abstol, reltol, dt, 0, 0, 0, 0, 0, 0, 0))
     loss = Ref(0.0); g = zeros(Float32, length(θ)); u0 = Ref(0.0f0); M = Int64(trajectories)
     GC.@preserve x0 θ g check(ccall((:ude_hjb_loss_grad, libudecore), Cint,
         (Ptr{Cvoid}, Ref{HjbDesc}, Int64, Ptr{Float32}, Ptr{Float32}, UInt32, Ref{Float64}, Ptr{Float32}, Ref{Float32}, Ptr{Float32},
@@ -241,13 +255,32 @@ function ChainRulesCore.rrule(::typeof(DiffEqBase.solve_up), prob, sensealg, u0,
 end
 
 # ensembles: solve(EnsembleProblem(prob; prob_func = (prob,i,_) -> remake(prob; u0 = u0s[:, i])), alg, EnsembleMI355(); trajectories = N)
+# Every member keeps ITS OWN tspan and save grid (prob_func may remake both: the segments of scenario_2.jl:104-124 are
+# remake(prob; u0, tspan = (T[1], T[end])) solved with saveat = T): they are handed over as 2 x N / ns x N arrays whenever
+# they differ between members.  Members are sharded in contiguous blocks over `ea.devices` (one host task per device).
 function SciMLBase.__solve(ens::SciMLBase.AbstractEnsembleProblem, alg::Union{MI355Tsit5,MI355Vern7}, ea::EnsembleMI355;
-                           trajectories, saveat, kw...)
+                           trajectories, saveat = nothing, kw...)
     probs = [ens.prob_func(ens.prob, i, 1) for i in 1:trajectories]
     u0s = reduce(hcat, [Vector{Float64}(p.u0) for p in probs])
-    ts = grid(saveat, ens.prob.tspan)
-    u, stats, rc = solve_ensemble(ens.prob.f.f, alg, u0s, ens.prob.tspan, Vector{Float64}(ens.prob.p), ts; kw...)
-    SciMLBase.EnsembleSolution([DiffEqBase.build_solution(probs[j], alg, ts, [u[:, i, j] for i in 1:length(ts)]) for j in 1:trajectories], 0.0, true)
+    grids = [grid(something(saveat, get(p.kwargs, :saveat, nothing)), p.tspan) for p in probs]
+    all(length(g) == length(grids[1]) for g in grids) || error("EnsembleMI355: every member needs the same NUMBER of save points")
+    same_span = all(p.tspan == probs[1].tspan for p in probs); same_grid = all(g == grids[1] for g in grids)
+    tspans = same_span ? probs[1].tspan : reduce(hcat, [Float64[p.tspan[1], p.tspan[2]] for p in probs])
+    tss = same_grid ? grids[1] : reduce(hcat, grids)
+    all(p.p == probs[1].p for p in probs) || error("EnsembleMI355: the members of an ensemble share the parameter vector")
+    θ = Vector{Float64}(probs[1].p); N = trajectories; nd = length(ea.devices)
+    u = Array{Float64}(undef, size(u0s, 1), length(grids[1]), N); rc = zeros(Int32, N)
+    bounds = [(div((k - 1) * N, nd) + 1, div(k * N, nd)) for k in 1:nd]
+    @sync for (k, dv) in enumerate(ea.devices)
+        lo, hi = bounds[k]; hi >= lo || continue
+        Threads.@spawn begin
+            uk, _, rck = solve_ensemble(ens.prob.f.f, alg, u0s[:, lo:hi], same_span ? tspans : tspans[:, lo:hi], θ,
+                                        same_grid ? tss : tss[:, lo:hi]; dev = dv, kw...)
+            u[:, :, lo:hi] .= uk; rc[lo:hi] .= rck
+        end
+    end
+    SciMLBase.EnsembleSolution([DiffEqBase.build_solution(probs[j], alg, grids[j], [u[:, i, j] for i in 1:length(grids[j])];
+                                                          retcode = rc[j] == 0 ? :Success : :Failure) for j in 1:trajectories], 0.0, true)
 end
 
 end # module

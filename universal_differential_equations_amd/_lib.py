@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libudecore.so")
+# UDE_LIB_VARIANT=dbg selects the debug build (libudecore_dbg.so: same kernels, host side compiled with -DUDE_DEBUG_HOOKS --
+# register poison, workspace fill, phase clocks; tests/test_gpu_poison.py runs the parity tests against it in a subprocess)
+LIB_PATH = os.path.join(HERE, "libudecore_dbg.so" if os.environ.get("UDE_LIB_VARIANT") == "dbg" else "libudecore.so")
 MAX_LAYERS = 8
 NSTATS = 8
 

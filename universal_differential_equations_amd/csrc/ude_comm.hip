@@ -4,13 +4,16 @@
 //     id; or all devices in one process: ude_comm_create_local = ncclCommInitAll).  RCCL is bound with dlopen so that
 //     libudecore.so loads on a box without it and shares whichever librccl the process already mapped (PyTorch's).
 //   * one-shot P2P reducer (single process, peer access over xGMI): every device reads the buffers of all ranks and adds
-//     them in RANK ORDER -- a deterministic fp64 sum, identical bits on every device, two kernel launches of latency
-//     instead of a 2(N-1)-step ring for a 704 B .. 36 KB payload.
+//     them in RANK ORDER -- a deterministic fp64 sum, identical bits on every device; per call and device ONE kernel and
+//     ONE device-to-device copy between pre-created events (the pointer table is device resident and re-uploaded only when
+//     the caller's buffers change), instead of a 2(N-1)-step ring for a 704 B .. 36 KB payload.  Works without librccl.
 // The reference is single-process CPU Julia: nothing is replaced, this is the multi-GPU row of the scope table.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "ude_ctx.h"
@@ -35,9 +38,8 @@ struct Rccl {
 };
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.h) break;
@@ -53,7 +55,7 @@ Rccl* rccl() {
             r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.AllReduce || !r.CommDestroy) r.h = nullptr;
         }
-    }
+    });
     return r.h ? &r : nullptr;
 }
 
@@ -67,10 +69,33 @@ __global__ void p2p_sum_kernel(const double* const* in, int nranks, int64_t n, d
 }
 }  // namespace
 
+// state of the one-shot P2P reducer shared by the communicators of one ude_comm_create_local call: everything a call needs
+// exists before the first call (events) or is cached across calls (device-resident pointer table, output buffer)
+struct P2PGroup {
+    int ndev = 0;
+    bool peers_ok = false;  // every device can read every other device's memory (checked, not assumed)
+    std::vector<int> device;
+    std::vector<hipEvent_t> ready, readdone;          // one pair per device, created once
+    std::vector<void*> table;                          // per device: [ndev pointers | n doubles] in HBM
+    std::vector<size_t> table_cap;
+    std::vector<double*> cached;                       // the buffer pointers the tables currently hold
+    size_t ptr_bytes() const { return (sizeof(double*) * ndev + 15) / 16 * 16; }
+    ~P2PGroup() {
+        for (int i = 0; i < ndev; ++i) {
+            (void)hipSetDevice(device[i]);
+            (void)hipDeviceSynchronize();
+            if (ready[i]) (void)hipEventDestroy(ready[i]);
+            if (readdone[i]) (void)hipEventDestroy(readdone[i]);
+            if (table[i]) (void)hipFree(table[i]);
+        }
+    }
+};
+
 struct ude_comm {
     ude_ctx* ctx = nullptr;
     ncclComm_t nccl = nullptr;
     int nranks = 1, rank = 0;
+    std::shared_ptr<P2PGroup> p2p;
 };
 
 #define NCCLCHK(c, call)                                                                                            \
@@ -110,25 +135,45 @@ extern "C" int ude_comm_create(ude_ctx* c, int32_t nranks, int32_t rank, const c
 
 extern "C" int ude_comm_create_local(int32_t ndev, ude_ctx* const* ctxs, ude_comm** out) {
     if (!ctxs || !out || ndev < 1) return UDE_ERR_INVALID;
-    Rccl* R = rccl();
-    if (!R) return fail(ctxs[0], UDE_ERR_UNSUPPORTED, "librccl could not be loaded");
+    for (int i = 0; i < ndev; ++i)
+        if (!ctxs[i]) return UDE_ERR_INVALID;
+    Rccl* R = rccl();  // optional: without librccl the communicators still serve the P2P reducer
     std::vector<int> devs(ndev);
-    std::vector<ncclComm_t> comms(ndev);
+    std::vector<ncclComm_t> comms(ndev, nullptr);
     for (int i = 0; i < ndev; ++i) devs[i] = ctxs[i]->device;
-    NCCLCHK(ctxs[0], R->CommInitAll(comms.data(), ndev, devs.data()));
+    if (R) NCCLCHK(ctxs[0], R->CommInitAll(comms.data(), ndev, devs.data()));
+    auto grp = std::make_shared<P2PGroup>();
+    grp->ndev = ndev;
+    grp->device = devs;
+    grp->ready.assign(ndev, nullptr);
+    grp->readdone.assign(ndev, nullptr);
+    grp->table.assign(ndev, nullptr);
+    grp->table_cap.assign(ndev, 0);
+    grp->cached.assign(ndev, nullptr);
+    bool ok = true, peers = true;
+    for (int i = 0; i < ndev && ok; ++i) {
+        ok = hipSetDevice(devs[i]) == hipSuccess &&
+             hipEventCreateWithFlags(&grp->ready[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&grp->readdone[i], hipEventDisableTiming) == hipSuccess;
+        for (int j = 0; j < ndev && ok; ++j) {
+            if (devs[j] == devs[i]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devs[i], devs[j]) != hipSuccess || !can) { peers = false; continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(devs[j], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peers = false;
+        }
+        (void)hipGetLastError();
+    }
+    if (!ok) {  // (the group's destructor releases what was created)
+        for (int i = 0; i < ndev; ++i)
+            if (comms[i] && R) (void)R->CommDestroy(comms[i]);
+        return fail(ctxs[0], UDE_ERR_HIP, "could not create the events of the P2P reducer");
+    }
+    grp->peers_ok = peers;
     for (int i = 0; i < ndev; ++i) {
         ude_comm* m = new ude_comm();
-        m->ctx = ctxs[i]; m->nccl = comms[i]; m->nranks = ndev; m->rank = i;
+        m->ctx = ctxs[i]; m->nccl = comms[i]; m->nranks = ndev; m->rank = i; m->p2p = grp;
         out[i] = m;
-        // peer access for the P2P reducer (best effort: already-enabled is fine)
-        (void)hipSetDevice(ctxs[i]->device);
-        for (int j = 0; j < ndev; ++j)
-            if (j != i) {
-                int can = 0;
-                if (hipDeviceCanAccessPeer(&can, ctxs[i]->device, ctxs[j]->device) == hipSuccess && can)
-                    (void)hipDeviceEnablePeerAccess(ctxs[j]->device, 0);
-            }
-        (void)hipGetLastError();
     }
     return UDE_OK;
 }
@@ -142,6 +187,7 @@ extern "C" void ude_comm_destroy(ude_comm* m) {
 extern "C" int ude_allreduce_grad(ude_comm* m, double* buf_dev, int64_t n) {
     if (!m || !buf_dev || n <= 0) return UDE_ERR_INVALID;
     ude_ctx* c = m->ctx;
+    if (!m->nccl || !rccl()) return fail(c, UDE_ERR_UNSUPPORTED, "this communicator has no RCCL handle (librccl could not be loaded)");
     HIPCHK(c, hipSetDevice(c->device));
     NCCLCHK(c, rccl()->AllReduce(buf_dev, buf_dev, (size_t)n, ncclFloat64, ncclSum, m->nccl, c->stream));
     return UDE_OK;
@@ -150,62 +196,86 @@ extern "C" int ude_allreduce_grad(ude_comm* m, double* buf_dev, int64_t n) {
 // all ranks of one process at once (a single-threaded host must group the calls: RCCL would deadlock otherwise)
 extern "C" int ude_allreduce_grad_local(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n) {
     if (!comms || !bufs_dev || ndev < 1 || n <= 0) return UDE_ERR_INVALID;
+    for (int i = 0; i < ndev; ++i)
+        if (!comms[i] || !bufs_dev[i]) return UDE_ERR_INVALID;
     Rccl* R = rccl();
     ude_ctx* c0 = comms[0]->ctx;
+    if (!R || !comms[0]->nccl) return fail(c0, UDE_ERR_UNSUPPORTED, "librccl could not be loaded (ude_allreduce_grad_p2p needs no RCCL)");
     if (R->GroupStart) NCCLCHK(c0, R->GroupStart());
-    for (int i = 0; i < ndev; ++i) {
-        ude_ctx* c = comms[i]->ctx;
-        HIPCHK(c, hipSetDevice(c->device));
-        NCCLCHK(c, R->AllReduce(bufs_dev[i], bufs_dev[i], (size_t)n, ncclFloat64, ncclSum, comms[i]->nccl, c->stream));
-    }
-    if (R->GroupEnd) NCCLCHK(c0, R->GroupEnd());
-    return UDE_OK;
-}
-
-// one-shot P2P reducer: out_d = sum_r in_r in rank order on every device d, then in_d <- out_d.  Ordering across the
-// devices' streams by events: (1) every stream's producer work is done before any device reads, (2) every device has
-// finished reading before any buffer is overwritten.
-extern "C" int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n) {
-    if (!comms || !bufs_dev || ndev < 1 || n <= 0) return UDE_ERR_INVALID;
-    std::vector<hipEvent_t> ready(ndev), readdone(ndev);
-    ude_ctx* c0 = comms[0]->ctx;
-    for (int i = 0; i < ndev; ++i) {
-        ude_ctx* c = comms[i]->ctx;
-        HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipEventCreateWithFlags(&ready[i], hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&readdone[i], hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(ready[i], c->stream));
-    }
     int rc = UDE_OK;
     for (int i = 0; i < ndev && rc == UDE_OK; ++i) {
         ude_ctx* c = comms[i]->ctx;
-        HIPCHK(c, hipSetDevice(c->device));
-        for (int j = 0; j < ndev; ++j)
-            if (j != i) HIPCHK(c, hipStreamWaitEvent(c->stream, ready[j], 0));
-        // workspace: [ndev pointers | n doubles]
-        const size_t ptr_bytes = (sizeof(double*) * ndev + 15) / 16 * 16;
-        if ((rc = ensure(c, c->hj[31], ptr_bytes + sizeof(double) * n))) break;
-        HIPCHK(c, hipMemcpyAsync(c->hj[31].p, bufs_dev, sizeof(double*) * ndev, hipMemcpyHostToDevice, c->stream));
-        double* out = (double*)((char*)c->hj[31].p + ptr_bytes);
-        hipLaunchKernelGGL(p2p_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                           (const double* const*)c->hj[31].p, (int)ndev, n, out);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(readdone[i], c->stream));
+        if (hipSetDevice(c->device) != hipSuccess) { rc = fail(c, UDE_ERR_HIP, "hipSetDevice(%d) failed", c->device); break; }
+        const ncclResult_t r = R->AllReduce(bufs_dev[i], bufs_dev[i], (size_t)n, ncclFloat64, ncclSum, comms[i]->nccl, c->stream);
+        if (r != ncclSuccess) rc = fail(c, UDE_ERR_HIP, "ncclAllReduce failed: %s", R->GetErrorString ? R->GetErrorString(r) : "rccl error");
     }
-    for (int i = 0; i < ndev && rc == UDE_OK; ++i) {
+    // the group is ALWAYS closed: an error between GroupStart and GroupEnd must not leave RCCL in group mode
+    if (R->GroupEnd) {
+        const ncclResult_t r = R->GroupEnd();
+        if (r != ncclSuccess && rc == UDE_OK) rc = fail(c0, UDE_ERR_HIP, "ncclGroupEnd failed: %s", R->GetErrorString ? R->GetErrorString(r) : "rccl error");
+    }
+    return rc;
+}
+
+// one-shot P2P reducer: out_d = sum_r in_r in rank order on every device d, then in_d <- out_d.  Ordering across the
+// devices' streams by the group's pre-created events: (1) every stream's producer work is done before any device reads,
+// (2) every device has finished reading before any buffer is overwritten.  Per call and device: one event record, ndev - 1
+// stream waits, ONE kernel, one record, ndev - 1 waits, ONE device-to-device copy -- no allocation, no event creation and no
+// host-to-device copy once the tables hold the caller's buffers.
+extern "C" int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n) {
+    if (!comms || !bufs_dev || ndev < 1 || n <= 0) return UDE_ERR_INVALID;
+    for (int i = 0; i < ndev; ++i)
+        if (!comms[i] || !bufs_dev[i]) return UDE_ERR_INVALID;
+    ude_ctx* c0 = comms[0]->ctx;
+    P2PGroup* g = comms[0]->p2p.get();
+    if (!g || g->ndev != ndev) return fail(c0, UDE_ERR_INVALID, "ude_allreduce_grad_p2p needs the communicators of one ude_comm_create_local call");
+    for (int i = 0; i < ndev; ++i)
+        if (comms[i]->p2p.get() != g || comms[i]->rank != i) return fail(c0, UDE_ERR_INVALID, "communicators out of order / from different groups");
+    if (!g->peers_ok) return fail(c0, UDE_ERR_UNSUPPORTED, "peer access between the devices of this group is not available: use ude_allreduce_grad_local");
+    const size_t pb = g->ptr_bytes(), need = pb + sizeof(double) * (size_t)n;
+    // (re)build the device-resident tables only when the payload grew or the caller's buffers moved
+    bool same = true;
+    for (int i = 0; i < ndev; ++i) same = same && g->cached[i] == bufs_dev[i] && g->table_cap[i] >= need;
+    if (!same) {
+        for (int i = 0; i < ndev; ++i) {
+            ude_ctx* c = comms[i]->ctx;
+            HIPCHK(c, hipSetDevice(c->device));
+            if (g->table_cap[i] < need) {
+                HIPCHK(c, hipDeviceSynchronize());
+                if (g->table[i]) HIPCHK(c, hipFree(g->table[i]));
+                g->table[i] = nullptr;
+                g->table_cap[i] = 0;
+                if (hipMalloc(&g->table[i], need + need / 4) != hipSuccess) return fail(c, UDE_ERR_NOMEM, "hipMalloc(%zu) failed", need + need / 4);
+                g->table_cap[i] = need + need / 4;
+            }
+            // stream-ordered after whatever still reads the old table; the source is copied before the call returns
+            HIPCHK(c, hipMemcpyAsync(g->table[i], bufs_dev, sizeof(double*) * ndev, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        for (int i = 0; i < ndev; ++i) g->cached[i] = bufs_dev[i];
+    }
+    for (int i = 0; i < ndev; ++i) {
+        ude_ctx* c = comms[i]->ctx;
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipEventRecord(g->ready[i], c->stream));
+    }
+    for (int i = 0; i < ndev; ++i) {
         ude_ctx* c = comms[i]->ctx;
         HIPCHK(c, hipSetDevice(c->device));
         for (int j = 0; j < ndev; ++j)
-            if (j != i) HIPCHK(c, hipStreamWaitEvent(c->stream, readdone[j], 0));
-        const size_t ptr_bytes = (sizeof(double*) * ndev + 15) / 16 * 16;
-        HIPCHK(c, hipMemcpyAsync(bufs_dev[i], (char*)c->hj[31].p + ptr_bytes, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+            if (j != i) HIPCHK(c, hipStreamWaitEvent(c->stream, g->ready[j], 0));
+        double* out = (double*)((char*)g->table[i] + pb);
+        hipLaunchKernelGGL(p2p_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double* const*)g->table[i], (int)ndev, n, out);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(g->readdone[i], c->stream));
     }
     for (int i = 0; i < ndev; ++i) {
-        (void)hipSetDevice(comms[i]->ctx->device);
-        // (events are released once the work queued behind them has been submitted; destruction is deferred by the runtime)
-        (void)hipEventDestroy(ready[i]);
-        (void)hipEventDestroy(readdone[i]);
+        ude_ctx* c = comms[i]->ctx;
+        HIPCHK(c, hipSetDevice(c->device));
+        for (int j = 0; j < ndev; ++j)
+            if (j != i) HIPCHK(c, hipStreamWaitEvent(c->stream, g->readdone[j], 0));
+        HIPCHK(c, hipMemcpyAsync(bufs_dev[i], (char*)g->table[i] + pb, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     }
-    (void)c0;
-    return rc;
+    return UDE_OK;
 }

@@ -65,5 +65,11 @@ static inline int ensure(ude_ctx* c, DevBuf& b, size_t bytes) {
     return UDE_OK;
 }
 
-// debugging hook (UDE_EXP_POISON, udecore.hip): garbage into every register / LDS byte of the chip in front of a kernel
-void ude_poison_chip(hipStream_t st, bool before_forward);
+// debugging hook of the DEBUG build only (-DUDE_DEBUG_HOOKS, libudecore_dbg.so; UDE_EXP_POISON, udecore.hip): garbage into
+// every register / LDS byte of the chip in front of a kernel.  In the shipping library this is an empty inline function.
+#ifdef UDE_DEBUG_HOOKS
+void ude_poison_chip_dbg(hipStream_t st, bool before_forward);
+static inline void ude_poison_chip(hipStream_t st, bool before_forward) { ude_poison_chip_dbg(st, before_forward); }
+#else
+static inline void ude_poison_chip(hipStream_t, bool) {}
+#endif

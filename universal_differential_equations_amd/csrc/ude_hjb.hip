@@ -134,7 +134,11 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
     const int32_t qstart = (int32_t)(nblk_f * NT);
     p.queue = (int32_t*)c->hj[B_QUEUE].p;
     HIPCHK(c, hipMemcpyAsync(p.queue, &qstart, sizeof qstart, hipMemcpyHostToDevice, c->stream));
-    const bool prof = getenv("UDE_HJB_PROF") != nullptr;  // debug: phase clocks of block 0 on stderr (blocks the stream)
+#ifdef UDE_DEBUG_HOOKS
+    static const bool prof = getenv("UDE_HJB_PROF") != nullptr;  // debug build: phase clocks of block 0 on stderr (blocks the stream)
+#else
+    constexpr bool prof = false;
+#endif
     if (prof) {
         if ((rc = ensure(c, c->hj[30], sizeof(unsigned long long) * 16))) return rc;
         p.prof = (unsigned long long*)c->hj[30].p;
@@ -261,6 +265,9 @@ extern "C" int ude_hjb_net(ude_ctx* c, int32_t d, int32_t hls, const float* thet
 // debugging aid for parity work: raw copy of a workspace of the most recent call (which: 0 prep, 1 Xin records, 5 E4 records)
 extern "C" int ude_hjb_debug_read(ude_ctx* c, int32_t which, int64_t offset_floats, int64_t n_floats, float* out_host) {
     if (!c || !out_host || which < 0 || which > B_E4 || !c->hj[which].p) return UDE_ERR_INVALID;
+    if (offset_floats < 0 || n_floats < 0 || (size_t)(offset_floats + n_floats) * sizeof(float) > c->hj[which].cap)
+        return fail(c, UDE_ERR_INVALID, "debug read [%lld, %lld) floats is outside workspace %d (%zu bytes)", (long long)offset_floats,
+                    (long long)(offset_floats + n_floats), which, c->hj[which].cap);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out_host, (const float*)c->hj[which].p + offset_floats, sizeof(float) * n_floats, hipMemcpyDeviceToHost));

@@ -175,9 +175,12 @@ __global__ void mfma_probe_kernel(const double* x, const double* y, double* out)
 }  // namespace ude
 
 #include "ude_ctx.h"
+#ifdef UDE_DEBUG_HOOKS
+// Debug build only (libudecore_dbg.so, build.py): the shipping library contains none of this and reads no environment
+// variable on its launch path.  ude_poison_gen.h is generated into build/ by tools/gen_poison_header.py at build time.
+// UDE_EXP_POISON=<kind>[,<what>]: between the forward and the backward kernel every register and every LDS byte of the chip
+// is set to a known pattern -- a kernel whose result changes with the pattern reads state it never wrote
 #include "ude_poison_gen.h"
-// debugging experiment (UDE_EXP_POISON=<kind>[,<what>]): between the forward and the backward kernel every register and every LDS
-// byte of the chip is set to a known pattern -- a kernel whose result changes with the pattern reads state it never wrote
 __global__ void __launch_bounds__(256) poison_regs_kernel(unsigned pat, unsigned* sink, unsigned mask, unsigned lo, unsigned hi) {
     if (hi > lo) { UDE_POISON_ASM_RANGE(0x9e3779b1u, lo, hi); } else if (mask) { UDE_POISON_ASM_MASK(0x9e3779b1u, mask); } else if (pat == 0x9e3779b1u) { UDE_POISON_ASM_LANES(pat); } else { UDE_POISON_ASM(pat); }
     if (pat == 0x12345u && sink) sink[threadIdx.x] = pat;
@@ -188,8 +191,8 @@ __global__ void __launch_bounds__(256) poison_lds_kernel(unsigned pat, int words
     __syncthreads();
     if (pat == 0x12345u && sink) sink[threadIdx.x] = pl[threadIdx.x];
 }
-void ude_poison_chip(hipStream_t st, bool before_forward) {  // (what & 4: also in front of the forward kernels)
-    const char* e = getenv("UDE_EXP_POISON");
+void ude_poison_chip_dbg(hipStream_t st, bool before_forward) {  // (what & 4: also in front of the forward kernels)
+    static const char* e = getenv("UDE_EXP_POISON");  // read once per process
     if (!e) return;
     int kind = 0, what = 3;
     unsigned mask = 0;  // kind 4: bit k < 8: v[32k, 32k+32) get lane-varying garbage, bit 8+k: a[32k, 32k+32); every other register zero
@@ -203,6 +206,7 @@ void ude_poison_chip(hipStream_t st, bool before_forward) {  // (what & 4: also 
         hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 160 * 1024, st, pat, 160 * 256, (unsigned*)nullptr);
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // compiled model table (instances live in their own translation units, see build.py)
@@ -425,8 +429,13 @@ extern "C" int ude_set_stream(ude_ctx* c, void* s) {
         // finish before work on the new stream may reuse them
         HIPCHK(c, hipSetDevice(c->device));
         if (!capturing(ns) && !capturing(c->stream)) {  // (a capture starts from an idle context: the caller synchronises first)
-            HIPCHK(c, hipEventRecord(c->ev_sync, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(ns, c->ev_sync, 0));
+            // the old stream may already have been destroyed by the host: then (or on any other failure of the event hop) fall
+            // back to a device-wide sync -- the context must never stay bound to a dead stream
+            if (hipEventRecord(c->ev_sync, c->stream) != hipSuccess || hipStreamWaitEvent(ns, c->ev_sync, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                c->stream = ns;
+                HIPCHK(c, hipDeviceSynchronize());
+            }
         }
         c->stream = ns;
     }
@@ -653,13 +662,16 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if (shmem_f > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
     const bool cap_graph = capturing(c->stream);  // inside a hipGraph capture: the per-kernel timing events are left out
-    if (const char* fill = getenv("UDE_EXP_WS_FILL")) {  // debugging experiment: every workspace byte the kernels may read set to a known value first
-        const int v = atoi(fill);
+#ifdef UDE_DEBUG_HOOKS
+    static const char* ws_fill = getenv("UDE_EXP_WS_FILL");  // debug build: every workspace byte the kernels may read set to a known value first
+    if (ws_fill) {
+        const int v = atoi(ws_fill);
         HIPCHK(c, hipMemsetAsync(c->dense.p, v, c->dense.cap, c->stream));
         HIPCHK(c, hipMemsetAsync(c->dense_n.p, v, c->dense_n.cap, c->stream));
         HIPCHK(c, hipMemsetAsync(c->cot.p, v, c->cot.cap, c->stream));
         if (c->slot_glob.p) HIPCHK(c, hipMemsetAsync(c->slot_glob.p, v, c->slot_glob.cap, c->stream));
     }
+#endif
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)nwaves * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     ude_poison_chip(c->stream, true);

@@ -29,9 +29,10 @@ def pack_payload(grad_loss, stats):
     s = stats.sum(0)
     if hasattr(s, "to"):      # torch
         import torch
-        c = torch.stack([s[0] + s[4], s[1] + s[5], s[2] + s[6]]).to(grad_loss.dtype)
-        return torch.cat([grad_loss, c])
-    return np.concatenate([grad_loss, np.array([s[0] + s[4], s[1] + s[5], s[2] + s[6]], dtype=grad_loss.dtype)])
+        # the payload is ALWAYS float64 (a Float32 problem's counters exceed 2^24 on a real ensemble)
+        c = torch.stack([s[0] + s[4], s[1] + s[5], s[2] + s[6]]).to(torch.float64)
+        return torch.cat([grad_loss.to(torch.float64), c])
+    return np.concatenate([np.asarray(grad_loss, dtype=np.float64), np.array([s[0] + s[4], s[1] + s[5], s[2] + s[6]], dtype=np.float64)])
 
 
 def allreduce_payload(buf, dist=None):
