@@ -198,7 +198,9 @@ typedef struct {
     int32_t hls;        /* 10 + d (lambaem.jl:20) */
     int32_t adaptive;   /* 1 = LambaEM with error control (lambaem.jl:33); 0 = fixed-step Euler-Maruyama with `dt` */
     int32_t maxiters;   /* step attempts per trajectory, <= 0 -> 1000000 */
-    int32_t max_steps;  /* capacity of the accepted-step store per trajectory, <= 0 -> 512 */
+    int32_t max_steps;  /* capacity of the accepted-step store per trajectory (2.2 KB per step); <= 0 = automatic: starts at 512 and is
+                           multiplied by 4 when a trajectory outgrows it (ude_hjb_loss_grad re-runs the call by itself,
+                           ude_hjb_last_failures does it for the asynchronous _dev entry point); loss-only calls record nothing */
     int32_t reserved;
     uint64_t seed;      /* Philox key */
     double lambda;      /* lambaem.jl:12 */
@@ -209,7 +211,8 @@ typedef struct {
     double qmin, qmax, gamma, qoldinit, beta1, beta2, dtmax; /* <= 0 -> StochasticDiffEq defaults 1/5, 9/8, 9/10, 1e-4, 7/10, 2/5, t1 - t0 */
 } ude_hjb_desc;
 enum { UDE_HJB_NSTATS = 4 }; /* per trajectory: 0 network evaluations, 1 naccept, 2 nreject, 3 random draw events */
-enum { UDE_RET_STACK_OVERFLOW = 5 /* more than 32 unconsumed rejected increments (RSwM stack) */ };
+enum { UDE_RET_STORE_OVERFLOW = 4 /* more accepted steps than ude_hjb_desc.max_steps (gradient calls only) */,
+       UDE_RET_STACK_OVERFLOW = 5 /* more than 32 unconsumed rejected increments (RSwM stack) */ };
 
 int ude_hjb_num_params(int32_t d, int32_t hls, int32_t* np_u0, int32_t* np_sg);
 /* replaces: one evaluation of loss_n_sde() and its Tracker gradient inside Flux.train!(loss_n_sde, ps, data, opt)
@@ -233,6 +236,10 @@ int ude_hjb_net(ude_ctx* ctx, int32_t d, int32_t hls, const float* theta_sg_host
 /* debugging aid for parity work: raw float copy out of a workspace of the most recent call (0: [u0, initial dt, ...],
  * 1: the accepted-step records [trajectory][step][104] = X_n (100), t_n; 5: [trajectory][step][100] = 2 lambda dt z + dW) */
 int ude_hjb_debug_read(ude_ctx* ctx, int32_t which, int64_t offset_floats, int64_t n_floats, float* out_host);
+/* failure accounting of the most recent ude_hjb_loss_grad_dev call on this context (blocks on its stream): *nfail = trajectories
+ * whose retcode is not Success (retcode_dev = the array passed to the call, or NULL for the context's own); if one of them outgrew the
+ * AUTOMATIC accepted-step store, its capacity is multiplied by 4 and *grown = 1: the caller repeats the call */
+int ude_hjb_last_failures(ude_ctx* ctx, const int32_t* retcode_dev, int64_t M, int32_t* nfail, int32_t* grown);
 /* device time (ms) of the forward and backward kernels of the most recent ude_hjb_loss_grad* call (HIP events on the stream) */
 int ude_hjb_last_kernel_ms(ude_ctx* ctx, float* fwd_ms, float* bwd_ms);
 

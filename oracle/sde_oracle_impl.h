@@ -15,12 +15,20 @@ static REAL NAME(tsum)(const REAL* v, int n) {
     return b[0];
 }
 
-/* Dense layer, Flux layout W (out x in, column-major) then b: out_j = act(chain(b_j; W[j,k] a_k, k ascending)) */
+/* Dense layer, Flux layout W (out x in, column-major) then b: out_j = act(chain(b_j; W[j,k] a_k, k ascending)).
+ * relu: NNlib's relu(x) = max(zero(x), x) (Flux 0.9, highdim_pde/Manifest.toml:264).  Its derivative under Tracker /
+ * ForwardDiff is the partial of `max` with respect to its SECOND argument, `0 > x ? 0 : 1`: ONE at x == 0 [UP?].  That
+ * convention is not a curiosity here: with x0 = 0 (lambaem.jl:9) and Flux's zero-initialised biases every pre-activation of
+ * the u0 chain -- and of the first step's sigma^T grad u evaluation at (X, t) = (0, 0) -- is exactly 0 at the first
+ * iteration; with relu'(0) = 0 only the output bias of u0 would ever receive a gradient there.
+ * The output keeps the SIGN BIT of a non-positive pre-activation (-0.0 for a negative one, +0.0 for +0) (value 0 either way; a product with +-0 never changes a
+ * sum that starts from a bias): RELU_ON(a) = "the pre-activation was >= 0" is what the reverse sweeps need. */
+#define RELU_ON(a) (!signbit(a))
 static void NAME(dense)(const REAL* W, const REAL* b, int in, int out, const REAL* a, REAL* o, int relu) {
     for (int j = 0; j < out; ++j) {
         REAL acc = b[j];
         for (int k = 0; k < in; ++k) acc = FMA(W[j + (size_t)k * out], a[k], acc);
-        o[j] = relu ? (acc > (REAL)0 ? acc : (REAL)0) : acc;
+        o[j] = relu ? (acc > (REAL)0 ? acc : (signbit(acc) ? (REAL)-0.0 : (REAL)0)) : acc;
     }
 }
 
@@ -199,11 +207,22 @@ static void NAME(traj)(const udeo_hjb_desc* D, const NAME(Nets)* n, const NAME(P
             xin[d] = t;
             NAME(sg_fwd)(n, xin, a1, a2, a3, z3);
             st->nf += 2;
-            for (int c = 0; c < d; ++c) tmp[c] = (z3[c] - z[c]) * (dW[c] * dW[c]);
-            const REAL En = (NAME(tsum)(tmp, d) / sq) * (REAL)0.5;
+            /* non-diagonal noise: the diffusion enters the estimate through SCALAR norms [UP?] --
+             *   g_sized = ||G(h)||_F, ggprime = (||G(utilde)||_F - g_sized) / sqrt(dt), En = ggprime * internalnorm(dW.^2) / 2
+             * (internalnorm = RMS), one number added to EVERY component's residual; the drift part Ed lives on the u row only */
+            const REAL gs3 = SQRT(FMA((REAL)d * p->sig, p->sig, NAME(sumsq)(z3, d)));
+            const REAL ggp = (gs3 - gs) / sq;
+            for (int c = 0; c < d; ++c) { const REAL w2 = dW[c] * dW[c]; tmp[c] = w2 * w2; }
+            const REAL nW2 = SQRT(NAME(tsum)(tmp, d) / (REAL)d);
+            const REAL En = (ggp * nW2) * (REAL)0.5;
+            for (int c = 0; c < d; ++c) {
+                const REAL a0 = FABS(X[c]), a1x = FABS(Xn[c]);
+                const REAL r = En / FMA((a0 > a1x ? a0 : a1x), p->reltol, p->abstol);
+                tmp[c] = r * r;
+            }
             const REAL au = FABS(u), aun = FABS(un);
             const REAL res = (Ed + En) / FMA((au > aun ? au : aun), p->reltol, p->abstol);
-            EE = SQRT((res * res) / (REAL)(d + 1));
+            EE = SQRT((NAME(tsum)(tmp, d) + res * res) / (REAL)(d + 1));
             if (EE == (REAL)0) {
                 q = (REAL)1 / p->qmax;
                 q11 = (REAL)1; /* (unused on this branch) */
@@ -311,17 +330,17 @@ static void NAME(step_bwd)(const NAME(Nets)* n, const NAME(Par)* p, const REAL* 
     for (int i = 0; i < H; ++i) {
         REAL acc = (REAL)0;
         for (int c = 0; c < d; ++c) acc = FMA(n->W4[c + (size_t)i * d], d4[c], acc);
-        d3[i] = a3[i] > (REAL)0 ? acc : (REAL)0;
+        d3[i] = RELU_ON(a3[i]) ? acc : (REAL)0;
     }
     for (int i = 0; i < H; ++i) {
         REAL acc = (REAL)0;
         for (int k = 0; k < H; ++k) acc = FMA(n->W3[k + (size_t)i * H], d3[k], acc);
-        d2[i] = a2[i] > (REAL)0 ? acc : (REAL)0;
+        d2[i] = RELU_ON(a2[i]) ? acc : (REAL)0;
     }
     for (int i = 0; i < H; ++i) {
         REAL acc = (REAL)0;
         for (int k = 0; k < H; ++k) acc = FMA(n->W2[k + (size_t)i * H], d2[k], acc);
-        d1[i] = a1[i] > (REAL)0 ? acc : (REAL)0;
+        d1[i] = RELU_ON(a1[i]) ? acc : (REAL)0;
     }
     double* gp = g;
     for (int k = 0; k <= d; ++k) for (int j = 0; j < H; ++j) gp[j + (size_t)k * H] += (double)d1[j] * (double)xin[k];
@@ -349,11 +368,11 @@ static REAL NAME(u0_net)(const NAME(Nets)* n, const REAL* x0, REAL U, double* g)
     NAME(dense)(n->U2, n->c2, H, H, a1, a2, 1);
     NAME(dense)(n->U3, n->c3, H, 1, a2, o, 0);
     if (g) {
-        for (int i = 0; i < H; ++i) d2[i] = a2[i] > (REAL)0 ? n->U3[i] * U : (REAL)0;
+        for (int i = 0; i < H; ++i) d2[i] = RELU_ON(a2[i]) ? n->U3[i] * U : (REAL)0;
         for (int i = 0; i < H; ++i) {
             REAL acc = (REAL)0;
             for (int k = 0; k < H; ++k) acc = FMA(n->U2[k + (size_t)i * H], d2[k], acc);
-            d1[i] = a1[i] > (REAL)0 ? acc : (REAL)0;
+            d1[i] = RELU_ON(a1[i]) ? acc : (REAL)0;
         }
         double* gp = g;
         for (int k = 0; k < d; ++k) for (int j = 0; j < H; ++j) gp[j + (size_t)k * H] += (double)d1[j] * (double)x0[k];

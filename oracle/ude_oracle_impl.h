@@ -202,9 +202,26 @@ void FN(udeo_rhs)(const udeo_model_desc* m, const REAL* th, const REAL* u, REAL 
                             int ti = idx[a]; idx[a] = idx[b2]; idx[b2] = ti;
                             REAL tc = cf[a]; cf[a] = cf[b2]; cf[b2] = tc;
                         }
-                REAL acc = 0;
-                for (int a = 0; a < 3; ++a) acc += cf[a] * u[idx[a]];
-                du[i] = acc + (r * u[i]) * ((REAL)1 - u[i]);
+                /* ARITH-SPEC (dense sgemv/dgemv model): the script multiplies a DENSE 26 x 26 matrix by rho (BLAS gemv).  Restated
+                 * as column blocks of 8: inside a block a fused chain from 0 over the columns in ascending order (the zeros of the
+                 * dense row contribute fma(0, x, acc) == acc), block sums added to y in block order.  Among the 280 Float32
+                 * arithmetic shapes of tools/f32_golden_search.py (profiles/r03_f32_golden_search.md) this one reproduces the
+                 * stored DEStats of scenario_3.jl:56-57 (243 / 39 / 1) for every error-norm shape and lies closest to the stored
+                 * states (1.8e-4; the solve runs at Tsit5's stability limit and amplifies rounding x500 from t = 1 on, so no
+                 * shape reproduces the states bit for bit) */
+                REAL acc = 0, y = 0;
+                int cb = -1, have = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const int b8 = idx[a] >> 3;
+                    if (b8 != cb) {
+                        if (cb >= 0) { y = have ? y + acc : acc; have = 1; }
+                        cb = b8;
+                        acc = 0;
+                    }
+                    acc = R_FMA(cf[a], u[idx[a]], acc);
+                }
+                y = have ? y + acc : acc;
+                du[i] = y + (r * u[i]) * ((REAL)1 - u[i]);
             }
         } break;
         case UDEO_KIND_KPP_UDE: { /* Fisher-KPP-CNN.jl:111-126 */

@@ -26,11 +26,12 @@ def test_true_fisher_kpp_f32_golden_destats_on_device(golden):
     assert np.array_equal(np.asarray(sol).T, out[0])                       # device == oracle, bit for bit
     d = sol.destats
     assert (d.nf, d.naccept, d.nreject) == tuple(st[0][:3])
-    # the reference's artifact: rejections exact, accepted steps to +-1 (the solve runs at Tsit5's stability limit,
-    # tests/test_oracle_golden.py::test_kpp_true_f32), states to Float32 rounding before that phase
-    assert d.nreject == s["destats"]["nreject"] == 1 and abs(d.naccept - s["destats"]["naccept"]) <= 1
+    # the reference's artifact: DEStats reproduced exactly on the device (the solve runs at Tsit5's stability limit; which
+    # Float32 arithmetic shape gives the stored counts: tests/test_oracle_golden.py::test_kpp_true_f32,
+    # profiles/r03_f32_golden_search.md), states to Float32 rounding before that phase and to 2e-4 after it
+    assert (d.nf, d.naccept, d.nreject) == (s["destats"]["nf"], s["destats"]["naccept"], s["destats"]["nreject"]) == (243, 39, 1)
     Ug = np.array(s["u"], dtype=f32)
-    assert np.abs(np.asarray(sol).T[:2] - Ug[:2]).max() < 1e-6 and np.abs(np.asarray(sol).T - Ug).max() < 2e-3
+    assert np.abs(np.asarray(sol).T[:2] - Ug[:2]).max() < 1e-6 and np.abs(np.asarray(sol).T - Ug).max() < 2e-4   # (the reference's two artifacts of this solve differ by 7.1e-4)
 
 
 def test_scenario3_ude_f32_loss_known_answer_and_gradients(golden):

@@ -67,7 +67,7 @@ EXPORTS = ["ude_version", "ude_create", "ude_destroy", "ude_last_error", "ude_se
            "ude_vjp_ensemble_dev", "ude_loss_grad_ensemble", "ude_loss_grad_ensemble_dev", "ude_last_kernel_ms",
            "ude_fastpow_dev", "ude_set_trace", "ude_get_trace", "ude_math_dev", "ude_rhs_ensemble", "ude_rhs_ensemble_dev",
            "ude_last_failures", "ude_hjb_num_params", "ude_hjb_loss_grad_dev", "ude_hjb_loss_grad", "ude_hjb_normals",
-           "ude_hjb_net", "ude_hjb_last_kernel_ms", "ude_hjb_debug_read",
+           "ude_hjb_net", "ude_hjb_last_kernel_ms", "ude_hjb_debug_read", "ude_hjb_last_failures",
            "ude_comm_unique_id", "ude_comm_create", "ude_comm_create_local", "ude_comm_destroy", "ude_allreduce_grad",
            "ude_allreduce_grad_local", "ude_allreduce_grad_p2p"]
 
@@ -116,6 +116,7 @@ def load():
     L.ude_hjb_num_params.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32)]
     for name in ("ude_hjb_loss_grad_dev", "ude_hjb_loss_grad"):
         getattr(L, name).argtypes = [vp, C.POINTER(HjbDesc), i64, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ude_hjb_last_failures.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     L.ude_hjb_normals.argtypes = [vp, u64, u32, u32, u32, i32, vp]
     L.ude_hjb_net.argtypes = [vp, i32, i32, vp, i64, vp, vp]
     L.ude_comm_unique_id.argtypes = [vp]

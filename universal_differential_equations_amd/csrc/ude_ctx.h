@@ -31,6 +31,8 @@ struct ude_ctx {
     // workspaces of the stochastic (deep-BSDE / LambaEM) path, see ude_hjb.hip
     DevBuf hj[32];
     float hj_fwd_ms = 0.f, hj_bwd_ms = 0.f;
+    bool hj_cap_was_auto = false;  // the most recent ude_hjb_loss_grad_dev call recorded steps with the automatic capacity
+    int hj_auto_cap = 512;  // accepted-step store per trajectory when ude_hjb_desc.max_steps == 0; grows x4 on StoreOverflow
     hipEvent_t hj_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -63,7 +63,10 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
     HjbParams p;
     memset(&p, 0, sizeof p);
     p.M = M;
-    p.cap = D->max_steps > 0 ? D->max_steps : 512;
+    // capacity of the accepted-step store: the caller's, or the context's automatic one (grown x4 by the host-buffer entry point /
+    // ude_hjb_last_failures when a trajectory outgrows it); a loss-only call records nothing and has no limit
+    p.cap = !grad ? 0x7fffffff : D->max_steps > 0 ? D->max_steps : c->hj_auto_cap;
+    c->hj_cap_was_auto = grad && D->max_steps <= 0;
     p.maxiters = D->maxiters > 0 ? D->maxiters : 1000000;
     p.adaptive = D->adaptive ? 1 : 0;
     p.record = grad ? 1 : 0;
@@ -82,7 +85,16 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
     p.x0 = x0;
     p.theta = theta;
     int rc;
-    const size_t ncol = (size_t)M * p.cap;
+    const size_t ncol = grad ? (size_t)M * p.cap : 0;
+    if (grad) {  // the records must fit the device: refuse instead of driving the box out of memory
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        const size_t need = ncol * sizeof(float) * (size_t)(C::RX + 3 * C::RA + C::RE);
+        const size_t have = c->hj[B_XIN].cap + c->hj[B_A1].cap + c->hj[B_A2].cap + c->hj[B_A3].cap + c->hj[B_E4].cap;
+        if (need > have && need - have > fr / 10 * 9)
+            return fail(c, UDE_ERR_NOMEM, "the accepted-step store for %lld trajectories x %d steps needs %zu MB (free: %zu MB)", (long long)M, p.cap,
+                        need >> 20, fr >> 20);
+    }
     if ((rc = ensure(c, c->hj[B_PREP], sizeof(float) * (2 + 2 * KH)))) return rc;
     if (grad) {
         if ((rc = ensure(c, c->hj[B_XIN], sizeof(float) * ncol * C::RX))) return rc;
@@ -207,11 +219,21 @@ extern "C" int ude_hjb_loss_grad(ude_ctx* c, const ude_hjb_desc* D, int64_t M, c
     if ((rc = ensure(c, c->hj[S_LT], sizeof(double) * M))) return rc;
     if ((rc = ensure(c, c->hj[S_STATS], sizeof(int64_t) * 4 * M))) return rc;
     if ((rc = ensure(c, c->hj[S_RET], sizeof(int32_t) * M))) return rc;
-    rc = ude_hjb_loss_grad_dev(c, D, M, (const float*)dx0, (const float*)dth, iter, (double*)c->hj[B_LOSS].p,
-                               grad ? (float*)c->hj[S_GRAD].p : nullptr, (float*)c->hj[S_U0].p, (float*)c->hj[S_UT].p,
-                               (float*)c->hj[S_XT].p, (double*)c->hj[S_LT].p, (int64_t*)c->hj[S_STATS].p, (int32_t*)c->hj[S_RET].p);
-    if (rc) return rc;
     std::vector<int32_t> rtmp(M);
+    for (;;) {
+        rc = ude_hjb_loss_grad_dev(c, D, M, (const float*)dx0, (const float*)dth, iter, (double*)c->hj[B_LOSS].p,
+                                   grad ? (float*)c->hj[S_GRAD].p : nullptr, (float*)c->hj[S_U0].p, (float*)c->hj[S_UT].p,
+                                   (float*)c->hj[S_XT].p, (double*)c->hj[S_LT].p, (int64_t*)c->hj[S_STATS].p, (int32_t*)c->hj[S_RET].p);
+        if (rc) return rc;
+        if ((rc = dn(c, rtmp.data(), c->hj[S_RET].p, sizeof(int32_t) * M))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // a trajectory that outgrew the accepted-step store: re-run with four times the capacity (upstream's solution
+        // arrays simply grow) unless the caller pinned max_steps
+        bool overflow = false;
+        for (int64_t j = 0; j < M; ++j) overflow = overflow || rtmp[j] == RET_STORE_OVERFLOW;
+        if (!overflow || !grad || D->max_steps > 0 || c->hj_auto_cap >= (1 << 22)) break;
+        c->hj_auto_cap *= 4;
+    }
     if ((rc = dn(c, loss, c->hj[B_LOSS].p, sizeof(double)))) return rc;
     if ((rc = dn(c, grad, c->hj[S_GRAD].p, sizeof(float) * np))) return rc;
     if ((rc = dn(c, u0_out, c->hj[S_U0].p, sizeof(float)))) return rc;
@@ -219,7 +241,6 @@ extern "C" int ude_hjb_loss_grad(ude_ctx* c, const ude_hjb_desc* D, int64_t M, c
     if ((rc = dn(c, XT, c->hj[S_XT].p, sizeof(float) * M * d))) return rc;
     if ((rc = dn(c, loss_traj, c->hj[S_LT].p, sizeof(double) * M))) return rc;
     if ((rc = dn(c, stats, c->hj[S_STATS].p, sizeof(int64_t) * 4 * M))) return rc;
-    if ((rc = dn(c, rtmp.data(), c->hj[S_RET].p, sizeof(int32_t) * M))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (retcode) memcpy(retcode, rtmp.data(), sizeof(int32_t) * M);
     for (int64_t j = 0; j < M; ++j)
@@ -271,5 +292,30 @@ extern "C" int ude_hjb_debug_read(ude_ctx* c, int32_t which, int64_t offset_floa
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out_host, (const float*)c->hj[which].p + offset_floats, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+    return UDE_OK;
+}
+
+// Failure accounting of the most recent ude_hjb_loss_grad_dev call (blocks on the context's stream): number of trajectories whose
+// retcode is not Success; if one of them outgrew the automatic accepted-step store, the capacity is multiplied by 4 and *grown = 1
+// (the caller repeats the call) -- the asynchronous counterpart of what ude_hjb_loss_grad does by itself.
+extern "C" int ude_hjb_last_failures(ude_ctx* c, const int32_t* retcode_dev, int64_t M, int32_t* nfail, int32_t* grown) {
+    if (!c || !nfail) return UDE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *nfail = 0;
+    if (grown) *grown = 0;
+    const int32_t* src = retcode_dev ? retcode_dev : (const int32_t*)c->hj[B_RET].p;
+    if (!src || M <= 0) return UDE_OK;
+    std::vector<int32_t> r(M);
+    HIPCHK(c, hipMemcpy(r.data(), src, sizeof(int32_t) * M, hipMemcpyDeviceToHost));
+    bool overflow = false;
+    for (int64_t j = 0; j < M; ++j) {
+        *nfail += r[j] != 0;
+        overflow = overflow || r[j] == RET_STORE_OVERFLOW;
+    }
+    if (overflow && c->hj_cap_was_auto && c->hj_auto_cap < (1 << 22)) {
+        c->hj_auto_cap *= 4;
+        if (grown) *grown = 1;
+    }
     return UDE_OK;
 }

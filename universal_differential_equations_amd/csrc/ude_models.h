@@ -595,14 +595,27 @@ struct KppTrue : LinearTheta {
             const int i = cc * G + c.r;
             if (i < n) {
                 const int im = (i + n - 1) % n, ip = (i + 1) % n;
-                // dense mat-vec row: the three nonzeros in ascending column order (oracle: same order)
-                real acc = 0.0;
-                if (i == 0) {
-                    acc += c.cdiag * c.row[i]; acc += c.coff * c.row[ip]; acc += c.coff * c.row[im];
-                } else if (i == n - 1) {
-                    acc += c.coff * c.row[ip]; acc += c.coff * c.row[im]; acc += c.cdiag * c.row[i];
+                // ARITH-SPEC dense gemv model (oracle: UDEO_KIND_KPP_TRUE): the three nonzeros of the dense row in ascending
+                // column order, column blocks of 8 -- a fused chain from 0 inside a block, block sums added in block order
+                // (the shape that reproduces the Float32 golden 243 / 39 / 1, profiles/r03_f32_golden_search.md)
+                int j0, j1, j2;
+                real c0, c1, c2;
+                if (i == 0) { j0 = i; c0 = c.cdiag; j1 = ip; c1 = c.coff; j2 = im; c2 = c.coff; }
+                else if (i == n - 1) { j0 = ip; c0 = c.coff; j1 = im; c1 = c.coff; j2 = i; c2 = c.cdiag; }
+                else { j0 = im; c0 = c.coff; j1 = i; c1 = c.cdiag; j2 = ip; c2 = c.coff; }
+                const real p0 = rfma(c0, c.row[j0], real(0));  // (a chain STARTS as fma(a, x, +0): the oracle's sign of zero)
+                const bool s01 = (j0 >> 3) == (j1 >> 3), s12 = (j1 >> 3) == (j2 >> 3);
+                const real x1 = c.row[j1], x2 = c.row[j2];
+                // [j0 j1 j2] | [j0 j1][j2] | [j0][j1 j2] | [j0][j1][j2]
+                const real a01 = rfma(c1, x1, s01 ? p0 : real(0));           // chain through j1 (continued or restarted)
+                const real y01 = s01 ? real(0) : p0;                         // closed block sum so far (only if j0's block ended)
+                real acc;
+                if (s12) {
+                    const real a012 = rfma(c2, x2, a01);
+                    acc = s01 ? a012 : y01 + a012;
                 } else {
-                    acc += c.coff * c.row[im]; acc += c.cdiag * c.row[i]; acc += c.coff * c.row[ip];
+                    const real yb = s01 ? a01 : y01 + a01;
+                    acc = yb + rfma(c2, x2, real(0));
                 }
                 du[cc] = acc + (c.rr * u[cc]) * (real(1) - u[cc]);
             } else {

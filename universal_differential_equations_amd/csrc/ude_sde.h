@@ -143,6 +143,12 @@ __device__ __forceinline__ float wave_tree_sum_f32(float x) {
 // tsum of a vector whose components 2l, 2l+1 sit on lane l (zeros beyond the vector)
 __device__ __forceinline__ float tsum2(float v0, float v1) { return wave_tree_sum_f32(v0 + v1); }
 
+// relu as the oracle states it (oracle/sde_oracle_impl.h: dense): the value of max(0, x), with the SIGN BIT of a non-positive
+// pre-activation kept (-0.0 for a negative one): the reverse sweeps need "pre-activation >= 0" (relu'(0) = 1, the derivative
+// Tracker / ForwardDiff give NNlib's relu(x) = max(zero(x), x)), and the zero's sign never changes a sum
+__device__ __forceinline__ float relu_enc(float a) { return a > 0.0f ? a : __uint_as_float(__float_as_uint(a) & 0x80000000u); }
+__device__ __forceinline__ bool relu_on(float a) { return (__float_as_uint(a) >> 31) == 0u; }
+
 // ---- one Dense layer on the matrix cores: out[32w .. 32w+31][columns of tiles nt0..nt1) = act(W in + b) -----------------
 // wf: this lane's weight fragments (A operand: row 32w + (l&31), k = 2s + (l>>5)); in/out: LDS tiles [row][LDA]
 template <int KS, bool RELU>
@@ -170,7 +176,7 @@ __device__ __forceinline__ void layer(const float (&wf)[KS], const float* in, fl
         });
         if constexpr (RELU) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+            for (int r = 0; r < 16; ++r) acc[r] = relu_enc(acc[r]);
         }
         float* op = out + rbase * LDA + nt * 32 + (l & 31);
 #pragma unroll
@@ -465,15 +471,35 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                     }
                     const float F2 = p.lam * tsum8(tmp);
                     const float Ed = (dt * (F2 - F)) * 0.5f;
+                    // non-diagonal noise: the diffusion enters through SCALAR norms (oracle/sde_oracle_impl.h, [UP?]) --
+                    // ggprime = (||G(utilde)||_F - ||G(h)||_F) / sqrt(dt), En = ggprime * RMS(dW.^2) / 2, one number added to the
+                    // residual of EVERY component; the drift part Ed lives on the u row only
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float y = (cb + i < D) ? bufA[(cb + i) * LDA + 64 + tr] : 0.0f;
-                        tmp[i] = (y - z[i]) * (dW[i] * dW[i]);
+                        tmp[i] = y * y;
                     }
-                    const float En = (tsum8(tmp) / sq) * 0.5f;
+                    const float dsig = (float)D * p.sig;
+                    const float gs3 = __builtin_sqrtf(__builtin_fmaf(dsig, p.sig, tsum8(tmp)));
+                    const float gs = __builtin_sqrtf(__builtin_fmaf(dsig, p.sig, Sz));
+                    const float ggp = (gs3 - gs) / sq;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float w2 = dW[i] * dW[i];
+                        tmp[i] = w2 * w2;
+                    }
+                    const float nW2 = __builtin_sqrtf(tsum8(tmp) / (float)D);
+                    const float En = (ggp * nW2) * 0.5f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float a0 = fabsf(X[i]), a1 = fabsf(Xn[i]);
+                        const float r = En / __builtin_fmaf((a0 > a1 ? a0 : a1), p.reltol, p.abstol);
+                        tmp[i] = (cb + i < D) ? r * r : 0.0f;
+                    }
+                    const float sX = tsum8(tmp);
                     const float au = fabsf(u), aun = fabsf(un);
                     const float res = (Ed + En) / __builtin_fmaf((au > aun ? au : aun), p.reltol, p.abstol);
-                    EE = __builtin_sqrtf((res * res) / (float)(D + 1));
+                    EE = __builtin_sqrtf((sX + res * res) / (float)(D + 1));
                     if (EE == 0.0f) {
                         qq = 1.0f / p.qmax;
                         q11 = 1.0f;
@@ -737,7 +763,7 @@ __device__ __forceinline__ void dense_valu(const float* W, const float* b, const
     if (j < OUT) {
         float acc = b[j];
         for (int k = 0; k < IN; ++k) acc = __builtin_fmaf(W[j + (size_t)k * OUT], a[k], acc);
-        o[j] = RELU ? (acc > 0.0f ? acc : 0.0f) : acc;
+        o[j] = RELU ? relu_enc(acc) : acc;
     }
 }
 
@@ -873,7 +899,7 @@ __device__ __forceinline__ void layer_bwd(const float (&wt)[KS], const float* di
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int idx = (rbase + (r & 3) + 8 * (r >> 2)) * LDT + (l & 31);
-        dout[idx] = mask[idx] > 0.0f ? acc[r] : 0.0f;
+        dout[idx] = relu_on(mask[idx]) ? acc[r] : 0.0f;
     }
 }
 
@@ -1083,12 +1109,12 @@ __global__ void __launch_bounds__(256) hjb_reduce_kernel(const HjbParams p, int 
     const float* thu = p.theta;
     const float* a1 = p.prep + 2;
     const float* a2 = p.prep + 2 + H;
-    if (tid < H) d2[tid] = a2[tid] > 0.0f ? thu[C::U3 + tid] * U : 0.0f;
+    if (tid < H) d2[tid] = relu_on(a2[tid]) ? thu[C::U3 + tid] * U : 0.0f;
     __syncthreads();
     if (tid < H) {
         float acc = 0.0f;
         for (int k = 0; k < H; ++k) acc = __builtin_fmaf(thu[C::U2 + k + (size_t)tid * H], d2[k], acc);
-        d1[tid] = a1[tid] > 0.0f ? acc : 0.0f;
+        d1[tid] = relu_on(a1[tid]) ? acc : 0.0f;
     }
     __syncthreads();
     float* g = p.grad;

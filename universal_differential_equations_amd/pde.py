@@ -115,13 +115,21 @@ class DeviceBSDE:
         self.stats = torch.zeros((self.M, 4), dtype=torch.int64, device=dev)
         self.retcode = torch.zeros(self.M, dtype=torch.int32, device=dev)
 
-    def loss_grad(self, theta, it=0, want_grad=True):
+    def loss_grad(self, theta, it=0, want_grad=True, check_store=True):
         e = self.eng
         e.set_stream(self.torch.cuda.current_stream().cuda_stream)
         assert theta.dtype == self.torch.float32 and theta.numel() == self.np
-        e.check(e.L.ude_hjb_loss_grad_dev(e.h, C.byref(self.D), self.M, _ptr(self.x0), _ptr(theta), it, _ptr(self.loss),
-                                          _ptr(self.grad) if want_grad else None, _ptr(self.u0), _ptr(self.uT), _ptr(self.XT),
-                                          _ptr(self.loss_traj), _ptr(self.stats), _ptr(self.retcode)))
+        while True:
+            e.check(e.L.ude_hjb_loss_grad_dev(e.h, C.byref(self.D), self.M, _ptr(self.x0), _ptr(theta), it, _ptr(self.loss),
+                                              _ptr(self.grad) if want_grad else None, _ptr(self.u0), _ptr(self.uT), _ptr(self.XT),
+                                              _ptr(self.loss_traj), _ptr(self.stats), _ptr(self.retcode)))
+            if not (want_grad and check_store):
+                break
+            # a trajectory that outgrew the automatic accepted-step store: the library has grown it, repeat the call
+            nfail, grown = C.c_int32(0), C.c_int32(0)
+            e.check(e.L.ude_hjb_last_failures(e.h, _ptr(self.retcode), self.M, C.byref(nfail), C.byref(grown)))
+            if not grown.value:
+                break
         return self.loss, self.grad
 
     def kernel_ms(self):
