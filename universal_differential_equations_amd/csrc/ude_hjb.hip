@@ -42,6 +42,18 @@ int dn(ude_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 }  // namespace
 
+// a trajectory that outgrows the accepted-step store keeps stepping unrecorded and reports its true number of accepted steps:
+// the automatic capacity becomes the largest count of the call that just ended (+ 1/8), so ONE re-run suffices
+static int grow_store(ude_ctx* c, int64_t M) {
+    std::vector<int32_t> n(M);
+    HIPCHK(c, hipMemcpy(n.data(), c->hj[B_NACC].p, sizeof(int32_t) * M, hipMemcpyDeviceToHost));
+    int32_t mx = 0;
+    for (int64_t j = 0; j < M; ++j) mx = n[j] > mx ? n[j] : mx;
+    const int64_t want = (int64_t)mx + mx / 8 + 32;
+    c->hj_auto_cap = (int)(want > 2 * (int64_t)c->hj_auto_cap ? want : 2 * (int64_t)c->hj_auto_cap);
+    return UDE_OK;
+}
+
 extern "C" int ude_hjb_num_params(int32_t d, int32_t H, int32_t* np_u0, int32_t* np_sg) {
     if (np_u0) *np_u0 = H * d + H + H * H + H + H + 1;
     if (np_sg) *np_sg = H * (d + 1) + H + H * H + H + H * H + H + d * H + d;
@@ -231,8 +243,8 @@ extern "C" int ude_hjb_loss_grad(ude_ctx* c, const ude_hjb_desc* D, int64_t M, c
         // arrays simply grow) unless the caller pinned max_steps
         bool overflow = false;
         for (int64_t j = 0; j < M; ++j) overflow = overflow || rtmp[j] == RET_STORE_OVERFLOW;
-        if (!overflow || !grad || D->max_steps > 0 || c->hj_auto_cap >= (1 << 22)) break;
-        c->hj_auto_cap *= 4;
+        if (!overflow || !grad || D->max_steps > 0 || c->hj_auto_cap >= (1 << 24)) break;
+        if ((rc = grow_store(c, M))) return rc;
     }
     if ((rc = dn(c, loss, c->hj[B_LOSS].p, sizeof(double)))) return rc;
     if ((rc = dn(c, grad, c->hj[S_GRAD].p, sizeof(float) * np))) return rc;
@@ -313,8 +325,9 @@ extern "C" int ude_hjb_last_failures(ude_ctx* c, const int32_t* retcode_dev, int
         *nfail += r[j] != 0;
         overflow = overflow || r[j] == RET_STORE_OVERFLOW;
     }
-    if (overflow && c->hj_cap_was_auto && c->hj_auto_cap < (1 << 22)) {
-        c->hj_auto_cap *= 4;
+    if (overflow && c->hj_cap_was_auto && c->hj_auto_cap < (1 << 24)) {
+        int rc = grow_store(c, M);
+        if (rc) return rc;
         if (grown) *grown = 1;
     }
     return UDE_OK;

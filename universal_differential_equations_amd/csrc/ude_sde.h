@@ -300,6 +300,8 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
     int* iEv = iIter + NT;
     int* iNdraw = iEv + NT;
     int* iJ = iNdraw + NT;        // trajectory of the slot
+    int* iOvf = iJ + NT;          // the slot's trajectory has outgrown the accepted-step store (it keeps stepping, unrecorded, so that its
+                                  // true step count reaches the host: ONE re-run with the right capacity instead of a x4 ladder)
     float* sLs = fT + 16 * NT;    // lengths of the RSwM stack pieces [slot][depth] (the increments themselves: HBM)
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -345,7 +347,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
         if (m == 0) {
             fT[tr] = p.t0; fDt[tr] = dt; fU[tr] = u0; fQold[tr] = p.qoldinit; fQ11[tr] = 1.0f;
             iLast[tr] = last; iDone[tr] = 0; iNacc[tr] = 0; iNrej[tr] = 0; iNstack[tr] = 0; iIter[tr] = 0;
-            iEv[tr] = 1; iNdraw[tr] = 1; iJ[tr] = (int)j;
+            iEv[tr] = 1; iNdraw[tr] = 1; iJ[tr] = (int)j; iOvf[tr] = 0;
         }
     };
 
@@ -353,7 +355,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
         const int tr = w * 8 + ps * 4 + rr;
         const int64_t j = (int64_t)blockIdx.x * NT + tr;
         if (j < p.M) start_slot(tr, j);
-        else if (m == 0) { iDone[tr] = 1; iJ[tr] = 0; iNacc[tr] = 0; }
+        else if (m == 0) { iDone[tr] = 1; iJ[tr] = 0; iNacc[tr] = 0; iOvf[tr] = 0; }
     }
     __syncthreads();
 
@@ -516,11 +518,9 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                 }
                 tick(5);
                 if (!fin && accept) {
-                    if (nacc >= p.cap) {
-                        ret = RET_STORE_OVERFLOW;
-                        fin = true;
-                    } else {
-                        if (p.record && lane_on) {
+                    {
+                        if (p.record && nacc >= p.cap && m == 0) iOvf[tr] = 1;  // (read back by the same lanes at the end of the trajectory)
+                        if (p.record && lane_on && nacc < p.cap) {
                             const size_t col = (size_t)j * p.cap + nacc;
                             float* rx = p.rXin + col * C::RX + cb;
                             const float coef = (2.0f * p.lam) * dt;
@@ -646,6 +646,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
             if (fin) {
                 // loss term of this trajectory: (g(X_T) - u_T)^2, g(X) = log(0.5 + 0.5 |X|^2)  (lambaem.jl:14)
                 float lj = 0.0f, ub = 0.0f;
+                if (ret == RET_SUCCESS && iOvf[tr]) ret = RET_STORE_OVERFLOW;  // out of the loss (+Inf) and of the gradient; p.nacc = its true count
                 if (ret == RET_SUCCESS) {
                     float tmp[8];
 #pragma unroll
