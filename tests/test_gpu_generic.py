@@ -1,0 +1,173 @@
+"""The runtime-shape fallback kernel (csrc/ude_model_generic.h): any ude_model_desc of the replicated-state kinds with <= 8
+Dense layers of width <= 64 and activations identity / tanh / rbf / relu -- the reference accepts any chain
+(`U = Lux.Chain(...)` /root/reference/LotkaVolterra/scenario_1.jl:62-64 is a script variable; `FastChain` of
+SEIR_exposure/seir_exposure.jl:53,114) -- against the oracle's generic dense chain: per trajectory bit-identical
+(forward and backward step counts, states, dL/du0, per-trajectory loss; for a single trajectory every gradient entry).
+Plus Fisher-KPP-CNN-Small.jl:88 with n_weights in {1, 2, 3} (compiled instances of the pointwise-network kernel)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import universal_differential_equations_amd as U
+from universal_differential_equations_amd import _lib, models
+from test_gpu_parity import REL_GRAD_SUM, assert_bitwise, check_per_trajectory
+
+pytestmark = pytest.mark.gpu
+WIDTHS = [1, 2, 3, 5, 8, 16, 17, 31, 32, 48, 63, 64]
+ACTS = ["tanh", "rbf", "relu", "identity"]
+
+
+def random_chain(rng, n_in, n_out, max_hidden=7, widths=WIDTHS):
+    nh = int(rng.integers(1, max_hidden + 1))
+    dims = [n_in] + [int(rng.choice(widths)) for _ in range(nh)] + [n_out]
+    acts = [str(rng.choice(ACTS[:3] if rng.random() < 0.8 else ACTS)) for _ in range(nh)] + ["identity"]
+    return dims, acts
+
+
+def chain_of(dims, acts):
+    return models.Chain(*[models.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(dims) - 1)])
+
+
+def theta_for(chain, rng, scale):
+    th = chain.glorot_uniform(rng)
+    th = scale * th + 0.02 * rng.standard_normal(th.size)      # non-zero biases: every parameter gets a cotangent
+    return th
+
+
+def supported(f, alg=0, sense=0):
+    eng = U.Engine.get(0)
+    o = _lib.SolveOpts()
+    o.alg, o.sensealg = alg, sense
+    return eng.L.ude_model_supported(eng.h, C.byref(f), C.byref(o), 1)
+
+
+def test_model_supported_reports_fast_instance_or_generic_kernel():
+    assert supported(models.ude_dynamics()) == 0                                          # scenario_1's shape: compiled instance
+    assert supported(models.ude_dynamics(chain_of([2, 6, 5, 2], ["rbf", "tanh", "identity"]))) == 1   # hidden width 6: the fallback
+    assert supported(models.dudt_(chain_of([3, 16, 1], ["tanh", "identity"]))) == 1
+    assert supported(models.dudt_node(chain_of([7, 32, 32, 7], ["relu", "tanh", "identity"]))) == 1
+    assert supported(models.ude_dynamics(chain_of([2, 65, 2], ["tanh", "identity"]))) == -2   # wider than a wavefront: UDE_ERR_UNSUPPORTED
+    assert supported(models.ude_dynamics(chain_of([2, 6, 2], ["tanh", "identity"])), sense=1) == -2   # no discrete sweep for runtime shapes
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_lv_kind_random_shapes(golden, seed):
+    rng = np.random.default_rng(100 + seed)
+    dims, acts = random_chain(rng, 2, 2)
+    chain = chain_of(dims, acts)
+    trainable = [None, "delta", "both"][seed % 3]
+    f = models.ude_dynamics(chain, trainable=trainable)
+    nn_off = {None: 0, "delta": 1, "both": 2}[trainable]
+    om = O.make_model(O.KIND_LV_UDE, 2, dims, acts, nn_offset=nn_off,
+                      lin_idx={None: (-1, -1), "delta": (-1, 0), "both": (0, 1)}[trainable],
+                      lin_sign={None: (1.0, 1.0), "delta": (1.0, -1.0), "both": (1.0, -1.0)}[trainable],
+                      lin_const={None: (1.3, -1.8), "delta": (1.3, 0.0), "both": (0.0, 0.0)}[trainable])
+    lead = {None: [], "delta": [1.8], "both": [1.3, 1.8]}[trainable]       # scenario_2: theta = [delta; ude]; hudson_bay: [p1; p2; ude]
+    th = np.concatenate([lead, theta_for(chain, rng, 0.3)]).astype(np.float64)
+    assert supported(f) == 1 and f.n_param == th.size == om.n_param
+    g = golden("Scenario_1_recovery_0.005")
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+    t = np.array(g["solution"]["t"])
+    N = 1 if seed % 2 == 0 else 5
+    u0 = X[0] * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))
+    data = np.repeat(X[None], N, axis=0)
+    alg, oalg = (U.Tsit5, O.TSIT5) if seed % 4 < 2 else (U.Vern7, O.VERN7)
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (t[0], t[-1]), th), u0)
+    sol = U.solve(ens, alg(), saveat=t, abstol=1e-6, reltol=1e-6)
+    out, st, rc = O.solve_ensemble(om, O.opts(oalg, 1e-6, 1e-6), u0, [t[0], t[-1]], th, t)
+    assert (rc == 0).all()
+    assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts %s %s" % (dims, acts))
+    assert_bitwise(sol.u, out, "forward states")
+    r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6)
+    ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6), u0, [t[0], t[-1]], th, t, data, nthreads=4)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
+    if N == 1:
+        assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta %s %s" % (dims, acts))
+    else:
+        gn = np.linalg.norm(ref["grad_theta"])
+        assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_seir_kinds_random_shapes(seed):
+    rng = np.random.default_rng(200 + seed)
+    node = seed % 2 == 1
+    dims, acts = random_chain(rng, 7 if node else 3, 7 if node else 1, max_hidden=4, widths=[4, 16, 33, 64])
+    chain = chain_of(dims, acts)
+    f = (models.dudt_node if node else models.dudt_)(chain)
+    om = O.make_model(O.KIND_SEIR_NODE if node else O.KIND_SEIR_UDE, 7, dims, acts, consts=O.SEIR_P)
+    th = theta_for(chain, rng, 0.5)
+    assert supported(f) == 1
+    N = 1 if seed < 4 else 4
+    S0 = 100.0
+    u0 = np.zeros((N, 7))
+    u0[:, 0] = rng.uniform(0.8, 0.95, N) * S0
+    u0[:, 1] = rng.uniform(0.5, 2.0, N)
+    u0[:, 2] = rng.uniform(0.2, 1.0, N)
+    u0[:, 4] = S0
+    tf = 4.0
+    t = np.arange(0.0, tf + 0.5, 1.0)
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, tf], [], t)
+    alg, oalg = (U.Vern7, O.VERN7) if seed % 4 < 2 else (U.Tsit5, O.TSIT5)
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, tf), th), u0)
+    du = U.rhs(f, u0, th)
+    assert_bitwise(du, np.array([O.rhs(om, th, u) for u in u0]), "rhs %s %s" % (dims, acts))
+    r = U.loss_and_gradient(ens, alg(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6)
+    ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6), u0, [0.0, tf], th, t, truth, row_mask=mask, nthreads=4)
+    assert (r.retcode == 0).all() and (ref["retcode"] == 0).all()
+    check_per_trajectory(r, ref)
+    assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
+    if N == 1:
+        assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta %s %s" % (dims, acts))
+    else:
+        gn = np.linalg.norm(ref["grad_theta"])
+        assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
+
+
+def test_generic_kernel_agrees_with_the_compiled_instance_of_the_same_shape():
+    """The fallback is chosen by shape alone.  scenario_1's own chain runs on its compiled instance, a chain one neuron away from it
+    on the fallback: both bit-identical to the same oracle, i.e. the two kernels implement one specification."""
+    rng = np.random.default_rng(7)
+    for dims in ([2, 5, 5, 5, 2], [2, 5, 6, 5, 2]):
+        acts = ["rbf", "rbf", "rbf", "identity"]
+        chain = chain_of(dims, acts)
+        f = models.ude_dynamics(chain)
+        om = O.make_model(O.KIND_LV_UDE, 2, dims, acts, lin_const=(1.3, -1.8))
+        th = theta_for(chain, rng, 0.5)
+        assert supported(f) == (0 if dims[2] == 5 else 1)
+        u0 = np.array([[0.44249296, 4.6280594]])
+        t = np.linspace(0.0, 3.0, 31)
+        data = np.ones((1, 31, 2))
+        r = U.loss_and_gradient(U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 3.0), th), u0), U.Vern7(), data, saveat=t, abstol=1e-6, reltol=1e-6)
+        ref = O.loss_grad_ensemble(om, O.opts(O.VERN7, 1e-6, 1e-6), u0, [0.0, 3.0], th, t, data)
+        assert_bitwise(r.stats, ref["stats"], "stats")
+        assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta")
+
+
+@pytest.mark.parametrize("n_weights", [1, 2, 3])
+def test_fisher_kpp_small_n_weights(n_weights):
+    """Fisher-KPP-CNN-Small.jl:88 `n_weights` (timing log :343-391 for 1, 2, 3): reaction network 1 -> n -> 1 tanh"""
+    rng = np.random.default_rng(40 + n_weights)
+    nx = 26
+    chain = models.kpp_small_chain(n_weights)
+    f = models.nn_ode(nx, chain)
+    th = models.kpp_theta(chain, rng)
+    assert th.size == 3 * n_weights + 6 and supported(f) == 0
+    om = O.kpp_ude(nx, (1, n_weights, 1), ("tanh", "identity"))
+    rho = models.rho0(nx)
+    t = np.arange(11) * 0.5
+    truth, _, rc = O.solve_ensemble(O.kpp_true(nx), O.opts(O.TSIT5), rho, [0.0, 5.0], [], t)
+    prob = U.ODEProblem(f, rho, (0.0, 5.0), th)
+    r = U.loss_and_gradient(prob, U.Tsit5(), truth, saveat=t)
+    ref = O.loss_grad_ensemble(om, O.opts(O.TSIT5), rho[None], [0.0, 5.0], th, t, truth)
+    assert (r.retcode == 0).all()
+    assert_bitwise(r.stats, ref["stats"], "stats")
+    assert_bitwise(r.u, ref["u"], "states")
+    assert_bitwise(r.grad_u0, ref["grad_u0"], "dL/du0")
+    gn = np.linalg.norm(ref["grad_theta"])
+    assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < 1e-12 * gn

@@ -1061,7 +1061,10 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     real lam[Sys::NR];
     static_for<0, Sys::NR>([&](auto c) { lam[c] = 0.0; });
     constexpr int NSLOT = Model::DEFERRED ? Model::NSL : NSL;  // slots this thread reports (deferred: system-owned)
-    static_for<0, NSLOT>([&](auto c) { mu_lds[(size_t)c * MS] = 0.0; });
+    if constexpr (NSLOT > 160) {  // (runtime-shape model: hundreds of slots -- a loop, not unrolled stores)
+#pragma unroll 4
+        for (int c = 0; c < NSLOT; ++c) mu_lds[(size_t)c * MS] = 0.0;
+    } else static_for<0, NSLOT>([&](auto c) { mu_lds[(size_t)c * MS] = 0.0; });
     real* mu_final = mu_lds;
     const bool in_range = gid < p.N && (int)threadIdx.x < GROUPS * G;
     bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
@@ -1107,7 +1110,9 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
                 if (sys.cwrite(c)) p.grad_u0[(size_t)gid * p.n_state + sys.comp(c)] = lam[c];
             });
         if (ret != RET_SUCCESS) {  // never poison the batch gradient
-            static_for<0, NSLOT>([&](auto c) { mu_final[(size_t)c * MS] = 0.0; });
+            if constexpr (NSLOT > 160) {
+                for (int c = 0; c < NSLOT; ++c) mu_final[(size_t)c * MS] = 0.0;
+            } else static_for<0, NSLOT>([&](auto c) { mu_final[(size_t)c * MS] = 0.0; });
         }
     }
     if constexpr (!pow2_group<G>()) {

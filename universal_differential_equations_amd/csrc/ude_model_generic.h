@@ -1,0 +1,386 @@
+// ude_model_generic.h -- the runtime-shape fallback (included by ude_models.h, Float64 translation units only).
+//
+// The reference's networks are script variables: `U = Lux.Chain(Dense(2,5,rbf), ...)` (LotkaVolterra/scenario_1.jl:62-64),
+// `ann = FastChain(FastDense(3,64,tanh), ...)` (SEIR_exposure/seir_exposure.jl:114), `n_weights` of
+// FisherKPP/Fisher-KPP-CNN-Small.jl:88 -- any chain is accepted upstream.  The compiled instances cover the shapes the scripts
+// ship; THIS model covers every other ude_model_desc of the replicated-state kinds (UDE_KIND_LV_UDE, UDE_KIND_SEIR_UDE,
+// UDE_KIND_SEIR_NODE): up to 8 Dense layers of width <= 64, activations identity / tanh / rbf / relu, the layer sizes and
+// activations read from the kernel arguments (ModelConsts::dims / act).
+//
+// One wavefront per trajectory; lane j = neuron j of every layer; weights are read from HBM (L2-resident: every trajectory
+// reads the same theta) -- there is no LDS copy whose size would depend on the shape; the activations of a layer cross lanes
+// through rows of the wavefront's LDS stage storage.  Arithmetic = oracle/ude_oracle_impl.h: mlp_forward / mlp_vjp_acc / wide_dot
+// (ARITH-SPEC): dots of fewer than 64 terms are one fma chain from 0 in ascending order; 64-term dots with >= 64 results are
+// four 16-term chains added left to right; 64-term dots with fewer than 64 results are rounded products summed by the
+// adjacent-pair tree of the wavefront.  Per trajectory every number is therefore bit-identical to the oracle.
+// The parameter cotangent is DEFERRED exactly as in SeirNode: every adjoint stage leaves its factors (a_l and delta_l rows) in
+// LDS and the RK-weighted sums of all slots are formed at the end of the step, fused with error norm and candidate mu (mu in
+// HBM, two columns that swap on acceptance).  This is a fallback: it is written for generality, not for speed.
+#pragma once
+
+namespace ude {
+
+enum { GK_LV_UDE = 1, GK_SEIR_UDE = 3, GK_SEIR_NODE = 6 };  // = UDE_KIND_* of include/udecore.h (ude_model_desc.kind)
+
+template <int NSTATE>
+struct GenericUde {
+    static constexpr int H = 64, LMAX = 8;
+    static constexpr int NS = NSTATE;
+    static constexpr int NSLW = LMAX * (H + 1);   // weight + bias slots of lane j: (in_l + 1) per layer, layer after layer
+    static constexpr int NSL = NSLW + 2;           // + the two (optional) trainable diagonal coefficients of the LV kind (lane 0)
+    static constexpr bool STATE_DISTRIBUTED = false;
+    static constexpr bool THETA_GLOBAL = true, FUSED_ACC = true, SLOTS_GLOBAL = true, CPL = true, DEFERRED = true;
+    static constexpr bool DADJ_K_FROM_DENSE = false, COMPACT_STAGES = true;
+    static constexpr bool NO_DADJ = true;          // no discretise-then-optimise sweep for runtime shapes (the host reports UNSUPPORTED)
+    static constexpr int NSTG = 10, NSTC = 8;      // tableau stages, stored (compacted) stages
+    static constexpr int RX = 16;                  // short row per stage: x_0..x_6 (the network input) | u0 u1 lam0 lam1 (LV diagonal slots)
+    static constexpr int STG = 2 * LMAX * H + RX;  // doubles of one stored stage: A rows (a_0 .. a_{L-1}), delta rows (delta_1 .. delta_L), short row
+    static constexpr int WORK = (LMAX + 1) * H + LMAX * H + 2 * H;  // forward working rows: a_0..a_L, dphi_0..dphi_{L-1}, spare
+    static constexpr int SCRATCH = NSTC * STG + WORK;
+    static constexpr int SCRATCH_FWD = WORK;
+    typedef __attribute__((address_space(3))) double lds_t;
+    struct Ctx {
+        const double* nn;     // theta + nn_offset (HBM)
+        lds_t* work;          // a rows [l * H + lane], then dphi rows
+        lds_t* fac;           // stage storage of this wavefront
+        const ModelConsts* mc;  // dims / act of the chain: kernel arguments, read with wave-uniform indices (scalar loads)
+        int L, kind, nnp;       // layers, kind, number of NN parameters
+        double lin[2], lin_on[2];
+        double mu_c, sg, F, b0, ga, dd, la;   // SEIR constants
+        int j, r;
+    };
+    static __host__ __device__ constexpr int theta_lds(int) { return 0; }
+    static __device__ __forceinline__ void stage_theta(double*, const double*, int, int, int) {}
+    static __device__ __forceinline__ void init(Ctx& c, double* theta, double* scratch, double*, int, const ModelConsts& mc, int r,
+                                                const double* theta_g) {
+        (void)theta;
+        c.j = r & 63; c.r = r;
+        c.nn = theta_g + mc.nn_offset;
+        c.work = (lds_t*)scratch;               // (the working rows first: all the forward / rhs kernels need of the scratch)
+        c.fac = (lds_t*)scratch + WORK;
+        c.mc = &mc;
+        c.L = mc.n_layers; c.kind = mc.kind;
+        int o = 0;
+        for (int l = 0; l < mc.n_layers; ++l) o += mc.dims[l] * mc.dims[l + 1] + mc.dims[l + 1];
+        c.nnp = o;
+        for (int i = 0; i < 2; ++i) {
+            c.lin[i] = mc.lin_idx[i] >= 0 ? mc.lin_sign[i] * theta_g[mc.lin_idx[i]] : mc.lin_const[i];
+            c.lin_on[i] = (mc.lin_idx[i] >= 0 && r == 0) ? mc.lin_sign[i] : 0.0;
+        }
+        c.F = mc.consts[0]; c.b0 = mc.consts[1]; c.mu_c = mc.consts[4]; c.sg = mc.consts[5]; c.ga = mc.consts[6]; c.dd = mc.consts[7];
+        c.la = mc.consts[8];
+    }
+    static __device__ __forceinline__ double actf(int a, double z) {
+        return a == ACT_TANH ? dtanh(z) : a == ACT_RBF ? dexp(-(z * z)) : a == ACT_RELU ? (z > 0.0 ? z : 0.0) : z;
+    }
+    static __device__ __forceinline__ double dactf(int a, double z, double av) {
+        return a == ACT_TANH ? __builtin_fma(-av, av, 1.0) : a == ACT_RBF ? (-2.0 * z) * av : a == ACT_RELU ? (z > 0.0 ? 1.0 : 0.0) : 1.0;
+    }
+    // ---- wide_dot (oracle): result r of `nres` results over n terms; term i = w[i * ws] * x_i ----
+    // x lives in an LDS row (lane i wrote x_i); lane j owns result j.  wbase(j): address of the lane's term 0, ws: term stride.
+    static __device__ __forceinline__ double dot_lane(const double* w, int ws, const lds_t* x, int n) {
+        if (n < 64) {  // one chain from 0, ascending
+            double acc = 0.0;
+#pragma unroll 4
+            for (int i = 0; i < n; ++i) acc = __builtin_fma(w[(size_t)i * ws], x[i], acc);
+            return acc;
+        }
+        double tot = 0.0;  // 64 terms: four 16-term chains, block sums left to right
+#pragma unroll 1
+        for (int b = 0; b < 64; b += 16) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = __builtin_fma(w[(size_t)(b + i) * ws], x[b + i], acc);
+            tot = b == 0 ? acc : tot + acc;
+        }
+        return tot;
+    }
+    // forward chain: x on lanes 0..dims[0]-1 (others 0).  A rows go to `arow` (row l at arow[l * H]), dphi rows to c.work.
+    // Returns this lane's a_L (valid on lanes < dims[L]).
+    static __device__ __forceinline__ double forward(const Ctx& c, double xlane, lds_t* arow, bool want_dphi) {
+        const int j = c.j;
+        lds_t* dphi = c.work + (LMAX + 1) * H;
+        double a = xlane;
+        arow[j] = a;
+        int off = 0;
+#pragma unroll 1
+        for (int l = 0; l < c.L; ++l) {
+            const int in = c.mc->dims[l], out = c.mc->dims[l + 1], actl = c.mc->act[l];
+            const double* W = c.nn + off;
+            off += in * out + out;
+            const int jj = j < out ? j : out - 1;   // (lanes beyond the layer compute a discarded copy of the last neuron: in-bounds reads)
+            const lds_t* x = arow + l * H;
+            double z;
+            if (in == 64 && out < 64) {
+                // 64 terms, fewer than 64 results: rounded products, adjacent-pair tree over the wavefront (lane i = term i)
+                z = 0.0;
+#pragma unroll 1
+                for (int rr = 0; rr < out; ++rr) {
+                    const double s = wave_tree_sum(W[rr + (size_t)j * out] * a);
+                    z = (j == rr) ? s : z;
+                }
+            } else {
+                z = dot_lane(W + jj, out, x, in);
+            }
+            z += W[(size_t)in * out + jj];
+            const double av = actf(actl, z);
+            a = j < out ? av : 0.0;
+            // the next layer's input row: row l + 1 of the same storage, except that a_L (never a factor) goes to the spare row
+            lds_t* nxt = (l + 1 < c.L) ? arow + (l + 1) * H : c.work + LMAX * H;
+            nxt[j] = a;
+            if (want_dphi) dphi[l * H + j] = j < out ? dactf(actl, z, av) : 0.0;
+        }
+        return a;
+    }
+    // reverse chain: gy on lanes 0..dims[L]-1; delta rows to `drow` (row l = delta of layer l's OUTPUT); returns this lane's input cotangent
+    static __device__ __forceinline__ double backward(const Ctx& c, double gylane, lds_t* drow) {
+        const int j = c.j;
+        const lds_t* dphi = c.work + (LMAX + 1) * H;
+        double delta = gylane;
+        int off = c.nnp;
+#pragma unroll 1
+        for (int l = c.L - 1; l >= 0; --l) {
+            const int in = c.mc->dims[l], out = c.mc->dims[l + 1];
+            off -= in * out + out;
+            const double* W = c.nn + off;
+            delta = delta * dphi[l * H + j];
+            delta = j < out ? delta : 0.0;
+            drow[l * H + j] = delta;
+            double prev;
+            if (out == 64 && in < 64) {
+                prev = 0.0;
+#pragma unroll 1
+                for (int k = 0; k < in; ++k) {
+                    const double s = wave_tree_sum(W[j + (size_t)k * 64] * delta);
+                    prev = (j == k) ? s : prev;
+                }
+            } else {
+                const int kk = j < in ? j : in - 1;
+                prev = dot_lane(W + (size_t)kk * out, 1, drow + l * H, out);
+            }
+            delta = j < in ? prev : 0.0;
+        }
+        return delta;
+    }
+    // ---- kind wiring (oracle: udeo_rhs / udeo_rhs_vjp) ----
+    static __device__ __forceinline__ double input_lane(const Ctx& c, const double* u) {
+        const int j = c.j;
+        double x = 0.0;
+        if (c.kind == GK_LV_UDE) {
+            x = j == 0 ? u[0] : j == 1 ? u[1 % NS] : 0.0;
+        } else if (c.kind == GK_SEIR_UDE) {
+            if constexpr (NS == 7) x = j == 0 ? u[0] / u[4] : j == 1 ? u[2] : j == 2 ? u[5] / u[4] : 0.0;
+        } else {
+            if constexpr (NS == 7)
+                x = j == 0 ? u[0] / u[4] : j == 1 ? u[1] : j == 2 ? u[2] : j == 3 ? u[3] : j == 4 ? u[4] : j == 5 ? u[5] / u[4] : j == 6 ? u[6] : 0.0;
+        }
+        return x;
+    }
+    static __device__ __forceinline__ void rhs_from(const Ctx& c, const double* u, double aL, double* du) {
+        if (c.kind == GK_LV_UDE) {
+            du[0] = __builtin_fma(c.lin[0], u[0], readlane_real(aL, 0));
+            du[1 % NS] = __builtin_fma(c.lin[1], u[1 % NS], readlane_real(aL, 1));
+        } else if constexpr (NS == 7) {
+            const double S = u[0], E = u[1], I = u[2], Rr = u[3], N = u[4], D = u[5];
+            if (c.kind == GK_SEIR_UDE) {
+                const double z = readlane_real(aL, 0);
+                du[0] = -c.b0 * S * c.F / N - z - c.mu_c * S;
+                du[1] = c.b0 * S * c.F / N + z - (c.sg + c.mu_c) * E;
+                du[2] = c.sg * E - (c.ga + c.mu_c) * I;
+                du[3] = c.ga * I - c.mu_c * Rr;
+                du[4] = -c.mu_c * N;
+                du[5] = c.dd * c.ga * I - c.la * D;
+                du[6] = c.sg * E;
+            } else {
+                du[0] = readlane_real(aL, 0); du[1] = readlane_real(aL, 1); du[2] = readlane_real(aL, 2); du[3] = readlane_real(aL, 3);
+                du[4] = -c.mu_c * N;
+                du[5] = readlane_real(aL, 4);
+                du[6] = c.sg * E;
+            }
+        }
+    }
+    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
+        const double aL = forward(c, input_lane(c, u), c.work, false);
+        rhs_from(c, u, aL, du);
+    }
+    // reverse sweep of one evaluation: factors into stage slot q (A rows, delta rows, short row), state cotangent out
+    static __device__ __forceinline__ void sweep(const Ctx& c, const double* u, const double* lam, double* dlam, int q) {
+        const int j = c.j;
+        lds_t* st = c.fac + q * STG;
+        const double xl = input_lane(c, u);
+        forward(c, xl, st, true);
+        double gy = 0.0;
+        if (c.kind == GK_LV_UDE) gy = j == 0 ? lam[0] : j == 1 ? lam[1 % NS] : 0.0;
+        else if constexpr (NS == 7) {
+            if (c.kind == GK_SEIR_UDE) gy = j == 0 ? lam[1] - lam[0] : 0.0;
+            else gy = j == 0 ? lam[0] : j == 1 ? lam[1] : j == 2 ? lam[2] : j == 3 ? lam[3] : j == 4 ? lam[5] : 0.0;
+        }
+        const double gxl = backward(c, gy, st + LMAX * H);
+        // short row: the network input x_0..x_6 is row 0 of the A rows already; the LV diagonal slots need u and lambda
+        double sh = 0.0;
+        if (c.kind == GK_LV_UDE) sh = j == 0 ? u[0] : j == 1 ? u[1 % NS] : j == 2 ? lam[0] : j == 3 ? lam[1 % NS] : 0.0;
+        st[2 * LMAX * H + (j < RX ? j : RX - 1)] = sh;
+        if (c.kind == GK_LV_UDE) {
+            dlam[0] = __builtin_fma(c.lin[0], lam[0], readlane_real(gxl, 0));
+            dlam[1 % NS] = __builtin_fma(c.lin[1], lam[1 % NS], readlane_real(gxl, 1));
+        } else if constexpr (NS == 7) {
+            const double S = u[0], N = u[4], D = u[5];
+            if (c.kind == GK_SEIR_UDE) {
+                const double g0 = readlane_real(gxl, 0), g1 = readlane_real(gxl, 1), g2 = readlane_real(gxl, 2);
+                const double cc = c.b0 * c.F / N;
+                const double cN = c.b0 * S * c.F / (N * N);
+                dlam[0] = (-cc - c.mu_c) * lam[0] + cc * lam[1] + g0 / N;
+                dlam[1] = -(c.sg + c.mu_c) * lam[1] + c.sg * lam[2] + c.sg * lam[6];
+                dlam[2] = -(c.ga + c.mu_c) * lam[2] + c.ga * lam[3] + c.dd * c.ga * lam[5] + g1;
+                dlam[3] = -c.mu_c * lam[3];
+                dlam[4] = cN * lam[0] - cN * lam[1] - c.mu_c * lam[4] - g0 * S / (N * N) - g2 * D / (N * N);
+                dlam[5] = -c.la * lam[5] + g2 / N;
+                dlam[6] = 0.0;
+            } else {
+                double gx[7];
+                static_for<0, 7>([&](auto m) { gx[m] = readlane_real(gxl, decltype(m)::value); });
+                dlam[0] = gx[0] / N;
+                dlam[1] = __builtin_fma(c.sg, lam[6], gx[1]);
+                dlam[2] = gx[2];
+                dlam[3] = gx[3];
+                dlam[4] = ((gx[4] - gx[0] * S / (N * N)) - gx[5] * D / (N * N)) - c.mu_c * lam[4];
+                dlam[5] = gx[5] / N;
+                dlam[6] = gx[6];
+            }
+        }
+    }
+    template <bool WANT_PARAM>
+    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam, double*) {
+        static_assert(!WANT_PARAM, "deferred parameter cotangent only");
+        sweep(c, u, lam, dlam, 0);
+    }
+    template <bool WANT_E>
+    static __device__ __forceinline__ void vjp_acc(const Ctx&, const double*, const double*, double*, double*, double*, double, double) {}
+    static __device__ __forceinline__ void vjp_store(const Ctx& c, const double* u, const double* lam, double* dlam, int s) {
+        sweep(c, u, lam, dlam, s);
+    }
+    template <unsigned MASK>
+    static constexpr int slot_of(int s) {
+        int q = 0;
+        for (int i = 0; i < s; ++i) q += (MASK >> i) & 1u;
+        return q;
+    }
+    // every slot of this lane in slot order: body(slot, g[NST], m0) with g_s = the NEGATED cotangent of stage s, m0 = mu[slot].
+    // Lanes beyond a layer's width own nothing there: their factors are stored as zeros, every one of their sums is an exact 0.
+    template <int NST, unsigned MASK, class Body>
+    static __device__ __forceinline__ void for_each_slot(const Ctx& c, const double* mu, int ms, Body body) {
+        const int j = c.j;
+        int sb = 0;
+#pragma unroll 1
+        for (int l = 0; l < c.L; ++l) {
+            const int in = c.mc->dims[l];
+            double d[NST];  // this lane's delta of layer l at every stored stage
+            static_for<0, NST>([&](auto s) {
+                if constexpr ((MASK >> decltype(s)::value) & 1u) d[s] = c.fac[slot_of<MASK>(decltype(s)::value) * STG + (LMAX + l) * H + j];
+            });
+            double m0 = mu[(size_t)sb * ms];
+#pragma unroll 1
+            for (int k = 0; k <= in; ++k) {   // k == in: the bias
+                const double mnext = mu[(size_t)(sb + (k < in ? k + 1 : 0)) * ms];  // (one slot ahead; the wrap-around read is discarded)
+                double g[NST];
+                static_for<0, NST>([&](auto s) {
+                    if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                        const double a = k < in ? (double)c.fac[slot_of<MASK>(decltype(s)::value) * STG + l * H + k] : 1.0;
+                        g[s] = k < in ? -(d[s] * a) : -d[s];
+                    }
+                });
+                body(sb + k, g, m0);
+                m0 = mnext;
+            }
+            sb += in + 1;
+        }
+        if (c.kind == GK_LV_UDE) {  // the two trainable diagonal coefficients (lane 0): g = -((sign u_i) lam_i)
+            static_for<0, 2>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                double g[NST];
+                static_for<0, NST>([&](auto s) {
+                    if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                        const lds_t* p = c.fac + slot_of<MASK>(decltype(s)::value) * STG + 2 * LMAX * H;
+                        g[s] = -((c.lin_on[i] * p[i]) * p[2 + i]);
+                    }
+                });
+                body(NSLW + i, g, mu[(size_t)(NSLW + i) * ms]);
+            });
+        }
+    }
+    template <int NST, unsigned MASK>
+    static __device__ __forceinline__ double step_slots(const Ctx& c, const double* B, const double* BT, double dt, double abstol,
+                                                        double reltol, const double* mu, double* mu_new, int ms) {
+        static_assert(MASK & 1u, "the first stage starts the chains");
+        double bb[NST], bt[NST];
+        static_for<0, NST>([&](auto s) { bb[s] = uniform_real(B[s]); bt[s] = uniform_real(BT[s]); });
+        double ps = 0.0;
+        for_each_slot<NST, MASK>(c, mu, ms, [&](int slot, const double* g, double m0) {
+            double ab = bb[0] * g[0], ae = bt[0] * g[0];
+            static_for<1, NST>([&](auto s) {
+                if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                    ab = __builtin_fma(bb[s], g[s], ab);
+                    ae = __builtin_fma(bt[s], g[s], ae);
+                }
+            });
+            const double m1 = __builtin_fma(dt, ab, m0);
+            mu_new[(size_t)slot * ms] = m1;
+            const double a0 = fabs(m0), a1 = fabs(m1);
+            const double res = (dt * ae) / __builtin_fma((a0 > a1 ? a0 : a1), reltol, abstol);
+            ps = __builtin_fma(res, res, ps);
+        });
+        return ps;
+    }
+    template <int NST, unsigned MASK>
+    static __device__ __forceinline__ void commit_slots(const Ctx& c, const double* B, double dt, double* mu, int ms) {
+        static_assert(MASK & 1u, "the first stage starts the chains");
+        double bb[NST];
+        static_for<0, NST>([&](auto s) { bb[s] = uniform_real(B[s]); });
+        for_each_slot<NST, MASK>(c, mu, ms, [&](int slot, const double* g, double m0) {
+            double ab = bb[0] * g[0];
+            static_for<1, NST>([&](auto s) {
+                if constexpr ((MASK >> decltype(s)::value) & 1u) ab = __builtin_fma(bb[s], g[s], ab);
+            });
+            mu[(size_t)slot * ms] = __builtin_fma(dt, ab, m0);
+        });
+    }
+    static __device__ __forceinline__ void init_norm01(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
+                                                       double& h0, double& l0, double& h1, double& l1) {
+        for_each_slot<1, 1u>(c, mu, ms, [&](int, const double* g, double m) {
+            const double sk = __builtin_fma(fabs(m), reltol, abstol);
+            const double q0 = m / sk, q1 = g[0] / sk;
+            dd_acc(h0, l0, q0 * q0);
+            dd_acc(h1, l1, q1 * q1);
+        });
+    }
+    static __device__ __forceinline__ void init_norm2(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
+                                                      double& h2, double& l2) {
+        for_each_slot<2, 3u>(c, mu, ms, [&](int, const double* g, double m) {
+            const double sk = __builtin_fma(fabs(m), reltol, abstol);
+            const double q = (g[1] - g[0]) / sk;
+            dd_acc(h2, l2, q * q);
+        });
+    }
+    // theta index of lane r's slot s, or -1
+    static __device__ __forceinline__ int slot_index(const ModelConsts& mc, int r, int s) {
+        const int j = r & 63;
+        if (s >= NSLW) {
+            const int i = s - NSLW;
+            return (j == 0 && i < 2 && mc.kind == GK_LV_UDE && mc.lin_idx[i] >= 0) ? mc.lin_idx[i] : -1;
+        }
+        int o = 0, sb = 0;
+        for (int l = 0; l < mc.n_layers; ++l) {
+            const int in = mc.dims[l], out = mc.dims[l + 1];
+            if (s < sb + in + 1) {
+                if (j >= out) return -1;
+                const int k = s - sb;
+                return mc.nn_offset + o + (k < in ? j + k * out : in * out + j);
+            }
+            o += in * out + out;
+            sb += in + 1;
+        }
+        return -1;
+    }
+};
+
+}  // namespace ude

@@ -15,6 +15,7 @@ namespace ude {
 
 struct ModelConsts {
     int32_t n_state, n_param, nn_offset, stencil_offset, d0_offset;
+    int32_t kind, n_layers, dims[9], act[8];  // the descriptor's chain (read by the runtime-shape model only, ude_model_generic.h)
     int32_t lin_idx[2];
     double lin_sign[2], lin_const[2];
     double consts[16];
@@ -561,6 +562,9 @@ struct SeirUde {
 
 }  // namespace ude
 #include "ude_model_node.h"
+#ifdef UDE_INST_GENERIC  // (only the translation units of the runtime-shape instances pull the model in: build.py)
+#include "ude_model_generic.h"
+#endif
 namespace ude {
 #endif  // UDE_F32
 

@@ -27,16 +27,20 @@ struct Launch {
     }
 };
 
+// models without a discretise-then-optimise sweep (Model::NO_DADJ: the runtime-shape fallback) leave those entries null
+template <class M, class = void> struct no_dadj { static constexpr bool v = false; };
+template <class M> struct no_dadj<M, std::void_t<decltype(M::NO_DADJ)>> { static constexpr bool v = M::NO_DADJ; };
+
 template <class Model, class Tab, int G, int BLOCK = 64, int VAR = 1, class RTag = real>
 inline Launch make_launch() {
     Launch l;
     l.fwd = fwd_kernel<Model, Tab, G, BLOCK>;
     l.adj = adj_kernel<Model, Tab, G, BLOCK, false, VAR>;
-    l.dadj = dadj_kernel<Model, Tab, G, BLOCK>;
+    if constexpr (no_dadj<Model>::v) { l.dadj = nullptr; l.dadj_pt = nullptr; }
+    else { l.dadj = dadj_kernel<Model, Tab, G, BLOCK>; l.dadj_pt = dadj_kernel<Model, Tab, G, BLOCK, true>; }
     l.rhs = rhs_kernel<Model, Tab, G, BLOCK>;
     l.fwd_pt = fwd_kernel<Model, Tab, G, BLOCK, true>;
     l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true, VAR>;
-    l.dadj_pt = dadj_kernel<Model, Tab, G, BLOCK, true>;
     l.adj_fast = adj_kernel<Model, Tab, G, BLOCK, false, 3>;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
@@ -63,10 +67,15 @@ enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, 
        MID_LV_S1N /* scenario_1's chain with CONSTANT diagonal coefficients: no slots for them */,
        // Float32 problems (ude_model_desc.dtype = 1): hudson_bay.jl:77-104, scenario_3.jl:26-57 (true Fisher-KPP) and :83-126 (its UDE)
        MID_LV_HUDSON_F32, MID_KPP_TRUE_32_F32, MID_KPP_S3_32_F32,
-       MID_SEIR_NODE /* the pure neural ODE 7-64-64-64-7 of seir_exposure.jl:53-73 */ };
+       MID_SEIR_NODE /* the pure neural ODE 7-64-64-64-7 of seir_exposure.jl:53-73 */,
+       // runtime-shape fallback (ude_model_generic.h): any chain of <= 8 Dense layers of width <= 64 for the replicated-state kinds
+       MID_GENERIC_2 /* UDE_KIND_LV_UDE */, MID_GENERIC_7 /* UDE_KIND_SEIR_UDE, UDE_KIND_SEIR_NODE */,
+       MID_KPP_SMALL1_32, MID_KPP_SMALL2_32 /* Fisher-KPP-CNN-Small.jl:88 with n_weights = 1, 2 */ };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88
 using NetKppSmall = NetCfg<IntList<1, 3, 1>, IntList<ACT_TANH, ACT_IDENTITY>>;                        // Fisher-KPP-CNN-Small.jl:89-94 (15 parameters)
+using NetKppSmall1 = NetCfg<IntList<1, 1, 1>, IntList<ACT_TANH, ACT_IDENTITY>>;                       // n_weights = 1 (:88, timing log :343-391)
+using NetKppSmall2 = NetCfg<IntList<1, 2, 1>, IntList<ACT_TANH, ACT_IDENTITY>>;                       // n_weights = 2
 
 }  // namespace ude

@@ -258,6 +258,11 @@ static int model_id(const ude_model_desc* m) {
         if (dims_are(m, {1, 3, 1}, {ACT_TANH, ACT_IDENTITY}) && m->n_param == 15 && m->stencil_offset == 10 && m->d0_offset == 14 &&
             m->n_state <= 32)
             return MID_KPP_SMALL_32;  // the only variant the reference publishes timings for (Fisher-KPP-CNN-Small.jl:319-341)
+        // n_weights = 1, 2 of Fisher-KPP-CNN-Small.jl:88 (timing log :343-391): theta = [W1 (n); b1 (n); W2 (n); b2; w1 w2 w3 unused; D0]
+        for (int nw = 1; nw <= 2; ++nw)
+            if (dims_are(m, {1, nw, 1}, {ACT_TANH, ACT_IDENTITY}) && m->n_param == 3 * nw + 6 && m->stencil_offset == 3 * nw + 1 &&
+                m->d0_offset == 3 * nw + 5 && m->n_state <= 32)
+                return nw == 1 ? MID_KPP_SMALL1_32 : MID_KPP_SMALL2_32;
         if (dims_are(m, {1, 5, 5, 5, 1}, {ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY}) && m->n_param == 81 &&
             m->stencil_offset == 76 && m->d0_offset == 80 && m->n_state <= 32)
             return MID_KPP_S3_32;
@@ -272,6 +277,29 @@ static int model_id(const ude_model_desc* m) {
     return MID_NONE;
 }
 
+// the runtime-shape fallback (csrc/ude_model_generic.h) takes any chain of 1..8 Dense layers of width 1..64 with activations
+// identity / tanh / rbf / relu whose ends fit the kind's wiring: LV 2 -> 2, SEIR exposure 3 -> 1, neural ODE 7 -> 7
+static int generic_id(const ude_model_desc* m) {
+    if (m->dtype != 0 || m->n_layers < 1 || m->n_layers > UDE_MAX_LAYERS || m->nn_offset < 0) return MID_NONE;
+    int np = 0;
+    for (int l = 0; l <= m->n_layers; ++l)
+        if (m->dims[l] < 1 || m->dims[l] > 64) return MID_NONE;
+    for (int l = 0; l < m->n_layers; ++l) {
+        if (m->act[l] < UDE_ACT_IDENTITY || m->act[l] > UDE_ACT_RELU) return MID_NONE;
+        np += m->dims[l] * m->dims[l + 1] + m->dims[l + 1];
+    }
+    if (m->nn_offset + np > m->n_param) return MID_NONE;
+    const int in = m->dims[0], out = m->dims[m->n_layers];
+    if (m->kind == UDE_KIND_LV_UDE && m->n_state == 2 && in == 2 && out == 2) {
+        for (int i = 0; i < 2; ++i)
+            if (m->lin_idx[i] >= m->n_param || (m->lin_idx[i] >= m->nn_offset && m->lin_idx[i] < m->nn_offset + np)) return MID_NONE;
+        return MID_GENERIC_2;
+    }
+    if (m->kind == UDE_KIND_SEIR_UDE && m->n_state == 7 && in == 3 && out == 1) return MID_GENERIC_7;
+    if (m->kind == UDE_KIND_SEIR_NODE && m->n_state == 7 && in == 7 && out == 7) return MID_GENERIC_7;
+    return MID_NONE;
+}
+
 static int default_lanes(int mid, bool discrete) {
     switch (mid) {
         case MID_LV_TRUE: return 1;
@@ -282,10 +310,14 @@ static int default_lanes(int mid, bool discrete) {
         case MID_SEIR_TRUE: return 1;
         case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
         case MID_SEIR_NODE: return 64;  // wavefront per trajectory, 3 per block (two 64x64 layers + the compacted stage factors fill the LDS)
+        case MID_GENERIC_2:
+        case MID_GENERIC_7: return 64;  // wavefront per trajectory, one per block
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32:
         case MID_KPP_SMALL_32:
+        case MID_KPP_SMALL1_32:
+        case MID_KPP_SMALL2_32:
         case MID_KPP_TRUE_32_F32:
         case MID_KPP_S3_32_F32: return 32;
         case MID_KPP_TRUE_1024: return 64;
@@ -294,10 +326,16 @@ static int default_lanes(int mid, bool discrete) {
     return 1;
 }
 
-static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, Launch& l, int& G) {
-    const int mid = model_id(m);
+static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, Launch& l, int& G, bool* generic = nullptr) {
+    int mid = model_id(m);
+    if (generic) *generic = false;
+    if (mid == MID_NONE) {  // no compiled instance for this exact shape: the runtime-shape kernel, if the descriptor fits it
+        mid = generic_id(m);
+        if (generic) *generic = mid != MID_NONE;
+    }
     if (mid == MID_NONE)
-        return fail(c, UDE_ERR_UNSUPPORTED, "no compiled kernel for model kind=%d dtype=%d n_layers=%d (see udecore.hip model table)",
+        return fail(c, UDE_ERR_UNSUPPORTED, "no kernel for model kind=%d dtype=%d n_layers=%d: not a compiled instance (udecore.hip model table) and "
+                                            "outside the runtime-shape fallback (Float64, replicated-state kinds LV / SEIR, <= 8 layers of width <= 64)",
                     m->kind, m->dtype, m->n_layers);
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
     const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
@@ -348,6 +386,10 @@ static void fill_params(KParams& p, const ude_model_desc* m, const ude_solve_opt
     p.mc.nn_offset = m->nn_offset;
     p.mc.stencil_offset = m->stencil_offset;
     p.mc.d0_offset = m->d0_offset;
+    p.mc.kind = m->kind;
+    p.mc.n_layers = m->n_layers;
+    for (int i = 0; i <= UDE_MAX_LAYERS; ++i) p.mc.dims[i] = (i <= m->n_layers && m->n_layers <= UDE_MAX_LAYERS) ? m->dims[i] : 0;
+    for (int i = 0; i < UDE_MAX_LAYERS; ++i) p.mc.act[i] = i < m->n_layers ? m->act[i] : 0;
     for (int i = 0; i < 2; ++i) {
         p.mc.lin_idx[i] = m->lin_idx[i];
         p.mc.lin_sign[i] = m->lin_sign[i];
@@ -448,11 +490,16 @@ extern "C" int ude_set_launch_opts(ude_ctx* c, const ude_launch_opts* lo) {
     return UDE_OK;
 }
 
-extern "C" int ude_model_supported(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int32_t) {
+extern "C" int ude_model_supported(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, int32_t need_adjoint) {
     if (!c || !m || !o) return UDE_ERR_INVALID;
     Launch l;
     int G;
-    return resolve(c, m, o, l, G);
+    bool generic = false;
+    const int rc = resolve(c, m, o, l, G, &generic);
+    if (rc) return rc;
+    if (need_adjoint && o->sensealg == UDE_SENSE_DISCRETE && !l.dadj)
+        return fail(c, UDE_ERR_UNSUPPORTED, "the runtime-shape kernel has no discretise-then-optimise sweep: use the interpolating adjoint");
+    return generic ? 1 : UDE_OK;   // 0: compiled fast instance, 1: runtime-shape fallback kernel
 }
 
 extern "C" int ude_set_trace(ude_ctx* c, int64_t traj, int32_t cap) {
@@ -651,6 +698,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const bool pt = o->per_trajectory != 0;
     if (fast && pt) return fail(c, UDE_ERR_UNSUPPORTED, "UDE_SENSE_INTERPOLATING_ADJOINT_FAST has no per-trajectory time-grid instances");
     void (*bwd)(const KParams) = discrete ? (pt ? l.dadj_pt : l.dadj) : fast ? l.adj_fast : (pt ? l.adj_pt : l.adj);
+    if (!bwd) return fail(c, UDE_ERR_UNSUPPORTED, "the runtime-shape kernel has no discretise-then-optimise sweep: use the interpolating adjoint");
     void (*kfwd)(const KParams) = pt ? l.fwd_pt : l.fwd;
     const size_t shmem_f = l.lds_bytes(np, false);
     const size_t shmem_a = l.lds_bytes(np, true, discrete);
