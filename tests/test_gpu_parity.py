@@ -287,12 +287,13 @@ def test_seir_true_matches_oracle():
     assert (rc == 0).all() and out[:, -1, 2].min() > 0          # the epidemic actually develops
 
 
-@pytest.mark.parametrize("alg,oalg,lanes", [(U.Vern7, O.VERN7, 0), (U.Tsit5, O.TSIT5, 0), (U.Vern7, O.VERN7, 256), (U.Tsit5, O.TSIT5, 256)])
-def test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg, lanes):
+@pytest.mark.parametrize("alg,oalg,lanes", [(U.Vern7, O.VERN7, 0), (U.Tsit5, O.TSIT5, 0), (U.Vern7, O.VERN7, 256), (U.Tsit5, O.TSIT5, 256),
+                                            (U.Vern7, O.VERN7, 16), (U.Tsit5, O.TSIT5, 16), (U.Vern7, O.VERN7, 64)])
+def test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg, lanes, N=12):
     """dudt_ (seir_exposure.jl:114-147): 3-64-64-1 tanh exposure network, loss on rows 2:4 (E, I, R).
-    lanes = 0: the default wavefront-per-trajectory kernels (deferred parameter cotangent); 256: four wavefronts per
-    trajectory (register-resident weight slices) -- both bit-identical to the oracle's wide-dot arithmetic."""
-    N = 12
+    lanes = 64: one wavefront per trajectory (deferred parameter cotangent); 256: four wavefronts per trajectory
+    (register-resident weight slices); 16: the lock-step backward kernel (16 trajectories per block as columns of FP64
+    matrix-core products, csrc/ude_seir_ls.h) -- all bit-identical to the oracle's wide-dot arithmetic."""
     kw = {"ensemblealg": U.EnsembleMI355(lanes)} if lanes else {}
     u0, t = seir_inputs(N)
     truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
@@ -314,6 +315,15 @@ def test_seir_ude_forward_and_adjoint_match_oracle(alg, oalg, lanes):
     assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
     assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
     assert np.linalg.norm(ref["grad_theta"]) > 0
+    if N == 1:
+        assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta (single trajectory: no sum over trajectories)")
+
+
+@pytest.mark.parametrize("N", [1, 37])
+def test_seir_lockstep_kernel_partial_blocks_and_single_trajectory(N):
+    """the lock-step kernel with one live slot of sixteen (every one of the 4481 gradient entries bitwise) and with 37
+    trajectories = two full blocks and one of five slots"""
+    test_seir_ude_forward_and_adjoint_match_oracle(U.Vern7, O.VERN7, 16, N=N)
 
 
 def kpp_case(nx, N, chain, omodel, seed=4):

@@ -1,0 +1,651 @@
+// ude_seir_ls.h -- the interpolating adjoint of the SEIR exposure UDE (dudt_, SEIR_exposure/seir_exposure.jl:114-147) with the
+// trajectories of a block stepping in LOCK-STEP as columns of FP64 matrix-core products.
+//
+// adj_kernel<SeirUde<64>> gives every trajectory a wavefront of its own: the 64x64 hidden layer is 64 dependent fma's per lane
+// behind 64 LDS broadcast reads, twice per evaluation, with one wavefront per SIMD and nothing to hide the latency behind
+// (4.9 % of the FP64 peak).  Here a block of four wavefronts owns SIXTEEN trajectory slots:
+//   * the network of an adjoint evaluation runs for all 16 slots at once on v_mfma_f64_16x16x4 (D = C + A(16x4) B(4x16),
+//     d = fma(a_k, b_k, d) for k ascending: tools/probe/mfma_order_probe.hip): wavefront w owns hidden rows 16w .. 16w+15, its
+//     rows of W2 and of W2^T are A-operand fragments in registers (no LDS weight copy, no broadcast reads), activations and
+//     deltas of the 16 slots cross wavefronts as B operands through [row][slot] LDS tiles;
+//   * ARITH-SPEC is kept bit for bit: a 64-term hidden dot is four 16-term chains (four MFMAs each, from C = 0) added left to
+//     right -- the oracle's wide-dot rule --, the 3-term first layer is one MFMA whose fourth k-step adds the bias
+//     (fma(b, 1, acc) == acc + b), the three input-cotangent sums are rounded products reduced by the adjacent-pair tree;
+//   * everything per trajectory that is not a matrix product -- interval lookup and dense-output interpolation of the forward
+//     state, the stage combinations, the error norm, the PI controller, save-point jumps -- runs on the 16-lane ROW that owns
+//     the slot (slot 4w + r on row r of wavefront w), component c on lane c of the row, exactly the Driver's sequence;
+//   * the parameter cotangent stays deferred: every stage leaves its factors (a1 a2 delta1 delta2 per hidden row, x and delta3
+//     per slot) in an L2-resident workspace, and at the end of a step each wavefront forms, slot after slot of its own four,
+//     the RK-weighted sums of the 71 parameter slots per lane, the candidate mu and its share of the error norm with the very
+//     loops of SeirUde<64>::step_slots (mu in HBM, two columns that swap on acceptance).
+// Per trajectory every number -- step counts, dL/du0, each of the 4481 gradient entries -- is bit-identical to the oracle and
+// to adj_kernel<SeirUde<64>>.  Float64, shared time grid, interpolating adjoint with mu under error control (parity mode).
+#pragma once
+#include "ude_kernels.h"
+
+namespace ude {
+namespace seirls {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int H = 64, NSLOTS = 16, BLOCKT = 256, NC = 7;
+constexpr int TLD = 17;   // leading dimension of the [row][slot] tiles (odd: the transposed copy to the factor workspace is conflict-free)
+constexpr int PLD = 65;   // slot stride of the [slot][row] product tiles
+constexpr int NSLK = H + 7;  // parameter slots per hidden row: W2[i, 0..63], W1[i, 0..2], b1[i], b2[i], W3[i], b3 (row 0)
+constexpr int OFF_W1 = 0, OFF_B1 = 3 * H, OFF_W2 = 4 * H, OFF_B2 = 4 * H + H * H, OFF_W3 = OFF_B2 + H, OFF_B3 = OFF_W3 + H;
+
+template <class Tab>
+constexpr unsigned stage_mask() {
+    unsigned m = 0;
+    for (int s = 0; s < Tab::S; ++s)
+        if (Tab::B(s) != 0.0 || Tab::BT(s) != 0.0) m |= 1u << s;
+    return m;
+}
+constexpr int popc(unsigned m) { int c = 0; for (; m; m &= m - 1) ++c; return c; }
+template <unsigned MASK>
+constexpr int cslot(int s) { return popc(MASK & ((1u << s) - 1u)); }   // compacted storage slot of stage s
+
+template <class Tab>
+constexpr int lds_doubles() {
+    constexpr int NSTC = popc(stage_mask<Tab>());
+    return 4 * H * TLD + 4 * 16 + 16 + 3 * NSLOTS * PLD + NSTC * NSLOTS * 4 + NSLOTS * 16 + NSLOTS * 8 + NSLOTS * 8 + 4 * NSTC * H;
+}
+// doubles of factor workspace per block
+template <class Tab>
+constexpr size_t fac_doubles_per_block() { return (size_t)NSLOTS * popc(stage_mask<Tab>()) * 4 * H; }
+
+__device__ __forceinline__ double rshfl(double x, int c) { return __shfl(x, c, 16); }   // lane c of this 16-lane row
+__device__ __forceinline__ double row_tree4(double v0, double v1, double v2, double v3) {
+    double x = (v0 + v1) + (v2 + v3);
+    x += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x);
+    x += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x);
+    x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
+    x += dpp_mov<DPP_ROW_MIRROR>(x);
+    return x;
+}
+
+// one pass over the 71 parameter slots of ONE trajectory by a whole wavefront (lane i = hidden row i): SeirUde<64>'s loops.
+//   MODE 0: end of a step -- candidate mu_new, returns this lane's sum of squared residuals
+//   MODE 1 / 2: the initial-dt norms (h, l) += (g0 / sk)^2  /  ((g1 - g0) / sk)^2 in real-real arithmetic
+template <int NST, unsigned MASK, int MODE>
+__device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* this trajectory's factors: [cs][field][64] */,
+                                            double* a1s /* LDS staging [cs][64] of this wavefront */, const double* xf /* LDS [cs][16][4] */,
+                                            int slot, int lane, const double* Bw, const double* BTw, double dt, double abstol, double reltol,
+                                            const double* mu, double* mu_new, double& hh, double& ll) {
+    double a2[NST], d1[NST], d2[NST], xs[NST][4];
+    static_for<0, NST>([&](auto s) {
+        if constexpr ((MASK >> decltype(s)::value) & 1u) {
+            constexpr int cs = cslot<MASK>(decltype(s)::value);
+            const double* f = fbase + (size_t)cs * 4 * H + lane;
+            a1s[cs * H + lane] = f[0];
+            a2[s] = f[H]; d1[s] = f[2 * H]; d2[s] = f[3 * H];
+            static_for<0, 4>([&](auto q) { xs[s][q] = xf[(cs * NSLOTS + slot) * 4 + decltype(q)::value]; });
+        }
+    });
+    double bb[NST], bt[NST];
+    if constexpr (MODE == 0) static_for<0, NST>([&](auto s) { bb[s] = uniform_real(Bw[s]); bt[s] = uniform_real(BTw[s]); });
+    double ps = 0.0;
+    auto body = [&](int sl, const double* g, double m0) {
+        if constexpr (MODE == 0) {
+            double ab = bb[0] * g[0], ae = bt[0] * g[0];
+            static_for<1, NST>([&](auto s) {
+                if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                    ab = __builtin_fma(bb[s], g[s], ab);
+                    ae = __builtin_fma(bt[s], g[s], ae);
+                }
+            });
+            const double m1 = __builtin_fma(dt, ab, m0);
+            mu_new[(size_t)sl * H] = m1;
+            const double a0 = fabs(m0), a1 = fabs(m1);
+            const double res = (dt * ae) / __builtin_fma((a0 > a1 ? a0 : a1), reltol, abstol);
+            ps = __builtin_fma(res, res, ps);
+        } else {
+            const double sk = __builtin_fma(fabs(m0), reltol, abstol);
+            const double q = MODE == 1 ? g[0] / sk : (g[NST - 1] - g[0]) / sk;
+            dd_acc(hh, ll, q * q);
+        }
+    };
+    constexpr int CH = 8;
+    double mcur[CH], mnext[CH];
+    static_for<0, CH>([&](auto i) { mcur[i] = mu[(size_t)decltype(i)::value * H]; });
+#pragma unroll 1
+    for (int k0 = 0; k0 < H; k0 += CH) {
+        static_for<0, CH>([&](auto i) {
+            const int sl = k0 + CH + decltype(i)::value;
+            mnext[i] = sl < NSLK ? mu[(size_t)sl * H] : 0.0;
+        });
+        static_for<0, CH>([&](auto i) {
+            const int k = k0 + decltype(i)::value;
+            double g[NST];
+            static_for<0, NST>([&](auto s) {
+                if constexpr ((MASK >> decltype(s)::value) & 1u) g[s] = -(d2[s] * a1s[cslot<MASK>(decltype(s)::value) * H + k]);
+            });
+            body(k, g, mcur[i]);
+        });
+        static_for<0, CH>([&](auto i) { mcur[i] = mnext[i]; });
+    }
+    static_for<0, 7>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        double g[NST];
+        static_for<0, NST>([&](auto s) {
+            if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                double v;
+                if constexpr (e < 3) v = -(d1[s] * xs[s][e]);
+                else if constexpr (e == 3) v = -d1[s];
+                else if constexpr (e == 4) v = -d2[s];
+                else if constexpr (e == 5) v = -(xs[s][3] * a2[s]);
+                else v = lane == 0 ? -xs[s][3] : -0.0;
+                g[s] = v;
+            }
+        });
+        body(H + e, g, mcur[e]);
+    });
+    return ps;
+}
+
+template <class Tab>
+__global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p, double* __restrict__ facws) {
+    constexpr int S = Tab::S, NK = Tab::NK;
+    constexpr unsigned MASK = stage_mask<Tab>();
+    constexpr int NSTC = popc(MASK);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* T_A1 = sm;
+    double* T_D2 = T_A1 + H * TLD;
+    double* T_A2 = T_D2 + H * TLD;
+    double* T_D1 = T_A2 + H * TLD;
+    double* XIN = T_D1 + H * TLD;             // [4][16]: x0 x1 x2 1
+    double* D3S = XIN + 4 * 16;               // [16]
+    double* PG = D3S + 16;                    // [3][16][PLD]
+    double* XF = PG + 3 * NSLOTS * PLD;       // [NSTC][16][4]
+    double* BQ = XF + NSTC * NSLOTS * 4;      // [16][16]
+    double* YS = BQ + NSLOTS * 16;            // [16][8]
+    double* SUM = YS + NSLOTS * 8;            // [16][8]
+    double* A1S = SUM + NSLOTS * 8;           // [4][NSTC][64]
+
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int kq = l >> 4, jc = l & 15;       // matrix view: k index / column (= slot) of this lane
+    const int rr = l >> 4, lm = l & 15;       // scalar view: row of the wavefront (slot 4w + rr), lane inside the row
+    const int slot = 4 * w + rr;
+    const int64_t gid = (int64_t)blockIdx.x * NSLOTS + slot;
+    const double* __restrict__ th = p.theta;
+    const TabDev* __restrict__ tab = p.tab;
+    const int n = NC;
+    const int nfld = 3 + n + NK * n;
+
+    // ---- weights: A-operand fragments and per-row constants of this wavefront's 16 hidden rows ----
+    double W2A[16], W2T[16];
+    {
+        const int row = 16 * w + jc;
+        static_for<0, 16>([&](auto sc) {
+            const int col = 4 * decltype(sc)::value + kq;
+            W2A[sc] = th[OFF_W2 + row + col * H];      // A[i][k] = W2[16w + i][4s + k]
+            W2T[sc] = th[OFF_W2 + col + row * H];      // A[i][k] = W2[4s + k][16w + i]
+        });
+    }
+    const double W1A = kq < 3 ? th[OFF_W1 + (16 * w + jc) + kq * H] : th[OFF_B1 + 16 * w + jc];
+    double w1r[3][4], b2r[4], w3r[4];
+    static_for<0, 4>([&](auto r) {
+        const int row = 16 * w + kq + 4 * decltype(r)::value;
+        static_for<0, 3>([&](auto mm) { w1r[mm][r] = th[OFF_W1 + row + decltype(mm)::value * H]; });
+        b2r[r] = th[OFF_B2 + row];
+        w3r[r] = th[OFF_W3 + row];
+    });
+    const double Fc = p.mc.consts[0], b0c = p.mc.consts[1], muc = p.mc.consts[4], sgc = p.mc.consts[5], gac = p.mc.consts[6],
+                 dc = p.mc.consts[7], lac = p.mc.consts[8];
+    if (tid < 16) XIN[3 * 16 + tid] = 1.0;
+    for (int i = tid; i < NSLOTS * 8; i += BLOCKT) { SUM[i] = 0.0; YS[i] = 0.0; }
+
+    // ---- per-slot scalar state (replicated in the 16 lanes of the slot's row; component c on lane c) ----
+    const OptsR o(p.o);
+    const double T0 = p.t0, TF = p.tf, tdir = -1.0;
+    const double dtmax = o.dtmax;
+    const double ntot = (double)(p.n_state + p.n_param);
+    const bool in_range = gid < p.N;
+    bool live = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
+    const bool started = live;
+    int ret = RET_SUCCESS;
+    double lam[NC], K[S], us = 0.0, ks[NK], ts = 0.0, te = 0.0;
+    static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
+    static_for<0, S>([&](auto s) { K[s] = 0.0; });
+    static_for<0, NK>([&](auto q) { ks[q] = 0.0; });
+    int sf = 0, cur = p.ns - 1, nsteps = live ? p.dense_n[gid] : 1;
+    double rq[7];
+    {
+        const int q = lm < NK ? lm : 0;
+        static_for<0, 7>([&](auto i) { rq[i] = tab->R[q][i]; });
+    }
+    const double* cot;
+    size_t cot_si, cot_sc;
+    const int64_t gsafe = in_range ? gid : 0;
+    if (p.cot_in) { cot = p.cot_in + (size_t)gsafe * p.ns * n; cot_si = n; cot_sc = 1; }
+    else { cot = p.cot + gsafe; cot_si = (size_t)n * p.Npad; cot_sc = p.Npad; }
+    double* mu_cur = p.slot_glob + (size_t)gsafe * (2 * NSLK * H);
+    double* mu_new = mu_cur + NSLK * H;
+    double* fmine = facws + (size_t)blockIdx.x * fac_doubles_per_block<Tab>();   // this block's factor workspace
+
+    auto load_interval = [&](int s) {
+        sf = s;
+        const double* base = p.dense + ((size_t)s * nfld) * p.Npad + gsafe;
+        ts = base[0];
+        te = base[(size_t)1 * p.Npad];
+        const bool on = lm < n;
+        const int rc = on ? lm : 0;
+        us = on ? base[(size_t)(3 + rc) * p.Npad] : 0.0;
+        static_for<0, NK>([&](auto q) {
+            if constexpr (Tab::dense_uses(decltype(q)::value)) ks[q] = on ? base[(size_t)(3 + n + (int)decltype(q)::value * n + rc) * p.Npad] : 0.0;
+        });
+    };
+    auto own = [&](const double (&v)[NC]) {
+        double r = 0.0;
+        static_for<0, NC>([&](auto c) { r = (lm == (int)decltype(c)::value) ? v[c] : r; });
+        return r;
+    };
+    auto bcast = [&](double ownv, double (&out)[NC]) { static_for<0, NC>([&](auto c) { out[c] = rshfl(ownv, decltype(c)::value); }); };
+    auto SV = [&](int i) { return p.saveat[i]; };
+    auto tstop_from_cur = [&]() { return (cur >= 0 && SV(cur) > T0) ? SV(cur) : T0; };
+    auto at_tstop = [&](double t) {
+        bool mod = false;
+        while (cur >= 0 && SV(cur) >= t) {
+            if (SV(cur) == t) {
+                static_for<0, NC>([&](auto c) { lam[c] += cot[(size_t)cur * cot_si + (size_t)decltype(c)::value * cot_sc]; });
+                mod = true;
+            }
+            cur -= 1;
+        }
+        return mod;
+    };
+    // zero this trajectory's mu (current column) -- every wavefront for its own four slots, lane i = hidden row i
+    for (int q = 0; q < 4; ++q) {
+        const int64_t g = (int64_t)blockIdx.x * NSLOTS + 4 * w + q;
+        if (g < p.N) {
+            double* m0 = p.slot_glob + (size_t)g * (2 * NSLK * H) + l;
+#pragma unroll 4
+            for (int k = 0; k < NSLK; ++k) m0[(size_t)k * H] = 0.0;
+        }
+    }
+    if (live) {
+        load_interval(nsteps - 1);
+        at_tstop(TF);   // init_cb: the jump at t = tf precedes the first step
+    }
+    __syncthreads();
+
+    // ---- one adjoint evaluation of all 16 slots: lambda' = -(df/du)^T lambda at y(te) into kl[]; the stage's factors go to
+    // compacted slot `cs` of the workspace.  `ev` = this slot takes part (its inputs are valid) ----
+    auto eval_all = [&](bool ev, double tev, const double (&zs)[NC], int cs, double (&kl)[NC]) {
+        double y[NC];
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0, d3 = 0.0;
+        if (ev) {
+            while (tev < ts && sf > 0) load_interval(sf - 1);
+            while (tev >= te && sf < nsteps - 1) load_interval(sf + 1);
+            const double dtf = te - ts;
+            const double thv = (tev - ts) / dtf;
+            double hq = rq[0];
+            static_for<1, 7>([&](auto i) { hq = __builtin_fma(thv, hq, rq[i]); });
+            BQ[slot * 16 + lm] = (lm == 0 ? thv : thv * thv) * hq;
+            double acc = 0.0;
+            bool first = true;
+            static_for<0, NK>([&](auto q) {
+                if constexpr (Tab::dense_uses(decltype(q)::value)) {
+                    const double bqv = BQ[slot * 16 + decltype(q)::value];
+                    acc = first ? ks[q] * bqv : __builtin_fma(ks[q], bqv, acc);
+                    first = false;
+                }
+            });
+            if (lm < NC) YS[slot * 8 + lm] = __builtin_fma(dtf, acc, us);
+            static_for<0, NC>([&](auto c) { y[c] = YS[slot * 8 + decltype(c)::value]; });
+            x0 = y[0] / y[4]; x1 = y[2]; x2 = y[5] / y[4];
+            d3 = (zs[1] - zs[0]) * 1.0;
+            if (lm == 0) {
+                XIN[0 * 16 + slot] = x0; XIN[1 * 16 + slot] = x1; XIN[2 * 16 + slot] = x2;
+                D3S[slot] = d3;
+                double* xf = XF + (cs * NSLOTS + slot) * 4;
+                xf[0] = x0; xf[1] = x1; xf[2] = x2; xf[3] = d3;
+            }
+        }
+        __syncthreads();
+        // ---- layer 1 (3 inputs + bias in one k-step) ----
+        v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(W1A, XIN[kq * 16 + jc], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        double a1[4], a2[4], dv1[4], dv2[4];
+        static_for<0, 4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            a1[r] = dtanh(z[r]);
+            T_A1[(16 * w + kq + 4 * r) * TLD + jc] = a1[r];
+        });
+        __syncthreads();
+        // ---- hidden layer: four 16-term chains (four MFMAs each) added left to right ----
+        {
+            v4d acc[4];
+            static_for<0, 4>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                static_for<0, 4>([&](auto q) {
+                    constexpr int s = 4 * b + decltype(q)::value;
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                });
+            });
+            const double d3j = D3S[jc];
+            static_for<0, 4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + b2r[r];
+                a2[r] = dtanh(z2);
+                dv2[r] = __builtin_fma(w3r[r], d3j, 0.0) * __builtin_fma(-a2[r], a2[r], 1.0);
+                const int row = 16 * w + kq + 4 * r;
+                T_D2[row * TLD + jc] = dv2[r];
+                T_A2[row * TLD + jc] = a2[r];
+            });
+        }
+        __syncthreads();
+        // ---- transposed hidden layer on the deltas ----
+        {
+            v4d acc[4];
+            static_for<0, 4>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                static_for<0, 4>([&](auto q) {
+                    constexpr int s = 4 * b + decltype(q)::value;
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                });
+            });
+            static_for<0, 4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const double s1 = ((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r];
+                dv1[r] = s1 * __builtin_fma(-a1[r], a1[r], 1.0);
+                const int row = 16 * w + kq + 4 * r;
+                T_D1[row * TLD + jc] = dv1[r];
+                static_for<0, 3>([&](auto mm) { PG[(decltype(mm)::value * NSLOTS + jc) * PLD + row] = w1r[mm][r] * dv1[r]; });
+            });
+        }
+        __syncthreads();
+        // ---- factors of this stage to the workspace, slot-major: wavefront w copies its own four slots (lane i = hidden row i) ----
+        static_for<0, 4>([&](auto q) {
+            const int sl = 4 * w + decltype(q)::value;
+            double* dst = fmine + ((size_t)sl * NSTC + cs) * 4 * H + l;
+            dst[0] = T_A1[l * TLD + sl];
+            dst[H] = T_A2[l * TLD + sl];
+            dst[2 * H] = T_D1[l * TLD + sl];
+            dst[3 * H] = T_D2[l * TLD + sl];
+        });
+        // ---- the slot's row: input cotangent (adjacent-pair trees over the 64 rounded products) and the state cotangent ----
+        if (ev) {
+            double gx[3];
+            static_for<0, 3>([&](auto mm) {
+                const double* pr = PG + (decltype(mm)::value * NSLOTS + slot) * PLD + 4 * lm;
+                gx[mm] = row_tree4(pr[0], pr[1], pr[2], pr[3]);
+            });
+            const double Sv = y[0], Nv = y[4], Dv = y[5];
+            const double cc = b0c * Fc / Nv;
+            const double cN = b0c * Sv * Fc / (Nv * Nv);
+            double dl[NC];
+            dl[0] = (-cc - muc) * zs[0] + cc * zs[1] + gx[0] / Nv;
+            dl[1] = -(sgc + muc) * zs[1] + sgc * zs[2] + sgc * zs[6];
+            dl[2] = -(gac + muc) * zs[2] + gac * zs[3] + dc * gac * zs[5] + gx[1];
+            dl[3] = -muc * zs[3];
+            dl[4] = cN * zs[0] - cN * zs[1] - muc * zs[4] - gx[0] * Sv / (Nv * Nv) - gx[2] * Dv / (Nv * Nv);
+            dl[5] = -lac * zs[5] + gx[2] / Nv;
+            dl[6] = 0.0;
+            static_for<0, NC>([&](auto c) { kl[c] = -dl[c]; });
+        }
+        // (the next evaluation's first barrier separates these reads from the next writes of XIN / D3S; the tiles and PG are
+        //  rewritten only after further barriers)
+    };
+
+    // ---- a pass over the parameter slots of this wavefront's four trajectories (lane i = hidden row i) ----
+    auto mu_pass = [&](auto modec, bool take, double dtv) {
+        constexpr int MODE = decltype(modec)::value;
+        static_for<0, 4>([&](auto q) {
+            const int sl = 4 * w + decltype(q)::value;
+            const bool on = __builtin_amdgcn_readlane((int)take, 16 * decltype(q)::value) != 0;   // (wave-uniform: the row's flag)
+            if (on) {
+                const int64_t g = (int64_t)blockIdx.x * NSLOTS + sl;
+                const double dts = readlane_real(dtv, 16 * decltype(q)::value);
+                // which of the two mu columns is current is the row's state: column pointers as 64-bit values of lane 16q
+                const unsigned long long mc_ = (unsigned long long)mu_cur, mn_ = (unsigned long long)mu_new;
+                const unsigned long long mcq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mc_ >> 32), 16 * decltype(q)::value) << 32) |
+                                               (unsigned)__builtin_amdgcn_readlane((int)mc_, 16 * decltype(q)::value);
+                const unsigned long long mnq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mn_ >> 32), 16 * decltype(q)::value) << 32) |
+                                               (unsigned)__builtin_amdgcn_readlane((int)mn_, 16 * decltype(q)::value);
+                const double* mcur = (const double*)mcq + l;
+                double* mnew = (double*)mnq + l;
+                const double* fb = fmine + (size_t)sl * NSTC * 4 * H;
+                double hh = 0.0, ll = 0.0;
+                (void)g;
+                if constexpr (MODE == 0) {
+                    const double ps = slot_pass<S, MASK, 0>(fb, A1S + w * NSTC * H, XF, sl, l, tab->B, tab->BT, dts, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    const double tot = group_sum<64>(ps);
+                    if (l == 0) SUM[sl * 8 + 0] = tot;
+                } else if constexpr (MODE == 1) {
+                    slot_pass<1, 1u, 1>(fb, A1S + w * NSTC * H, XF, sl, l, tab->B, tab->BT, dts, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    group_dd_sum<64>(hh, ll);
+                    if (l == 0) { SUM[sl * 8 + 1] = hh; SUM[sl * 8 + 2] = ll; }
+                } else {
+                    slot_pass<2, 3u, 2>(fb, A1S + w * NSTC * H, XF, sl, l, tab->B, tab->BT, dts, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    group_dd_sum<64>(hh, ll);
+                    if (l == 0) { SUM[sl * 8 + 3] = hh; SUM[sl * 8 + 4] = ll; }
+                }
+            }
+        });
+    };
+
+    // =====================================================================================================================
+    // the Driver's sequence (ude_kernels.h: Driver::run with CPL, DEFER), one trajectory per 16-lane row
+    // =====================================================================================================================
+    double t = TF, dt = 0.0, qold = o.qoldinit, q11 = 1.0;
+    bool accept = true;
+    int iter = 0;
+    int64_t nfc = 0, nacc = 0, nrej = 0;
+    double tstop = tstop_from_cur();
+    double f0[NC], f1[NC], z1[NC];
+    static_for<0, NC>([&](auto c) { f0[c] = 0.0; f1[c] = 0.0; z1[c] = 0.0; });
+
+    // ---- initial dt (ode_determine_initdt): two evaluations ----
+    const bool user_dt = o.dt0 > 0.0;
+    if (user_dt) {
+        dt = tdir * o.dt0;
+        if constexpr (Tab::FSAL) nfc += 1;
+    }
+    {
+        const bool ev0 = live && !user_dt;
+        eval_all(ev0, t, lam, 0, f0);
+        if (ev0) K[0] = own(f0);
+        __syncthreads();   // factors of stage slot 0 are in the workspace (written by the wavefronts that own the slots themselves)
+        mu_pass(std::integral_constant<int, 1>{}, ev0, 0.0);
+        bool ev1 = false;
+        double dt0 = 0.0, d1n = 0.0, sk[NC];
+        if (ev0) {
+            double h0 = 0.0, l0 = 0.0, h1 = SUM[slot * 8 + 1], l1 = SUM[slot * 8 + 2];
+            static_for<0, NC>([&](auto c) {
+                sk[c] = __builtin_fma(fabs(lam[c]), o.reltol, o.abstol);
+                const double q0 = lam[c] / sk[c], q1 = f0[c] / sk[c];
+                dd_acc(h0, l0, q0 * q0);
+                dd_acc(h1, l1, q1 * q1);
+            });
+            const double s0 = h0 + l0, s1 = h1 + l1;
+            const double d0 = __builtin_sqrt(s0 / ntot);
+            d1n = __builtin_sqrt(s1 / ntot);
+            if (d1n != d1n) { ret = RET_UNSTABLE; live = false; }
+            dt0 = (d0 < 1e-5 || d1n < 1e-5) ? 1e-6 : (d0 / d1n) / 100.0;
+            if (dt0 > dtmax) dt0 = dtmax;
+            if (dt0 < 10.0 * REAL_EPS) dt = tdir * 1e-6;
+            else ev1 = live;
+            if (ev1) {
+                const double dt0t = tdir * dt0;
+                static_for<0, NC>([&](auto c) { z1[c] = __builtin_fma(dt0t, f0[c], lam[c]); });
+            }
+        }
+        eval_all(ev1, t + tdir * dt0, z1, 1, f1);
+        __syncthreads();
+        mu_pass(std::integral_constant<int, 2>{}, ev1, 0.0);
+        if (ev1) {
+            double h2 = SUM[slot * 8 + 3], l2 = SUM[slot * 8 + 4];
+            static_for<0, NC>([&](auto c) {
+                const double q = (f1[c] - f0[c]) / sk[c];
+                dd_acc(h2, l2, q * q);
+            });
+            const double s2 = h2 + l2;
+            const double d2 = __builtin_sqrt(s2 / ntot) / dt0;
+            const double mx = d1n > d2 ? d1n : d2;
+            double dt1;
+            if (mx <= 1e-15) {
+                dt1 = dt0 * 1e-3;
+                if (dt1 < 1e-6) dt1 = 1e-6;
+            } else {
+                const double ex = -(2.0 + rlog10(mx)) / (double)Tab::ORDER;
+                dt1 = rpow10(ex);
+            }
+            double d = 100.0 * dt0;
+            if (dt1 < d) d = dt1;
+            if (dtmax < d) d = dtmax;
+            dt = tdir * d;
+        }
+        if (ev0) {
+            nfc += 2;
+            if constexpr (Tab::FSAL) nfc += 1;
+        }
+    }
+
+    // ---- the step loop: every live slot makes one attempt per trip ----
+    for (;;) {
+        bool go = live;
+        if (go) {
+            if (iter > 0 && !accept) {
+                double den = q11 / o.gamma;
+                const double iq = 1.0 / o.qmin;
+                if (iq < den) den = iq;
+                dt = dt / den;
+            }
+            iter += 1;
+            if (fabs(dt) > dtmax) dt = tdir * dtmax;
+            {
+                const double rem = fabs(tstop - t);
+                if (fabs(dt) > rem) dt = tdir * rem;
+            }
+            if (iter > o.maxiters) { ret = RET_MAXITERS; live = false; go = false; }
+            else if (dt != dt) { ret = RET_UNSTABLE; live = false; go = false; }
+            else if (fabs(dt) <= REAL_EPS * fabs(t) && fabs(dt) < fabs(tstop - t)) { ret = RET_DTLESSTHANMIN; live = false; go = false; }
+        }
+        if (!__syncthreads_or(go)) break;
+        double znew[NC];
+        static_for<0, NC>([&](auto c) { znew[c] = lam[c]; });
+        const double zo = own(lam);
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            double zs[NC], kr[NC];
+            static_for<0, NC>([&](auto c) { zs[c] = lam[c]; kr[c] = 0.0; });
+            if (go && s > 0) {
+                double acc = tab->A[s][0] * K[0];
+                // K is a register array: the chain over j < s with a wave-uniform s, unrolled with selects
+                static_for<1, S>([&](auto j) {
+                    if ((int)decltype(j)::value < s) acc = __builtin_fma(tab->A[s][decltype(j)::value], K[j], acc);
+                });
+                bcast(__builtin_fma(dt, acc, zo), zs);
+            }
+            if (Tab::FSAL && s == S - 1) static_for<0, NC>([&](auto c) { znew[c] = zs[c]; });
+            eval_all(go, t + tab->C[s] * dt, zs, __builtin_popcount(MASK & ((1u << s) - 1u)), kr);
+            if (go) {
+                const double ko = own(kr);
+                static_for<0, S>([&](auto j) { K[j] = ((int)decltype(j)::value == s) ? ko : K[j]; });
+            }
+        }
+        __syncthreads();   // the last stage's factors are in the workspace
+        double ss = 0.0;
+        if (go) {
+            nfc += Tab::FSAL ? S - 1 : S;
+            if constexpr (!Tab::FSAL) {
+                double acc = tab->B[0] * K[0];
+                static_for<1, S>([&](auto j) { acc = __builtin_fma(tab->B[decltype(j)::value], K[j], acc); });
+                bcast(__builtin_fma(dt, acc, zo), znew);
+            }
+            double acc = tab->BT[0] * K[0];
+            static_for<1, S>([&](auto j) { acc = __builtin_fma(tab->BT[decltype(j)::value], K[j], acc); });
+            const double a0 = fabs(zo), a1 = fabs(own(znew));
+            double res[NC];
+            bcast((dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
+            static_for<0, NC>([&](auto c) { ss = __builtin_fma(res[c], res[c], ss); });
+        }
+        mu_pass(std::integral_constant<int, 0>{}, go, dt);
+        if (go) {
+            ss += SUM[slot * 8 + 0];
+            const double EEst = __builtin_sqrt(ss / ntot);
+            double q;
+            if (EEst == 0.0) {
+                q = 1.0 / o.qmax;
+            } else {
+                q11 = fastpow(EEst, o.beta1);
+                q = q11 / fastpow(qold, o.beta2);
+                q = q / o.gamma;
+                const double lo = 1.0 / o.qmax, hi = 1.0 / o.qmin;
+                if (q > hi) q = hi;
+                if (q < lo) q = lo;
+            }
+            accept = EEst <= 1.0;
+            if (p.trace && lm == 0 && gid == p.trace_traj && iter <= p.trace_cap) {
+                double* row = p.trace + ((size_t)p.trace_cap + (iter - 1)) * 5;
+                row[0] = t; row[1] = dt; row[2] = EEst; row[3] = q; row[4] = accept ? 1.0 : 0.0;
+            }
+            if (accept) {
+                nacc += 1;
+                qold = EEst > o.qoldinit ? EEst : o.qoldinit;
+                double dtnew = dt / q;
+                const double ttmp = t + dt;
+                {
+                    const double mxt = t > tstop ? t : tstop;
+                    t = fabs(ttmp - tstop) < 100.0 * ulp_of(mxt) ? tstop : ttmp;
+                }
+                if (fabs(dtnew) > dtmax) dtnew = tdir * dtmax;
+                dt = dtnew;
+                bool bad = false;
+                static_for<0, NC>([&](auto c) {
+                    lam[c] = znew[c];
+                    bad = bad || (znew[c] != znew[c]);
+                });
+                { double* tsw = mu_cur; mu_cur = mu_new; mu_new = tsw; }   // slot_accept: the candidate column becomes current
+                if (bad) { ret = RET_UNSTABLE; live = false; }
+                if (t == tstop) {
+                    const bool modified = at_tstop(t);
+                    if (tstop == T0) live = false;   // done
+                    else {
+                        tstop = tstop_from_cur();
+                        if (modified && Tab::FSAL) nfc += 1;   // reset_fsal! after u_modified! (counted as upstream does; this system re-evaluates stage 0 every step anyway)
+                    }
+                }
+            } else {
+                nrej += 1;
+                if (EEst != EEst) { ret = RET_UNSTABLE; live = false; }
+            }
+        }
+    }
+
+    // ---- results ----
+    if (started && lm == 0) {
+        if (p.stats) {
+            int64_t* s = p.stats + (size_t)gid * 8;
+            s[4] = nfc; s[5] = nacc; s[6] = nrej;
+        }
+        if (ret != RET_SUCCESS) p.retcode[gid] = ret;
+    }
+    if (started && p.grad_u0 && lm < NC) p.grad_u0[(size_t)gid * n + lm] = own(lam);
+    // gradient rows: wavefront w for its four slots, lane i = hidden row i; a failed trajectory contributes nothing
+    static_for<0, 4>([&](auto q) {
+        const int64_t g = (int64_t)blockIdx.x * NSLOTS + 4 * w + decltype(q)::value;
+        const bool ok = __builtin_amdgcn_readlane((int)(started && ret == RET_SUCCESS), 16 * decltype(q)::value) != 0;
+        if (g < p.N) {
+            const unsigned long long mc_ = (unsigned long long)mu_cur;
+            const unsigned long long mcq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mc_ >> 32), 16 * decltype(q)::value) << 32) |
+                                           (unsigned)__builtin_amdgcn_readlane((int)mc_, 16 * decltype(q)::value);
+            const double* mfin = (const double*)mcq + l;
+            double* row = p.grad_part + (size_t)g * p.n_param;
+#pragma unroll 2
+            for (int k = 0; k < NSLK; ++k) {
+                int idx;
+                if (k < H) idx = OFF_W2 + l + k * H;
+                else {
+                    const int e = k - H;
+                    idx = e < 3 ? OFF_W1 + l + e * H : e == 3 ? OFF_B1 + l : e == 4 ? OFF_B2 + l : e == 5 ? OFF_W3 + l : (l == 0 ? OFF_B3 : -1);
+                }
+                if (idx >= 0) row[idx] = ok ? mfin[(size_t)k * H] : 0.0;
+            }
+        }
+    });
+}
+
+}  // namespace seirls
+}  // namespace ude

@@ -1,0 +1,19 @@
+// ude_seir_ls.hip -- translation unit of the lock-step matrix-core adjoint of the SEIR exposure UDE (ude_seir_ls.h).
+#include <hip/hip_runtime.h>
+
+#include "ude_seir_ls.h"
+
+using namespace ude;
+
+// kernel entry points for udecore.hip: alg 0 = Tsit5, 1 = Vern7
+extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*), size_t* lds_bytes, size_t* fac_doubles_per_block) {
+    if (alg == 1) {
+        *kern = seirls::seir_ls_adj_kernel<Vern7Tab>;
+        *lds_bytes = sizeof(double) * seirls::lds_doubles<Vern7Tab>() + 16;
+        *fac_doubles_per_block = seirls::fac_doubles_per_block<Vern7Tab>();
+    } else {
+        *kern = seirls::seir_ls_adj_kernel<Tsit5Tab>;
+        *lds_bytes = sizeof(double) * seirls::lds_doubles<Tsit5Tab>() + 16;
+        *fac_doubles_per_block = seirls::fac_doubles_per_block<Tsit5Tab>();
+    }
+}

@@ -212,6 +212,8 @@ void ude_poison_chip_dbg(hipStream_t st, bool before_forward) {  // (what & 4: a
 // compiled model table (instances live in their own translation units, see build.py)
 // ---------------------------------------------------------------------------------------------
 #include "ude_instances_gen.h"
+// lock-step matrix-core adjoint of the SEIR exposure UDE (csrc/ude_seir_ls.hip)
+extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 
 struct InstanceRow {
     int mid, alg, G, W;
@@ -300,6 +302,9 @@ static int generic_id(const ude_model_desc* m) {
     return MID_NONE;
 }
 
+#ifndef UDE_SEIR_LS_DEFAULT
+#define UDE_SEIR_LS_DEFAULT 0   // 1: the lock-step matrix-core backward kernel is the default for the SEIR exposure UDE
+#endif
 static int default_lanes(int mid, bool discrete) {
     switch (mid) {
         case MID_LV_TRUE: return 1;
@@ -338,6 +343,7 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
                                             "outside the runtime-shape fallback (Float64, replicated-state kinds LV / SEIR, <= 8 layers of width <= 64)",
                     m->kind, m->dtype, m->n_layers);
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
+    if (mid == MID_SEIR_UDE && G == 16) G = 64;  // (16 = the lock-step backward kernel of grad_dev_impl; every other kernel of that model: one wavefront per trajectory)
     const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
     bool ok = false;
     // scenario_1's chain with both diagonal coefficients constant has a leaner instance (no slots for them) where compiled
@@ -435,7 +441,7 @@ extern "C" void ude_destroy(ude_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
-    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs, &c->slot_glob, &c->nfail, &c->tspan_pt,
+    DevBuf* bufs[] = {&c->dense, &c->dense_n, &c->cot, &c->loss_traj, &c->grad_part, &c->retcode, &c->stats, &c->trace, &c->tabs, &c->slot_glob, &c->nfail, &c->tspan_pt, &c->ls_fac,
                       &c->s_u0, &c->s_theta, &c->s_saveat, &c->s_out, &c->s_data, &c->s_mask, &c->s_gtheta,
                       &c->s_gu0, &c->s_loss, &c->s_lpt, &c->s_stats, &c->s_ret};
     for (DevBuf* b : bufs)
@@ -641,6 +647,12 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     HIPCHK(c, hipSetDevice(c->device));
     Launch l;
     int G;
+    // SEIR exposure UDE, interpolating adjoint in parity mode, shared time grid: lanes_per_traj = 16 selects the lock-step
+    // matrix-core backward kernel (16 trajectories per block as MFMA columns, csrc/ude_seir_ls.h); the forward kernel is the
+    // wavefront-per-trajectory one either way
+    const int want_lanes = c->lo.lanes_per_traj;
+    const bool seir_ls = model_id(m) == MID_SEIR_UDE && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT && o->per_trajectory == 0 &&
+                         (want_lanes == 16 || (want_lanes == 0 && UDE_SEIR_LS_DEFAULT));
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
@@ -652,7 +664,13 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const int BLOCK = l.block;
     const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
-    const int64_t nwaves = (int64_t)grid * ((BLOCK >= 64 && G <= 64) ? BLOCK / 64 : 1);  // rows of the partial-gradient matrix
+    int64_t nwaves = (int64_t)grid * ((BLOCK >= 64 && G <= 64) ? BLOCK / 64 : 1);  // rows of the partial-gradient matrix
+    void (*ls_kern)(const KParams, double*) = nullptr;
+    size_t ls_lds = 0, ls_fac = 0;
+    if (seir_ls) {
+        ude_seir_ls_get(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &ls_fac);
+        if (nwaves < N) nwaves = N;   // one gradient row per trajectory
+    }
     const int nf = 3 + n + l.nf * n;
     p.N = N;
     p.Npad = (N + 7) / 8 * 8;
@@ -671,7 +689,12 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = ensure(c, c->loss_traj, es * N))) return rc;
     if ((rc = ensure(c, c->grad_part, es * (size_t)nwaves * np))) return rc;
     p.slot_glob = nullptr;
-    if (l.slot_glob > 0) {  // slot state mu of the adjoint in HBM: [slot][thread]
+    if (seir_ls) {  // mu of every trajectory: two columns of 71 slots x 64 hidden rows; the stage factors of every block of 16 slots
+        const int64_t nblk = (N + 15) / 16;
+        if ((rc = ensure(c, c->slot_glob, sizeof(double) * (size_t)N * 2 * 71 * 64))) return rc;
+        if ((rc = ensure(c, c->ls_fac, sizeof(double) * (size_t)nblk * ls_fac))) return rc;
+        p.slot_glob = (double*)c->slot_glob.p;
+    } else if (l.slot_glob > 0) {  // slot state mu of the adjoint in HBM: [slot][thread]
         if ((rc = ensure(c, c->slot_glob, es * (size_t)l.slot_glob * grid * BLOCK))) return rc;
         p.slot_glob = (double*)c->slot_glob.p;
     }
@@ -730,6 +753,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     }
     ude_poison_chip(c->stream, false);
+    if (seir_ls) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)ls_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls_lds));
+        hipLaunchKernelGGL(ls_kern, dim3((unsigned)((N + 15) / 16)), dim3(256), ls_lds, c->stream, p, (double*)c->ls_fac.p);
+    } else
     hipLaunchKernelGGL(bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
     HIPCHK(c, hipGetLastError());
     if (!cap_graph) {
