@@ -6,7 +6,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # UDE_LIB_VARIANT=dbg selects the debug build (libudecore_dbg.so: same kernels, host side compiled with -DUDE_DEBUG_HOOKS --
 # register poison, workspace fill, phase clocks; tests/test_gpu_poison.py runs the parity tests against it in a subprocess)
-LIB_PATH = os.path.join(HERE, "libudecore_dbg.so" if os.environ.get("UDE_LIB_VARIANT") == "dbg" else "libudecore.so")
+# (any other value <name>: libudecore_<name>.so, a developer's timing-experiment build -- build.py: UDE_EXP_VARIANTS)
+_variant = os.environ.get("UDE_LIB_VARIANT", "")
+LIB_PATH = os.path.join(HERE, "libudecore_%s.so" % _variant if _variant else "libudecore.so")
 MAX_LAYERS = 8
 NSTATS = 8
 

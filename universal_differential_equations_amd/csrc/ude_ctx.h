@@ -23,6 +23,7 @@ struct ude_ctx {
     // workspaces (grow on demand, reused across calls)
     DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs, slot_glob, nfail, tspan_pt, ls_fac;
     hipEvent_t ev_sync = nullptr;  // orders work across a change of the bound stream
+    int ncu = 0;         // compute units of the device (queried once)
     int auto_cap = 256;  // dense-store capacity used when lo.max_dense_steps == 0; grows x4 on DenseOverflow (host-buffer path)
     int64_t trace_traj = -1;
     int32_t trace_cap = 0;

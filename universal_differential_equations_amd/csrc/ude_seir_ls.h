@@ -44,10 +44,12 @@ constexpr int popc(unsigned m) { int c = 0; for (; m; m &= m - 1) ++c; return c;
 template <unsigned MASK>
 constexpr int cslot(int s) { return popc(MASK & ((1u << s) - 1u)); }   // compacted storage slot of stage s
 
+constexpr int TABL = 16 * 16 + 3 * 16;   // LDS copy of the tableau: A[16][16], B[16], BT[16], C[16]
 template <class Tab>
 constexpr int lds_doubles() {
     constexpr int NSTC = popc(stage_mask<Tab>());
-    return 4 * H * TLD + 4 * 16 + 16 + 3 * NSLOTS * PLD + NSTC * NSLOTS * 4 + NSLOTS * 16 + NSLOTS * 8 + NSLOTS * 8 + 4 * NSTC * H;
+    return 4 * H * TLD + 4 * 16 + 16 + 3 * NSLOTS * PLD + NSTC * NSLOTS * 4 + NSLOTS * 16 + NSLOTS * 8 + TABL + 6 * NSLOTS + NSLOTS * 4 * 2 +
+           4 * NSTC * H + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16;
 }
 // doubles of factor workspace per block
 template <class Tab>
@@ -63,26 +65,32 @@ __device__ __forceinline__ double row_tree4(double v0, double v1, double v2, dou
     return x;
 }
 
-// one pass over the 71 parameter slots of ONE trajectory by a whole wavefront (lane i = hidden row i): SeirUde<64>'s loops.
+// one pass over the 71 parameter slots of ONE trajectory by a whole wavefront (lane i = hidden row i): the loops of
+// SeirUde<64>::step_slots / init_norm01 / init_norm2.
 //   MODE 0: end of a step -- candidate mu_new, returns this lane's sum of squared residuals
-//   MODE 1 / 2: the initial-dt norms (h, l) += (g0 / sk)^2  /  ((g1 - g0) / sk)^2 in real-real arithmetic
+//   MODE 1 / 2: the initial-dt norms (h, l) += (g0 / sk)^2  /  ((g1 - g0) / sk)^2 in real-real arithmetic (mu == 0 there)
 template <int NST, unsigned MASK, int MODE>
 __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* this trajectory's factors: [cs][field][64] */,
                                             double* a1s /* LDS staging [cs][64] of this wavefront */, const double* xf /* LDS [cs][16][4] */,
                                             int slot, int lane, const double* Bw, const double* BTw, double dt, double abstol, double reltol,
-                                            const double* mu, double* mu_new, double& hh, double& ll) {
-    double a2[NST], d1[NST], d2[NST], xs[NST][4];
+                                            const double* __restrict__ mu, double* __restrict__ mu_new, double& hh, double& ll) {
+    constexpr int CH = 8;
+    double mcur[CH], mnext[CH], mnext2[CH];   // two chunks of mu in flight behind the one being processed (HBM latency > one chunk's arithmetic)
+    static_for<0, CH>([&](auto i) {
+        mcur[i] = MODE == 0 ? mu[(size_t)decltype(i)::value * H] : 0.0;
+        mnext[i] = MODE == 0 ? mu[(size_t)(CH + decltype(i)::value) * H] : 0.0;
+    });
+    double a2[NST], d1[NST], d2[NST];
     static_for<0, NST>([&](auto s) {
         if constexpr ((MASK >> decltype(s)::value) & 1u) {
             constexpr int cs = cslot<MASK>(decltype(s)::value);
             const double* f = fbase + (size_t)cs * 4 * H + lane;
             a1s[cs * H + lane] = f[0];
             a2[s] = f[H]; d1[s] = f[2 * H]; d2[s] = f[3 * H];
-            static_for<0, 4>([&](auto q) { xs[s][q] = xf[(cs * NSLOTS + slot) * 4 + decltype(q)::value]; });
         }
     });
     double bb[NST], bt[NST];
-    if constexpr (MODE == 0) static_for<0, NST>([&](auto s) { bb[s] = uniform_real(Bw[s]); bt[s] = uniform_real(BTw[s]); });
+    if constexpr (MODE == 0) static_for<0, NST>([&](auto s) { bb[s] = Bw[decltype(s)::value]; bt[s] = BTw[decltype(s)::value]; });
     double ps = 0.0;
     auto body = [&](int sl, const double* g, double m0) {
         if constexpr (MODE == 0) {
@@ -104,14 +112,11 @@ __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* 
             dd_acc(hh, ll, q * q);
         }
     };
-    constexpr int CH = 8;
-    double mcur[CH], mnext[CH];
-    static_for<0, CH>([&](auto i) { mcur[i] = mu[(size_t)decltype(i)::value * H]; });
 #pragma unroll 1
     for (int k0 = 0; k0 < H; k0 += CH) {
-        static_for<0, CH>([&](auto i) {
-            const int sl = k0 + CH + decltype(i)::value;
-            mnext[i] = sl < NSLK ? mu[(size_t)sl * H] : 0.0;
+        static_for<0, CH>([&](auto i) {   // (the last chunk requested: the 7 extra slots)
+            const int sl = k0 + 2 * CH + decltype(i)::value;
+            mnext2[i] = (MODE == 0 && sl < NSLK) ? mu[(size_t)sl * H] : 0.0;
         });
         static_for<0, CH>([&](auto i) {
             const int k = k0 + decltype(i)::value;
@@ -121,19 +126,20 @@ __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* 
             });
             body(k, g, mcur[i]);
         });
-        static_for<0, CH>([&](auto i) { mcur[i] = mnext[i]; });
+        static_for<0, CH>([&](auto i) { mcur[i] = mnext[i]; mnext[i] = mnext2[i]; });
     }
     static_for<0, 7>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         double g[NST];
         static_for<0, NST>([&](auto s) {
             if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                const double* xs = xf + (cslot<MASK>(decltype(s)::value) * NSLOTS + slot) * 4;   // x0 x1 x2 delta3 of this stage
                 double v;
-                if constexpr (e < 3) v = -(d1[s] * xs[s][e]);
+                if constexpr (e < 3) v = -(d1[s] * xs[e]);
                 else if constexpr (e == 3) v = -d1[s];
                 else if constexpr (e == 4) v = -d2[s];
-                else if constexpr (e == 5) v = -(xs[s][3] * a2[s]);
-                else v = lane == 0 ? -xs[s][3] : -0.0;
+                else if constexpr (e == 5) v = -(xs[3] * a2[s]);
+                else v = lane == 0 ? -xs[3] : -0.0;
                 g[s] = v;
             }
         });
@@ -142,8 +148,16 @@ __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* 
     return ps;
 }
 
+enum { PH_IDLE = -4, PH_FLUSH = -3, PH_INIT0 = -2, PH_INIT1 = -1 };   // >= 0: stage s of a step attempt
+enum { RQ_NONE = -1, RQ_STEP = 0, RQ_NORM01 = 1, RQ_NORM2 = 2, RQ_FLUSH = 4 };
+
+// PERSISTENT blocks: every slot runs the Driver's sequence as its own little state machine (initial-dt evaluations, the stages
+// of a step attempt, the end of the step); one trip of the block's loop = ONE adjoint evaluation of every busy slot, whatever
+// stage each of them is at, followed by the parameter-slot work the slots asked for.  A slot whose trajectory has ended writes
+// its gradient row and takes the next trajectory of the ensemble from a global queue: no second, half-empty round of blocks,
+// no slot idling until the slowest trajectory of its block is through.
 template <class Tab>
-__global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p, double* __restrict__ facws) {
+__global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p, double* __restrict__ facws, int* __restrict__ queue) {
     constexpr int S = Tab::S, NK = Tab::NK;
     constexpr unsigned MASK = stage_mask<Tab>();
     constexpr int NSTC = popc(MASK);
@@ -158,14 +172,25 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     double* XF = PG + 3 * NSLOTS * PLD;       // [NSTC][16][4]
     double* BQ = XF + NSTC * NSLOTS * 4;      // [16][16]
     double* YS = BQ + NSLOTS * 16;            // [16][8]
-    double* SUM = YS + NSLOTS * 8;            // [16][8]
-    double* A1S = SUM + NSLOTS * 8;           // [4][NSTC][64]
+    double* TB = YS + NSLOTS * 8;             // tableau: A[16][16], B, BT, C
+    double* RDT = TB + TABL;                  // [16] step size of a step request
+    long long* RG = reinterpret_cast<long long*>(RDT + NSLOTS);    // [16] trajectory of the slot
+    int* REQI = reinterpret_cast<int*>(RG + NSLOTS);               // [16] request, [16] zero-mu flag, [16] current mu column, [16] success, [16] cs of this trip
+    int* REQZ = REQI + NSLOTS;
+    int* RCOL = REQZ + NSLOTS;
+    int* ROK = RCOL + NSLOTS;
+    int* RCS = ROK + NSLOTS;
+    int* REV = RCS + NSLOTS;
+    double* SUMW = RDT + 6 * NSLOTS;          // [16][4][2] per slot and wavefront: ps | (h, l)
+    double* A1S = SUMW + NSLOTS * 4 * 2;      // [4][NSTC][64]
+    double* KSL = A1S + 4 * NSTC * H;         // [16 slots][NK + 2][8]: interval cache (u_start, k_q) and f0 of the initial-dt phase, component c at [..][c]
+    double* RQL = KSL + NSLOTS * 8 * (NK + 2); // [16 lanes q][8]: Horner tables of b_q(theta)
+    double* ZK = RQL + 16 * 8;                // [16 slots][16]: znew[7] | kr[7] parked across the parameter-slot work of a trip
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int kq = l >> 4, jc = l & 15;       // matrix view: k index / column (= slot) of this lane
     const int rr = l >> 4, lm = l & 15;       // scalar view: row of the wavefront (slot 4w + rr), lane inside the row
     const int slot = 4 * w + rr;
-    const int64_t gid = (int64_t)blockIdx.x * NSLOTS + slot;
     const double* __restrict__ th = p.theta;
     const TabDev* __restrict__ tab = p.tab;
     const int n = NC;
@@ -192,47 +217,49 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     const double Fc = p.mc.consts[0], b0c = p.mc.consts[1], muc = p.mc.consts[4], sgc = p.mc.consts[5], gac = p.mc.consts[6],
                  dc = p.mc.consts[7], lac = p.mc.consts[8];
     if (tid < 16) XIN[3 * 16 + tid] = 1.0;
-    for (int i = tid; i < NSLOTS * 8; i += BLOCKT) { SUM[i] = 0.0; YS[i] = 0.0; }
+    for (int i = tid; i < 16 * 16; i += BLOCKT) TB[i] = tab->A[i >> 4][i & 15];
+    if (tid < 16) { TB[256 + tid] = tab->B[tid]; TB[272 + tid] = tab->BT[tid]; TB[288 + tid] = tab->C[tid]; }
+    for (int i = tid; i < NSLOTS * 8; i += BLOCKT) { YS[i] = 0.0; SUMW[i] = 0.0; }
 
-    // ---- per-slot scalar state (replicated in the 16 lanes of the slot's row; component c on lane c) ----
+    // ---- per-slot state (replicated in the 16 lanes of the slot's row; component c on lane c) ----
     const OptsR o(p.o);
     const double T0 = p.t0, TF = p.tf, tdir = -1.0;
     const double dtmax = o.dtmax;
     const double ntot = (double)(p.n_state + p.n_param);
-    const bool in_range = gid < p.N;
-    bool live = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
-    const bool started = live;
-    int ret = RET_SUCCESS;
-    double lam[NC], K[S], us = 0.0, ks[NK], ts = 0.0, te = 0.0;
+    const bool user_dt = o.dt0 > 0.0;
+    int ph = PH_IDLE, ret = RET_SUCCESS, col = 0, iter = 0, sf = 0, cur = 0, nsteps = 1;
+    long long gid = 0;
+    bool accept = true, exhausted = false, zero_req = false;
+    double t = TF, dt = 0.0, dt0 = 0.0, d1n = 0.0, qold = o.qoldinit, q11 = 1.0, tstop = T0, ssrep = 0.0;
+    long long nfc = 0, nacc = 0, nrej = 0;
+    double lam[NC], K[S], ts = 0.0, te = 0.0;
     static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
     static_for<0, S>([&](auto s) { K[s] = 0.0; });
-    static_for<0, NK>([&](auto q) { ks[q] = 0.0; });
-    int sf = 0, cur = p.ns - 1, nsteps = live ? p.dense_n[gid] : 1;
-    double rq[7];
-    {
-        const int q = lm < NK ? lm : 0;
-        static_for<0, 7>([&](auto i) { rq[i] = tab->R[q][i]; });
-    }
-    const double* cot;
-    size_t cot_si, cot_sc;
-    const int64_t gsafe = in_range ? gid : 0;
-    if (p.cot_in) { cot = p.cot_in + (size_t)gsafe * p.ns * n; cot_si = n; cot_sc = 1; }
-    else { cot = p.cot + gsafe; cot_si = (size_t)n * p.Npad; cot_sc = p.Npad; }
-    double* mu_cur = p.slot_glob + (size_t)gsafe * (2 * NSLK * H);
-    double* mu_new = mu_cur + NSLK * H;
-    double* fmine = facws + (size_t)blockIdx.x * fac_doubles_per_block<Tab>();   // this block's factor workspace
+    for (int i = tid; i < 16 * 8; i += BLOCKT) RQL[i] = ((i >> 3) < NK && (i & 7) < 7) ? tab->R[i >> 3][i & 7] : 0.0;
+    double* const ksl = KSL + slot * 8 * (NK + 2) + (lm < 8 ? lm : 7);   // this lane's component column of the slot's cache (lanes >= 7: the spare column)
+    double* const f0l = KSL + slot * 8 * (NK + 2) + (NK + 1) * 8;       // f0[c] at f0l[c]
+    const double* cot = p.cot;
+    size_t cot_si = 0, cot_sc = 0;
+    double* const fmine = facws + (size_t)blockIdx.x * fac_doubles_per_block<Tab>();   // this block's factor workspace
 
     auto load_interval = [&](int s) {
         sf = s;
-        const double* base = p.dense + ((size_t)s * nfld) * p.Npad + gsafe;
+        const double* base = p.dense + ((size_t)s * nfld) * p.Npad + gid;
         ts = base[0];
         te = base[(size_t)1 * p.Npad];
         const bool on = lm < n;
         const int rc = on ? lm : 0;
-        us = on ? base[(size_t)(3 + rc) * p.Npad] : 0.0;
+        // (all loads first, then the LDS stores: one round trip)
+        double usv = base[(size_t)(3 + rc) * p.Npad], kv[NK];
         static_for<0, NK>([&](auto q) {
-            if constexpr (Tab::dense_uses(decltype(q)::value)) ks[q] = on ? base[(size_t)(3 + n + (int)decltype(q)::value * n + rc) * p.Npad] : 0.0;
+            if constexpr (Tab::dense_uses(decltype(q)::value)) kv[q] = base[(size_t)(3 + n + (int)decltype(q)::value * n + rc) * p.Npad];
         });
+        if (on) {
+            ksl[0] = usv;
+            static_for<0, NK>([&](auto q) {
+                if constexpr (Tab::dense_uses(decltype(q)::value)) ksl[(1 + (int)decltype(q)::value) * 8] = kv[q];
+            });
+        }
     };
     auto own = [&](const double (&v)[NC]) {
         double r = 0.0;
@@ -242,10 +269,10 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     auto bcast = [&](double ownv, double (&out)[NC]) { static_for<0, NC>([&](auto c) { out[c] = rshfl(ownv, decltype(c)::value); }); };
     auto SV = [&](int i) { return p.saveat[i]; };
     auto tstop_from_cur = [&]() { return (cur >= 0 && SV(cur) > T0) ? SV(cur) : T0; };
-    auto at_tstop = [&](double t) {
+    auto at_tstop = [&](double tt) {
         bool mod = false;
-        while (cur >= 0 && SV(cur) >= t) {
-            if (SV(cur) == t) {
+        while (cur >= 0 && SV(cur) >= tt) {
+            if (SV(cur) == tt) {
                 static_for<0, NC>([&](auto c) { lam[c] += cot[(size_t)cur * cot_si + (size_t)decltype(c)::value * cot_sc]; });
                 mod = true;
             }
@@ -253,47 +280,128 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
         }
         return mod;
     };
-    // zero this trajectory's mu (current column) -- every wavefront for its own four slots, lane i = hidden row i
-    for (int q = 0; q < 4; ++q) {
-        const int64_t g = (int64_t)blockIdx.x * NSLOTS + 4 * w + q;
-        if (g < p.N) {
-            double* m0 = p.slot_glob + (size_t)g * (2 * NSLK * H) + l;
-#pragma unroll 4
-            for (int k = 0; k < NSLK; ++k) m0[(size_t)k * H] = 0.0;
-        }
-    }
-    if (live) {
-        load_interval(nsteps - 1);
-        at_tstop(TF);   // init_cb: the jump at t = tf precedes the first step
-    }
     __syncthreads();
+#if defined(LS_EXP) && LS_EXP == 9
+    unsigned long long tk = __builtin_readcyclecounter(), tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntrip = 0;
+#define LS_TICK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tsec[i] += now_ - tk; tk = now_; }
+#else
+#define LS_TICK(i)
+#endif
 
-    // ---- one adjoint evaluation of all 16 slots: lambda' = -(df/du)^T lambda at y(te) into kl[]; the stage's factors go to
-    // compacted slot `cs` of the workspace.  `ev` = this slot takes part (its inputs are valid) ----
-    auto eval_all = [&](bool ev, double tev, const double (&zs)[NC], int cs, double (&kl)[NC]) {
+    for (;;) {
+        // ---- A. an idle slot takes the next trajectory of the ensemble ----
+        if (ph == PH_IDLE && !exhausted) {
+            for (;;) {
+                int g = 0;
+                if (lm == 0) g = atomicAdd(queue, 1);
+                g = __shfl(g, 0, 16);
+                if (g >= p.N) { exhausted = true; break; }
+                if (p.retcode[g] != RET_SUCCESS) continue;   // (its forward solve failed: no gradient row, the host-cleared zeros stay)
+                gid = g;
+                if (p.cot_in) { cot = p.cot_in + (size_t)gid * p.ns * n; cot_si = n; cot_sc = 1; }
+                else { cot = p.cot + gid; cot_si = (size_t)n * p.Npad; cot_sc = p.Npad; }
+                nsteps = p.dense_n[gid];
+                cur = p.ns - 1;
+                static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
+                t = TF; qold = o.qoldinit; q11 = 1.0; accept = true; iter = 0; ret = RET_SUCCESS; col = 0;
+                nfc = 0; nacc = 0; nrej = 0;
+                load_interval(nsteps - 1);
+                at_tstop(TF);   // init_cb: the jump at t = tf precedes the first step
+                tstop = tstop_from_cur();
+                zero_req = true;
+                if (user_dt) {
+                    dt = tdir * o.dt0;
+                    if constexpr (Tab::FSAL) nfc += 1;
+                    ph = 0;
+                } else ph = PH_INIT0;
+                break;
+            }
+        }
+        LS_TICK(0)
+
+        // ---- B. the evaluation this slot needs now ----
+        bool ev = false;
+        double tev = t, zs[NC], kr[NC], znew[NC];
+        int cs = 0;
+        static_for<0, NC>([&](auto c) { zs[c] = lam[c]; kr[c] = 0.0; znew[c] = lam[c]; });
+        const double zo = own(lam);
+        if (ph == PH_INIT0) {
+            ev = true;
+        } else if (ph == PH_INIT1) {
+            ev = true;
+            const double dt0t = tdir * dt0;
+            static_for<0, NC>([&](auto c) { zs[c] = __builtin_fma(dt0t, f0l[decltype(c)::value], lam[c]); });
+            tev = t + dt0t;
+            cs = 1;
+        } else if (ph >= 0) {
+            const int s = ph;
+            bool go = true;
+            if (s == 0) {   // loopheader!
+                if (iter > 0 && !accept) {
+                    double den = q11 / o.gamma;
+                    const double iq = 1.0 / o.qmin;
+                    if (iq < den) den = iq;
+                    dt = dt / den;
+                }
+                iter += 1;
+                if (fabs(dt) > dtmax) dt = tdir * dtmax;
+                {
+                    const double rem = fabs(tstop - t);
+                    if (fabs(dt) > rem) dt = tdir * rem;
+                }
+                if (iter > o.maxiters) { ret = RET_MAXITERS; go = false; }
+                else if (dt != dt) { ret = RET_UNSTABLE; go = false; }
+                else if (fabs(dt) <= REAL_EPS * fabs(t) && fabs(dt) < fabs(tstop - t)) { ret = RET_DTLESSTHANMIN; go = false; }
+            }
+            if (go) {
+                ev = true;
+                if (s > 0) {
+                    // all S - 1 possible terms: the coefficients of stages >= s are zero in the table, fma(0, K, acc) == acc exactly
+                    const double* Ar = TB + s * 16;
+                    double acc = Ar[0] * K[0];
+                    static_for<1, S - 1>([&](auto j) { acc = __builtin_fma(Ar[decltype(j)::value], K[j], acc); });
+                    bcast(__builtin_fma(dt, acc, zo), zs);
+                }
+                tev = t + TB[288 + s] * dt;
+                cs = __builtin_popcount(MASK & ((1u << s) - 1u));
+            } else {
+                ph = PH_FLUSH;   // ended with an error: results now, the (zero) gradient row in the next trip
+                if (lm == 0) {
+                    if (p.stats) { int64_t* st = p.stats + (size_t)gid * 8; st[4] = nfc; st[5] = nacc; st[6] = nrej; }
+                    p.retcode[gid] = ret;
+                }
+                if (p.grad_u0 && lm < NC) p.grad_u0[(size_t)gid * n + lm] = zo;
+            }
+        }
+        if (lm == 0) { RCS[slot] = cs; REV[slot] = ev ? 1 : 0; }
+
+        LS_TICK(1)
+        // ---- C. one adjoint evaluation of all 16 slots ----
         double y[NC];
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0, d3 = 0.0;
+        static_for<0, NC>([&](auto c) { y[c] = 1.0; });
         if (ev) {
             while (tev < ts && sf > 0) load_interval(sf - 1);
             while (tev >= te && sf < nsteps - 1) load_interval(sf + 1);
             const double dtf = te - ts;
             const double thv = (tev - ts) / dtf;
+            const double* rq = RQL + lm * 8;
             double hq = rq[0];
-            static_for<1, 7>([&](auto i) { hq = __builtin_fma(thv, hq, rq[i]); });
+            static_for<1, 7>([&](auto i) { hq = __builtin_fma(thv, hq, rq[decltype(i)::value]); });
             BQ[slot * 16 + lm] = (lm == 0 ? thv : thv * thv) * hq;
             double acc = 0.0;
             bool first = true;
             static_for<0, NK>([&](auto q) {
                 if constexpr (Tab::dense_uses(decltype(q)::value)) {
                     const double bqv = BQ[slot * 16 + decltype(q)::value];
-                    acc = first ? ks[q] * bqv : __builtin_fma(ks[q], bqv, acc);
+                    const double kq_ = ksl[(1 + (int)decltype(q)::value) * 8];
+                    acc = first ? kq_ * bqv : __builtin_fma(kq_, bqv, acc);
                     first = false;
                 }
             });
-            if (lm < NC) YS[slot * 8 + lm] = __builtin_fma(dtf, acc, us);
+            if (lm < NC) YS[slot * 8 + lm] = __builtin_fma(dtf, acc, ksl[0]);
             static_for<0, NC>([&](auto c) { y[c] = YS[slot * 8 + decltype(c)::value]; });
-            x0 = y[0] / y[4]; x1 = y[2]; x2 = y[5] / y[4];
-            d3 = (zs[1] - zs[0]) * 1.0;
+            const double x0 = y[0] / y[4], x1 = y[2], x2 = y[5] / y[4];
+            const double d3 = (zs[1] - zs[0]) * 1.0;
             if (lm == 0) {
                 XIN[0 * 16 + slot] = x0; XIN[1 * 16 + slot] = x1; XIN[2 * 16 + slot] = x2;
                 D3S[slot] = d3;
@@ -301,70 +409,78 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
                 xf[0] = x0; xf[1] = x1; xf[2] = x2; xf[3] = d3;
             }
         }
-        __syncthreads();
-        // ---- layer 1 (3 inputs + bias in one k-step) ----
-        v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(W1A, XIN[kq * 16 + jc], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-        double a1[4], a2[4], dv1[4], dv2[4];
-        static_for<0, 4>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            a1[r] = dtanh(z[r]);
-            T_A1[(16 * w + kq + 4 * r) * TLD + jc] = a1[r];
-        });
-        __syncthreads();
-        // ---- hidden layer: four 16-term chains (four MFMAs each) added left to right ----
+        if (!__syncthreads_or(ph != PH_IDLE)) break;   // (the barrier in front of the matrix products; all slots idle and the queue empty: done)
+        LS_TICK(2)
         {
-            v4d acc[4];
-            static_for<0, 4>([&](auto bc) {
-                constexpr int b = decltype(bc)::value;
-                acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
-                static_for<0, 4>([&](auto q) {
-                    constexpr int s = 4 * b + decltype(q)::value;
-                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
-                });
-            });
-            const double d3j = D3S[jc];
+            // layer 1 (3 inputs + bias in one k-step)
+            v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(W1A, XIN[kq * 16 + jc], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            double a1[4], a2[4], dv1[4], dv2[4];
             static_for<0, 4>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + b2r[r];
-                a2[r] = dtanh(z2);
-                dv2[r] = __builtin_fma(w3r[r], d3j, 0.0) * __builtin_fma(-a2[r], a2[r], 1.0);
-                const int row = 16 * w + kq + 4 * r;
-                T_D2[row * TLD + jc] = dv2[r];
-                T_A2[row * TLD + jc] = a2[r];
+                a1[r] = dtanh(z[r]);
+                T_A1[(16 * w + kq + 4 * r) * TLD + jc] = a1[r];
             });
-        }
-        __syncthreads();
-        // ---- transposed hidden layer on the deltas ----
-        {
-            v4d acc[4];
-            static_for<0, 4>([&](auto bc) {
-                constexpr int b = decltype(bc)::value;
-                acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
-                static_for<0, 4>([&](auto q) {
-                    constexpr int s = 4 * b + decltype(q)::value;
-                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+            __syncthreads();
+            // hidden layer: four 16-term chains (four MFMAs each) added left to right
+            {
+                v4d acc[4];
+                static_for<0, 4>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, 4>([&](auto q) {
+                        constexpr int s = 4 * b + decltype(q)::value;
+                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                    });
                 });
-            });
-            static_for<0, 4>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const double s1 = ((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r];
-                dv1[r] = s1 * __builtin_fma(-a1[r], a1[r], 1.0);
-                const int row = 16 * w + kq + 4 * r;
-                T_D1[row * TLD + jc] = dv1[r];
-                static_for<0, 3>([&](auto mm) { PG[(decltype(mm)::value * NSLOTS + jc) * PLD + row] = w1r[mm][r] * dv1[r]; });
-            });
+                const double d3j = D3S[jc];
+                static_for<0, 4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + b2r[r];
+                    a2[r] = dtanh(z2);
+                    dv2[r] = __builtin_fma(w3r[r], d3j, 0.0) * __builtin_fma(-a2[r], a2[r], 1.0);
+                    const int row = 16 * w + kq + 4 * r;
+                    T_D2[row * TLD + jc] = dv2[r];
+                    T_A2[row * TLD + jc] = a2[r];
+                });
+            }
+            __syncthreads();
+            // transposed hidden layer on the deltas
+            {
+                v4d acc[4];
+                static_for<0, 4>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, 4>([&](auto q) {
+                        constexpr int s = 4 * b + decltype(q)::value;
+                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                    });
+                });
+                static_for<0, 4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const double s1 = ((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r];
+                    dv1[r] = s1 * __builtin_fma(-a1[r], a1[r], 1.0);
+                    const int row = 16 * w + kq + 4 * r;
+                    T_D1[row * TLD + jc] = dv1[r];
+                    static_for<0, 3>([&](auto mm) { PG[(decltype(mm)::value * NSLOTS + jc) * PLD + row] = w1r[mm][r] * dv1[r]; });
+                });
+            }
         }
         __syncthreads();
-        // ---- factors of this stage to the workspace, slot-major: wavefront w copies its own four slots (lane i = hidden row i) ----
-        static_for<0, 4>([&](auto q) {
-            const int sl = 4 * w + decltype(q)::value;
-            double* dst = fmine + ((size_t)sl * NSTC + cs) * 4 * H + l;
-            dst[0] = T_A1[l * TLD + sl];
-            dst[H] = T_A2[l * TLD + sl];
-            dst[2 * H] = T_D1[l * TLD + sl];
-            dst[3 * H] = T_D2[l * TLD + sl];
-        });
-        // ---- the slot's row: input cotangent (adjacent-pair trees over the 64 rounded products) and the state cotangent ----
+        LS_TICK(3)
+        // factors of this evaluation to the workspace, slot-major: wavefront w copies its own four slots (lane i = hidden row i)
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            const int sl = 4 * w + q;
+            if (REV[sl]) {
+                double* dst = fmine + ((size_t)sl * NSTC + RCS[sl]) * 4 * H + l;
+                dst[0] = T_A1[l * TLD + sl];
+                dst[H] = T_A2[l * TLD + sl];
+                dst[2 * H] = T_D1[l * TLD + sl];
+                dst[3 * H] = T_D2[l * TLD + sl];
+            }
+        }
+        // ---- D. the slot's row: state cotangent of this evaluation, and what it asks of the parameter-slot pass ----
+        int req = RQ_NONE;
         if (ev) {
             double gx[3];
             static_for<0, 3>([&](auto mm) {
@@ -382,102 +498,139 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
             dl[4] = cN * zs[0] - cN * zs[1] - muc * zs[4] - gx[0] * Sv / (Nv * Nv) - gx[2] * Dv / (Nv * Nv);
             dl[5] = -lac * zs[5] + gx[2] / Nv;
             dl[6] = 0.0;
-            static_for<0, NC>([&](auto c) { kl[c] = -dl[c]; });
-        }
-        // (the next evaluation's first barrier separates these reads from the next writes of XIN / D3S; the tiles and PG are
-        //  rewritten only after further barriers)
-    };
-
-    // ---- a pass over the parameter slots of this wavefront's four trajectories (lane i = hidden row i) ----
-    auto mu_pass = [&](auto modec, bool take, double dtv) {
-        constexpr int MODE = decltype(modec)::value;
-        static_for<0, 4>([&](auto q) {
-            const int sl = 4 * w + decltype(q)::value;
-            const bool on = __builtin_amdgcn_readlane((int)take, 16 * decltype(q)::value) != 0;   // (wave-uniform: the row's flag)
-            if (on) {
-                const int64_t g = (int64_t)blockIdx.x * NSLOTS + sl;
-                const double dts = readlane_real(dtv, 16 * decltype(q)::value);
-                // which of the two mu columns is current is the row's state: column pointers as 64-bit values of lane 16q
-                const unsigned long long mc_ = (unsigned long long)mu_cur, mn_ = (unsigned long long)mu_new;
-                const unsigned long long mcq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mc_ >> 32), 16 * decltype(q)::value) << 32) |
-                                               (unsigned)__builtin_amdgcn_readlane((int)mc_, 16 * decltype(q)::value);
-                const unsigned long long mnq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mn_ >> 32), 16 * decltype(q)::value) << 32) |
-                                               (unsigned)__builtin_amdgcn_readlane((int)mn_, 16 * decltype(q)::value);
-                const double* mcur = (const double*)mcq + l;
-                double* mnew = (double*)mnq + l;
-                const double* fb = fmine + (size_t)sl * NSTC * 4 * H;
-                double hh = 0.0, ll = 0.0;
-                (void)g;
-                if constexpr (MODE == 0) {
-                    const double ps = slot_pass<S, MASK, 0>(fb, A1S + w * NSTC * H, XF, sl, l, tab->B, tab->BT, dts, o.abstol, o.reltol, mcur, mnew, hh, ll);
-                    const double tot = group_sum<64>(ps);
-                    if (l == 0) SUM[sl * 8 + 0] = tot;
-                } else if constexpr (MODE == 1) {
-                    slot_pass<1, 1u, 1>(fb, A1S + w * NSTC * H, XF, sl, l, tab->B, tab->BT, dts, o.abstol, o.reltol, mcur, mnew, hh, ll);
-                    group_dd_sum<64>(hh, ll);
-                    if (l == 0) { SUM[sl * 8 + 1] = hh; SUM[sl * 8 + 2] = ll; }
-                } else {
-                    slot_pass<2, 3u, 2>(fb, A1S + w * NSTC * H, XF, sl, l, tab->B, tab->BT, dts, o.abstol, o.reltol, mcur, mnew, hh, ll);
-                    group_dd_sum<64>(hh, ll);
-                    if (l == 0) { SUM[sl * 8 + 3] = hh; SUM[sl * 8 + 4] = ll; }
+            static_for<0, NC>([&](auto c) { kr[c] = -dl[c]; });
+            if (ph == PH_INIT0) {
+                if (lm == 0) static_for<0, NC>([&](auto c) { f0l[decltype(c)::value] = kr[c]; });
+                K[0] = own(kr);
+                req = RQ_NORM01;
+            } else if (ph == PH_INIT1) {
+                req = RQ_NORM2;
+            } else {
+                const int s = ph;
+                const double ko = own(kr);
+                static_for<0, S>([&](auto j) { K[j] = ((int)decltype(j)::value == s) ? ko : K[j]; });
+                if (s == S - 1) {
+                    // perform_step! is complete: new state and the replicated part of the error norm
+                    if constexpr (Tab::FSAL) static_for<0, NC>([&](auto c) { znew[c] = zs[c]; });
+                    else {
+                        double acc = TB[256] * K[0];
+                        static_for<1, S>([&](auto j) { acc = __builtin_fma(TB[256 + decltype(j)::value], K[j], acc); });
+                        bcast(__builtin_fma(dt, acc, zo), znew);
+                    }
+                    double acc = TB[272] * K[0];
+                    static_for<1, S>([&](auto j) { acc = __builtin_fma(TB[272 + decltype(j)::value], K[j], acc); });
+                    const double a0 = fabs(zo), a1 = fabs(own(znew));
+                    double res[NC];
+                    bcast((dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
+                    ssrep = 0.0;
+                    static_for<0, NC>([&](auto c) { ssrep = __builtin_fma(res[c], res[c], ssrep); });
+                    req = RQ_STEP;
                 }
             }
-        });
-    };
+        } else if (ph == PH_FLUSH) {
+            req = RQ_FLUSH;
+        }
+        if (lm == 0) {
+            REQI[slot] = req; REQZ[slot] = zero_req ? 1 : 0; RDT[slot] = dt; RG[slot] = gid; RCOL[slot] = col; ROK[slot] = ret == RET_SUCCESS ? 1 : 0;
+            static_for<0, NC>([&](auto c) { ZK[slot * 16 + decltype(c)::value] = znew[c]; ZK[slot * 16 + 8 + decltype(c)::value] = kr[c]; });
+        }
+        zero_req = false;
+        __syncthreads();
+        LS_TICK(4)
 
-    // =====================================================================================================================
-    // the Driver's sequence (ude_kernels.h: Driver::run with CPL, DEFER), one trajectory per 16-lane row
-    // =====================================================================================================================
-    double t = TF, dt = 0.0, qold = o.qoldinit, q11 = 1.0;
-    bool accept = true;
-    int iter = 0;
-    int64_t nfc = 0, nacc = 0, nrej = 0;
-    double tstop = tstop_from_cur();
-    double f0[NC], f1[NC], z1[NC];
-    static_for<0, NC>([&](auto c) { f0[c] = 0.0; f1[c] = 0.0; z1[c] = 0.0; });
+        // ---- E. the parameter-slot work the slots asked for: the requests of this trip are dealt to the four wavefronts in turn
+        // (slots in the same phase -- the usual case -- ask together: four whole passes per wavefront, the next chunk of mu always
+        //  in flight behind the current one) ----
+        {
+            int ord = 0;
+#pragma unroll 1
+            for (int sl = 0; sl < NSLOTS; ++sl) {
+                const int mode = __builtin_amdgcn_readfirstlane(REQI[sl]);
+                const int zr = __builtin_amdgcn_readfirstlane(REQZ[sl]);
+                if (mode == RQ_NONE && !zr) continue;
+                const bool mine = (ord & 3) == w;
+                ord += 1;
+                if (!mine) continue;
+                const long long g = RG[sl];
+                const int cl = __builtin_amdgcn_readfirstlane(RCOL[sl]);
+                double* mbase = p.slot_glob + (size_t)g * (2 * NSLK * H) + l;
+                double* mcur = mbase + (size_t)cl * (NSLK * H);
+                double* mnew = mbase + (size_t)(1 - cl) * (NSLK * H);
+                if (zr) {   // a fresh trajectory: its current mu column starts at zero
+#pragma unroll 8
+                    for (int k = 0; k < NSLK; ++k) mcur[(size_t)k * H] = 0.0;
+                }
+                const double* fb = fmine + (size_t)sl * NSTC * 4 * H;
+                double hh = 0.0, ll = 0.0;
+                double* a1s = A1S + w * NSTC * H;
+                if (mode == RQ_STEP) {
+                    const double ps = slot_pass<S, MASK, 0>(fb, a1s, XF, sl, l, TB + 256, TB + 272, RDT[sl], o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    const double tot = group_sum<64>(ps);
+                    if (l == 0) SUMW[sl * 2] = tot;
+                } else if (mode == RQ_NORM01) {
+                    slot_pass<1, 1u, 1>(fb, a1s, XF, sl, l, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    group_dd_sum<64>(hh, ll);
+                    if (l == 0) { SUMW[sl * 2] = hh; SUMW[sl * 2 + 1] = ll; }
+                } else if (mode == RQ_NORM2) {
+                    slot_pass<2, 3u, 2>(fb, a1s, XF, sl, l, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    group_dd_sum<64>(hh, ll);
+                    if (l == 0) { SUMW[sl * 2] = hh; SUMW[sl * 2 + 1] = ll; }
+                } else if (mode == RQ_FLUSH) {   // the trajectory's gradient row (zeros if it failed)
+                    const bool ok = __builtin_amdgcn_readfirstlane(ROK[sl]) != 0;
+                    double* row = p.grad_part + (size_t)g * p.n_param;
+#pragma unroll 4
+                    for (int k = 0; k < H; ++k) row[OFF_W2 + l + k * H] = ok ? mcur[(size_t)k * H] : 0.0;
+                    static_for<0, 7>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        const int idx = e < 3 ? OFF_W1 + l + e * H : e == 3 ? OFF_B1 + l : e == 4 ? OFF_B2 + l : e == 5 ? OFF_W3 + l : (l == 0 ? OFF_B3 : -1);
+                        if (idx >= 0) row[idx] = ok ? mcur[(size_t)(H + e) * H] : 0.0;
+                    });
+                }
+            }
+        }
+        __syncthreads();
+        LS_TICK(5)
 
-    // ---- initial dt (ode_determine_initdt): two evaluations ----
-    const bool user_dt = o.dt0 > 0.0;
-    if (user_dt) {
-        dt = tdir * o.dt0;
-        if constexpr (Tab::FSAL) nfc += 1;
-    }
-    {
-        const bool ev0 = live && !user_dt;
-        eval_all(ev0, t, lam, 0, f0);
-        if (ev0) K[0] = own(f0);
-        __syncthreads();   // factors of stage slot 0 are in the workspace (written by the wavefronts that own the slots themselves)
-        mu_pass(std::integral_constant<int, 1>{}, ev0, 0.0);
-        bool ev1 = false;
-        double dt0 = 0.0, d1n = 0.0, sk[NC];
-        if (ev0) {
-            double h0 = 0.0, l0 = 0.0, h1 = SUM[slot * 8 + 1], l1 = SUM[slot * 8 + 2];
+        // ---- F. the slot's row moves its state machine on ----
+        static_for<0, NC>([&](auto c) { znew[c] = ZK[slot * 16 + decltype(c)::value]; kr[c] = ZK[slot * 16 + 8 + decltype(c)::value]; });
+        if (ph == PH_FLUSH) {
+            if (req == RQ_FLUSH) ph = PH_IDLE;
+        } else if (ph == PH_INIT0 && ev) {
+            // ode_determine_initdt, first half (the slot sums first -- mu == 0: only the g0 terms --, then the replicated components)
+            double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
+            h1 = SUMW[slot * 2]; l1 = SUMW[slot * 2 + 1];
             static_for<0, NC>([&](auto c) {
-                sk[c] = __builtin_fma(fabs(lam[c]), o.reltol, o.abstol);
-                const double q0 = lam[c] / sk[c], q1 = f0[c] / sk[c];
+                const double sk = __builtin_fma(fabs(lam[c]), o.reltol, o.abstol);
+                const double q0 = lam[c] / sk, q1 = f0l[decltype(c)::value] / sk;
                 dd_acc(h0, l0, q0 * q0);
                 dd_acc(h1, l1, q1 * q1);
             });
             const double s0 = h0 + l0, s1 = h1 + l1;
             const double d0 = __builtin_sqrt(s0 / ntot);
             d1n = __builtin_sqrt(s1 / ntot);
-            if (d1n != d1n) { ret = RET_UNSTABLE; live = false; }
             dt0 = (d0 < 1e-5 || d1n < 1e-5) ? 1e-6 : (d0 / d1n) / 100.0;
             if (dt0 > dtmax) dt0 = dtmax;
-            if (dt0 < 10.0 * REAL_EPS) dt = tdir * 1e-6;
-            else ev1 = live;
-            if (ev1) {
-                const double dt0t = tdir * dt0;
-                static_for<0, NC>([&](auto c) { z1[c] = __builtin_fma(dt0t, f0[c], lam[c]); });
+            if (d1n != d1n) {
+                ret = RET_UNSTABLE;
+                ph = PH_FLUSH;
+                if (lm == 0) {
+                    if (p.stats) { int64_t* st = p.stats + (size_t)gid * 8; st[4] = 2 + (Tab::FSAL ? 1 : 0); st[5] = 0; st[6] = 0; }
+                    p.retcode[gid] = ret;
+                }
+                if (p.grad_u0 && lm < NC) p.grad_u0[(size_t)gid * n + lm] = zo;
+            } else if (dt0 < 10.0 * REAL_EPS) {
+                dt = tdir * 1e-6;
+                nfc += 2;
+                if constexpr (Tab::FSAL) nfc += 1;
+                ph = 0;
+            } else {
+                ph = PH_INIT1;
             }
-        }
-        eval_all(ev1, t + tdir * dt0, z1, 1, f1);
-        __syncthreads();
-        mu_pass(std::integral_constant<int, 2>{}, ev1, 0.0);
-        if (ev1) {
-            double h2 = SUM[slot * 8 + 3], l2 = SUM[slot * 8 + 4];
+        } else if (ph == PH_INIT1 && ev) {
+            double h2 = SUMW[slot * 2], l2 = SUMW[slot * 2 + 1];
             static_for<0, NC>([&](auto c) {
-                const double q = (f1[c] - f0[c]) / sk[c];
+                const double sk = __builtin_fma(fabs(lam[c]), o.reltol, o.abstol);
+                const double q = (kr[c] - f0l[decltype(c)::value]) / sk;
                 dd_acc(h2, l2, q * q);
             });
             const double s2 = h2 + l2;
@@ -495,156 +648,87 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
             if (dt1 < d) d = dt1;
             if (dtmax < d) d = dtmax;
             dt = tdir * d;
-        }
-        if (ev0) {
             nfc += 2;
             if constexpr (Tab::FSAL) nfc += 1;
-        }
-    }
-
-    // ---- the step loop: every live slot makes one attempt per trip ----
-    for (;;) {
-        bool go = live;
-        if (go) {
-            if (iter > 0 && !accept) {
-                double den = q11 / o.gamma;
-                const double iq = 1.0 / o.qmin;
-                if (iq < den) den = iq;
-                dt = dt / den;
-            }
-            iter += 1;
-            if (fabs(dt) > dtmax) dt = tdir * dtmax;
-            {
-                const double rem = fabs(tstop - t);
-                if (fabs(dt) > rem) dt = tdir * rem;
-            }
-            if (iter > o.maxiters) { ret = RET_MAXITERS; live = false; go = false; }
-            else if (dt != dt) { ret = RET_UNSTABLE; live = false; go = false; }
-            else if (fabs(dt) <= REAL_EPS * fabs(t) && fabs(dt) < fabs(tstop - t)) { ret = RET_DTLESSTHANMIN; live = false; go = false; }
-        }
-        if (!__syncthreads_or(go)) break;
-        double znew[NC];
-        static_for<0, NC>([&](auto c) { znew[c] = lam[c]; });
-        const double zo = own(lam);
-#pragma unroll 1
-        for (int s = 0; s < S; ++s) {
-            double zs[NC], kr[NC];
-            static_for<0, NC>([&](auto c) { zs[c] = lam[c]; kr[c] = 0.0; });
-            if (go && s > 0) {
-                double acc = tab->A[s][0] * K[0];
-                // K is a register array: the chain over j < s with a wave-uniform s, unrolled with selects
-                static_for<1, S>([&](auto j) {
-                    if ((int)decltype(j)::value < s) acc = __builtin_fma(tab->A[s][decltype(j)::value], K[j], acc);
-                });
-                bcast(__builtin_fma(dt, acc, zo), zs);
-            }
-            if (Tab::FSAL && s == S - 1) static_for<0, NC>([&](auto c) { znew[c] = zs[c]; });
-            eval_all(go, t + tab->C[s] * dt, zs, __builtin_popcount(MASK & ((1u << s) - 1u)), kr);
-            if (go) {
-                const double ko = own(kr);
-                static_for<0, S>([&](auto j) { K[j] = ((int)decltype(j)::value == s) ? ko : K[j]; });
-            }
-        }
-        __syncthreads();   // the last stage's factors are in the workspace
-        double ss = 0.0;
-        if (go) {
-            nfc += Tab::FSAL ? S - 1 : S;
-            if constexpr (!Tab::FSAL) {
-                double acc = tab->B[0] * K[0];
-                static_for<1, S>([&](auto j) { acc = __builtin_fma(tab->B[decltype(j)::value], K[j], acc); });
-                bcast(__builtin_fma(dt, acc, zo), znew);
-            }
-            double acc = tab->BT[0] * K[0];
-            static_for<1, S>([&](auto j) { acc = __builtin_fma(tab->BT[decltype(j)::value], K[j], acc); });
-            const double a0 = fabs(zo), a1 = fabs(own(znew));
-            double res[NC];
-            bcast((dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
-            static_for<0, NC>([&](auto c) { ss = __builtin_fma(res[c], res[c], ss); });
-        }
-        mu_pass(std::integral_constant<int, 0>{}, go, dt);
-        if (go) {
-            ss += SUM[slot * 8 + 0];
-            const double EEst = __builtin_sqrt(ss / ntot);
-            double q;
-            if (EEst == 0.0) {
-                q = 1.0 / o.qmax;
+            ph = 0;
+        } else if (ph >= 0 && ev) {
+            if (ph < S - 1) {
+                ph += 1;
             } else {
-                q11 = fastpow(EEst, o.beta1);
-                q = q11 / fastpow(qold, o.beta2);
-                q = q / o.gamma;
-                const double lo = 1.0 / o.qmax, hi = 1.0 / o.qmin;
-                if (q > hi) q = hi;
-                if (q < lo) q = lo;
-            }
-            accept = EEst <= 1.0;
-            if (p.trace && lm == 0 && gid == p.trace_traj && iter <= p.trace_cap) {
-                double* row = p.trace + ((size_t)p.trace_cap + (iter - 1)) * 5;
-                row[0] = t; row[1] = dt; row[2] = EEst; row[3] = q; row[4] = accept ? 1.0 : 0.0;
-            }
-            if (accept) {
-                nacc += 1;
-                qold = EEst > o.qoldinit ? EEst : o.qoldinit;
-                double dtnew = dt / q;
-                const double ttmp = t + dt;
-                {
-                    const double mxt = t > tstop ? t : tstop;
-                    t = fabs(ttmp - tstop) < 100.0 * ulp_of(mxt) ? tstop : ttmp;
+                nfc += Tab::FSAL ? S - 1 : S;
+                double ss = ssrep;
+                ss += SUMW[slot * 2];
+                const double EEst = __builtin_sqrt(ss / ntot);
+                double q;
+                if (EEst == 0.0) {
+                    q = 1.0 / o.qmax;
+                } else {
+                    q11 = fastpow(EEst, o.beta1);
+                    q = q11 / fastpow(qold, o.beta2);
+                    q = q / o.gamma;
+                    const double lo = 1.0 / o.qmax, hi = 1.0 / o.qmin;
+                    if (q > hi) q = hi;
+                    if (q < lo) q = lo;
                 }
-                if (fabs(dtnew) > dtmax) dtnew = tdir * dtmax;
-                dt = dtnew;
-                bool bad = false;
-                static_for<0, NC>([&](auto c) {
-                    lam[c] = znew[c];
-                    bad = bad || (znew[c] != znew[c]);
-                });
-                { double* tsw = mu_cur; mu_cur = mu_new; mu_new = tsw; }   // slot_accept: the candidate column becomes current
-                if (bad) { ret = RET_UNSTABLE; live = false; }
-                if (t == tstop) {
-                    const bool modified = at_tstop(t);
-                    if (tstop == T0) live = false;   // done
-                    else {
-                        tstop = tstop_from_cur();
-                        if (modified && Tab::FSAL) nfc += 1;   // reset_fsal! after u_modified! (counted as upstream does; this system re-evaluates stage 0 every step anyway)
+                accept = EEst <= 1.0;
+                if (p.trace && lm == 0 && gid == p.trace_traj && iter <= p.trace_cap) {
+                    double* row = p.trace + ((size_t)p.trace_cap + (iter - 1)) * 5;
+                    row[0] = t; row[1] = dt; row[2] = EEst; row[3] = q; row[4] = accept ? 1.0 : 0.0;
+                }
+                bool fin = false;
+                if (accept) {
+                    nacc += 1;
+                    qold = EEst > o.qoldinit ? EEst : o.qoldinit;
+                    double dtnew = dt / q;
+                    const double ttmp = t + dt;
+                    {
+                        const double mxt = t > tstop ? t : tstop;
+                        t = fabs(ttmp - tstop) < 100.0 * ulp_of(mxt) ? tstop : ttmp;
                     }
+                    if (fabs(dtnew) > dtmax) dtnew = tdir * dtmax;
+                    dt = dtnew;
+                    bool bad = false;
+                    static_for<0, NC>([&](auto c) {
+                        lam[c] = znew[c];
+                        bad = bad || (znew[c] != znew[c]);
+                    });
+                    col = 1 - col;   // slot_accept: the candidate column becomes current
+                    if (bad) { ret = RET_UNSTABLE; fin = true; }
+                    if (t == tstop) {
+                        const bool modified = at_tstop(t);
+                        if (tstop == T0) fin = true;   // done
+                        else {
+                            tstop = tstop_from_cur();
+                            if (modified && Tab::FSAL) nfc += 1;   // reset_fsal! after u_modified! (counted as upstream does)
+                        }
+                    }
+                } else {
+                    nrej += 1;
+                    if (EEst != EEst) { ret = RET_UNSTABLE; fin = true; }
                 }
-            } else {
-                nrej += 1;
-                if (EEst != EEst) { ret = RET_UNSTABLE; live = false; }
+                if (fin) {
+                    ph = PH_FLUSH;
+                    if (lm == 0) {
+                        if (p.stats) { int64_t* st = p.stats + (size_t)gid * 8; st[4] = nfc; st[5] = nacc; st[6] = nrej; }
+                        if (ret != RET_SUCCESS) p.retcode[gid] = ret;
+                    }
+                    if (p.grad_u0 && lm < NC) p.grad_u0[(size_t)gid * n + lm] = own(lam);
+                } else {
+                    ph = 0;
+                }
             }
         }
+        LS_TICK(6)
+#if defined(LS_EXP) && LS_EXP == 9
+        ntrip += 1;
+#endif
     }
-
-    // ---- results ----
-    if (started && lm == 0) {
-        if (p.stats) {
-            int64_t* s = p.stats + (size_t)gid * 8;
-            s[4] = nfc; s[5] = nacc; s[6] = nrej;
-        }
-        if (ret != RET_SUCCESS) p.retcode[gid] = ret;
+#if defined(LS_EXP) && LS_EXP == 9
+    if (p.trace && blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 7; ++i) p.trace[i] = (double)tsec[i];
+        p.trace[7] = (double)ntrip;
     }
-    if (started && p.grad_u0 && lm < NC) p.grad_u0[(size_t)gid * n + lm] = own(lam);
-    // gradient rows: wavefront w for its four slots, lane i = hidden row i; a failed trajectory contributes nothing
-    static_for<0, 4>([&](auto q) {
-        const int64_t g = (int64_t)blockIdx.x * NSLOTS + 4 * w + decltype(q)::value;
-        const bool ok = __builtin_amdgcn_readlane((int)(started && ret == RET_SUCCESS), 16 * decltype(q)::value) != 0;
-        if (g < p.N) {
-            const unsigned long long mc_ = (unsigned long long)mu_cur;
-            const unsigned long long mcq = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mc_ >> 32), 16 * decltype(q)::value) << 32) |
-                                           (unsigned)__builtin_amdgcn_readlane((int)mc_, 16 * decltype(q)::value);
-            const double* mfin = (const double*)mcq + l;
-            double* row = p.grad_part + (size_t)g * p.n_param;
-#pragma unroll 2
-            for (int k = 0; k < NSLK; ++k) {
-                int idx;
-                if (k < H) idx = OFF_W2 + l + k * H;
-                else {
-                    const int e = k - H;
-                    idx = e < 3 ? OFF_W1 + l + e * H : e == 3 ? OFF_B1 + l : e == 4 ? OFF_B2 + l : e == 5 ? OFF_W3 + l : (l == 0 ? OFF_B3 : -1);
-                }
-                if (idx >= 0) row[idx] = ok ? mfin[(size_t)k * H] : 0.0;
-            }
-        }
-    });
+#endif
 }
 
 }  // namespace seirls

@@ -6,7 +6,7 @@
 using namespace ude;
 
 // kernel entry points for udecore.hip: alg 0 = Tsit5, 1 = Vern7
-extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*), size_t* lds_bytes, size_t* fac_doubles_per_block) {
+extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block) {
     if (alg == 1) {
         *kern = seirls::seir_ls_adj_kernel<Vern7Tab>;
         *lds_bytes = sizeof(double) * seirls::lds_doubles<Vern7Tab>() + 16;

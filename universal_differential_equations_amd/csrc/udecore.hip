@@ -213,7 +213,7 @@ void ude_poison_chip_dbg(hipStream_t st, bool before_forward) {  // (what & 4: a
 // ---------------------------------------------------------------------------------------------
 #include "ude_instances_gen.h"
 // lock-step matrix-core adjoint of the SEIR exposure UDE (csrc/ude_seir_ls.hip)
-extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*), size_t* lds_bytes, size_t* fac_doubles_per_block);
+extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 
 struct InstanceRow {
     int mid, alg, G, W;
@@ -302,6 +302,16 @@ static int generic_id(const ude_model_desc* m) {
     return MID_NONE;
 }
 
+// blocks of the lock-step SEIR backward kernel: 16 trajectory slots each, at most one block per compute unit (the slots refill
+// from a queue)
+static int64_t ls_blocks(ude_ctx* c, int64_t N) {
+    if (c->ncu <= 0) {
+        hipDeviceProp_t prop;
+        c->ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const int64_t nb = (N + 15) / 16;
+    return nb < c->ncu ? nb : c->ncu;
+}
 #ifndef UDE_SEIR_LS_DEFAULT
 #define UDE_SEIR_LS_DEFAULT 0   // 1: the lock-step matrix-core backward kernel is the default for the SEIR exposure UDE
 #endif
@@ -665,7 +675,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     int64_t nwaves = (int64_t)grid * ((BLOCK >= 64 && G <= 64) ? BLOCK / 64 : 1);  // rows of the partial-gradient matrix
-    void (*ls_kern)(const KParams, double*) = nullptr;
+    void (*ls_kern)(const KParams, double*, int*) = nullptr;
     size_t ls_lds = 0, ls_fac = 0;
     if (seir_ls) {
         ude_seir_ls_get(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &ls_fac);
@@ -690,9 +700,8 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = ensure(c, c->grad_part, es * (size_t)nwaves * np))) return rc;
     p.slot_glob = nullptr;
     if (seir_ls) {  // mu of every trajectory: two columns of 71 slots x 64 hidden rows; the stage factors of every block of 16 slots
-        const int64_t nblk = (N + 15) / 16;
         if ((rc = ensure(c, c->slot_glob, sizeof(double) * (size_t)N * 2 * 71 * 64))) return rc;
-        if ((rc = ensure(c, c->ls_fac, sizeof(double) * (size_t)nblk * ls_fac))) return rc;
+        if ((rc = ensure(c, c->ls_fac, sizeof(double) * (size_t)ls_blocks(c, N) * ls_fac + 64))) return rc;
         p.slot_glob = (double*)c->slot_glob.p;
     } else if (l.slot_glob > 0) {  // slot state mu of the adjoint in HBM: [slot][thread]
         if ((rc = ensure(c, c->slot_glob, es * (size_t)l.slot_glob * grid * BLOCK))) return rc;
@@ -754,8 +763,12 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     }
     ude_poison_chip(c->stream, false);
     if (seir_ls) {
+        // persistent blocks (one per CU at most), trajectories handed out through a queue counter that lives behind the factor workspace
+        const int64_t nblk = ls_blocks(c, N);
+        int* queue = (int*)((double*)c->ls_fac.p + (size_t)nblk * ls_fac);
+        HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)ls_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls_lds));
-        hipLaunchKernelGGL(ls_kern, dim3((unsigned)((N + 15) / 16)), dim3(256), ls_lds, c->stream, p, (double*)c->ls_fac.p);
+        hipLaunchKernelGGL(ls_kern, dim3((unsigned)nblk), dim3(256), ls_lds, c->stream, p, (double*)c->ls_fac.p, queue);
     } else
     hipLaunchKernelGGL(bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
     HIPCHK(c, hipGetLastError());
