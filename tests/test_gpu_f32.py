@@ -83,7 +83,7 @@ def test_hudson_bay_f32_trained_loss_and_gradient(golden):
 
 def test_f32_descriptor_without_instance_is_refused():
     f = models.ude_dynamics(dtype="float32")          # scenario_1's rbf chain has no Float32 instance
-    with pytest.raises(U.UdeError, match="no compiled kernel"):
+    with pytest.raises(U.UdeError, match="no kernel for model"):   # (not a compiled instance; the runtime-shape fallback is Float64 only)
         U.solve(U.ODEProblem(f, [1.0, 1.0], (0.0, 1.0), np.zeros(87)), U.Tsit5(), saveat=0.5)
 
 

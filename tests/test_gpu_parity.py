@@ -462,9 +462,13 @@ def test_failed_trajectory_is_reported_not_summed(golden):
 
 
 def test_unsupported_descriptor_is_an_error():
+    """a chain no compiled instance covers runs on the runtime-shape fallback (tests/test_gpu_generic.py); one outside the
+    fallback too (a layer wider than a wavefront) is refused loudly"""
     prob = U.ODEProblem(models.ude_dynamics(models.Chain(models.Dense(2, 7, "tanh"), models.Dense(7, 2))), [1.0, 1.0], (0.0, 1.0), np.zeros(37))
-    with pytest.raises(U.sciml.UdeError):
-        U.solve(prob, U.Tsit5(), saveat=0.5)
+    assert U.solve(prob, U.Tsit5(), saveat=0.5).retcode == "Success"
+    wide = models.Chain(models.Dense(2, 65, "tanh"), models.Dense(65, 2))
+    with pytest.raises(U.sciml.UdeError, match="no kernel for model"):
+        U.solve(U.ODEProblem(models.ude_dynamics(wide), [1.0, 1.0], (0.0, 1.0), np.zeros(wide.n_param)), U.Tsit5(), saveat=0.5)
 
 
 def test_full_size_seir_and_kpp_properties():

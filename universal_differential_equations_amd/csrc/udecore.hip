@@ -313,7 +313,7 @@ static int64_t ls_blocks(ude_ctx* c, int64_t N) {
     return nb < c->ncu ? nb : c->ncu;
 }
 #ifndef UDE_SEIR_LS_DEFAULT
-#define UDE_SEIR_LS_DEFAULT 0   // 1: the lock-step matrix-core backward kernel is the default for the SEIR exposure UDE
+#define UDE_SEIR_LS_DEFAULT 1   // 1: the lock-step matrix-core backward kernel is the default for the SEIR exposure UDE
 #endif
 static int default_lanes(int mid, bool discrete) {
     switch (mid) {
