@@ -475,6 +475,14 @@ def main():
     nf_fwd = int(ens.stats[:, 0].sum().item())
     nf_bwd = int(ens.stats[:, 4].sum().item())
     nfail = int((ens.retcode != 0).sum().item())
+    # lock-step utilisation of the backward kernel: trajectories that share a wavefront (or a block of lock-step slots) make their
+    # step attempts together, so a group runs as long as its slowest member, and a one-round launch as long as its slowest group
+    att = (ens.stats[:, 5] + ens.stats[:, 6]).to(torch.float64).cpu().numpy()
+    grp = {"lv": 12 if not a.lanes else max(1, 64 // a.lanes), "seir": 16, "node": 1, "kpp": 1}[a.workload]
+    pad = (-len(att)) % grp
+    gmax = np.concatenate([att, np.zeros(pad)]).reshape(-1, grp).max(axis=1)
+    lane_step_util = float(att.sum() / max((gmax * grp).sum(), 1.0))
+    critical_path = float(att.max() / max(att.mean(), 1e-9))
     evals = torch.tensor([nf_fwd + nf_bwd, nfail], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(evals)
@@ -494,6 +502,7 @@ def main():
                        "trajectories_per_gpu": N, "sensealg": a.sensealg, "hip_graph": bool(a.graph), "lanes_per_trajectory": a.lanes or "default",
                        "evals_per_step_fwd": nf_fwd, "evals_per_step_bwd": nf_bwd, "failed_trajectories": int(evals[1].item()),
                        "adjoint_grad_wallclock_ms": ms_per_step, "sustained_loop": {"steps": n_sus, "ms_per_step": sustained_ms},
+                       "lane_step_util": lane_step_util, "bwd_attempts_max_over_mean": critical_path,
                        "fwd_kernel_ms": float(np.mean(fwd_ms)),
                        "bwd_kernel_ms": float(np.mean(bwd_ms))},
             "roofline": {"bound": "mfma", "unit_busy": "mfma-f64" if a.workload == "kpp" else "valu-f64",

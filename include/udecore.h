@@ -100,8 +100,9 @@ enum { UDE_PT_TSPAN = 1, UDE_PT_SAVEAT = 2 };
 /* launch/tuning knobs of the HIP back end (not part of the reference surface) */
 typedef struct {
     int32_t lanes_per_traj;   /* 0 = auto; lanes cooperating on one trajectory.  Compiled variants: LV 2-5-5-5-2: 1, 4, 5 (default:
-                                 12 trajectories per wavefront), 8; LV 2-32-2: 8, 32; SEIR UDE: 64 (default, wavefront per
-                                 trajectory) or 256 (four wavefronts); Fisher-KPP UDE <= 32 points: 32; 1024 points: 256
+                                 12 trajectories per wavefront), 8; LV 2-32-2: 8, 32 (default); SEIR UDE: 64 (wavefront per
+                                 trajectory), 256 (four wavefronts), 16 (default for the interpolating adjoint: lock-step backward
+                                 kernel, 16 trajectories per block as columns of FP64 matrix-core products); Fisher-KPP UDE <= 32 points: 32; 1024 points: 256
                                  (default, four wavefronts per PDE) or 64.  Every variant returns identical bits. */
     int32_t block_threads;    /* 0 = auto (64) */
     int32_t max_dense_steps;  /* capacity of the dense forward store per trajectory; 0 = automatic: starts at 256 and is

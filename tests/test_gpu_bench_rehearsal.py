@@ -1,0 +1,30 @@
+"""Rehearsal of the driver's multi-GPU bench launch on a one-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py
+--gpus 2` with both ranks on device 0 (UDE_BENCH_DEVICE=0) and gloo in place of RCCL (which refuses two ranks on one device;
+UDE_BENCH_BACKEND=gloo).  Everything else is the real N > 1 path: one process per rank, the ONE all-reduce of
+double[np + 4] per gradient, barrier + synchronize around the timed region, MAX over ranks, rank 0 prints the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ, UDE_BENCH_DEVICE="0", UDE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--traj", "2000",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["config"]["failed_trajectories"] == 0
+    # whole-job value: both ranks' evaluations over the slower rank's time
+    per_rank = d["config"]["evals_per_step_fwd"] + d["config"]["evals_per_step_bwd"]
+    assert d["value"] > per_rank * 3 / (d["ms_per_step"] * 3e-3) * 1.5
