@@ -34,7 +34,7 @@ SENSE_NAME = {"adjoint": "InterpolatingAdjoint", "discrete": "discretise-then-op
               "fast": "InterpolatingAdjoint with lambda-only error control (SURVEY 8(b) fast mode; not the reference's step sequence)"}
 # which unit dominates each backward kernel: the LV / SEIR kernels run on the FP64 VALU, Fisher-KPP on the FP64 matrix cores
 # (both peaks are 78.6 TF; the schema's "bound" offers hbm | mfma)
-BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint)", "discrete": "dadj_kernel (frozen-step reverse sweep)",
+BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint; SEIR exposure UDE: seir_ls_adj_kernel, 16 trajectories per block in lock-step on the FP64 matrix cores)", "discrete": "dadj_kernel (frozen-step reverse sweep)",
               "fast": "adj_kernel, fast mode (lambda-only error control)"}
 
 
@@ -131,6 +131,8 @@ def pmc_traffic(a):
     if a.net != "s1" or a.alg != "tsit5" or a.lanes or a.waves or a.traj or a.sensealg == "fast":
         return None
     kern = "adj_kernel<" if a.sensealg == "adjoint" else "dadj_kernel<"
+    if a.workload == "seir" and a.sensealg == "adjoint" and a.lanes in (0, 16):
+        kern = "seirls::seir_ls_adj_kernel<"     # the lock-step matrix-core backward kernel (the default)
     return pmc_traffic_file("r03_pmc_%s.md" % a.workload, "`void " + kern) or pmc_traffic_file("r02_pmc_%s.md" % a.workload, "`void " + kern)
 
 
@@ -325,7 +327,7 @@ def quick_measure(name, device, steps=3, warmup=1):
     nf_fwd, nf_bwd = int(ens.stats[:, 0].sum().item()), int(ens.stats[:, 4].sum().item())
     flop_key = "lv" if wl == "lv" else wl
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
-    kern = "dadj_kernel" if sense == "discrete" else "adj_kernel"
+    kern = "dadj_kernel" if sense == "discrete" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete") else wl
     return {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
             "fwd_kernel_ms": f, "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,

@@ -561,7 +561,7 @@ def test_tanh32_wide_lane_group_variant():
     data, _, rc = O.solve_ensemble(O.lv_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 3.0], [1.3, 0.9, 0.8, 1.8], t)
     ens = U.EnsembleProblem(U.ODEProblem(models.ude_dynamics(models.tanh32_chain()), u0[0], (0.0, 3.0), th), u0)
     ref = O.loss_grad_ensemble(O.lv_ude_tanh32(), O.opts(O.TSIT5, 1e-6, 1e-6), u0, [0.0, 3.0], th, t, data, nthreads=4)
-    for lanes in (0, 32):
+    for lanes in (0, 8):
         r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, abstol=1e-6, reltol=1e-6,
                                 **({"ensemblealg": U.EnsembleMI355(lanes)} if lanes else {}))
         check_per_trajectory(r, ref)
