@@ -27,7 +27,10 @@ HJB_FLOP_PER_BWD_COL = 2.0 * (100 * 110 + 110 * 110 * 2) + 2.0 * (102 * 110 + 11
 # algorithmic flop per work unit (forward RHS eval, adjoint eval): SURVEY.md 8(d) roofline table
 FLOPS = {"lv": (160.0, 550.0), "seir": (8744.0, 26000.0), "kpp": (0.87e6, 2.6e6),
          # neural ODE 7-64-64-64-7: forward 2*(7*64 + 2*64*64 + 64*7) = 18.2 kflop; adjoint = forward + transposed products + outer products
-         "node": (18176.0, 54500.0)}
+         "node": (18176.0, 54500.0),
+         # BASELINE's literal "2-layer tanh MLP" 2-32-2 on the LV ensemble: forward 2*(2*32 + 32*2) = 256 flop (+ 2 for the diagonal terms);
+         # adjoint = forward + the two transposed products + the 162 outer-product / bias entries
+         "lv_tanh32": (258.0, 840.0)}
 
 
 SENSE_NAME = {"adjoint": "InterpolatingAdjoint", "discrete": "discretise-then-optimise (ForwardDiffSensitivity-equivalent)",
@@ -325,7 +328,7 @@ def quick_measure(name, device, steps=3, warmup=1):
     ms = (time.perf_counter() - t0) / steps * 1e3
     f, b = ens.kernel_ms()
     nf_fwd, nf_bwd = int(ens.stats[:, 0].sum().item()), int(ens.stats[:, 4].sum().item())
-    flop_key = "lv" if wl == "lv" else wl
+    flop_key = "lv_tanh32" if name == "lv_tanh32" else wl
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
     kern = "dadj_kernel" if sense == "discrete" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete") else wl
@@ -494,7 +497,8 @@ def main():
 
     if rank == 0:
         bwd = float(np.mean(bwd_ms)) * 1e-3
-        flops_bwd = nf_bwd * FLOPS[a.workload][1]
+        fkey = "lv_tanh32" if (a.workload == "lv" and a.net == "tanh32") else a.workload
+        flops_bwd = nf_bwd * FLOPS[fkey][1]
         achieved = flops_bwd / bwd / 1e12
         out = {
             "metric": "ODE RHS-evals/s (fwd+adjoint)", "value": value, "unit": "RHS-evals/s", "n_gpus": world,
@@ -517,7 +521,7 @@ def main():
                                  "algorithmic %g flop per adjoint eval; "
                                  "the path is FP64-ALU/latency bound, not HBM bound (DESIGN.md); traffic = FETCH_SIZE + "
                                  "WRITE_SIZE bytes per adj_kernel launch from the separate rocprofv3 --pmc passes of this "
-                                 "command (profiles/r03_pmc_<workload>.md, tools/prof_r03.sh), null for non-default commands" % FLOPS[a.workload][1]},
+                                 "command (profiles/r03_pmc_<workload>.md, tools/prof_r03.sh), null for non-default commands" % FLOPS[fkey][1]},
         }
         if not a.no_cpu_baseline and world == 1:  # (the CPU leg is a rank-0, N=1 measurement)
             out["cpu_baseline"] = cpu_baseline(theta_h, u0_d.cpu().numpy(), t, data.cpu().numpy(), workload=a.workload, mask=mask)
