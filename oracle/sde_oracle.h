@@ -12,10 +12,11 @@
  *   SDE state h = [X (d); u], drift F(h) = [mu(X); -f(X,u,z)] = [0; lambda |z|^2], z = sigma^T grad u net([X; t]),
  *   noise matrix G(h) = [sigma I_d; z^T]  ((d+1) x d, non-diagonal)           (NNPDENS: pde_solve_ns.jl F, G)
  *   LambaEM step: K = h + dt F(h); h' = K + G(h) dW                                [UP+: Lamba 2003 / the EM step]
- *     error estimate as StochasticDiffEq's perform_step! states it for NON-DIAGONAL noise (its source is not under
- *     /root/reference; each piece is marked [UP+] where two independent statements of upstream agree -- the SDE
- *     solver documentation / the Rackauckas-Nie paper and the round-2 code review -- and [UP?] where it is this
- *     restatement's reading):
+ *     error estimate of StochasticDiffEq's perform_step! for NON-DIAGONAL noise.  Its source is not under /root/reference
+ *     and cannot be fetched, so NO piece is verified against upstream's text.  [UP+] marks a piece on which two
+ *     second-hand statements agree (the published method -- Lamba 2003, Rackauckas-Nie 2017 -- and the round-2 code
+ *     review's description of the non-diagonal branch); [UP?] marks this restatement's own reading.  Both are
+ *     unpinned:
  *       Ed      = dt (F(K, t+dt) - F(h, t)) / 2                                            [UP+]  drift part, u row only here
  *       g_sized = ||G(h)||_F  (norm(L, 2) of the (d+1) x d matrix)                          [UP+]  non-diagonal branch: SCALAR norms
  *       utilde  = K + g_sized sqrt(dt)            (the scalar added to every component)     [UP?]  probe point

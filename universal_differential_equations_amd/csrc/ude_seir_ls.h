@@ -44,16 +44,17 @@ constexpr int popc(unsigned m) { int c = 0; for (; m; m &= m - 1) ++c; return c;
 template <unsigned MASK>
 constexpr int cslot(int s) { return popc(MASK & ((1u << s) - 1u)); }   // compacted storage slot of stage s
 
+constexpr int NFAC = 3;     // per-stage factor rows kept in HBM: a2, delta1, delta2 (a1 of every slot and stage stays in LDS)
 constexpr int TABL = 16 * 16 + 3 * 16;   // LDS copy of the tableau: A[16][16], B[16], BT[16], C[16]
 template <class Tab>
 constexpr int lds_doubles() {
     constexpr int NSTC = popc(stage_mask<Tab>());
     return 4 * H * TLD + 4 * 16 + 16 + 3 * NSLOTS * PLD + NSTC * NSLOTS * 4 + NSLOTS * 16 + NSLOTS * 8 + TABL + 6 * NSLOTS + NSLOTS * 4 * 2 +
-           4 * NSTC * H + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16;
+           NSLOTS * NSTC * H + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16;
 }
 // doubles of factor workspace per block
 template <class Tab>
-constexpr size_t fac_doubles_per_block() { return (size_t)NSLOTS * popc(stage_mask<Tab>()) * 4 * H; }
+constexpr size_t fac_doubles_per_block() { return (size_t)NSLOTS * popc(stage_mask<Tab>()) * NFAC * H; }
 
 __device__ __forceinline__ double rshfl(double x, int c) { return __shfl(x, c, 16); }   // lane c of this 16-lane row
 __device__ __forceinline__ double row_tree4(double v0, double v1, double v2, double v3) {
@@ -65,28 +66,40 @@ __device__ __forceinline__ double row_tree4(double v0, double v1, double v2, dou
     return x;
 }
 
-// one pass over the 71 parameter slots of ONE trajectory by a whole wavefront (lane i = hidden row i): the loops of
-// SeirUde<64>::step_slots / init_norm01 / init_norm2.
+// the 71 parameter slots of ONE trajectory, a quarter per wavefront (lane i = hidden row i; wavefront w: W2 columns 16w .. 16w+15
+// and the extra slots 2w, 2w+1): the loops of SeirUde<64>::step_slots / init_norm01 / init_norm2.  Every request of a trip is
+// worked on by all four wavefronts, so the trip waits for a quarter pass per request instead of a whole pass of the busiest wavefront.
 //   MODE 0: end of a step -- candidate mu_new, returns this lane's sum of squared residuals
 //   MODE 1 / 2: the initial-dt norms (h, l) += (g0 / sk)^2  /  ((g1 - g0) / sk)^2 in real-real arithmetic (mu == 0 there)
+constexpr int QW = H / 4;   // W2 columns per wavefront
+#ifndef LS_CUT
+#define LS_CUT 0   // timing experiments only (results wrong): 1 no mu loads, 2 no mu stores, 4 no division, 8 no factor loads
+#endif
 template <int NST, unsigned MASK, int MODE>
-__device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* this trajectory's factors: [cs][field][64] */,
-                                            double* a1s /* LDS staging [cs][64] of this wavefront */, const double* xf /* LDS [cs][16][4] */,
-                                            int slot, int lane, const double* Bw, const double* BTw, double dt, double abstol, double reltol,
+__device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* this trajectory's factors: [cs][a2 | delta1 | delta2][64] */,
+                                            const double* a1s /* LDS [cs][64]: a1 of this slot's stages */, const double* xf /* LDS [cs][16][4] */,
+                                            int slot, int lane, int w, const double* Bw, const double* BTw, double dt, double abstol, double reltol,
                                             const double* __restrict__ mu, double* __restrict__ mu_new, double& hh, double& ll) {
     constexpr int CH = 8;
-    double mcur[CH], mnext[CH], mnext2[CH];   // two chunks of mu in flight behind the one being processed (HBM latency > one chunk's arithmetic)
-    static_for<0, CH>([&](auto i) {
-        mcur[i] = MODE == 0 ? mu[(size_t)decltype(i)::value * H] : 0.0;
-        mnext[i] = MODE == 0 ? mu[(size_t)(CH + decltype(i)::value) * H] : 0.0;
-    });
+    // every load of the pass is issued before the first use: delta2 (needed first), mu, then the rows only the extra slots use
     double a2[NST], d1[NST], d2[NST];
     static_for<0, NST>([&](auto s) {
         if constexpr ((MASK >> decltype(s)::value) & 1u) {
             constexpr int cs = cslot<MASK>(decltype(s)::value);
-            const double* f = fbase + (size_t)cs * 4 * H + lane;
-            a1s[cs * H + lane] = f[0];
-            a2[s] = f[H]; d1[s] = f[2 * H]; d2[s] = f[3 * H];
+            d2[s] = (LS_CUT & 8) ? dt + 3.0 : fbase[(size_t)(cs * NFAC + 2) * H + lane];
+        }
+    });
+    double mcur[CH], mnext[CH], mex[2];
+    static_for<0, CH>([&](auto i) {
+        mcur[i] = (MODE == 0 && !(LS_CUT & 1)) ? mu[(size_t)(QW * w + decltype(i)::value) * H] : 0.0;
+        mnext[i] = (MODE == 0 && !(LS_CUT & 1)) ? mu[(size_t)(QW * w + CH + decltype(i)::value) * H] : 0.0;
+    });
+    static_for<0, 2>([&](auto i) { mex[i] = (MODE == 0 && !(LS_CUT & 1) && 2 * w + decltype(i)::value < 7) ? mu[(size_t)(H + 2 * w + decltype(i)::value) * H] : 0.0; });
+    static_for<0, NST>([&](auto s) {
+        if constexpr ((MASK >> decltype(s)::value) & 1u) {
+            constexpr int cs = cslot<MASK>(decltype(s)::value);
+            a2[s] = (LS_CUT & 8) ? dt + 1.0 : fbase[(size_t)(cs * NFAC) * H + lane];
+            d1[s] = (LS_CUT & 8) ? dt + 2.0 : fbase[(size_t)(cs * NFAC + 1) * H + lane];
         }
     });
     double bb[NST], bt[NST];
@@ -102,9 +115,9 @@ __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* 
                 }
             });
             const double m1 = __builtin_fma(dt, ab, m0);
-            mu_new[(size_t)sl * H] = m1;
+            if (!(LS_CUT & 2)) mu_new[(size_t)sl * H] = m1;
             const double a0 = fabs(m0), a1 = fabs(m1);
-            const double res = (dt * ae) / __builtin_fma((a0 > a1 ? a0 : a1), reltol, abstol);
+            const double res = (LS_CUT & 4) ? (dt * ae) * __builtin_fma((a0 > a1 ? a0 : a1), reltol, abstol) : (dt * ae) / __builtin_fma((a0 > a1 ? a0 : a1), reltol, abstol);
             ps = __builtin_fma(res, res, ps);
         } else {
             const double sk = __builtin_fma(fabs(m0), reltol, abstol);
@@ -112,12 +125,9 @@ __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* 
             dd_acc(hh, ll, q * q);
         }
     };
+    // (a rolled loop on purpose: with the two chunks written out the register allocator spills 350 registers)
 #pragma unroll 1
-    for (int k0 = 0; k0 < H; k0 += CH) {
-        static_for<0, CH>([&](auto i) {   // (the last chunk requested: the 7 extra slots)
-            const int sl = k0 + 2 * CH + decltype(i)::value;
-            mnext2[i] = (MODE == 0 && sl < NSLK) ? mu[(size_t)sl * H] : 0.0;
-        });
+    for (int k0 = QW * w; k0 < QW * w + QW; k0 += CH) {
         static_for<0, CH>([&](auto i) {
             const int k = k0 + decltype(i)::value;
             double g[NST];
@@ -126,24 +136,26 @@ __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* 
             });
             body(k, g, mcur[i]);
         });
-        static_for<0, CH>([&](auto i) { mcur[i] = mnext[i]; mnext[i] = mnext2[i]; });
+        static_for<0, CH>([&](auto i) { mcur[i] = mnext[i]; });
     }
     static_for<0, 7>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
-        double g[NST];
-        static_for<0, NST>([&](auto s) {
-            if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                const double* xs = xf + (cslot<MASK>(decltype(s)::value) * NSLOTS + slot) * 4;   // x0 x1 x2 delta3 of this stage
-                double v;
-                if constexpr (e < 3) v = -(d1[s] * xs[e]);
-                else if constexpr (e == 3) v = -d1[s];
-                else if constexpr (e == 4) v = -d2[s];
-                else if constexpr (e == 5) v = -(xs[3] * a2[s]);
-                else v = lane == 0 ? -xs[3] : -0.0;
-                g[s] = v;
-            }
-        });
-        body(H + e, g, mcur[e]);
+        if ((e >> 1) == w) {
+            double g[NST];
+            static_for<0, NST>([&](auto s) {
+                if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                    const double* xs = xf + (cslot<MASK>(decltype(s)::value) * NSLOTS + slot) * 4;   // x0 x1 x2 delta3 of this stage
+                    double v;
+                    if constexpr (e < 3) v = -(d1[s] * xs[e]);
+                    else if constexpr (e == 3) v = -d1[s];
+                    else if constexpr (e == 4) v = -d2[s];
+                    else if constexpr (e == 5) v = -(xs[3] * a2[s]);
+                    else v = lane == 0 ? -xs[3] : -0.0;
+                    g[s] = v;
+                }
+            });
+            body(H + e, g, mex[e & 1]);
+        }
     });
     return ps;
 }
@@ -182,8 +194,8 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     int* RCS = ROK + NSLOTS;
     int* REV = RCS + NSLOTS;
     double* SUMW = RDT + 6 * NSLOTS;          // [16][4][2] per slot and wavefront: ps | (h, l)
-    double* A1S = SUMW + NSLOTS * 4 * 2;      // [4][NSTC][64]
-    double* KSL = A1S + 4 * NSTC * H;         // [16 slots][NK + 2][8]: interval cache (u_start, k_q) and f0 of the initial-dt phase, component c at [..][c]
+    double* A1P = SUMW + NSLOTS * 4 * 2;      // [16 slots][NSTC][64]: a1 of every stage of the slot's current step (read by broadcast in E)
+    double* KSL = A1P + NSLOTS * NSTC * H;         // [16 slots][NK + 2][8]: interval cache (u_start, k_q) and f0 of the initial-dt phase, component c at [..][c]
     double* RQL = KSL + NSLOTS * 8 * (NK + 2); // [16 lanes q][8]: Horner tables of b_q(theta)
     double* ZK = RQL + 16 * 8;                // [16 slots][16]: znew[7] | kr[7] parked across the parameter-slot work of a trip
 
@@ -282,10 +294,14 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     };
     __syncthreads();
 #if defined(LS_EXP) && LS_EXP == 9
-    unsigned long long tk = __builtin_readcyclecounter(), tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntrip = 0;
+    unsigned long long tk = __builtin_readcyclecounter(), tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntrip = 0, ecyc[4] = {0, 0, 0, 0}, ecnt[4] = {0, 0, 0, 0};
+#define LS_E0 const unsigned long long e0_ = __builtin_readcyclecounter();
+#define LS_E1(i) { ecyc[i] += __builtin_readcyclecounter() - e0_; ecnt[i] += 1; }
 #define LS_TICK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tsec[i] += now_ - tk; tk = now_; }
 #else
 #define LS_TICK(i)
+#define LS_E0
+#define LS_E1(i)
 #endif
 
     for (;;) {
@@ -373,7 +389,6 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
                 if (p.grad_u0 && lm < NC) p.grad_u0[(size_t)gid * n + lm] = zo;
             }
         }
-        if (lm == 0) { RCS[slot] = cs; REV[slot] = ev ? 1 : 0; }
 
         LS_TICK(1)
         // ---- C. one adjoint evaluation of all 16 slots ----
@@ -468,16 +483,27 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
         __syncthreads();
         LS_TICK(3)
         // factors of this evaluation to the workspace, slot-major: wavefront w copies its own four slots (lane i = hidden row i)
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-            const int sl = 4 * w + q;
-            if (REV[sl]) {
-                double* dst = fmine + ((size_t)sl * NSTC + RCS[sl]) * 4 * H + l;
-                dst[0] = T_A1[l * TLD + sl];
-                dst[H] = T_A2[l * TLD + sl];
-                dst[2 * H] = T_D1[l * TLD + sl];
-                dst[3 * H] = T_D2[l * TLD + sl];
-            }
+        // (whether and where: from the registers of the slot's row, all four slots' tile reads issued together)
+        {
+            const int evi = ev ? 1 : 0;
+            double va1[4], va2[4], vd1[4], vd2[4];
+            static_for<0, 4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int sl = 4 * w + q;
+                va1[q] = T_A1[l * TLD + sl]; va2[q] = T_A2[l * TLD + sl]; vd1[q] = T_D1[l * TLD + sl]; vd2[q] = T_D2[l * TLD + sl];
+            });
+            static_for<0, 4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int sl = 4 * w + q;
+                if (__builtin_amdgcn_readlane(evi, 16 * q)) {
+                    const int cs_ = __builtin_amdgcn_readlane(cs, 16 * q);
+                    double* dst = fmine + ((size_t)sl * NSTC + cs_) * NFAC * H + l;
+                    A1P[(sl * NSTC + cs_) * H + l] = va1[q];
+                    dst[0] = va2[q];
+                    dst[H] = vd1[q];
+                    dst[2 * H] = vd2[q];
+                }
+            });
         }
         // ---- D. the slot's row: state cotangent of this evaluation, and what it asks of the parameter-slot pass ----
         int req = RQ_NONE;
@@ -538,56 +564,72 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
         __syncthreads();
         LS_TICK(4)
 
-        // ---- E. the parameter-slot work the slots asked for: the requests of this trip are dealt to the four wavefronts in turn
-        // (slots in the same phase -- the usual case -- ask together: four whole passes per wavefront, the next chunk of mu always
-        //  in flight behind the current one) ----
+        // ---- E. the parameter-slot work the slots asked for: every request is worked on by all four wavefronts, a quarter of the
+        // slots each (no cross-wavefront dependence: a wavefront only ever touches its own columns of mu) ----
         {
-            int ord = 0;
+            // (the 16 request records in one go: lane q holds slot q's, the loop below walks the slots that asked)
+            const int q16 = l & 15;
+            const int r_mode = REQI[q16], r_zr = REQZ[q16], r_col = RCOL[q16], r_ok = ROK[q16];
+            const long long r_g = RG[q16];
+            const double r_dt = RDT[q16];
+            unsigned pend = (unsigned)__ballot(l < 16 && (r_mode != RQ_NONE || r_zr != 0));
+            auto rl32 = [&](int v, int src) { return __builtin_amdgcn_readlane(v, src); };
 #pragma unroll 1
-            for (int sl = 0; sl < NSLOTS; ++sl) {
-                const int mode = __builtin_amdgcn_readfirstlane(REQI[sl]);
-                const int zr = __builtin_amdgcn_readfirstlane(REQZ[sl]);
-                if (mode == RQ_NONE && !zr) continue;
-                const bool mine = (ord & 3) == w;
-                ord += 1;
-                if (!mine) continue;
-                const long long g = RG[sl];
-                const int cl = __builtin_amdgcn_readfirstlane(RCOL[sl]);
+            while (pend != 0u) {
+                const int sl = __builtin_ctz(pend);
+                pend &= pend - 1u;
+                const int mode = rl32(r_mode, sl);
+                const int zr = rl32(r_zr, sl);
+                const long long g = (long long)(((unsigned long long)(unsigned)rl32((int)((unsigned long long)r_g >> 32), sl) << 32) |
+                                                (unsigned)rl32((int)(unsigned long long)r_g, sl));
+                const int cl = rl32(r_col, sl);
+                const double dt_req = __longlong_as_double((long long)(((unsigned long long)(unsigned)rl32((int)((unsigned long long)__double_as_longlong(r_dt) >> 32), sl) << 32) |
+                                                                       (unsigned)rl32((int)(unsigned long long)__double_as_longlong(r_dt), sl)));
                 double* mbase = p.slot_glob + (size_t)g * (2 * NSLK * H) + l;
                 double* mcur = mbase + (size_t)cl * (NSLK * H);
                 double* mnew = mbase + (size_t)(1 - cl) * (NSLK * H);
                 if (zr) {   // a fresh trajectory: its current mu column starts at zero
-#pragma unroll 8
-                    for (int k = 0; k < NSLK; ++k) mcur[(size_t)k * H] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < QW; ++k) mcur[(size_t)(QW * w + k) * H] = 0.0;
+                    if (2 * w < 7) mcur[(size_t)(H + 2 * w) * H] = 0.0;
+                    if (2 * w + 1 < 7) mcur[(size_t)(H + 2 * w + 1) * H] = 0.0;
                 }
-                const double* fb = fmine + (size_t)sl * NSTC * 4 * H;
+                const double* fb = fmine + (size_t)sl * NSTC * NFAC * H;
                 double hh = 0.0, ll = 0.0;
-                double* a1s = A1S + w * NSTC * H;
+                const double* a1s = A1P + sl * NSTC * H;
+                double* sw = SUMW + (sl * 4 + w) * 2;
+                LS_E0
                 if (mode == RQ_STEP) {
-                    const double ps = slot_pass<S, MASK, 0>(fb, a1s, XF, sl, l, TB + 256, TB + 272, RDT[sl], o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    const double ps = slot_pass<S, MASK, 0>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, dt_req, o.abstol, o.reltol, mcur, mnew, hh, ll);
                     const double tot = group_sum<64>(ps);
-                    if (l == 0) SUMW[sl * 2] = tot;
+                    if (l == 0) sw[0] = tot;
+                    LS_E1(0)
                 } else if (mode == RQ_NORM01) {
-                    slot_pass<1, 1u, 1>(fb, a1s, XF, sl, l, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    slot_pass<1, 1u, 1>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mcur, mnew, hh, ll);
                     group_dd_sum<64>(hh, ll);
-                    if (l == 0) { SUMW[sl * 2] = hh; SUMW[sl * 2 + 1] = ll; }
+                    if (l == 0) { sw[0] = hh; sw[1] = ll; }
                 } else if (mode == RQ_NORM2) {
-                    slot_pass<2, 3u, 2>(fb, a1s, XF, sl, l, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    slot_pass<2, 3u, 2>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mcur, mnew, hh, ll);
                     group_dd_sum<64>(hh, ll);
-                    if (l == 0) { SUMW[sl * 2] = hh; SUMW[sl * 2 + 1] = ll; }
+                    if (l == 0) { sw[0] = hh; sw[1] = ll; }
                 } else if (mode == RQ_FLUSH) {   // the trajectory's gradient row (zeros if it failed)
-                    const bool ok = __builtin_amdgcn_readfirstlane(ROK[sl]) != 0;
+                    const bool ok = rl32(r_ok, sl) != 0;
                     double* row = p.grad_part + (size_t)g * p.n_param;
 #pragma unroll 4
-                    for (int k = 0; k < H; ++k) row[OFF_W2 + l + k * H] = ok ? mcur[(size_t)k * H] : 0.0;
+                    for (int k = QW * w; k < QW * w + QW; ++k) row[OFF_W2 + l + k * H] = ok ? mcur[(size_t)k * H] : 0.0;
                     static_for<0, 7>([&](auto ec) {
                         constexpr int e = decltype(ec)::value;
-                        const int idx = e < 3 ? OFF_W1 + l + e * H : e == 3 ? OFF_B1 + l : e == 4 ? OFF_B2 + l : e == 5 ? OFF_W3 + l : (l == 0 ? OFF_B3 : -1);
-                        if (idx >= 0) row[idx] = ok ? mcur[(size_t)(H + e) * H] : 0.0;
+                        if ((e >> 1) == w) {
+                            const int idx = e < 3 ? OFF_W1 + l + e * H : e == 3 ? OFF_B1 + l : e == 4 ? OFF_B2 + l : e == 5 ? OFF_W3 + l : (l == 0 ? OFF_B3 : -1);
+                            if (idx >= 0) row[idx] = ok ? mcur[(size_t)(H + e) * H] : 0.0;
+                        }
                     });
                 }
             }
         }
+#if defined(LS_EXP) && LS_EXP == 9
+        { const unsigned long long now_ = __builtin_readcyclecounter(); ecyc[3] += now_ - tk; }
+#endif
         __syncthreads();
         LS_TICK(5)
 
@@ -598,7 +640,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
         } else if (ph == PH_INIT0 && ev) {
             // ode_determine_initdt, first half (the slot sums first -- mu == 0: only the g0 terms --, then the replicated components)
             double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
-            h1 = SUMW[slot * 2]; l1 = SUMW[slot * 2 + 1];
+            static_for<0, 4>([&](auto q) { dd_acc(h1, l1, SUMW[(slot * 4 + decltype(q)::value) * 2]); dd_acc(h1, l1, SUMW[(slot * 4 + decltype(q)::value) * 2 + 1]); });
             static_for<0, NC>([&](auto c) {
                 const double sk = __builtin_fma(fabs(lam[c]), o.reltol, o.abstol);
                 const double q0 = lam[c] / sk, q1 = f0l[decltype(c)::value] / sk;
@@ -627,7 +669,8 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
                 ph = PH_INIT1;
             }
         } else if (ph == PH_INIT1 && ev) {
-            double h2 = SUMW[slot * 2], l2 = SUMW[slot * 2 + 1];
+            double h2 = 0.0, l2 = 0.0;
+            static_for<0, 4>([&](auto q) { dd_acc(h2, l2, SUMW[(slot * 4 + decltype(q)::value) * 2]); dd_acc(h2, l2, SUMW[(slot * 4 + decltype(q)::value) * 2 + 1]); });
             static_for<0, NC>([&](auto c) {
                 const double sk = __builtin_fma(fabs(lam[c]), o.reltol, o.abstol);
                 const double q = (kr[c] - f0l[decltype(c)::value]) / sk;
@@ -657,7 +700,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
             } else {
                 nfc += Tab::FSAL ? S - 1 : S;
                 double ss = ssrep;
-                ss += SUMW[slot * 2];
+                ss += ((SUMW[slot * 8] + SUMW[slot * 8 + 2]) + SUMW[slot * 8 + 4]) + SUMW[slot * 8 + 6];
                 const double EEst = __builtin_sqrt(ss / ntot);
                 double q;
                 if (EEst == 0.0) {
@@ -727,6 +770,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     if (p.trace && blockIdx.x == 0 && tid == 0) {
         for (int i = 0; i < 7; ++i) p.trace[i] = (double)tsec[i];
         p.trace[7] = (double)ntrip;
+        for (int i = 0; i < 4; ++i) { p.trace[8 + i] = (double)ecyc[i]; p.trace[12 + i] = (double)ecnt[i]; }
     }
 #endif
 }
