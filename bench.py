@@ -334,7 +334,7 @@ def quick_measure(name, device, steps=3, warmup=1):
     pm = name if name in ("lv_tanh32", "lv_discrete") else wl
     return {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
             "fwd_kernel_ms": f, "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
-            "unit": "mfma-f64" if wl == "kpp" else "valu-f64", "failed_trajectories": int((ens.retcode != 0).sum().item()),
+            "unit": "mfma-f64" if wl == "kpp" else ("mfma-f64 + valu-f64" if wl == "seir" else "valu-f64"), "failed_trajectories": int((ens.retcode != 0).sum().item()),
             "traffic": pmc_any(pm, "`void " + kern + "<"), "setup_s": time.perf_counter() - t_setup}
 
 
@@ -511,8 +511,9 @@ def main():
                        "lane_step_util": lane_step_util, "bwd_attempts_max_over_mean": critical_path,
                        "fwd_kernel_ms": float(np.mean(fwd_ms)),
                        "bwd_kernel_ms": float(np.mean(bwd_ms))},
-            "roofline": {"bound": "mfma", "unit_busy": "mfma-f64" if a.workload == "kpp" else "valu-f64",
-                         "kernel": BWD_KERNEL[a.sensealg] + (", FP64 matrix cores" if a.workload == "kpp" else ", FP64 VALU (no MFMA: 5- and 64-wide layers stay on the vector unit)"),
+            "roofline": {"bound": "mfma", "unit_busy": {"kpp": "mfma-f64", "seir": "mfma-f64 + valu-f64"}.get(a.workload, "valu-f64"),
+                         "kernel": BWD_KERNEL[a.sensealg] + {"kpp": ", FP64 matrix cores", "seir": ", network on the FP64 matrix cores, parameter-slot sums / controller on the FP64 vector unit"}.get(
+                                       a.workload, ", FP64 VALU (no MFMA: 5- and 64-wide layers stay on the vector unit)"),
                          "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": pmc_traffic(a),

@@ -202,9 +202,10 @@ typedef struct {
     int32_t hls;        /* 10 + d (lambaem.jl:20) */
     int32_t adaptive;   /* 1 = LambaEM with error control (lambaem.jl:33); 0 = fixed-step Euler-Maruyama with `dt` */
     int32_t maxiters;   /* step attempts per trajectory, <= 0 -> 1000000 */
-    int32_t max_steps;  /* capacity of the accepted-step store per trajectory (2.2 KB per step); <= 0 = automatic: starts at 512 and is
-                           multiplied by 4 when a trajectory outgrows it (ude_hjb_loss_grad re-runs the call by itself,
-                           ude_hjb_last_failures does it for the asynchronous _dev entry point); loss-only calls record nothing */
+    int32_t max_steps;  /* capacity of the accepted-step store per trajectory (2.2 KB per step); <= 0 = automatic: starts at 512; a trajectory
+                           that outgrows it keeps stepping unrecorded and reports its true count, the capacity becomes the largest
+                           count of the call (+ 1/8) and the call is repeated ONCE (ude_hjb_loss_grad does that by itself,
+                           ude_hjb_last_failures for the asynchronous _dev entry point); loss-only calls record nothing */
     int32_t reserved;
     uint64_t seed;      /* Philox key */
     double lambda;      /* lambaem.jl:12 */
@@ -242,7 +243,7 @@ int ude_hjb_net(ude_ctx* ctx, int32_t d, int32_t hls, const float* theta_sg_host
 int ude_hjb_debug_read(ude_ctx* ctx, int32_t which, int64_t offset_floats, int64_t n_floats, float* out_host);
 /* failure accounting of the most recent ude_hjb_loss_grad_dev call on this context (blocks on its stream): *nfail = trajectories
  * whose retcode is not Success (retcode_dev = the array passed to the call, or NULL for the context's own); if one of them outgrew the
- * AUTOMATIC accepted-step store, its capacity is multiplied by 4 and *grown = 1: the caller repeats the call */
+ * AUTOMATIC accepted-step store, its capacity is raised to the largest accepted-step count of that call (+ 1/8) and *grown = 1: the caller repeats the call */
 int ude_hjb_last_failures(ude_ctx* ctx, const int32_t* retcode_dev, int64_t M, int32_t* nfail, int32_t* grown);
 /* device time (ms) of the forward and backward kernels of the most recent ude_hjb_loss_grad* call (HIP events on the stream) */
 int ude_hjb_last_kernel_ms(ude_ctx* ctx, float* fwd_ms, float* bwd_ms);

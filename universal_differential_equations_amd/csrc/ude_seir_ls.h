@@ -14,10 +14,13 @@
 //   * everything per trajectory that is not a matrix product -- interval lookup and dense-output interpolation of the forward
 //     state, the stage combinations, the error norm, the PI controller, save-point jumps -- runs on the 16-lane ROW that owns
 //     the slot (slot 4w + r on row r of wavefront w), component c on lane c of the row, exactly the Driver's sequence;
-//   * the parameter cotangent stays deferred: every stage leaves its factors (a1 a2 delta1 delta2 per hidden row, x and delta3
-//     per slot) in an L2-resident workspace, and at the end of a step each wavefront forms, slot after slot of its own four,
-//     the RK-weighted sums of the 71 parameter slots per lane, the candidate mu and its share of the error norm with the very
-//     loops of SeirUde<64>::step_slots (mu in HBM, two columns that swap on acceptance).
+//   * the parameter cotangent stays deferred: every stage leaves its factors -- a1 of every (slot, stage) in LDS (64 KB), a2 delta1
+//     delta2 per hidden row in an HBM workspace, x and delta3 per slot in LDS -- and at the end of a step the four wavefronts
+//     form, a quarter of the 71 parameter slots per lane each, the RK-weighted sums, the candidate mu and the slots' share of the
+//     error norm with the very loops of SeirUde<64>::step_slots (mu in HBM, two columns that swap on acceptance);
+//   * the blocks are PERSISTENT: every slot runs the Driver's sequence as its own state machine (initial-dt evaluations, the
+//     stages of a step attempt, the end of the step), one trip of the block's loop = one adjoint evaluation of every busy slot
+//     whatever stage it is at; a slot whose trajectory has ended takes the next one from a global queue.
 // Per trajectory every number -- step counts, dL/du0, each of the 4481 gradient entries -- is bit-identical to the oracle and
 // to adj_kernel<SeirUde<64>>.  Float64, shared time grid, interpolating adjoint with mu under error control (parity mode).
 #pragma once
