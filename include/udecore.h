@@ -46,7 +46,13 @@ enum { UDE_SENSE_INTERPOLATING_ADJOINT = 0, UDE_SENSE_DISCRETE = 1,
         * estimate, no candidate/commit (cheaper steps, not fewer).  Not the step sequence of upstream's InterpolatingAdjoint
         * (which keeps mu in the error norm) -- an opt-in; gradients agree with mode 0 to the solver tolerance.  Shared time
         * grids only (per_trajectory = 0). */
-       UDE_SENSE_INTERPOLATING_ADJOINT_FAST = 2 };
+       UDE_SENSE_INTERPOLATING_ADJOINT_FAST = 2,
+       /* InterpolatingAdjoint(checkpointing = true), as store-u-only + recompute (SURVEY.md 8(b) `store dense|recompute`): the forward
+        * pass keeps (t, t_end, dt, u) of every accepted step instead of u and all stage derivatives -- 1/(1 + stages) of the dense store
+        * (Fisher-KPP 1024 points, Tsit5: 8.2 KB instead of 65.6 KB per step) -- and the adjoint kernel re-runs a step's stages when it
+        * enters its interval.  Same operation sequence on the same inputs: every result is bit-identical to mode 0; the price is
+        * 7 right-hand sides per forward interval.  Instances: the Fisher-KPP UDEs with Tsit5 (shared time grid); else UDE_ERR_UNSUPPORTED */
+       UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED = 3 };
 enum { UDE_ALG_TSIT5 = 0 /* Tsit5() scenario_1.jl:191 */, UDE_ALG_VERN7 = 1 /* Vern7() scenario_1.jl:84 */ };
 /* per-trajectory return codes mirror the SciML retcodes stored in the reference's artifacts */
 enum { UDE_RET_SUCCESS = 0, UDE_RET_MAXITERS = 1, UDE_RET_DTLESSTHANMIN = 2, UDE_RET_UNSTABLE = 3,

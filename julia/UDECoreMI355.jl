@@ -111,9 +111,11 @@ EnsembleMI355(; devices = [0]) = EnsembleMI355(collect(Int, devices))
 algcode(::MI355Tsit5) = Int32(0)
 algcode(::MI355Vern7) = Int32(1)
 # sensealg codes (include/udecore.h): 0 InterpolatingAdjoint (default), 1 discretise-then-optimise (ForwardDiffSensitivity), 2 `fast`
-# (interpolating adjoint with lambda-only error control: opt-in, not upstream's step sequence)
-opts(alg; abstol = 0.0, reltol = 0.0, dtmax = 0.0, dt = 0.0, maxiters = 0, discrete = false, fast = false, per_trajectory = 0, kw...) =
-    SolveOpts(algcode(alg), maxiters, abstol, reltol, dtmax, dt, 0, 0, 0, 0, 0, 0, discrete ? 1 : (fast ? 2 : 0), per_trajectory)
+# (interpolating adjoint with lambda-only error control: opt-in, not upstream's step sequence), 3 InterpolatingAdjoint(checkpointing = true)
+# (store u only, recompute the stages: results identical to 0, an eighth of the dense store; Fisher-KPP UDEs with Tsit5)
+opts(alg; abstol = 0.0, reltol = 0.0, dtmax = 0.0, dt = 0.0, maxiters = 0, discrete = false, fast = false, checkpointing = false,
+     per_trajectory = 0, kw...) =
+    SolveOpts(algcode(alg), maxiters, abstol, reltol, dtmax, dt, 0, 0, 0, 0, 0, 0, discrete ? 1 : (fast ? 2 : (checkpointing ? 3 : 0)), per_trajectory)
 function grid(saveat::Number, tspan)      # SciML: save_end = true for a Number saveat
     ts = collect(tspan[1]:saveat:tspan[2])
     ts[end] < tspan[2] && push!(ts, tspan[2])

@@ -99,7 +99,9 @@ def test_adjoint_work_counts_cross_check(golden):
 
 def test_adam_trajectory_known_answer(golden):
     """App. A.6: Optimisers.ADAM(0.1), callback sees loss(theta_k) before the update (scenario_1.jl:99-114);
-    an adjoint gradient good to 1e-6 reproduces the stored losses[1..3]."""
+    an adjoint gradient good to 1e-6 reproduces the stored losses -- ALL 200 ADAM iterations of the reference's run
+    (losses[0..199]; entry 200 on is BFGS): 200 different parameter vectors, each reached only if every gradient before it was
+    right to ~1e-6.  This is the strongest pin the reference offers for the adjoint (its backward step sequence has no artifact)."""
     g, X, t = s1_setup(golden)
     gold = g["losses"]["data_colmajor"]
     th = np.array(g["initial_parameters"])
@@ -108,9 +110,9 @@ def test_adam_trajectory_known_answer(golden):
     eta, b1, b2, eps = 0.1, 0.9, 0.999, np.finfo(float).eps
     mt, vt = np.zeros_like(th), np.zeros_like(th)
     b1t, b2t = b1, b2
-    for k in range(4):
+    for k in range(200):
         r = O.loss_grad_ensemble(m, o, X[0], [t[0], t[-1]], th, t, X[None])
-        tol = 1e-11 if k == 0 else 2e-6
+        tol = 1e-11 if k < 2 else 5e-6
         assert abs(r["loss"] - gold[k]) < tol * gold[k], (k, r["loss"], gold[k])
         gr = r["grad_theta"]
         mt = b1 * mt + (1 - b1) * gr
@@ -250,9 +252,9 @@ def test_adam_trajectory_with_discrete_gradient(golden):
     m, o = O.lv_ude_s1(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=1)
     eta, b1, b2, eps = 0.1, 0.9, 0.999, np.finfo(float).eps
     mt, vt, b1t, b2t = np.zeros_like(th), np.zeros_like(th), b1, b2
-    for k in range(4):
+    for k in range(200):   # (all of the reference's ADAM iterations: losses[0..199])
         r = O.loss_grad_ensemble(m, o, X[0], [t[0], t[-1]], th, t, X[None])
-        assert abs(r["loss"] - gold[k]) < (1e-11 if k == 0 else 2e-6) * gold[k], (k, r["loss"], gold[k])
+        assert abs(r["loss"] - gold[k]) < (1e-11 if k < 2 else 5e-6) * gold[k], (k, r["loss"], gold[k])
         gr = r["grad_theta"]
         mt = b1 * mt + (1 - b1) * gr
         vt = b2 * vt + (1 - b2) * gr * gr

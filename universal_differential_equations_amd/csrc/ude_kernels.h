@@ -69,6 +69,9 @@ struct KParams {
     // per-trajectory time grids (kernels instantiated with PT = true): tspan_pt = 2 x N, saveat = ns x N when saveat_pt
     const double* tspan_pt;   // (2 x N doubles, as the host holds them)
     int32_t saveat_pt, dtmax_auto;
+    // checkpointed adjoint (UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED): the forward store keeps (t, t_end, dt, u) of every accepted
+    // step and NOT its stage derivatives; the adjoint kernel recomputes them when it enters an interval (AdjSys::RECOMPUTE)
+    int32_t ckpt, pad_;
 };
 
 
@@ -658,9 +661,9 @@ struct FwdSys {
         }
         if (p->dense) {
             if (uni(nsteps >= p->cap)) return RET_DENSE_OVERFLOW;
-            lazy();
+            if (!p->ckpt) lazy();
             {
-                const int nf = 3 + n + Tab::NK * n;
+                const int nf = p->ckpt ? 3 + n : 3 + n + Tab::NK * n;
                 real* base = p->dense + ((size_t)nsteps * nf) * p->Npad + j;
                 if (writer) {
                     base[0] = tprev;
@@ -672,10 +675,11 @@ struct FwdSys {
                     const real zo = own_of<NR>(reinterpret_cast<const real(&)[NR]>(*z));
                     if (r < n) {
                         base[(size_t)(3 + r) * p->Npad] = zo;
-                        static_for<0, Tab::NK>([&](auto q) { base[(size_t)(3 + n + q * n + r) * p->Npad] = k1(q); });
+                        if (!p->ckpt) static_for<0, Tab::NK>([&](auto q) { base[(size_t)(3 + n + q * n + r) * p->Npad] = k1(q); });
                     }
                 } else {
                 static_for<0, NR>([&](auto c) { if (cwrite(c)) base[(size_t)(3 + comp(c)) * p->Npad] = z[c]; });
+                if (!p->ckpt)
                 static_for<0, Tab::NK>([&](auto q) {
                     // every stage is stored (the discrete adjoint needs k2, k3, k10 too, not only the dense-output ones)
                     static_for<0, NR>([&](auto c) {
@@ -800,6 +804,13 @@ struct AdjSys {
     __device__ __forceinline__ real dtmax(const OptsR& o) const { return tg.DTMAX(o); }
     static constexpr bool DEFERRED = Model::DEFERRED;
     static constexpr bool FAST = (VAR == 3);  // UDE_SENSE_FAST: lambda-only error control
+    // VAR == 5: InterpolatingAdjoint(checkpointing = true) in its store-u-only form.  The forward store holds (t, t_end, dt, u)
+    // per accepted step; entering an interval the kernel re-runs that step's stages from u with the stored dt -- the SAME
+    // operation sequence as Driver::run's perform_step on the same inputs, so the recomputed k are the forward pass's k bit for
+    // bit and every result equals the dense-store mode's.  Distributed-state FSAL systems (Fisher-KPP with Tsit5).
+    static constexpr bool RECOMPUTE = (VAR == 5);
+    static_assert(!RECOMPUTE || (Model::STATE_DISTRIBUTED && Tab::FSAL && Tab::NK == Tab::S && !Model::CPL),
+                  "recompute mode: distributed state, FSAL tableau whose dense output uses the step's own stages");
     static constexpr int NR = Model::NS, NSL = (DEFERRED || VAR == 9) ? 0 : Model::NSL;
     static constexpr bool STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     // LDS-slot models re-evaluate stage 0 every step (its parameter cotangent is folded straight into the shared
@@ -875,11 +886,32 @@ struct AdjSys {
             }
         }
         sf = s;
-        const int nf = 3 + n + Tab::NK * n;
+        const int nf = RECOMPUTE ? 3 + n : 3 + n + Tab::NK * n;
         const real* base = p->dense + ((size_t)s * nf) * p->Npad + j;
         ts = base[0];
         te = base[(size_t)1 * p->Npad];
-        if constexpr (IC_LDS) {
+        if constexpr (RECOMPUTE) {
+            const real dtf = base[(size_t)2 * p->Npad];   // the step size the forward pass used (t_end may be a snapped tstop)
+            static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p->Npad] : 0.0; });
+            static_for<0, Tab::NK>([&](auto q) { static_for<0, NR>([&](auto c) { ks[q][c] = 0.0; }); });
+            const TabDevT<real>* tab = p->tab;
+            static_for<0, Tab::S>([&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                real zs[NR], kr[NR];
+                if constexpr (st == 0) {
+                    static_for<0, NR>([&](auto c) { zs[c] = us[c]; });
+                } else {
+                    static_for<0, NR>([&](auto c) {   // Driver::run: all S - 1 terms, zero coefficients (and zero k) contribute exactly nothing
+                        real acc = tab->A[st][0] * ks[0][c];
+                        static_for<1, Tab::S - 1>([&](auto jc) { acc = rfma(tab->A[st][decltype(jc)::value], ks[decltype(jc)::value][c], acc); });
+                        zs[c] = rfma(dtf, acc, us[c]);
+                    });
+                }
+                asm volatile("" ::: "memory");
+                Model::rhs(mctx, zs, kr);
+                static_for<0, NR>([&](auto c) { ks[st][c] = kr[c]; });
+            });
+        } else if constexpr (IC_LDS) {
             // the G lanes of the group fetch the fields round-robin and publish them in the group's LDS row
             asm volatile("" ::: "memory");
             if constexpr (G > 64) __syncthreads();  // (block-uniform: t is replicated) readers of the old row are done

@@ -640,6 +640,7 @@ struct KppTrue : LinearTheta {
 // over the points in ascending order -- the oracle's order, so the result is bit-identical.
 template <class Net, int G, int PPL>
 struct KppUde : LinearTheta {
+    static constexpr bool RECOMPUTE_OK = true;   // checkpointed adjoint available (AdjSys::RECOMPUTE)
     static __host__ __device__ constexpr int point(int c, int r) { return c * G + r; }
     using Mlp = CoopMlp<Net, 1>;
     static_assert(Net::dim(0) == 1 && Net::dim(Net::L) == 1, "pointwise reaction network R -> R");
@@ -830,6 +831,7 @@ struct KppUde : LinearTheta {
 // ---------------------------------------------------------------------------------------------
 template <class Net>
 struct KppUdeW : LinearTheta {
+    static constexpr bool RECOMPUTE_OK = true;   // checkpointed adjoint available (AdjSys::RECOMPUTE)
     static constexpr int G = 256, PPL = 4, NWV = 4, TP = 64, BLK = 256, NTILE = BLK / 16;
     static constexpr bool DADJ_K_FROM_DENSE = true;  // (k and kbar of a 1024-point state do not both fit next to the tiles)
     static __host__ __device__ constexpr int point(int c, int r) { return (r >> 6) * BLK + c * TP + (r & 63); }

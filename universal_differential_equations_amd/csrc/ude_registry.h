@@ -11,6 +11,7 @@ struct Launch {
     void (*rhs)(const KParams);   // one right-hand-side evaluation per state
     void (*fwd_pt)(const KParams), (*adj_pt)(const KParams), (*dadj_pt)(const KParams);  // per-trajectory tspan / saveat
     void (*adj_fast)(const KParams);  // UDE_SENSE_FAST: lambda-only error control (shared time grid only)
+    void (*adj_ckpt)(const KParams);  // checkpointed adjoint: store u only, recompute the stages (null: no such instance)
     int nf;  // dense fields per step
     int G, block;
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
@@ -31,6 +32,10 @@ struct Launch {
 template <class M, class = void> struct no_dadj { static constexpr bool v = false; };
 template <class M> struct no_dadj<M, std::void_t<decltype(M::NO_DADJ)>> { static constexpr bool v = M::NO_DADJ; };
 
+// models that declare Model::RECOMPUTE_OK get the checkpointed-adjoint kernel (store u only, recompute the stages) for FSAL tableaux
+template <class M, class = void> struct recompute_ok { static constexpr bool v = false; };
+template <class M> struct recompute_ok<M, std::void_t<decltype(M::RECOMPUTE_OK)>> { static constexpr bool v = M::RECOMPUTE_OK; };
+
 template <class Model, class Tab, int G, int BLOCK = 64, int VAR = 1, class RTag = real>
 inline Launch make_launch() {
     Launch l;
@@ -42,6 +47,9 @@ inline Launch make_launch() {
     l.fwd_pt = fwd_kernel<Model, Tab, G, BLOCK, true>;
     l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true, VAR>;
     l.adj_fast = adj_kernel<Model, Tab, G, BLOCK, false, 3>;
+    if constexpr (recompute_ok<Model>::v && Tab::FSAL && Tab::NK == Tab::S)
+        l.adj_ckpt = adj_kernel<Model, Tab, G, BLOCK, false, 5>;
+    else l.adj_ckpt = nullptr;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;

@@ -514,6 +514,8 @@ extern "C" int ude_model_supported(ude_ctx* c, const ude_model_desc* m, const ud
     bool generic = false;
     const int rc = resolve(c, m, o, l, G, &generic);
     if (rc) return rc;
+    if (need_adjoint && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED && (!l.adj_ckpt || o->per_trajectory))
+        return UDE_ERR_UNSUPPORTED;
     if (need_adjoint && o->sensealg == UDE_SENSE_DISCRETE && !l.dadj)
         return fail(c, UDE_ERR_UNSUPPORTED, "the runtime-shape kernel has no discretise-then-optimise sweep: use the interpolating adjoint");
     return generic ? 1 : UDE_OK;   // 0: compiled fast instance, 1: runtime-shape fallback kernel
@@ -682,7 +684,9 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         ude_seir_ls_get(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &ls_fac);
         if (nwaves < N) nwaves = N;   // one gradient row per trajectory
     }
-    const int nf = 3 + n + l.nf * n;
+    const bool ckpt = o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED;
+    const int nf = ckpt ? 3 + n : 3 + n + l.nf * n;   // dense fields per accepted step (checkpointed: t, t_end, dt, u)
+    p.ckpt = ckpt ? 1 : 0;
     p.N = N;
     p.Npad = (N + 7) / 8 * 8;
     p.ns = ns;
@@ -726,11 +730,14 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.grad_u0 = grad_u0;
     const bool discrete = o->sensealg == UDE_SENSE_DISCRETE;
     const bool fast = o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST;
-    if (o->sensealg != UDE_SENSE_INTERPOLATING_ADJOINT && !discrete && !fast) return fail(c, UDE_ERR_INVALID, "unknown sensealg %d", o->sensealg);
+    if (o->sensealg != UDE_SENSE_INTERPOLATING_ADJOINT && !discrete && !fast && !ckpt) return fail(c, UDE_ERR_INVALID, "unknown sensealg %d", o->sensealg);
     if ((rc = setup_time_grids(c, o, N, tspan, p))) return rc;
     const bool pt = o->per_trajectory != 0;
     if (fast && pt) return fail(c, UDE_ERR_UNSUPPORTED, "UDE_SENSE_INTERPOLATING_ADJOINT_FAST has no per-trajectory time-grid instances");
-    void (*bwd)(const KParams) = discrete ? (pt ? l.dadj_pt : l.dadj) : fast ? l.adj_fast : (pt ? l.adj_pt : l.adj);
+    if (ckpt && (pt || !l.adj_ckpt))
+        return fail(c, UDE_ERR_UNSUPPORTED, "the checkpointed adjoint (store u only, recompute the stages) exists for the Fisher-KPP UDEs with Tsit5 "
+                                            "on a shared time grid");
+    void (*bwd)(const KParams) = discrete ? (pt ? l.dadj_pt : l.dadj) : fast ? l.adj_fast : ckpt ? l.adj_ckpt : (pt ? l.adj_pt : l.adj);
     if (!bwd) return fail(c, UDE_ERR_UNSUPPORTED, "the runtime-shape kernel has no discretise-then-optimise sweep: use the interpolating adjoint");
     void (*kfwd)(const KParams) = pt ? l.fwd_pt : l.fwd;
     const size_t shmem_f = l.lds_bytes(np, false);

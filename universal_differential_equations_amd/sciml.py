@@ -32,11 +32,14 @@ class Vern7:
 
 class InterpolatingAdjoint:
     """sensealg = InterpolatingAdjoint(autojacvec = ReverseDiffVJP())  (seir_exposure.jl:140).
-    autojacvec is accepted and ignored: the VJP is hand-derived inside the fused kernel."""
+    autojacvec is accepted and ignored: the VJP is hand-derived inside the fused kernel.
+    checkpointing = True selects UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED: the forward pass stores (t, dt, u) of every accepted
+    step only, the adjoint kernel recomputes a step's stages when it enters its interval -- results bit-identical to the dense
+    store, 1 / (1 + stages) of its memory.  Instances: the Fisher-KPP UDEs with Tsit5 (the stiff 1024-point variant is what needs
+    it); anything else fails with UDE_ERR_UNSUPPORTED."""
 
     def __init__(self, autojacvec=None, checkpointing=False):
-        if checkpointing:
-            raise NotImplementedError("checkpointing=true is not used by the reference and not built")
+        self.checkpointing = bool(checkpointing)
 
 
 class ReverseDiffVJP:
@@ -166,7 +169,8 @@ class Engine:
 def _opts(alg, abstol=None, reltol=None, dtmax=None, dt=None, maxiters=None, sensealg=None, **kw):
     o = SolveOpts()
     o.alg = alg.alg if not isinstance(alg, int) else alg
-    o.sensealg = 1 if isinstance(sensealg, ForwardDiffSensitivity) else 2 if isinstance(sensealg, FastInterpolatingAdjoint) else 0
+    o.sensealg = (1 if isinstance(sensealg, ForwardDiffSensitivity) else 2 if isinstance(sensealg, FastInterpolatingAdjoint)
+                  else 3 if getattr(sensealg, "checkpointing", False) else 0)
     o.abstol = abstol or 0.0
     o.reltol = reltol or 0.0
     o.dtmax = dtmax or 0.0
