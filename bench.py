@@ -152,14 +152,24 @@ def run_hjb(a, rank, world, local, device, dist):
     prob = pde.TerminalPDEProblem(pde.hjb(1.0), np.zeros(100), (0.0, 1.0))
     bs = pde.DeviceBSDE(prob, alg, pde.LambaEM(), M, device=device, abstol=a.tol, reltol=a.tol, seed=1234 + rank, max_steps=a.max_steps)
     theta = torch.tensor(theta_h, device=device)
-    buf = torch.zeros(bs.np + 1, dtype=torch.float32, device=device)
+    # mean over all ranks' trajectories: ONE all-reduce of [grad; loss].  --allreduce udecore: through libudecore's own RCCL binding
+    # (ude_allreduce_grad on double[np + 1], what a non-Python host calls), bootstrapped over the torch.distributed group
+    comm = None
+    if dist is not None and a.allreduce == "udecore":
+        from universal_differential_equations_amd.parallel import Comm
+        comm = Comm.from_torch_dist(bs.eng, dist)
+    buf = torch.zeros(bs.np + 1, dtype=torch.float64 if comm is not None else torch.float32, device=device)
 
     def step(it=0):
         loss, g = bs.loss_grad(theta, it=it)
-        if dist is not None:   # mean over all ranks' trajectories: one all-reduce of [grad; loss]
+        if dist is not None:
             buf[:-1] = g
-            buf[-1] = loss[0].to(torch.float32)
-            dist.all_reduce(buf)
+            buf[-1] = loss[0].to(buf.dtype)
+            if comm is not None:
+                bs.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+                comm.allreduce(buf)
+            else:
+                dist.all_reduce(buf)
             buf.div_(world)
         return loss
 
@@ -376,9 +386,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("UDE_BENCH_FORCE_DIST"):   # (FORCE_DIST: a one-rank group, so that a 1-GPU box exercises the collective code)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("UDE_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)

@@ -28,3 +28,22 @@ def test_bench_two_ranks_on_one_gpu():
     # whole-job value: both ranks' evaluations over the slower rank's time
     per_rank = d["config"]["evals_per_step_fwd"] + d["config"]["evals_per_step_bwd"]
     assert d["value"] > per_rank * 3 / (d["ms_per_step"] * 3e-3) * 1.5
+
+
+@pytest.mark.parametrize("workload", ["hjb", "lv"])
+def test_bench_collective_through_libudecore_single_rank(workload):
+    """`bench.py --allreduce udecore`: the one all-reduce per gradient through libudecore's own RCCL binding (ude_comm_create from a
+    unique id + ude_allreduce_grad on the context's stream) instead of torch.distributed -- what a non-Python host calls.  RCCL
+    wants one device per rank, so on a one-GPU box this is a ONE-rank communicator (UDE_BENCH_FORCE_DIST=1): the binding, the
+    payload packing and the mean over ranks run, the numbers must equal the plain single-process run."""
+    env = dict(os.environ, UDE_BENCH_FORCE_DIST="1", UDE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    extra = ["--workload", "hjb", "--traj", "2048"] if workload == "hjb" else ["--traj", "2000"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-others",
+           "--allreduce", "udecore"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["failed_trajectories"] == 0
