@@ -129,7 +129,12 @@ int ude_version(void);
 int ude_create(int32_t device_id, ude_ctx** out);
 void ude_destroy(ude_ctx* ctx);
 const char* ude_last_error(ude_ctx* ctx);
-/* stream on which the _dev entry points enqueue (a hipStream_t); NULL = the null stream */
+/* stream on which the _dev entry points enqueue (a hipStream_t); NULL = the null stream.  Rebinding orders the new stream behind the
+ * work already enqueued on the old one (an event; if the old stream no longer exists: a device synchronise).
+ * hipGraph capture: the _dev entry points may be captured on the bound stream (the per-kernel timing events are left out).  A captured
+ * graph bakes in the context's workspaces: while it is alive, use the context only with the SAME problem sizes (nothing may make the
+ * workspaces grow -- a larger ensemble, an automatic dense-store regrowth after UDE_RET_DENSE_OVERFLOW) and do not run ordinary calls of
+ * the same context on another stream concurrently with a replay: the library keeps no ordering between them. */
 int ude_set_stream(ude_ctx* ctx, void* hip_stream);
 int ude_set_launch_opts(ude_ctx* ctx, const ude_launch_opts* lo);
 /* 0: this (model, alg) runs on a compiled fast instance; 1: it runs on the runtime-shape fallback kernel (any chain of <= 8 Dense
