@@ -1064,7 +1064,8 @@ static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const
     FN(ropts) r;
     FN(resolve_opts)(o, t0, tf, &r);
     if (o->sensealg == UDEO_SENSE_FAST) r.nerr = n; /* lambda-only error control */
-    r.dt0 = 0;
+    /* a user `dt` reaches the adjoint solve too: _concrete_solve_adjoint hands the solve's keyword arguments on to
+     * adjoint_sensitivities -> solve(adj_prob, alg; abstol, reltol, kwargs...) [UP?]; OrdinaryDiffEq takes dt = tdir * abs(dt) */
     ret = FN(integrate)(&r, nz, FN(adj_rhs), &ac, z, tf, tst, nt, 0, 0, FN(adj_tstop), &ac,
                         &stats[4], &stats[5], &stats[6], 0);
     for (int i = 0; i < np; ++i) grad_theta[i] += z[n + i];

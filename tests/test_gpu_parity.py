@@ -333,6 +333,74 @@ def test_seir_lockstep_kernel_partial_blocks_and_single_trajectory(N):
     test_seir_ude_forward_and_adjoint_match_oracle(U.Vern7, O.VERN7, 16, N=N)
 
 
+def _seir_ls_setup(N, seed=11):
+    u0, t = seir_inputs(N)
+    th = models.seir_chain().glorot_uniform(np.random.default_rng(seed))
+    th[-65:-1] *= 10.0
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 21.0), th), u0)
+    return u0, t, th, ens
+
+
+def test_seir_lockstep_kernel_user_cotangent_and_fixed_initial_dt():
+    """the lock-step backward kernel behind ude_vjp_ensemble (a user cotangent instead of data: Zygote's pullback of
+    concrete_solve, seir_exposure.jl:138-140) and with `dt = ...` given (no initial-dt evaluations: the slots start in stage 0)"""
+    N = 21
+    u0, t, th, ens = _seir_ls_setup(N)
+    cot = np.random.default_rng(5).normal(size=(N, len(t), 7)) * 1e-6
+    kw = {"ensemblealg": U.EnsembleMI355(16)}
+    r = U.adjoint_pullback(ens, U.Vern7(), cot, saveat=t, abstol=1e-6, reltol=1e-6, **kw)
+    ref = O.vjp_ensemble(O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6), u0, [0.0, 21.0], th, t, cot, nthreads=4)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    r = U.loss_and_gradient(ens, U.Tsit5(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6, dt=0.05, **kw)
+    ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(O.TSIT5, 1e-6, 1e-6, dt0=0.05), u0, [0.0, 21.0], th, t, truth, row_mask=mask, nthreads=4)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
+
+
+def test_user_dt_reaches_the_adjoint_solve_in_every_kernel_family(golden):
+    """`dt = ...` is a keyword of the solve; _concrete_solve_adjoint hands the keywords on to the adjoint solve [UP?]: both passes
+    start from it (the backward one with dt = tdir * |dt|).  LV (lane groups), SEIR one wavefront per trajectory, Fisher-KPP."""
+    g, X, t = s1_data(golden)
+    th = np.array(g["trained_parameters"])
+    u0 = ensemble_u0(X, 24, 5)
+    data = np.repeat(X[None], 24, axis=0)
+    ens = U.EnsembleProblem(U.ODEProblem(models.ude_dynamics(), u0[0], (t[0], t[-1]), th), u0)
+    r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, abstol=1e-6, reltol=1e-6, dt=0.01)
+    ref = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(O.TSIT5, 1e-6, 1e-6, dt0=0.01), u0, [t[0], t[-1]], th, t, data, nthreads=4)
+    check_per_trajectory(r, ref)
+    us, ts_, ths, enss = _seir_ls_setup(6)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), us, [0.0, 21.0], [], ts_)
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    r = U.loss_and_gradient(enss, U.Vern7(), truth, row_mask=mask, saveat=ts_, abstol=1e-6, reltol=1e-6, dt=0.02, ensemblealg=U.EnsembleMI355(64))
+    ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6, dt0=0.02), us, [0.0, 21.0], ths, ts_, truth, row_mask=mask, nthreads=4)
+    check_per_trajectory(r, ref)
+    thk, u0k, tk, truthk = kpp_case(26, 3, models.kpp_chain(), None)
+    ensk = U.EnsembleProblem(U.ODEProblem(models.nn_ode(26), u0k[0], (0.0, 5.0), thk), u0k)
+    r = U.loss_and_gradient(ensk, U.Tsit5(), truthk, saveat=tk, dt=0.003)
+    ref = O.loss_grad_ensemble(O.kpp_ude(26), O.opts(O.TSIT5, dt0=0.003), u0k, [0.0, 5.0], thk, tk, truthk)
+    check_per_trajectory(r, ref)
+
+
+def test_seir_lockstep_kernel_backward_failures_are_reported_per_trajectory():
+    """maxiters small enough that every backward solve stops early: retcode MaxIters for each trajectory, zero gradient rows,
+    loss +Inf -- and the block's slots still hand themselves on to the rest of the ensemble (40 trajectories on 16 slots)"""
+    N = 40
+    u0, t, th, ens = _seir_ls_setup(N)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    r = U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6, maxiters=25,
+                            ensemblealg=U.EnsembleMI355(16), allow_failures=True)
+    ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6, maxiters=25), u0, [0.0, 21.0], th, t, truth, row_mask=mask, nthreads=4)
+    assert_bitwise(r.retcode, ref["retcode"], "retcodes")
+    assert (r.retcode != 0).all() and np.isinf(r.loss) and not r.grad_theta.any()
+    assert_bitwise(r.stats[:, [0, 1, 2, 4, 5, 6]], ref["stats"][:, [0, 1, 2, 4, 5, 6]], "work counts of the stopped solves")
+
+
 def kpp_case(nx, N, chain, omodel, seed=4):
     rng = np.random.default_rng(seed)
     th = models.kpp_theta(chain, rng)
