@@ -193,3 +193,87 @@ def test_ragged_large_fisher_kpp_grids_match_oracle(nx):
         assert (r.retcode == 0).all()
         check_per_trajectory(r, ref)
         assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) <= REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+
+
+@pytest.mark.parametrize("seed", range(18))
+def test_random_solver_keywords_match_oracle(golden, seed):
+    """the solve keywords the scripts can pass besides the tolerances -- dt, dtmax, qmin / qmax / gamma, beta1 / beta2, qoldinit --
+    over every kernel family: LV lane groups, the SEIR kernels (one wavefront per trajectory, and the lock-step matrix-core
+    backward kernel), the runtime-shape fallback, Fisher-KPP with the dense store and with the checkpointed adjoint; loss + gradient
+    or a user cotangent.  Both solves of a gradient receive the keywords (the backward one with dt = tdir |dt|)."""
+    rng = np.random.default_rng(5000 + seed)
+    fam = ["lv", "seir64", "seirls", "generic", "kpp", "kppck"][seed % 6]
+    okw, kw = {}, {}
+    if rng.random() < 0.6:
+        kw["dt"] = okw["dt0"] = float(10.0 ** rng.uniform(-3, -1))
+    if rng.random() < 0.5:
+        kw["dtmax"] = okw["dtmax"] = float(rng.uniform(0.05, 0.5))
+    if rng.random() < 0.5:
+        kw["qmax"] = okw["qmax"] = float(rng.choice([2.0, 5.0, 20.0]))
+        kw["qmin"] = okw["qmin"] = float(rng.choice([0.1, 0.2, 0.5]))
+    if rng.random() < 0.5:
+        kw["gamma"] = okw["gamma"] = float(rng.uniform(0.7, 0.95))
+    if rng.random() < 0.4:
+        kw["beta1"] = okw["beta1"] = float(rng.uniform(0.08, 0.2))
+        kw["beta2"] = okw["beta2"] = float(rng.uniform(0.0, 0.08)) or 0.04
+    if rng.random() < 0.3:
+        kw["qoldinit"] = okw["qoldinit"] = float(10.0 ** rng.uniform(-5, -2))
+    alg, oalg = ((U.Tsit5, O.TSIT5), (U.Vern7, O.VERN7))[int(rng.integers(2))]
+    tol = float(10.0 ** rng.uniform(-8, -5))
+    ealg, sense, osense, mask = None, None, 0, None
+    if fam == "lv":
+        g = golden("Scenario_1_recovery_0.005")
+        f, om = models.ude_dynamics(), O.lv_ude_s1()
+        th = np.array(g["trained_parameters"]) * (1 + 0.05 * rng.standard_normal(87))
+        N = int(rng.integers(1, 30))
+        u0 = np.array([0.44249296, 4.6280594]) * (1 + 0.3 * rng.uniform(-1, 1, (N, 2)))
+        tf = float(rng.uniform(0.5, 3.0))
+    elif fam in ("seir64", "seirls", "generic"):
+        if fam == "generic":
+            dims, acts = [3, 16, 33, 1], ["tanh", "rbf", "identity"]
+            chain = models.Chain(*[models.Dense(dims[i], dims[i + 1], acts[i]) for i in range(3)])
+            f, om = models.dudt_(chain), O.make_model(O.KIND_SEIR_UDE, 7, dims, acts, consts=O.SEIR_P)
+            th = chain.glorot_uniform(rng)
+        else:
+            f, om = models.dudt_(), O.seir_ude()
+            th = models.seir_chain().glorot_uniform(rng) * float(rng.uniform(0.5, 2.0))
+            ealg = U.EnsembleMI355(64 if fam == "seir64" else 16)
+        S0 = float(10.0 ** rng.uniform(2, 7))
+        N = int(rng.integers(1, 20))
+        u0 = np.zeros((N, 7))
+        u0[:, 0] = rng.uniform(0.8, 0.95, N) * S0
+        u0[:, 1] = rng.uniform(0.0, 5.0, N)
+        u0[:, 4] = S0
+        tf = float(rng.uniform(2.0, 8.0))
+        mask = [0, 1, 1, 1, 0, 0, 0]
+    else:
+        nx = 26
+        chain = models.kpp_chain()
+        f, om = models.nn_ode(nx, chain), O.kpp_ude(nx)
+        th = models.kpp_theta(chain, rng)
+        N = int(rng.integers(1, 5))
+        u0 = np.clip(models.rho0(nx)[None, :] * (1 + 0.2 * rng.uniform(-1, 1, (N, 1))), 0, None)
+        tf = float(rng.uniform(0.5, 3.0))
+        alg, oalg = U.Tsit5, O.TSIT5
+        tol = float(10.0 ** rng.uniform(-7, -3))
+        if fam == "kppck":
+            sense = U.InterpolatingAdjoint(checkpointing=True)     # (the oracle has one mode: the results are the dense store's)
+    n = u0.shape[1]
+    grid = np.unique(np.concatenate([[0.0], np.sort(rng.uniform(0.0, tf, int(rng.integers(1, 8)))), [tf]]))
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, tf), th), u0)
+    oo = O.opts(oalg, tol, tol, sensealg=osense, **okw)
+    what = "seed %d: %s %s tol %.1e N %d ns %d kw %s" % (seed, fam, alg.__name__, tol, N, len(grid), kw)
+    if rng.random() < 0.35:
+        cot = rng.standard_normal((N, len(grid), n)) * (1e-6 if fam.startswith("seir") or fam == "generic" else 1.0)
+        r = U.adjoint_pullback(ens, alg(), cot, saveat=grid, abstol=tol, reltol=tol, sensealg=sense, ensemblealg=ealg, **kw)
+        ref = O.vjp_ensemble(om, oo, u0, [0.0, tf], th, grid, cot, nthreads=8)
+    else:
+        data = u0[:, None, :] * (1 + 0.05 * rng.standard_normal((N, len(grid), n)))
+        r = U.loss_and_gradient(ens, alg(), data, row_mask=mask, saveat=grid, abstol=tol, reltol=tol, sensealg=sense, ensemblealg=ealg, **kw)
+        ref = O.loss_grad_ensemble(om, oo, u0, [0.0, tf], th, grid, data, row_mask=mask, nthreads=8)
+        if not fam.startswith("kpp"):   # (a distributed state sums its loss over lanes: association differs from the oracle's)
+            assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], what)
+    assert (r.retcode == 0).all() and (ref["retcode"] == 0).all(), what
+    check_per_trajectory(r, ref)
+    gn = np.linalg.norm(ref["grad_theta"])
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) <= REL_GRAD_SUM * max(gn, 1e-300), what
