@@ -386,6 +386,42 @@ def test_user_dt_reaches_the_adjoint_solve_in_every_kernel_family(golden):
     check_per_trajectory(r, ref)
 
 
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+def test_seir_lockstep_forward_kernel_plain_solves(alg, oalg):
+    """the forward lock-step kernel (csrc/ude_seir_ls_fwd.h) without a dense store: a ragged save grid that contains neither end
+    point (Vern7 builds its six lazy stages only in steps with a save point strictly inside), a given dt (Tsit5: the FSAL
+    evaluation comes first), 41 trajectories on 16-slot blocks; and solves that stop at maxiters"""
+    N = 41
+    u0, _, th, _ = _seir_ls_setup(N)
+    grid = np.array([0.37, 2.0, 2.5, 7.25, 11.0, 19.99])
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 21.0), th), u0)
+    for kw, okw in (({}, {}), ({"dt": 0.03}, {"dt0": 0.03}), ({"maxiters": 7}, {"maxiters": 7})):
+        sol = U.solve(ens, alg(), saveat=grid, abstol=1e-6, reltol=1e-6, ensemblealg=U.EnsembleMI355(16), **kw)
+        out, st, rc = O.solve_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6, **okw), u0, [0.0, 21.0], th, grid)
+        assert_bitwise(sol.retcodes, rc, "retcodes %s" % kw)
+        assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts incl. lazy stages %s" % kw)
+        if "maxiters" in kw:
+            assert (rc != 0).all()
+        else:
+            assert (rc == 0).all()
+            assert_bitwise(sol.u, out, "states %s" % kw)
+
+
+def test_seir_lockstep_forward_kernel_dense_overflow_matches_the_wavefront_kernel():
+    """a dense store of 4 steps: every trajectory stops with DenseOverflow after its fourth accepted step, with the same
+    counters whichever forward kernel ran"""
+    N = 19
+    u0, t, th, ens = _seir_ls_setup(N)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    res = [U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6,
+                               ensemblealg=U.EnsembleMI355(lanes, 4), allow_failures=True) for lanes in (16, 64)]
+    assert (res[0].retcode != 0).all()
+    assert_bitwise(res[0].retcode, res[1].retcode, "retcodes")
+    assert_bitwise(res[0].stats, res[1].stats, "counters")
+    assert np.isinf(res[0].loss) and not res[0].grad_theta.any()
+
+
 def test_seir_lockstep_kernel_backward_failures_are_reported_per_trajectory():
     """maxiters small enough that every backward solve stops early: retcode MaxIters for each trajectory, zero gradient rows,
     loss +Inf -- and the block's slots still hand themselves on to the rest of the ensemble (40 trajectories on 16 slots)"""

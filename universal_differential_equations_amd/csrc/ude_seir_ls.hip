@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ude_seir_ls.h"
+#include "ude_seir_ls_fwd.h"
 
 using namespace ude;
 
@@ -16,4 +17,10 @@ extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, i
         *lds_bytes = sizeof(double) * seirls::lds_doubles<Tsit5Tab>() + 16;
         *fac_doubles_per_block = seirls::fac_doubles_per_block<Tsit5Tab>();
     }
+}
+
+// the forward solve on the same architecture (ude_seir_ls_fwd.h)
+extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes) {
+    *kern = alg == 1 ? seirls::seir_ls_fwd_kernel<Vern7Tab> : seirls::seir_ls_fwd_kernel<Tsit5Tab>;
+    *lds_bytes = sizeof(double) * seirls::fwd_lds_doubles() + 16;
 }
