@@ -305,16 +305,19 @@ static int generic_id(const ude_model_desc* m) {
 
 // blocks of the lock-step SEIR backward kernel: 16 trajectory slots each, at most one block per compute unit (the slots refill
 // from a queue)
-static int64_t ls_blocks(ude_ctx* c, int64_t N) {
+static int64_t ls_blocks(ude_ctx* c, int64_t N, int per_cu = 1) {
     if (c->ncu <= 0) {
         hipDeviceProp_t prop;
         c->ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const int64_t nb = (N + 15) / 16;
-    return nb < c->ncu ? nb : c->ncu;
+    return nb < (int64_t)per_cu * c->ncu ? nb : (int64_t)per_cu * c->ncu;
 }
 #ifndef UDE_SEIR_LS_DEFAULT
 #define UDE_SEIR_LS_DEFAULT 1   // 1: the lock-step matrix-core backward kernel is the default for the SEIR exposure UDE
+#endif
+#ifndef UDE_SEIR_LS_FWD_PER_CU
+#define UDE_SEIR_LS_FWD_PER_CU 1   // resident blocks of the forward lock-step kernel per compute unit (two, at 256 registers: 3.8 instead of 2.7 ms -- spills)
 #endif
 #ifndef UDE_SEIR_LS_FWD
 #define UDE_SEIR_LS_FWD 1       // 1: ... and the forward pass of a gradient call runs on the same architecture (ude_seir_ls_fwd.h)
@@ -654,7 +657,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
         int* queue = (int*)c->ls_fac.p;
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_lds));
-        hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N)), dim3(256), lf_lds, c->stream, p, queue);
+        hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, UDE_SEIR_LS_FWD_PER_CU)), dim3(256), lf_lds, c->stream, p, queue);
     } else
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
     HIPCHK(c, hipGetLastError());
@@ -788,7 +791,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         int* queue = (int*)((double*)c->ls_fac.p + (size_t)nblk * ls_fac) + 1;   // (the backward kernel's counter is the int in front of it)
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_lds));
-        hipLaunchKernelGGL(lf, dim3((unsigned)nblk), dim3(256), lf_lds, c->stream, p, queue);
+        hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, UDE_SEIR_LS_FWD_PER_CU)), dim3(256), lf_lds, c->stream, p, queue);
     } else
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
