@@ -13,11 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("workload,traj,port", [("lv", "2000", "29541"), ("seir", "300", "29545")])
+def test_bench_two_ranks_on_one_gpu(workload, traj, port):
     env = dict(os.environ, UDE_BENCH_DEVICE="0", UDE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--traj", "2000",
-           "--no-cpu-baseline"]
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--traj", traj,
+           "--workload", workload, "--no-cpu-baseline", "--no-others"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
