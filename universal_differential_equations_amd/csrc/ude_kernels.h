@@ -1053,6 +1053,9 @@ struct AdjSys {
     }
 };
 
+template <class M, class = void> struct model_gfac { static constexpr int v = 0; };
+template <class M> struct model_gfac<M, std::void_t<decltype(M::GFAC)>> { static constexpr int v = M::GFAC; };
+
 template <class Model, class Tab, int G, int BLOCK, bool PT = false, int VAR = 1, class RTag = real>
 __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1109,6 +1112,10 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         sys.j = gid;
         sys.n = p.n_state;
         if constexpr (Model::DEFERRED) sys.load_bth_table();
+        if constexpr (model_gfac<Model>::v > 0) {   // stage factors a model keeps in HBM: this thread's words behind its two mu columns
+            sys.mctx.gfac = mu_lds + (size_t)(2 * Model::NSL) * MS;
+            sys.mctx.gms = MS;
+        }
         sys.mu_cur = mu_lds;
         sys.mu_new = mu_lds + (size_t)(Model::DEFERRED ? Model::NSL : 0) * MS;
         sys.ms = MS;

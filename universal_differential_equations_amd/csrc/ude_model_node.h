@@ -12,7 +12,7 @@
 // conflict-free), activations cross lanes through a wave-private LDS broadcast row, 64-term hidden dots follow the
 // ARITH-SPEC wide-dot rule (4 blocks of 16, block sums left to right), reductions to replicated scalars (the 7-row
 // output layer, the input cotangent) are wavefront tree sums.  The parameter cotangent is DEFERRED: every adjoint stage
-// stores its factors (a1 a2 a3 delta1 delta2 delta3 per lane, x and delta4 once per wave) in LDS and the RK-weighted
+// stores its factors (a1 a2 delta2 delta3 per lane and x, delta4 once per wave in LDS; a3 and delta1 per lane in HBM) and the RK-weighted
 // sums of the 146 slots per lane are formed at the end of the step, fused with the error norm and the candidate mu
 // (mu itself in HBM, two columns that swap on acceptance).
 #pragma once
@@ -32,21 +32,27 @@ struct SeirNode {
     static constexpr bool STATE_DISTRIBUTED = false;
     static constexpr bool THETA_GLOBAL = false, FUSED_ACC = true, SLOTS_GLOBAL = true, CPL = true, DEFERRED = true;
     static constexpr bool DADJ_K_FROM_DENSE = false;
-    // Stage factors in LDS: only the stages whose B or BT weight is nonzero are kept (Tsit5: all 7; Vern7: 8 of 10), in
-    // COMPACTED slots (AdjSys passes popcount(mask below s); a stage nobody reads lands in the slot of the next kept stage
-    // and is overwritten by it), six full rows per stage plus one short row (x0..x6 | delta4_0..6: 14 words).  With that
-    // THREE wavefronts fit next to the 74 KB of weights: 3 x (8 x 3.1 KB + 1 KB) + 74 KB + stage storage = 157 KB of the
-    // CU's 160 KB -- three of the four SIMDs busy instead of two (the kernels use all 512 registers of a SIMD lane)
+    // Stage factors: only the stages whose B or BT weight is nonzero are kept (Tsit5: all 7; Vern7: 8 of 10), in COMPACTED slots
+    // (AdjSys passes popcount(mask below s); a stage nobody reads lands in the slot of the next kept stage and is overwritten by
+    // it).  Per stage FOUR full rows stay in LDS -- a1 and a2 (read by every lane: the broadcast factors of the W2 / W3 blocks),
+    // delta2 and delta3 -- plus one short row (x0..x6 | delta4_0..6: 14 words); a3 and delta1, which only the lane that wrote
+    // them reads (the 15 slots of the W1 / b1 / W4 blocks), live in a thread-strided HBM workspace behind the mu columns
+    // (GFAC words per thread).  With that FOUR wavefronts fit next to the 74 KB of weights -- 4 x (8 x 2.2 KB + 1 KB) + 74 KB +
+    // stage storage = 151 KB of the CU's 160 KB: every SIMD has its wavefront (the kernels use all 512 registers of a SIMD lane;
+    // round 2 kept six rows in LDS and ran three wavefronts per CU)
     static constexpr bool COMPACT_STAGES = true;
-    static constexpr int NSTG = 10, NSTC = 8, NFAC = 7, WPB = 3, RX = 16;  // tableau stages, stored stages, factor fields, wavefronts per block, short row
-    static constexpr int STG = 6 * H + RX;                                 // doubles of one stored stage
+    static constexpr int NSTG = 10, NSTC = 8, WPB = 4, RX = 16;   // tableau stages, stored stages, wavefronts per block, short row
+    static constexpr int NROW = 4;                                 // LDS rows per stored stage: a1 a2 delta2 delta3
+    static constexpr int STG = NROW * H + RX;                      // doubles of one stored stage
+    static constexpr int GFAC = 2 * NSTC;                          // HBM words per thread: (a3, delta1) of every stored stage
     static constexpr int LD = 65;
     static constexpr int OFF_W1 = 0, OFF_B1 = NIN * H, OFF_W2 = OFF_B1 + H, OFF_B2 = OFF_W2 + H * H, OFF_W3 = OFF_B2 + H,
                          OFF_B3 = OFF_W3 + H * H, OFF_W4 = OFF_B3 + H, OFF_B4 = OFF_W4 + NOUT * H, NPARAM = OFF_B4 + NOUT;
     static_assert(NPARAM == 9287, "7-64-64-64-7");
     static constexpr int SCRATCH = WPB * (NSTC * STG + 2 * H);  // stage factors + 2 broadcast rows per wavefront
-    static constexpr int SCRATCH_FWD = WPB * 2 * H;             // forward / rhs kernels: the broadcast rows only
-    static constexpr int FWD_BLOCKS = 2;                        // 2 x 80 KB of LDS, 256 registers
+    static constexpr int FWD_BLOCK_THREADS = 192;               // forward / rhs kernels: three wavefronts per block ...
+    static constexpr int SCRATCH_FWD = (FWD_BLOCK_THREADS / 64) * 2 * H;   // ... their broadcast rows only
+    static constexpr int FWD_BLOCKS = 2;                        // ... and two blocks per CU: 2 x 80 KB of LDS, 256 registers (six wavefronts per CU)
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
         double b1, b2, b3, b4[NOUT];
@@ -54,7 +60,9 @@ struct SeirNode {
         const lds_t* wx;         // LDS: this lane's column of the narrow layers, W1[j, m] at wx[m*H] (m < 7), W4[i, j] at wx[(7+i)*H]
                                  // (28 registers less per lane than a register copy; the adjoint kernels are at the 512-register limit)
         lds_t* bc;               // two wave-private broadcast rows: lane j writes, every lane reads all 64
-        lds_t* fac;              // stage factors of this wavefront: field f < 6 of stored stage q at fac[q*STG + f*H + lane], the short row at fac[q*STG + 6*H]
+        lds_t* fac;              // stage factors of this wavefront: row f < 4 (a1 a2 delta2 delta3) of stored stage q at fac[q*STG + f*H + lane], the short row at fac[q*STG + 4*H]
+        double* gfac;            // HBM: a3 of stored stage q at gfac[(2q) * gms], delta1 at gfac[(2q + 1) * gms] (this thread's words)
+        int gms;
         double mu_c, sg;
         int j, r;
     };
@@ -205,11 +213,13 @@ struct SeirNode {
         Bwd q;
         sweep(c, u, lam, dlam, q);
         lds_t* f = c.fac + s * STG + c.j;  // (s: compacted slot)
-        f[0] = q.f.a1; f[H] = q.f.a2; f[2 * H] = q.f.a3; f[3 * H] = q.d1; f[4 * H] = q.d2; f[5 * H] = q.d3;
+        f[0] = q.f.a1; f[H] = q.f.a2; f[2 * H] = q.d2; f[3 * H] = q.d3;
+        c.gfac[(size_t)(2 * s) * c.gms] = q.f.a3;
+        c.gfac[(size_t)(2 * s + 1) * c.gms] = q.d1;
         double sh = 0.0;
         static_for<0, NIN>([&](auto m) { sh = (c.j == (int)decltype(m)::value) ? q.f.x[m] : sh; });
         static_for<0, NOUT>([&](auto i) { sh = (c.j == NIN + (int)decltype(i)::value) ? q.d4[i] : sh; });
-        c.fac[s * STG + 6 * H + (c.j < RX ? c.j : RX - 1)] = sh;  // (lanes >= 14 all carry 0.0: one word, one value)
+        c.fac[s * STG + NROW * H + (c.j < RX ? c.j : RX - 1)] = sh;  // (lanes >= 14 all carry 0.0: one word, one value)
     }
     // this lane's delta of ONE layer at all stages (registers): the 64 slots of a weight block share it; the 18 extras
     // read their factors straight from the lane's own LDS words (one use each -- keeping all four per-lane factor sets
@@ -236,18 +246,25 @@ struct SeirNode {
             if constexpr ((MASK >> decltype(s)::value) & 1u) g[s] = -(f.d[s] * c.fac[slot_of<MASK>(decltype(s)::value) * STG + LAYER * H + k]);
         });
     }
+    // a3 / delta1 of all stored stages (this lane's own words in the HBM workspace)
+    template <int NST, unsigned MASK, int WHICH>
+    static __device__ __forceinline__ void load_gfac(const Ctx& c, Fac& f) {
+        static_for<0, NST>([&](auto s) {
+            if constexpr ((MASK >> decltype(s)::value) & 1u) f.d[s] = c.gfac[(size_t)(2 * slot_of<MASK>(decltype(s)::value) + WHICH) * c.gms];
+        });
+    }
     template <int NST, unsigned MASK, int E>
-    static __device__ __forceinline__ void g_extra(const Ctx& c, double* g) {
+    static __device__ __forceinline__ void g_extra(const Ctx& c, const Fac& a3, const Fac& d1, double* g) {
         static_for<0, NST>([&](auto s) {
             if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                const lds_t* own = c.fac + slot_of<MASK>(decltype(s)::value) * STG + c.j;  // a1 a2 a3 d1 d2 d3 of this lane
-                const lds_t* p = c.fac + slot_of<MASK>(decltype(s)::value) * STG + 6 * H;  // x0..x6 | delta4_0..6
+                const lds_t* own = c.fac + slot_of<MASK>(decltype(s)::value) * STG + c.j;       // a1 a2 delta2 delta3 of this lane
+                const lds_t* p = c.fac + slot_of<MASK>(decltype(s)::value) * STG + NROW * H;   // x0..x6 | delta4_0..6
                 double v;
-                if constexpr (E < NIN) v = -(own[3 * H] * p[E]);
-                else if constexpr (E == NIN) v = -own[3 * H];
-                else if constexpr (E == NIN + 1) v = -own[4 * H];
-                else if constexpr (E == NIN + 2) v = -own[5 * H];
-                else if constexpr (E < NIN + 3 + NOUT) v = -(p[NIN + (E - NIN - 3)] * own[2 * H]);
+                if constexpr (E < NIN) v = -(d1.d[s] * p[E]);
+                else if constexpr (E == NIN) v = -d1.d[s];
+                else if constexpr (E == NIN + 1) v = -own[2 * H];
+                else if constexpr (E == NIN + 2) v = -own[3 * H];
+                else if constexpr (E < NIN + 3 + NOUT) v = -(p[NIN + (E - NIN - 3)] * a3.d[s]);
                 else v = c.j < NOUT ? -p[NIN + c.j] : -0.0;
                 g[s] = v;
             }
@@ -273,7 +290,7 @@ struct SeirNode {
         static_for<0, 2>([&](auto layer) {
             constexpr int LAYER = decltype(layer)::value;
             Fac f;
-            load_factor<NST, MASK, 4 + LAYER>(c, f);  // delta2 / delta3
+            load_factor<NST, MASK, 2 + LAYER>(c, f);  // delta2 / delta3
 #pragma unroll 1
             for (int k0 = 0; k0 < H; k0 += CH) {
                 fetch(LAYER * H + k0 + CH);
@@ -285,6 +302,9 @@ struct SeirNode {
                 roll();
             }
         });
+        Fac fa3, fd1;
+        load_gfac<NST, MASK, 0>(c, fa3);
+        load_gfac<NST, MASK, 1>(c, fd1);
         static_for<0, NCHX>([&](auto chunk) {
             constexpr int e0 = decltype(chunk)::value * CH;
             if constexpr (e0 + CH < NEXTRA) fetch(2 * H + e0 + CH);
@@ -292,7 +312,7 @@ struct SeirNode {
                 constexpr int e = e0 + decltype(i)::value;
                 if constexpr (e < NEXTRA) {
                     double g[NST];
-                    g_extra<NST, MASK, e>(c, g);
+                    g_extra<NST, MASK, e>(c, fa3, fd1, g);
                     body(2 * H + e, g, mcur[i]);
                     NODE_BARRIER;
                 }

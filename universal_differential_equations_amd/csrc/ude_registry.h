@@ -14,14 +14,15 @@ struct Launch {
     void (*adj_ckpt)(const KParams);  // checkpointed adjoint: store u only, recompute the stages (null: no such instance)
     int nf;  // dense fields per step
     int G, block;
+    int block_fwd;  // threads per block of the forward / rhs kernels (Model::FWD_BLOCK_THREADS; else = block)
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
-    int theta_lds, scratch, scratch_fwd, k_doubles, k_doubles_d, slots_reg;
+    int theta_lds, scratch, scratch_fwd, k_doubles, k_doubles_d, slots_reg, k_doubles_fwd;
     bool dadj_k_dense;  // the reverse sweep reads k from the dense store (HBM) instead of an LDS copy
     int slot_glob;  // > 0: slot state in HBM, this many elements per thread (SLOTS_GLOBAL models)
     int elem;       // bytes of the instance's scalar type (8: Float64, 4: Float32)
     size_t lds_bytes(int np, bool adjoint, bool discrete = false) const {
         const size_t np_pad = (size_t)((np + 1) & ~1);
-        size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + ((adjoint || discrete) ? scratch : scratch_fwd) + k_doubles;
+        size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + ((adjoint || discrete) ? scratch : scratch_fwd) + ((adjoint || discrete) ? k_doubles : k_doubles_fwd);
         if (discrete) d += (dadj_k_dense ? 1 : 2) * (size_t)k_doubles_d - k_doubles;  // [k and] kbar in the reverse sweep's own layout
         if (adjoint) d += (size_t)slots_reg;
         return d * (size_t)elem + 16;
@@ -32,6 +33,12 @@ struct Launch {
 template <class M, class = void> struct no_dadj { static constexpr bool v = false; };
 template <class M> struct no_dadj<M, std::void_t<decltype(M::NO_DADJ)>> { static constexpr bool v = M::NO_DADJ; };
 
+// a model whose forward / rhs kernels run with fewer threads per block than its adjoint (Model::FWD_BLOCK_THREADS: LDS per block)
+template <class M, int BLOCK, class = void> struct fwd_block_threads { static constexpr int v = BLOCK; };
+template <class M, int BLOCK> struct fwd_block_threads<M, BLOCK, std::void_t<decltype(M::FWD_BLOCK_THREADS)>> { static constexpr int v = M::FWD_BLOCK_THREADS; };
+// per-thread HBM words behind the two mu columns that a model keeps stage factors in (Model::GFAC: SeirNode's a3 / delta1 rows)
+template <class M, class = void> struct gfac_words { static constexpr int v = 0; };
+template <class M> struct gfac_words<M, std::void_t<decltype(M::GFAC)>> { static constexpr int v = M::GFAC; };
 // models that declare Model::RECOMPUTE_OK get the checkpointed-adjoint kernel (store u only, recompute the stages) for FSAL tableaux
 template <class M, class = void> struct recompute_ok { static constexpr bool v = false; };
 template <class M> struct recompute_ok<M, std::void_t<decltype(M::RECOMPUTE_OK)>> { static constexpr bool v = M::RECOMPUTE_OK; };
@@ -39,12 +46,13 @@ template <class M> struct recompute_ok<M, std::void_t<decltype(M::RECOMPUTE_OK)>
 template <class Model, class Tab, int G, int BLOCK = 64, int VAR = 1, class RTag = real>
 inline Launch make_launch() {
     Launch l;
-    l.fwd = fwd_kernel<Model, Tab, G, BLOCK>;
+    constexpr int FB = fwd_block_threads<Model, BLOCK>::v;
+    l.fwd = fwd_kernel<Model, Tab, G, FB>;
     l.adj = adj_kernel<Model, Tab, G, BLOCK, false, VAR>;
     if constexpr (no_dadj<Model>::v) { l.dadj = nullptr; l.dadj_pt = nullptr; }
     else { l.dadj = dadj_kernel<Model, Tab, G, BLOCK>; l.dadj_pt = dadj_kernel<Model, Tab, G, BLOCK, true>; }
-    l.rhs = rhs_kernel<Model, Tab, G, BLOCK>;
-    l.fwd_pt = fwd_kernel<Model, Tab, G, BLOCK, true>;
+    l.rhs = rhs_kernel<Model, Tab, G, FB>;
+    l.fwd_pt = fwd_kernel<Model, Tab, G, FB, true>;
     l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true, VAR>;
     l.adj_fast = adj_kernel<Model, Tab, G, BLOCK, false, 3>;
     if constexpr (recompute_ok<Model>::v && Tab::FSAL && Tab::NK == Tab::S)
@@ -53,6 +61,8 @@ inline Launch make_launch() {
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;
+    l.block_fwd = FB;
+    l.k_doubles_fwd = Layout<Model, Tab, G, FB>::K_DOUBLES;
     l.theta_lds = Model::theta_lds(7) == 8 ? -1 : Model::theta_lds(0);
     l.scratch = Model::SCRATCH;
     l.scratch_fwd = scratch_fwd<Model>::v;
@@ -60,7 +70,7 @@ inline Launch make_launch() {
     l.k_doubles_d = Layout<Model, Tab, G, BLOCK, false>::K_DOUBLES;
     l.dadj_k_dense = Model::DADJ_K_FROM_DENSE;
     l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : (Tab::FSAL ? 3 : 2) * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
-    l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL : 0;
+    l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL + gfac_words<Model>::v : 0;
     l.elem = (int)sizeof(real);
     return l;
 }

@@ -636,7 +636,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
         retcode = (int32_t*)c->retcode.p;
     }
     p.retcode = retcode;
-    const int BLOCK = l.block;
+    const int BLOCK = l.block_fwd;
     const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const size_t shmem = l.lds_bytes(m->n_param, false);
@@ -793,7 +793,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         HIPCHK(c, hipFuncSetAttribute((const void*)lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_lds));
         hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, UDE_SEIR_LS_FWD_PER_CU)), dim3(256), lf_lds, c->stream, p, queue);
     } else
-    hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem_f, c->stream, p);
+    {   // (the forward kernel may run with fewer threads per block than the adjoint: Launch::block_fwd)
+        const int64_t gpb_f = l.block_fwd / G;
+        hipLaunchKernelGGL(kfwd, dim3((unsigned)((N + gpb_f - 1) / gpb_f)), dim3(l.block_fwd), shmem_f, c->stream, p);
+    }
     HIPCHK(c, hipGetLastError());
     if (!cap_graph) {
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -862,7 +865,7 @@ extern "C" int ude_rhs_ensemble_dev(ude_ctx* c, const ude_model_desc* m, int64_t
     p.u0 = u;
     p.theta = theta;
     p.u_out = du;
-    const int BLOCK = l.block;
+    const int BLOCK = l.block_fwd;
     const int64_t gpb = BLOCK / G;
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const size_t shmem = l.lds_bytes(m->n_param, false);
