@@ -22,9 +22,12 @@ namespace ude {
 
 enum { GK_LV_UDE = 1, GK_SEIR_UDE = 3, GK_SEIR_NODE = 6 };  // = UDE_KIND_* of include/udecore.h (ude_model_desc.kind)
 
-template <int NSTATE>
+// LMAX_: the deepest chain an instance takes.  The stage storage of a wavefront is 8 x (2 LMAX x 64 + 16) doubles of LDS: 67 KB for
+// LMAX = 8 (two wavefronts per CU), 34 KB for LMAX = 4 (four: every SIMD busy) -- chains of <= 4 layers, i.e. every network of the
+// reference's scripts, run on the LMAX = 4 instance
+template <int NSTATE, int LMAX_ = 8>
 struct GenericUde {
-    static constexpr int H = 64, LMAX = 8;
+    static constexpr int H = 64, LMAX = LMAX_;
     static constexpr int NS = NSTATE;
     static constexpr int NSLW = LMAX * (H + 1);   // weight + bias slots of lane j: (in_l + 1) per layer, layer after layer
     static constexpr int NSL = NSLW + 2;           // + the two (optional) trainable diagonal coefficients of the LV kind (lane 0)
@@ -38,6 +41,7 @@ struct GenericUde {
     static constexpr int WORK = (LMAX + 1) * H + LMAX * H + 2 * H;  // forward working rows: a_0..a_L, dphi_0..dphi_{L-1}, spare
     static constexpr int SCRATCH = NSTC * STG + WORK;
     static constexpr int SCRATCH_FWD = WORK;
+    static constexpr int FWD_BLOCKS = 2;           // forward / rhs kernels compiled for two wavefronts per SIMD (256 registers; their LDS share is WORK only)
     typedef __attribute__((address_space(3))) double lds_t;
     struct Ctx {
         const double* nn;     // theta + nn_offset (HBM)

@@ -296,10 +296,10 @@ static int generic_id(const ude_model_desc* m) {
     if (m->kind == UDE_KIND_LV_UDE && m->n_state == 2 && in == 2 && out == 2) {
         for (int i = 0; i < 2; ++i)
             if (m->lin_idx[i] >= m->n_param || (m->lin_idx[i] >= m->nn_offset && m->lin_idx[i] < m->nn_offset + np)) return MID_NONE;
-        return MID_GENERIC_2;
+        return m->n_layers <= 4 ? MID_GENERIC_2_L4 : MID_GENERIC_2;   // (<= 4 layers: the instance with half the stage storage)
     }
-    if (m->kind == UDE_KIND_SEIR_UDE && m->n_state == 7 && in == 3 && out == 1) return MID_GENERIC_7;
-    if (m->kind == UDE_KIND_SEIR_NODE && m->n_state == 7 && in == 7 && out == 7) return MID_GENERIC_7;
+    if (m->kind == UDE_KIND_SEIR_UDE && m->n_state == 7 && in == 3 && out == 1) return m->n_layers <= 4 ? MID_GENERIC_7_L4 : MID_GENERIC_7;
+    if (m->kind == UDE_KIND_SEIR_NODE && m->n_state == 7 && in == 7 && out == 7) return m->n_layers <= 4 ? MID_GENERIC_7_L4 : MID_GENERIC_7;
     return MID_NONE;
 }
 
@@ -334,7 +334,9 @@ static int default_lanes(int mid, bool discrete) {
         case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
         case MID_SEIR_NODE: return 64;  // wavefront per trajectory, 3 per block (two 64x64 layers + the compacted stage factors fill the LDS)
         case MID_GENERIC_2:
-        case MID_GENERIC_7: return 64;  // wavefront per trajectory, one per block
+        case MID_GENERIC_7:
+        case MID_GENERIC_2_L4:
+        case MID_GENERIC_7_L4: return 64;  // wavefront per trajectory, one per block
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32:
