@@ -829,10 +829,16 @@ struct KppUde : LinearTheta {
 // parameter sums; the four block sums meet in LDS and are added left to right by the parameter's final owner
 // (theta index p = r + 256 m: the Driver's register slots).  The state itself is distributed 4 points per lane.
 // ---------------------------------------------------------------------------------------------
-template <class Net>
+// NWV_: wavefronts per PDE.  The adjoint (and everything that sums parameter cotangents over blocks of 256 points: ARITH-SPEC) runs
+// with four; the FORWARD solve, which has no such sums, runs with eight (FwdModel below): two wavefronts per SIMD instead of one on
+// the CU that owns the PDE -- the 256 PDEs of configs[3] are one block per CU whatever the block size is.
+template <class Net, int NWV_ = 4>
 struct KppUdeW : LinearTheta {
     static constexpr bool RECOMPUTE_OK = true;   // checkpointed adjoint available (AdjSys::RECOMPUTE)
-    static constexpr int G = 256, PPL = 4, NWV = 4, TP = 64, BLK = 256, NTILE = BLK / 16;
+    static constexpr int NWV = NWV_, G = 64 * NWV, PPL = 1024 / G, TP = 64, BLK = TP * PPL, NTILE = BLK / 16;
+    static_assert(NWV == 4 || NWV == 8, "1024 points on four or eight wavefronts");
+    static constexpr int FWD_BLOCKS = NWV == 8 ? 2 : 1;
+    using FwdModel = KppUdeW<Net, 8>;            // make_launch: forward / rhs kernels of the four-wavefront model
     static constexpr bool DADJ_K_FROM_DENSE = true;  // (k and kbar of a 1024-point state do not both fit next to the tiles)
     static __host__ __device__ constexpr int point(int c, int r) { return (r >> 6) * BLK + c * TP + (r & 63); }
     static_assert(Net::dim(0) == 1 && Net::dim(Net::L) == 1, "pointwise reaction network R -> R");
@@ -872,6 +878,7 @@ struct KppUdeW : LinearTheta {
     static constexpr int NPP = (NP + 1) & ~1;  // block-sum row (aliases the tile once the column tiles are consumed)
     static_assert(NPP <= TILE, "block sums must fit the tile they alias");
     static constexpr int SCRATCH = 3 * (NPT + 2) + NWV * TILE;  // u, lambda, result rows + tiles
+    static constexpr int SCRATCH_FWD = 3 * (NPT + 2);           // forward / rhs kernels: the rows only (the tiles belong to the parameter contraction)
     struct Ctx {
         double af[NAF], ab[NAB], bs[NBS];
         lds_t *urow, *lrow, *orow, *tile, *part;

@@ -14,7 +14,8 @@ struct Launch {
     void (*adj_ckpt)(const KParams);  // checkpointed adjoint: store u only, recompute the stages (null: no such instance)
     int nf;  // dense fields per step
     int G, block;
-    int block_fwd;  // threads per block of the forward / rhs kernels (Model::FWD_BLOCK_THREADS; else = block)
+    int block_fwd;  // threads per block of the forward / rhs kernels (Model::FWD_BLOCK_THREADS or Model::FwdModel; else = block)
+    int G_fwd;      // lanes per trajectory of the forward / rhs kernels (Model::FwdModel; else = G)
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
     int theta_lds, scratch, scratch_fwd, k_doubles, k_doubles_d, slots_reg, k_doubles_fwd;
     bool dadj_k_dense;  // the reverse sweep reads k from the dense store (HBM) instead of an LDS copy
@@ -33,6 +34,12 @@ struct Launch {
 template <class M, class = void> struct no_dadj { static constexpr bool v = false; };
 template <class M> struct no_dadj<M, std::void_t<decltype(M::NO_DADJ)>> { static constexpr bool v = M::NO_DADJ; };
 
+// a model whose forward / rhs kernels are a different instantiation (Model::FwdModel, with FwdModel::G lanes per trajectory = threads per block)
+template <class M, class = void> struct fwd_model { using type = M; static constexpr int G = 0; };
+template <class M> struct fwd_model<M, std::void_t<typename M::FwdModel>> {
+    using type = std::conditional_t<std::is_same<typename M::FwdModel, M>::value, M, typename M::FwdModel>;
+    static constexpr int G = M::FwdModel::G;
+};
 // a model whose forward / rhs kernels run with fewer threads per block than its adjoint (Model::FWD_BLOCK_THREADS: LDS per block)
 template <class M, int BLOCK, class = void> struct fwd_block_threads { static constexpr int v = BLOCK; };
 template <class M, int BLOCK> struct fwd_block_threads<M, BLOCK, std::void_t<decltype(M::FWD_BLOCK_THREADS)>> { static constexpr int v = M::FWD_BLOCK_THREADS; };
@@ -46,13 +53,18 @@ template <class M> struct recompute_ok<M, std::void_t<decltype(M::RECOMPUTE_OK)>
 template <class Model, class Tab, int G, int BLOCK = 64, int VAR = 1, class RTag = real>
 inline Launch make_launch() {
     Launch l;
-    constexpr int FB = fwd_block_threads<Model, BLOCK>::v;
-    l.fwd = fwd_kernel<Model, Tab, G, FB>;
+    // forward / rhs kernels: the model itself, with its own block size where it declares one, or a different instantiation of the
+    // model altogether (Model::FwdModel: Fisher-KPP's eight-wavefront forward next to the four-wavefront adjoint)
+    using FM = typename fwd_model<Model>::type;
+    constexpr bool OWN_FWD = !std::is_same<FM, Model>::value;
+    constexpr int GF = OWN_FWD ? fwd_model<Model>::G : G;
+    constexpr int FB = OWN_FWD ? fwd_model<Model>::G : fwd_block_threads<Model, BLOCK>::v;
+    l.fwd = fwd_kernel<FM, Tab, GF, FB>;
     l.adj = adj_kernel<Model, Tab, G, BLOCK, false, VAR>;
     if constexpr (no_dadj<Model>::v) { l.dadj = nullptr; l.dadj_pt = nullptr; }
     else { l.dadj = dadj_kernel<Model, Tab, G, BLOCK>; l.dadj_pt = dadj_kernel<Model, Tab, G, BLOCK, true>; }
-    l.rhs = rhs_kernel<Model, Tab, G, FB>;
-    l.fwd_pt = fwd_kernel<Model, Tab, G, FB, true>;
+    l.rhs = rhs_kernel<FM, Tab, GF, FB>;
+    l.fwd_pt = fwd_kernel<FM, Tab, GF, FB, true>;
     l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true, VAR>;
     l.adj_fast = adj_kernel<Model, Tab, G, BLOCK, false, 3>;
     if constexpr (recompute_ok<Model>::v && Tab::FSAL && Tab::NK == Tab::S)
@@ -62,10 +74,11 @@ inline Launch make_launch() {
     l.G = G;
     l.block = BLOCK;
     l.block_fwd = FB;
-    l.k_doubles_fwd = Layout<Model, Tab, G, FB>::K_DOUBLES;
+    l.G_fwd = GF;
+    l.k_doubles_fwd = Layout<FM, Tab, GF, FB>::K_DOUBLES;
     l.theta_lds = Model::theta_lds(7) == 8 ? -1 : Model::theta_lds(0);
     l.scratch = Model::SCRATCH;
-    l.scratch_fwd = scratch_fwd<Model>::v;
+    l.scratch_fwd = scratch_fwd<FM>::v;
     l.k_doubles = Layout<Model, Tab, G, BLOCK>::K_DOUBLES;
     l.k_doubles_d = Layout<Model, Tab, G, BLOCK, false>::K_DOUBLES;
     l.dadj_k_dense = Model::DADJ_K_FROM_DENSE;

@@ -639,7 +639,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     }
     p.retcode = retcode;
     const int BLOCK = l.block_fwd;
-    const int64_t gpb = BLOCK / G;  // trajectories (lane groups) per block
+    const int64_t gpb = BLOCK / l.G_fwd;  // trajectories (lane groups) per block
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const size_t shmem = l.lds_bytes(m->n_param, false);
     if ((rc = setup_time_grids(c, o, N, tspan, p))) return rc;
@@ -796,7 +796,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, UDE_SEIR_LS_FWD_PER_CU)), dim3(256), lf_lds, c->stream, p, queue);
     } else
     {   // (the forward kernel may run with fewer threads per block than the adjoint: Launch::block_fwd)
-        const int64_t gpb_f = l.block_fwd / G;
+        const int64_t gpb_f = l.block_fwd / l.G_fwd;
         hipLaunchKernelGGL(kfwd, dim3((unsigned)((N + gpb_f - 1) / gpb_f)), dim3(l.block_fwd), shmem_f, c->stream, p);
     }
     HIPCHK(c, hipGetLastError());
@@ -868,7 +868,7 @@ extern "C" int ude_rhs_ensemble_dev(ude_ctx* c, const ude_model_desc* m, int64_t
     p.theta = theta;
     p.u_out = du;
     const int BLOCK = l.block_fwd;
-    const int64_t gpb = BLOCK / G;
+    const int64_t gpb = BLOCK / l.G_fwd;
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const size_t shmem = l.lds_bytes(m->n_param, false);
     if (shmem > 160 * 1024) return fail(c, UDE_ERR_UNSUPPORTED, "kernel instance needs %zu bytes of LDS", shmem);
