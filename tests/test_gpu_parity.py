@@ -462,6 +462,8 @@ KPP_CASES = [
     ("cnn26_vern7", 26, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Vern7, O.VERN7, dict(abstol=1e-6, reltol=1e-6)),
     ("s3_26", 26, models.kpp_s3_chain, lambda nx: O.kpp_ude_s3(0), U.Vern7, O.VERN7, {}),                    # scenario_3.jl:123 (Float64 here)
     ("cnn1024", 1024, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Tsit5, O.TSIT5, {}),                    # BASELINE C4 size
+    ("cnn1024_vern7", 1024, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Vern7, O.VERN7, dict(abstol=1e-6, reltol=1e-6)),   # scenario_3.jl:123-125's solver on the C4 grid
+    ("cnn300_vern7", 300, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Vern7, O.VERN7, dict(abstol=1e-5, reltol=1e-5)),
     ("cnn300", 300, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Tsit5, O.TSIT5, {}),   # ragged: 2 blocks (256 + 44 points), partial column tile, empty wavefronts
     ("cnn33", 33, models.kpp_chain, lambda nx: O.kpp_ude(nx), U.Tsit5, O.TSIT5, {}),     # smallest grid of the 4-wavefront kernels
 ]

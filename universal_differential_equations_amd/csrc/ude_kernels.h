@@ -706,6 +706,10 @@ struct Layout {
     static constexpr int KSTRIDE = k_stride<Model::STATE_DISTRIBUTED, G, BLOCK, CPL>();
     static_assert(!CPL || Model::NS < KCP, "component-per-lane: state must fit the KCP columns");
     static constexpr int K_DOUBLES = CPL ? (BLOCK / 64) * Tab::NK * KCP : Tab::NK * Model::NS * KSTRIDE;
+    // the adjoint solve never builds the lazy dense-output stages (it has no save points of its own): a distributed state with a
+    // tableau of more interpolation stages than steps (Vern7: 16 against 10) keeps only the S step stages -- what lets the
+    // 1024-point Fisher-KPP adjoint fit the LDS with Vern7 (82 KB instead of 131 KB of stage storage)
+    static constexpr int K_DOUBLES_ADJ = (!CPL && Model::STATE_DISTRIBUTED && Tab::NK > Tab::S) ? Tab::S * Model::NS * KSTRIDE : K_DOUBLES;
     // group-shared forward-interval cache of the adjoint kernel (see AdjSys::IC_LDS)
     static constexpr bool IC_LDS = (G >= 5) && !Model::STATE_DISTRIBUTED && !Model::CPL;
     static constexpr int IC_DOUBLES = IC_LDS ? (Model::NS + Tab::NK * Model::NS) * (BLOCK / G) : 0;
@@ -837,12 +841,18 @@ struct AdjSys {
     static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !CPL;
     static constexpr int IC_FIELDS = NR + Tab::NK * NR;
     static constexpr int IC_NR = (IC_LDS || CPL) ? 1 : NR;
-    real ts, te, us[IC_NR], ks[IC_LDS ? 1 : Tab::NK][IC_NR];
+    // KS_STREAM: a distributed state with more than 8 interpolation stages (Fisher-KPP with Vern7: 16 x 4 doubles per lane) does not
+    // cache the interval's k in registers at all: every evaluation reads them from the dense store (coalesced, L2-resident)
+    static constexpr bool KS_STREAM = STATE_DISTRIBUTED && !CPL && Tab::NK > 8 && Tab::NK * NR > 32 && VAR != 5;
+    real ts, te, us[IC_NR], ks[(IC_LDS || KS_STREAM) ? 1 : Tab::NK][IC_NR];
+    const real* kstore;   // KS_STREAM: field 0 of the current interval's record (this trajectory's column)
     real* ic;      // LDS: field f of this group at ic[f * icstride]
     int icstride;
     __device__ __forceinline__ real US(int c) const { if constexpr (IC_LDS) return ic[c * icstride]; else return us[c]; }
     __device__ __forceinline__ real KS(int q, int c) const {
-        if constexpr (IC_LDS) return ic[(NR + q * NR + c) * icstride]; else return ks[q][c];
+        if constexpr (IC_LDS) return ic[(NR + q * NR + c) * icstride];
+        else if constexpr (KS_STREAM) return cvalid(c) ? kstore[(size_t)(3 + n + q * n + comp(c)) * p->Npad] : real(0);
+        else return ks[q][c];
     }
     // cotangent access
     const real* cot;
@@ -928,6 +938,8 @@ struct AdjSys {
             });
         } else {
             static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p->Npad] : 0.0; });
+            if constexpr (KS_STREAM) kstore = base;
+            else
             static_for<0, Tab::NK>([&](auto q) {
                 if constexpr (Tab::dense_uses(q))
                     static_for<0, NR>([&](auto c) {
@@ -1063,17 +1075,17 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     real* th = reinterpret_cast<real*>(smem_raw);
     real* scratch = th + Model::theta_lds(p.n_param);
     real* kbase = scratch + Model::SCRATCH;
-    real* slots = kbase + L::K_DOUBLES;
+    real* slots = kbase + L::K_DOUBLES_ADJ;
     const int np_pad = L::np_pad(p.n_param);
 #ifdef UDE_EXP_LDS_FILL  // debugging experiment: poison (or zero) the whole dynamic LDS before anything is staged
     {
-        const int tot = Model::theta_lds(p.n_param) + Model::SCRATCH + L::K_DOUBLES;
+        const int tot = Model::theta_lds(p.n_param) + Model::SCRATCH + L::K_DOUBLES_ADJ;
         for (int i = threadIdx.x; i < tot; i += BLOCK) th[i] = UDE_EXP_LDS_FILL;
         __syncthreads();
     }
 #endif
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
-    for (int i = threadIdx.x; i < L::K_DOUBLES; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
+    for (int i = threadIdx.x; i < L::K_DOUBLES_ADJ; i += BLOCK) kbase[i] = 0.0;  // stage storage must always be finite
     __syncthreads();
 
     constexpr int GROUPS = BLOCK / G;

@@ -17,13 +17,13 @@ struct Launch {
     int block_fwd;  // threads per block of the forward / rhs kernels (Model::FWD_BLOCK_THREADS or Model::FwdModel; else = block)
     int G_fwd;      // lanes per trajectory of the forward / rhs kernels (Model::FwdModel; else = G)
     // dynamic LDS (doubles): theta copy (<0: (np+1)&~1) + scratch + k [+ adjoint: slot columns (mu, FSAL hand-over) + interval cache]
-    int theta_lds, scratch, scratch_fwd, k_doubles, k_doubles_d, slots_reg, k_doubles_fwd;
+    int theta_lds, scratch, scratch_fwd, k_doubles, k_doubles_d, slots_reg, k_doubles_fwd, k_doubles_adj;
     bool dadj_k_dense;  // the reverse sweep reads k from the dense store (HBM) instead of an LDS copy
     int slot_glob;  // > 0: slot state in HBM, this many elements per thread (SLOTS_GLOBAL models)
     int elem;       // bytes of the instance's scalar type (8: Float64, 4: Float32)
     size_t lds_bytes(int np, bool adjoint, bool discrete = false) const {
         const size_t np_pad = (size_t)((np + 1) & ~1);
-        size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + ((adjoint || discrete) ? scratch : scratch_fwd) + ((adjoint || discrete) ? k_doubles : k_doubles_fwd);
+        size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + ((adjoint || discrete) ? scratch : scratch_fwd) + (discrete ? k_doubles : adjoint ? k_doubles_adj : k_doubles_fwd);
         if (discrete) d += (dadj_k_dense ? 1 : 2) * (size_t)k_doubles_d - k_doubles;  // [k and] kbar in the reverse sweep's own layout
         if (adjoint) d += (size_t)slots_reg;
         return d * (size_t)elem + 16;
@@ -80,6 +80,7 @@ inline Launch make_launch() {
     l.scratch = Model::SCRATCH;
     l.scratch_fwd = scratch_fwd<FM>::v;
     l.k_doubles = Layout<Model, Tab, G, BLOCK>::K_DOUBLES;
+    l.k_doubles_adj = Layout<Model, Tab, G, BLOCK>::K_DOUBLES_ADJ;
     l.k_doubles_d = Layout<Model, Tab, G, BLOCK, false>::K_DOUBLES;
     l.dadj_k_dense = Model::DADJ_K_FROM_DENSE;
     l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : (Tab::FSAL ? 3 : 2) * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
