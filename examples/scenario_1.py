@@ -43,9 +43,9 @@ def callback(p, l):                                                             
 
 n_adam = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n_bfgs = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-p1, _ = training.adam(loss_grad, p0, eta=0.1, maxiters=n_adam, callback=callback)
+p1, _ = training.adam(loss_grad, p0, eta=0.1, maxiters=n_adam, callback=callback, result="evaluated")   # (res1.u: the last evaluated parameters)
 print("Training loss after %d iterations: %g" % (len(losses), losses[-1]))
-p2, _ = training.bfgs(loss_grad, p1, initial_stepnorm=0.01, maxiters=n_bfgs, callback=callback)
+p2, _ = training.bfgs_hagerzhang(loss_grad, p1, initial_stepnorm=0.01, maxiters=n_bfgs, callback=callback)   # Optim.BFGS + HagerZhang
 print("Final training loss after %d iterations: %g" % (len(losses), losses[-1]))
 gold = g["losses"]["data_colmajor"]
 print("reference artifact: losses[0..3] = %s ; ours = %s" % (gold[:4], losses[:4]))

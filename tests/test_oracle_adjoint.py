@@ -263,6 +263,30 @@ def test_adam_trajectory_with_discrete_gradient(golden):
         b2t *= b2
 
 
+def test_bfgs_hagerzhang_follows_the_stored_losses(golden):
+    """scenario_1.jl:111-118: 200 iterations of ADAM(0.1), then Optim.BFGS(initial_stepnorm = 0.01) -- Optim's default HagerZhang line
+    search from alpha = 1 -- starting at the last parameters ADAM evaluated (stored losses[199] == [200] == [201]).  The host
+    restatement (training.bfgs_hagerzhang: inverse-Hessian BFGS + Hager-Zhang bracket / secant^2 / update) reproduces the stored BFGS
+    losses: the first six iterations to 1e-6, the seventh -- the step on which the loss falls from 1.40 to 0.65 -- to 1e-4; after
+    that the two runs separate (every line search amplifies the 2e-7 they start apart)."""
+    from universal_differential_equations_amd import training
+    g, X, t = s1_setup(golden)
+    gold = np.array(g["losses"]["data_colmajor"])
+    m, o = O.lv_ude_s1(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=1)
+
+    def lg(th):
+        r = O.loss_grad_ensemble(m, o, X[0], [t[0], t[-1]], np.asarray(th), t, X[None])
+        return r["loss"], r["grad_theta"]
+
+    th199, la = training.adam(lg, np.array(g["initial_parameters"]), eta=0.1, maxiters=200, result="evaluated")
+    assert len(la) == 200 and abs(la[199] - gold[199]) < 5e-6 * gold[199] and gold[199] == gold[200] == gold[201]
+    _, lb = training.bfgs_hagerzhang(lg, th199, initial_stepnorm=0.01, maxiters=12)
+    dev = np.abs(np.array(lb) - gold[201:201 + len(lb)]) / gold[201:201 + len(lb)]
+    assert (dev[:7] < 1e-6).all(), dev
+    assert dev[7] < 1e-4 and (dev[8:12] < 2e-3).all(), dev
+    assert lb[7] < 0.5 * lb[6]                       # the big step is taken on the same iteration
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Full-loss pins where the reference is silent (it ships no SEIR / Fisher-KPP artifact): the interpolating-adjoint
 # gradient of the WHOLE loss (row mask, S0 = 14e6 state scaling, periodic stencil) against central finite differences of

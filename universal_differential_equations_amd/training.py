@@ -7,8 +7,9 @@
 `loss_grad(theta) -> (loss, grad)` is any callable (numpy or torch tensors; the device-resident ensemble keeps theta,
 gradient and optimiser state in HBM, nothing crosses PCIe inside the loop).  ADAM is Optimisers.jl's rule
 (eta, beta=(0.9,0.999), eps=eps(Float64)); the callback sees loss(theta_k) BEFORE the update, as upstream's does
-(SURVEY App. A.6).  BFGS here is a plain inverse-Hessian BFGS with Armijo backtracking: it plays Optim.BFGS's role in the
-scripts but is not a restatement of Optim.jl's HagerZhang line search.
+(SURVEY App. A.6).  `bfgs_hagerzhang` restates Optim.BFGS with its default HagerZhang line search (pinned by the BFGS part of
+scenario_1's stored losses); `bfgs` is a plain inverse-Hessian BFGS with Armijo backtracking (cheaper per iteration, kept for the
+examples that do not compare with an artifact).
 """
 import numpy as np
 
@@ -17,7 +18,10 @@ def _xp(x):
     return __import__("torch") if type(x).__module__.startswith("torch") else np
 
 
-def adam(loss_grad, theta, eta=0.1, beta=(0.9, 0.999), maxiters=200, callback=None, eps=None):
+def adam(loss_grad, theta, eta=0.1, beta=(0.9, 0.999), maxiters=200, callback=None, eps=None, result="updated"):
+    """result = "updated": the parameters after the last update; "evaluated": the last parameters the objective was evaluated at
+    (theta_{maxiters-1}) -- what Optimization.solve hands on as `res1.u`: in scenario_1's stored `losses` the entries 199, 200 and 201
+    are equal (the last ADAM callback, and BFGS starting from the same point)."""
     xp = _xp(theta)
     eps = np.finfo(np.float64).eps if eps is None else eps
     theta = theta.clone() if xp is not np else np.array(theta, dtype=np.float64)
@@ -30,12 +34,13 @@ def adam(loss_grad, theta, eta=0.1, beta=(0.9, 0.999), maxiters=200, callback=No
         losses.append(float(loss))
         if callback is not None and callback(theta, losses[-1]):
             break
+        last = theta
         m = beta[0] * m + (1 - beta[0]) * g
         v = beta[1] * v + (1 - beta[1]) * g * g
         theta = theta - eta * (m / (1 - b1t)) / (xp.sqrt(v / (1 - b2t)) + eps)
         b1t *= beta[0]
         b2t *= beta[1]
-    return theta, losses
+    return (last if result == "evaluated" and losses else theta), losses
 
 
 def bfgs(loss_grad, theta, initial_stepnorm=0.01, maxiters=1000, gtol=1e-8, callback=None, c1=1e-4):
@@ -75,6 +80,183 @@ def bfgs(loss_grad, theta, initial_stepnorm=0.01, maxiters=1000, gtol=1e-8, call
         theta, f, g = theta + s, fn, gn
         losses.append(f)
     return theta, losses
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Optim.BFGS(initial_stepnorm = 0.01) as the scripts call it (scenario_1.jl:116-118; Optim's defaults: HagerZhang line search,
+# InitialStatic step guess alpha = 1).  Neither Optim.jl nor LineSearches.jl is under /root/reference: this restates the published
+# algorithms -- BFGS on the inverse Hessian; Hager & Zhang, "A new conjugate gradient method with guaranteed descent and an
+# efficient line search" (SIAM J. Optim. 16, 2005), sections 4-5: approximate Wolfe conditions, bracket (B0-B3), secant^2 (S1-S4),
+# update (U0-U3), with LineSearches.jl's default constants (delta 0.1, sigma 0.9, rho 5, epsilon 1e-6, gamma 0.66, psi3 0.1, 50
+# evaluations) -- and is pinned by the reference's own artifact: the BFGS part of scenario_1's stored `losses`
+# (tests/test_oracle_adjoint.py).
+# ---------------------------------------------------------------------------------------------------------------
+class _HZ:
+    delta, sigma, rho, epsilon, gamma, psi3, linesearchmax, alphamax = 0.1, 0.9, 5.0, 1e-6, 0.66, 0.1, 50, float("inf")
+
+
+def _hz_wolfe(c, phi_c, dphi_c, phi_0, dphi_0, phi_lim):
+    wolfe1 = _HZ.delta * dphi_0 >= (phi_c - phi_0) / c and dphi_c >= _HZ.sigma * dphi_0
+    wolfe2 = (2 * _HZ.delta - 1) * dphi_0 >= dphi_c >= _HZ.sigma * dphi_0 and phi_c <= phi_lim
+    return wolfe1 or wolfe2
+
+
+def hagerzhang(phidphi, c, phi_0, dphi_0):
+    """line search along a descent direction: phidphi(alpha) -> (phi, dphi); returns (alpha, phi(alpha))"""
+    if not (np.isfinite(phi_0) and np.isfinite(dphi_0)) or dphi_0 >= 0:
+        return 0.0, phi_0
+    phi_lim = phi_0 + _HZ.epsilon * abs(phi_0)
+    al, va, sl = [0.0], [phi_0], [dphi_0]
+
+    def ev(a):
+        p, d = phidphi(a)
+        al.append(a); va.append(p); sl.append(d)
+        return p, d
+
+    phi_c, dphi_c = phidphi(c)
+    it = 1
+    while not (np.isfinite(phi_c) and np.isfinite(dphi_c)) and it < 1000:
+        c *= _HZ.psi3
+        phi_c, dphi_c = phidphi(c)
+        it += 1
+    al.append(c); va.append(phi_c); sl.append(dphi_c)
+
+    def bisect(ia, ib):
+        a, b = al[ia], al[ib]
+        while b - a > np.spacing(b):
+            d = (a + b) / 2
+            p, gphi = ev(d)
+            idd = len(al) - 1
+            if gphi >= 0:
+                return ia, idd
+            if p <= phi_lim:
+                a, ia = d, idd
+            else:
+                b, ib = d, idd
+        return ia, ib
+
+    def update(ia, ib, ic):
+        a, b, cc = al[ia], al[ib], al[ic]
+        if cc < a or cc > b:
+            return ia, ib
+        if sl[ic] >= 0:
+            return ia, ic
+        if va[ic] <= phi_lim:
+            return ic, ib
+        return bisect(ia, ic)
+
+    def secant(a, b, da, db):
+        return (a * db - b * da) / (db - da)
+
+    def secant2(ia, ib):
+        a, b = al[ia], al[ib]
+        cc = secant(a, b, sl[ia], sl[ib])
+        p, d = ev(cc)
+        ic = len(al) - 1
+        if _hz_wolfe(cc, p, d, phi_0, dphi_0, phi_lim):
+            return True, ic, ic
+        iA, iB = update(ia, ib, ic)
+        a2, b2 = al[iA], al[iB]
+        c2 = None
+        if iB == ic:
+            c2 = secant(al[ib], al[iB], sl[ib], sl[iB])
+        elif iA == ic:
+            c2 = secant(al[ia], al[iA], sl[ia], sl[iA])
+        if c2 is not None and np.isfinite(c2) and a2 <= c2 <= b2:
+            p, d = ev(c2)
+            ic = len(al) - 1
+            if _hz_wolfe(c2, p, d, phi_0, dphi_0, phi_lim):
+                return True, ic, ic
+            iA, iB = update(iA, iB, ic)
+        return False, iA, iB
+
+    # bracket
+    ia, ib, bracketed, it = 0, 1, False, 1
+    while not bracketed and it < _HZ.linesearchmax:
+        if dphi_c >= 0:
+            ib = len(al) - 1
+            ia = 0
+            for i in range(ib - 1, -1, -1):
+                if va[i] <= phi_lim:
+                    ia = i
+                    break
+            bracketed = True
+        elif va[-1] > phi_lim:
+            ib = len(al) - 1
+            ia, ib = bisect(0, ib)
+            bracketed = True
+        else:
+            c *= _HZ.rho
+            phi_c, dphi_c = ev(c)
+            while not (np.isfinite(phi_c) and np.isfinite(dphi_c)):
+                c = (al[-2] + c) / 2 if len(al) > 2 else c * _HZ.psi3
+                al.pop(); va.pop(); sl.pop()
+                phi_c, dphi_c = ev(c)
+        it += 1
+    while it < _HZ.linesearchmax:
+        a, b = al[ia], al[ib]
+        if b - a <= np.spacing(b):
+            return a, va[ia]
+        ok, iA, iB = secant2(ia, ib)
+        if ok:
+            return al[iA], va[iA]
+        A, B = al[iA], al[iB]
+        if B - A < _HZ.gamma * (b - a):
+            if np.nextafter(va[ia], np.inf) >= va[ib] and np.nextafter(va[iA], np.inf) >= va[iB]:
+                return A, va[iA]
+            ia, ib = iA, iB
+        else:
+            cm = (A + B) / 2
+            ev(cm)
+            ia, ib = update(iA, iB, len(al) - 1)
+        it += 1
+    return al[ia], va[ia]
+
+
+def bfgs_hagerzhang(loss_grad, theta, initial_stepnorm=0.01, maxiters=1000, g_tol=1e-8, callback=None):
+    """Optim.BFGS(initial_stepnorm = ...) with HagerZhang / InitialStatic(alpha = 1): returns (theta, losses) with losses[k] the
+    objective after iteration k (losses[0]: the starting point), i.e. what the scripts' callback records."""
+    x = np.array(theta, dtype=np.float64)
+    n = x.size
+    f, g = loss_grad(x)
+    f, g = float(f), np.asarray(g, dtype=np.float64)
+    scale = initial_stepnorm / np.linalg.norm(g, np.inf)
+    invH = np.eye(n) * scale
+    losses = [f]
+    for _ in range(maxiters):
+        if callback is not None and callback(x, f):
+            break
+        if np.linalg.norm(g, np.inf) <= g_tol:
+            break
+        s = -(invH @ g)
+        dphi_0 = float(g @ s)
+        if dphi_0 >= 0:                                  # not a descent direction: reset the approximation
+            invH = np.eye(n) * (initial_stepnorm / np.linalg.norm(g, np.inf))
+            s = -(invH @ g)
+            dphi_0 = float(g @ s)
+        cache = {}
+
+        def phidphi(a, x=x, s=s, cache=cache):
+            fa, ga = loss_grad(x + a * s)
+            ga = np.asarray(ga, dtype=np.float64)
+            cache[a] = (float(fa), ga)
+            return float(fa), float(ga @ s)
+
+        alpha, _ = hagerzhang(phidphi, 1.0, f, dphi_0)
+        if alpha == 0.0:
+            break
+        fn, gn = cache[alpha] if alpha in cache else loss_grad(x + alpha * s)
+        gn = np.asarray(gn, dtype=np.float64)
+        dx, dg = alpha * s, gn - g
+        dx_dg = float(dx @ dg)
+        if dx_dg > 0:
+            u = invH @ dg
+            c1 = (dx_dg + float(dg @ u)) / (dx_dg * dx_dg)
+            c2 = 1.0 / dx_dg
+            invH = invH + c1 * np.outer(dx, dx) - c2 * (np.outer(u, dx) + np.outer(dx, u))
+        x, f, g = x + dx, float(fn), gn
+        losses.append(f)
+    return x, losses
 
 
 # ---------------------------------------------------------------------------------------------------------------
