@@ -33,7 +33,7 @@ def build(golden_path=os.path.join(ROOT, "tests", "golden", "Scenario_2_recovery
     return g, XS, TS, YS
 
 
-def make_loss(XS, TS, YS):
+def make_loss(XS, TS, YS, sensealg=None):
     f = models.ude_dynamics(trainable="delta")                       # scenario_2.jl:87-95
     u0s = np.stack([XS[:, 0], YS[:, 0]], axis=1)
     tspans = np.stack([TS[:, 0], TS[:, -1]], axis=1)                 # remake(prob; tspan = (T[1], T[end])), scenario_2.jl:105
@@ -51,7 +51,7 @@ def make_loss(XS, TS, YS):
         cot = np.zeros_like(Xh)
         cot[:, :, 0] = 2.0 * (Xh[:, :, 0] - XS)
         cot[:, -1, 1] = np.sign(Xh[:, -1, 1] - YS[:, 1])
-        r = U.adjoint_pullback(ens, U.Vern7(), cot, saveat=tau, abstol=1e-6, reltol=1e-6)
+        r = U.adjoint_pullback(ens, U.Vern7(), cot, saveat=tau, abstol=1e-6, reltol=1e-6, sensealg=sensealg)
         grad = r.grad_theta.copy()
         grad[1:] += 2e-3 * theta[1:] / (theta.size - 1)
         return l, grad

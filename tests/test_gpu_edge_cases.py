@@ -134,6 +134,29 @@ def test_scenario2_segment_loss_as_one_ensemble(golden):
     assert abs(fd - g0 @ d) < 2e-5 * abs(fd)
 
 
+def test_scenario2_adam_follows_the_stored_losses(golden):
+    """scenario_2.jl:139-145 on the device: 200 iterations of ADAM(0.1) on the five-segment loss (per-trajectory time grids, the generic
+    pullback, trainable delta) against the stored `losses` of Scenario_2_recovery_0.005: the first ten iterations to 5e-6, every one
+    of the 200 to 5 % (the loss has an abs() term; BFGS from a point 4e-3 away from the reference's does not follow its losses)."""
+    import importlib.util
+    import os
+    from universal_differential_equations_amd import training
+    spec = importlib.util.spec_from_file_location("scenario_2", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "scenario_2.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g, XS, TS, YS = mod.build()
+    gold = np.array(g["losses"]["data_colmajor"])
+    assert gold[199] == gold[200] == gold[201]
+    for sense in (U.ForwardDiffSensitivity(), None):       # the script's sensealg (frozen-step sweep), and the interpolating adjoint
+        lg = mod.make_loss(XS, TS, YS, sensealg=sense)
+        _, la = training.adam(lg, np.array(g["initial_parameters"]), eta=0.1, maxiters=200)
+        dev = np.abs(np.array(la) - gold[:200]) / gold[:200]
+        print("scenario_2 ADAM (%s): worst relative deviation from the stored losses %.2e at %d, first ten %.1e, last %.1e"
+              % (type(sense).__name__, dev.max(), int(dev.argmax()), dev[:10].max(), dev[-1]))
+        # (the loss has an abs() term: where a residual changes sign the gradient jumps, and a 1e-7 difference decides on which side)
+        assert dev[0] < 1e-11 and dev[:10].max() < 5e-6 and dev.max() < 5e-2, (dev.max(), int(dev.argmax()))
+
+
 def test_multiple_shoot_on_device_matches_oracle_backend(golden):
     """hudson_bay.jl:108-118: the groups of DiffEqFlux.multiple_shoot as one ensemble through libudecore."""
     from universal_differential_equations_amd import training
