@@ -55,6 +55,35 @@ def test_scenario3_ude_f32_loss_known_answer_and_gradients(golden):
     assert abs(loss - gold) < 2e-5 * gold                                            # 2967.0867
 
 
+@pytest.mark.parametrize("name", [S3, "Scenario_3_recovery_0.025"])
+def test_scenario3_f32_adam_trajectory_follows_the_stored_losses(golden, name):
+    """scenario_3.jl:148-154: `Optimization.solve(optprob, ADAM(0.1), maxiters = 10)` on the Float32 Fisher-KPP UDE -- objective =
+    sum(abs2, pred .- Xn) + abs(sum(p[end-4:end-2])) -- with the Float32 kernels' gradient (the script's ForwardDiffSensitivity as the
+    frozen-step sweep, and the interpolating adjoint): all ten stored losses of BOTH artifacts (noise 0.005 and 0.025) to Float32
+    accuracy.  Optimisers' ADAM keeps its moments in the parameters' type (Float32) and computes with the Float64 eta / betas."""
+    g = golden(name)
+    X = np.array(g["X"]["data_colmajor"], dtype=f32).reshape(11, 26)
+    t = np.array(g["t"], dtype=f32)
+    gold = np.array(g["losses"]["data_colmajor"])
+    f = models.nn_ode(26, models.kpp_s3_chain(), dtype="float32")
+    for sense in (U.ForwardDiffSensitivity(), None):
+        th = np.array(g["initial_parameters"], dtype=f32)
+        mt, vt, b1t, b2t = np.zeros_like(th), np.zeros_like(th), 0.9, 0.999
+        for k in range(10):
+            r = U.loss_and_gradient(U.ODEProblem(f, X[0], (float(t[0]), float(t[-1])), th), U.Vern7(), X[None], saveat=t, sensealg=sense)
+            sw = float(th[-5:-2].astype(np.float64).sum())
+            loss = float(r.loss) + abs(sw)
+            assert abs(loss - gold[k]) < 5e-5 * gold[k], (name, type(sense).__name__, k, loss, gold[k])
+            gr = r.grad_theta.astype(np.float64)
+            gr[-5:-2] += np.sign(sw)
+            mt = (0.9 * mt.astype(np.float64) + 0.1 * gr).astype(f32)
+            vt = (0.999 * vt.astype(np.float64) + 0.001 * gr * gr).astype(f32)
+            step = 0.1 * (mt.astype(np.float64) / (1 - b1t)) / (np.sqrt(vt.astype(np.float64) / (1 - b2t)) + np.finfo(np.float64).eps)
+            th = (th.astype(np.float64) - step).astype(f32)
+            b1t *= 0.9
+            b2t *= 0.999
+
+
 def test_hudson_bay_f32_trained_loss_and_gradient(golden):
     """hudson_bay.jl:98-123 in Float32: loss(trained_parameters) = losses[end] = 0.00357905; gradient vs the oracle"""
     g = golden(HB)
