@@ -263,6 +263,32 @@ def test_adam_trajectory_with_discrete_gradient(golden):
         b2t *= b2
 
 
+def test_loop_recoveries_adam_trajectory_follows_the_stored_losses(golden):
+    """LotkaVolterra/loop_recoveries.jl:18-71 (noise 0.05, a Float32 run upstream): loss = sum(abs2, X .- pred) + 1f-4 sum(abs2, theta) /
+    length(theta) (:50), ADAM(0.1f0) for 200 iterations, gradients by ForwardDiffSensitivity.  The Float64 restatement with the discrete
+    sweep follows ALL 200 stored losses of Scenario_1_recovery_0.05 to Float32 accuracy (worst 4.8e-5)."""
+    g = golden("Scenario_1_recovery_0.05")
+    t = np.array(g["solution"]["t"], dtype=np.float64)
+    X = np.array(g["X"]["data_colmajor"], dtype=np.float64).reshape(len(t), 2)
+    gold = np.array(g["losses"]["data_colmajor"])
+    m, o = O.lv_ude_s1(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=1)
+    th = np.array(g["initial_parameters"], dtype=np.float64)
+    mt, vt, b1t, b2t = np.zeros_like(th), np.zeros_like(th), 0.9, 0.999
+    worst = 0.0
+    for k in range(200):
+        r = O.loss_grad_ensemble(m, o, X[0], [t[0], t[-1]], th, t, X[None])
+        loss = r["loss"] + 1e-4 * np.sum(th ** 2) / th.size
+        gr = r["grad_theta"] + 2e-4 * th / th.size
+        worst = max(worst, abs(loss - gold[k]) / gold[k])
+        assert abs(loss - gold[k]) < (5e-6 if k < 10 else 2e-4) * gold[k], (k, loss, gold[k])
+        mt = 0.9 * mt + 0.1 * gr
+        vt = 0.999 * vt + 0.001 * gr * gr
+        th = th - 0.1 * (mt / (1 - b1t)) / (np.sqrt(vt / (1 - b2t)) + np.finfo(np.float32).eps)
+        b1t *= 0.9
+        b2t *= 0.999
+    assert worst < 2e-4
+
+
 def test_bfgs_hagerzhang_follows_the_stored_losses(golden):
     """scenario_1.jl:111-118: 200 iterations of ADAM(0.1), then Optim.BFGS(initial_stepnorm = 0.01) -- Optim's default HagerZhang line
     search from alpha = 1 -- starting at the last parameters ADAM evaluated (stored losses[199] == [200] == [201]).  The host
