@@ -94,3 +94,22 @@ def test_node_adjoint_is_reproducible_run_to_run(N):
         r = U.loss_and_gradient(ens, U.Tsit5() if a == "t" else U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
         assert_bitwise(r.stats, refs[a]["stats"], "stats (%s)" % a)
         assert_bitwise(r.grad_u0, refs[a]["grad_u0"], "dL/du0 (%s)" % a)
+
+
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+@pytest.mark.parametrize("N,S0,tf", [(1, 100.0, 6.0), (21, 100.0, 6.0), (5, 14e6, 21.0)])
+def test_node_lockstep_kernel_matches_oracle(alg, oalg, N, S0, tf):
+    """the lock-step matrix-core backward kernel of the neural ODE (csrc/ude_node_ls.h, lanes_per_traj = 16): backward step counts,
+    dL/du0 and -- for a single trajectory -- every one of the 9287 gradient entries bit-identical to the oracle"""
+    u0, th = node_case(N, S0)
+    t = np.arange(0.0, tf + 0.5, 1.0)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, tf], [], t)
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_node(), u0[0], (0.0, tf), th), u0)
+    r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=U.EnsembleMI355(16))
+    ref = O.loss_grad_ensemble(O.seir_node(), O.opts(oalg, 1e-6, 1e-6), u0, [0.0, tf], th, t, truth, row_mask=MASK, nthreads=6)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    gn = np.linalg.norm(ref["grad_theta"])
+    assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
+    if N == 1:
+        assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta (single trajectory)")

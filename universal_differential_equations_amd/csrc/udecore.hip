@@ -215,6 +215,7 @@ void ude_poison_chip_dbg(hipStream_t st, bool before_forward) {  // (what & 4: a
 // lock-step matrix-core adjoint of the SEIR exposure UDE (csrc/ude_seir_ls.hip)
 extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes);
+extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 
 struct InstanceRow {
     int mid, alg, G, W;
@@ -316,6 +317,9 @@ static int64_t ls_blocks(ude_ctx* c, int64_t N, int per_cu = 1) {
 #ifndef UDE_SEIR_LS_DEFAULT
 #define UDE_SEIR_LS_DEFAULT 1   // 1: the lock-step matrix-core backward kernel is the default for the SEIR exposure UDE
 #endif
+#ifndef UDE_NODE_LS_DEFAULT
+#define UDE_NODE_LS_DEFAULT 0   // the SEIR neural ODE on the same architecture (csrc/ude_node_ls.h): lanes_per_traj = 16 selects it
+#endif
 #ifndef UDE_SEIR_LS_FWD_PER_CU
 #define UDE_SEIR_LS_FWD_PER_CU 1   // resident blocks of the forward lock-step kernel per compute unit (two, at 256 registers: 3.8 instead of 2.7 ms -- spills)
 #endif
@@ -363,7 +367,7 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
                                             "outside the runtime-shape fallback (Float64, replicated-state kinds LV / SEIR, <= 8 layers of width <= 64)",
                     m->kind, m->dtype, m->n_layers);
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
-    if (mid == MID_SEIR_UDE && G == 16) G = 64;  // (16 = the lock-step backward kernel of grad_dev_impl; every other kernel of that model: one wavefront per trajectory)
+    if ((mid == MID_SEIR_UDE || mid == MID_SEIR_NODE) && G == 16) G = 64;  // (16 = the lock-step backward kernel of grad_dev_impl; every other kernel of that model: one wavefront per trajectory)
     const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
     bool ok = false;
     // scenario_1's chain with both diagonal coefficients constant has a leaner instance (no slots for them) where compiled
@@ -688,6 +692,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const int want_lanes = c->lo.lanes_per_traj;
     const bool seir_ls = model_id(m) == MID_SEIR_UDE && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT && o->per_trajectory == 0 &&
                          (want_lanes == 16 || (want_lanes == 0 && UDE_SEIR_LS_DEFAULT));
+    const bool node_ls = model_id(m) == MID_SEIR_NODE && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT && o->per_trajectory == 0 &&
+                         (want_lanes == 16 || (want_lanes == 0 && UDE_NODE_LS_DEFAULT));
+    const bool any_ls = seir_ls || node_ls;
+    const int ls_slk = seir_ls ? 71 : 146;   // parameter slots per hidden row (mu: two columns of ls_slk x 64 per trajectory)
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
@@ -702,8 +710,8 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     int64_t nwaves = (int64_t)grid * ((BLOCK >= 64 && G <= 64) ? BLOCK / 64 : 1);  // rows of the partial-gradient matrix
     void (*ls_kern)(const KParams, double*, int*) = nullptr;
     size_t ls_lds = 0, ls_fac = 0;
-    if (seir_ls) {
-        ude_seir_ls_get(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &ls_fac);
+    if (any_ls) {
+        (seir_ls ? ude_seir_ls_get : ude_node_ls_get)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &ls_fac);
         if (nwaves < N) nwaves = N;   // one gradient row per trajectory
     }
     const bool ckpt = o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED;
@@ -726,8 +734,8 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = ensure(c, c->loss_traj, es * N))) return rc;
     if ((rc = ensure(c, c->grad_part, es * (size_t)nwaves * np))) return rc;
     p.slot_glob = nullptr;
-    if (seir_ls) {  // mu of every trajectory: two columns of 71 slots x 64 hidden rows; the stage factors of every block of 16 slots
-        if ((rc = ensure(c, c->slot_glob, sizeof(double) * (size_t)N * 2 * 71 * 64))) return rc;
+    if (any_ls) {  // mu of every trajectory: two columns of 71 (146) slots x 64 hidden rows; the stage factors of every block of 16 slots
+        if ((rc = ensure(c, c->slot_glob, sizeof(double) * (size_t)N * 2 * ls_slk * 64))) return rc;
         if ((rc = ensure(c, c->ls_fac, sizeof(double) * (size_t)ls_blocks(c, N) * ls_fac + 64))) return rc;
         p.slot_glob = (double*)c->slot_glob.p;
     } else if (l.slot_glob > 0) {  // slot state mu of the adjoint in HBM: [slot][thread]
@@ -805,7 +813,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     }
     ude_poison_chip(c->stream, false);
-    if (seir_ls) {
+    if (any_ls) {
         // persistent blocks (one per CU at most), trajectories handed out through a queue counter that lives behind the factor workspace
         const int64_t nblk = ls_blocks(c, N);
         int* queue = (int*)((double*)c->ls_fac.p + (size_t)nblk * ls_fac);
