@@ -51,13 +51,14 @@ def test_node_forward_and_adjoint_match_oracle(alg, oalg, S0, tf):
     assert (rc == 0).all()
     assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts")
     assert_bitwise(sol.u, out, "forward states")
-    r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
     ref = O.loss_grad_ensemble(O.seir_node(), O.opts(oalg, 1e-6, 1e-6), u0, [0.0, tf], th, t, truth, row_mask=MASK, nthreads=6)
-    assert (r.retcode == 0).all()
-    check_per_trajectory(r, ref)
-    assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
     gn = np.linalg.norm(ref["grad_theta"])
-    assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
+    for ealg in (None, U.EnsembleMI355(64)):    # the default (the lock-step kernel, csrc/ude_node_ls.h) and the wavefront-per-trajectory kernel
+        r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=ealg)
+        assert (r.retcode == 0).all()
+        check_per_trajectory(r, ref)
+        assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
+        assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
     W4g = r.grad_theta[-455:-7].reshape(64, 7)
     assert np.all(W4g[:, 5:] == 0) and np.all(r.grad_theta[-2:] == 0) and np.abs(W4g[:, 1:4]).min() > 0   # rows of dE, dI, dR: the masked loss rows
     if S0 == 100.0:
@@ -113,3 +114,28 @@ def test_node_lockstep_kernel_matches_oracle(alg, oalg, N, S0, tf):
     assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
     if N == 1:
         assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta (single trajectory)")
+
+
+def test_node_lockstep_kernel_user_cotangent_fixed_dt_and_failures():
+    """the lock-step neural-ODE kernel behind ude_vjp_ensemble (a user cotangent), with `dt = ...` given, and with backward solves that
+    stop at maxiters (retcodes and work counts per trajectory, zero gradient rows, the slots moving on to the rest of the ensemble)"""
+    N, S0, tf = 37, 100.0, 6.0
+    u0, th = node_case(N, S0)
+    t = np.arange(0.0, tf + 0.5, 1.0)
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_node(), u0[0], (0.0, tf), th), u0)
+    kw = {"ensemblealg": U.EnsembleMI355(16)}
+    cot = np.random.default_rng(3).normal(size=(N, len(t), 7))
+    r = U.adjoint_pullback(ens, U.Vern7(), cot, saveat=t, abstol=1e-6, reltol=1e-6, **kw)
+    ref = O.vjp_ensemble(O.seir_node(), O.opts(O.VERN7, 1e-6, 1e-6), u0, [0.0, tf], th, t, cot, nthreads=6)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, tf], [], t)
+    r = U.loss_and_gradient(ens, U.Tsit5(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, dt=0.02, **kw)
+    ref = O.loss_grad_ensemble(O.seir_node(), O.opts(O.TSIT5, 1e-6, 1e-6, dt0=0.02), u0, [0.0, tf], th, t, truth, row_mask=MASK, nthreads=6)
+    check_per_trajectory(r, ref)
+    r = U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, maxiters=9, allow_failures=True, **kw)
+    ref = O.loss_grad_ensemble(O.seir_node(), O.opts(O.VERN7, 1e-6, 1e-6, maxiters=9), u0, [0.0, tf], th, t, truth, row_mask=MASK, nthreads=6)
+    assert_bitwise(r.retcode, ref["retcode"], "retcodes")
+    assert (r.retcode != 0).any() and np.isinf(r.loss)
+    assert_bitwise(r.stats[:, [0, 1, 2, 4, 5, 6]], ref["stats"][:, [0, 1, 2, 4, 5, 6]], "work counts")

@@ -318,7 +318,7 @@ static int64_t ls_blocks(ude_ctx* c, int64_t N, int per_cu = 1) {
 #define UDE_SEIR_LS_DEFAULT 1   // 1: the lock-step matrix-core backward kernel is the default for the SEIR exposure UDE
 #endif
 #ifndef UDE_NODE_LS_DEFAULT
-#define UDE_NODE_LS_DEFAULT 0   // the SEIR neural ODE on the same architecture (csrc/ude_node_ls.h): lanes_per_traj = 16 selects it
+#define UDE_NODE_LS_DEFAULT 1   // ... and so does the SEIR neural ODE (csrc/ude_node_ls.h); lanes_per_traj = 64 selects the wavefront-per-trajectory kernel
 #endif
 #ifndef UDE_SEIR_LS_FWD_PER_CU
 #define UDE_SEIR_LS_FWD_PER_CU 1   // resident blocks of the forward lock-step kernel per compute unit (two, at 256 registers: 3.8 instead of 2.7 ms -- spills)
