@@ -41,7 +41,7 @@ template <class Tab>
 constexpr int lds_doubles() {
     constexpr int NSTC = popc(stage_mask<Tab>());
     return 2 * H * LDW + 4 * H * TLD + 8 * 16 + 8 * 16 + NIN * NSLOTS * 4 + NSTC * NSLOTS * XFW + NSLOTS * 16 + NSLOTS * 8 + TABL + 6 * NSLOTS +
-           NSLOTS * 4 * 2 + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16 + 4 * 2 * NSTC * QW;
+           NSLOTS * 4 * 2 + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16 + 4 * 2 * NSTC * QW + NIN * H;
 }
 template <class Tab>
 constexpr size_t fac_doubles_per_block() { return (size_t)NSLOTS * popc(stage_mask<Tab>()) * NFAC * H; }
@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
     double* RQL = KSL + NSLOTS * 8 * (NK + 2); // [16][8]
     double* ZK = RQL + 16 * 8;                 // [16][16]
     double* ASTG = ZK + NSLOTS * 16;           // [4 wavefronts][2][NSTC][16]
+    double* W1L = ASTG + 4 * 2 * NSTC * QW;    // [7][64]: W1[i][m] at W1L[m * H + i] (read where the input-cotangent products are formed)
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int kq = l >> 4, jc = l & 15;
@@ -225,10 +226,10 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
         W1A[sc] = k < NIN ? th[OFF_W1 + row + k * H] : th[OFF_B1 + row];
         W4T[sc] = k < NOUT ? th[OFF_W4 + k + row * NOUT] : 0.0;
     });
-    double w1r[NIN][4], b2r[4], b3r[4];
+    for (int i = tid; i < NIN * H; i += BLOCKT) W1L[i] = th[OFF_W1 + i];
+    double b2r[4], b3r[4];
     static_for<0, 4>([&](auto r) {
         const int row = 16 * w + kq + 4 * decltype(r)::value;
-        static_for<0, NIN>([&](auto mm) { w1r[mm][r] = th[OFF_W1 + row + decltype(mm)::value * H]; });
         b2r[r] = th[OFF_B2 + row];
         b3r[r] = th[OFF_B3 + row];
     });
@@ -506,7 +507,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
                 double v[4];
                 static_for<0, 4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    double x = w1r[mm][r] * dv1[r];
+                    double x = W1L[decltype(mm)::value * H + 16 * w + kq + 4 * r] * dv1[r];
                     x += __shfl_xor(x, 16, 64);
                     x += __shfl_xor(x, 32, 64);
                     v[r] = x;
