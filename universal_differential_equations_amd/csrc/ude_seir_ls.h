@@ -53,7 +53,7 @@ template <class Tab>
 constexpr int lds_doubles() {
     constexpr int NSTC = popc(stage_mask<Tab>());
     return 4 * H * TLD + 4 * 16 + 16 + 3 * NSLOTS * PLD + NSTC * NSLOTS * 4 + NSLOTS * 16 + NSLOTS * 8 + TABL + 6 * NSLOTS + NSLOTS * 4 * 2 +
-           NSLOTS * NSTC * H + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16;
+           NSLOTS * NSTC * H + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16 + 3 * H;
 }
 // doubles of factor workspace per block
 template <class Tab>
@@ -201,6 +201,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     double* KSL = A1P + NSLOTS * NSTC * H;         // [16 slots][NK + 2][8]: interval cache (u_start, k_q) and f0 of the initial-dt phase, component c at [..][c]
     double* RQL = KSL + NSLOTS * 8 * (NK + 2); // [16 lanes q][8]: Horner tables of b_q(theta)
     double* ZK = RQL + 16 * 8;                // [16 slots][16]: znew[7] | kr[7] parked across the parameter-slot work of a trip
+    double* W1L = ZK + NSLOTS * 16;           // [3][64]: W1[i][m] at W1L[m * H + i] (read where the input-cotangent products are formed)
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int kq = l >> 4, jc = l & 15;       // matrix view: k index / column (= slot) of this lane
@@ -222,10 +223,10 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
         });
     }
     const double W1A = kq < 3 ? th[OFF_W1 + (16 * w + jc) + kq * H] : th[OFF_B1 + 16 * w + jc];
-    double w1r[3][4], b2r[4], w3r[4];
+    for (int i = tid; i < 3 * H; i += BLOCKT) W1L[i] = th[OFF_W1 + i];
+    double b2r[4], w3r[4];
     static_for<0, 4>([&](auto r) {
         const int row = 16 * w + kq + 4 * decltype(r)::value;
-        static_for<0, 3>([&](auto mm) { w1r[mm][r] = th[OFF_W1 + row + decltype(mm)::value * H]; });
         b2r[r] = th[OFF_B2 + row];
         w3r[r] = th[OFF_W3 + row];
     });
@@ -479,7 +480,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
                     dv1[r] = s1 * __builtin_fma(-a1[r], a1[r], 1.0);
                     const int row = 16 * w + kq + 4 * r;
                     T_D1[row * TLD + jc] = dv1[r];
-                    static_for<0, 3>([&](auto mm) { PG[(decltype(mm)::value * NSLOTS + jc) * PLD + row] = w1r[mm][r] * dv1[r]; });
+                    static_for<0, 3>([&](auto mm) { PG[(decltype(mm)::value * NSLOTS + jc) * PLD + row] = W1L[decltype(mm)::value * H + row] * dv1[r]; });
                 });
             }
         }
