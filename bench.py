@@ -37,7 +37,7 @@ SENSE_NAME = {"adjoint": "InterpolatingAdjoint", "discrete": "discretise-then-op
               "fast": "InterpolatingAdjoint with lambda-only error control (SURVEY 8(b) fast mode; not the reference's step sequence)"}
 # which unit dominates each backward kernel: the LV / SEIR kernels run on the FP64 VALU, Fisher-KPP on the FP64 matrix cores
 # (both peaks are 78.6 TF; the schema's "bound" offers hbm | mfma)
-BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint; SEIR exposure UDE: seir_ls_adj_kernel, 16 trajectories per block in lock-step on the FP64 matrix cores)", "discrete": "dadj_kernel (frozen-step reverse sweep)",
+BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint; SEIR exposure UDE / neural ODE: seir_ls_adj_kernel / node_ls_adj_kernel, 16 trajectories per block in lock-step on the FP64 matrix cores)", "discrete": "dadj_kernel (frozen-step reverse sweep)",
               "fast": "adj_kernel, fast mode (lambda-only error control)"}
 
 
@@ -136,6 +136,8 @@ def pmc_traffic(a):
     kern = "adj_kernel<" if a.sensealg == "adjoint" else "dadj_kernel<"
     if a.workload == "seir" and a.sensealg == "adjoint" and a.lanes in (0, 16):
         kern = "seirls::seir_ls_adj_kernel<"     # the lock-step matrix-core backward kernel (the default)
+    if a.workload == "node" and a.sensealg == "adjoint" and a.lanes in (0, 16):
+        kern = "nodels::node_ls_adj_kernel<"
     return pmc_traffic_file("r03_pmc_%s.md" % a.workload, "`void " + kern) or pmc_traffic_file("r02_pmc_%s.md" % a.workload, "`void " + kern)
 
 
@@ -340,11 +342,11 @@ def quick_measure(name, device, steps=3, warmup=1):
     nf_fwd, nf_bwd = int(ens.stats[:, 0].sum().item()), int(ens.stats[:, 4].sum().item())
     flop_key = "lv_tanh32" if name == "lv_tanh32" else wl
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
-    kern = "dadj_kernel" if sense == "discrete" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "adj_kernel"
+    kern = "dadj_kernel" if sense == "discrete" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "nodels::node_ls_adj_kernel" if wl == "node" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete") else wl
     return {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
             "fwd_kernel_ms": f, "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
-            "unit": "mfma-f64" if wl == "kpp" else ("mfma-f64 + valu-f64" if wl == "seir" else "valu-f64"), "failed_trajectories": int((ens.retcode != 0).sum().item()),
+            "unit": "mfma-f64" if wl == "kpp" else ("mfma-f64 + valu-f64" if wl in ("seir", "node") else "valu-f64"), "failed_trajectories": int((ens.retcode != 0).sum().item()),
             "traffic": pmc_any(pm, "`void " + kern + "<"), "setup_s": time.perf_counter() - t_setup}
 
 
@@ -524,8 +526,9 @@ def main():
                        "lane_step_util": lane_step_util, "bwd_attempts_max_over_mean": critical_path,
                        "fwd_kernel_ms": float(np.mean(fwd_ms)),
                        "bwd_kernel_ms": float(np.mean(bwd_ms))},
-            "roofline": {"bound": "mfma", "unit_busy": {"kpp": "mfma-f64", "seir": "mfma-f64 + valu-f64"}.get(a.workload, "valu-f64"),
-                         "kernel": BWD_KERNEL[a.sensealg] + {"kpp": ", FP64 matrix cores", "seir": ", network on the FP64 matrix cores, parameter-slot sums / controller on the FP64 vector unit"}.get(
+            "roofline": {"bound": "mfma", "unit_busy": {"kpp": "mfma-f64", "seir": "mfma-f64 + valu-f64", "node": "mfma-f64 + valu-f64"}.get(a.workload, "valu-f64"),
+                         "kernel": BWD_KERNEL[a.sensealg] + {"kpp": ", FP64 matrix cores", "seir": ", network on the FP64 matrix cores, parameter-slot sums / controller on the FP64 vector unit",
+                                    "node": ", network on the FP64 matrix cores, parameter-slot sums / controller on the FP64 vector unit"}.get(
                                        a.workload, ", FP64 VALU (no MFMA: 5- and 64-wide layers stay on the vector unit)"),
                          "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
