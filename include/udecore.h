@@ -108,8 +108,10 @@ typedef struct {
     int32_t lanes_per_traj;   /* 0 = auto; lanes cooperating on one trajectory.  Compiled variants: LV 2-5-5-5-2: 1, 4, 5 (default:
                                  12 trajectories per wavefront), 8; LV 2-32-2: 8, 32 (default); SEIR UDE: 64 (wavefront per
                                  trajectory), 256 (four wavefronts), 16 (default for the interpolating adjoint: lock-step backward
-                                 kernel, 16 trajectories per block as columns of FP64 matrix-core products); Fisher-KPP UDE <= 32 points: 32; 1024 points: 256
-                                 (default, four wavefronts per PDE) or 64.  Every variant returns identical bits. */
+                                 kernel, 16 trajectories per block as columns of FP64 matrix-core products; plain solves and the forward pass of a gradient
+                                 run on the same architecture); SEIR neural ODE 7-64-64-64-7: 64 (wavefront per trajectory), 16 (default for the
+                                 interpolating adjoint: lock-step backward kernel); Fisher-KPP UDE <= 32 points: 32; 1024 points: 256 (default,
+                                 four wavefronts per PDE in the adjoint, eight in the forward solve) or 64.  Every variant returns identical bits. */
     int32_t block_threads;    /* 0 = auto (64) */
     int32_t max_dense_steps;  /* capacity of the dense forward store per trajectory; 0 = automatic: starts at 256 and is
                                  re-run with 4x the capacity on UDE_RET_DENSE_OVERFLOW by the host-buffer entry points
