@@ -139,3 +139,41 @@ def test_node_lockstep_kernel_user_cotangent_fixed_dt_and_failures():
     assert_bitwise(r.retcode, ref["retcode"], "retcodes")
     assert (r.retcode != 0).any() and np.isinf(r.loss)
     assert_bitwise(r.stats[:, [0, 1, 2, 4, 5, 6]], ref["stats"][:, [0, 1, 2, 4, 5, 6]], "work counts")
+
+
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+def test_node_lockstep_forward_kernel_plain_solves(alg, oalg):
+    """the forward lock-step kernel of the neural ODE (csrc/ude_node_ls_fwd.h) without a dense store: a ragged save grid that
+    contains neither end point (Vern7's lazy stages only in steps with a save point strictly inside), a given dt, 41 trajectories
+    on 16-slot blocks, solves that stop at maxiters -- and the same calls on the wavefront-per-trajectory kernel"""
+    N, tf = 41, 6.0
+    u0, th = node_case(N, 100.0)
+    grid = np.array([0.37, 2.0, 2.5, 4.25, 5.99])
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_node(), u0[0], (0.0, tf), th), u0)
+    for kw, okw in (({}, {}), ({"dt": 0.03}, {"dt0": 0.03}), ({"maxiters": 5}, {"maxiters": 5})):
+        out, st, rc = O.solve_ensemble(O.seir_node(), O.opts(oalg, 1e-6, 1e-6, **okw), u0, [0.0, tf], th, grid)
+        for lanes in (16, 64):
+            sol = U.solve(ens, alg(), saveat=grid, abstol=1e-6, reltol=1e-6, ensemblealg=U.EnsembleMI355(lanes), **kw)
+            assert_bitwise(sol.retcodes, rc, "retcodes %s" % kw)
+            assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts incl. lazy stages %s" % kw)
+            if "maxiters" in kw:
+                assert (rc != 0).any()          # (a mixed block: some slots stop at maxiters, the others finish)
+            else:
+                assert (rc == 0).all()
+            assert_bitwise(sol.u[rc == 0], out[rc == 0], "states %s" % kw)
+
+
+def test_node_lockstep_forward_kernel_dense_overflow_matches_the_wavefront_kernel():
+    """a dense store of 3 steps: every trajectory stops with DenseOverflow after its third accepted step, with the same counters
+    whichever forward kernel ran"""
+    N, tf = 19, 6.0
+    u0, th = node_case(N, 100.0)
+    t = np.arange(0.0, tf + 0.5, 1.0)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, tf], [], t)
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_node(), u0[0], (0.0, tf), th), u0)
+    res = [U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6,
+                               ensemblealg=U.EnsembleMI355(lanes, 3), allow_failures=True) for lanes in (16, 64)]
+    assert (res[0].retcode != 0).all()
+    assert_bitwise(res[0].retcode, res[1].retcode, "retcodes")
+    assert_bitwise(res[0].stats, res[1].stats, "counters")
+    assert np.isinf(res[0].loss) and not res[0].grad_theta.any()

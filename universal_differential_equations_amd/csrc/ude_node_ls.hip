@@ -1,8 +1,15 @@
 // ude_node_ls.hip -- translation unit of the lock-step matrix-core adjoint of the SEIR neural ODE (ude_node_ls.h).
 #include <hip/hip_runtime.h>
 #include "ude_node_ls.h"
+#include "ude_node_ls_fwd.h"
 using namespace ude;
 extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block) {
     if (alg == 1) { *kern = nodels::node_ls_adj_kernel<Vern7Tab>; *lds_bytes = sizeof(double) * nodels::lds_doubles<Vern7Tab>() + 16; *fac_doubles_per_block = nodels::fac_doubles_per_block<Vern7Tab>(); }
     else { *kern = nodels::node_ls_adj_kernel<Tsit5Tab>; *lds_bytes = sizeof(double) * nodels::lds_doubles<Tsit5Tab>() + 16; *fac_doubles_per_block = nodels::fac_doubles_per_block<Tsit5Tab>(); }
+}
+
+// the forward solve on the same architecture (ude_node_ls_fwd.h)
+extern "C" void ude_node_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes) {
+    *kern = alg == 1 ? nodels::node_ls_fwd_kernel<Vern7Tab> : nodels::node_ls_fwd_kernel<Tsit5Tab>;
+    *lds_bytes = sizeof(double) * nodels::fwd_lds_doubles() + 16;
 }

@@ -1,0 +1,423 @@
+// ude_node_ls_fwd.h -- the FORWARD solve of the SEIR script's pure neural ODE (dudt_node, SEIR_exposure/seir_exposure.jl:53-83) on
+// the lock-step architecture of ude_seir_ls_fwd.h: one trip of a persistent block is ONE right-hand side of every busy slot
+// (initial-dt heuristic, a stage of a step attempt, one of Vern7's lazy dense-output stages), sixteen slots as the columns of
+// v_mfma_f64_16x16x4.  First layer 7 -> 64: two k-steps, the eighth term adds the bias (fma(b, 1, acc) == acc + b); the two
+// 64x64 layers: A-operand fragments of W2 and W3 in registers (the forward kernel has room for both), four 16-term chains added
+// left to right; output layer: the five outputs the script uses, each the adjacent-pair tree over the 64 rounded products
+// W4[i, j] a3[j] on the slot's 16-lane row, plus b4[i].  Everything else is ude_seir_ls_fwd.h's state machine verbatim.  Per
+// trajectory every number is bit-identical to fwd_kernel<SeirNode<64>> and to the oracle.  Float64, shared time grid.
+#pragma once
+#include "ude_node_ls.h"
+
+namespace ude {
+namespace nodels {
+
+using seirls::row_tree4;
+using seirls::PLD;
+constexpr int NFO = 5;   // outputs of the network the right-hand side uses (du0..du3, du5)
+
+enum { FPH_IDLE = -4, FPH_FSAL0 = -3, FPH_INIT0 = -2, FPH_INIT1 = -1 };   // >= 0: stage s; s >= S: lazy dense-output stage s - S
+
+constexpr int fwd_lds_doubles() { return 2 * H * TLD + 8 * 16 + NFO * NSLOTS * PLD + TABL + 16; }
+
+template <class Tab>
+__global__ void __launch_bounds__(BLOCKT, 1) node_ls_fwd_kernel(const KParams p, int* __restrict__ queue) {
+    constexpr int S = Tab::S, NK = Tab::NK, NX = Tab::NEXTRA;
+    constexpr int FIRST = Tab::FSAL ? 1 : 0;   // first stage an attempt evaluates (FSAL: stage 0 is handed over)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* T_A1 = sm;                       // [64][17]
+    double* T_A2 = T_A1 + H * TLD;           // [64][17]
+    double* XIN = T_A2 + H * TLD;            // [8][16]: x0 .. x6, 1
+    double* PG = XIN + 8 * 16;               // [5][16][65]: W4[o, i] a3[i] of output o, slot (column) and hidden row i
+    double* TB = PG + NFO * NSLOTS * PLD;    // tableau: A[16][16], B, BT, C
+
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int kq = l >> 4, jc = l & 15;      // matrix view
+    const int rr = l >> 4, lm = l & 15;      // scalar view: slot 4w + rr, lane lm of its row
+    const int slot = 4 * w + rr;
+    const double* __restrict__ th = p.theta;
+    const TabDev* __restrict__ tab = p.tab;
+    const int n = NC;
+
+    double W2A[16], W3A[16], W1A[2];
+    {
+        const int row = 16 * w + jc;
+        static_for<0, 16>([&](auto sc) {
+            W2A[sc] = th[OFF_W2 + row + (4 * decltype(sc)::value + kq) * H];
+            W3A[sc] = th[OFF_W3 + row + (4 * decltype(sc)::value + kq) * H];
+        });
+        static_for<0, 2>([&](auto sc) {
+            const int k = 4 * decltype(sc)::value + kq;
+            W1A[sc] = k < NIN ? th[OFF_W1 + row + k * H] : th[OFF_B1 + row];
+        });
+    }
+    double b2r[4], b3r[4], w4r[NFO][4], b4c[NFO];
+    static_for<0, 4>([&](auto r) {
+        const int row = 16 * w + kq + 4 * decltype(r)::value;
+        b2r[r] = th[OFF_B2 + row];
+        b3r[r] = th[OFF_B3 + row];
+        static_for<0, NFO>([&](auto oc) { w4r[oc][r] = th[OFF_W4 + (int)decltype(oc)::value + row * NOUT]; });
+    });
+    static_for<0, NFO>([&](auto oc) { b4c[oc] = th[OFF_B4 + decltype(oc)::value]; });
+    const double muc = p.mc.consts[4], sgc = p.mc.consts[5];
+    if (tid < 16) XIN[7 * 16 + tid] = 1.0;
+    for (int i = tid; i < 7 * 16; i += BLOCKT) XIN[i] = 1.0;   // (columns of idle slots: finite)
+    for (int i = tid; i < 16 * 16; i += BLOCKT) TB[i] = tab->A[i >> 4][i & 15];
+    if (tid < 16) { TB[256 + tid] = tab->B[tid]; TB[272 + tid] = tab->BT[tid]; TB[288 + tid] = tab->C[tid]; }
+
+    const OptsR o(p.o);
+    const double T0 = p.t0, TF = p.tf, tdir = 1.0;
+    const double dtmax = o.dtmax;
+    const double ntot = (double)p.n_state;
+    const bool user_dt = o.dt0 > 0.0;
+    int ph = FPH_IDLE, ret = RET_SUCCESS, iter = 0, si = 0, nsteps = 0;
+    long long gid = 0;
+    bool accept = true, exhausted = false, fresh = false;
+    double t = T0, dt = 0.0, dt0 = 0.0, d1n = 0.0, qold = o.qoldinit, q11 = 1.0, tprev = T0, dtnew = 0.0, loss = 0.0;
+    long long nfc = 0, nacc = 0, nrej = 0, nlazy = 0;
+    double u[NC], znew[NC], K[NK];
+    static_for<0, NC>([&](auto c) { u[c] = 0.0; znew[c] = 0.0; });
+    static_for<0, NK>([&](auto q) { K[q] = 0.0; });
+
+    auto own = [&](const double (&v)[NC]) {
+        double r = 0.0;
+        static_for<0, NC>([&](auto c) { r = (lm == (int)decltype(c)::value) ? v[c] : r; });
+        return r;
+    };
+    auto bcast = [&](double ownv, double (&out)[NC]) { static_for<0, NC>([&](auto c) { out[c] = rshfl(ownv, decltype(c)::value); }); };
+    auto SV = [&](int i) { return p.saveat[i]; };
+    // FwdSys::save_point: a saved state, its loss term and the cotangent row the adjoint will jump by
+    auto save_point = [&](int i, const double (&v)[NC]) {
+        if (p.u_out && lm < NC) p.u_out[((size_t)gid * p.ns + i) * n + lm] = own(v);
+        if (p.data) {
+            const double* d = p.data + ((size_t)gid * p.ns + i) * n;
+            static_for<0, NC>([&](auto c) {
+                constexpr int ci = decltype(c)::value;
+                const double e = (p.row_mask && !p.row_mask[ci]) ? 0.0 : (v[c] - d[ci]);
+                loss = __builtin_fma(e, e, loss);
+                if (lm == ci) p.cot[((size_t)i * n + ci) * p.Npad + gid] = 2.0 * e;
+            });
+        }
+    };
+    // the end of a trajectory: counters, return code, number of dense records, its loss
+    auto finish = [&]() {
+        if (lm == 0) {
+            if (p.stats) {
+                int64_t* s = p.stats + (size_t)gid * 8;
+                s[0] = nfc; s[1] = nacc; s[2] = nrej;
+                if (p.dense) { s[3] = 0; s[7] = nlazy; } else { s[3] = nlazy; s[7] = 0; }
+                s[4] = 0; s[5] = 0; s[6] = 0;
+            }
+            p.retcode[gid] = ret;
+            if (p.dense_n) p.dense_n[gid] = nsteps;
+            if (p.loss_traj) p.loss_traj[gid] = ret == RET_SUCCESS ? loss : 0.0;
+        }
+        ph = FPH_IDLE;
+    };
+    __syncthreads();
+
+    for (;;) {
+        // ---- A. an idle slot takes the next trajectory ----
+        if (ph == FPH_IDLE && !exhausted) {
+            int g = 0;
+            if (lm == 0) g = atomicAdd(queue, 1);
+            g = __shfl(g, 0, 16);
+            if (g >= p.N) exhausted = true;
+            else {
+                gid = g;
+                static_for<0, NC>([&](auto c) { u[c] = p.u0[(size_t)gid * n + decltype(c)::value]; znew[c] = 0.0; });
+                static_for<0, NK>([&](auto q) { K[q] = 0.0; });
+                t = T0; qold = o.qoldinit; q11 = 1.0; accept = true; iter = 0; ret = RET_SUCCESS;
+                nfc = 0; nacc = 0; nrej = 0; nlazy = 0; si = 0; nsteps = 0; loss = 0.0;
+                while (si < p.ns && SV(si) <= T0) { save_point(si, u); si += 1; }   // save_start
+                if (user_dt) {
+                    dt = tdir * o.dt0;
+                    if constexpr (Tab::FSAL) ph = FPH_FSAL0;
+                    else { ph = 0; fresh = true; }
+                } else ph = FPH_INIT0;
+            }
+        }
+
+        // ---- B. the state this slot's right-hand side is evaluated at ----
+        bool ev = false;
+        double zs[NC], kr[NC];
+        static_for<0, NC>([&](auto c) { zs[c] = u[c]; kr[c] = 0.0; });
+        const double zo = own(u);
+        if (ph == FPH_INIT0 || ph == FPH_FSAL0) {
+            ev = true;
+        } else if (ph == FPH_INIT1) {
+            ev = true;
+            const double dt0t = tdir * dt0;
+            static_for<0, NC>([&](auto c) { zs[c] = __builtin_fma(dt0t, znew[c], u[c]); });   // (znew holds f0 during the heuristic)
+        } else if (ph >= 0) {
+            bool go = true;
+            if (fresh) {   // loopheader!
+                fresh = false;
+                if (iter > 0 && !accept) {
+                    double den = q11 / o.gamma;
+                    const double iq = 1.0 / o.qmin;
+                    if (iq < den) den = iq;
+                    dt = dt / den;
+                }
+                iter += 1;
+                if (fabs(dt) > dtmax) dt = tdir * dtmax;
+                {
+                    const double rem = fabs(TF - t);
+                    if (fabs(dt) > rem) dt = tdir * rem;
+                }
+                if (iter > o.maxiters) { ret = RET_MAXITERS; go = false; }
+                else if (dt != dt) { ret = RET_UNSTABLE; go = false; }
+                else if (fabs(dt) <= REAL_EPS * fabs(t) && fabs(dt) < fabs(TF - t)) { ret = RET_DTLESSTHANMIN; go = false; }
+            }
+            if (go) {
+                ev = true;
+                if (ph > 0) {
+                    // all NK - 1 possible terms: coefficients beyond the row's own are zero in the table, the k storage is always
+                    // finite, fma(0, k, acc) == acc exactly
+                    const double* Ar = TB + ph * 16;
+                    double acc = Ar[0] * K[0];
+                    static_for<1, NK>([&](auto j) { acc = __builtin_fma(Ar[decltype(j)::value], K[j], acc); });
+                    bcast(__builtin_fma(dt, acc, zo), zs);
+                }
+            } else {
+                finish();
+            }
+        }
+        if (ev && lm < NIN) {
+            // network input [S/N, E, I, R, N, D/N, C]
+            const double xin[NIN] = {zs[0] / zs[4], zs[1], zs[2], zs[3], zs[4], zs[5] / zs[4], zs[6]};
+            XIN[lm * 16 + slot] = own(xin);
+        }
+        if (!__syncthreads_or(ph != FPH_IDLE)) break;   // all slots idle and the queue empty: done
+
+        // ---- C. the network for all 16 slots ----
+        {
+            v4d z = v4d{0.0, 0.0, 0.0, 0.0};
+            static_for<0, 2>([&](auto sc) { z = __builtin_amdgcn_mfma_f64_16x16x4f64(W1A[sc], XIN[(4 * decltype(sc)::value + kq) * 16 + jc], z, 0, 0, 0); });
+            static_for<0, 4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                T_A1[(16 * w + kq + 4 * r) * TLD + jc] = dtanh(z[r]);
+            });
+            __syncthreads();
+            // a 64-term hidden product: four 16-term chains (four MFMAs each) added left to right
+            auto hidden = [&](const double (&WA)[16], const double* T, double (&out)[4]) {
+                v4d acc[4];
+                static_for<0, 4>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, 4>([&](auto q) {
+                        constexpr int s = 4 * b + decltype(q)::value;
+                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(WA[s], T[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                    });
+                });
+                static_for<0, 4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    out[r] = ((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r];
+                });
+            };
+            double hz[4];
+            hidden(W2A, T_A1, hz);
+            static_for<0, 4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                T_A2[(16 * w + kq + 4 * r) * TLD + jc] = dtanh(hz[r] + b2r[r]);
+            });
+            __syncthreads();
+            hidden(W3A, T_A2, hz);
+            static_for<0, 4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const double a3 = dtanh(hz[r] + b3r[r]);
+                static_for<0, NFO>([&](auto oc) { PG[((int)decltype(oc)::value * NSLOTS + jc) * PLD + 16 * w + kq + 4 * r] = w4r[oc][r] * a3; });
+            });
+        }
+        __syncthreads();
+
+        // ---- D. the slot's row: right-hand side of dudt_node ----
+        if (ev) {
+            double on[NFO];
+            static_for<0, NFO>([&](auto oc) {
+                const double* pr = PG + ((int)decltype(oc)::value * NSLOTS + slot) * PLD + 4 * lm;
+                on[oc] = row_tree4(pr[0], pr[1], pr[2], pr[3]) + b4c[oc];
+            });
+            kr[0] = on[0]; kr[1] = on[1]; kr[2] = on[2]; kr[3] = on[3];
+            kr[4] = -muc * zs[4];
+            kr[5] = on[4];
+            kr[6] = sgc * zs[1];
+        }
+
+        // ---- F. the slot's state machine ----
+        bool finalize = false;
+        if (ph == FPH_FSAL0 && ev) {
+            K[0] = own(kr);
+            nfc += 1;
+            ph = FIRST; fresh = true;
+        } else if (ph == FPH_INIT0 && ev) {
+            K[0] = own(kr);
+            static_for<0, NC>([&](auto c) { znew[c] = kr[c]; });   // f0
+            double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
+            static_for<0, NC>([&](auto c) {
+                const double sk = __builtin_fma(fabs(u[c]), o.reltol, o.abstol);
+                const double q0 = u[c] / sk, q1 = kr[c] / sk;
+                dd_acc(h0, l0, q0 * q0);
+                dd_acc(h1, l1, q1 * q1);
+            });
+            const double s0 = h0 + l0, s1 = h1 + l1;
+            const double d0 = __builtin_sqrt(s0 / ntot);
+            d1n = __builtin_sqrt(s1 / ntot);
+            if (d1n != d1n) ret = RET_UNSTABLE;
+            dt0 = (d0 < 1e-5 || d1n < 1e-5) ? 1e-6 : (d0 / d1n) / 100.0;
+            if (dt0 > dtmax) dt0 = dtmax;
+            if (dt0 < 10.0 * REAL_EPS) {
+                dt = tdir * 1e-6;
+                nfc += 2;
+                if constexpr (Tab::FSAL) nfc += 1;
+                if (ret != RET_SUCCESS) finish();
+                else { ph = FIRST; fresh = true; }
+            } else {
+                ph = FPH_INIT1;
+            }
+        } else if (ph == FPH_INIT1 && ev) {
+            double h2 = 0.0, l2 = 0.0;
+            static_for<0, NC>([&](auto c) {
+                const double sk = __builtin_fma(fabs(u[c]), o.reltol, o.abstol);
+                const double q = (kr[c] - znew[c]) / sk;
+                dd_acc(h2, l2, q * q);
+            });
+            const double s2 = h2 + l2;
+            const double d2 = __builtin_sqrt(s2 / ntot) / dt0;
+            const double mx = d1n > d2 ? d1n : d2;
+            double dt1;
+            if (mx <= 1e-15) {
+                dt1 = dt0 * 1e-3;
+                if (dt1 < 1e-6) dt1 = 1e-6;
+            } else {
+                const double ex = -(2.0 + rlog10(mx)) / (double)Tab::ORDER;
+                dt1 = rpow10(ex);
+            }
+            double d = 100.0 * dt0;
+            if (dt1 < d) d = dt1;
+            if (dtmax < d) d = dtmax;
+            dt = tdir * d;
+            nfc += 2;
+            if constexpr (Tab::FSAL) nfc += 1;
+            if (ret != RET_SUCCESS) finish();
+            else { ph = FIRST; fresh = true; }
+        } else if (ph >= 0 && ev) {
+            const double ko = own(kr);
+            static_for<0, NK>([&](auto j) { K[j] = ((int)decltype(j)::value == ph) ? ko : K[j]; });
+            if (ph < S - 1) {
+                ph += 1;
+            } else if (ph == S - 1) {
+                // perform_step! is complete: new state, error estimate, controller
+                nfc += Tab::FSAL ? S - 1 : S;
+                if constexpr (Tab::FSAL) static_for<0, NC>([&](auto c) { znew[c] = zs[c]; });
+                else {
+                    double acc = TB[256] * K[0];
+                    static_for<1, S>([&](auto j) { acc = __builtin_fma(TB[256 + decltype(j)::value], K[j], acc); });
+                    bcast(__builtin_fma(dt, acc, zo), znew);
+                }
+                double acc = TB[272] * K[0];
+                static_for<1, S>([&](auto j) { acc = __builtin_fma(TB[272 + decltype(j)::value], K[j], acc); });
+                const double a0 = fabs(zo), a1 = fabs(own(znew));
+                double res[NC];
+                bcast((dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
+                double ss = 0.0;
+                static_for<0, NC>([&](auto c) { ss = __builtin_fma(res[c], res[c], ss); });
+                const double EEst = __builtin_sqrt(ss / ntot);
+                double q;
+                if (EEst == 0.0) {
+                    q = 1.0 / o.qmax;
+                } else {
+                    q11 = fastpow(EEst, o.beta1);
+                    q = q11 / fastpow(qold, o.beta2);
+                    q = q / o.gamma;
+                    const double lo = 1.0 / o.qmax, hi = 1.0 / o.qmin;
+                    if (q > hi) q = hi;
+                    if (q < lo) q = lo;
+                }
+                accept = EEst <= 1.0;
+                if (p.trace && lm == 0 && gid == p.trace_traj && iter <= p.trace_cap) {
+                    double* row = p.trace + (size_t)(iter - 1) * 5;
+                    row[0] = t; row[1] = dt; row[2] = EEst; row[3] = q; row[4] = accept ? 1.0 : 0.0;
+                }
+                if (accept) {
+                    nacc += 1;
+                    qold = EEst > o.qoldinit ? EEst : o.qoldinit;
+                    dtnew = dt / q;
+                    tprev = t;
+                    const double ttmp = t + dt;
+                    {
+                        const double mxt = t > TF ? t : TF;
+                        t = fabs(ttmp - TF) < 100.0 * ulp_of(mxt) ? TF : ttmp;
+                    }
+                    if (fabs(dtnew) > dtmax) dtnew = tdir * dtmax;
+                    // the lazy dense-output stages are needed by a save point strictly inside the step and by the dense record
+                    bool need = false;
+                    if constexpr (NX > 0) {
+                        need = p.dense != nullptr && nsteps < p.cap;
+                        for (int i = si; i < p.ns && SV(i) <= t; ++i) need = need || (SV(i) != t);
+                    }
+                    if (need) ph = S;
+                    else finalize = true;
+                } else {
+                    nrej += 1;
+                    if (EEst != EEst) { ret = RET_UNSTABLE; finish(); }
+                    else { ph = FIRST; fresh = true; }
+                }
+            } else {
+                // a lazy stage is in place
+                if (ph < S + NX - 1) ph += 1;
+                else { nlazy += NX; finalize = true; }
+            }
+        }
+        if (finalize) {
+            // FwdSys::accepted: save points inside (tprev, t], the dense record
+            bool fin = false;
+            while (si < p.ns && SV(si) <= t) {
+                const double curt = SV(si);
+                if (curt != t) {
+                    const double thv = (curt - tprev) / dt;
+                    double b[NK], y[NC];
+                    Tab::bth(thv, b);
+                    const double acc = chain2<RowDense<Tab>, NK>([&](auto q) { return K[q]; }, [&](auto q) { return b[q]; });
+                    bcast(__builtin_fma(dt, acc, zo), y);
+                    save_point(si, y);
+                } else {
+                    save_point(si, znew);
+                }
+                si += 1;
+            }
+            if (p.dense) {
+                if (nsteps >= p.cap) { ret = RET_DENSE_OVERFLOW; fin = true; }
+                else {
+                    const int nf = 3 + n + NK * n;
+                    double* base = p.dense + ((size_t)nsteps * nf) * p.Npad + gid;
+                    if (lm == 0) {
+                        base[0] = tprev;
+                        base[(size_t)1 * p.Npad] = t;
+                        base[(size_t)2 * p.Npad] = dt;
+                    }
+                    if (lm < n) {
+                        base[(size_t)(3 + lm) * p.Npad] = zo;
+                        static_for<0, NK>([&](auto q) { base[(size_t)(3 + n + (int)decltype(q)::value * n + lm) * p.Npad] = K[q]; });
+                    }
+                    nsteps += 1;
+                }
+            }
+            // (Driver::run goes on after a dense overflow: the state moves, a NaN in it overrides the return code)
+            dt = dtnew;
+            bool bad = false;
+            static_for<0, NC>([&](auto c) {
+                u[c] = znew[c];
+                bad = bad || (znew[c] != znew[c]);
+            });
+            if constexpr (Tab::FSAL) K[0] = K[S - 1];
+            if (bad) { ret = RET_UNSTABLE; fin = true; }
+            else if (t == TF) fin = true;   // the one tstop of a forward solve
+            if (fin) finish();
+            else { ph = FIRST; fresh = true; }
+        }
+    }
+}
+
+}  // namespace nodels
+}  // namespace ude

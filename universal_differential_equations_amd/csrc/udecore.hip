@@ -215,6 +215,7 @@ void ude_poison_chip_dbg(hipStream_t st, bool before_forward) {  // (what & 4: a
 // lock-step matrix-core adjoint of the SEIR exposure UDE (csrc/ude_seir_ls.hip)
 extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes);
+extern "C" void ude_node_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes);
 extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 
 struct InstanceRow {
@@ -322,6 +323,9 @@ static int64_t ls_blocks(ude_ctx* c, int64_t N, int per_cu = 1) {
 #endif
 #ifndef UDE_SEIR_LS_FWD_PER_CU
 #define UDE_SEIR_LS_FWD_PER_CU 1   // resident blocks of the forward lock-step kernel per compute unit (two, at 256 registers: 3.8 instead of 2.7 ms -- spills)
+#endif
+#ifndef UDE_NODE_LS_FWD
+#define UDE_NODE_LS_FWD 1       // the neural ODE's forward solve on the lock-step architecture (ude_node_ls_fwd.h)
 #endif
 #ifndef UDE_SEIR_LS_FWD
 #define UDE_SEIR_LS_FWD 1       // 1: ... and the forward pass of a gradient call runs on the same architecture (ude_seir_ls_fwd.h)
@@ -650,16 +654,17 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     void (*kfwd)(const KParams) = o->per_trajectory ? l.fwd_pt : l.fwd;
     if (shmem > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    // SEIR exposure UDE, Float64, shared time grid, lanes_per_traj 0 (default) or 16: the lock-step matrix-core forward kernel
-    const bool seir_ls = UDE_SEIR_LS_FWD && model_id(m) == MID_SEIR_UDE && o->per_trajectory == 0 &&
-                         (c->lo.lanes_per_traj == 16 || (c->lo.lanes_per_traj == 0 && UDE_SEIR_LS_DEFAULT));
+    // SEIR exposure UDE / its neural ODE, Float64, shared time grid, lanes_per_traj 0 (default) or 16: the lock-step matrix-core forward kernel
+    const bool is_node = model_id(m) == MID_SEIR_NODE;
+    const bool seir_ls = ((UDE_SEIR_LS_FWD && model_id(m) == MID_SEIR_UDE) || (UDE_NODE_LS_FWD && is_node)) && o->per_trajectory == 0 &&
+                         (c->lo.lanes_per_traj == 16 || (c->lo.lanes_per_traj == 0 && (is_node ? UDE_NODE_LS_DEFAULT : UDE_SEIR_LS_DEFAULT)));
     if (seir_ls && (rc = ensure(c, c->ls_fac, 64))) return rc;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     ude_poison_chip(c->stream, true);
     if (seir_ls) {
         void (*lf)(const KParams, int*) = nullptr;
         size_t lf_lds = 0;
-        ude_seir_ls_get_fwd(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds);
+        (is_node ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds);
         int* queue = (int*)c->ls_fac.p;
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_lds));
@@ -793,10 +798,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)nwaves * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     ude_poison_chip(c->stream, true);
-    if (seir_ls && UDE_SEIR_LS_FWD) {
+    if ((seir_ls && UDE_SEIR_LS_FWD) || (node_ls && UDE_NODE_LS_FWD)) {
         void (*lf)(const KParams, int*) = nullptr;
         size_t lf_lds = 0;
-        ude_seir_ls_get_fwd(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds);
+        (node_ls ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds);
         const int64_t nblk = ls_blocks(c, N);
         int* queue = (int*)((double*)c->ls_fac.p + (size_t)nblk * ls_fac) + 1;   // (the backward kernel's counter is the int in front of it)
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
