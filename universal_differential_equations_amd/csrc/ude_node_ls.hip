@@ -1,6 +1,10 @@
 // ude_node_ls.hip -- translation unit of the lock-step matrix-core adjoint of the SEIR neural ODE (ude_node_ls.h).
 #include <hip/hip_runtime.h>
 #include "ude_node_ls.h"
+// two blocks of the forward kernel per compute unit (60 KB of LDS each, 256 registers per lane)
+#ifndef UDE_LS_FWD_PER_CU
+#define UDE_LS_FWD_PER_CU 2
+#endif
 #include "ude_node_ls_fwd.h"
 using namespace ude;
 extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block) {
@@ -9,7 +13,8 @@ extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, i
 }
 
 // the forward solve on the same architecture (ude_node_ls_fwd.h)
-extern "C" void ude_node_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes) {
+extern "C" void ude_node_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu) {
+    *blocks_per_cu = UDE_LS_FWD_PER_CU;
     *kern = alg == 1 ? nodels::node_ls_fwd_kernel<Vern7Tab> : nodels::node_ls_fwd_kernel<Tsit5Tab>;
-    *lds_bytes = sizeof(double) * nodels::fwd_lds_doubles() + 16;
+    *lds_bytes = sizeof(double) * (alg == 1 ? nodels::fwd_lds_doubles<Vern7Tab>() : nodels::fwd_lds_doubles<Tsit5Tab>()) + 16;
 }

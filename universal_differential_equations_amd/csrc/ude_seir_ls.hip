@@ -2,6 +2,10 @@
 #include <hip/hip_runtime.h>
 
 #include "ude_seir_ls.h"
+// two blocks of the forward kernel per compute unit (256 registers per lane: 132 B of scratch in cold paths): 2.7 -> 1.8 ms
+#ifndef UDE_LS_FWD_PER_CU
+#define UDE_LS_FWD_PER_CU 2
+#endif
 #include "ude_seir_ls_fwd.h"
 
 using namespace ude;
@@ -20,7 +24,8 @@ extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, i
 }
 
 // the forward solve on the same architecture (ude_seir_ls_fwd.h)
-extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes) {
+extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu) {
+    *blocks_per_cu = UDE_LS_FWD_PER_CU;
     *kern = alg == 1 ? seirls::seir_ls_fwd_kernel<Vern7Tab> : seirls::seir_ls_fwd_kernel<Tsit5Tab>;
-    *lds_bytes = sizeof(double) * seirls::fwd_lds_doubles() + 16;
+    *lds_bytes = sizeof(double) * (alg == 1 ? seirls::fwd_lds_doubles<Vern7Tab>() : seirls::fwd_lds_doubles<Tsit5Tab>()) + 16;
 }

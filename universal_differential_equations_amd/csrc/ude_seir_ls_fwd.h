@@ -11,6 +11,9 @@
 // slot's row, component c on lane c.  Per trajectory every number (saved states, step counts, dense store, loss and cotangent
 // rows) is bit-identical to fwd_kernel<SeirUde<64>> and to the oracle.  Float64, shared time grid.
 #pragma once
+#ifndef UDE_LS_FWD_PER_CU
+#define UDE_LS_FWD_PER_CU 1   // resident blocks of the forward lock-step kernel per compute unit (launch bounds AND grid size)
+#endif
 #include "ude_seir_ls.h"
 
 namespace ude {
@@ -18,10 +21,11 @@ namespace seirls {
 
 enum { FPH_IDLE = -4, FPH_FSAL0 = -3, FPH_INIT0 = -2, FPH_INIT1 = -1 };   // >= 0: stage s; s >= S: lazy dense-output stage s - S
 
-constexpr int fwd_lds_doubles() { return H * TLD + 4 * 16 + NSLOTS * PLD + TABL + 16; }
+template <class Tab>
+constexpr int fwd_lds_doubles() { return H * TLD + 4 * 16 + NSLOTS * PLD + TABL + NSLOTS * Tab::NK * 16 + 16; }
 
 template <class Tab>
-__global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p, int* __restrict__ queue) {
+__global__ void __launch_bounds__(BLOCKT, UDE_LS_FWD_PER_CU) seir_ls_fwd_kernel(const KParams p, int* __restrict__ queue) {
     constexpr int S = Tab::S, NK = Tab::NK, NX = Tab::NEXTRA;
     constexpr int FIRST = Tab::FSAL ? 1 : 0;   // first stage an attempt evaluates (FSAL: stage 0 is handed over)
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -29,6 +33,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
     double* XIN = T_A1 + H * TLD;            // [4][16]: x0 x1 x2 1
     double* PG = XIN + 4 * 16;               // [16][65]: w3[i] a2[i] of slot (column) and hidden row i
     double* TB = PG + NSLOTS * PLD;          // tableau: A[16][16], B, BT, C
+    double* KSL = TB + TABL;                 // [16 slots][NK][16]: stage derivatives, component c of the slot on lane c of its row
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int kq = l >> 4, jc = l & 15;      // matrix view
@@ -66,10 +71,10 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
     long long gid = 0;
     bool accept = true, exhausted = false, fresh = false;
     double t = T0, dt = 0.0, dt0 = 0.0, d1n = 0.0, qold = o.qoldinit, q11 = 1.0, tprev = T0, dtnew = 0.0, loss = 0.0;
-    long long nfc = 0, nacc = 0, nrej = 0, nlazy = 0;
-    double u[NC], znew[NC], K[NK];
-    static_for<0, NC>([&](auto c) { u[c] = 0.0; znew[c] = 0.0; });
-    static_for<0, NK>([&](auto q) { K[q] = 0.0; });
+    int nfc = 0, nacc = 0, nrej = 0, nlazy = 0;
+    double zo = 0.0, zn = 0.0;   // this lane's component of the state and of the candidate state (zn: f0 during the initial-dt heuristic)
+    double* const K = KSL + (size_t)(4 * w + (l >> 4)) * NK * 16 + (l & 15);   // K[16 q]: stage q (LDS: sixteen doubles per lane less in registers)
+    static_for<0, NK>([&](auto q) { K[16 * decltype(q)::value] = 0.0; });
 
     auto own = [&](const double (&v)[NC]) {
         double r = 0.0;
@@ -117,11 +122,17 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
             if (g >= p.N) exhausted = true;
             else {
                 gid = g;
-                static_for<0, NC>([&](auto c) { u[c] = p.u0[(size_t)gid * n + decltype(c)::value]; znew[c] = 0.0; });
-                static_for<0, NK>([&](auto q) { K[q] = 0.0; });
+                zo = lm < NC ? p.u0[(size_t)gid * n + lm] : 0.0;
+                zn = 0.0;
+                static_for<0, NK>([&](auto q) { K[16 * decltype(q)::value] = 0.0; });
                 t = T0; qold = o.qoldinit; q11 = 1.0; accept = true; iter = 0; ret = RET_SUCCESS;
                 nfc = 0; nacc = 0; nrej = 0; nlazy = 0; si = 0; nsteps = 0; loss = 0.0;
-                while (si < p.ns && SV(si) <= T0) { save_point(si, u); si += 1; }   // save_start
+                while (si < p.ns && SV(si) <= T0) {   // save_start
+                    double y[NC];
+                    bcast(zo, y);
+                    save_point(si, y);
+                    si += 1;
+                }
                 if (user_dt) {
                     dt = tdir * o.dt0;
                     if constexpr (Tab::FSAL) ph = FPH_FSAL0;
@@ -133,14 +144,14 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
         // ---- B. the state this slot's right-hand side is evaluated at ----
         bool ev = false;
         double zs[NC], kr[NC];
-        static_for<0, NC>([&](auto c) { zs[c] = u[c]; kr[c] = 0.0; });
-        const double zo = own(u);
+        static_for<0, NC>([&](auto c) { kr[c] = 0.0; });
+        double zsrc = zo;   // this lane's component of the state the right-hand side is evaluated at
         if (ph == FPH_INIT0 || ph == FPH_FSAL0) {
             ev = true;
         } else if (ph == FPH_INIT1) {
             ev = true;
             const double dt0t = tdir * dt0;
-            static_for<0, NC>([&](auto c) { zs[c] = __builtin_fma(dt0t, znew[c], u[c]); });   // (znew holds f0 during the heuristic)
+            zsrc = __builtin_fma(dt0t, zn, zo);   // (zn holds f0 during the heuristic)
         } else if (ph >= 0) {
             bool go = true;
             if (fresh) {   // loopheader!
@@ -168,13 +179,14 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
                     // finite, fma(0, k, acc) == acc exactly
                     const double* Ar = TB + ph * 16;
                     double acc = Ar[0] * K[0];
-                    static_for<1, NK>([&](auto j) { acc = __builtin_fma(Ar[decltype(j)::value], K[j], acc); });
-                    bcast(__builtin_fma(dt, acc, zo), zs);
+                    static_for<1, NK>([&](auto j) { acc = __builtin_fma(Ar[decltype(j)::value], K[16 * decltype(j)::value], acc); });
+                    zsrc = __builtin_fma(dt, acc, zo);
                 }
             } else {
                 finish();
             }
         }
+        bcast(zsrc, zs);
         if (ev && lm == 0) {
             XIN[0 * 16 + slot] = zs[0] / zs[4];
             XIN[1 * 16 + slot] = zs[2];
@@ -229,11 +241,11 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
             ph = FIRST; fresh = true;
         } else if (ph == FPH_INIT0 && ev) {
             K[0] = own(kr);
-            static_for<0, NC>([&](auto c) { znew[c] = kr[c]; });   // f0
+            zn = own(kr);   // f0
             double h0 = 0.0, l0 = 0.0, h1 = 0.0, l1 = 0.0;
             static_for<0, NC>([&](auto c) {
-                const double sk = __builtin_fma(fabs(u[c]), o.reltol, o.abstol);
-                const double q0 = u[c] / sk, q1 = kr[c] / sk;
+                const double sk = __builtin_fma(fabs(zs[c]), o.reltol, o.abstol);   // (zs is the state itself in this phase)
+                const double q0 = zs[c] / sk, q1 = kr[c] / sk;
                 dd_acc(h0, l0, q0 * q0);
                 dd_acc(h1, l1, q1 * q1);
             });
@@ -254,9 +266,12 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
             }
         } else if (ph == FPH_INIT1 && ev) {
             double h2 = 0.0, l2 = 0.0;
+            double f0[NC], uu[NC];
+            bcast(zn, f0);
+            bcast(zo, uu);
             static_for<0, NC>([&](auto c) {
-                const double sk = __builtin_fma(fabs(u[c]), o.reltol, o.abstol);
-                const double q = (kr[c] - znew[c]) / sk;
+                const double sk = __builtin_fma(fabs(uu[c]), o.reltol, o.abstol);
+                const double q = (kr[c] - f0[c]) / sk;
                 dd_acc(h2, l2, q * q);
             });
             const double s2 = h2 + l2;
@@ -280,21 +295,21 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
             else { ph = FIRST; fresh = true; }
         } else if (ph >= 0 && ev) {
             const double ko = own(kr);
-            static_for<0, NK>([&](auto j) { K[j] = ((int)decltype(j)::value == ph) ? ko : K[j]; });
+            K[16 * ph] = ko;
             if (ph < S - 1) {
                 ph += 1;
             } else if (ph == S - 1) {
                 // perform_step! is complete: new state, error estimate, controller
                 nfc += Tab::FSAL ? S - 1 : S;
-                if constexpr (Tab::FSAL) static_for<0, NC>([&](auto c) { znew[c] = zs[c]; });
+                if constexpr (Tab::FSAL) zn = own(zs);
                 else {
                     double acc = TB[256] * K[0];
-                    static_for<1, S>([&](auto j) { acc = __builtin_fma(TB[256 + decltype(j)::value], K[j], acc); });
-                    bcast(__builtin_fma(dt, acc, zo), znew);
+                    static_for<1, S>([&](auto j) { acc = __builtin_fma(TB[256 + decltype(j)::value], K[16 * decltype(j)::value], acc); });
+                    zn = __builtin_fma(dt, acc, zo);
                 }
                 double acc = TB[272] * K[0];
-                static_for<1, S>([&](auto j) { acc = __builtin_fma(TB[272 + decltype(j)::value], K[j], acc); });
-                const double a0 = fabs(zo), a1 = fabs(own(znew));
+                static_for<1, S>([&](auto j) { acc = __builtin_fma(TB[272 + decltype(j)::value], K[16 * decltype(j)::value], acc); });
+                const double a0 = fabs(zo), a1 = fabs(zn);
                 double res[NC];
                 bcast((dt * acc) / __builtin_fma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
                 double ss = 0.0;
@@ -353,13 +368,23 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
                 const double curt = SV(si);
                 if (curt != t) {
                     const double thv = (curt - tprev) / dt;
+                    // b_q(theta) by lane q of the row from the tableau's Horner table (bit-identical to Tab::bth; as compile-time
+                    // constants the 16 x 7 coefficients of Vern7 would sit in registers for the whole solve)
                     double b[NK], y[NC];
-                    Tab::bth(thv, b);
-                    const double acc = chain2<RowDense<Tab>, NK>([&](auto q) { return K[q]; }, [&](auto q) { return b[q]; });
+                    {
+                        const double* R = tab->R[lm < NK ? lm : 0];
+                        double h = R[0];
+                        static_for<1, 7>([&](auto i) { h = __builtin_fma(thv, h, R[decltype(i)::value]); });
+                        const double bq = (lm == 0 ? thv : thv * thv) * h;
+                        static_for<0, NK>([&](auto q) { b[q] = Tab::dense_uses(decltype(q)::value) ? rshfl(bq, decltype(q)::value) : 0.0; });
+                    }
+                    const double acc = chain2<RowDense<Tab>, NK>([&](auto q) { return K[16 * decltype(q)::value]; }, [&](auto q) { return b[q]; });
                     bcast(__builtin_fma(dt, acc, zo), y);
                     save_point(si, y);
                 } else {
-                    save_point(si, znew);
+                    double y[NC];
+                    bcast(zn, y);
+                    save_point(si, y);
                 }
                 si += 1;
             }
@@ -375,7 +400,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
                     }
                     if (lm < n) {
                         base[(size_t)(3 + lm) * p.Npad] = zo;
-                        static_for<0, NK>([&](auto q) { base[(size_t)(3 + n + (int)decltype(q)::value * n + lm) * p.Npad] = K[q]; });
+                        static_for<0, NK>([&](auto q) { base[(size_t)(3 + n + (int)decltype(q)::value * n + lm) * p.Npad] = K[16 * decltype(q)::value]; });
                     }
                     nsteps += 1;
                 }
@@ -383,11 +408,9 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_fwd_kernel(const KParams p,
             // (Driver::run goes on after a dense overflow: the state moves, a NaN in it overrides the return code)
             dt = dtnew;
             bool bad = false;
-            static_for<0, NC>([&](auto c) {
-                u[c] = znew[c];
-                bad = bad || (znew[c] != znew[c]);
-            });
-            if constexpr (Tab::FSAL) K[0] = K[S - 1];
+            zo = zn;
+            bad = ((__ballot(zn != zn) >> (16 * rr)) & 0x7Full) != 0;   // (a NaN in any of the row's seven components)
+            if constexpr (Tab::FSAL) K[0] = K[16 * (S - 1)];
             if (bad) { ret = RET_UNSTABLE; fin = true; }
             else if (t == TF) fin = true;   // the one tstop of a forward solve
             if (fin) finish();

@@ -214,8 +214,8 @@ void ude_poison_chip_dbg(hipStream_t st, bool before_forward) {  // (what & 4: a
 #include "ude_instances_gen.h"
 // lock-step matrix-core adjoint of the SEIR exposure UDE (csrc/ude_seir_ls.hip)
 extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
-extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes);
-extern "C" void ude_node_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes);
+extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu);
+extern "C" void ude_node_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu);
 extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 
 struct InstanceRow {
@@ -320,9 +320,6 @@ static int64_t ls_blocks(ude_ctx* c, int64_t N, int per_cu = 1) {
 #endif
 #ifndef UDE_NODE_LS_DEFAULT
 #define UDE_NODE_LS_DEFAULT 1   // ... and so does the SEIR neural ODE (csrc/ude_node_ls.h); lanes_per_traj = 64 selects the wavefront-per-trajectory kernel
-#endif
-#ifndef UDE_SEIR_LS_FWD_PER_CU
-#define UDE_SEIR_LS_FWD_PER_CU 1   // resident blocks of the forward lock-step kernel per compute unit (two, at 256 registers: 3.8 instead of 2.7 ms -- spills)
 #endif
 #ifndef UDE_NODE_LS_FWD
 #define UDE_NODE_LS_FWD 1       // the neural ODE's forward solve on the lock-step architecture (ude_node_ls_fwd.h)
@@ -664,11 +661,12 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     if (seir_ls) {
         void (*lf)(const KParams, int*) = nullptr;
         size_t lf_lds = 0;
-        (is_node ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds);
+        int lf_per_cu = 1;
+        (is_node ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds, &lf_per_cu);
         int* queue = (int*)c->ls_fac.p;
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_lds));
-        hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, UDE_SEIR_LS_FWD_PER_CU)), dim3(256), lf_lds, c->stream, p, queue);
+        hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, lf_per_cu)), dim3(256), lf_lds, c->stream, p, queue);
     } else
     hipLaunchKernelGGL(kfwd, dim3(grid), dim3(BLOCK), shmem, c->stream, p);
     HIPCHK(c, hipGetLastError());
@@ -801,12 +799,13 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((seir_ls && UDE_SEIR_LS_FWD) || (node_ls && UDE_NODE_LS_FWD)) {
         void (*lf)(const KParams, int*) = nullptr;
         size_t lf_lds = 0;
-        (node_ls ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds);
+        int lf_per_cu = 1;
+        (node_ls ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds, &lf_per_cu);
         const int64_t nblk = ls_blocks(c, N);
         int* queue = (int*)((double*)c->ls_fac.p + (size_t)nblk * ls_fac) + 1;   // (the backward kernel's counter is the int in front of it)
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_lds));
-        hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, UDE_SEIR_LS_FWD_PER_CU)), dim3(256), lf_lds, c->stream, p, queue);
+        hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, lf_per_cu)), dim3(256), lf_lds, c->stream, p, queue);
     } else
     {   // (the forward kernel may run with fewer threads per block than the adjoint: Launch::block_fwd)
         const int64_t gpb_f = l.block_fwd / l.G_fwd;
