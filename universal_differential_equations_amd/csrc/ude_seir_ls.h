@@ -49,11 +49,15 @@ constexpr int cslot(int s) { return popc(MASK & ((1u << s) - 1u)); }   // compac
 
 constexpr int NFAC = 3;     // per-stage factor rows kept in HBM: a2, delta1, delta2 (a1 of every slot and stage stays in LDS)
 constexpr int TABL = 16 * 16 + 3 * 16;   // LDS copy of the tableau: A[16][16], B[16], BT[16], C[16]
+// interval cache of a slot: the forward record of the interval as it is stored (t, t_end, dt, u[7], k_q[7] for q < NK), rounded up to
+// whole 16-lane rows (the slot's sixteen lanes fetch it round-robin)
+template <class Tab>
+constexpr int kst() { return (3 + NC + Tab::NK * NC + 15) / 16 * 16; }
 template <class Tab>
 constexpr int lds_doubles() {
     constexpr int NSTC = popc(stage_mask<Tab>());
     return 4 * H * TLD + 4 * 16 + 16 + 3 * NSLOTS * PLD + NSTC * NSLOTS * 4 + NSLOTS * 16 + NSLOTS * 8 + TABL + 6 * NSLOTS + NSLOTS * 4 * 2 +
-           NSLOTS * NSTC * H + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16 + 3 * H;
+           NSLOTS * NSTC * H + NSLOTS * kst<Tab>() + NSLOTS * 8 + 16 * 8 + NSLOTS * 16 + 3 * H;
 }
 // doubles of factor workspace per block
 template <class Tab>
@@ -198,8 +202,9 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     int* REV = RCS + NSLOTS;
     double* SUMW = RDT + 6 * NSLOTS;          // [16][4][2] per slot and wavefront: ps | (h, l)
     double* A1P = SUMW + NSLOTS * 4 * 2;      // [16 slots][NSTC][64]: a1 of every stage of the slot's current step (read by broadcast in E)
-    double* KSL = A1P + NSLOTS * NSTC * H;         // [16 slots][NK + 2][8]: interval cache (u_start, k_q) and f0 of the initial-dt phase, component c at [..][c]
-    double* RQL = KSL + NSLOTS * 8 * (NK + 2); // [16 lanes q][8]: Horner tables of b_q(theta)
+    double* KSL = A1P + NSLOTS * NSTC * H;         // [16 slots][KST]: interval cache, the stored record of the slot's current forward interval
+    double* F0L = KSL + NSLOTS * kst<Tab>();       // [16 slots][8]: f0 of the initial-dt phase
+    double* RQL = F0L + NSLOTS * 8;                // [16 lanes q][8]: Horner tables of b_q(theta)
     double* ZK = RQL + 16 * 8;                // [16 slots][16]: znew[7] | kr[7] parked across the parameter-slot work of a trip
     double* W1L = ZK + NSLOTS * 16;           // [3][64]: W1[i][m] at W1L[m * H + i] (read where the input-cotangent products are formed)
 
@@ -252,30 +257,35 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
     static_for<0, S>([&](auto s) { K[s] = 0.0; });
     for (int i = tid; i < 16 * 8; i += BLOCKT) RQL[i] = ((i >> 3) < NK && (i & 7) < 7) ? tab->R[i >> 3][i & 7] : 0.0;
-    double* const ksl = KSL + slot * 8 * (NK + 2) + (lm < 8 ? lm : 7);   // this lane's component column of the slot's cache (lanes >= 7: the spare column)
-    double* const f0l = KSL + slot * 8 * (NK + 2) + (NK + 1) * 8;       // f0[c] at f0l[c]
+    constexpr int KST = kst<Tab>(), NPF = KST / 16;
+    double* const krec = KSL + slot * KST;                              // the slot's record: field f at krec[f]
+    const double* const ksl = krec + 3 + (lm < NC ? lm : NC - 1);       // this lane's component: u_start at ksl[0], k_q at ksl[NC + NC q]
+    double* const f0l = F0L + slot * 8;                                 // f0[c] at f0l[c]
+    // the backward solve walks the stored intervals downwards: while interval s is in use the record of s - 1 is already on its way
+    // from HBM into pf (field lm + 16 i on lane lm of the row), so the switch to s - 1 is an LDS write of data that has long arrived
+    // instead of a dependent HBM round trip in front of the block's barrier
+    double pf[NPF];
+    int pf_s = -1;
+    static_for<0, NPF>([&](auto i) { pf[i] = 0.0; });
     const double* cot = p.cot;
     size_t cot_si = 0, cot_sc = 0;
     double* const fmine = facws + (size_t)blockIdx.x * fac_doubles_per_block<Tab>();   // this block's factor workspace
 
-    auto load_interval = [&](int s) {
-        sf = s;
+    auto fetch_interval = [&](int s) {
+        pf_s = s;
         const double* base = p.dense + ((size_t)s * nfld) * p.Npad + gid;
-        ts = base[0];
-        te = base[(size_t)1 * p.Npad];
-        const bool on = lm < n;
-        const int rc = on ? lm : 0;
-        // (all loads first, then the LDS stores: one round trip)
-        double usv = base[(size_t)(3 + rc) * p.Npad], kv[NK];
-        static_for<0, NK>([&](auto q) {
-            if constexpr (Tab::dense_uses(decltype(q)::value)) kv[q] = base[(size_t)(3 + n + (int)decltype(q)::value * n + rc) * p.Npad];
+        static_for<0, NPF>([&](auto i) {
+            const int f = lm + 16 * (int)decltype(i)::value;
+            pf[i] = base[(size_t)(f < nfld ? f : 0) * p.Npad];
         });
-        if (on) {
-            ksl[0] = usv;
-            static_for<0, NK>([&](auto q) {
-                if constexpr (Tab::dense_uses(decltype(q)::value)) ksl[(1 + (int)decltype(q)::value) * 8] = kv[q];
-            });
-        }
+    };
+    auto load_interval = [&](int s) {
+        if (pf_s != s) fetch_interval(s);   // (row-uniform; the first interval of a trajectory, a step upwards)
+        sf = s;
+        static_for<0, NPF>([&](auto i) { krec[lm + 16 * (int)decltype(i)::value] = pf[i]; });
+        ts = krec[0];
+        te = krec[1];
+        if (s > 0) fetch_interval(s - 1);
     };
     auto own = [&](const double (&v)[NC]) {
         double r = 0.0;
@@ -321,6 +331,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
                 if (p.cot_in) { cot = p.cot_in + (size_t)gid * p.ns * n; cot_si = n; cot_sc = 1; }
                 else { cot = p.cot + gid; cot_si = (size_t)n * p.Npad; cot_sc = p.Npad; }
                 nsteps = p.dense_n[gid];
+                pf_s = -1;
                 cur = p.ns - 1;
                 static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
                 t = TF; qold = o.qoldinit; q11 = 1.0; accept = true; iter = 0; ret = RET_SUCCESS; col = 0;
@@ -399,10 +410,16 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
         double y[NC];
         static_for<0, NC>([&](auto c) { y[c] = 1.0; });
         if (ev) {
+#if !(LS_CUT & 16)   // (16: timing experiment -- never leave the first interval)
             while (tev < ts && sf > 0) load_interval(sf - 1);
             while (tev >= te && sf < nsteps - 1) load_interval(sf + 1);
+#endif
             const double dtf = te - ts;
+#if LS_CUT & 16
+            const double thv = fmin(fmax((tev - ts) / dtf, 0.0), 1.0);
+#else
             const double thv = (tev - ts) / dtf;
+#endif
             const double* rq = RQL + lm * 8;
             double hq = rq[0];
             static_for<1, 7>([&](auto i) { hq = __builtin_fma(thv, hq, rq[decltype(i)::value]); });
@@ -412,7 +429,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
             static_for<0, NK>([&](auto q) {
                 if constexpr (Tab::dense_uses(decltype(q)::value)) {
                     const double bqv = BQ[slot * 16 + decltype(q)::value];
-                    const double kq_ = ksl[(1 + (int)decltype(q)::value) * 8];
+                    const double kq_ = ksl[NC + NC * (int)decltype(q)::value];
                     acc = first ? kq_ * bqv : __builtin_fma(kq_, bqv, acc);
                     first = false;
                 }
