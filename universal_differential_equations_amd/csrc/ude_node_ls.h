@@ -41,7 +41,7 @@ template <class Tab>
 constexpr int lds_doubles() {
     constexpr int NSTC = popc(stage_mask<Tab>());
     return 2 * H * LDW + 4 * H * TLD + 8 * 16 + 8 * 16 + NIN * NSLOTS * 4 + NSTC * NSLOTS * XFW + NSLOTS * 16 + NSLOTS * 8 + TABL + 6 * NSLOTS +
-           NSLOTS * 4 * 2 + NSLOTS * 8 * (Tab::NK + 2) + 16 * 8 + NSLOTS * 16 + 4 * 2 * NSTC * QW + NIN * H;
+           NSLOTS * 4 * 2 + NSLOTS * seirls::kst<Tab>() + NSLOTS * 8 + 16 * 8 + NSLOTS * 16 + 4 * 2 * NSTC * QW + NIN * H;
 }
 template <class Tab>
 constexpr size_t fac_doubles_per_block() { return (size_t)NSLOTS * popc(stage_mask<Tab>()) * NFAC * H; }
@@ -203,8 +203,9 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
     int* RCS = ROK + NSLOTS;
     int* REV = RCS + NSLOTS;
     double* SUMW = RDT + 6 * NSLOTS;           // [16][4][2]
-    double* KSL = SUMW + NSLOTS * 4 * 2;       // [16 slots][NK + 2][8]
-    double* RQL = KSL + NSLOTS * 8 * (NK + 2); // [16][8]
+    double* KSL = SUMW + NSLOTS * 4 * 2;       // [16 slots][KST]: interval cache, the stored record of the slot's current forward interval
+    double* F0L = KSL + NSLOTS * seirls::kst<Tab>();   // [16 slots][8]: f0 of the initial-dt phase
+    double* RQL = F0L + NSLOTS * 8;            // [16][8]
     double* ZK = RQL + 16 * 8;                 // [16][16]
     double* ASTG = ZK + NSLOTS * 16;           // [4 wavefronts][2][NSTC][16]
     double* W1L = ASTG + 4 * 2 * NSTC * QW;    // [7][64]: W1[i][m] at W1L[m * H + i] (read where the input-cotangent products are formed)
@@ -255,30 +256,33 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
     static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
     static_for<0, S>([&](auto s) { K[s] = 0.0; });
     for (int i = tid; i < 16 * 8; i += BLOCKT) RQL[i] = ((i >> 3) < NK && (i & 7) < 7) ? tab->R[i >> 3][i & 7] : 0.0;
-    double* const ksl = KSL + slot * 8 * (NK + 2) + (lm < 8 ? lm : 7);   // this lane's component column of the slot's cache (lanes >= 7: the spare column)
-    double* const f0l = KSL + slot * 8 * (NK + 2) + (NK + 1) * 8;       // f0[c] at f0l[c]
+    constexpr int KST = seirls::kst<Tab>(), NPF = KST / 16;
+    double* const krec = KSL + slot * KST;                              // the slot's record: field f at krec[f]
+    const double* const ksl = krec + 3 + (lm < NC ? lm : NC - 1);       // this lane's component: u_start at ksl[0], k_q at ksl[NC + NC q]
+    double* const f0l = F0L + slot * 8;                                 // f0[c] at f0l[c]
+    // (ude_seir_ls.h) the record of the next-lower interval is prefetched into pf: field lm + 16 i on lane lm of the row
+    double pf[NPF];
+    int pf_s = -1;
+    static_for<0, NPF>([&](auto i) { pf[i] = 0.0; });
     const double* cot = p.cot;
     size_t cot_si = 0, cot_sc = 0;
     double* const fmine = facws + (size_t)blockIdx.x * fac_doubles_per_block<Tab>();   // this block's factor workspace
 
-    auto load_interval = [&](int s) {
-        sf = s;
+    auto fetch_interval = [&](int s) {
+        pf_s = s;
         const double* base = p.dense + ((size_t)s * nfld) * p.Npad + gid;
-        ts = base[0];
-        te = base[(size_t)1 * p.Npad];
-        const bool on = lm < n;
-        const int rc = on ? lm : 0;
-        // (all loads first, then the LDS stores: one round trip)
-        double usv = base[(size_t)(3 + rc) * p.Npad], kv[NK];
-        static_for<0, NK>([&](auto q) {
-            if constexpr (Tab::dense_uses(decltype(q)::value)) kv[q] = base[(size_t)(3 + n + (int)decltype(q)::value * n + rc) * p.Npad];
+        static_for<0, NPF>([&](auto i) {
+            const int f = lm + 16 * (int)decltype(i)::value;
+            pf[i] = base[(size_t)(f < nfld ? f : 0) * p.Npad];
         });
-        if (on) {
-            ksl[0] = usv;
-            static_for<0, NK>([&](auto q) {
-                if constexpr (Tab::dense_uses(decltype(q)::value)) ksl[(1 + (int)decltype(q)::value) * 8] = kv[q];
-            });
-        }
+    };
+    auto load_interval = [&](int s) {
+        if (pf_s != s) fetch_interval(s);   // (row-uniform; the first interval of a trajectory, a step upwards)
+        sf = s;
+        static_for<0, NPF>([&](auto i) { krec[lm + 16 * (int)decltype(i)::value] = pf[i]; });
+        ts = krec[0];
+        te = krec[1];
+        if (s > 0) fetch_interval(s - 1);
     };
     auto own = [&](const double (&v)[NC]) {
         double r = 0.0;
@@ -324,6 +328,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
                 if (p.cot_in) { cot = p.cot_in + (size_t)gid * p.ns * n; cot_si = n; cot_sc = 1; }
                 else { cot = p.cot + gid; cot_si = (size_t)n * p.Npad; cot_sc = p.Npad; }
                 nsteps = p.dense_n[gid];
+                pf_s = -1;
                 cur = p.ns - 1;
                 static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
                 t = TF; qold = o.qoldinit; q11 = 1.0; accept = true; iter = 0; ret = RET_SUCCESS; col = 0;
@@ -415,7 +420,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
             static_for<0, NK>([&](auto q) {
                 if constexpr (Tab::dense_uses(decltype(q)::value)) {
                     const double bqv = BQ[slot * 16 + decltype(q)::value];
-                    const double kq_ = ksl[(1 + (int)decltype(q)::value) * 8];
+                    const double kq_ = ksl[NC + NC * (int)decltype(q)::value];
                     acc = first ? kq_ * bqv : __builtin_fma(kq_, bqv, acc);
                     first = false;
                 }

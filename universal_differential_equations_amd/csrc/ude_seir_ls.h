@@ -79,6 +79,10 @@ __device__ __forceinline__ double row_tree4(double v0, double v1, double v2, dou
 //   MODE 0: end of a step -- candidate mu_new, returns this lane's sum of squared residuals
 //   MODE 1 / 2: the initial-dt norms (h, l) += (g0 / sk)^2  /  ((g1 - g0) / sk)^2 in real-real arithmetic (mu == 0 there)
 constexpr int QW = H / 4;   // W2 columns per wavefront
+#ifndef LS_PF_AT
+#define LS_PF_AT 2   // where the prefetch of the next-lower forward interval is issued: 0 at the switch itself, 1 / 2 inside the matrix phase
+#endif
+#define LS_PF_ISSUE if (pf_want >= 0) { fetch_interval(pf_want); pf_want = -1; }
 #ifndef LS_CUT
 #define LS_CUT 0   // timing experiments only (results wrong): 1 no mu loads, 2 no mu stores, 4 no division, 8 no factor loads
 #endif
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     // from HBM into pf (field lm + 16 i on lane lm of the row), so the switch to s - 1 is an LDS write of data that has long arrived
     // instead of a dependent HBM round trip in front of the block's barrier
     double pf[NPF];
-    int pf_s = -1;
+    int pf_s = -1, pf_want = -1;
     static_for<0, NPF>([&](auto i) { pf[i] = 0.0; });
     const double* cot = p.cot;
     size_t cot_si = 0, cot_sc = 0;
@@ -285,7 +289,11 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
         static_for<0, NPF>([&](auto i) { krec[lm + 16 * (int)decltype(i)::value] = pf[i]; });
         ts = krec[0];
         te = krec[1];
+#if LS_PF_AT == 0
         if (s > 0) fetch_interval(s - 1);
+#else
+        pf_want = s - 1;   // issued inside the matrix phase (LS_PF_ISSUE): nothing that follows there waits on a younger memory operation
+#endif
     };
     auto own = [&](const double (&v)[NC]) {
         double r = 0.0;
@@ -331,7 +339,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
                 if (p.cot_in) { cot = p.cot_in + (size_t)gid * p.ns * n; cot_si = n; cot_sc = 1; }
                 else { cot = p.cot + gid; cot_si = (size_t)n * p.Npad; cot_sc = p.Npad; }
                 nsteps = p.dense_n[gid];
-                pf_s = -1;
+                pf_s = -1; pf_want = -1;
                 cur = p.ns - 1;
                 static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
                 t = TF; qold = o.qoldinit; q11 = 1.0; accept = true; iter = 0; ret = RET_SUCCESS; col = 0;
@@ -447,6 +455,9 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
         }
         if (!__syncthreads_or(ph != PH_IDLE)) break;   // (the barrier in front of the matrix products; all slots idle and the queue empty: done)
         LS_TICK(2)
+#if LS_PF_AT == 1
+        LS_PF_ISSUE
+#endif
         {
             // layer 1 (3 inputs + bias in one k-step)
             v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(W1A, XIN[kq * 16 + jc], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
@@ -457,6 +468,9 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
                 T_A1[(16 * w + kq + 4 * r) * TLD + jc] = a1[r];
             });
             __syncthreads();
+#if LS_PF_AT == 2
+            LS_PF_ISSUE
+#endif
             // hidden layer: four 16-term chains (four MFMAs each) added left to right
             {
                 v4d acc[4];
