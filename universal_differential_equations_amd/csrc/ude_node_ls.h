@@ -37,6 +37,10 @@ constexpr int QW = H / 4;                 // columns of a weight block per wavef
 constexpr int XFW = 14;
 constexpr int LDW = 65;                  // leading dimension of the LDS copies of W2 / W3: row AND column fragments conflict-free                   // x0..x6 | delta4_0..6 per (stage, slot)
 
+#ifndef NL_PF_AT
+#define NL_PF_AT 3   // where the prefetch of the next-lower forward interval is issued: 0 at the switch itself, 1 / 2 / 3 inside the matrix phase (3: in front of the third layer)
+#endif
+#define NL_PF_ISSUE if (pf_want >= 0) { fetch_interval(pf_want); pf_want = -1; }
 template <class Tab>
 constexpr int lds_doubles() {
     constexpr int NSTC = popc(stage_mask<Tab>());
@@ -262,7 +266,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
     double* const f0l = F0L + slot * 8;                                 // f0[c] at f0l[c]
     // (ude_seir_ls.h) the record of the next-lower interval is prefetched into pf: field lm + 16 i on lane lm of the row
     double pf[NPF];
-    int pf_s = -1;
+    int pf_s = -1, pf_want = -1;
     static_for<0, NPF>([&](auto i) { pf[i] = 0.0; });
     const double* cot = p.cot;
     size_t cot_si = 0, cot_sc = 0;
@@ -282,7 +286,11 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
         static_for<0, NPF>([&](auto i) { krec[lm + 16 * (int)decltype(i)::value] = pf[i]; });
         ts = krec[0];
         te = krec[1];
+#if NL_PF_AT == 0
         if (s > 0) fetch_interval(s - 1);
+#else
+        pf_want = s - 1;   // issued inside the matrix phase (NL_PF_ISSUE), in front of its longest stretch without a memory wait
+#endif
     };
     auto own = [&](const double (&v)[NC]) {
         double r = 0.0;
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
                 if (p.cot_in) { cot = p.cot_in + (size_t)gid * p.ns * n; cot_si = n; cot_sc = 1; }
                 else { cot = p.cot + gid; cot_si = (size_t)n * p.Npad; cot_sc = p.Npad; }
                 nsteps = p.dense_n[gid];
-                pf_s = -1;
+                pf_s = -1; pf_want = -1;
                 cur = p.ns - 1;
                 static_for<0, NC>([&](auto c) { lam[c] = 0.0; });
                 t = TF; qold = o.qoldinit; q11 = 1.0; accept = true; iter = 0; ret = RET_SUCCESS; col = 0;
@@ -474,6 +482,9 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
                     out[r] = ((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r];
                 });
             };
+#if NL_PF_AT == 2
+            NL_PF_ISSUE
+#endif
             double hz[4];
             hidden(WL2, T_A1, false, hz);
             static_for<0, 4>([&](auto rc) {
@@ -482,10 +493,16 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_ls_adj_kernel(const KParams p,
                 T_A2[(16 * w + kq + 4 * r) * TLD + jc] = a2[r];
             });
             __syncthreads();
+#if NL_PF_AT == 3
+            NL_PF_ISSUE
+#endif
             hidden(WL3, T_A2, false, hz);
             // delta3 = (W4^T delta4) (1 - a3^2): the 7-term chain, its zero eighth term included
             v4d s3 = v4d{0.0, 0.0, 0.0, 0.0};
             static_for<0, 2>([&](auto sc) { s3 = __builtin_amdgcn_mfma_f64_16x16x4f64(W4T[sc], D4S[(4 * decltype(sc)::value + kq) * 16 + jc], s3, 0, 0, 0); });
+#if NL_PF_AT == 1
+            NL_PF_ISSUE
+#endif
             double dv3[4], dv2[4];
             static_for<0, 4>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
