@@ -90,7 +90,8 @@ template <int NST, unsigned MASK, int MODE>
 __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* this trajectory's factors: [cs][a2 | delta1 | delta2][64] */,
                                             const double* a1s /* LDS [cs][64]: a1 of this slot's stages */, const double* xf /* LDS [cs][16][4] */,
                                             int slot, int lane, int w, const double* Bw, const double* BTw, double dt, double abstol, double reltol,
-                                            const double* __restrict__ mu, double* __restrict__ mu_new, double& hh, double& ll) {
+                                            const double (&mq)[2 * 8 + 2] /* MODE 0: this lane's 18 mu words, loaded by the caller (mu_load) */, double* __restrict__ mu_new,
+                                            double& hh, double& ll) {
     constexpr int CH = 8;
     // every load of the pass is issued before the first use: delta2 (needed first), mu, then the rows only the extra slots use
     double a2[NST], d1[NST], d2[NST];
@@ -102,10 +103,10 @@ __device__ __forceinline__ double slot_pass(const double* __restrict__ fbase /* 
     });
     double mcur[CH], mnext[CH], mex[2];
     static_for<0, CH>([&](auto i) {
-        mcur[i] = (MODE == 0 && !(LS_CUT & 1)) ? mu[(size_t)(QW * w + decltype(i)::value) * H] : 0.0;
-        mnext[i] = (MODE == 0 && !(LS_CUT & 1)) ? mu[(size_t)(QW * w + CH + decltype(i)::value) * H] : 0.0;
+        mcur[i] = MODE == 0 ? mq[i] : 0.0;
+        mnext[i] = MODE == 0 ? mq[CH + decltype(i)::value] : 0.0;
     });
-    static_for<0, 2>([&](auto i) { mex[i] = (MODE == 0 && !(LS_CUT & 1) && 2 * w + decltype(i)::value < 7) ? mu[(size_t)(H + 2 * w + decltype(i)::value) * H] : 0.0; });
+    static_for<0, 2>([&](auto i) { mex[i] = MODE == 0 ? mq[2 * CH + decltype(i)::value] : 0.0; });
     static_for<0, NST>([&](auto s) {
         if constexpr ((MASK >> decltype(s)::value) & 1u) {
             constexpr int cs = cslot<MASK>(decltype(s)::value);
@@ -271,6 +272,13 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
     double pf[NPF];
     int pf_s = -1, pf_want = -1;
     static_for<0, NPF>([&](auto i) { pf[i] = 0.0; });
+    // this lane's 18 words of a trajectory's current mu column (W2 columns 16w .. 16w + 15 of hidden row `l`, extra slots 2w, 2w + 1)
+    double mq[2 * 8 + 2];
+    static_for<0, 18>([&](auto i) { mq[i] = 0.0; });
+    auto mu_load = [&](const double* mc) {
+        static_for<0, 16>([&](auto i) { mq[i] = (LS_CUT & 1) ? 0.0 : mc[(size_t)(QW * w + (int)decltype(i)::value) * H]; });
+        static_for<0, 2>([&](auto i) { mq[16 + decltype(i)::value] = (!(LS_CUT & 1) && 2 * w + (int)decltype(i)::value < 7) ? mc[(size_t)(H + 2 * w + (int)decltype(i)::value) * H] : 0.0; });
+    };
     const double* cot = p.cot;
     size_t cot_si = 0, cot_sc = 0;
     double* const fmine = facws + (size_t)blockIdx.x * fac_doubles_per_block<Tab>();   // this block's factor workspace
@@ -635,16 +643,17 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
                 double* sw = SUMW + (sl * 4 + w) * 2;
                 LS_E0
                 if (mode == RQ_STEP) {
-                    const double ps = slot_pass<S, MASK, 0>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, dt_req, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    mu_load(mcur);
+                    const double ps = slot_pass<S, MASK, 0>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, dt_req, o.abstol, o.reltol, mq, mnew, hh, ll);
                     const double tot = group_sum<64>(ps);
                     if (l == 0) sw[0] = tot;
                     LS_E1(0)
                 } else if (mode == RQ_NORM01) {
-                    slot_pass<1, 1u, 1>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    slot_pass<1, 1u, 1>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mq, mnew, hh, ll);
                     group_dd_sum<64>(hh, ll);
                     if (l == 0) { sw[0] = hh; sw[1] = ll; }
                 } else if (mode == RQ_NORM2) {
-                    slot_pass<2, 3u, 2>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mcur, mnew, hh, ll);
+                    slot_pass<2, 3u, 2>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, 0.0, o.abstol, o.reltol, mq, mnew, hh, ll);
                     group_dd_sum<64>(hh, ll);
                     if (l == 0) { sw[0] = hh; sw[1] = ll; }
                 } else if (mode == RQ_FLUSH) {   // the trajectory's gradient row (zeros if it failed)
