@@ -37,8 +37,22 @@ SENSE_NAME = {"adjoint": "InterpolatingAdjoint", "discrete": "discretise-then-op
               "fast": "InterpolatingAdjoint with lambda-only error control (SURVEY 8(b) fast mode; not the reference's step sequence)"}
 # which unit dominates each backward kernel: the LV / SEIR kernels run on the FP64 VALU, Fisher-KPP on the FP64 matrix cores
 # (both peaks are 78.6 TF; the schema's "bound" offers hbm | mfma)
-BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint; SEIR exposure UDE / neural ODE: seir_ls_adj_kernel / node_ls_adj_kernel, 16 trajectories per block in lock-step on the FP64 matrix cores)", "discrete": "dadj_kernel (frozen-step reverse sweep)",
+BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint)", "discrete": "dadj_kernel (frozen-step reverse sweep)",
               "fast": "adj_kernel, fast mode (lambda-only error control)"}
+
+
+def roofline_kernel_name(a):
+    """the dominant kernel of the command, as rocprofv3 names it, and the unit it runs on"""
+    ls = a.sensealg == "adjoint" and a.lanes in (0, 16)
+    if a.workload == "seir" and ls:
+        return ("seirls::seir_ls_adj_kernel (interpolating adjoint, 16 trajectories per block in lock-step), network on the FP64 matrix cores, "
+                "parameter-slot sums / controller on the FP64 vector unit")
+    if a.workload == "node" and ls:
+        return ("nodels::node_ls_adj_kernel (interpolating adjoint, 16 trajectories per block in lock-step), network on the FP64 matrix cores, "
+                "parameter-slot sums / controller on the FP64 vector unit")
+    if a.workload == "kpp":
+        return BWD_KERNEL[a.sensealg] + ", FP64 matrix cores"
+    return BWD_KERNEL[a.sensealg] + ", FP64 VALU (no MFMA: 5- and 64-wide layers stay on the vector unit)"
 
 
 def SENSE_OBJ(U, name):
@@ -527,9 +541,7 @@ def main():
                        "fwd_kernel_ms": float(np.mean(fwd_ms)),
                        "bwd_kernel_ms": float(np.mean(bwd_ms))},
             "roofline": {"bound": "mfma", "unit_busy": {"kpp": "mfma-f64", "seir": "mfma-f64 + valu-f64", "node": "mfma-f64 + valu-f64"}.get(a.workload, "valu-f64"),
-                         "kernel": BWD_KERNEL[a.sensealg] + {"kpp": ", FP64 matrix cores", "seir": ", network on the FP64 matrix cores, parameter-slot sums / controller on the FP64 vector unit",
-                                    "node": ", network on the FP64 matrix cores, parameter-slot sums / controller on the FP64 vector unit"}.get(
-                                       a.workload, ", FP64 VALU (no MFMA: 5- and 64-wide layers stay on the vector unit)"),
+                         "kernel": roofline_kernel_name(a),
                          "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": pmc_traffic(a),
