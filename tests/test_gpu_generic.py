@@ -171,3 +171,31 @@ def test_fisher_kpp_small_n_weights(n_weights):
     assert_bitwise(r.grad_u0, ref["grad_u0"], "dL/du0")
     gn = np.linalg.norm(ref["grad_theta"])
     assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < 1e-12 * gn
+
+
+def test_tanh_bits_across_the_argument_range():
+    """ARITH-SPEC tanh = em / (em + 2), em = expm1(2|x|): the kernels form that quotient without the operand scaling and special-case
+    fix-up of the general division (csrc/ude_math.h, div_em) -- it must still be the correctly rounded quotient for EVERY argument:
+    zeros, subnormal and barely normal arguments (the divisor is then exactly 2 and the quotient may be subnormal), the range where
+    em + 2 starts to differ from 2, moderate and saturating arguments.  A 2-2-2 chain with identity weights makes the right-hand
+    side return tanh(u) itself: compared bit for bit with the oracle, which divides with the C operator."""
+    dims, acts = [2, 2, 2], ["tanh", "identity"]
+    chain = chain_of(dims, acts)
+    f = models.ude_dynamics(chain, p_true=(0.0, 0.9, 0.8, 0.0))
+    om = O.make_model(O.KIND_LV_UDE, 2, dims, acts, lin_const=(0.0, -0.0))
+    th = np.array([1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0], dtype=np.float64)          # W1 = I, b1 = 0, W2 = I, b2 = 0
+    assert f.n_param == th.size == om.n_param
+    rng = np.random.default_rng(7)
+    tiny = np.float64(5e-324)
+    special = [0.0, tiny, 3 * tiny, 1e-320, 2.2250738585072014e-308, 2.2250738585072009e-308, 4.4501477170144023e-308, 1e-300, 1e-292,
+               1e-280, 2.0 ** -54, 2.0 ** -53, 2.0 ** -52, 2.0 ** -51, 1e-10, 1e-3, 0.34657359027997264, 0.5, 1.0, 10.0, 19.999999999999996, 20.0,
+               25.0, 700.0]
+    x = np.concatenate([special, 10.0 ** rng.uniform(-323, 1.5, 4000), rng.uniform(0, 2, 2000), np.ldexp(rng.uniform(1, 2, 1000), rng.integers(-1074, -1000, 1000))])
+    x = np.concatenate([x, -x])
+    if x.size % 2:
+        x = np.append(x, 0.0)
+    u = x.reshape(-1, 2)
+    du = U.rhs(f, u, th)
+    ref = np.array([O.rhs(om, th, ui) for ui in u])
+    assert_bitwise(du, ref, "tanh over %d arguments" % x.size)
+    assert np.abs(ref).max() == 1.0 and (np.abs(ref[np.abs(u) < 1e-300]) <= np.abs(u[np.abs(u) < 1e-300])).all()
