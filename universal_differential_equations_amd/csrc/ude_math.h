@@ -76,6 +76,30 @@ __device__ __forceinline__ double fastpow(double x, double y) {
 // (explicit fma, no contraction: the library is compiled with -ffp-contract=off).  The CPU oracle restates
 // the same sequences independently (oracle/ude_oracle.c); tests/test_gpu_parity.py checks bitwise equality.
 // ---------------------------------------------------------------------------------------------
+// Horner steps of the exp / tanh Taylor polynomial, p = 1/13!; p = fma(p, r, 1/12!); ... ; p = fma(p, r, 1/3!), as ONE block of
+// three-address v_fma_f64.  Left to itself the compiler picks the two-address v_fmac_f64 for a Horner step and first copies the
+// coefficient into the destination (one v_mov_b64, or two literal v_mov_b32, per term), and with one wavefront per SIMD every
+// instruction is an issue slot: 13 of the ~57 slots of a tanh in the Fisher-KPP network loop were such copies.  Written as separate
+// asm statements the hazard recogniser pads each with an s_nop (a slot again); inside one block the dependent v_fma_f64 need none
+// (ordinary VALU -> VALU dependences are interlocked).  Same operations, same order, same rounding as the __builtin_fma chain.
+__device__ __forceinline__ double taylor_13_to_3(double r) {
+    double p;
+    asm("v_fma_f64 %0, %2, %1, %3\n\t"
+        "v_fma_f64 %0, %0, %1, %4\n\t"
+        "v_fma_f64 %0, %0, %1, %5\n\t"
+        "v_fma_f64 %0, %0, %1, %6\n\t"
+        "v_fma_f64 %0, %0, %1, %7\n\t"
+        "v_fma_f64 %0, %0, %1, %8\n\t"
+        "v_fma_f64 %0, %0, %1, %9\n\t"
+        "v_fma_f64 %0, %0, %1, %10\n\t"
+        "v_fma_f64 %0, %0, %1, %11\n\t"
+        "v_fma_f64 %0, %0, %1, %12"
+        : "=&v"(p)
+        : "v"(r), "v"(1.0 / 6227020800.0), "v"(1.0 / 479001600.0), "v"(1.0 / 39916800.0), "v"(1.0 / 3628800.0), "v"(1.0 / 362880.0),
+          "v"(1.0 / 40320.0), "v"(1.0 / 5040.0), "v"(1.0 / 720.0), "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
+    return p;
+}
+
 __device__ __forceinline__ double dexp(double x) {
     if (x != x) return x;
     if (x > 709.0) return __builtin_inf();
@@ -83,17 +107,7 @@ __device__ __forceinline__ double dexp(double x) {
     const double k = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(-k, 0.6931471803691238, x);
     r = __builtin_fma(-k, 1.9082149292705877e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = __builtin_fma(p, r, 1.0 / 479001600.0);
-    p = __builtin_fma(p, r, 1.0 / 39916800.0);
-    p = __builtin_fma(p, r, 1.0 / 3628800.0);
-    p = __builtin_fma(p, r, 1.0 / 362880.0);
-    p = __builtin_fma(p, r, 1.0 / 40320.0);
-    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);
+    double p = taylor_13_to_3(r);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -128,17 +142,7 @@ __device__ __forceinline__ double dtanh(double x) {
     const double k = __builtin_rint(z * 1.4426950408889634);
     double r = __builtin_fma(-k, 0.6931471803691238, z);
     r = __builtin_fma(-k, 1.9082149292705877e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = __builtin_fma(p, r, 1.0 / 479001600.0);
-    p = __builtin_fma(p, r, 1.0 / 39916800.0);
-    p = __builtin_fma(p, r, 1.0 / 3628800.0);
-    p = __builtin_fma(p, r, 1.0 / 362880.0);
-    p = __builtin_fma(p, r, 1.0 / 40320.0);
-    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);
+    double p = taylor_13_to_3(r);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     const double q = p * r;
