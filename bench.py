@@ -291,10 +291,23 @@ def pmc_traffic_file(fname, kernel_prefix):
     return None
 
 
-def quick_measure(name, device, steps=3, warmup=1):
-    """One of the OTHER workloads, measured in the same process as the headline (driver-observed): `steps` timed steps between
-    synchronisations after `warmup`, kernel times from the library's HIP events, algorithmic roofline fraction of the dominant
-    kernel as in the stand-alone `--workload` runs.  Returns a small dict for config.other_workloads."""
+def timed_steps(fn, steps):
+    """median wall-clock of `steps` individually synchronised calls, in ms (a few steps only: one host hiccup -- a page fault, a
+    late code-object load -- must not become the number)"""
+    ts = []
+    for i in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(i)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def quick_measure(name, device, steps=5, warmup=1):
+    """One of the OTHER workloads, measured in the same process as the headline (driver-observed): the median of `steps`
+    individually synchronised steps after `warmup`, kernel times from the library's HIP events, algorithmic roofline fraction of the
+    dominant kernel as in the stand-alone `--workload` runs.  Returns a small dict for config.other_workloads."""
     import universal_differential_equations_amd as U
     from universal_differential_equations_amd import models
     t_setup = time.perf_counter()
@@ -307,12 +320,7 @@ def quick_measure(name, device, steps=3, warmup=1):
         bs = pde.DeviceBSDE(prob, alg, pde.LambaEM(), M, device=device, abstol=0.1, reltol=0.1, seed=1234)
         for i in range(warmup):
             bs.loss_grad(theta, it=i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            bs.loss_grad(theta, it=i, check_store=False)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        ms = timed_steps(lambda i: bs.loss_grad(theta, it=i, check_store=False), steps)
         f, b = bs.kernel_ms()
         nf, nacc = int(bs.stats[:, 0].sum().item()), int(bs.stats[:, 1].sum().item())
         ach = nf * HJB_FLOP_PER_EVAL / (f * 1e-3) / 1e12
@@ -346,12 +354,7 @@ def quick_measure(name, device, steps=3, warmup=1):
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)
     for _ in range(warmup):
         ens.loss_grad(theta)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ens.loss_grad(theta)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    ms = timed_steps(lambda i: ens.loss_grad(theta), steps)
     f, b = ens.kernel_ms()
     nf_fwd, nf_bwd = int(ens.stats[:, 0].sum().item()), int(ens.stats[:, 4].sum().item())
     flop_key = "lv_tanh32" if name == "lv_tanh32" else wl
@@ -387,7 +390,7 @@ def main():
                                                          "instead of launching the six operations individually")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip config.other_workloads (the headline run also measures seir, kpp, hjb, "
-                                                             "node, lv_tanh32 and lv_discrete for 3 steps each)")
+                                                             "node, lv_tanh32 and lv_discrete: median of 5 steps each)")
     ap.add_argument("--allreduce", default="torch", choices=["torch", "udecore"],
                     help="N > 1: transport of the one all-reduce per gradient (torch.distributed nccl, or libudecore's RCCL binding)")
     a = ap.parse_args()
