@@ -189,7 +189,7 @@ def test_tanh_bits_across_the_argument_range():
     tiny = np.float64(5e-324)
     special = [0.0, tiny, 3 * tiny, 1e-320, 2.2250738585072014e-308, 2.2250738585072009e-308, 4.4501477170144023e-308, 1e-300, 1e-292,
                1e-280, 2.0 ** -54, 2.0 ** -53, 2.0 ** -52, 2.0 ** -51, 1e-10, 1e-3, 0.34657359027997264, 0.5, 1.0, 10.0, 19.999999999999996, 20.0,
-               25.0, 700.0]
+               25.0, 700.0, np.nan]
     x = np.concatenate([special, 10.0 ** rng.uniform(-323, 1.5, 4000), rng.uniform(0, 2, 2000), np.ldexp(rng.uniform(1, 2, 1000), rng.integers(-1074, -1000, 1000))])
     x = np.concatenate([x, -x])
     if x.size % 2:
@@ -198,4 +198,5 @@ def test_tanh_bits_across_the_argument_range():
     du = U.rhs(f, u, th)
     ref = np.array([O.rhs(om, th, ui) for ui in u])
     assert_bitwise(du, ref, "tanh over %d arguments" % x.size)
-    assert np.abs(ref).max() == 1.0 and (np.abs(ref[np.abs(u) < 1e-300]) <= np.abs(u[np.abs(u) < 1e-300])).all()
+    assert np.nanmax(np.abs(ref)) == 1.0 and (np.abs(ref[np.abs(u) < 1e-300]) <= np.abs(u[np.abs(u) < 1e-300])).all()
+    assert np.isnan(du[np.isnan(u)]).all() and np.isnan(du).sum() == 4   # (0 * NaN: the row's other component is NaN as well)

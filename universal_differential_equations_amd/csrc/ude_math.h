@@ -101,7 +101,8 @@ __device__ __forceinline__ double taylor_13_to_3(double r) {
 }
 
 __device__ __forceinline__ double dexp(double x) {
-    if (x != x) return x;
+    // (a NaN argument fails both range tests and runs through every operation below as NaN: no test of its own, which the
+    // compiler turns into an EXEC-masked branch -- four issue slots per call)
     if (x > 709.0) return __builtin_inf();
     if (x < -745.0) return 0.0;
     const double k = __builtin_rint(x * 1.4426950408889634);
