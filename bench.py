@@ -33,6 +33,39 @@ FLOPS = {"lv": (160.0, 550.0), "seir": (8744.0, 26000.0), "kpp": (0.87e6, 2.6e6)
          "lv_tanh32": (258.0, 840.0)}
 
 
+HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
+# The roof that bounds each workload's dominant (backward) kernel -- `roofline.bound`:
+#   valu  the FP64 vector unit (78.6 TF): the LV kernels (5- and 32-wide layers stay on the vector unit, as north_star says)
+#   mfma  the FP64 / FP32 matrix cores: Fisher-KPP (78.6 TF), the deep-BSDE step (157.3 TF)
+#   hbm   the lock-step SEIR / neural-ODE backward kernels in parity mode: the parameter cotangent mu (np doubles per slot) lives in
+#         HBM and every step attempt reads the current column and writes the candidate -- 2 * np * 8 B per attempt, the algorithmic
+#         stream SURVEY.md 8(d) C3 names ("HBM in parity mode"); their flop fraction is reported beside it (`flop_frac`)
+BOUND = {"lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
+
+
+def mu_stream_bytes(stats, n_param):
+    """algorithmic HBM bytes of one backward launch of a deferred-cotangent kernel: (accepted + rejected) step attempts x (read mu, write candidate)"""
+    return float((stats[:, 5].sum() + stats[:, 6].sum()).item()) * 2.0 * n_param * 8.0
+
+
+def headline_roofline(a, fkey, achieved_tflops, bwd_s, stats, n_param):
+    """the `roofline` object of the JSON line for the dominant (backward) kernel: `bound` names the roof that bounds it (BOUND above),
+    achieved / peak / frac are against THAT roof; hbm-bound kernels carry their flop fraction beside it"""
+    bound = BOUND["lv_tanh32" if fkey == "lv_tanh32" else a.workload]
+    if a.sensealg != "adjoint" or a.lanes not in (0, 16):
+        bound = "valu" if bound == "hbm" else bound   # (the wavefront-per-trajectory / fast / discrete kernels of seir and node)
+    r = {"bound": bound, "kernel": roofline_kernel_name(a), "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": pmc_traffic(a),
+         "note": "bound: valu = FP64 vector unit, mfma = FP64 matrix cores (both 78.6 TF on this part), hbm = 8 TB/s; algorithmic %g flop per "
+                 "adjoint eval; traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of the kernel from the separate rocprofv3 --pmc passes of this "
+                 "command (profiles/r04_pmc_<workload>.md, tools/prof_r04.sh), null for non-default commands" % FLOPS[fkey][1]}
+    if bound == "hbm":
+        gbps = mu_stream_bytes(stats, n_param) / bwd_s / 1e9
+        r.update({"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                  "flop_frac": achieved_tflops / FP64_PEAK_TFLOPS, "achieved_tflops": achieved_tflops})
+    return r
+
+
 SENSE_NAME = {"adjoint": "InterpolatingAdjoint", "discrete": "discretise-then-optimise (ForwardDiffSensitivity-equivalent)",
               "fast": "InterpolatingAdjoint with lambda-only error control (SURVEY 8(b) fast mode; not the reference's step sequence)"}
 # which unit dominates each backward kernel: the LV / SEIR kernels run on the FP64 VALU, Fisher-KPP on the FP64 matrix cores
@@ -152,7 +185,7 @@ def pmc_traffic(a):
         kern = "seirls::seir_ls_adj_kernel<"     # the lock-step matrix-core backward kernel (the default)
     if a.workload == "node" and a.sensealg == "adjoint" and a.lanes in (0, 16):
         kern = "nodels::node_ls_adj_kernel<"
-    return pmc_traffic_file("r03_pmc_%s.md" % a.workload, "`void " + kern) or pmc_traffic_file("r02_pmc_%s.md" % a.workload, "`void " + kern)
+    return pmc_any(a.workload, "`void " + kern)
 
 
 def run_hjb(a, rank, world, local, device, dist):
@@ -270,7 +303,11 @@ def cpu_baseline_hjb(theta_h, tol, seconds_target=15.0):
 
 def pmc_any(stem, kernel_prefix):
     """this round's PMC summary of a workload if it has been collected, else last round's"""
-    return pmc_traffic_file("r03_pmc_%s.md" % stem, kernel_prefix) or pmc_traffic_file("r02_pmc_%s.md" % stem, kernel_prefix)
+    for rnd in ("r04", "r03", "r02"):
+        v = pmc_traffic_file("%s_pmc_%s.md" % (rnd, stem), kernel_prefix)
+        if v:
+            return v
+    return None
 
 
 def pmc_traffic_file(fname, kernel_prefix):
@@ -311,22 +348,27 @@ def quick_measure(name, device, steps=5, warmup=1):
     import universal_differential_equations_amd as U
     from universal_differential_equations_amd import models
     t_setup = time.perf_counter()
-    if name == "hjb":
+    if name in ("hjb", "hjb_script_tol"):
         from universal_differential_equations_amd import pde
-        M = 16384
+        # hjb: the throughput configuration (16 384 trajectories per GPU, tol 0.1); hjb_script_tol: the SCRIPT's own call
+        # (lambaem.jl:27-34: trajectories = 100, abstol = reltol = 1e-4) -- 1.4e4 .. 4.8e4 steps per trajectory, a latency measurement
+        M, tol = (16384, 0.1) if name == "hjb" else (100, 1e-4)
         alg = pde.NNPDENS(100, 110, opt=pde.ADAM(0.03))
         theta = torch.tensor(alg.init_params(np.random.default_rng(0)), device=device)
         prob = pde.TerminalPDEProblem(pde.hjb(1.0), np.zeros(100), (0.0, 1.0))
-        bs = pde.DeviceBSDE(prob, alg, pde.LambaEM(), M, device=device, abstol=0.1, reltol=0.1, seed=1234)
+        bs = pde.DeviceBSDE(prob, alg, pde.LambaEM(), M, device=device, abstol=tol, reltol=tol, seed=1234)
+        if name == "hjb_script_tol":
+            steps = min(steps, 2)
         for i in range(warmup):
             bs.loss_grad(theta, it=i)
         ms = timed_steps(lambda i: bs.loss_grad(theta, it=i, check_store=False), steps)
         f, b = bs.kernel_ms()
         nf, nacc = int(bs.stats[:, 0].sum().item()), int(bs.stats[:, 1].sum().item())
         ach = nf * HJB_FLOP_PER_EVAL / (f * 1e-3) / 1e12
-        return {"workload": "configs[4] per-GPU share: deep-BSDE step, 16384 trajectories, LambaEM tol 0.1", "ms_per_step": ms,
+        return {"workload": "configs[4] per-GPU share: deep-BSDE step, 16384 trajectories, LambaEM tol 0.1" if name == "hjb" else
+                "highdim_pde/lambaem.jl's own call: one deep-BSDE step, 100 trajectories, LambaEM abstol = reltol = 1e-4", "ms_per_step": ms,
                 "evals_per_s": (nf + nacc) / (ms * 1e-3), "dominant_kernel": "hjb_fwd_kernel", "kernel_ms": f, "bwd_kernel_ms": b,
-                "achieved_tflops": ach, "peak_tflops": FP32_MFMA_PEAK_TFLOPS, "frac": ach / FP32_MFMA_PEAK_TFLOPS, "unit": "mfma-f32",
+                "bound": "mfma", "achieved_tflops": ach, "peak_tflops": FP32_MFMA_PEAK_TFLOPS, "frac": ach / FP32_MFMA_PEAK_TFLOPS, "unit": "mfma-f32",
                 "failed_trajectories": int((bs.retcode != 0).sum().item()), "traffic": pmc_any("hjb", "hjb_fwd_kernel")}
     sense, wl, net = "adjoint", name, "s1"
     if name == "lv_tanh32":
@@ -361,10 +403,14 @@ def quick_measure(name, device, steps=5, warmup=1):
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
     kern = "dadj_kernel" if sense == "discrete" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "nodels::node_ls_adj_kernel" if wl == "node" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete") else wl
-    return {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
-            "fwd_kernel_ms": f, "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
-            "unit": "mfma-f64" if wl == "kpp" else ("mfma-f64 + valu-f64" if wl in ("seir", "node") else "valu-f64"), "failed_trajectories": int((ens.retcode != 0).sum().item()),
-            "traffic": pmc_any(pm, "`void " + kern + "<"), "setup_s": time.perf_counter() - t_setup}
+    out = {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
+           "fwd_kernel_ms": f, "bound": BOUND[name], "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
+           "unit": "mfma-f64" if wl == "kpp" else ("mfma-f64 + valu-f64" if wl in ("seir", "node") else "valu-f64"), "failed_trajectories": int((ens.retcode != 0).sum().item()),
+           "traffic": pmc_any(pm, "`void " + kern + "<"), "setup_s": time.perf_counter() - t_setup}
+    if BOUND[name] == "hbm":  # frac = against the roof that bounds the kernel; the flop fraction stays beside it
+        gbps = mu_stream_bytes(ens.stats, len(theta_h)) / (b * 1e-3) / 1e9
+        out.update({"flop_frac": out["frac"], "achieved_gbps": gbps, "peak_gbps": HBM_PEAK_GBPS, "frac": gbps / HBM_PEAK_GBPS})
+    return out
 
 
 def main():
@@ -543,17 +589,7 @@ def main():
                        "lane_step_util": lane_step_util, "bwd_attempts_max_over_mean": critical_path,
                        "fwd_kernel_ms": float(np.mean(fwd_ms)),
                        "bwd_kernel_ms": float(np.mean(bwd_ms))},
-            "roofline": {"bound": "mfma", "unit_busy": {"kpp": "mfma-f64", "seir": "mfma-f64 + valu-f64", "node": "mfma-f64 + valu-f64"}.get(a.workload, "valu-f64"),
-                         "kernel": roofline_kernel_name(a),
-                         "achieved": achieved,
-                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(a),
-                         "note": "compute roof = the FP64 VECTOR unit (valu) for lv / seir / node, the FP64 matrix cores for kpp; the schema's `bound` "
-                                 "offers hbm | mfma only and both FP64 peaks are 78.6 TF, so `mfma` names that compute roof (see unit_busy); "
-                                 "algorithmic %g flop per adjoint eval; "
-                                 "the path is FP64-ALU/latency bound, not HBM bound (DESIGN.md); traffic = FETCH_SIZE + "
-                                 "WRITE_SIZE bytes per adj_kernel launch from the separate rocprofv3 --pmc passes of this "
-                                 "command (profiles/r03_pmc_<workload>.md, tools/prof_r03.sh), null for non-default commands" % FLOPS[fkey][1]},
+            "roofline": headline_roofline(a, fkey, achieved, bwd, ens.stats, len(theta_h)),
         }
         if not a.no_cpu_baseline and world == 1:  # (the CPU leg is a rank-0, N=1 measurement)
             out["cpu_baseline"] = cpu_baseline(theta_h, u0_d.cpu().numpy(), t, data.cpu().numpy(), workload=a.workload, mask=mask)
@@ -563,7 +599,7 @@ def main():
             del ens
             torch.cuda.empty_cache()
             others = {}
-            for name in ("seir", "kpp", "hjb", "node", "lv_tanh32", "lv_discrete"):
+            for name in ("seir", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_discrete"):
                 try:
                     others[name] = quick_measure(name, device)
                 except Exception as e:  # a failing secondary workload must not take the headline line with it

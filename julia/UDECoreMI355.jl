@@ -85,12 +85,15 @@ end
 
 # ---- context ----------------------------------------------------------------------------------------------------
 const CTXS = Dict{Int,Ptr{Cvoid}}()      # one context per device; a device is driven by one host task at a time
+const TABLE_LOCK = ReentrantLock()       # CTXS / COMMS are plain Dicts: the per-device tasks of __solve look contexts up concurrently
 function ctx(dev::Integer = 0)
-    get!(CTXS, dev) do
-        h = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:ude_create, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}), dev, h)
-        rc == 0 || error("ude_create(device = $dev) failed ($rc)")
-        h[]
+    lock(TABLE_LOCK) do
+        get!(CTXS, dev) do
+            h = Ref{Ptr{Cvoid}}(C_NULL)
+            rc = ccall((:ude_create, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}), dev, h)
+            rc == 0 || error("ude_create(device = $dev) failed ($rc)")
+            h[]
+        end
     end
 end
 # UDE_ERR_TRAJECTORY (-5): a member stopped early; like upstream the solution RETURNS and its retcode says why, but a
@@ -171,11 +174,13 @@ end
 the caller's GPU array package (AMDGPU.jl `ROCArray` pointers) -- shown here with `Ptr{Float64}` arguments."
 const COMMS = Dict{Vector{Int},Vector{Ptr{Cvoid}}}()     # communicators are created once per device set and kept
 function comms_for(devs::Vector{Int})
-    get!(COMMS, devs) do
-        ctxs = [ctx(dv) for dv in devs]
-        comms = Vector{Ptr{Cvoid}}(undef, length(devs))
-        check(ccall((:ude_comm_create_local, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), length(devs), ctxs, comms), devs[1])
-        comms
+    lock(TABLE_LOCK) do   # (reentrant: ctx() takes it again)
+        get!(COMMS, devs) do
+            ctxs = [ctx(dv) for dv in devs]
+            comms = Vector{Ptr{Cvoid}}(undef, length(devs))
+            check(ccall((:ude_comm_create_local, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), length(devs), ctxs, comms), devs[1])
+            comms
+        end
     end
 end
 "every device's `payload` = double[np + 1] = [grad(np); loss] is filled by its own ude_loss_grad_ensemble_dev and then summed over
@@ -273,6 +278,7 @@ function SciMLBase.__solve(ens::SciMLBase.AbstractEnsembleProblem, alg::Union{MI
     θ = Vector{Float64}(probs[1].p); N = trajectories; nd = length(ea.devices)
     u = Array{Float64}(undef, size(u0s, 1), length(grids[1]), N); rc = zeros(Int32, N)
     bounds = [(div((k - 1) * N, nd) + 1, div(k * N, nd)) for k in 1:nd]
+    foreach(ctx, ea.devices)   # contexts exist before the per-device tasks start (and the tables are locked anyway)
     @sync for (k, dv) in enumerate(ea.devices)
         lo, hi = bounds[k]; hi >= lo || continue
         Threads.@spawn begin

@@ -30,3 +30,24 @@ def test_every_reported_workload_has_its_flop_count():
     for k in ("lv", "seir", "kpp", "node", "lv_tanh32"):
         fwd, adj = bench.FLOPS[k]
         assert 0 < fwd < adj
+
+
+def test_roofline_bound_is_chosen_per_kernel():
+    """`roofline.bound` names the roof that bounds the command's dominant kernel -- valu / mfma / hbm -- and achieved / peak / frac are
+    against that roof; the HBM-bound lock-step kernels keep their flop fraction beside it"""
+    import torch
+    stats = torch.zeros(4, 8, dtype=torch.int64)
+    stats[:, 5], stats[:, 6] = 40, 3                    # backward: 43 step attempts per trajectory
+    a = _args(alg="tsit5", waves=0, traj=0)
+    r = bench.headline_roofline(a, "lv", 2.0, 1.3e-3, stats, 87)
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - 2.0 / 78.6) < 1e-12
+    r = bench.headline_roofline(_args(workload="kpp", alg="tsit5", waves=0, traj=0), "kpp", 8.0, 25e-3, stats, 466)
+    assert r["bound"] == "mfma"
+    r = bench.headline_roofline(_args(workload="seir", alg="tsit5", waves=0, traj=0), "seir", 5.5, 12e-3, stats, 4481)
+    want = 4 * 43 * 2 * 4481 * 8 / 12e-3 / 1e9
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["achieved"] - want) < 1e-6 * want and r["peak"] == 8000.0
+    assert abs(r["flop_frac"] - 5.5 / 78.6) < 1e-12
+    # the wavefront-per-trajectory kernel of the same workload keeps mu in LDS/registers: compute bound
+    r = bench.headline_roofline(_args(workload="seir", lanes=64, alg="tsit5", waves=0, traj=0), "seir", 3.0, 18e-3, stats, 4481)
+    assert r["bound"] == "valu"
+    assert set(bench.BOUND.values()) <= {"valu", "mfma", "hbm"}

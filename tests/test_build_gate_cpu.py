@@ -1,0 +1,140 @@
+"""The build-time gate against the code-generation defect of DESIGN.md 2a (register copies in front of the EXEC restore of a
+join block: lanes that skipped the region keep a stale value).  tools/isa_endcf_fix.py repairs the device assembly of every
+translation unit and refuses what it cannot prove safe; here: its behaviour on the patterns it must move, must leave alone and
+must refuse, and -- when this container has built the library -- that every repaired assembly file under build/ is clean."""
+import glob
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tool():
+    spec = importlib.util.spec_from_file_location("isa_endcf_fix", os.path.join(ROOT, "tools", "isa_endcf_fix.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+KERNEL = "_Z6kernelv:\n"
+
+# the site found in adj_kernel<LvUde<NetTanh32, 8>, Tsit5, fast> (round 4): three live-range copies in front of the join of a
+# guarded loop; the lanes whose guard was false arrive with EXEC == 0 and would skip them
+JOIN_WITH_COPIES = KERNEL + """\ts_and_saveexec_b64 s[12:13], s[4:5]
+\ts_cbranch_execz .LBB0_3
+; %bb.1:
+\tv_add_f64 v[0:1], v[2:3], v[4:5]
+.LBB0_3:
+\tv_mov_b64_e32 v[142:143], v[18:19]
+\tv_mov_b32_e32 v133, v12
+\tv_mov_b64_e32 v[138:139], v[42:43]
+\ts_or_b64 exec, exec, s[12:13]
+\tv_add_f64 v[0:1], v[72:73], -v[70:71]
+\ts_endpgm
+"""
+
+
+def test_copies_in_front_of_the_exec_restore_are_moved_behind_it():
+    T = tool()
+    text, rep = T.process(JOIN_WITH_COPIES)
+    assert len(rep["fixed"]) == 1 and not rep["unhandled"]
+    body = [l.strip() for l in text.split("\n") if l.strip()]
+    i = body.index(".LBB0_3:")
+    assert body[i + 1] == "s_or_b64 exec, exec, s[12:13]"
+    assert body[i + 2:i + 5] == ["v_mov_b64_e32 v[142:143], v[18:19]", "v_mov_b32_e32 v133, v12", "v_mov_b64_e32 v[138:139], v[42:43]"]
+    assert body[i + 5] == "s_nop 4"
+    _, again = T.process(text, repair=False)
+    assert not again["fixed"] and not again["unhandled"]       # idempotent: the repaired text is clean
+
+
+def test_loop_exit_by_fall_through_is_an_entry_with_exec_zero():
+    T = tool()
+    src = KERNEL + """.LBB0_1:
+\tv_add_u32_e32 v1, 1, v1
+\ts_andn2_b64 exec, exec, s[2:3]
+\ts_cbranch_execnz .LBB0_1
+; %bb.2:
+\tv_accvgpr_read_b32 v5, a7
+\ts_or_b64 exec, exec, s[2:3]
+\ts_endpgm
+"""
+    text, rep = T.process(src)
+    assert len(rep["fixed"]) == 1
+    body = [l.strip() for l in text.split("\n") if l.strip()]
+    assert body.index("s_or_b64 exec, exec, s[2:3]") < body.index("v_accvgpr_read_b32 v5, a7")
+
+
+def test_scalar_reload_of_the_mask_stays_in_front():
+    """`v_readlane sN` (EXEC-independent) reloading the spilled mask must stay in front of the restore; a copy next to it moves"""
+    T = tool()
+    src = KERNEL + """\ts_cbranch_execz .LBB0_5
+.LBB0_5:
+\tv_readlane_b32 s2, v255, 47
+\tv_mov_b32_e32 v9, v8
+\tv_readlane_b32 s3, v255, 48
+\ts_or_b64 exec, exec, s[2:3]
+\ts_endpgm
+"""
+    text, rep = T.process(src)
+    assert len(rep["fixed"]) == 1 and not rep["unhandled"]
+    body = [l.strip() for l in text.split("\n") if l.strip()]
+    i = body.index(".LBB0_5:")
+    assert body[i + 1:i + 5] == ["v_readlane_b32 s2, v255, 47", "v_readlane_b32 s3, v255, 48", "s_or_b64 exec, exec, s[2:3]", "v_mov_b32_e32 v9, v8"]
+
+
+def test_region_entry_after_a_wave_level_skip_is_left_alone():
+    """EXEC == 0 on entry and the next EXEC write narrows further (a region ENTRY, plain or open-coded): the lanes stay off until an
+    outer join; nothing in between can be owed to them"""
+    T = tool()
+    for entry in ("\ts_and_saveexec_b64 s[4:5], s[0:1]\n",
+                  "\ts_mov_b64 s[8:9], exec\n\ts_and_b64 s[2:3], s[8:9], s[2:3]\n\ts_mov_b64 exec, s[2:3]\n"):
+        src = KERNEL + "\ts_cbranch_execz .LBB0_58\n.LBB0_58:\n\tv_mov_b32_e32 v230, 0\n" + entry + "\ts_cbranch_execz .LBB0_60\n.LBB0_60:\n\ts_endpgm\n"
+        text, rep = T.process(src)
+        assert not rep["fixed"] and not rep["unhandled"] and text == src
+
+
+def test_unprovable_moves_are_refused():
+    T = tool()
+    # the vector instruction writes the mask register the restore reads
+    src = KERNEL + "\ts_cbranch_execz .LBB0_1\n.LBB0_1:\n\tv_cmp_lt_f64_e64 s[2:3], v[0:1], v[2:3]\n\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n"
+    _, rep = T.process(src)
+    assert rep["unhandled"] and not rep["fixed"]
+    # a scalar instruction in the prefix depends on a vector result
+    src = KERNEL + "\ts_cbranch_execz .LBB0_1\n.LBB0_1:\n\tv_cmp_lt_f64_e64 s[6:7], v[0:1], v[2:3]\n\ts_and_b64 s[8:9], s[6:7], s[10:11]\n\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n"
+    _, rep = T.process(src)
+    assert rep["unhandled"] and not rep["fixed"]
+    # a memory instruction in front of a wait
+    src = KERNEL + "\ts_cbranch_execz .LBB0_1\n.LBB0_1:\n\tds_read_b64 v[0:1], v2\n\ts_waitcnt lgkmcnt(0)\n\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n"
+    _, rep = T.process(src)
+    assert rep["unhandled"] and not rep["fixed"]
+
+
+def test_region_tail_that_falls_into_its_join_is_not_a_site():
+    """an else-body that falls through into its own `s_or_b64 exec` (no label in between, entered with its lanes ON) is ordinary code"""
+    T = tool()
+    src = KERNEL + """\ts_or_saveexec_b64 s[2:3], s[36:37]
+\ts_xor_b64 exec, exec, s[2:3]
+\ts_cbranch_execz .LBB0_48
+.LBB0_50:
+\tv_add_u32_e32 v8, v254, v241
+\tds_write2st64_b64 v8, v[66:67], v[68:69] offset1:1
+\ts_or_b64 exec, exec, s[2:3]
+.LBB0_48:
+\ts_endpgm
+"""
+    text, rep = T.process(src)
+    assert not rep["fixed"] and not rep["unhandled"] and text == src
+
+
+def test_every_built_translation_unit_is_clean():
+    """build.py keeps the repaired device assembly of every translation unit (build/*.fixed.s, this container only): none of
+    them may contain a vector instruction between an EXEC == 0 entry and the EXEC restore"""
+    files = sorted(glob.glob(os.path.join(ROOT, "universal_differential_equations_amd", "build", "*.fixed.s")))
+    if not files:
+        pytest.skip("no build/ directory here (the GPU box receives the built library only)")
+    T = tool()
+    for f in files:
+        _, rep = T.process(open(f).read(), repair=False)
+        assert not rep["fixed"] and not rep["unhandled"], "%s: %s" % (os.path.basename(f), (rep["fixed"] + rep["unhandled"])[:2])

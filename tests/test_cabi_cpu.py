@@ -27,6 +27,19 @@ def test_library_exports_every_declared_symbol():
     assert L.ude_version() == 100
 
 
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """no -fvisibility leak: `nm -D --defined-only` of the shipping library lists the entry points of include/udecore.h and
+    nothing else (the instance getters ude_inst_*, the lock-step getters and every C++ symbol are local: build.py links with a
+    version script written from the header); the debug library adds its one probe"""
+    import subprocess
+    from universal_differential_equations_amd import _lib, build
+    names = set(declared_functions())
+    for lib, extra in ((build.LIB, set()), (build.LIB_DBG, set(build.DBG_EXPORTS))):
+        out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+        syms = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+        assert syms == names | extra, "%s: unexpected %s, missing %s" % (os.path.basename(lib), sorted(syms - names - extra)[:8], sorted((names | extra) - syms)[:8])
+
+
 def test_struct_sizes_match_header():
     from universal_differential_equations_amd import _lib
     # ude_model_desc: 5 + 9 + 8 + 1 + 2 + 3 int32 = 28 int32 = 112 B, then 2+2+16 doubles = 160 B

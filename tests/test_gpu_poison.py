@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-# the parity tests that are repeated under the poison kernel (pytest -k expressions per file)
+# Every oracle-comparing GPU test file is repeated under the poison kernel (pytest -k expressions per file; "" = the whole
+# file).  Round 4: the fuzz corners, the fast-adjoint, Float32, stiff and edge-case files joined (the round-3 review); what the
+# poison test can and cannot see is stated in DESIGN.md 2a -- a register that keeps an OLDER VALUE OF THE SAME KERNEL is not
+# garbage and stays invisible here; that class is closed at build time (tools/isa_endcf_fix.py, tests/test_build_gate_cpu.py).
 SELECTION = [
     ("test_gpu_node.py", "forward_and_adjoint_match_oracle or reproducible_run_to_run or rhs_matches_oracle"),
     ("test_gpu_parity.py", "test_seir_ude_forward_and_adjoint_match_oracle or test_adjoint_gradient_matches_oracle or "
@@ -25,6 +28,11 @@ SELECTION = [
                            "test_seir_true_matches_oracle or test_kpp_true_matches_oracle or test_forward_ensemble_matches_oracle"),
     ("test_gpu_hjb.py", "test_adaptive_loss_and_gradient_match_oracle or test_rejections_and_stack_match_oracle"),
     ("test_gpu_generic.py", "fuzz"),
+    ("test_gpu_fuzz.py", ""),
+    ("test_gpu_fast_adjoint.py", ""),
+    ("test_gpu_f32.py", ""),
+    ("test_gpu_stiff.py", ""),
+    ("test_gpu_edge_cases.py", ""),
 ]
 
 
@@ -34,20 +42,24 @@ def _run(files_k, extra_env):
         path = os.path.join(HERE, fname)
         if not os.path.exists(path):
             continue
-        r = subprocess.run([sys.executable, "-m", "pytest", path, "-x", "-q", "-m", "gpu", "-k", kexpr, "-p", "no:cacheprovider"],
+        r = subprocess.run([sys.executable, "-m", "pytest", path, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + (["-k", kexpr] if kexpr else []),
                            env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
         assert r.returncode == 0, "%s under %s:\n%s\n%s" % (fname, extra_env, r.stdout[-3000:], r.stderr[-2000:])
         assert " passed" in r.stdout, r.stdout[-500:]
 
 
 def test_debug_library_really_poisons():
-    """the hook is live in the debug build: with NaN garbage in LDS *and* a deliberately too-small check it still passes, i.e.
-    the child loads libudecore_dbg.so (a missing debug library must not turn this file into a no-op)"""
-    code = ("import os, ctypes; from universal_differential_equations_amd import _lib; L = _lib.load(); "
-            "assert _lib.LIB_PATH.endswith('libudecore_dbg.so'), _lib.LIB_PATH; print('dbg ok')")
+    """positive control: the child loads libudecore_dbg.so AND its poison kernel reaches the register file -- after a poison
+    launch with a given pattern a fresh wavefront finds that pattern in a VGPR and an AGPR it never wrote (a debug library built
+    without the hook, or a hook that no longer runs, fails here instead of turning this file into a plain re-run)"""
+    code = ("import ctypes as C, numpy as np; from universal_differential_equations_amd import _lib; import universal_differential_equations_amd as U; "
+            "L = _lib.load(); assert _lib.LIB_PATH.endswith('libudecore_dbg.so'), _lib.LIB_PATH; eng = U.Engine.get(0); "
+            "L.ude_dbg_poison_selftest.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]; out = np.zeros(128, dtype=np.uint32); "
+            "rc = L.ude_dbg_poison_selftest(eng.h, 0x5EED1234, out.ctypes.data); assert rc == 0, rc; "
+            "hits = int((out == 0x5EED1234).sum()); print('hits', hits); assert hits == 128, out; print('dbg ok')")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UDE_LIB_VARIANT="dbg"), capture_output=True, text=True,
                        cwd=os.path.dirname(HERE))
-    assert r.returncode == 0 and "dbg ok" in r.stdout, r.stderr[-2000:]
+    assert r.returncode == 0 and "dbg ok" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("idx", range(len(SELECTION)), ids=[s[0][9:-3] for s in SELECTION])

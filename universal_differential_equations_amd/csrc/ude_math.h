@@ -82,6 +82,13 @@ __device__ __forceinline__ double fastpow(double x, double y) {
 // instruction is an issue slot: 13 of the ~57 slots of a tanh in the Fisher-KPP network loop were such copies.  Written as separate
 // asm statements the hazard recogniser pads each with an s_nop (a slot again); inside one block the dependent v_fma_f64 need none
 // (ordinary VALU -> VALU dependences are interlocked).  Same operations, same order, same rounding as the __builtin_fma chain.
+// The ten addends of the Horner steps are wave-uniform constants: as SCALAR operands (one SGPR pair per v_fma_f64: the constant
+// bus of gfx9-class VOP3 carries one) they are materialised by s_mov_b32 on the scalar unit -- or stay resident in SGPRs --
+// instead of by two v_mov_b32 (or v_accvgpr_read) each on the vector unit in front of every call: 20 vector issue slots less per
+// exp / tanh where the compiler does not find the registers to hoist them (the LV kernels: every call), round 4.
+#ifndef UDE_TAYLOR_C
+#define UDE_TAYLOR_C(x) "s"(x)
+#endif
 __device__ __forceinline__ double taylor_13_to_3(double r) {
     double p;
     asm("v_fma_f64 %0, %2, %1, %3\n\t"
@@ -95,10 +102,16 @@ __device__ __forceinline__ double taylor_13_to_3(double r) {
         "v_fma_f64 %0, %0, %1, %11\n\t"
         "v_fma_f64 %0, %0, %1, %12"
         : "=&v"(p)
-        : "v"(r), "v"(1.0 / 6227020800.0), "v"(1.0 / 479001600.0), "v"(1.0 / 39916800.0), "v"(1.0 / 3628800.0), "v"(1.0 / 362880.0),
-          "v"(1.0 / 40320.0), "v"(1.0 / 5040.0), "v"(1.0 / 720.0), "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
+        : "v"(r), "v"(1.0 / 6227020800.0), UDE_TAYLOR_C(1.0 / 479001600.0), UDE_TAYLOR_C(1.0 / 39916800.0), UDE_TAYLOR_C(1.0 / 3628800.0),
+          UDE_TAYLOR_C(1.0 / 362880.0), UDE_TAYLOR_C(1.0 / 40320.0), UDE_TAYLOR_C(1.0 / 5040.0), UDE_TAYLOR_C(1.0 / 720.0),
+          UDE_TAYLOR_C(1.0 / 120.0), UDE_TAYLOR_C(1.0 / 24.0), UDE_TAYLOR_C(1.0 / 6.0));
     return p;
 }
+
+// the integer-valued double k (|k| < 2^31) as int32 WITHOUT a float -> int cast: the low word of k + 1.5 * 2^52 (exact).  A cast
+// of a NaN is undefined in the language (poison in LLVM), and exp / tanh have no NaN test in front of it; this is defined for
+// every bit pattern (a NaN gives some integer, and ldexp(NaN, anything) is NaN) and costs the one v_add_f64 the v_cvt_i32_f64 did.
+__device__ __forceinline__ int exponent_of(double k) { return __double2loint(k + 6755399441055744.0); }
 
 __device__ __forceinline__ double dexp(double x) {
     // (a NaN argument fails both range tests and runs through every operation below as NaN: no test of its own, which the
@@ -112,7 +125,7 @@ __device__ __forceinline__ double dexp(double x) {
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)k);
+    return __builtin_ldexp(p, exponent_of(k));
 }
 
 // em / d for d = em + 2, 0 <= em < 2^58: the correctly rounded quotient, bit for bit what `em / d` returns, without the operand
@@ -136,10 +149,13 @@ __device__ __forceinline__ double dtanh(double x) {
     // ARITH-SPEC tanh: ONE branch-free path (lanes of a wavefront never diverge over the argument's size):
     //   z = 2|x| = k ln2 + r;  q = expm1(r) (dexp's Taylor polynomial without its final + 1);
     //   em = expm1(z) = 2^k q + (2^k - 1) (one fma, 2^k - 1 exact);  tanh = em / (em + 2)
-    // accurate for small |x| (k = 0: em = q) and large alike; |x| >= 20 rounds to 1
-    if (x != x) return x;
+    // accurate for small |x| (k = 0: em = q) and large alike; |x| >= 20 rounds to 1.
+    // No test for a NaN argument (round 4; it was an EXEC-masked branch per call, 5 % of the Fisher-KPP network loop): both
+    // selects are written `!(ax >= 20)` so that a NaN takes the arithmetic path and comes out as NaN (the oracle returns its
+    // argument: equal under the NaN-aware comparison of the tests); the exponent goes through exponent_of(), not a cast.
     const double ax = fabs(x);
-    const double z = ax < 20.0 ? ax + ax : 40.0;
+    const bool small = !(ax >= 20.0);
+    const double z = small ? ax + ax : 40.0;
     const double k = __builtin_rint(z * 1.4426950408889634);
     double r = __builtin_fma(-k, 0.6931471803691238, z);
     r = __builtin_fma(-k, 1.9082149292705877e-10, r);
@@ -147,10 +163,10 @@ __device__ __forceinline__ double dtanh(double x) {
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     const double q = p * r;
-    const double s = __builtin_ldexp(1.0, (int)k);
+    const double s = __builtin_ldexp(1.0, exponent_of(k));
     const double em = __builtin_fma(s, q, s - 1.0);
     double t = div_em(em, em + 2.0);
-    t = ax < 20.0 ? t : 1.0;
+    t = small ? t : 1.0;
     return x < 0 ? -t : t;
 }
 

@@ -206,6 +206,27 @@ void ude_poison_chip_dbg(hipStream_t st, bool before_forward) {  // (what & 4: a
         hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 160 * 1024, st, pat, 160 * 256, (unsigned*)nullptr);
     }
 }
+// Positive control of the hook (tests/test_gpu_poison.py): fill the chip with one pattern, then let a single wavefront report
+// what two registers it never wrote hold.  A debug library built without the poison kernels -- or a poison launch that does
+// not reach the register file -- fails this instead of silently turning every poison test into a plain re-run.
+__global__ void __launch_bounds__(64) poison_probe_kernel(unsigned* out) {
+    unsigned v, a;
+    asm volatile("v_mov_b32 %0, v200\n\tv_accvgpr_read_b32 %1, a100" : "=v"(v), "=v"(a) : : "v200", "a100");
+    out[threadIdx.x] = v;
+    out[64 + threadIdx.x] = a;
+}
+extern "C" int ude_dbg_poison_selftest(ude_ctx* c, unsigned pat, unsigned* out_host /* 128 */) {
+    if (!c || !out_host) return UDE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 128 * sizeof(unsigned)));
+    hipLaunchKernelGGL(poison_regs_kernel, dim3(2048), dim3(256), 0, c->stream, pat, (unsigned*)nullptr, 0u, 0u, 0u);
+    hipLaunchKernelGGL(poison_probe_kernel, dim3(1), dim3(64), 0, c->stream, d);
+    HIPCHK(c, hipMemcpyAsync(out_host, d, 128 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d));
+    return UDE_OK;
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -29,12 +29,13 @@ def adam(loss_grad, theta, eta=0.1, beta=(0.9, 0.999), maxiters=200, callback=No
     v = xp.zeros_like(theta)
     b1t, b2t = beta
     losses = []
+    last = theta  # the last parameters the objective was evaluated at (also when the callback stops the very first iteration)
     for _ in range(maxiters):
         loss, g = loss_grad(theta)
         losses.append(float(loss))
+        last = theta
         if callback is not None and callback(theta, losses[-1]):
             break
-        last = theta
         m = beta[0] * m + (1 - beta[0]) * g
         v = beta[1] * v + (1 - beta[1]) * g * g
         theta = theta - eta * (m / (1 - b1t)) / (xp.sqrt(v / (1 - b2t)) + eps)
@@ -93,6 +94,7 @@ def bfgs(loss_grad, theta, initial_stepnorm=0.01, maxiters=1000, gtol=1e-8, call
 # ---------------------------------------------------------------------------------------------------------------
 class _HZ:
     delta, sigma, rho, epsilon, gamma, psi3, linesearchmax, alphamax = 0.1, 0.9, 5.0, 1e-6, 0.66, 0.1, 50, float("inf")
+    iterfinitemax = 1074  # LineSearches.jl: ceil(-log2(eps(Float64)-subnormal range)): the bound of both non-finite retry loops
 
 
 def _hz_wolfe(c, phi_c, dphi_c, phi_0, dphi_0, phi_lim):
@@ -115,10 +117,12 @@ def hagerzhang(phidphi, c, phi_0, dphi_0):
 
     phi_c, dphi_c = phidphi(c)
     it = 1
-    while not (np.isfinite(phi_c) and np.isfinite(dphi_c)) and it < 1000:
+    while not (np.isfinite(phi_c) and np.isfinite(dphi_c)) and it < _HZ.iterfinitemax:
         c *= _HZ.psi3
         phi_c, dphi_c = phidphi(c)
         it += 1
+    if not (np.isfinite(phi_c) and np.isfinite(dphi_c)):
+        return 0.0, phi_0  # no finite trial step exists: stay (upstream warns and returns alpha = 0)
     al.append(c); va.append(phi_c); sl.append(dphi_c)
 
     def bisect(ia, ib):
@@ -146,11 +150,16 @@ def hagerzhang(phidphi, c, phi_0, dphi_0):
         return bisect(ia, ic)
 
     def secant(a, b, da, db):
-        return (a * db - b * da) / (db - da)
+        # equal slopes: Julia's float division gives Inf / NaN, which the isfinite(c2) guard of secant2 expects (a Python
+        # ZeroDivisionError here would end the optimisation instead of this one interpolation)
+        den = db - da
+        return (a * db - b * da) / den if den != 0.0 else float("nan")
 
     def secant2(ia, ib):
         a, b = al[ia], al[ib]
         cc = secant(a, b, sl[ia], sl[ib])
+        if not np.isfinite(cc):
+            return False, ia, ib  # flat bracket: nothing to interpolate, the caller bisects / terminates on its width test
         p, d = ev(cc)
         ic = len(al) - 1
         if _hz_wolfe(cc, p, d, phi_0, dphi_0, phi_lim):
@@ -188,7 +197,12 @@ def hagerzhang(phidphi, c, phi_0, dphi_0):
         else:
             c *= _HZ.rho
             phi_c, dphi_c = ev(c)
+            nfin = 0
             while not (np.isfinite(phi_c) and np.isfinite(dphi_c)):
+                nfin += 1
+                if nfin > _HZ.iterfinitemax:  # (upstream: "failed to achieve finite new evaluation point", returns the last good one)
+                    al.pop(); va.pop(); sl.pop()
+                    return al[-1], va[-1]
                 c = (al[-2] + c) / 2 if len(al) > 2 else c * _HZ.psi3
                 al.pop(); va.pop(); sl.pop()
                 phi_c, dphi_c = ev(c)
