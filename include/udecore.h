@@ -51,7 +51,9 @@ enum { UDE_SENSE_INTERPOLATING_ADJOINT = 0, UDE_SENSE_DISCRETE = 1,
         * pass keeps (t, t_end, dt, u) of every accepted step instead of u and all stage derivatives -- 1/(1 + stages) of the dense store
         * (Fisher-KPP 1024 points, Tsit5: 8.2 KB instead of 65.6 KB per step) -- and the adjoint kernel re-runs a step's stages when it
         * enters its interval.  Same operation sequence on the same inputs: every result is bit-identical to mode 0; the price is
-        * 7 right-hand sides per forward interval.  Instances: the Fisher-KPP UDEs with Tsit5 (shared time grid); else UDE_ERR_UNSUPPORTED */
+        * the stages (+ Vern7's six lazy dense-output stages) once more per forward interval.  Every model and both algorithms on a shared
+        * time grid (the lock-step SEIR / neural-ODE kernels hand over to the wavefront-per-trajectory ones), except a distributed state
+        * whose recomputed stage vectors do not fit the registers (1024-point Fisher-KPP with Vern7): UDE_ERR_UNSUPPORTED */
        UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED = 3 };
 enum { UDE_ALG_TSIT5 = 0 /* Tsit5() scenario_1.jl:191 */, UDE_ALG_VERN7 = 1 /* Vern7() scenario_1.jl:84 */ };
 /* per-trajectory return codes mirror the SciML retcodes stored in the reference's artifacts */

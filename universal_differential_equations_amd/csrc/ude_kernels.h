@@ -810,11 +810,14 @@ struct AdjSys {
     static constexpr bool FAST = (VAR == 3);  // UDE_SENSE_FAST: lambda-only error control
     // VAR == 5: InterpolatingAdjoint(checkpointing = true) in its store-u-only form.  The forward store holds (t, t_end, dt, u)
     // per accepted step; entering an interval the kernel re-runs that step's stages from u with the stored dt -- the SAME
-    // operation sequence as Driver::run's perform_step on the same inputs, so the recomputed k are the forward pass's k bit for
-    // bit and every result equals the dense-store mode's.  Distributed-state FSAL systems (Fisher-KPP with Tsit5).
+    // operation sequence as Driver::run's perform_step (and, for Vern7, its six lazy dense-output stages) on the same inputs, so
+    // the recomputed k are the forward pass's k bit for bit and every result equals the dense-store mode's.  Round 3: the
+    // Fisher-KPP UDEs with Tsit5; round 4: every model and both algorithms (replicated states keep the interval in registers
+    // instead of the prefetched LDS row; component-per-lane systems recompute on the replicated point and keep their own
+    // component), except distributed states whose NK stage vectors do not fit the registers (1024-point Fisher-KPP with Vern7).
     static constexpr bool RECOMPUTE = (VAR == 5);
-    static_assert(!RECOMPUTE || (Model::STATE_DISTRIBUTED && Tab::FSAL && Tab::NK == Tab::S && !Model::CPL),
-                  "recompute mode: distributed state, FSAL tableau whose dense output uses the step's own stages");
+    static_assert(!RECOMPUTE || !Model::STATE_DISTRIBUTED || Tab::NK * Model::NS <= 32 || (Tab::FSAL && Tab::NK == Tab::S),
+                  "recompute mode: a distributed state keeps its NK stage vectors in registers");
     static constexpr int NR = Model::NS, NSL = (DEFERRED || VAR == 9) ? 0 : Model::NSL;
     static constexpr bool STATE_DISTRIBUTED = Model::STATE_DISTRIBUTED;
     // LDS-slot models re-evaluate stage 0 every step (its parameter cotangent is folded straight into the shared
@@ -838,7 +841,7 @@ struct AdjSys {
     // cached forward interval: t_start/t_end in registers; u_start and the k's either in registers (IC_LDS = false)
     // or in a group-shared LDS row (IC_LDS: saves 2*NR*(NK+1) VGPRs per lane; reads are broadcasts inside the group)
     // CPL: lane c caches component c only (u_start and the k's of the interval: 1 + NK registers)
-    static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !CPL;
+    static constexpr bool IC_LDS = (G >= 5) && !STATE_DISTRIBUTED && !CPL && !RECOMPUTE;
     static constexpr int IC_FIELDS = NR + Tab::NK * NR;
     static constexpr int IC_NR = (IC_LDS || CPL) ? 1 : NR;
     // KS_STREAM: a distributed state with more than 8 interpolation stages (Fisher-KPP with Vern7: 16 x 4 doubles per lane) does not
@@ -902,18 +905,45 @@ struct AdjSys {
         te = base[(size_t)1 * p->Npad];
         if constexpr (RECOMPUTE) {
             const real dtf = base[(size_t)2 * p->Npad];   // the step size the forward pass used (t_end may be a snapped tstop)
+            const TabDevT<real>* tab = p->tab;
+            if constexpr (CPL) {
+                // component-per-lane: lane c keeps component c of u and of every k; a stage point is formed by that lane
+                // (Driver::run's CPL chain: terms j < s only) and broadcast, the right-hand side runs on the replicated point
+                const bool on = mctx.r < n;
+                us[0] = on ? base[(size_t)(3 + (on ? mctx.r : 0)) * p->Npad] : 0.0;
+                static_for<0, Tab::NK>([&](auto q) { ks[q][0] = 0.0; });
+                static_for<0, Tab::NK>([&](auto sc) {
+                    constexpr int st = decltype(sc)::value;
+                    real zs[NR], kr[NR];
+                    if constexpr (st == 0) {
+                        bcast_all(us[0], zs);
+                    } else {
+                        real acc = tab->A[st][0] * ks[0][0];
+                        static_for<1, st>([&](auto jc) { acc = rfma(tab->A[st][decltype(jc)::value], ks[decltype(jc)::value][0], acc); });
+                        bcast_all(rfma(dtf, acc, us[0]), zs);
+                    }
+                    asm volatile("" ::: "memory");
+                    Model::rhs(mctx, zs, kr);
+                    ks[st][0] = own_of(kr);
+                });
+            } else {
             static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p->Npad] : 0.0; });
             static_for<0, Tab::NK>([&](auto q) { static_for<0, NR>([&](auto c) { ks[q][c] = 0.0; }); });
-            const TabDevT<real>* tab = p->tab;
-            static_for<0, Tab::S>([&](auto sc) {
+            static_for<0, Tab::NK>([&](auto sc) {
                 constexpr int st = decltype(sc)::value;
                 real zs[NR], kr[NR];
                 if constexpr (st == 0) {
                     static_for<0, NR>([&](auto c) { zs[c] = us[c]; });
-                } else {
+                } else if constexpr (st < Tab::S) {
                     static_for<0, NR>([&](auto c) {   // Driver::run: all S - 1 terms, zero coefficients (and zero k) contribute exactly nothing
                         real acc = tab->A[st][0] * ks[0][c];
                         static_for<1, Tab::S - 1>([&](auto jc) { acc = rfma(tab->A[st][decltype(jc)::value], ks[decltype(jc)::value][c], acc); });
+                        zs[c] = rfma(dtf, acc, us[c]);
+                    });
+                } else {
+                    static_for<0, NR>([&](auto c) {   // Driver::run's lazy(): the dense-output stages, terms j < row
+                        real acc = tab->A[st][0] * ks[0][c];
+                        static_for<1, st>([&](auto jc) { acc = rfma(tab->A[st][decltype(jc)::value], ks[decltype(jc)::value][c], acc); });
                         zs[c] = rfma(dtf, acc, us[c]);
                     });
                 }
@@ -921,6 +951,7 @@ struct AdjSys {
                 Model::rhs(mctx, zs, kr);
                 static_for<0, NR>([&](auto c) { ks[st][c] = kr[c]; });
             });
+            }
         } else if constexpr (IC_LDS) {
             // the G lanes of the group fetch the fields round-robin and publish them in the group's LDS row
             asm volatile("" ::: "memory");

@@ -67,7 +67,9 @@ inline Launch make_launch() {
     l.fwd_pt = fwd_kernel<FM, Tab, GF, FB, true>;
     l.adj_pt = adj_kernel<Model, Tab, G, BLOCK, true, VAR>;
     l.adj_fast = adj_kernel<Model, Tab, G, BLOCK, false, 3>;
-    if constexpr (recompute_ok<Model>::v && Tab::FSAL && Tab::NK == Tab::S)
+    // checkpointed adjoint (store u only, recompute the stages): every replicated-state model; distributed states where the NK
+    // recomputed stage vectors fit the registers (AdjSys::RECOMPUTE) -- Model::RECOMPUTE_OK marks the distributed models that have it
+    if constexpr (!Model::STATE_DISTRIBUTED || (recompute_ok<Model>::v && (Tab::NK * Model::NS <= 32 || (Tab::FSAL && Tab::NK == Tab::S))))
         l.adj_ckpt = adj_kernel<Model, Tab, G, BLOCK, false, 5>;
     else l.adj_ckpt = nullptr;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)

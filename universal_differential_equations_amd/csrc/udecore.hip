@@ -789,8 +789,8 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const bool pt = o->per_trajectory != 0;
     if (fast && pt) return fail(c, UDE_ERR_UNSUPPORTED, "UDE_SENSE_INTERPOLATING_ADJOINT_FAST has no per-trajectory time-grid instances");
     if (ckpt && (pt || !l.adj_ckpt))
-        return fail(c, UDE_ERR_UNSUPPORTED, "the checkpointed adjoint (store u only, recompute the stages) exists for the Fisher-KPP UDEs with Tsit5 "
-                                            "on a shared time grid");
+        return fail(c, UDE_ERR_UNSUPPORTED, "the checkpointed adjoint (store u only, recompute the stages) runs on a shared time grid, and for a "
+                                            "distributed state only where its recomputed stage vectors fit the registers (not: 1024-point Fisher-KPP with Vern7)");
     void (*bwd)(const KParams) = discrete ? (pt ? l.dadj_pt : l.dadj) : fast ? l.adj_fast : ckpt ? l.adj_ckpt : (pt ? l.adj_pt : l.adj);
     if (!bwd) return fail(c, UDE_ERR_UNSUPPORTED, "the runtime-shape kernel has no discretise-then-optimise sweep: use the interpolating adjoint");
     void (*kfwd)(const KParams) = pt ? l.fwd_pt : l.fwd;
