@@ -147,13 +147,16 @@ _lib = None
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, os.environ.get("UDE_ORACLE_LIB", "libude_oracle.so")])
 
 
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(ORACLE_DIR, "libude_oracle.so")
+        name = os.environ.get("UDE_ORACLE_LIB", "libude_oracle.so")   # (libude_oracle_asan.so: the sanitizer build, oracle/Makefile `asan`)
+        path = os.path.join(ORACLE_DIR, name)
+        if name != "libude_oracle.so" and not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, name])
         src_newer = (not os.path.exists(path)) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(path)
             for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h")))

@@ -110,10 +110,46 @@ def test_hudson_bay_f32_trained_loss_and_gradient(golden):
     assert du.dtype == f32 and np.array_equal(du, ref_du)
 
 
-def test_f32_descriptor_without_instance_is_refused():
-    f = models.ude_dynamics(dtype="float32")          # scenario_1's rbf chain has no Float32 instance
-    with pytest.raises(U.UdeError, match="no kernel for model"):   # (not a compiled instance; the runtime-shape fallback is Float64 only)
-        U.solve(U.ODEProblem(f, [1.0, 1.0], (0.0, 1.0), np.zeros(87)), U.Tsit5(), saveat=0.5)
+def test_f32_descriptor_outside_the_fallback_is_refused():
+    f = models.nn_ode(26, models.kpp_chain(), dtype="float32")          # Fisher-KPP's tanh chain has no Float32 instance (scenario_3's has)
+    with pytest.raises(U.UdeError, match="no kernel for model"):
+        U.solve(U.ODEProblem(f, models.rho0(26).astype(f32), (0.0, 1.0), np.zeros(f.n_param, dtype=f32)), U.Tsit5(), saveat=0.5)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_f32_lv_kind_any_chain_matches_oracle(golden, seed):
+    """round 4: the runtime-shape kernel in Float32 -- hudson_bay.jl:77-79 is `FastChain(...)`, a script variable, and its problem is
+    Float32 (`:85-104`): any chain of <= 8 Dense layers of width <= 64, interpolating adjoint and the discrete sweep the script requests"""
+    from test_gpu_generic import chain_of, random_chain, theta_for
+    rng = np.random.default_rng(500 + seed)
+    dims, acts = random_chain(rng, 2, 2, max_hidden=4)
+    if seed == 0:
+        dims, acts = [2, 5, 5, 5, 2], ["rbf", "rbf", "rbf", "identity"]   # scenario_1's chain as a Float32 problem (no compiled instance)
+    chain = chain_of(dims, acts)
+    trainable = [None, "both"][seed % 2]
+    f = models.ude_dynamics(chain, trainable=trainable, dtype="float32")
+    om = O.make_model(O.KIND_LV_UDE, 2, dims, acts, nn_offset={None: 0, "both": 2}[trainable], lin_idx={None: (-1, -1), "both": (0, 1)}[trainable],
+                      lin_sign=(1.0, -1.0) if trainable else (1.0, 1.0), lin_const={None: (1.3, -1.8), "both": (0.0, 0.0)}[trainable], dtype=1)
+    th = np.concatenate([[1.3, 1.8] if trainable else [], theta_for(chain, rng, 0.3)]).astype(f32)
+    g = golden(HB)
+    X = np.array(g["X"]["data_colmajor"], dtype=f32).reshape(21, 2)[:13]
+    t = np.linspace(0.0, 3.0, 13).astype(f32)      # (an untrained random chain blows up over the script's 20 years: a short horizon)
+    N = 1 if seed < 3 else 4
+    u0 = (X[0][None, :] * (1 + 0.1 * rng.uniform(-1, 1, (N, 2)))).astype(f32)
+    data = np.repeat(X[None], N, axis=0)
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (float(t[0]), float(t[-1])), th), u0)
+    alg, oalg = (U.Vern7, O.VERN7) if seed % 3 else (U.Tsit5, O.TSIT5)
+    for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1)):
+        r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-5, reltol=1e-5, sensealg=sense)
+        ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-5, 1e-5, sensealg=osense), u0, [t[0], t[-1]], th, t, data, dtype=f32, nthreads=4)
+        what = "%s %s sense %d" % (dims, acts, osense)
+        assert (r.retcode == 0).all() and r.u.dtype == f32, what
+        assert np.array_equal(r.stats, ref["stats"]) and np.array_equal(r.u, ref["u"]) and np.array_equal(r.grad_u0, ref["grad_u0"]), what
+        assert np.array_equal(r.loss_per_traj, ref["loss_per_traj"]), what
+        if N == 1:
+            assert np.array_equal(r.grad_theta, ref["grad_theta"]), what
+        else:
+            assert np.linalg.norm(r.grad_theta.astype(float) - ref["grad_theta"].astype(float)) < 2e-6 * np.linalg.norm(ref["grad_theta"].astype(float)), what
 
 
 def test_device_resident_f32_ensemble_matches_host_buffer_path(golden):

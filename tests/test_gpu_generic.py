@@ -49,7 +49,9 @@ def test_model_supported_reports_fast_instance_or_generic_kernel():
     assert supported(models.dudt_(chain_of([3, 16, 1], ["tanh", "identity"]))) == 1
     assert supported(models.dudt_node(chain_of([7, 32, 32, 7], ["relu", "tanh", "identity"]))) == 1
     assert supported(models.ude_dynamics(chain_of([2, 65, 2], ["tanh", "identity"]))) == -2   # wider than a wavefront: UDE_ERR_UNSUPPORTED
-    assert supported(models.ude_dynamics(chain_of([2, 6, 2], ["tanh", "identity"])), sense=1) == -2   # no discrete sweep for runtime shapes
+    assert supported(models.ude_dynamics(chain_of([2, 6, 2], ["tanh", "identity"])), sense=1) == 1   # round 4: the discrete sweep too
+    assert supported(models.ude_dynamics(chain_of([2, 6, 2], ["tanh", "identity"]), dtype="float32")) == 1   # ... and Float32 LV-kind problems
+    assert supported(models.ude_dynamics(chain_of([2, 6, 2], ["tanh", "identity"])), sense=3) == 1   # ... and the checkpointed adjoint
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -82,6 +84,58 @@ def test_fuzz_lv_kind_random_shapes(golden, seed):
     assert_bitwise(sol.u, out, "forward states")
     r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6)
     ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6), u0, [t[0], t[-1]], th, t, data, nthreads=4)
+    assert (r.retcode == 0).all()
+    check_per_trajectory(r, ref)
+    assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")
+    if N == 1:
+        assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta %s %s" % (dims, acts))
+    else:
+        gn = np.linalg.norm(ref["grad_theta"])
+        assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_discrete_sweep_random_shapes(golden, seed):
+    """round 4: `sensealg = ForwardDiffSensitivity()` -- what scenario_1.jl:86 / scenario_2.jl:108 request -- for ANY chain: the
+    runtime-shape kernel's reverse sweep defers the parameter cotangent (factors of up to 8 VJPs in the stage storage, added to
+    the accumulators in VJP order) and is bit-identical to the oracle's discrete_sweep: VJP count, dL/du0, and for a single
+    trajectory every gradient entry.  LV kind (seeds 0-4) and the SEIR kinds (5-7); Vern7 steps with interior save points
+    exercise the 16-VJP steps (two flushes)."""
+    rng = np.random.default_rng(700 + seed)
+    if seed < 5:
+        dims, acts = random_chain(rng, 2, 2)
+        chain = chain_of(dims, acts)
+        trainable = [None, "delta", "both"][seed % 3]
+        f = models.ude_dynamics(chain, trainable=trainable)
+        om = O.make_model(O.KIND_LV_UDE, 2, dims, acts, nn_offset={None: 0, "delta": 1, "both": 2}[trainable],
+                          lin_idx={None: (-1, -1), "delta": (-1, 0), "both": (0, 1)}[trainable],
+                          lin_sign={None: (1.0, 1.0), "delta": (1.0, -1.0), "both": (1.0, -1.0)}[trainable],
+                          lin_const={None: (1.3, -1.8), "delta": (1.3, 0.0), "both": (0.0, 0.0)}[trainable])
+        th = np.concatenate([{None: [], "delta": [1.8], "both": [1.3, 1.8]}[trainable], theta_for(chain, rng, 0.3)]).astype(np.float64)
+        g = golden("Scenario_1_recovery_0.005")
+        X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+        t = np.array(g["solution"]["t"])
+        N = 1 if seed % 2 == 0 else 5
+        u0 = X[0] * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))
+        data = np.repeat(X[None], N, axis=0)
+        tspan, mask = (t[0], t[-1]), None
+    else:
+        node = seed % 2 == 1
+        dims, acts = random_chain(rng, 7 if node else 3, 7 if node else 1, max_hidden=3, widths=[4, 16, 33, 64])
+        chain = chain_of(dims, acts)
+        f = (models.dudt_node if node else models.dudt_)(chain)
+        om = O.make_model(O.KIND_SEIR_NODE if node else O.KIND_SEIR_UDE, 7, dims, acts, consts=O.SEIR_P)
+        th = theta_for(chain, rng, 0.5)
+        N = 1 if seed < 7 else 3
+        u0 = np.zeros((N, 7)); u0[:, 0] = rng.uniform(0.8, 0.95, N) * 100.0; u0[:, 1] = rng.uniform(0.5, 2.0, N); u0[:, 2] = rng.uniform(0.2, 1.0, N); u0[:, 4] = 100.0
+        t = np.arange(0.0, 4.5, 1.0)
+        data, _, _ = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 4.0], [], t)
+        tspan, mask = (0.0, 4.0), [0, 1, 1, 1, 0, 0, 0]
+    alg, oalg = (U.Vern7, O.VERN7) if seed % 2 else (U.Tsit5, O.TSIT5)
+    assert supported(f, sense=1) == 1
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], tspan, th), u0)
+    r = U.loss_and_gradient(ens, alg(), data, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=U.ForwardDiffSensitivity())
+    ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6, sensealg=1), u0, list(tspan), th, t, data, row_mask=mask, nthreads=4)
     assert (r.retcode == 0).all()
     check_per_trajectory(r, ref)
     assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss")

@@ -1031,9 +1031,9 @@ struct AdjSys {
             if (Tab::B(s) != 0.0 || Tab::BT(s) != 0.0) m |= 1u << s;
         return m;
     }
-    __device__ __forceinline__ real slot_step(real dt, const TabDev* tab, const OptsR& o) {
+    __device__ __forceinline__ acc_t slot_step(real dt, const TabDev* tab, const OptsR& o) {
         if constexpr (DEFERRED)
-            return Model::template step_slots<Tab::S, stage_mask()>(mctx, tab->B, tab->BT, dt, o.abstol, o.reltol, mu_cur, mu_new, ms);
+            return (acc_t)Model::template step_slots<Tab::S, stage_mask()>(mctx, tab->B, tab->BT, dt, o.abstol, o.reltol, mu_cur, mu_new, ms);
         else return 0.0;
     }
     // fast mode: mu += dt * sum_s B_s g_s for every slot, in place, on ACCEPTED steps only
@@ -1096,6 +1096,9 @@ struct AdjSys {
     }
 };
 
+// models whose discrete sweep defers the parameter cotangent (Model::DADJ_DEFERRED: the runtime-shape model -- hundreds of slots per lane)
+template <class M, class = void> struct dadj_deferred { static constexpr bool v = false; };
+template <class M> struct dadj_deferred<M, std::void_t<decltype(M::DADJ_DEFERRED)>> { static constexpr bool v = M::DADJ_DEFERRED; };
 template <class M, class = void> struct model_gfac { static constexpr int v = 0; };
 template <class M> struct model_gfac<M, std::void_t<decltype(M::GFAC)>> { static constexpr int v = M::GFAC; };
 
@@ -1285,8 +1288,15 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     const int np_pad = L::np_pad(p.n_param);
     Model::stage_theta(th, p.theta, p.n_param, threadIdx.x, BLOCK);
     constexpr bool SG = Model::SLOTS_GLOBAL;
+    constexpr bool DDEF = dadj_deferred<Model>::v;  // accumulators in this thread's HBM column, factors of the VJPs in the stage storage
     real* acc_lds = slots + threadIdx.x;  // register-slot models: accumulator row, element c at acc_lds[c*BLOCK]
     if constexpr (!SG) static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = 0.0; });
+    const int MSG = (int)(gridDim.x * BLOCK);
+    [[maybe_unused]] real* accg = DDEF ? p.slot_glob + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;  // element c at accg[c * MSG]
+    if constexpr (DDEF) {
+#pragma unroll 4
+        for (int c = 0; c < NSL; ++c) accg[(size_t)c * MSG] = 0.0;
+    }
     __syncthreads();
 
     const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
@@ -1326,15 +1336,24 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         auto COT = [&](int i, int c) { return cot[(size_t)i * cot_si + (size_t)comp(c) * cot_sc]; };
         const int nsteps = p.dense_n[gid];
         const int nf = 3 + n + NK * n;
-        real ubar[NR], un[NR], carry[NR], acc[NSLA];
+        real ubar[NR], un[NR], carry[NR], acc[DDEF ? 1 : NSLA];
         static_for<0, NR>([&](auto c) { ubar[c] = 0.0; carry[c] = 0.0; });
-        static_for<0, NSL>([&](auto c) { acc[c] = 0.0; });
+        if constexpr (!DDEF) static_for<0, NSL>([&](auto c) { acc[c] = 0.0; });
+        [[maybe_unused]] int nst = 0;  // DDEF: VJPs whose factors wait in the stage storage
         int si = p.ns - 1;
         int64_t nvjp = 0;
         // one VJP at stage input g with stage cotangent kbrow: w = (df/du)^T kbrow; parameter part into acc
         auto stage_vjp = [&](const real* g, const real* kbrow, real* w) {
             asm volatile("" ::: "memory");
-            if constexpr (Model::FUSED_ACC) {
+            if constexpr (DDEF) {
+                if (nst == Model::NSTC) {  // (wave-uniform) the stage storage is full: add its VJPs to the accumulators, in order
+                    Model::dadj_flush(mctx, nst, accg, MSG);
+                    nst = 0;
+                    asm volatile("" ::: "memory");
+                }
+                Model::vjp_store(mctx, g, kbrow, w, nst);
+                nst += 1;
+            } else if constexpr (Model::FUSED_ACC) {
                 Model::template vjp_acc<false>(mctx, g, kbrow, w, acc, acc, real(-1), real(0));  // acc += (df/dtheta)^T kbar
             } else {
                 real gs[NSLA];
@@ -1444,7 +1463,16 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         if (r == 0 && p.stats) p.stats[(size_t)gid * 8 + 4] = nvjp;
         if (p.grad_u0)
             static_for<0, NR>([&](auto c) { if (cwrite(c)) p.grad_u0[(size_t)gid * n + comp(c)] = ubar[c]; });
-        if constexpr (SG) {
+        if constexpr (DDEF) {
+            asm volatile("" ::: "memory");
+            Model::dadj_flush(mctx, nst, accg, MSG);
+            real* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
+#pragma unroll 2
+            for (int c = 0; c < NSL; ++c) {
+                const int idx = Model::slot_index(p.mc, r, c);
+                if (idx >= 0) row[idx] = accg[(size_t)c * MSG];
+            }
+        } else if constexpr (SG) {
             real* row = p.grad_part + (size_t)part_row<G, BLOCK>() * p.n_param;
             static_for<0, NSL>([&](auto c) {
                 const int idx = Model::slot_index(p.mc, r, c);

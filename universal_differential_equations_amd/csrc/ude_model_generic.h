@@ -1,4 +1,4 @@
-// ude_model_generic.h -- the runtime-shape fallback (included by ude_models.h, Float64 translation units only).
+// ude_model_generic.h -- the runtime-shape fallback (included by ude_models.h; Float64 and, for the LV kind, Float32 translation units).
 //
 // The reference's networks are script variables: `U = Lux.Chain(Dense(2,5,rbf), ...)` (LotkaVolterra/scenario_1.jl:62-64),
 // `ann = FastChain(FastDense(3,64,tanh), ...)` (SEIR_exposure/seir_exposure.jl:114), `n_weights` of
@@ -34,7 +34,10 @@ struct GenericUde {
     static constexpr bool STATE_DISTRIBUTED = false;
     static constexpr bool THETA_GLOBAL = true, FUSED_ACC = true, SLOTS_GLOBAL = true, CPL = true, DEFERRED = true;
     static constexpr bool DADJ_K_FROM_DENSE = false, COMPACT_STAGES = true;
-    static constexpr bool NO_DADJ = true;          // no discretise-then-optimise sweep for runtime shapes (the host reports UNSUPPORTED)
+    // discretise-then-optimise sweep (round 4): the reverse sweep's VJPs leave their factors in the stage storage like the adjoint's
+    // evaluations do, and dadj_flush adds them to the accumulators (HBM column) in VJP order -- `acc += delta * a`, the oracle's
+    // discrete_sweep sequence -- whenever the NSTC stage slots are full and at the end of the sweep
+    static constexpr bool DADJ_DEFERRED = true;
     static constexpr int NSTG = 10, NSTC = 8;      // tableau stages, stored (compacted) stages
     static constexpr int RX = 16;                  // short row per stage: x_0..x_6 (the network input) | u0 u1 lam0 lam1 (LV diagonal slots)
     static constexpr int STG = 2 * LMAX * H + RX;  // doubles of one stored stage: A rows (a_0 .. a_{L-1}), delta rows (delta_1 .. delta_L), short row
@@ -42,21 +45,21 @@ struct GenericUde {
     static constexpr int SCRATCH = NSTC * STG + WORK;
     static constexpr int SCRATCH_FWD = WORK;
     static constexpr int FWD_BLOCKS = 2;           // forward / rhs kernels compiled for two wavefronts per SIMD (256 registers; their LDS share is WORK only)
-    typedef __attribute__((address_space(3))) double lds_t;
+    typedef __attribute__((address_space(3))) real lds_t;
     struct Ctx {
-        const double* nn;     // theta + nn_offset (HBM)
+        const real* nn;     // theta + nn_offset (HBM)
         lds_t* work;          // a rows [l * H + lane], then dphi rows
         lds_t* fac;           // stage storage of this wavefront
         const ModelConsts* mc;  // dims / act of the chain: kernel arguments, read with wave-uniform indices (scalar loads)
         int L, kind, nnp;       // layers, kind, number of NN parameters
-        double lin[2], lin_on[2];
-        double mu_c, sg, F, b0, ga, dd, la;   // SEIR constants
+        real lin[2], lin_on[2];
+        real mu_c, sg, F, b0, ga, dd, la;   // SEIR constants
         int j, r;
     };
     static __host__ __device__ constexpr int theta_lds(int) { return 0; }
-    static __device__ __forceinline__ void stage_theta(double*, const double*, int, int, int) {}
-    static __device__ __forceinline__ void init(Ctx& c, double* theta, double* scratch, double*, int, const ModelConsts& mc, int r,
-                                                const double* theta_g) {
+    static __device__ __forceinline__ void stage_theta(real*, const real*, int, int, int) {}
+    static __device__ __forceinline__ void init(Ctx& c, real* theta, real* scratch, real*, int, const ModelConsts& mc, int r,
+                                                const real* theta_g) {
         (void)theta;
         c.j = r & 63; c.r = r;
         c.nn = theta_g + mc.nn_offset;
@@ -68,126 +71,126 @@ struct GenericUde {
         for (int l = 0; l < mc.n_layers; ++l) o += mc.dims[l] * mc.dims[l + 1] + mc.dims[l + 1];
         c.nnp = o;
         for (int i = 0; i < 2; ++i) {
-            c.lin[i] = mc.lin_idx[i] >= 0 ? mc.lin_sign[i] * theta_g[mc.lin_idx[i]] : mc.lin_const[i];
-            c.lin_on[i] = (mc.lin_idx[i] >= 0 && r == 0) ? mc.lin_sign[i] : 0.0;
+            c.lin[i] = mc.lin_idx[i] >= 0 ? (real)mc.lin_sign[i] * theta_g[mc.lin_idx[i]] : (real)mc.lin_const[i];
+            c.lin_on[i] = (mc.lin_idx[i] >= 0 && r == 0) ? mc.lin_sign[i] : real(0);
         }
-        c.F = mc.consts[0]; c.b0 = mc.consts[1]; c.mu_c = mc.consts[4]; c.sg = mc.consts[5]; c.ga = mc.consts[6]; c.dd = mc.consts[7];
-        c.la = mc.consts[8];
+        c.F = (real)mc.consts[0]; c.b0 = (real)mc.consts[1]; c.mu_c = (real)mc.consts[4]; c.sg = (real)mc.consts[5]; c.ga = (real)mc.consts[6];
+        c.dd = (real)mc.consts[7]; c.la = (real)mc.consts[8];
     }
-    static __device__ __forceinline__ double actf(int a, double z) {
-        return a == ACT_TANH ? dtanh(z) : a == ACT_RBF ? dexp(-(z * z)) : a == ACT_RELU ? (z > 0.0 ? z : 0.0) : z;
+    static __device__ __forceinline__ real actf(int a, real z) {
+        return a == ACT_TANH ? rtanh(z) : a == ACT_RBF ? rexp(-(z * z)) : a == ACT_RELU ? (z > real(0) ? z : real(0)) : z;
     }
-    static __device__ __forceinline__ double dactf(int a, double z, double av) {
-        return a == ACT_TANH ? __builtin_fma(-av, av, 1.0) : a == ACT_RBF ? (-2.0 * z) * av : a == ACT_RELU ? (z > 0.0 ? 1.0 : 0.0) : 1.0;
+    static __device__ __forceinline__ real dactf(int a, real z, real av) {
+        return a == ACT_TANH ? rfma(-av, av, real(1)) : a == ACT_RBF ? (real(-2) * z) * av : a == ACT_RELU ? (z > real(0) ? real(1) : real(0)) : real(1);
     }
     // ---- wide_dot (oracle): result r of `nres` results over n terms; term i = w[i * ws] * x_i ----
     // x lives in an LDS row (lane i wrote x_i); lane j owns result j.  wbase(j): address of the lane's term 0, ws: term stride.
-    static __device__ __forceinline__ double dot_lane(const double* w, int ws, const lds_t* x, int n) {
+    static __device__ __forceinline__ real dot_lane(const real* w, int ws, const lds_t* x, int n) {
         if (n < 64) {  // one chain from 0, ascending
-            double acc = 0.0;
+            real acc = real(0);
 #pragma unroll 4
-            for (int i = 0; i < n; ++i) acc = __builtin_fma(w[(size_t)i * ws], x[i], acc);
+            for (int i = 0; i < n; ++i) acc = rfma(w[(size_t)i * ws], x[i], acc);
             return acc;
         }
-        double tot = 0.0;  // 64 terms: four 16-term chains, block sums left to right
+        real tot = real(0);  // 64 terms: four 16-term chains, block sums left to right
 #pragma unroll 1
         for (int b = 0; b < 64; b += 16) {
-            double acc = 0.0;
+            real acc = real(0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc = __builtin_fma(w[(size_t)(b + i) * ws], x[b + i], acc);
+            for (int i = 0; i < 16; ++i) acc = rfma(w[(size_t)(b + i) * ws], x[b + i], acc);
             tot = b == 0 ? acc : tot + acc;
         }
         return tot;
     }
     // forward chain: x on lanes 0..dims[0]-1 (others 0).  A rows go to `arow` (row l at arow[l * H]), dphi rows to c.work.
     // Returns this lane's a_L (valid on lanes < dims[L]).
-    static __device__ __forceinline__ double forward(const Ctx& c, double xlane, lds_t* arow, bool want_dphi) {
+    static __device__ __forceinline__ real forward(const Ctx& c, real xlane, lds_t* arow, bool want_dphi) {
         const int j = c.j;
         lds_t* dphi = c.work + (LMAX + 1) * H;
-        double a = xlane;
+        real a = xlane;
         arow[j] = a;
         int off = 0;
 #pragma unroll 1
         for (int l = 0; l < c.L; ++l) {
             const int in = c.mc->dims[l], out = c.mc->dims[l + 1], actl = c.mc->act[l];
-            const double* W = c.nn + off;
+            const real* W = c.nn + off;
             off += in * out + out;
             const int jj = j < out ? j : out - 1;   // (lanes beyond the layer compute a discarded copy of the last neuron: in-bounds reads)
             const lds_t* x = arow + l * H;
-            double z;
+            real z;
             if (in == 64 && out < 64) {
                 // 64 terms, fewer than 64 results: rounded products, adjacent-pair tree over the wavefront (lane i = term i)
-                z = 0.0;
+                z = real(0);
 #pragma unroll 1
                 for (int rr = 0; rr < out; ++rr) {
-                    const double s = wave_tree_sum(W[rr + (size_t)j * out] * a);
+                    const real s = wave_tree_sum(W[rr + (size_t)j * out] * a);
                     z = (j == rr) ? s : z;
                 }
             } else {
                 z = dot_lane(W + jj, out, x, in);
             }
             z += W[(size_t)in * out + jj];
-            const double av = actf(actl, z);
-            a = j < out ? av : 0.0;
+            const real av = actf(actl, z);
+            a = j < out ? av : real(0);
             // the next layer's input row: row l + 1 of the same storage, except that a_L (never a factor) goes to the spare row
             lds_t* nxt = (l + 1 < c.L) ? arow + (l + 1) * H : c.work + LMAX * H;
             nxt[j] = a;
-            if (want_dphi) dphi[l * H + j] = j < out ? dactf(actl, z, av) : 0.0;
+            if (want_dphi) dphi[l * H + j] = j < out ? dactf(actl, z, av) : real(0);
         }
         return a;
     }
     // reverse chain: gy on lanes 0..dims[L]-1; delta rows to `drow` (row l = delta of layer l's OUTPUT); returns this lane's input cotangent
-    static __device__ __forceinline__ double backward(const Ctx& c, double gylane, lds_t* drow) {
+    static __device__ __forceinline__ real backward(const Ctx& c, real gylane, lds_t* drow) {
         const int j = c.j;
         const lds_t* dphi = c.work + (LMAX + 1) * H;
-        double delta = gylane;
+        real delta = gylane;
         int off = c.nnp;
 #pragma unroll 1
         for (int l = c.L - 1; l >= 0; --l) {
             const int in = c.mc->dims[l], out = c.mc->dims[l + 1];
             off -= in * out + out;
-            const double* W = c.nn + off;
+            const real* W = c.nn + off;
             delta = delta * dphi[l * H + j];
-            delta = j < out ? delta : 0.0;
+            delta = j < out ? delta : real(0);
             drow[l * H + j] = delta;
-            double prev;
+            real prev;
             if (out == 64 && in < 64) {
-                prev = 0.0;
+                prev = real(0);
 #pragma unroll 1
                 for (int k = 0; k < in; ++k) {
-                    const double s = wave_tree_sum(W[j + (size_t)k * 64] * delta);
+                    const real s = wave_tree_sum(W[j + (size_t)k * 64] * delta);
                     prev = (j == k) ? s : prev;
                 }
             } else {
                 const int kk = j < in ? j : in - 1;
                 prev = dot_lane(W + (size_t)kk * out, 1, drow + l * H, out);
             }
-            delta = j < in ? prev : 0.0;
+            delta = j < in ? prev : real(0);
         }
         return delta;
     }
     // ---- kind wiring (oracle: udeo_rhs / udeo_rhs_vjp) ----
-    static __device__ __forceinline__ double input_lane(const Ctx& c, const double* u) {
+    static __device__ __forceinline__ real input_lane(const Ctx& c, const real* u) {
         const int j = c.j;
-        double x = 0.0;
+        real x = real(0);
         if (c.kind == GK_LV_UDE) {
-            x = j == 0 ? u[0] : j == 1 ? u[1 % NS] : 0.0;
+            x = j == 0 ? u[0] : j == 1 ? u[1 % NS] : real(0);
         } else if (c.kind == GK_SEIR_UDE) {
-            if constexpr (NS == 7) x = j == 0 ? u[0] / u[4] : j == 1 ? u[2] : j == 2 ? u[5] / u[4] : 0.0;
+            if constexpr (NS == 7) x = j == 0 ? u[0] / u[4] : j == 1 ? u[2] : j == 2 ? u[5] / u[4] : real(0);
         } else {
             if constexpr (NS == 7)
-                x = j == 0 ? u[0] / u[4] : j == 1 ? u[1] : j == 2 ? u[2] : j == 3 ? u[3] : j == 4 ? u[4] : j == 5 ? u[5] / u[4] : j == 6 ? u[6] : 0.0;
+                x = j == 0 ? u[0] / u[4] : j == 1 ? u[1] : j == 2 ? u[2] : j == 3 ? u[3] : j == 4 ? u[4] : j == 5 ? u[5] / u[4] : j == 6 ? u[6] : real(0);
         }
         return x;
     }
-    static __device__ __forceinline__ void rhs_from(const Ctx& c, const double* u, double aL, double* du) {
+    static __device__ __forceinline__ void rhs_from(const Ctx& c, const real* u, real aL, real* du) {
         if (c.kind == GK_LV_UDE) {
-            du[0] = __builtin_fma(c.lin[0], u[0], readlane_real(aL, 0));
-            du[1 % NS] = __builtin_fma(c.lin[1], u[1 % NS], readlane_real(aL, 1));
+            du[0] = rfma(c.lin[0], u[0], readlane_real(aL, 0));
+            du[1 % NS] = rfma(c.lin[1], u[1 % NS], readlane_real(aL, 1));
         } else if constexpr (NS == 7) {
-            const double S = u[0], E = u[1], I = u[2], Rr = u[3], N = u[4], D = u[5];
+            const real S = u[0], E = u[1], I = u[2], Rr = u[3], N = u[4], D = u[5];
             if (c.kind == GK_SEIR_UDE) {
-                const double z = readlane_real(aL, 0);
+                const real z = readlane_real(aL, 0);
                 du[0] = -c.b0 * S * c.F / N - z - c.mu_c * S;
                 du[1] = c.b0 * S * c.F / N + z - (c.sg + c.mu_c) * E;
                 du[2] = c.sg * E - (c.ga + c.mu_c) * I;
@@ -203,48 +206,48 @@ struct GenericUde {
             }
         }
     }
-    static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
-        const double aL = forward(c, input_lane(c, u), c.work, false);
+    static __device__ __forceinline__ void rhs(const Ctx& c, const real* u, real* du) {
+        const real aL = forward(c, input_lane(c, u), c.work, false);
         rhs_from(c, u, aL, du);
     }
     // reverse sweep of one evaluation: factors into stage slot q (A rows, delta rows, short row), state cotangent out
-    static __device__ __forceinline__ void sweep(const Ctx& c, const double* u, const double* lam, double* dlam, int q) {
+    static __device__ __forceinline__ void sweep(const Ctx& c, const real* u, const real* lam, real* dlam, int q) {
         const int j = c.j;
         lds_t* st = c.fac + q * STG;
-        const double xl = input_lane(c, u);
+        const real xl = input_lane(c, u);
         forward(c, xl, st, true);
-        double gy = 0.0;
-        if (c.kind == GK_LV_UDE) gy = j == 0 ? lam[0] : j == 1 ? lam[1 % NS] : 0.0;
+        real gy = real(0);
+        if (c.kind == GK_LV_UDE) gy = j == 0 ? lam[0] : j == 1 ? lam[1 % NS] : real(0);
         else if constexpr (NS == 7) {
-            if (c.kind == GK_SEIR_UDE) gy = j == 0 ? lam[1] - lam[0] : 0.0;
-            else gy = j == 0 ? lam[0] : j == 1 ? lam[1] : j == 2 ? lam[2] : j == 3 ? lam[3] : j == 4 ? lam[5] : 0.0;
+            if (c.kind == GK_SEIR_UDE) gy = j == 0 ? lam[1] - lam[0] : real(0);
+            else gy = j == 0 ? lam[0] : j == 1 ? lam[1] : j == 2 ? lam[2] : j == 3 ? lam[3] : j == 4 ? lam[5] : real(0);
         }
-        const double gxl = backward(c, gy, st + LMAX * H);
+        const real gxl = backward(c, gy, st + LMAX * H);
         // short row: the network input x_0..x_6 is row 0 of the A rows already; the LV diagonal slots need u and lambda
-        double sh = 0.0;
-        if (c.kind == GK_LV_UDE) sh = j == 0 ? u[0] : j == 1 ? u[1 % NS] : j == 2 ? lam[0] : j == 3 ? lam[1 % NS] : 0.0;
+        real sh = real(0);
+        if (c.kind == GK_LV_UDE) sh = j == 0 ? u[0] : j == 1 ? u[1 % NS] : j == 2 ? lam[0] : j == 3 ? lam[1 % NS] : real(0);
         st[2 * LMAX * H + (j < RX ? j : RX - 1)] = sh;
         if (c.kind == GK_LV_UDE) {
-            dlam[0] = __builtin_fma(c.lin[0], lam[0], readlane_real(gxl, 0));
-            dlam[1 % NS] = __builtin_fma(c.lin[1], lam[1 % NS], readlane_real(gxl, 1));
+            dlam[0] = rfma(c.lin[0], lam[0], readlane_real(gxl, 0));
+            dlam[1 % NS] = rfma(c.lin[1], lam[1 % NS], readlane_real(gxl, 1));
         } else if constexpr (NS == 7) {
-            const double S = u[0], N = u[4], D = u[5];
+            const real S = u[0], N = u[4], D = u[5];
             if (c.kind == GK_SEIR_UDE) {
-                const double g0 = readlane_real(gxl, 0), g1 = readlane_real(gxl, 1), g2 = readlane_real(gxl, 2);
-                const double cc = c.b0 * c.F / N;
-                const double cN = c.b0 * S * c.F / (N * N);
+                const real g0 = readlane_real(gxl, 0), g1 = readlane_real(gxl, 1), g2 = readlane_real(gxl, 2);
+                const real cc = c.b0 * c.F / N;
+                const real cN = c.b0 * S * c.F / (N * N);
                 dlam[0] = (-cc - c.mu_c) * lam[0] + cc * lam[1] + g0 / N;
                 dlam[1] = -(c.sg + c.mu_c) * lam[1] + c.sg * lam[2] + c.sg * lam[6];
                 dlam[2] = -(c.ga + c.mu_c) * lam[2] + c.ga * lam[3] + c.dd * c.ga * lam[5] + g1;
                 dlam[3] = -c.mu_c * lam[3];
                 dlam[4] = cN * lam[0] - cN * lam[1] - c.mu_c * lam[4] - g0 * S / (N * N) - g2 * D / (N * N);
                 dlam[5] = -c.la * lam[5] + g2 / N;
-                dlam[6] = 0.0;
+                dlam[6] = real(0);
             } else {
-                double gx[7];
+                real gx[7];
                 static_for<0, 7>([&](auto m) { gx[m] = readlane_real(gxl, decltype(m)::value); });
                 dlam[0] = gx[0] / N;
-                dlam[1] = __builtin_fma(c.sg, lam[6], gx[1]);
+                dlam[1] = rfma(c.sg, lam[6], gx[1]);
                 dlam[2] = gx[2];
                 dlam[3] = gx[3];
                 dlam[4] = ((gx[4] - gx[0] * S / (N * N)) - gx[5] * D / (N * N)) - c.mu_c * lam[4];
@@ -254,13 +257,13 @@ struct GenericUde {
         }
     }
     template <bool WANT_PARAM>
-    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam, double*) {
+    static __device__ __forceinline__ void vjp(const Ctx& c, const real* u, const real* lam, real* dlam, real*) {
         static_assert(!WANT_PARAM, "deferred parameter cotangent only");
         sweep(c, u, lam, dlam, 0);
     }
     template <bool WANT_E>
-    static __device__ __forceinline__ void vjp_acc(const Ctx&, const double*, const double*, double*, double*, double*, double, double) {}
-    static __device__ __forceinline__ void vjp_store(const Ctx& c, const double* u, const double* lam, double* dlam, int s) {
+    static __device__ __forceinline__ void vjp_acc(const Ctx&, const real*, const real*, real*, real*, real*, real, real) {}
+    static __device__ __forceinline__ void vjp_store(const Ctx& c, const real* u, const real* lam, real* dlam, int s) {
         sweep(c, u, lam, dlam, s);
     }
     template <unsigned MASK>
@@ -272,24 +275,24 @@ struct GenericUde {
     // every slot of this lane in slot order: body(slot, g[NST], m0) with g_s = the NEGATED cotangent of stage s, m0 = mu[slot].
     // Lanes beyond a layer's width own nothing there: their factors are stored as zeros, every one of their sums is an exact 0.
     template <int NST, unsigned MASK, class Body>
-    static __device__ __forceinline__ void for_each_slot(const Ctx& c, const double* mu, int ms, Body body) {
+    static __device__ __forceinline__ void for_each_slot(const Ctx& c, const real* mu, int ms, Body body) {
         const int j = c.j;
         int sb = 0;
 #pragma unroll 1
         for (int l = 0; l < c.L; ++l) {
             const int in = c.mc->dims[l];
-            double d[NST];  // this lane's delta of layer l at every stored stage
+            real d[NST];  // this lane's delta of layer l at every stored stage
             static_for<0, NST>([&](auto s) {
                 if constexpr ((MASK >> decltype(s)::value) & 1u) d[s] = c.fac[slot_of<MASK>(decltype(s)::value) * STG + (LMAX + l) * H + j];
             });
-            double m0 = mu[(size_t)sb * ms];
+            real m0 = mu[(size_t)sb * ms];
 #pragma unroll 1
             for (int k = 0; k <= in; ++k) {   // k == in: the bias
-                const double mnext = mu[(size_t)(sb + (k < in ? k + 1 : 0)) * ms];  // (one slot ahead; the wrap-around read is discarded)
-                double g[NST];
+                const real mnext = mu[(size_t)(sb + (k < in ? k + 1 : 0)) * ms];  // (one slot ahead; the wrap-around read is discarded)
+                real g[NST];
                 static_for<0, NST>([&](auto s) {
                     if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                        const double a = k < in ? (double)c.fac[slot_of<MASK>(decltype(s)::value) * STG + l * H + k] : 1.0;
+                        const real a = k < in ? c.fac[slot_of<MASK>(decltype(s)::value) * STG + l * H + k] : real(1);
                         g[s] = k < in ? -(d[s] * a) : -d[s];
                     }
                 });
@@ -301,7 +304,7 @@ struct GenericUde {
         if (c.kind == GK_LV_UDE) {  // the two trainable diagonal coefficients (lane 0): g = -((sign u_i) lam_i)
             static_for<0, 2>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                double g[NST];
+                real g[NST];
                 static_for<0, NST>([&](auto s) {
                     if constexpr ((MASK >> decltype(s)::value) & 1u) {
                         const lds_t* p = c.fac + slot_of<MASK>(decltype(s)::value) * STG + 2 * LMAX * H;
@@ -313,55 +316,89 @@ struct GenericUde {
         }
     }
     template <int NST, unsigned MASK>
-    static __device__ __forceinline__ double step_slots(const Ctx& c, const double* B, const double* BT, double dt, double abstol,
-                                                        double reltol, const double* mu, double* mu_new, int ms) {
+    static __device__ __forceinline__ acc_t step_slots(const Ctx& c, const real* B, const real* BT, real dt, real abstol,
+                                                       real reltol, const real* mu, real* mu_new, int ms) {
         static_assert(MASK & 1u, "the first stage starts the chains");
-        double bb[NST], bt[NST];
+        real bb[NST], bt[NST];
         static_for<0, NST>([&](auto s) { bb[s] = uniform_real(B[s]); bt[s] = uniform_real(BT[s]); });
-        double ps = 0.0;
-        for_each_slot<NST, MASK>(c, mu, ms, [&](int slot, const double* g, double m0) {
-            double ab = bb[0] * g[0], ae = bt[0] * g[0];
+        acc_t ps = 0.0;
+        for_each_slot<NST, MASK>(c, mu, ms, [&](int slot, const real* g, real m0) {
+            real ab = bb[0] * g[0], ae = bt[0] * g[0];
             static_for<1, NST>([&](auto s) {
                 if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                    ab = __builtin_fma(bb[s], g[s], ab);
-                    ae = __builtin_fma(bt[s], g[s], ae);
+                    ab = rfma(bb[s], g[s], ab);
+                    ae = rfma(bt[s], g[s], ae);
                 }
             });
-            const double m1 = __builtin_fma(dt, ab, m0);
+            const real m1 = rfma(dt, ab, m0);
             mu_new[(size_t)slot * ms] = m1;
-            const double a0 = fabs(m0), a1 = fabs(m1);
-            const double res = (dt * ae) / __builtin_fma((a0 > a1 ? a0 : a1), reltol, abstol);
-            ps = __builtin_fma(res, res, ps);
+            const real a0 = rabs(m0), a1 = rabs(m1);
+            const real res = (dt * ae) / rfma((a0 > a1 ? a0 : a1), reltol, abstol);
+            ps = afma(res, res, ps);
         });
         return ps;
     }
     template <int NST, unsigned MASK>
-    static __device__ __forceinline__ void commit_slots(const Ctx& c, const double* B, double dt, double* mu, int ms) {
+    static __device__ __forceinline__ void commit_slots(const Ctx& c, const real* B, real dt, real* mu, int ms) {
         static_assert(MASK & 1u, "the first stage starts the chains");
-        double bb[NST];
+        real bb[NST];
         static_for<0, NST>([&](auto s) { bb[s] = uniform_real(B[s]); });
-        for_each_slot<NST, MASK>(c, mu, ms, [&](int slot, const double* g, double m0) {
-            double ab = bb[0] * g[0];
+        for_each_slot<NST, MASK>(c, mu, ms, [&](int slot, const real* g, real m0) {
+            real ab = bb[0] * g[0];
             static_for<1, NST>([&](auto s) {
-                if constexpr ((MASK >> decltype(s)::value) & 1u) ab = __builtin_fma(bb[s], g[s], ab);
+                if constexpr ((MASK >> decltype(s)::value) & 1u) ab = rfma(bb[s], g[s], ab);
             });
-            mu[(size_t)slot * ms] = __builtin_fma(dt, ab, m0);
+            mu[(size_t)slot * ms] = rfma(dt, ab, m0);
         });
     }
-    static __device__ __forceinline__ void init_norm01(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
-                                                       double& h0, double& l0, double& h1, double& l1) {
-        for_each_slot<1, 1u>(c, mu, ms, [&](int, const double* g, double m) {
-            const double sk = __builtin_fma(fabs(m), reltol, abstol);
-            const double q0 = m / sk, q1 = g[0] / sk;
+    // discrete sweep: add the `cnt` stored VJPs (stage slots 0 .. cnt-1, in that order) to this lane's accumulators: acc += delta_s * a_s
+    static __device__ __forceinline__ void dadj_flush(const Ctx& c, int cnt, real* acc, int ms) {
+        const int j = c.j;
+        int sb = 0;
+#pragma unroll 1
+        for (int l = 0; l < c.L; ++l) {
+            const int in = c.mc->dims[l];
+            real d[NSTC];
+            static_for<0, NSTC>([&](auto s) { d[s] = c.fac[decltype(s)::value * STG + (LMAX + l) * H + j]; });
+#pragma unroll 1
+            for (int k = 0; k <= in; ++k) {   // k == in: the bias
+                real m = acc[(size_t)(sb + k) * ms];
+                static_for<0, NSTC>([&](auto s) {
+                    const real a = k < in ? c.fac[decltype(s)::value * STG + l * H + k] : real(1);
+                    const real g = k < in ? d[s] * a : d[s];
+                    m = (int)decltype(s)::value < cnt ? m + g : m;
+                });
+                acc[(size_t)(sb + k) * ms] = m;
+            }
+            sb += in + 1;
+        }
+        if (c.kind == GK_LV_UDE) {
+            static_for<0, 2>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                real m = acc[(size_t)(NSLW + i) * ms];
+                static_for<0, NSTC>([&](auto s) {
+                    const lds_t* p = c.fac + decltype(s)::value * STG + 2 * LMAX * H;
+                    const real g = (c.lin_on[i] * p[i]) * p[2 + i];
+                    m = (int)decltype(s)::value < cnt ? m + g : m;
+                });
+                acc[(size_t)(NSLW + i) * ms] = m;
+            });
+        }
+    }
+    static __device__ __forceinline__ void init_norm01(const Ctx& c, real abstol, real reltol, const real* mu, int ms,
+                                                       real& h0, real& l0, real& h1, real& l1) {
+        for_each_slot<1, 1u>(c, mu, ms, [&](int, const real* g, real m) {
+            const real sk = rfma(rabs(m), reltol, abstol);
+            const real q0 = m / sk, q1 = g[0] / sk;
             dd_acc(h0, l0, q0 * q0);
             dd_acc(h1, l1, q1 * q1);
         });
     }
-    static __device__ __forceinline__ void init_norm2(const Ctx& c, double abstol, double reltol, const double* mu, int ms,
-                                                      double& h2, double& l2) {
-        for_each_slot<2, 3u>(c, mu, ms, [&](int, const double* g, double m) {
-            const double sk = __builtin_fma(fabs(m), reltol, abstol);
-            const double q = (g[1] - g[0]) / sk;
+    static __device__ __forceinline__ void init_norm2(const Ctx& c, real abstol, real reltol, const real* mu, int ms,
+                                                      real& h2, real& l2) {
+        for_each_slot<2, 3u>(c, mu, ms, [&](int, const real* g, real m) {
+            const real sk = rfma(rabs(m), reltol, abstol);
+            const real q = (g[1] - g[0]) / sk;
             dd_acc(h2, l2, q * q);
         });
     }

@@ -562,11 +562,13 @@ struct SeirUde {
 
 }  // namespace ude
 #include "ude_model_node.h"
-#ifdef UDE_INST_GENERIC  // (only the translation units of the runtime-shape instances pull the model in: build.py)
+namespace ude {
+#endif  // UDE_F32
+}  // namespace ude
+#ifdef UDE_INST_GENERIC  // (only the translation units of the runtime-shape instances pull the model in: build.py; Float64 and Float32)
 #include "ude_model_generic.h"
 #endif
 namespace ude {
-#endif  // UDE_F32
 
 // ---------------------------------------------------------------------------------------------
 // Fisher-KPP (FisherKPP/Fisher-KPP-CNN.jl, LotkaVolterra/scenario_3.jl): 1-D reaction-diffusion on a periodic

@@ -306,7 +306,8 @@ static int model_id(const ude_model_desc* m) {
 // the runtime-shape fallback (csrc/ude_model_generic.h) takes any chain of 1..8 Dense layers of width 1..64 with activations
 // identity / tanh / rbf / relu whose ends fit the kind's wiring: LV 2 -> 2, SEIR exposure 3 -> 1, neural ODE 7 -> 7
 static int generic_id(const ude_model_desc* m) {
-    if (m->dtype != 0 || m->n_layers < 1 || m->n_layers > UDE_MAX_LAYERS || m->nn_offset < 0) return MID_NONE;
+    if ((m->dtype != 0 && m->dtype != 1) || m->n_layers < 1 || m->n_layers > UDE_MAX_LAYERS || m->nn_offset < 0) return MID_NONE;
+    if (m->dtype == 1 && m->kind != UDE_KIND_LV_UDE) return MID_NONE;   // Float32: the LV kind (the reference's Float32 ODE problems)
     int np = 0;
     for (int l = 0; l <= m->n_layers; ++l)
         if (m->dims[l] < 1 || m->dims[l] > 64) return MID_NONE;
@@ -319,6 +320,7 @@ static int generic_id(const ude_model_desc* m) {
     if (m->kind == UDE_KIND_LV_UDE && m->n_state == 2 && in == 2 && out == 2) {
         for (int i = 0; i < 2; ++i)
             if (m->lin_idx[i] >= m->n_param || (m->lin_idx[i] >= m->nn_offset && m->lin_idx[i] < m->nn_offset + np)) return MID_NONE;
+        if (m->dtype == 1) return m->n_layers <= 4 ? MID_GENERIC_2_L4_F32 : MID_GENERIC_2_F32;
         return m->n_layers <= 4 ? MID_GENERIC_2_L4 : MID_GENERIC_2;   // (<= 4 layers: the instance with half the stage storage)
     }
     if (m->kind == UDE_KIND_SEIR_UDE && m->n_state == 7 && in == 3 && out == 1) return m->n_layers <= 4 ? MID_GENERIC_7_L4 : MID_GENERIC_7;
@@ -362,7 +364,9 @@ static int default_lanes(int mid, bool discrete) {
         case MID_GENERIC_2:
         case MID_GENERIC_7:
         case MID_GENERIC_2_L4:
-        case MID_GENERIC_7_L4: return 64;  // wavefront per trajectory, one per block
+        case MID_GENERIC_7_L4:
+        case MID_GENERIC_2_F32:
+        case MID_GENERIC_2_L4_F32: return 64;  // wavefront per trajectory, one per block
         case MID_KPP_TRUE_32:
         case MID_KPP_UDE_32:
         case MID_KPP_S3_32:
