@@ -437,8 +437,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip config.other_workloads (the headline run also measures seir, kpp, hjb, "
                                                              "node, lv_tanh32 and lv_discrete: median of 5 steps each)")
-    ap.add_argument("--allreduce", default="torch", choices=["torch", "udecore"],
-                    help="N > 1: transport of the one all-reduce per gradient (torch.distributed nccl, or libudecore's RCCL binding)")
+    ap.add_argument("--allreduce", default="torch", choices=["torch", "udecore", "p2p"],
+                    help="N > 1: transport of the one all-reduce per gradient: torch.distributed nccl, libudecore's RCCL binding, or libudecore's "
+                         "one-shot cross-process P2P reducer (IPC windows, one kernel per rank, rank-ordered deterministic sum; no RCCL)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -504,6 +505,8 @@ def main():
     comm = None
     if dist is not None and a.allreduce == "udecore":
         comm = Comm.from_torch_dist(ens.eng, dist)
+    elif dist is not None and a.allreduce == "p2p":
+        comm = Comm.p2p_from_torch_dist(ens.eng, dist, len(theta_h) + 4)
 
     replay = ens.graph(theta) if a.graph else None
 
@@ -514,7 +517,10 @@ def main():
         buf = pack_payload(g, ens.stats)
         if comm is not None:
             ens.eng.set_stream(torch.cuda.current_stream().cuda_stream)
-            comm.allreduce(buf)
+            if getattr(comm, "mp", False):
+                comm.allreduce_mp(buf)
+            else:
+                comm.allreduce(buf)
         else:
             allreduce_payload(buf, dist)
         return buf

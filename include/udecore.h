@@ -101,9 +101,15 @@ typedef struct {
     int32_t sensealg;   /* UDE_SENSE_*: how ude_vjp / ude_loss_grad differentiate */
     int32_t per_trajectory; /* UDE_PT_* flags: every ensemble member has its own tspan (2 x N) and / or save grid (ns x N,
                                strictly increasing inside its tspan) -- remake(prob; tspan = (T[1], T[end])) + saveat = T per
-                               segment, scenario_2.jl:104-124; 0 = one shared pair / grid */
+                               segment, scenario_2.jl:104-124 -- and / or its own parameter vector (UDE_PT_THETA); 0 = shared */
 } ude_solve_opts;
-enum { UDE_PT_TSPAN = 1, UDE_PT_SAVEAT = 2 };
+enum { UDE_PT_TSPAN = 1, UDE_PT_SAVEAT = 2,
+       /* per-member PARAMETERS: theta is np x N (column j = member j's parameters) and grad_theta comes back np x N, one gradient per
+        * member, nothing summed -- LotkaVolterra/run_loops.jl:55-62 runs 500 independent recoveries, each with its own data AND its own
+        * network; `loss` is still the sum, loss_per_traj the members' own.  LV-kind models whose kernel keeps the weights in registers
+        * (the default lane counts of scenario_1 / scenario_2 / hudson_bay's chains, Float64 and Float32), interpolating adjoint and the
+        * discrete sweep; UDE_ERR_UNSUPPORTED elsewhere.  May be combined with the two flags above. */
+       UDE_PT_THETA = 4 };
 
 /* launch/tuning knobs of the HIP back end (not part of the reference surface) */
 typedef struct {
@@ -281,6 +287,16 @@ void ude_comm_destroy(ude_comm* comm);
 int ude_allreduce_grad(ude_comm* comm, double* buf_dev, int64_t n);
 int ude_allreduce_grad_local(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n);
 int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n);
+/* The same one-shot reducer with ONE PROCESS PER GPU (the layout `bench.py --gpus N` and a multi-process Julia host use): every rank
+ * creates a communicator with an exchange window in its own HBM and gets a 64-byte IPC handle; the host all-gathers the handles
+ * (torch.distributed / MPI / Distributed.jl -- 64 bytes per rank, once) and connects; per gradient ONE kernel per rank: publish the
+ * payload, add all ranks' payloads in rank order (peer reads over xGMI, system-scope flags; identical bits on every rank), write the
+ * sum back.  n <= n_max <= 8192 doubles.  A peer that never arrives: the result is NaN after UDE_P2P_TIMEOUT_MS (default 5000) and
+ * ude_comm_p2p_status counts it -- never a hung GPU.  Needs no librccl. */
+int ude_comm_create_p2p(ude_ctx* ctx, int32_t nranks, int32_t rank, int64_t n_max, char handle_out[64], ude_comm** out);
+int ude_comm_p2p_connect(ude_comm* comm, const char* handles /* nranks x 64 bytes, rank order */);
+int ude_allreduce_grad_p2p_mp(ude_comm* comm, double* buf_dev, int64_t n);
+int ude_comm_p2p_status(ude_comm* comm, int32_t* timeouts);
 
 /* Failure accounting of the most recent gradient call on this context (blocks on the context's stream): the number
  * of trajectories whose retcode is not Success.  Such trajectories contribute nothing to the gradient and the

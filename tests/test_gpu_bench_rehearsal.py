@@ -13,12 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("workload,traj,port", [("lv", "2000", "29541"), ("seir", "300", "29545")])
-def test_bench_two_ranks_on_one_gpu(workload, traj, port):
-    env = dict(os.environ, UDE_BENCH_DEVICE="0", UDE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+@pytest.mark.parametrize("workload,traj,port,transport", [("lv", "2000", "29541", "torch"), ("seir", "300", "29545", "torch"),
+                                                         ("lv", "2000", "29547", "p2p")])
+def test_bench_two_ranks_on_one_gpu(workload, traj, port, transport):
+    """transport "p2p": `bench.py --gpus 2 --allreduce p2p` -- the one all-reduce per gradient through libudecore's cross-process
+    one-shot reducer (IPC windows, rank-ordered sum), the comparison with RCCL that SURVEY.md 8(e) asks for, from the very layout
+    the driver launches (one process per GPU); here both ranks share device 0"""
+    env = dict(os.environ, UDE_BENCH_DEVICE="0", UDE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--traj", traj,
-           "--workload", workload, "--no-cpu-baseline", "--no-others"]
+           "--workload", workload, "--no-cpu-baseline", "--no-others", "--allreduce", transport]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

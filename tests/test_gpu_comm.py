@@ -84,3 +84,63 @@ def test_two_gpu_gradient_equals_one_gpu_and_rccl_equals_p2p():
     assert np.abs(got[:-3] - ref[:-3]).max() <= 1e-12 * np.abs(ref[:-3]).max()
     assert np.array_equal(got[-3:], ref[-3:])                                                  # counters: exact
     comm.close()
+
+
+P2P_MP_CHILD = r"""
+import os, sys, ctypes as C
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import universal_differential_equations_amd as U
+from universal_differential_equations_amd.parallel import Comm
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["UDE_TEST_PORT"], rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+eng = U.Engine.get(0)                                   # both ranks on device 0: the IPC window is opened across PROCESSES
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+comm = Comm.p2p_from_torch_dist(eng, dist, 4485)
+ok = True
+for call in range(40):                                  # repeated calls: both slot parities are reused many times
+    n = [91, 4485, 1, 1024][call %% 4]
+    rng = np.random.default_rng(1000 * call)
+    parts = [rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8) for _ in range(world)]
+    want = parts[0].copy()
+    for r in range(1, world):
+        want = want + parts[r]                          # rank order, left to right: the reducer's association
+    buf = torch.tensor(parts[rank], dtype=torch.float64, device="cuda:0")
+    comm.allreduce_mp(buf)
+    torch.cuda.synchronize()
+    ok = ok and np.array_equal(buf.cpu().numpy(), want)
+assert comm.p2p_timeouts() == 0
+# a peer that never arrives: rank 1 skips a call; rank 0's result is NaN after the timeout, the GPU is not hung, the counter says so
+if rank == 0:
+    buf = torch.ones(8, dtype=torch.float64, device="cuda:0")
+    comm.allreduce_mp(buf)
+    torch.cuda.synchronize()
+    lost = bool(torch.isnan(buf).all().item()) and comm.p2p_timeouts() == 1
+else:
+    lost = True
+dist.barrier()
+print("RESULT rank %%d ok %%s lost %%s" %% (rank, ok, lost), flush=True)
+dist.destroy_process_group()
+os._exit(0)                                              # (the windows stay mapped in the peer: skip the destructors' ordering)
+"""
+
+
+def test_cross_process_p2p_reducer_two_ranks_on_one_gpu(tmp_path):
+    """round 4: `ude_allreduce_grad_p2p` with ONE PROCESS PER GPU (what `bench.py --gpus N` launches): IPC windows, one kernel per
+    rank and call, sums in rank order -- rehearsed with two processes on one device (the IPC path is the same; the peer reads then
+    stay inside one HBM).  40 calls of four payload sizes, bit-identical to the left-to-right sum on both ranks; a missing peer ends
+    in NaN + a counted timeout, not in a hung GPU."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", UDE_TEST_PORT=str(port), UDE_P2P_TIMEOUT_MS="1500", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", P2P_MP_CHILD % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d: %s" % (rank, se[-2000:])
+        assert "RESULT rank %d ok True lost True" % rank in so, (so[-500:], se[-1500:])

@@ -339,3 +339,65 @@ def test_wide_gradient_matrix_reduction_path():
     assert (r.retcode == 0).all() and np.array_equal(r.stats, ref["stats"]) and np.array_equal(r.grad_u0, ref["grad_u0"])
     assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < 1e-12 * np.linalg.norm(ref["grad_theta"])
     assert abs(r.loss - ref["loss"]) < 1e-12 * ref["loss"]
+
+
+@pytest.mark.parametrize("case", ["s1_adjoint", "s1_discrete", "hudson_adjoint", "hudson_f32_discrete", "s1_vern7_pt_grids"])
+def test_per_member_parameters_are_n_independent_recoveries(golden, case):
+    """LotkaVolterra/run_loops.jl:55-62 runs 500 INDEPENDENT recoveries -- every member its own data and its own network -- one after
+    the other; `EnsembleProblem(prob, u0s, ps = thetas)` (UDE_PT_THETA) runs them as one ensemble: member j reads its own parameter
+    column and gets its own gradient row, nothing is summed over trajectories.  Every member bit-identical to the oracle solving
+    that member alone with its parameters (states, step counts forward and backward, loss, dL/du0 AND every gradient entry)."""
+    rng = np.random.default_rng(77)
+    f32 = np.float32
+    sense, osense = (U.ForwardDiffSensitivity(), 1) if "discrete" in case else (None, 0)
+    if case.startswith("hudson"):
+        dt = f32 if "f32" in case else np.float64
+        g = golden("Hudson_Bay_recovery")
+        X = np.array(g["X"]["data_colmajor"], dtype=dt).reshape(21, 2)[:9]
+        t = np.arange(9, dtype=dt) * dt(0.25)
+        f = models.ude_dynamics(models.hudson_chain(), trainable="both", dtype="float32" if dt is f32 else "float64")
+        om = O.lv_ude_hudson(1 if dt is f32 else 0)
+        base = np.concatenate([[1.3, 1.8], 0.3 * models.hudson_chain().glorot_uniform(rng)])
+        alg, oalg, tol = U.Vern7, O.VERN7, 1e-5
+    else:
+        dt = np.float64
+        g = golden("Scenario_1_recovery_0.005")
+        X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+        t = np.array(g["solution"]["t"])
+        f, om = models.ude_dynamics(), O.lv_ude_s1()
+        base = np.array(g["initial_parameters"])
+        alg, oalg, tol = (U.Vern7, O.VERN7, 1e-7) if "vern7" in case else (U.Tsit5, O.TSIT5, 1e-6)
+    N = 17                                                   # two wavefronts of 12 (5 lanes) / three of 8 (8 lanes), the last partial
+    thetas = (base[None, :] * (1 + 0.2 * rng.standard_normal((N, base.size)))).astype(dt)
+    u0 = (X[0][None, :] * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))).astype(dt)
+    data = (X[None] * (1 + 0.05 * rng.standard_normal((N,) + X.shape))).astype(dt)
+    tspans, grids = None, t
+    if "pt_grids" in case:                                   # ... combined with per-member spans and save grids (UDE_PT_TSPAN | SAVEAT | THETA)
+        ends = rng.uniform(1.5, 3.0, N)
+        tspans = np.stack([np.zeros(N), ends], axis=1)
+        grids = np.stack([np.linspace(0.0, e, len(t)) for e in ends])
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (float(t[0]), float(t[-1])), thetas[0]), u0, tspans=tspans, ps=thetas)
+    sol = U.solve(ens, alg(), saveat=grids, abstol=tol, reltol=tol)
+    r = U.loss_and_gradient(ens, alg(), data, saveat=grids, abstol=tol, reltol=tol, sensealg=sense)
+    assert r.grad_theta.shape == (N, base.size) and (r.retcode == 0).all()
+    total = 0.0
+    for j in range(N):
+        tj = grids[j] if tspans is not None else t
+        sp = [tspans[j, 0], tspans[j, 1]] if tspans is not None else [t[0], t[-1]]
+        ref = O.loss_grad_ensemble(om, O.opts(oalg, tol, tol, sensealg=osense), u0[j:j + 1], sp, thetas[j], tj, data[j:j + 1], dtype=dt)
+        what = "%s member %d" % (case, j)
+        assert np.array_equal(sol.u[j], ref["u"][0]) and np.array_equal(sol.stats[j, :3], ref["stats"][0, :3]), what   # (plain solve: lazy stages count in column 3, gradient calls: 7)
+        assert np.array_equal(r.u[j], ref["u"][0]) and np.array_equal(r.stats[j], ref["stats"][0]), what
+        assert np.array_equal(r.grad_u0[j], ref["grad_u0"][0]) and r.loss_per_traj[j] == ref["loss_per_traj"][0], what
+        assert np.array_equal(r.grad_theta[j], ref["grad_theta"]), what      # one trajectory, one row: no sum, so bit for bit
+        total += float(ref["loss_per_traj"][0])
+    assert abs(float(r.loss) - total) <= 1e-6 * abs(total)
+
+
+def test_per_member_parameters_are_refused_where_theta_is_read_in_the_hot_loop():
+    f = models.ude_dynamics(models.tanh32_chain())          # 2-32-2: the weights stay in LDS (shared by the block's trajectories)
+    th = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(0))
+    u0 = np.array([[0.44, 4.6], [0.5, 4.2]])
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 1.0), th), u0, ps=np.stack([th, th]))
+    with pytest.raises(U.UdeError, match="per-member parameters"):
+        U.loss_and_gradient(ens, U.Tsit5(), np.zeros((2, 3, 2)), saveat=[0.0, 0.5, 1.0])

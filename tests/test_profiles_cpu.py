@@ -1,0 +1,40 @@
+"""The committed evidence under profiles/ is self-consistent: the bench line of a workload and the rocprofv3 kernel trace of the same
+command (tools/prof_r04.sh writes both in one pass) agree on the dominant kernel's average duration -- the roofline numerator of
+the bench line (HIP events inside bench.py) can be reproduced from the trace the judge reads."""
+import json
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+# workload -> (kernel name prefix in the trace, key of the kernel time in the bench line's config)
+CASES = {"lv": ("adj_kernel<", "bwd_kernel_ms"), "lv_discrete": ("dadj_kernel<", "bwd_kernel_ms"), "lv_tanh32": ("adj_kernel<", "bwd_kernel_ms"),
+         "seir": ("seirls::seir_ls_adj_kernel<", "bwd_kernel_ms"), "node": ("nodels::node_ls_adj_kernel<", "bwd_kernel_ms"),
+         "kpp": ("adj_kernel<", "bwd_kernel_ms")}
+
+
+def trace_avg_us(path, prefix):
+    """average duration (us) of the first kernel whose name starts with `void <prefix>` in a tools/rocpd_summary.py table
+    (| kernel | calls | total ms | avg us | min us | max us | % | -- the kernel name itself may contain `|`: count from the right)"""
+    for line in open(path):
+        if ("`void " + prefix) in line:
+            c = [x.strip() for x in line.rstrip().rstrip("|").split("|")]
+            return float(c[-4])
+    return None
+
+
+@pytest.mark.parametrize("wl", sorted(CASES))
+def test_bench_kernel_time_agrees_with_the_committed_trace(wl):
+    bench, trace = os.path.join(P, "r04_bench_%s.json" % wl), os.path.join(P, "r04_kernel_stats_%s.md" % wl)
+    if not (os.path.exists(bench) and os.path.exists(trace)):
+        pytest.skip("no round-4 profile of %s committed yet" % wl)
+    d = json.loads(open(bench).read().strip().splitlines()[-1])
+    prefix, key = CASES[wl]
+    ms = d["config"][key]
+    us = trace_avg_us(trace, prefix)
+    assert us is not None, "no %s row in %s" % (prefix, trace)
+    # 2 % for the single-kernel-per-step workloads; the trace run is a separate launch of the same command on the same box
+    assert abs(us * 1e-3 - ms) <= 0.02 * ms, "%s: bench %.4f ms vs trace %.4f ms" % (wl, ms, us * 1e-3)

@@ -71,7 +71,8 @@ EXPORTS = ["ude_version", "ude_create", "ude_destroy", "ude_last_error", "ude_se
            "ude_last_failures", "ude_hjb_num_params", "ude_hjb_loss_grad_dev", "ude_hjb_loss_grad", "ude_hjb_normals",
            "ude_hjb_net", "ude_hjb_last_kernel_ms", "ude_hjb_debug_read", "ude_hjb_last_failures",
            "ude_comm_unique_id", "ude_comm_create", "ude_comm_create_local", "ude_comm_destroy", "ude_allreduce_grad",
-           "ude_allreduce_grad_local", "ude_allreduce_grad_p2p"]
+           "ude_allreduce_grad_local", "ude_allreduce_grad_p2p", "ude_comm_create_p2p", "ude_comm_p2p_connect",
+           "ude_allreduce_grad_p2p_mp", "ude_comm_p2p_status"]
 
 
 def load():
@@ -129,6 +130,10 @@ def load():
     L.ude_allreduce_grad.argtypes = [vp, vp, i64]
     L.ude_allreduce_grad_local.argtypes = [i32, vp, vp, i64]
     L.ude_allreduce_grad_p2p.argtypes = [i32, vp, vp, i64]
+    L.ude_comm_create_p2p.argtypes = [vp, i32, i32, i64, vp, C.POINTER(vp)]
+    L.ude_comm_p2p_connect.argtypes = [vp, vp]
+    L.ude_allreduce_grad_p2p_mp.argtypes = [vp, vp, i64]
+    L.ude_comm_p2p_status.argtypes = [vp, C.POINTER(i32)]
     L.ude_hjb_debug_read.argtypes = [vp, i32, i64, i64, vp]
     L.ude_hjb_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ude_set_trace.argtypes = [vp, i64, i32]

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -91,11 +92,22 @@ struct P2PGroup {
     }
 };
 
+struct P2PMp {
+    int nranks = 0, rank = 0;
+    size_t nmax = 0;
+    char* win = nullptr;                  // this rank's window: [2][nmax] doubles | 2 x uint64 flags | uint32 timeout counter
+    std::vector<char*> peer;              // every rank's window as mapped into this process (peer[rank] == win)
+    char** peer_dev = nullptr;            // the same table in HBM
+    uint64_t seq = 0;
+    static size_t bytes(size_t nmax) { return 2 * nmax * sizeof(double) + 64; }
+};
+
 struct ude_comm {
     ude_ctx* ctx = nullptr;
     ncclComm_t nccl = nullptr;
     int nranks = 1, rank = 0;
-    std::shared_ptr<P2PGroup> p2p;
+    std::shared_ptr<P2PGroup> p2p;   // devices of one process (ude_comm_create_local)
+    std::shared_ptr<P2PMp> mp;       // one process per GPU (ude_comm_create_p2p)
 };
 
 #define NCCLCHK(c, call)                                                                                            \
@@ -181,6 +193,14 @@ extern "C" int ude_comm_create_local(int32_t ndev, ude_ctx* const* ctxs, ude_com
 extern "C" void ude_comm_destroy(ude_comm* m) {
     if (!m) return;
     if (m->nccl && rccl()) (void)rccl()->CommDestroy(m->nccl);
+    if (m->mp) {   // close the peers' windows, release this rank's
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipDeviceSynchronize();
+        for (int r = 0; r < (int)m->mp->peer.size(); ++r)
+            if (r != m->mp->rank && m->mp->peer[r]) (void)hipIpcCloseMemHandle(m->mp->peer[r]);
+        if (m->mp->peer_dev) (void)hipFree(m->mp->peer_dev);
+        if (m->mp->win) (void)hipFree(m->mp->win);
+    }
     delete m;
 }
 
@@ -277,5 +297,149 @@ extern "C" int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, doub
             if (j != i) HIPCHK(c, hipStreamWaitEvent(c->stream, g->readdone[j], 0));
         HIPCHK(c, hipMemcpyAsync(bufs_dev[i], (char*)g->table[i] + pb, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     }
+    return UDE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One process per GPU: the one-shot P2P reducer ACROSS PROCESSES (round 4; SURVEY.md 8(e) asks to compare it with RCCL from the
+// layout `bench.py --gpus N` uses).  Every rank owns an exchange WINDOW in its own HBM -- two payload slots (parity of the call
+// number) and two flag words -- exported with hipIpcGetMemHandle and opened by every peer (xGMI peer reads).  A call is ONE
+// kernel per rank:
+//   1. copy the rank's payload into its slot[k & 1], fence, publish flag[k & 1] = k (system-scope release);
+//   2. for r = 0 .. nranks-1 IN RANK ORDER: wait until rank r's flag[k & 1] >= k (acquire), add its slot (system-scope loads):
+//      a deterministic fp64 sum, identical bits on every rank;
+//   3. write the sum back into the caller's buffer.
+// Slot reuse needs no second handshake: slot[k & 1] is overwritten by call k + 2, and a rank that has SEEN every peer's flag of call
+// k + 1 (step 2 of its own call k + 1) knows every peer has finished call k (calls are stream-ordered per rank).
+// A peer that never arrives does not hang the GPU: the wait gives up after `UDE_P2P_TIMEOUT_MS` (default 5000), the result is NaN and a
+// sticky counter is raised (ude_comm_p2p_status).  No host synchronisation, no RCCL.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ uint64_t* p2p_flags(char* w, size_t nmax) { return (uint64_t*)(w + 2 * nmax * sizeof(double)); }
+
+__global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nranks, int rank, size_t nmax, uint64_t seq, double* buf, int64_t n,
+                                                      unsigned long long timeout_ticks) {
+    const int q = (int)(seq & 1);
+    char* mine = peers[rank];
+    double* myslot = (double*)mine + (size_t)q * nmax;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+        __hip_atomic_store(myslot + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(p2p_flags(mine, nmax) + q, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __shared__ int lost;
+    if (threadIdx.x == 0) lost = 0;
+    __syncthreads();
+    // (the sum of one element is kept in a register across the ranks: n <= blockDim.x * 8)
+    double acc[8];
+    for (int r = 0; r < nranks; ++r) {
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(p2p_flags(peers[r], nmax) + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                if (wall_clock64() - t0 > timeout_ticks) { lost = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        if (lost) break;
+        const double* slot = (const double*)peers[r] + (size_t)q * nmax;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = (int64_t)threadIdx.x + (int64_t)u * blockDim.x;
+            if (i < n) {
+                const double v = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                acc[u] = r == 0 ? v : acc[u] + v;
+            }
+        }
+    }
+    __syncthreads();
+    const bool bad = lost != 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int64_t i = (int64_t)threadIdx.x + (int64_t)u * blockDim.x;
+        if (i < n) buf[i] = bad ? __builtin_nan("") : acc[u];
+    }
+    if (bad && threadIdx.x == 0) atomicAdd((unsigned*)(p2p_flags(mine, nmax) + 2), 1u);
+}
+}  // namespace
+
+extern "C" int ude_comm_create_p2p(ude_ctx* c, int32_t nranks, int32_t rank, int64_t n_max, char handle_out[64], ude_comm** out) {
+    if (!c || !out || !handle_out || nranks < 1 || rank < 0 || rank >= nranks || n_max <= 0) return UDE_ERR_INVALID;
+    if (n_max > 8 * 1024) return fail(c, UDE_ERR_UNSUPPORTED, "the cross-process P2P reducer is a one-block kernel: payloads up to 8192 doubles (np + 4 of every model of the reference fits)");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    auto mp = std::make_shared<P2PMp>();
+    mp->nranks = nranks; mp->rank = rank; mp->nmax = (size_t)n_max;
+    void* w = nullptr;
+    // fine-grained device memory: peer loads and stores at system scope are coherent while the kernels run (coarse-grained HBM is
+    // only guaranteed visible to other agents at kernel boundaries); plain hipMalloc if the runtime has no such pool
+    if (hipExtMallocWithFlags(&w, P2PMp::bytes(mp->nmax), hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(c, hipMalloc(&w, P2PMp::bytes(mp->nmax)));
+    }
+    mp->win = (char*)w;
+    HIPCHK(c, hipMemset(w, 0, P2PMp::bytes(mp->nmax)));
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, w);
+    if (e != hipSuccess) {
+        (void)hipFree(w);
+        return fail(c, UDE_ERR_HIP, "hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set where the driver only supports dmabuf IPC)", hipGetErrorString(e));
+    }
+    memcpy(handle_out, &h, 64);
+    ude_comm* m = new ude_comm();
+    m->ctx = c; m->nranks = nranks; m->rank = rank; m->mp = mp;
+    *out = m;
+    return UDE_OK;
+}
+
+extern "C" int ude_comm_p2p_connect(ude_comm* m, const char* handles /* nranks x 64, rank order */) {
+    if (!m || !m->mp || !handles) return UDE_ERR_INVALID;
+    ude_ctx* c = m->ctx;
+    P2PMp& mp = *m->mp;
+    HIPCHK(c, hipSetDevice(c->device));
+    mp.peer.assign(mp.nranks, nullptr);
+    for (int r = 0; r < mp.nranks; ++r) {
+        if (r == mp.rank) { mp.peer[r] = mp.win; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)r * 64, 64);
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(c, UDE_ERR_HIP, "hipIpcOpenMemHandle(rank %d) failed: %s", r, hipGetErrorString(e));
+        mp.peer[r] = (char*)p;
+    }
+    if (!mp.peer_dev) HIPCHK(c, hipMalloc((void**)&mp.peer_dev, sizeof(char*) * mp.nranks));
+    HIPCHK(c, hipMemcpy(mp.peer_dev, mp.peer.data(), sizeof(char*) * mp.nranks, hipMemcpyHostToDevice));
+    return UDE_OK;
+}
+
+extern "C" int ude_allreduce_grad_p2p_mp(ude_comm* m, double* buf_dev, int64_t n) {
+    if (!m || !m->mp || !buf_dev || n <= 0) return UDE_ERR_INVALID;
+    ude_ctx* c = m->ctx;
+    P2PMp& mp = *m->mp;
+    if (!mp.peer_dev) return fail(c, UDE_ERR_INVALID, "ude_comm_p2p_connect has not been called");
+    if ((size_t)n > mp.nmax) return fail(c, UDE_ERR_INVALID, "payload of %lld doubles exceeds the window (%zu)", (long long)n, mp.nmax);
+    HIPCHK(c, hipSetDevice(c->device));
+    static const unsigned long long ticks = [] {
+        const char* e = getenv("UDE_P2P_TIMEOUT_MS");
+        const unsigned long long ms = e ? strtoull(e, nullptr, 10) : 5000ull;
+        return ms * 100000ull;   // wall_clock64: 100 MHz
+    }();
+    mp.seq += 1;
+    hipLaunchKernelGGL(p2p_mp_kernel, dim3(1), dim3(1024), 0, c->stream, (char* const*)mp.peer_dev, mp.nranks, mp.rank, mp.nmax, (uint64_t)mp.seq,
+                       buf_dev, n, ticks);
+    HIPCHK(c, hipGetLastError());
+    return UDE_OK;
+}
+
+// number of calls of this rank that gave up waiting for a peer (their result is NaN); blocks on the context's stream
+extern "C" int ude_comm_p2p_status(ude_comm* m, int32_t* timeouts) {
+    if (!m || !m->mp || !timeouts) return UDE_ERR_INVALID;
+    ude_ctx* c = m->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned v = 0;
+    HIPCHK(c, hipMemcpy(&v, m->mp->win + 2 * m->mp->nmax * sizeof(double) + 16, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *timeouts = (int32_t)v;
     return UDE_OK;
 }

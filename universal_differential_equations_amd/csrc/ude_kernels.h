@@ -71,7 +71,11 @@ struct KParams {
     int32_t saveat_pt, dtmax_auto;
     // checkpointed adjoint (UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED): the forward store keeps (t, t_end, dt, u) of every accepted
     // step and NOT its stage derivatives; the adjoint kernel recomputes them when it enters an interval (AdjSys::RECOMPUTE)
-    int32_t ckpt, pad_;
+    int32_t ckpt;
+    // per-member parameters (UDE_PT_THETA, LotkaVolterra/run_loops.jl:55-62: every ensemble member is its own recovery with its own
+    // theta): theta is np x N, member j reads theta + j * theta_pm, and the gradient is returned per member (grad_part = the
+    // caller's np x N array, row j written by trajectory j's lanes; no sum over trajectories).  0 = one shared theta.
+    int32_t theta_pm;
 };
 
 
@@ -735,7 +739,7 @@ __global__ void __launch_bounds__(BLOCK, fwd_blocks<Model>::v) fwd_kernel(const 
     using Sys = FwdSys<Model, Tab, G, BLOCK, PT>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
-    Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, nullptr, 0, p.mc, r, p.theta);
+    Model::init(sys.mctx, theta_of<Model, PT>(p, th, gid), scratch, nullptr, 0, p.mc, r, p.theta);
     sys.p = &p;
     sys.tg.init(p, gid);
     sys.j = gid;
@@ -1099,6 +1103,19 @@ struct AdjSys {
 // models whose discrete sweep defers the parameter cotangent (Model::DADJ_DEFERRED: the runtime-shape model -- hundreds of slots per lane)
 template <class M, class = void> struct dadj_deferred { static constexpr bool v = false; };
 template <class M> struct dadj_deferred<M, std::void_t<decltype(M::DADJ_DEFERRED)>> { static constexpr bool v = M::DADJ_DEFERRED; };
+// models that can run with per-member parameters (Model::PER_MEMBER_THETA: theta is only read while the context is set up --
+// weights and coefficients live in registers afterwards --, so a member's own HBM column can stand in for the block's LDS copy)
+template <class M, class = void> struct per_member { static constexpr bool v = false; };
+template <class M> struct per_member<M, std::void_t<decltype(M::PER_MEMBER_THETA)>> { static constexpr bool v = M::PER_MEMBER_THETA; };
+// the parameter vector a trajectory's context is built from: the block's LDS copy (or theta in HBM for THETA_GLOBAL models), or --
+// per-trajectory kernel variants of per-member models with UDE_PT_THETA -- the member's own column
+template <class Model, bool PT>
+__device__ __forceinline__ real* theta_of(const KParams& p, real* th_lds, int64_t gid) {
+    if constexpr (PT && per_member<Model>::v) {
+        if (p.theta_pm) return const_cast<real*>(p.theta) + (size_t)gid * p.theta_pm;
+    }
+    return Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th_lds;
+}
 template <class M, class = void> struct model_gfac { static constexpr int v = 0; };
 template <class M> struct model_gfac<M, std::void_t<decltype(M::GFAC)>> { static constexpr int v = M::GFAC; };
 
@@ -1152,7 +1169,7 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     if constexpr (Model::CPL || G >= 64) ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;  // one wavefront per trajectory: a scalar condition (Driver::uni)
     if (ok) {
         Sys sys;
-        Model::init(sys.mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
+        Model::init(sys.mctx, theta_of<Model, PT>(p, th, gid), scratch, slots, np_pad, p.mc, r, p.theta);
         sys.p = &p;
         sys.tg.init(p, gid);
         sys.j = gid;
@@ -1198,6 +1215,18 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
             if constexpr (NSLOT > 160) {
                 for (int c = 0; c < NSLOT; ++c) mu_final[(size_t)c * MS] = 0.0;
             } else static_for<0, NSLOT>([&](auto c) { mu_final[(size_t)c * MS] = 0.0; });
+        }
+    }
+    if constexpr (PT && per_member<Model>::v && !SG) {
+        if (p.theta_pm) {   // per-member parameters: trajectory gid's lanes write ITS gradient row, nothing is summed
+            if (in_range) {
+                real* row = p.grad_part + (size_t)gid * p.n_param;
+                for (int s = 0; s < NSL; ++s) {
+                    const int idx = Model::slot_index(p.mc, r, s);
+                    if (idx >= 0) row[idx] = mu_lds[(size_t)s * BLOCK];
+                }
+            }
+            return;
         }
     }
     if constexpr (!pow2_group<G>()) {
@@ -1305,7 +1334,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
     const bool ok = in_range && p.retcode[in_range ? gid : 0] == RET_SUCCESS;
     if (ok) {
         typename Model::Ctx mctx;
-        Model::init(mctx, Model::THETA_GLOBAL ? const_cast<real*>(p.theta) : th, scratch, slots, np_pad, p.mc, r, p.theta);
+        Model::init(mctx, theta_of<Model, PT>(p, th, gid), scratch, slots, np_pad, p.mc, r, p.theta);
         const int n = p.n_state;
         auto comp = [&](int c) {
             if constexpr (DIST) return Model::point(c, r); else return c;
@@ -1480,6 +1509,18 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             });
         } else {
             static_for<0, NSL>([&](auto c) { acc_lds[c * BLOCK] = acc[c]; });
+        }
+    }
+    if constexpr (PT && per_member<Model>::v && !SG) {
+        if (p.theta_pm) {   // per-member parameters: one gradient row per trajectory
+            if (in_range) {
+                real* rowm = p.grad_part + (size_t)gid * p.n_param;
+                for (int s = 0; s < NSL; ++s) {
+                    const int idx = Model::slot_index(p.mc, r, s);
+                    if (idx >= 0) rowm[idx] = ok ? acc_lds[(size_t)s * BLOCK] : real(0);
+                }
+            }
+            return;
         }
     }
     // ---- per-wave partial gradient row (fixed order) ----

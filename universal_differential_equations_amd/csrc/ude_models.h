@@ -92,6 +92,8 @@ struct LvUde : LinearTheta {
     static constexpr bool STATE_DISTRIBUTED = false;
     // weights in registers when the lane's share is small (narrow layers spread over >= 5 lanes), else read from LDS
     static constexpr bool REGW = WREG && (G >= 5) && (Net::maxdim() <= 8);
+    // per-member parameters (UDE_PT_THETA): with the weights in registers theta is only read by init()
+    static constexpr bool PER_MEMBER_THETA = REGW;
     struct Ctx {
         const real* th;   // full theta (LDS)
         const real* nn;   // th + nn_offset

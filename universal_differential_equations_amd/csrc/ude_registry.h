@@ -21,6 +21,7 @@ struct Launch {
     bool dadj_k_dense;  // the reverse sweep reads k from the dense store (HBM) instead of an LDS copy
     int slot_glob;  // > 0: slot state in HBM, this many elements per thread (SLOTS_GLOBAL models)
     int elem;       // bytes of the instance's scalar type (8: Float64, 4: Float32)
+    bool per_member;  // the per-trajectory kernel variants take per-member parameters (UDE_PT_THETA)
     size_t lds_bytes(int np, bool adjoint, bool discrete = false) const {
         const size_t np_pad = (size_t)((np + 1) & ~1);
         size_t d = (theta_lds < 0 ? np_pad : (size_t)theta_lds) + ((adjoint || discrete) ? scratch : scratch_fwd) + (discrete ? k_doubles : adjoint ? k_doubles_adj : k_doubles_fwd);
@@ -88,6 +89,7 @@ inline Launch make_launch() {
     l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : (Tab::FSAL ? 3 : 2) * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
     l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL + gfac_words<Model>::v : 0;
     l.elem = (int)sizeof(real);
+    l.per_member = per_member<Model>::v && !Model::SLOTS_GLOBAL;
     return l;
 }
 

@@ -673,6 +673,10 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     const unsigned grid = (unsigned)((N + gpb - 1) / gpb);
     const size_t shmem = l.lds_bytes(m->n_param, false);
     if ((rc = setup_time_grids(c, o, N, tspan, p))) return rc;
+    if (o->per_trajectory & UDE_PT_THETA) {
+        if (!l.per_member) return fail(c, UDE_ERR_UNSUPPORTED, "per-member parameters (UDE_PT_THETA): no instance for this model / lanes_per_traj");
+        p.theta_pm = m->n_param;
+    }
     void (*kfwd)(const KParams) = o->per_trajectory ? l.fwd_pt : l.fwd;
     if (shmem > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -745,6 +749,11 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const bool ckpt = o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED;
     const int nf = ckpt ? 3 + n : 3 + n + l.nf * n;   // dense fields per accepted step (checkpointed: t, t_end, dt, u)
     p.ckpt = ckpt ? 1 : 0;
+    const bool pm = (o->per_trajectory & UDE_PT_THETA) != 0;   // per-member parameters: theta np x N in, grad_theta np x N out
+    if (pm && (!l.per_member || any_ls || ckpt || o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST))
+        return fail(c, UDE_ERR_UNSUPPORTED, "per-member parameters (UDE_PT_THETA) exist for the LV-kind models whose kernel keeps the weights in "
+                                            "registers (default lanes_per_traj), with the interpolating adjoint or the discrete sweep");
+    p.theta_pm = pm ? np : 0;
     p.N = N;
     p.Npad = (N + 7) / 8 * 8;
     p.ns = ns;
@@ -760,7 +769,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = ensure(c, c->dense_n, sizeof(int32_t) * N))) return rc;
     if ((rc = ensure(c, c->cot, es * (size_t)ns * n * p.Npad))) return rc;
     if ((rc = ensure(c, c->loss_traj, es * N))) return rc;
-    if ((rc = ensure(c, c->grad_part, es * (size_t)nwaves * np))) return rc;
+    if (!pm && (rc = ensure(c, c->grad_part, es * (size_t)nwaves * np))) return rc;
     p.slot_glob = nullptr;
     if (any_ls) {  // mu of every trajectory: two columns of 71 (146) slots x 64 hidden rows; the stage factors of every block of 16 slots
         if ((rc = ensure(c, c->slot_glob, sizeof(double) * (size_t)N * 2 * ls_slk * 64))) return rc;
@@ -784,7 +793,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.dense_n = (int32_t*)c->dense_n.p;
     p.cot = (double*)c->cot.p;
     p.loss_traj = loss_per_traj ? loss_per_traj : (double*)c->loss_traj.p;
-    p.grad_part = (double*)c->grad_part.p;
+    p.grad_part = pm ? grad_theta : (double*)c->grad_part.p;   // (per-member: the trajectories write the caller's np x N array directly)
     p.grad_u0 = grad_u0;
     const bool discrete = o->sensealg == UDE_SENSE_DISCRETE;
     const bool fast = o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST;
@@ -818,7 +827,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         if (c->slot_glob.p) HIPCHK(c, hipMemsetAsync(c->slot_glob.p, v, c->slot_glob.cap, c->stream));
     }
 #endif
-    HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)nwaves * np, c->stream));
+    HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)(pm ? N : nwaves) * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     ude_poison_chip(c->stream, true);
     if ((seir_ls && UDE_SEIR_LS_FWD) || (node_ls && UDE_NODE_LS_FWD)) {
@@ -858,6 +867,16 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     }
     if ((rc = ensure(c, c->nfail, sizeof(int32_t)))) return rc;
     double* lossp = (loss && !cot_in) ? loss : (double*)nullptr;
+    if (pm) {  // nothing to reduce over trajectories: only the loss sum and the failure count (zero gradient columns)
+        if (m->dtype == 1)
+            hipLaunchKernelGGL(finish_kernel<float>, dim3(1), dim3(256), 0, c->stream, (const float*)nullptr, (int64_t)0, (int32_t)0, (float*)nullptr,
+                               (const float*)p.loss_traj, N, (float*)lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
+        else
+            hipLaunchKernelGGL(finish_kernel<double>, dim3(1), dim3(256), 0, c->stream, (const double*)nullptr, (int64_t)0, (int32_t)0, (double*)nullptr,
+                               (const double*)p.loss_traj, N, lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
+        HIPCHK(c, hipGetLastError());
+        return UDE_OK;
+    }
     if (m->dtype == 1)  // Float32 problem: every real-valued array behind these pointers is float
         hipLaunchKernelGGL(finish_kernel<float>, dim3(np + 1), dim3(256), 0, c->stream, (const float*)p.grad_part, nwaves, (int32_t)np,
                            (float*)grad_theta, (const float*)p.loss_traj, N, (float*)lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
@@ -989,7 +1008,7 @@ extern "C" int ude_solve_ensemble(ude_ctx* c, const ude_model_desc* m, const ude
     const size_t es = m->dtype == 1 ? sizeof(float) : sizeof(double);
     void *du0, *dth, *dsv;
     if ((rc = up(c, c->s_u0, u0, es * n * N, &du0))) return rc;
-    if ((rc = up(c, c->s_theta, theta, es * m->n_param, &dth))) return rc;
+    if ((rc = up(c, c->s_theta, theta, es * m->n_param * ((o->per_trajectory & UDE_PT_THETA) ? (size_t)N : 1), &dth))) return rc;
     if ((rc = up(c, c->s_saveat, saveat, es * ns * ((o->per_trajectory & UDE_PT_SAVEAT) ? N : 1), &dsv))) return rc;
     if ((rc = ensure(c, c->s_out, es * n * ns * N))) return rc;
     if ((rc = ensure(c, c->s_stats, sizeof(int64_t) * 8 * N))) return rc;
@@ -1017,14 +1036,15 @@ static int grad_host(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* 
     const size_t es = m->dtype == 1 ? sizeof(float) : sizeof(double);
     void *du0, *dth, *dsv, *ddat, *dmask;
     if ((rc = up(c, c->s_u0, u0, es * n * N, &du0))) return rc;
-    if ((rc = up(c, c->s_theta, theta, es * np, &dth))) return rc;
+    const size_t nth = (o->per_trajectory & UDE_PT_THETA) ? (size_t)N : 1;   // parameter vectors in / gradients out
+    if ((rc = up(c, c->s_theta, theta, es * np * nth, &dth))) return rc;
     if ((rc = up(c, c->s_saveat, saveat, es * ns * ((o->per_trajectory & UDE_PT_SAVEAT) ? N : 1), &dsv))) return rc;
     if ((rc = up(c, c->s_data, cot ? cot : data, es * n * ns * N, &ddat))) return rc;
     if ((rc = up(c, c->s_mask, row_mask, n, &dmask))) return rc;
     if ((rc = ensure(c, c->s_out, es * n * ns * N))) return rc;
     if ((rc = ensure(c, c->s_stats, sizeof(int64_t) * 8 * N))) return rc;
     if ((rc = ensure(c, c->s_ret, sizeof(int32_t) * N))) return rc;
-    if ((rc = ensure(c, c->s_gtheta, es * np))) return rc;
+    if ((rc = ensure(c, c->s_gtheta, es * np * nth))) return rc;
     if ((rc = ensure(c, c->s_gu0, es * n * N))) return rc;
     if ((rc = ensure(c, c->s_loss, es))) return rc;
     if ((rc = ensure(c, c->s_lpt, es * N))) return rc;
@@ -1047,7 +1067,7 @@ static int grad_host(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* 
     }
     if ((rc = dn(c, u_out, c->s_out.p, es * n * ns * N))) return rc;
     if ((rc = dn(c, stats, c->s_stats.p, sizeof(int64_t) * 8 * N))) return rc;
-    if ((rc = dn(c, grad_theta, c->s_gtheta.p, es * np))) return rc;
+    if ((rc = dn(c, grad_theta, c->s_gtheta.p, es * np * nth))) return rc;
     if ((rc = dn(c, grad_u0, c->s_gu0.p, es * n * N))) return rc;
     if (!cot) {
         if ((rc = dn(c, loss, c->s_loss.p, es))) return rc;

@@ -68,6 +68,32 @@ class Comm:
         return cls([engine], [h])
 
     @classmethod
+    def p2p_from_torch_dist(cls, engine, dist, n_max):
+        """one process per GPU, NO RCCL: every rank exports the IPC handle of its exchange window, the existing process group
+        all-gathers the 64-byte handles, every rank opens its peers' windows (ude_comm_create_p2p / ude_comm_p2p_connect)"""
+        L = _lib.load()
+        handle = (C.c_char * 64)()
+        h = C.c_void_p()
+        engine.check(L.ude_comm_create_p2p(engine.h, dist.get_world_size(), dist.get_rank(), int(n_max), handle, C.byref(h)))
+        box = [None] * dist.get_world_size()
+        dist.all_gather_object(box, bytes(handle))
+        engine.check(L.ude_comm_p2p_connect(h, b"".join(box)))
+        dist.barrier()                       # every rank has opened every window before the first call publishes into one
+        comm = cls([engine], [h])
+        comm.mp = True
+        return comm
+
+    def allreduce_mp(self, buf):
+        """the cross-process one-shot reducer (p2p_from_torch_dist): in place, on the context's stream"""
+        self.engines[0].check(self.L.ude_allreduce_grad_p2p_mp(self.handles[0], C.c_void_p(buf.data_ptr()), buf.numel()))
+        return buf
+
+    def p2p_timeouts(self):
+        n = C.c_int32(0)
+        self.engines[0].check(self.L.ude_comm_p2p_status(self.handles[0], C.byref(n)))
+        return n.value
+
+    @classmethod
     def local(cls, engines):
         """all devices of one process (what a single-threaded Julia host does)"""
         L = _lib.load()

@@ -221,12 +221,15 @@ def remake(prob, u0=None, tspan=None, p=None):
 
 
 class EnsembleProblem:
-    """EnsembleProblem(prob; u0s[, tspans]): N trajectories sharing prob.p (theta); u0s is (N, n).
+    """EnsembleProblem(prob; u0s[, tspans][, ps]): N trajectories sharing prob.p (theta); u0s is (N, n).
     tspans (N, 2): every member has its own time span -- prob_func = remake(prob; u0 = X[:, i0], tspan = (T[1], T[end]))
-    per shooting segment (scenario_2.jl:104-124); pass the members' save grids as a 2-D saveat (N, ns)."""
+    per shooting segment (scenario_2.jl:104-124); pass the members' save grids as a 2-D saveat (N, ns).
+    ps (N, np): every member has its OWN parameter vector -- prob_func = remake(prob; u0, p = p_i): the 500 independent
+    recoveries of LotkaVolterra/run_loops.jl:55-62 as one ensemble; loss_and_gradient then returns grad_theta (N, np), one
+    gradient per member (UDE_PT_THETA)."""
 
-    def __init__(self, prob, u0s, tspans=None):
-        self.prob, self.u0s, self.tspans = prob, u0s, tspans
+    def __init__(self, prob, u0s, tspans=None, ps=None):
+        self.prob, self.u0s, self.tspans, self.ps = prob, u0s, tspans, ps
 
 
 class ODESolution:
@@ -311,6 +314,8 @@ def _time_grids(prob, saveat, o):
             raise ValueError("per-trajectory tspans need explicit save grids (2-D saveat, or one shared grid inside every span)")
         ts = _saveat_grid(saveat, (float(tspan[0]), float(tspan[1])) if tspan.ndim == 1 else (float(tspan[:, 0].max()), float(tspan[:, 1].min())))
         ns = len(ts)
+    if ens and getattr(prob, "ps", None) is not None:
+        flags |= 4   # UDE_PT_THETA
     o.per_trajectory = flags
     return tspan, ts, ns
 
@@ -354,8 +359,12 @@ def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=
         u0 = u0[None, :]
     N, n = u0.shape
     assert n == base.f.n_state
-    theta = _np(base.p if base.p is not None else [], rt)
-    assert theta.size == base.f.n_param, "theta has %d entries, model expects %d" % (theta.size, base.f.n_param)
+    if ens and getattr(prob, "ps", None) is not None:       # per-member parameters (EnsembleProblem(..., ps = ...))
+        theta = _np(prob.ps, rt)
+        assert theta.shape[1] == base.f.n_param, "ps is (N, %d), model expects %d parameters" % (theta.shape[1], base.f.n_param)
+    else:
+        theta = _np(base.p if base.p is not None else [], rt)
+        assert theta.size == base.f.n_param, "theta has %d entries, model expects %d" % (theta.size, base.f.n_param)
     out = np.zeros((N, ns, n), dtype=rt)
     stats = np.zeros((N, NSTATS), dtype=np.int64)
     rc = np.zeros(N, dtype=np.int32)
@@ -408,12 +417,13 @@ def _grad_common(prob, alg, data, cotangent, row_mask, saveat, device, ensemblea
     if u0.ndim == 1:
         u0 = u0[None, :]
     N, n = u0.shape
-    theta = _np(base.p, rt)
-    assert theta.size == base.f.n_param
+    per_member = ens and getattr(prob, "ps", None) is not None
+    theta = _np(prob.ps if per_member else base.p, rt)
+    assert theta.shape == (N, base.f.n_param) if per_member else theta.size == base.f.n_param
     r = GradResult()
     r.t = ts
     r.u = np.zeros((N, ns, n), dtype=rt)
-    r.grad_theta = np.zeros(theta.size, dtype=rt)
+    r.grad_theta = np.zeros(theta.shape if per_member else theta.size, dtype=rt)
     r.grad_u0 = np.zeros((N, n), dtype=rt)
     r.stats = np.zeros((N, NSTATS), dtype=np.int64)
     r.retcode = np.zeros(N, dtype=np.int32)
