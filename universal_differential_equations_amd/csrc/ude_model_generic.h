@@ -10,8 +10,8 @@
 // One wavefront per trajectory; lane j = neuron j of every layer; weights are read from HBM (L2-resident: every trajectory
 // reads the same theta) -- there is no LDS copy whose size would depend on the shape; the activations of a layer cross lanes
 // through rows of the wavefront's LDS stage storage.  Arithmetic = oracle/ude_oracle_impl.h: mlp_forward / mlp_vjp_acc / wide_dot
-// (ARITH-SPEC): dots of fewer than 64 terms are one fma chain from 0 in ascending order; 64-term dots with >= 64 results are
-// four 16-term chains added left to right; 64-term dots with fewer than 64 results are rounded products summed by the
+// (ARITH-SPEC): dots of fewer than 64 terms are one fma chain from 0 in ascending order; 64-term dots with >= 16 results are
+// four 16-term chains added left to right; 64-term dots with fewer than 16 results are rounded products summed by the
 // adjacent-pair tree of the wavefront.  Per trajectory every number is therefore bit-identical to the oracle.
 // The parameter cotangent is DEFERRED exactly as in SeirNode: every adjoint stage leaves its factors (a_l and delta_l rows) in
 // LDS and the RK-weighted sums of all slots are formed at the end of the step, fused with error norm and candidate mu (mu in
@@ -86,13 +86,40 @@ struct GenericUde {
     // ---- wide_dot (oracle): result r of `nres` results over n terms; term i = w[i * ws] * x_i ----
     // x lives in an LDS row (lane i wrote x_i); lane j owns result j.  wbase(j): address of the lane's term 0, ws: term stride.
     static __device__ __forceinline__ real dot_lane(const real* w, int ws, const lds_t* x, int n) {
+        // The weights come from HBM / L2 (theta is shared by all trajectories, no LDS copy): what bounds a dot is the number of
+        // dependent memory round trips, not the fma's.  Loads are therefore issued in batches of GEN_BATCH before the first fma of
+        // the batch (the chain itself stays strictly ascending): 4 round trips per 64-term dot with 16, one with 64.
+#ifndef GEN_BATCH
+#define GEN_BATCH 16
+#endif
         if (n < 64) {  // one chain from 0, ascending
             real acc = real(0);
+            int i = 0;
+#pragma unroll 1
+            for (; i + GEN_BATCH <= n; i += GEN_BATCH) {
+                real wv[GEN_BATCH];
+#pragma unroll
+                for (int u = 0; u < GEN_BATCH; ++u) wv[u] = w[(size_t)(i + u) * ws];
+#pragma unroll
+                for (int u = 0; u < GEN_BATCH; ++u) acc = rfma(wv[u], x[i + u], acc);
+            }
 #pragma unroll 4
-            for (int i = 0; i < n; ++i) acc = rfma(w[(size_t)i * ws], x[i], acc);
+            for (; i < n; ++i) acc = rfma(w[(size_t)i * ws], x[i], acc);
             return acc;
         }
         real tot = real(0);  // 64 terms: four 16-term chains, block sums left to right
+#if GEN_BATCH >= 64
+        real wv[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) wv[i] = w[(size_t)i * ws];
+#pragma unroll
+        for (int b = 0; b < 64; b += 16) {
+            real acc = real(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = rfma(wv[b + i], x[b + i], acc);
+            tot = b == 0 ? acc : tot + acc;
+        }
+#else
 #pragma unroll 1
         for (int b = 0; b < 64; b += 16) {
             real acc = real(0);
@@ -100,6 +127,7 @@ struct GenericUde {
             for (int i = 0; i < 16; ++i) acc = rfma(w[(size_t)(b + i) * ws], x[b + i], acc);
             tot = b == 0 ? acc : tot + acc;
         }
+#endif
         return tot;
     }
     // forward chain: x on lanes 0..dims[0]-1 (others 0).  A rows go to `arow` (row l at arow[l * H]), dphi rows to c.work.
@@ -118,8 +146,9 @@ struct GenericUde {
             const int jj = j < out ? j : out - 1;   // (lanes beyond the layer compute a discarded copy of the last neuron: in-bounds reads)
             const lds_t* x = arow + l * H;
             real z;
-            if (in == 64 && out < 64) {
-                // 64 terms, fewer than 64 results: rounded products, adjacent-pair tree over the wavefront (lane i = term i)
+            if (in == 64 && out < 16) {
+                // 64 terms reduced to a few replicated scalars (wide-dot rule: fewer than 16 results): rounded products, adjacent-pair
+                // tree over the wavefront (lane i = term i); 16 .. 64 results: the lane-parallel blocked chains of dot_lane
                 z = real(0);
 #pragma unroll 1
                 for (int rr = 0; rr < out; ++rr) {
@@ -154,7 +183,7 @@ struct GenericUde {
             delta = j < out ? delta : real(0);
             drow[l * H + j] = delta;
             real prev;
-            if (out == 64 && in < 64) {
+            if (out == 64 && in < 16) {
                 prev = real(0);
 #pragma unroll 1
                 for (int k = 0; k < in; ++k) {
@@ -285,19 +314,33 @@ struct GenericUde {
             static_for<0, NST>([&](auto s) {
                 if constexpr ((MASK >> decltype(s)::value) & 1u) d[s] = c.fac[slot_of<MASK>(decltype(s)::value) * STG + (LMAX + l) * H + j];
             });
-            real m0 = mu[(size_t)sb * ms];
+            // mu of the layer's in + 1 slots comes from HBM: a chunk of GEN_CH slots is requested while the previous chunk is worked on
+            // (one slot ahead -- the round-3 form -- left a dependent HBM round trip per ~100 cycles of work: what bounded the kernel)
+#ifndef GEN_CH
+#define GEN_CH 8
+#endif
+            real mcur[GEN_CH], mnxt[GEN_CH];
+            static_for<0, GEN_CH>([&](auto u) { const int kk = (int)decltype(u)::value; mcur[u] = mu[(size_t)(sb + (kk <= in ? kk : in)) * ms]; });
 #pragma unroll 1
-            for (int k = 0; k <= in; ++k) {   // k == in: the bias
-                const real mnext = mu[(size_t)(sb + (k < in ? k + 1 : 0)) * ms];  // (one slot ahead; the wrap-around read is discarded)
-                real g[NST];
-                static_for<0, NST>([&](auto s) {
-                    if constexpr ((MASK >> decltype(s)::value) & 1u) {
-                        const real a = k < in ? c.fac[slot_of<MASK>(decltype(s)::value) * STG + l * H + k] : real(1);
-                        g[s] = k < in ? -(d[s] * a) : -d[s];
+            for (int k0 = 0; k0 <= in; k0 += GEN_CH) {
+                static_for<0, GEN_CH>([&](auto u) {
+                    const int kk = k0 + GEN_CH + (int)decltype(u)::value;
+                    mnxt[u] = mu[(size_t)(sb + (kk <= in ? kk : in)) * ms];   // (reads past the layer are clamped and discarded)
+                });
+                static_for<0, GEN_CH>([&](auto u) {
+                    const int k = k0 + (int)decltype(u)::value;
+                    if (k <= in) {   // k == in: the bias
+                        real g[NST];
+                        static_for<0, NST>([&](auto s) {
+                            if constexpr ((MASK >> decltype(s)::value) & 1u) {
+                                const real a = k < in ? c.fac[slot_of<MASK>(decltype(s)::value) * STG + l * H + k] : real(1);
+                                g[s] = k < in ? -(d[s] * a) : -d[s];
+                            }
+                        });
+                        body(sb + k, g, mcur[u]);
                     }
                 });
-                body(sb + k, g, m0);
-                m0 = mnext;
+                static_for<0, GEN_CH>([&](auto u) { mcur[u] = mnxt[u]; });
             }
             sb += in + 1;
         }
