@@ -147,10 +147,11 @@ const char* ude_last_error(ude_ctx* ctx);
  * the same context on another stream concurrently with a replay: the library keeps no ordering between them. */
 int ude_set_stream(ude_ctx* ctx, void* hip_stream);
 int ude_set_launch_opts(ude_ctx* ctx, const ude_launch_opts* lo);
-/* 0: this (model, alg) runs on a compiled fast instance; 1: it runs on the runtime-shape fallback kernel (any chain of <= 8 Dense
- * layers of width <= 64, activations identity / tanh / rbf / relu, for UDE_KIND_LV_UDE 2 -> 2, UDE_KIND_SEIR_UDE 3 -> 1 and
- * UDE_KIND_SEIR_NODE 7 -> 7, Float64, interpolating adjoint; slower, bit-identical to the oracle all the same);
- * UDE_ERR_UNSUPPORTED otherwise */
+/* 0: this (model, alg) runs on a compiled fast instance; 1: it runs on a runtime-shape fallback kernel -- any chain of <= 8 Dense
+ * layers of width <= 64, activations identity / tanh / rbf / relu, for UDE_KIND_LV_UDE 2 -> 2 (Float64 and Float32),
+ * UDE_KIND_SEIR_UDE 3 -> 1 and UDE_KIND_SEIR_NODE 7 -> 7 (Float64); any pointwise reaction chain 1 -> ... -> 1 of <= 4 layers of
+ * width <= 32 (<= 768 parameters) for UDE_KIND_KPP_UDE on <= 32 grid points (Float64); every sensealg; slower, bit-identical to the
+ * oracle all the same; UDE_ERR_UNSUPPORTED otherwise */
 int ude_model_supported(ude_ctx* ctx, const ude_model_desc* m, const ude_solve_opts* o, int32_t need_adjoint);
 
 /* Real-valued arrays: `ude_real` is void -- the element type is the problem's scalar type, double for

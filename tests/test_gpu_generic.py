@@ -49,6 +49,8 @@ def test_model_supported_reports_fast_instance_or_generic_kernel():
     assert supported(models.dudt_(chain_of([3, 16, 1], ["tanh", "identity"]))) == 1
     assert supported(models.dudt_node(chain_of([7, 32, 32, 7], ["relu", "tanh", "identity"]))) == 1
     assert supported(models.ude_dynamics(chain_of([2, 65, 2], ["tanh", "identity"]))) == -2   # wider than a wavefront: UDE_ERR_UNSUPPORTED
+    assert supported(models.nn_ode(26, chain_of([1, 7, 9, 1], ["tanh", "rbf", "identity"]))) == 1   # round 4: any pointwise reaction chain
+    assert supported(models.nn_ode(26, chain_of([1, 32, 32, 32, 1], ["tanh", "tanh", "tanh", "identity"]))) == -2   # > 768 parameters
     assert supported(models.ude_dynamics(chain_of([2, 6, 2], ["tanh", "identity"])), sense=1) == 1   # round 4: the discrete sweep too
     assert supported(models.ude_dynamics(chain_of([2, 6, 2], ["tanh", "identity"]), dtype="float32")) == 1   # ... and Float32 LV-kind problems
     assert supported(models.ude_dynamics(chain_of([2, 6, 2], ["tanh", "identity"])), sense=3) == 1   # ... and the checkpointed adjoint
@@ -225,6 +227,60 @@ def test_fisher_kpp_small_n_weights(n_weights):
     assert_bitwise(r.grad_u0, ref["grad_u0"], "dL/du0")
     gn = np.linalg.norm(ref["grad_theta"])
     assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < 1e-12 * gn
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_fisher_kpp_runtime_shape_reaction_network(seed):
+    """round 4: `nn_ode` (Fisher-KPP-CNN.jl:92-126) with ANY pointwise reaction chain 1 -> ... -> 1 of <= 4 layers and width <= 32 --
+    the scripts' `FastChain(...)` / `n_weights` are variables -- on the reference's grid sizes (<= 32 points, ragged), through the
+    runtime-shape kernel csrc/ude_model_kpp_generic.h: forward solve, interpolating adjoint, discrete sweep and the checkpointed
+    adjoint; per trajectory bit-identical to the oracle (a single PDE: every gradient entry)."""
+    rng = np.random.default_rng(900 + seed)
+    nh = int(rng.integers(1, 4))
+    widths = [1, 2, 4, 7, 8, 13, 16] if nh == 3 else [1, 3, 6, 12, 17, 24, 32]
+    while True:
+        dims = [1] + [int(rng.choice(widths)) for _ in range(nh)] + [1]
+        if sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1)) + 5 <= 768:
+            break
+    if seed == 0:
+        dims = [1, 16, 16, 16, 1]                     # 598 parameters: close to the 768 the kernel takes
+    acts = [str(rng.choice(["tanh", "rbf", "relu"])) for _ in range(len(dims) - 2)] + ["identity"]
+    chain = chain_of(dims, acts)
+    nx = int(rng.integers(3, 33))
+    f = models.nn_ode(nx, chain)
+    assert f.n_param <= 768 and supported(f) == 1, (dims, f.n_param)
+    om = O.kpp_ude(nx, tuple(dims), tuple(acts))
+    th = models.kpp_theta(chain, rng)
+    th[f.stencil_offset:f.stencil_offset + 3] = np.array([1.0, -2.0, 1.0]) + 0.1 * rng.standard_normal(3)
+    th[f.d0_offset] = rng.uniform(1.0, 6.0)
+    N = 1 if seed % 2 == 0 else 3
+    u0 = np.clip(models.rho0(nx)[None, :] * (1 + 0.2 * rng.uniform(-1, 1, (N, 1))) + 0.02 * rng.uniform(0, 1, (N, nx)), 0, None)
+    tf = float(rng.uniform(0.5, 3.0))
+    t = np.unique(np.concatenate([[0.0], np.sort(rng.uniform(0.0, tf, 5)), [tf]]))
+    data = rng.uniform(0.0, 1.0, (N, len(t), nx))
+    alg, oalg = (U.Vern7, O.VERN7) if seed % 3 == 0 else (U.Tsit5, O.TSIT5)
+    tol = float(10.0 ** rng.uniform(-7, -4))
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, tf), th), u0)
+    sol = U.solve(ens, alg(), saveat=t, abstol=tol, reltol=tol)
+    out, st, rc = O.solve_ensemble(om, O.opts(oalg, tol, tol), u0, [0.0, tf], th, t)
+    assert (rc == 0).all()
+    assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts %s %s" % (dims, acts))
+    assert_bitwise(sol.u, out, "forward states")
+    assert_bitwise(U.rhs(f, u0, th), np.array([O.rhs(om, th, u) for u in u0]), "rhs")
+    for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1), (U.InterpolatingAdjoint(checkpointing=True), 0)):
+        r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=tol, reltol=tol, sensealg=sense)
+        ref = O.loss_grad_ensemble(om, O.opts(oalg, tol, tol, sensealg=osense), u0, [0.0, tf], th, t, data, nthreads=3)
+        what = "%s %s nx %d sense %s" % (dims, acts, nx, type(sense).__name__)
+        assert (r.retcode == 0).all(), what
+        assert_bitwise(r.retcode, ref["retcode"], what)
+        assert_bitwise(r.stats[:, [0, 1, 2, 4, 5, 6]], ref["stats"][:, [0, 1, 2, 4, 5, 6]], what)
+        assert_bitwise(r.u, ref["u"], what)
+        assert_bitwise(r.grad_u0, ref["grad_u0"], what)
+        if N == 1:
+            assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta " + what)
+        else:
+            gn = np.linalg.norm(ref["grad_theta"])
+            assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn, what
 
 
 def test_tanh_bits_across_the_argument_range():

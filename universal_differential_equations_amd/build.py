@@ -59,6 +59,8 @@ MODELS = [
     # ... and for Float32 LV-kind problems (hudson_bay.jl:77-104 with any FastChain)
     ("MID_GENERIC_2_F32", "GenericUde<2>", 64, 1, 64, None, ("-DUDE_INST_GENERIC=1", "-DUDE_F32=1")),
     ("MID_GENERIC_2_L4_F32", "GenericUde<2,4>", 64, 1, 64, None, ("-DUDE_INST_GENERIC=1", "-DUDE_F32=1")),
+    # runtime-shape pointwise reaction network (any chain 1 -> .. -> 1 of <= 4 layers, width <= 32) on grids of <= 32 points
+    ("MID_KPP_GENERIC_32", "KppGenericUde<32,1>", 32, 1, 32, None, ("-DUDE_INST_KPPGEN=1",)),
     ("MID_KPP_UDE_1024", "KppUde<NetKpp,64,16>", 64, 1, 64, ("UDE_ALG_TSIT5",)),
     ("MID_KPP_UDE_1024", "KppUdeW<NetKpp>", 256, 1, 256),
     # Float32 problems (-DUDE_F32: the same kernels with real = float)

@@ -570,6 +570,9 @@ namespace ude {
 #ifdef UDE_INST_GENERIC  // (only the translation units of the runtime-shape instances pull the model in: build.py; Float64 and Float32)
 #include "ude_model_generic.h"
 #endif
+#ifdef UDE_INST_KPPGEN   // the runtime-shape pointwise Fisher-KPP network
+#include "ude_model_kpp_generic.h"
+#endif
 namespace ude {
 
 // ---------------------------------------------------------------------------------------------

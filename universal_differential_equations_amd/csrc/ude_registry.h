@@ -108,7 +108,8 @@ enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, 
        MID_GENERIC_2 /* UDE_KIND_LV_UDE */, MID_GENERIC_7 /* UDE_KIND_SEIR_UDE, UDE_KIND_SEIR_NODE */,
        MID_KPP_SMALL1_32, MID_KPP_SMALL2_32 /* Fisher-KPP-CNN-Small.jl:88 with n_weights = 1, 2 */,
        MID_GENERIC_2_L4, MID_GENERIC_7_L4 /* the runtime-shape fallback for chains of <= 4 layers: half the LDS, twice the wavefronts per CU */,
-       MID_GENERIC_2_F32, MID_GENERIC_2_L4_F32 /* Float32 LV-kind problems with any chain (hudson_bay.jl:77-79) */ };
+       MID_GENERIC_2_F32, MID_GENERIC_2_L4_F32 /* Float32 LV-kind problems with any chain (hudson_bay.jl:77-79) */,
+       MID_KPP_GENERIC_32 /* nn_ode with any pointwise reaction chain of <= 4 layers, width <= 32 (ude_model_kpp_generic.h) */ };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88

@@ -323,6 +323,14 @@ static int generic_id(const ude_model_desc* m) {
         if (m->dtype == 1) return m->n_layers <= 4 ? MID_GENERIC_2_L4_F32 : MID_GENERIC_2_F32;
         return m->n_layers <= 4 ? MID_GENERIC_2_L4 : MID_GENERIC_2;   // (<= 4 layers: the instance with half the stage storage)
     }
+    // nn_ode with a pointwise reaction network that has no compiled instance: <= 4 layers of width <= 32, <= 768 parameters in all,
+    // theta = [NN; w1 w2 w3 unused; D0] (Fisher-KPP-CNN.jl:100-109), grids of 3 .. 32 points, Float64
+    if (m->kind == UDE_KIND_KPP_UDE && m->dtype == 0 && in == 1 && out == 1 && m->n_layers <= 4 && m->nn_offset == 0 && m->n_state >= 3 &&
+        m->n_state <= 32 && m->n_param == np + 5 && m->n_param <= 768 && m->stencil_offset == np && m->d0_offset == np + 4) {
+        for (int l = 0; l <= m->n_layers; ++l)
+            if (m->dims[l] > 32) return MID_NONE;
+        return MID_KPP_GENERIC_32;
+    }
     if (m->kind == UDE_KIND_SEIR_UDE && m->n_state == 7 && in == 3 && out == 1) return m->n_layers <= 4 ? MID_GENERIC_7_L4 : MID_GENERIC_7;
     if (m->kind == UDE_KIND_SEIR_NODE && m->n_state == 7 && in == 7 && out == 7) return m->n_layers <= 4 ? MID_GENERIC_7_L4 : MID_GENERIC_7;
     return MID_NONE;
@@ -374,7 +382,8 @@ static int default_lanes(int mid, bool discrete) {
         case MID_KPP_SMALL1_32:
         case MID_KPP_SMALL2_32:
         case MID_KPP_TRUE_32_F32:
-        case MID_KPP_S3_32_F32: return 32;
+        case MID_KPP_S3_32_F32:
+        case MID_KPP_GENERIC_32: return 32;
         case MID_KPP_TRUE_1024: return 64;
         case MID_KPP_UDE_1024: return 256;  // 4 wavefronts per PDE
     }
@@ -390,7 +399,7 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
     }
     if (mid == MID_NONE)
         return fail(c, UDE_ERR_UNSUPPORTED, "no kernel for model kind=%d dtype=%d n_layers=%d: not a compiled instance (udecore.hip model table) and "
-                                            "outside the runtime-shape fallback (Float64, replicated-state kinds LV / SEIR, <= 8 layers of width <= 64)",
+                                            "outside the runtime-shape fallbacks (LV / SEIR kinds: <= 8 layers of width <= 64; Fisher-KPP on <= 32 points: <= 4 layers of width <= 32, Float64)",
                     m->kind, m->dtype, m->n_layers);
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
     if ((mid == MID_SEIR_UDE || mid == MID_SEIR_NODE) && G == 16) G = 64;  // (16 = the lock-step backward kernel of grad_dev_impl; every other kernel of that model: one wavefront per trajectory)
