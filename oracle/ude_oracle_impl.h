@@ -39,22 +39,25 @@ static inline REAL FN(dact)(int a, REAL z, REAL av) {
 #define UDEO_MAXW 128 /* max layer width supported by the oracle's stack buffers */
 
 /* ARITH-SPEC dot product of one matrix-vector product with `nres` results of `n` terms each; term i = w[i*ws] * x[i].
- *   n < 64            : one fma chain in ascending order started from 0
+ *   n < 64 (else)     : one fma chain in ascending order started from 0
  *   n >= 64, nres >= 16: blocks of 16 consecutive terms, each an fma chain started from 0; the block sums are added
  *                       left to right (a lane-parallel matrix-vector product: every lane owns a result; the device may
  *                       split the blocks over the wavefronts of a trajectory)
- *   n >= 64, nres < 16 : a reduction to a few replicated scalars (output layers 64 -> 1 / 64 -> 7, the input cotangent
- *                       64 -> 3 / 64 -> 7): rounded products, then the binary tree over adjacent index pairs (the
- *                       device's xor butterfly across the 64 lanes of a wavefront); n must be a power of two
+ *   n = 32 or 64, nres < 16 : a reduction to a few replicated scalars (output layers 64 -> 1 / 64 -> 7 / 32 -> 2, the input
+ *                       cotangent 64 -> 3 / 64 -> 7 / 32 -> 2): rounded products, then the binary tree over adjacent index
+ *                       pairs (the device's xor butterfly across the lanes that hold the terms); n a power of two.
+ *                       (round 4: n = 32 joined -- the 2-32-2 net of BASELINE's configs[1] spent its time gathering 32
+ *                       activations for two sequential 32-term chains; no network of the reference is affected)
  * (round 4: the threshold was nres >= 64 -- a 64 -> 63 layer then ran 63 wavefront tree sums per evaluation on the device's
  *  runtime-shape kernel; no network of the reference has a 64-term layer with 16..63 results, so no pinned number moved)   */
 static inline REAL FN(wide_dot)(int n, int nres, const REAL* w, size_t ws, const REAL* x) {
-    if (n < 64 || (n % 16) != 0) {
+    const int tree = n >= 32 && (n & (n - 1)) == 0 && nres < 16;   /* a 32- or 64-term reduction to a few replicated scalars */
+    if (!tree && (n < 64 || (n % 16) != 0)) {
         REAL acc = 0;
         for (int i = 0; i < n; ++i) acc = R_FMA(w[(size_t)i * ws], x[i], acc);
         return acc;
     }
-    if (nres >= 16 || (n & (n - 1)) != 0) {
+    if (!tree) {
         REAL tot = 0;
         for (int b = 0; b < n; b += 16) {
             REAL acc = 0;

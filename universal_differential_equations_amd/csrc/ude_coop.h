@@ -99,6 +99,17 @@ __device__ __forceinline__ T group_sum(T x) {
 #pragma unroll 1
         for (int i = 1; i < G; ++i) s += bpermute_real(base + (i << 2), x);
         return s;
+    } else if constexpr (G == 32 && sizeof(T) == 8) {
+        // two groups per wavefront: four DPP levels inside the 16-lane rows, then rows 1 and 3 add lane 15 of the row below
+        // (row_bcast15) -- every lane of rows 1 / 3 holds its group's total, which leaves through a scalar register; the same tree as
+        // the xor butterfly (commutative adds), 10 DPP moves + 4 v_readlane instead of 10 ds_bpermute round trips
+        x += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x);
+        x += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x);
+        x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
+        x += dpp_mov<DPP_ROW_MIRROR>(x);
+        x += dpp_mov_rows<0x142, 0xA>(x);
+        const T lo = readlane_real(x, 31), hi = readlane_real(x, 63);
+        return (threadIdx.x & 32) ? hi : lo;
     } else {
         if constexpr (G >= 2) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x) : __shfl_xor(x, 1, G);
         if constexpr (G >= 4) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x) : __shfl_xor(x, 2, G);
@@ -225,12 +236,35 @@ struct CoopMlp {
     }
     static constexpr int MAXD = N::maxdim();
     static constexpr int MAXOWN = maxown();
+    // ARITH-SPEC wide-dot rule, tree case (oracle: wide_dot): a dot of n = 32 or 64 terms that reduces to fewer than 16 replicated
+    // scalars is rounded products under the binary tree over adjacent index pairs.  With term j on lane j % G (register j / G) and
+    // n a multiple of the power-of-two G, the first log2(G) levels of that tree are the xor butterfly of the group (per register),
+    // the remaining levels pair the registers in place: no all-gather of the n terms, every lane ends with the same bits.
+    static constexpr bool tree_dot(int n, int nres) { return (n == 32 || n == 64) && nres < 16; }
+    static constexpr bool tree_ok(int n) { return G > 1 && pow2_group<G>() && G <= 64 && n % G == 0; }
+    template <int CNT>
+    static __device__ __forceinline__ real tree_reduce(real (&p)[CNT]) {   // p[m] = this lane's product of term r + m * G
+        static_for<0, CNT>([&](auto m) { p[m] = group_sum<G>(p[m]); });
+        static_for<0, 6>([&](auto lv) {
+            constexpr int step = 1 << decltype(lv)::value;       // pair registers m, m + step (m a multiple of 2 * step)
+            if constexpr (step < CNT)
+                static_for<0, CNT>([&](auto m) {
+                    if constexpr (decltype(m)::value % (2 * step) == 0 && decltype(m)::value + step < CNT) p[m] = p[m] + p[decltype(m)::value + step];
+                });
+        });
+        return p[0];
+    }
 
     typedef __attribute__((address_space(3))) real lds_t;
     // all-gather of one value per lane inside a group.  Power-of-two groups: DPP / bpermute broadcasts.  Other groups
     // (G = 5): through the group's words of a wave-private LDS row -- one ds_write + three ds_read2 per gather instead
     // of ten ds_bpermute (LDS is in order per wavefront: no barrier; `gb` = this GROUP's first word)
-    static constexpr bool LDS_GATHER = !pow2_group<G>();
+    // (round 4: wide power-of-two groups too -- G = 32 gathers 32 values: one ds_write_b64 + 16 broadcast ds_read_b128 instead of 64
+    //  ds_bpermute_b32; the group's words of the wave-private row are written and read in order by one wavefront: no barrier)
+#ifndef UDE_LDS_GATHER_MIN
+#define UDE_LDS_GATHER_MIN 32
+#endif
+    static constexpr bool LDS_GATHER = !pow2_group<G>() || (G >= UDE_LDS_GATHER_MIN && G <= 64);
     template <int CNT>
     static __device__ __forceinline__ void allgather(lds_t* gb, int r, const real* own, real* out) {
         if constexpr (LDS_GATHER) {
@@ -285,6 +319,14 @@ struct CoopMlp {
     template <class WS>
     static constexpr bool ws_is_reg = std::is_same<WS, WReg>::value;
 
+    // parameter `idx` of a pointer-like weight source (the tree layers read theta in place; they are compiled for pointer sources
+    // only -- the register copy holds rows, a tree layer wants the columns at the lane's inputs)
+    template <class WS>
+    static __device__ __forceinline__ real th_at(const WS& th, int idx) {
+        if constexpr (ws_is_reg<WS>) { (void)th; (void)idx; return real(0); }
+        else return (real)th[idx];
+    }
+
     // th: NN parameters (LDS or global) or a WReg; r: lane index inside the group
     template <class WS>
     static __device__ __forceinline__ void forward(const WS& th, int r, const real* x, Cache& c, real* y) {
@@ -292,6 +334,26 @@ struct CoopMlp {
         static_for<0, L>([&](auto lc) {
             constexpr int l = lc;
             constexpr int in = N::dim(l), out = N::dim(l + 1);
+            if constexpr (l > 0 && tree_dot(in, out) && tree_ok(in) && !ws_is_reg<WS>) {
+                // a tree layer (2-32-2's output layer): every lane multiplies ITS inputs (the activations it produced in the layer
+                // below) with its weights, the group's butterfly does the rest: all `out` results arrive replicated
+                static_assert(own(l - 1) * G == in && own(l) == 1 && out <= G, "tree layer: inputs dealt evenly, one output neuron per lane at most");
+                real zall[out];
+                static_for<0, out>([&](auto ic) {
+                    constexpr int i = ic;
+                    real p[own(l - 1)];
+                    static_for<0, own(l - 1)>([&](auto m) {
+                        const int k = r + (int)decltype(m)::value * G;
+                        p[m] = th_at(th, N::off(l) + i + k * out) * c.ao[l - 1][m];
+                    });
+                    zall[i] = tree_reduce(p) + th_at(th, N::off(l) + in * out + i);
+                });
+                real zr = zall[0];
+                static_for<1, out>([&](auto i) { zr = (r == (int)decltype(i)::value) ? zall[i] : zr; });
+                c.z[l][0] = zr;
+                c.ao[l][0] = r < out ? act_fwd<N::act(l)>(zr) : real(0);
+                static_for<0, out>([&](auto i) { c.a[l + 1][i] = act_fwd<N::act(l)>(zall[i]); });
+            } else {
             static_for<0, own(l)>([&](auto mc) {
                 constexpr int m = mc;
                 const int j = r + m * G;
@@ -308,7 +370,10 @@ struct CoopMlp {
                 c.z[l][m] = acc;
                 c.ao[l][m] = valid ? act_fwd<N::act(l)>(acc) : 0.0;
             });
-            allgather<out>(c.gb, r, c.ao[l], c.a[l + 1]);
+            // (the activations feed a tree layer above: it reads them where they are -- no gather)
+            // (... unless its parameter slots go by input, KMAJ: then nothing else reads the replicated copy)
+            if constexpr (!(KMAJ && l + 2 == L && tree_dot(out, N::dim(L)) && tree_ok(out) && !ws_is_reg<WS>)) allgather<out>(c.gb, r, c.ao[l], c.a[l + 1]);
+            }
         });
         static_for<0, N::dim(L)>([&](auto k) { y[k] = c.a[L][k]; });
     }
@@ -374,6 +439,17 @@ struct CoopMlp {
             }
             if constexpr (l > 0) {
                 allgather<out>(c.gb, r, down, dall);
+            } else if constexpr (tree_dot(out, in) && tree_ok(out) && !ws_is_reg<WS>) {
+                // input cotangent as a tree (wide-dot rule: `out` = 32 or 64 terms, `in` < 16 results): products where the deltas are
+                static_assert(own(0) * G == out, "tree: the first layer's neurons are dealt evenly");
+                static_for<0, in>([&](auto k) {
+                    real p[own(0)];
+                    static_for<0, own(0)>([&](auto m) {
+                        const int j = r + (int)decltype(m)::value * G;
+                        p[m] = th_at(th, N::off(0) + j + (int)decltype(k)::value * out) * down[m];
+                    });
+                    gx[k] = tree_reduce(p);
+                });
             } else {
                 // input cotangent: gx[k] = sum_j W0[j,k] delta0[j]; every lane needs it, so gather delta0 too
                 real d0[MAXD];

@@ -146,13 +146,16 @@ struct GenericUde {
             const int jj = j < out ? j : out - 1;   // (lanes beyond the layer compute a discarded copy of the last neuron: in-bounds reads)
             const lds_t* x = arow + l * H;
             real z;
-            if (in == 64 && out < 16) {
-                // 64 terms reduced to a few replicated scalars (wide-dot rule: fewer than 16 results): rounded products, adjacent-pair
-                // tree over the wavefront (lane i = term i); 16 .. 64 results: the lane-parallel blocked chains of dot_lane
+            if ((in == 64 || in == 32) && out < 16) {
+                // 32 or 64 terms reduced to a few replicated scalars (wide-dot rule: fewer than 16 results): rounded products,
+                // adjacent-pair tree over the wavefront (lane i = term i; with 32 terms the upper half contributes -0.0, the identity
+                // of IEEE addition: x + (-0.0) == x for every x); 16 .. 64 results: the lane-parallel chains of dot_lane
                 z = real(0);
+                const int ji = j < in ? j : in - 1;
 #pragma unroll 1
                 for (int rr = 0; rr < out; ++rr) {
-                    const real s = wave_tree_sum(W[rr + (size_t)j * out] * a);
+                    const real pr = W[rr + (size_t)ji * out] * a;
+                    const real s = wave_tree_sum(j < in ? pr : real(-0.0));
                     z = (j == rr) ? s : z;
                 }
             } else {
@@ -183,11 +186,13 @@ struct GenericUde {
             delta = j < out ? delta : real(0);
             drow[l * H + j] = delta;
             real prev;
-            if (out == 64 && in < 16) {
+            if ((out == 64 || out == 32) && in < 16) {
                 prev = real(0);
+                const int jo = j < out ? j : out - 1;
 #pragma unroll 1
                 for (int k = 0; k < in; ++k) {
-                    const real s = wave_tree_sum(W[j + (size_t)k * 64] * delta);
+                    const real pr = W[jo + (size_t)k * out] * delta;
+                    const real s = wave_tree_sum(j < out ? pr : real(-0.0));
                     prev = (j == k) ? s : prev;
                 }
             } else {

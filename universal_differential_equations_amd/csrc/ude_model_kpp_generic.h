@@ -74,6 +74,24 @@ struct KppGenericUde : LinearTheta {
     static __device__ __forceinline__ real actf(int a, real z) {
         return a == ACT_TANH ? rtanh(z) : a == ACT_RBF ? rexp(-(z * z)) : a == ACT_RELU ? (z > real(0) ? z : real(0)) : z;
     }
+    // ARITH-SPEC dot of n terms (term i = w[i * ws] * x[i]) of a product with nres results (oracle: wide_dot; n <= 32 here): 32 terms
+    // reducing to fewer than 16 results are rounded products under the adjacent-pair tree, everything else one ascending fma chain
+    static __device__ __forceinline__ real dot_rule(const real* w, int ws, const real* x, int n, int nres) {
+        if (n == 32 && nres < 16) {
+            real v[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = w[i * ws] * x[i];
+#pragma unroll
+            for (int m = 32; m > 1; m >>= 1)
+#pragma unroll
+                for (int i = 0; i < m / 2; ++i) v[i] = v[2 * i] + v[2 * i + 1];
+            return v[0];
+        }
+        real acc = real(0);
+#pragma unroll 4
+        for (int k = 0; k < n; ++k) acc = rfma(w[k * ws], x[k], acc);
+        return acc;
+    }
     static __device__ __forceinline__ real dactf(int a, real z, real av) {
         return a == ACT_TANH ? rfma(-av, av, real(1)) : a == ACT_RBF ? (real(-2) * z) * av : a == ACT_RELU ? (z > real(0) ? real(1) : real(0)) : real(1);
     }
@@ -91,9 +109,7 @@ struct KppGenericUde : LinearTheta {
             const real* W = c.nn + off;
 #pragma unroll 1
             for (int j = 0; j < out; ++j) {
-                real acc = real(0);
-#pragma unroll 4
-                for (int k = 0; k < in; ++k) acc = rfma(W[j + k * out], a[aoff + k], acc);
+                real acc = dot_rule(W + j, out, a + aoff, in, out);
                 acc += W[in * out + j];
                 const real av = actf(actl, acc);
                 if (l + 1 < c.L) a[aoff + in + j] = av; else y = av;
@@ -124,17 +140,9 @@ struct KppGenericUde : LinearTheta {
                 const int pin = c.mc->dims[l];   // = in: the outputs of layer l - 1
                 real* dp = d + doff - pin;
 #pragma unroll 1
-                for (int k = 0; k < in; ++k) {
-                    real s = real(0);
-#pragma unroll 4
-                    for (int j = 0; j < out; ++j) s = rfma(W[j + k * out], d[doff + j], s);
-                    dp[k] = s;
-                }
+                for (int k = 0; k < in; ++k) dp[k] = dot_rule(W + k * out, 1, d + doff, out, in);
             } else {
-                real s = real(0);
-#pragma unroll 4
-                for (int j = 0; j < out; ++j) s = rfma(W[j], d[doff + j], s);   // in == 1
-                gx = s;
+                gx = dot_rule(W, 1, d + doff, out, 1);   // in == 1
             }
         }
         return gx;
