@@ -19,7 +19,7 @@ NETS = {
     "hudson": (lambda: models.ude_dynamics(models.hudson_chain(), trainable="both"), O.lv_ude_hudson,
                lambda rng, g: np.concatenate([[1.3, 1.8], 0.3 * rng.standard_normal(87)]), (0, 8)),
     "tanh32": (lambda: models.ude_dynamics(models.tanh32_chain()), O.lv_ude_tanh32,
-               lambda rng, g: 0.1 * models.tanh32_chain().glorot_uniform(rng), (0, 8, 32)),
+               lambda rng, g: 0.1 * models.tanh32_chain().glorot_uniform(rng), (0, 8, 16, 32)),
 }
 
 

@@ -664,8 +664,9 @@ def test_mfma_f64_is_the_ascending_fused_chain():
 
 
 def test_tanh32_wide_lane_group_variant():
-    """BASELINE's '2-layer tanh' (2-32-2): the default is 8 lanes per trajectory; the 32-lane build (one neuron per lane)
-    must return the same bits."""
+    """BASELINE's '2-layer tanh' (2-32-2): every compiled lane-group width (8, 16, 32 lanes per trajectory = 4, 2, 1 hidden neurons per
+    lane; 0 = the library's default) must return the same bits -- the output layer and the input cotangent are 32-term tree sums
+    (ARITH-SPEC wide-dot rule) formed by the group's butterfly plus register pairs, a different split per width."""
     rng = np.random.default_rng(3)
     N = 24
     t = np.arange(31) * 0.1
@@ -674,7 +675,7 @@ def test_tanh32_wide_lane_group_variant():
     data, _, rc = O.solve_ensemble(O.lv_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 3.0], [1.3, 0.9, 0.8, 1.8], t)
     ens = U.EnsembleProblem(U.ODEProblem(models.ude_dynamics(models.tanh32_chain()), u0[0], (0.0, 3.0), th), u0)
     ref = O.loss_grad_ensemble(O.lv_ude_tanh32(), O.opts(O.TSIT5, 1e-6, 1e-6), u0, [0.0, 3.0], th, t, data, nthreads=4)
-    for lanes in (0, 8):
+    for lanes in (0, 8, 16, 32):
         r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, abstol=1e-6, reltol=1e-6,
                                 **({"ensemblealg": U.EnsembleMI355(lanes)} if lanes else {}))
         check_per_trajectory(r, ref)

@@ -39,6 +39,7 @@ MODELS = [
     ("MID_LV_S1", "LvUde<NetS1,8>", 8, 1),
     ("MID_LV_HUDSON", "LvUde<NetHudson,8>", 8, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,8>", 8, 1),
+    ("MID_LV_TANH32", "LvUde<NetTanh32,16>", 16, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,32>", 32, 1),
     ("MID_SEIR_TRUE", "SeirTrue<1>", 1, 1),
     ("MID_SEIR_UDE", "SeirUde<64>", 64, 1, 256),

@@ -111,11 +111,13 @@ __device__ __forceinline__ T group_sum(T x) {
         const T lo = readlane_real(x, 31), hi = readlane_real(x, 63);
         return (threadIdx.x & 32) ? hi : lo;
     } else {
-        if constexpr (G >= 2) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x) : __shfl_xor(x, 1, G);
-        if constexpr (G >= 4) x += (G == 4 || G == 8) ? dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x) : __shfl_xor(x, 2, G);
-        if constexpr (G >= 8) x += (G == 8) ? dpp_mov<DPP_ROW_HALF_MIRROR>(x) : __shfl_xor(x, 4, G);
+        constexpr bool DPPG = (G == 4 || G == 8 || G == 16);   // groups inside a 16-lane row: every level is a DPP move
+        if constexpr (G >= 2) x += DPPG ? dpp_mov<DPP_QUAD(1, 0, 3, 2)>(x) : __shfl_xor(x, 1, G);
+        if constexpr (G >= 4) x += DPPG ? dpp_mov<DPP_QUAD(2, 3, 0, 1)>(x) : __shfl_xor(x, 2, G);
+        if constexpr (G >= 8) x += DPPG ? dpp_mov<DPP_ROW_HALF_MIRROR>(x) : __shfl_xor(x, 4, G);
+        if constexpr (G >= 16) x += DPPG ? dpp_mov<DPP_ROW_MIRROR>(x) : __shfl_xor(x, 8, G);
 #pragma unroll
-        for (int m = 8; m < G; m <<= 1) x += __shfl_xor(x, m, G);
+        for (int m = 16; m < G; m <<= 1) x += __shfl_xor(x, m, G);
         return x;
     }
 }
@@ -221,8 +223,11 @@ struct CoopMlp {
     // (in <= G, one neuron of the layer below per lane) its slots go by INPUT instead: lane r owns W[:, r] (out slots) and,
     // for r < out, the bias b[r] -- out + 1 slots per lane instead of in + 1 (LV 2-5-5-5-2 on 5 lanes: 21 -> 18 slots).
     // Every slot value is the same product as before (delta_j * a_r with delta replicated, a_r the lane's own activation).
-    static constexpr bool KMAJ = (G > 1) && (L >= 2) && (N::dim(L - 1) <= G) && (own(L - 2 >= 0 ? L - 2 : 0) == 1);
-    static constexpr int layer_slots(int l) { return (KMAJ && l == L - 1) ? N::dim(L) + 1 : own(l) * (N::dim(l) + 1); }
+    // (round 4: also when every lane holds SEVERAL inputs of the last layer, dealt evenly -- 2-32-2 on 8 lanes: lane r owns W[:, r + 8m],
+    //  m < 4: 4 * 2 + 1 = 9 slots instead of 33, and nothing reads the replicated copy of the 32 activations any more)
+    static constexpr int OM = own(L - 2 >= 0 ? L - 2 : 0);   // inputs of the last layer per lane
+    static constexpr bool KMAJ = (G > 1) && (L >= 2) && (N::dim(L) <= G) && (OM == 1 ? N::dim(L - 1) <= G : N::dim(L - 1) == OM * G);
+    static constexpr int layer_slots(int l) { return (KMAJ && l == L - 1) ? OM * N::dim(L) + 1 : own(l) * (N::dim(l) + 1); }
     static constexpr int slot_off(int l) {
         int o = 0;
         for (int i = 0; i < l; ++i) o += layer_slots(i);
@@ -254,6 +259,14 @@ struct CoopMlp {
         });
         return p[0];
     }
+
+    // A narrow linear LAST layer (LV: 5 -> 2) is computed REPLICATED: its inputs are on every lane already (the gather below it), so
+    // every lane runs the `out` chains itself -- the same fma chains, hence the same bits -- instead of one chain on `out` lanes
+    // followed by a second gather: one LDS / DPP round trip less in the latency chain of every evaluation.
+    static constexpr bool rep_last(int l) {
+        return G > 1 && L >= 2 && l == L - 1 && N::dim(L) <= G && N::dim(L) * N::dim(L - 1) <= 16 && !(tree_dot(N::dim(L - 1), N::dim(L)) && tree_ok(N::dim(L - 1)));
+    }
+    static constexpr int REP_OUT = rep_last(L - 1) ? N::dim(L) : 1;
 
     typedef __attribute__((address_space(3))) real lds_t;
     // all-gather of one value per lane inside a group.  Power-of-two groups: DPP / bpermute broadcasts.  Other groups
@@ -292,6 +305,7 @@ struct CoopMlp {
         real row[L][MAXOWN][MAXD + 1];  // [l][m][k], bias at k = dim(l)
         real col[L][MAXOWN][MAXD];      // [l][m][i] = W_{l+1}[i, j]
         real w0[MAXD * MAXD];           // W_0[j + k*out]
+        real last[REP_OUT][MAXD + 1];   // replicated last layer (rep_last): every row of W_{L-1}, bias at k = dim(L-1)
     };
     template <class P>
     static __device__ __forceinline__ void load_weights(const P* th, int r, WReg& w) {
@@ -313,6 +327,12 @@ struct CoopMlp {
             });
         });
         static_for<0, N::dim(0) * N::dim(1)>([&](auto i) { w.w0[i] = (real)th[N::off(0) + i]; });
+        if constexpr (rep_last(L - 1)) {
+            constexpr int in = N::dim(L - 1), out = N::dim(L);
+            static_for<0, out>([&](auto i) {
+                static_for<0, in + 1>([&](auto k) { w.last[i][k] = (real)th[N::off(L - 1) + (int)decltype(i)::value + (int)decltype(k)::value * out]; });
+            });
+        }
     }
 
     // WS = const P* (weights read from LDS/global at every use) or WReg (register-resident copy)
@@ -325,6 +345,12 @@ struct CoopMlp {
     static __device__ __forceinline__ real th_at(const WS& th, int idx) {
         if constexpr (ws_is_reg<WS>) { (void)th; (void)idx; return real(0); }
         else return (real)th[idx];
+    }
+
+    template <int I, int K, class WS>
+    static __device__ __forceinline__ real last_at(const WS& th) {   // W_{L-1}[I, K]; K = dim(L-1): the bias of output I
+        if constexpr (ws_is_reg<WS>) return th.last[I][K];
+        else return (real)th[N::off(L - 1) + I + K * N::dim(L)];
     }
 
     // th: NN parameters (LDS or global) or a WReg; r: lane index inside the group
@@ -347,6 +373,19 @@ struct CoopMlp {
                         p[m] = th_at(th, N::off(l) + i + k * out) * c.ao[l - 1][m];
                     });
                     zall[i] = tree_reduce(p) + th_at(th, N::off(l) + in * out + i);
+                });
+                real zr = zall[0];
+                static_for<1, out>([&](auto i) { zr = (r == (int)decltype(i)::value) ? zall[i] : zr; });
+                c.z[l][0] = zr;
+                c.ao[l][0] = r < out ? act_fwd<N::act(l)>(zr) : real(0);
+                static_for<0, out>([&](auto i) { c.a[l + 1][i] = act_fwd<N::act(l)>(zall[i]); });
+            } else if constexpr (rep_last(l)) {
+                real zall[out];
+                static_for<0, out>([&](auto ic) {
+                    constexpr int i = ic;
+                    real acc = 0.0;
+                    static_for<0, in>([&](auto k) { acc = rfma(last_at<i, decltype(k)::value>(th), c.a[l][k], acc); });
+                    zall[i] = acc + last_at<i, in>(th);
                 });
                 real zr = zall[0];
                 static_for<1, out>([&](auto i) { zr = (r == (int)decltype(i)::value) ? zall[i] : zr; });
@@ -431,14 +470,17 @@ struct CoopMlp {
             if constexpr (WANT_PARAM && KMAJ && l == L - 1) {
                 // slots by input: dall still holds the (replicated) deltas of this linear layer = gy
                 constexpr int s0 = slot_off(L - 1);
-                const real ak = c.ao[L - 2][0];  // this lane's own activation below = a_{L-1}[r] (0 on lanes without a neuron)
-                static_for<0, out>([&](auto j) { g[s0 + j] = dall[j] * ak; });
+                static_for<0, OM>([&](auto m) {
+                    const real ak = c.ao[L - 2][m];  // this lane's own activation below = a_{L-1}[r + m G] (0 on lanes without a neuron)
+                    static_for<0, out>([&](auto j) { g[s0 + (int)decltype(m)::value * out + j] = dall[j] * ak; });
+                });
                 real gb = dall[0];
                 static_for<1, out>([&](auto i) { gb = (r == i) ? dall[i] : gb; });
-                g[s0 + out] = r < out ? gb : 0.0;
+                g[s0 + OM * out] = r < out ? gb : 0.0;
             }
             if constexpr (l > 0) {
-                allgather<out>(c.gb, r, down, dall);
+                // (the output layer is linear: its deltas ARE the replicated output cotangent, gy[j] * 1 -- dall holds them already)
+                if constexpr (l < L - 1) allgather<out>(c.gb, r, down, dall);
             } else if constexpr (tree_dot(out, in) && tree_ok(out) && !ws_is_reg<WS>) {
                 // input cotangent as a tree (wide-dot rule: `out` = 32 or 64 terms, `in` < 16 results): products where the deltas are
                 static_assert(own(0) * G == out, "tree: the first layer's neurons are dealt evenly");
@@ -477,7 +519,7 @@ struct CoopMlp {
             if constexpr (KMAJ && l == L - 1) {
                 if (s >= lo && s < hi) {
                     const int q = s - lo;
-                    if (q < out) { if (r < in) res = N::off(l) + q + r * out; }
+                    if (q < OM * out) { const int k = r + (q / out) * G; if (k < in) res = N::off(l) + q % out + k * out; }
                     else if (r < out) res = N::off(l) + in * out + r;
                 }
             } else

@@ -364,8 +364,9 @@ static int default_lanes(int mid, bool discrete) {
         case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
         case MID_LV_HUDSON:
         case MID_LV_HUDSON_F32: return 8;
-        case MID_LV_TANH32: return 32;  // one hidden neuron per lane: ~6 parameter slots per lane, 253 registers = two wavefronts per SIMD;
-                                        // 10k-trajectory gradient 4.9 ms against 6.8 ms with 8 lanes and 9.5 ms with 16 (round-3 measurement)
+        case MID_LV_TANH32: return 16;  // two hidden neurons per lane, four trajectories per wavefront, 253 registers = two wavefronts per SIMD.
+                                        // Round 4 (32-term tree sums by the group's butterfly, parameter slots by input): 10k-trajectory gradient
+                                        // 1.98 ms against 2.27 ms with 8 lanes and 2.28 ms with 32; 16 lanes stay ahead from 5k to 40k trajectories
         case MID_SEIR_TRUE: return 1;
         case MID_SEIR_UDE: return 64;  // wavefront per trajectory, 4 per block
         case MID_SEIR_NODE: return 64;  // wavefront per trajectory, 3 per block (two 64x64 layers + the compacted stage factors fill the LDS)
