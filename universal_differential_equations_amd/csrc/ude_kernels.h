@@ -48,14 +48,15 @@ struct KParams {
     real* u_out;         // n x ns x N or null
     int64_t* stats;        // 8 x N or null
     int32_t* retcode;      // N
-    // dense forward store (SoA, field-major: [(step*NF + field)*Npad + traj]); null for plain solves
+    // dense forward store (replicated states: SoA, field-major [(step*NF + field)*Npad + traj]; distributed states: one contiguous record
+    // per (traj, step) -- dense_rec / dense_fs below); null for plain solves
     real* dense;
     int32_t* dense_n;
     // loss / cotangent
     const real* data;       // n x ns x N or null
     const uint8_t* row_mask;  // n or null
     const real* cot_in;     // n x ns x N user cotangent or null
-    real* cot;              // SoA [(i*n + c)*Npad + traj] written by the forward kernel when data != null
+    real* cot;              // SoA [(i*n + c)*Npad + traj] (distributed states: [(traj*ns + i)*n + c]) written by the forward kernel when data != null
     real* loss_traj;        // N
     // backward outputs
     real* grad_part;  // [nwaves_total][np] per-wave partial gradients
@@ -77,6 +78,19 @@ struct KParams {
     // caller's np x N array, row j written by trajectory j's lanes; no sum over trajectories).  0 = one shared theta.
     int32_t theta_pm;
 };
+
+// Workspace layouts.  Replicated states -- the lanes of a wavefront belong to different trajectories -- keep the dense store and the
+// cotangent rows as SoA, field-major: field f of step s of trajectory j at (s nf + f) Npad + j (adjacent trajectories adjacent).
+// Distributed states -- a PDE's grid dealt over the lanes of its wavefronts -- keep every record contiguous instead: record (j, s) at
+// (j cap + s) nf, field stride 1, so the lanes' components are adjacent words (round 4: with the SoA layout every 8-byte
+// component sat in a cache line of its own -- the 6x read amplification of the Fisher-KPP adjoint in profiles/r03_pmc_kpp.md)
+template <bool DIST>
+__device__ __forceinline__ size_t dense_fs(const KParams& p) { return DIST ? (size_t)1 : (size_t)p.Npad; }
+template <bool DIST>
+__device__ __forceinline__ real* dense_rec(const KParams& p, int s, int nf, int64_t j) {
+    return DIST ? p.dense + ((size_t)j * p.cap + s) * nf : p.dense + ((size_t)s * nf) * p.Npad + j;
+}
+
 
 
 // ---------------------------------------------------------------------------------------------
@@ -631,7 +645,7 @@ struct FwdSys {
                     // reach the loss -- the reference slices those rows away, seir_exposure.jl:146)
                     const real e = (p->row_mask && !p->row_mask[ci]) ? real(0) : (v[c] - d[ci]);
                     loss = rfma(e, e, loss);
-                    if (cwrite(c)) p->cot[((size_t)i * n + ci) * p->Npad + j] = real(2) * e;
+                    if (cwrite(c)) p->cot[STATE_DISTRIBUTED ? ((size_t)j * p->ns + i) * n + ci : ((size_t)i * n + ci) * p->Npad + j] = real(2) * e;
                 }
             });
         }
@@ -668,26 +682,27 @@ struct FwdSys {
             if (!p->ckpt) lazy();
             {
                 const int nf = p->ckpt ? 3 + n : 3 + n + Tab::NK * n;
-                real* base = p->dense + ((size_t)nsteps * nf) * p->Npad + j;
+                const size_t DFS = dense_fs<STATE_DISTRIBUTED>(*p);
+                real* base = dense_rec<STATE_DISTRIBUTED>(*p, nsteps, nf, j);
                 if (writer) {
                     base[0] = tprev;
-                    base[(size_t)1 * p->Npad] = t;
-                    base[(size_t)2 * p->Npad] = dt;
+                    base[(size_t)1 * DFS] = t;
+                    base[(size_t)2 * DFS] = dt;
                 }
                 if constexpr (CPL) {
                     // lane c stores component c of u and of every stage
                     const real zo = own_of<NR>(reinterpret_cast<const real(&)[NR]>(*z));
                     if (r < n) {
-                        base[(size_t)(3 + r) * p->Npad] = zo;
-                        if (!p->ckpt) static_for<0, Tab::NK>([&](auto q) { base[(size_t)(3 + n + q * n + r) * p->Npad] = k1(q); });
+                        base[(size_t)(3 + r) * DFS] = zo;
+                        if (!p->ckpt) static_for<0, Tab::NK>([&](auto q) { base[(size_t)(3 + n + q * n + r) * DFS] = k1(q); });
                     }
                 } else {
-                static_for<0, NR>([&](auto c) { if (cwrite(c)) base[(size_t)(3 + comp(c)) * p->Npad] = z[c]; });
+                static_for<0, NR>([&](auto c) { if (cwrite(c)) base[(size_t)(3 + comp(c)) * DFS] = z[c]; });
                 if (!p->ckpt)
                 static_for<0, Tab::NK>([&](auto q) {
                     // every stage is stored (the discrete adjoint needs k2, k3, k10 too, not only the dense-output ones)
                     static_for<0, NR>([&](auto c) {
-                        if (cwrite(c)) base[(size_t)(3 + n + q * n + comp(c)) * p->Npad] = k(q, c);
+                        if (cwrite(c)) base[(size_t)(3 + n + q * n + comp(c)) * DFS] = k(q, c);
                     });
                 });
                 }
@@ -858,7 +873,7 @@ struct AdjSys {
     __device__ __forceinline__ real US(int c) const { if constexpr (IC_LDS) return ic[c * icstride]; else return us[c]; }
     __device__ __forceinline__ real KS(int q, int c) const {
         if constexpr (IC_LDS) return ic[(NR + q * NR + c) * icstride];
-        else if constexpr (KS_STREAM) return cvalid(c) ? kstore[(size_t)(3 + n + q * n + comp(c)) * p->Npad] : real(0);
+        else if constexpr (KS_STREAM) return cvalid(c) ? kstore[(size_t)(3 + n + q * n + comp(c)) * dense_fs<STATE_DISTRIBUTED>(*p)] : real(0);
         else return ks[q][c];
     }
     // cotangent access
@@ -877,7 +892,7 @@ struct AdjSys {
             pf_s = s;
             if (s >= 0) {
                 const int nf = 3 + n + Tab::NK * n;
-                const real* base = p->dense + ((size_t)s * nf) * p->Npad + j;
+                const real* base = dense_rec<STATE_DISTRIBUTED>(*p, s, nf, j);
                 pf_ts = base[0];
                 static_for<0, PF_N>([&](auto q) {
                     const int f = mctx.r + (int)decltype(q)::value * G;
@@ -904,17 +919,18 @@ struct AdjSys {
         }
         sf = s;
         const int nf = RECOMPUTE ? 3 + n : 3 + n + Tab::NK * n;
-        const real* base = p->dense + ((size_t)s * nf) * p->Npad + j;
+        const size_t DFS = dense_fs<STATE_DISTRIBUTED>(*p);
+        const real* base = dense_rec<STATE_DISTRIBUTED>(*p, s, nf, j);
         ts = base[0];
-        te = base[(size_t)1 * p->Npad];
+        te = base[(size_t)1 * DFS];
         if constexpr (RECOMPUTE) {
-            const real dtf = base[(size_t)2 * p->Npad];   // the step size the forward pass used (t_end may be a snapped tstop)
+            const real dtf = base[(size_t)2 * DFS];   // the step size the forward pass used (t_end may be a snapped tstop)
             const TabDevT<real>* tab = p->tab;
             if constexpr (CPL) {
                 // component-per-lane: lane c keeps component c of u and of every k; a stage point is formed by that lane
                 // (Driver::run's CPL chain: terms j < s only) and broadcast, the right-hand side runs on the replicated point
                 const bool on = mctx.r < n;
-                us[0] = on ? base[(size_t)(3 + (on ? mctx.r : 0)) * p->Npad] : 0.0;
+                us[0] = on ? base[(size_t)(3 + (on ? mctx.r : 0)) * DFS] : 0.0;
                 static_for<0, Tab::NK>([&](auto q) { ks[q][0] = 0.0; });
                 static_for<0, Tab::NK>([&](auto sc) {
                     constexpr int st = decltype(sc)::value;
@@ -931,7 +947,7 @@ struct AdjSys {
                     ks[st][0] = own_of(kr);
                 });
             } else {
-            static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p->Npad] : 0.0; });
+            static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * DFS] : 0.0; });
             static_for<0, Tab::NK>([&](auto q) { static_for<0, NR>([&](auto c) { ks[q][c] = 0.0; }); });
             static_for<0, Tab::NK>([&](auto sc) {
                 constexpr int st = decltype(sc)::value;
@@ -960,25 +976,25 @@ struct AdjSys {
             // the G lanes of the group fetch the fields round-robin and publish them in the group's LDS row
             asm volatile("" ::: "memory");
             if constexpr (G > 64) __syncthreads();  // (block-uniform: t is replicated) readers of the old row are done
-            for (int f = mctx.r; f < IC_FIELDS; f += G) ic[f * icstride] = base[(size_t)(3 + f) * p->Npad];
+            for (int f = mctx.r; f < IC_FIELDS; f += G) ic[f * icstride] = base[(size_t)(3 + f) * DFS];
             if constexpr (G > 64) __syncthreads();
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             prefetch_interval(s - 1);
         } else if constexpr (CPL) {
             const bool on = mctx.r < n;
             const int rc = on ? mctx.r : 0;
-            us[0] = on ? base[(size_t)(3 + rc) * p->Npad] : 0.0;
+            us[0] = on ? base[(size_t)(3 + rc) * DFS] : 0.0;
             static_for<0, Tab::NK>([&](auto q) {
-                if constexpr (Tab::dense_uses(q)) ks[q][0] = on ? base[(size_t)(3 + n + q * n + rc) * p->Npad] : 0.0;
+                if constexpr (Tab::dense_uses(q)) ks[q][0] = on ? base[(size_t)(3 + n + q * n + rc) * DFS] : 0.0;
             });
         } else {
-            static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p->Npad] : 0.0; });
+            static_for<0, NR>([&](auto c) { us[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * DFS] : 0.0; });
             if constexpr (KS_STREAM) kstore = base;
             else
             static_for<0, Tab::NK>([&](auto q) {
                 if constexpr (Tab::dense_uses(q))
                     static_for<0, NR>([&](auto c) {
-                        ks[q][c] = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * p->Npad] : 0.0;
+                        ks[q][c] = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * DFS] : 0.0;
                     });
             });
         }
@@ -1185,8 +1201,8 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         sys.ic = icbase + threadIdx.x / G;
         sys.icstride = BLOCK / G;
         sys.nsteps = p.dense_n[gid];
-        if (p.cot_in) {
-            sys.cot = p.cot_in + (size_t)gid * p.ns * p.n_state;
+        if (p.cot_in || Model::STATE_DISTRIBUTED) {   // (distributed states keep a trajectory's cotangent rows contiguous)
+            sys.cot = (p.cot_in ? p.cot_in : p.cot) + (size_t)gid * p.ns * p.n_state;
             sys.cot_si = p.n_state;
             sys.cot_sc = 1;
         } else {
@@ -1346,15 +1362,15 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         tg.init(p, gid);
         const real* kdense = nullptr;  // first stage field of the current step in the dense store (KD)
         auto K = [&](int j, int c) -> real {
-            if constexpr (KD) return cvalid(c) ? kdense[(size_t)(j * n + comp(c)) * p.Npad] : 0.0;
+            if constexpr (KD) return cvalid(c) ? kdense[(size_t)(j * n + comp(c)) * dense_fs<DIST>(p)] : 0.0;
             else return kbase[(j * NR + c) * KSTRIDE + koff];
         };
         auto KB = [&](int j, int c) -> real& { return kbbase[(j * NR + c) * KSTRIDE + koff]; };
         const TabDev* tab = p.tab;
         const real* cot;
         size_t cot_si, cot_sc;
-        if (p.cot_in) {
-            cot = p.cot_in + (size_t)gid * p.ns * n;
+        if (p.cot_in || DIST) {
+            cot = (p.cot_in ? p.cot_in : p.cot) + (size_t)gid * p.ns * n;
             cot_si = n;
             cot_sc = 1;
         } else {
@@ -1399,18 +1415,20 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             real tn, tn1, dt, u[NR], k[PREF ? NK : 1][NR];
         };
         auto fetch_step = [&](int st, StepRec& rec) {
-            const real* base = p.dense + ((size_t)st * nf) * p.Npad + gid;
-            rec.tn = base[0]; rec.tn1 = base[(size_t)1 * p.Npad]; rec.dt = base[(size_t)2 * p.Npad];
-            static_for<0, NR>([&](auto c) { rec.u[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * p.Npad] : real(0); });
+            const size_t DFS = dense_fs<DIST>(p);
+            const real* base = dense_rec<DIST>(p, st, nf, gid);
+            rec.tn = base[0]; rec.tn1 = base[(size_t)1 * DFS]; rec.dt = base[(size_t)2 * DFS];
+            static_for<0, NR>([&](auto c) { rec.u[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * DFS] : real(0); });
             if constexpr (PREF)
                 static_for<0, NK>([&](auto q) {
-                    static_for<0, NR>([&](auto c) { rec.k[q][c] = cvalid(c) ? base[(size_t)(3 + n + (int)decltype(q)::value * n + comp(c)) * p.Npad] : real(0); });
+                    static_for<0, NR>([&](auto c) { rec.k[q][c] = cvalid(c) ? base[(size_t)(3 + n + (int)decltype(q)::value * n + comp(c)) * DFS] : real(0); });
                 });
         };
         StepRec nxt;
         if constexpr (PREF) { if (nsteps > 0) fetch_step(nsteps - 1, nxt); }
         for (int st = nsteps - 1; st >= 0; --st) {
-            const real* base = p.dense + ((size_t)st * nf) * p.Npad + gid;
+            const size_t DFS = dense_fs<DIST>(p);
+            const real* base = dense_rec<DIST>(p, st, nf, gid);
             StepRec cur;
             if constexpr (PREF) {
                 cur = nxt;
@@ -1421,7 +1439,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             const real tn = cur.tn, tn1 = cur.tn1, dt = cur.dt;
             real u_n[NR];
             static_for<0, NR>([&](auto c) { u_n[c] = cur.u[c]; });
-            kdense = base + (size_t)(3 + n) * p.Npad;
+            kdense = base + (size_t)(3 + n) * DFS;
             if constexpr (PREF) {
                 static_for<0, NK>([&](auto q) {
                     static_for<0, NR>([&](auto c) { kbase[((int)decltype(q)::value * NR + c) * KSTRIDE + koff] = cur.k[q][c]; });
@@ -1429,7 +1447,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             } else {
             for (int q = 0; q < NK; ++q)
                 static_for<0, NR>([&](auto c) {
-                    if constexpr (!KD) kbase[(q * NR + c) * KSTRIDE + koff] = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * p.Npad] : 0.0;
+                    if constexpr (!KD) kbase[(q * NR + c) * KSTRIDE + koff] = cvalid(c) ? base[(size_t)(3 + n + q * n + comp(c)) * DFS] : 0.0;
                 });
             }
             // (1) saves exactly at the step end feed the cotangent of u_{n+1}
