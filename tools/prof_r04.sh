@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 profiling pass on the MI355X box (run through gpurun): for every bench workload the bench line, a rocprofv3
-# kernel trace (--stats) and the PMC passes (one counter group per run, --kernel-trace only; FETCH_SIZE / WRITE_SIZE in
+# Round-4 profiling pass on the MI355X box (run through gpurun): for every bench workload a rocprofv3 kernel trace (--stats), the PMC
+# passes and then the bench line (one counter group per run, --kernel-trace only; FETCH_SIZE / WRITE_SIZE in
 # their own runs).  Summaries land in gpurun_out/; the ones committed under profiles/ are copies of these files.
 #   PROF_W="seir node" refreshes only those workloads; PROF_PMC=0 skips the counter passes.
 export TMPDIR=/tmp
@@ -9,13 +9,6 @@ cd $R
 WL=${PROF_W:-"lv seir kpp hjb node lv_tanh32 lv_discrete"}
 has() { case " $WL " in *" $1 "*) return 0;; *) return 1;; esac; }
 args() { case $1 in lv_tanh32) echo "--workload lv --net tanh32";; lv_discrete) echo "--workload lv --sensealg discrete";; *) echo "--workload $1";; esac; }
-has lv && python bench.py --steps 20 --warmup 3 > $O/r04_bench_lv.json 2> $O/r04_bench.err
-for W in $WL; do
-  [ $W = lv ] && continue
-  case $W in lv_*) ST="--steps 20 --warmup 3";; *) ST="--steps 3 --warmup 1";; esac
-  python bench.py $(args $W) $ST --no-others > $O/r04_bench_$W.json 2>/dev/null
-done
-has hjb && python bench.py --workload hjb --steps 5 --warmup 2 --traj 8192 --no-cpu-baseline > $O/r04_bench_hjb_8k.json 2>/dev/null
 cd /tmp
 for W in $WL; do
   case $W in lv*) ST="--steps 10 --warmup 2";; *) ST="--steps 2 --warmup 1";; esac
@@ -30,5 +23,16 @@ for W in $WL; do
     ( cd $R; python tools/pmc_summary.py $O/r04_pmc_${W}.md $(find $O/p4_${W}_f $O/p4_${W}_w $O/p4_${W}_1 $O/p4_${W}_2 -name "*.db") > /dev/null 2>>$O/p4.err )
   fi
 done
+# the bench lines come LAST: bench.py takes roofline.traffic from profiles/r04_pmc_<workload>.md, i.e. from the counter passes just made
+# (copied into this box's checkout; the committed copies are the same files, merged back through gpurun_out/)
+cp $O/r04_pmc_*.md $R/profiles/ 2>/dev/null
+cd $R
+has lv && python bench.py --steps 20 --warmup 3 > $O/r04_bench_lv.json 2> $O/r04_bench.err
+for W in $WL; do
+  [ $W = lv ] && continue
+  case $W in lv_*) ST="--steps 20 --warmup 3";; *) ST="--steps 3 --warmup 1";; esac
+  python bench.py $(args $W) $ST --no-others > $O/r04_bench_$W.json 2>/dev/null
+done
+has hjb && python bench.py --workload hjb --steps 5 --warmup 2 --traj 8192 --no-cpu-baseline > $O/r04_bench_hjb_8k.json 2>/dev/null
 rm -rf $O/p4_*_kt $O/p4_*_f $O/p4_*_w $O/p4_*_1 $O/p4_*_2
 ls $O | head -60; for W in $WL; do head -5 $O/r04_kernel_stats_${W}.md; done

@@ -81,9 +81,11 @@ struct KParams {
 
 // Workspace layouts.  Replicated states -- the lanes of a wavefront belong to different trajectories -- keep the dense store and the
 // cotangent rows as SoA, field-major: field f of step s of trajectory j at (s nf + f) Npad + j (adjacent trajectories adjacent).
-// Distributed states -- a PDE's grid dealt over the lanes of its wavefronts -- keep every record contiguous instead: record (j, s) at
-// (j cap + s) nf, field stride 1, so the lanes' components are adjacent words (round 4: with the SoA layout every 8-byte
-// component sat in a cache line of its own -- the 6x read amplification of the Fisher-KPP adjoint in profiles/r03_pmc_kpp.md)
+// Distributed states -- a PDE's grid dealt over the lanes of its wavefronts -- and component-per-lane models (CPL: one wavefront per
+// trajectory, lane c = component c; the lock-step SEIR / neural-ODE kernels fetch a record with the sixteen lanes of a slot's row)
+// keep every record contiguous instead: record (j, s) at (j cap + s) nf, field stride 1, so the lanes' components are adjacent
+// words (round 4: with the SoA layout every 8-byte component sat in a cache line of its own -- the 6x read amplification of the
+// Fisher-KPP adjoint in profiles/r03_pmc_kpp.md; FETCH 6.2 -> 0.44 GB per launch)
 template <bool DIST>
 __device__ __forceinline__ size_t dense_fs(const KParams& p) { return DIST ? (size_t)1 : (size_t)p.Npad; }
 template <bool DIST>
@@ -682,8 +684,8 @@ struct FwdSys {
             if (!p->ckpt) lazy();
             {
                 const int nf = p->ckpt ? 3 + n : 3 + n + Tab::NK * n;
-                const size_t DFS = dense_fs<STATE_DISTRIBUTED>(*p);
-                real* base = dense_rec<STATE_DISTRIBUTED>(*p, nsteps, nf, j);
+                const size_t DFS = dense_fs<STATE_DISTRIBUTED || CPL>(*p);
+                real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, nsteps, nf, j);
                 if (writer) {
                     base[0] = tprev;
                     base[(size_t)1 * DFS] = t;
@@ -873,7 +875,7 @@ struct AdjSys {
     __device__ __forceinline__ real US(int c) const { if constexpr (IC_LDS) return ic[c * icstride]; else return us[c]; }
     __device__ __forceinline__ real KS(int q, int c) const {
         if constexpr (IC_LDS) return ic[(NR + q * NR + c) * icstride];
-        else if constexpr (KS_STREAM) return cvalid(c) ? kstore[(size_t)(3 + n + q * n + comp(c)) * dense_fs<STATE_DISTRIBUTED>(*p)] : real(0);
+        else if constexpr (KS_STREAM) return cvalid(c) ? kstore[(size_t)(3 + n + q * n + comp(c)) * dense_fs<STATE_DISTRIBUTED || CPL>(*p)] : real(0);
         else return ks[q][c];
     }
     // cotangent access
@@ -892,7 +894,7 @@ struct AdjSys {
             pf_s = s;
             if (s >= 0) {
                 const int nf = 3 + n + Tab::NK * n;
-                const real* base = dense_rec<STATE_DISTRIBUTED>(*p, s, nf, j);
+                const real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, s, nf, j);
                 pf_ts = base[0];
                 static_for<0, PF_N>([&](auto q) {
                     const int f = mctx.r + (int)decltype(q)::value * G;
@@ -919,8 +921,8 @@ struct AdjSys {
         }
         sf = s;
         const int nf = RECOMPUTE ? 3 + n : 3 + n + Tab::NK * n;
-        const size_t DFS = dense_fs<STATE_DISTRIBUTED>(*p);
-        const real* base = dense_rec<STATE_DISTRIBUTED>(*p, s, nf, j);
+        const size_t DFS = dense_fs<STATE_DISTRIBUTED || CPL>(*p);
+        const real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, s, nf, j);
         ts = base[0];
         te = base[(size_t)1 * DFS];
         if constexpr (RECOMPUTE) {
@@ -1362,7 +1364,7 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         tg.init(p, gid);
         const real* kdense = nullptr;  // first stage field of the current step in the dense store (KD)
         auto K = [&](int j, int c) -> real {
-            if constexpr (KD) return cvalid(c) ? kdense[(size_t)(j * n + comp(c)) * dense_fs<DIST>(p)] : 0.0;
+            if constexpr (KD) return cvalid(c) ? kdense[(size_t)(j * n + comp(c)) * dense_fs<DIST || Model::CPL>(p)] : 0.0;
             else return kbase[(j * NR + c) * KSTRIDE + koff];
         };
         auto KB = [&](int j, int c) -> real& { return kbbase[(j * NR + c) * KSTRIDE + koff]; };
@@ -1415,8 +1417,8 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
             real tn, tn1, dt, u[NR], k[PREF ? NK : 1][NR];
         };
         auto fetch_step = [&](int st, StepRec& rec) {
-            const size_t DFS = dense_fs<DIST>(p);
-            const real* base = dense_rec<DIST>(p, st, nf, gid);
+            const size_t DFS = dense_fs<DIST || Model::CPL>(p);
+            const real* base = dense_rec<DIST || Model::CPL>(p, st, nf, gid);
             rec.tn = base[0]; rec.tn1 = base[(size_t)1 * DFS]; rec.dt = base[(size_t)2 * DFS];
             static_for<0, NR>([&](auto c) { rec.u[c] = cvalid(c) ? base[(size_t)(3 + comp(c)) * DFS] : real(0); });
             if constexpr (PREF)
@@ -1427,8 +1429,8 @@ __global__ void __launch_bounds__(BLOCK) dadj_kernel(const KParams p) {
         StepRec nxt;
         if constexpr (PREF) { if (nsteps > 0) fetch_step(nsteps - 1, nxt); }
         for (int st = nsteps - 1; st >= 0; --st) {
-            const size_t DFS = dense_fs<DIST>(p);
-            const real* base = dense_rec<DIST>(p, st, nf, gid);
+            const size_t DFS = dense_fs<DIST || Model::CPL>(p);
+            const real* base = dense_rec<DIST || Model::CPL>(p, st, nf, gid);
             StepRec cur;
             if constexpr (PREF) {
                 cur = nxt;

@@ -422,15 +422,15 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LS_FWD_PER_CU) node_ls_fwd_kernel(
                 if (nsteps >= p.cap) { ret = RET_DENSE_OVERFLOW; fin = true; }
                 else {
                     const int nf = 3 + n + NK * n;
-                    double* base = p.dense + ((size_t)nsteps * nf) * p.Npad + gid;
+                    double* base = dense_rec<true>(p, nsteps, nf, gid);   // (record-major: ude_kernels.h)
                     if (lm == 0) {
                         base[0] = tprev;
-                        base[(size_t)1 * p.Npad] = t;
-                        base[(size_t)2 * p.Npad] = dt;
+                        base[1] = t;
+                        base[2] = dt;
                     }
                     if (lm < n) {
-                        base[(size_t)(3 + lm) * p.Npad] = zo;
-                        static_for<0, NK>([&](auto q) { base[(size_t)(3 + n + (int)decltype(q)::value * n + lm) * p.Npad] = K[16 * decltype(q)::value]; });
+                        base[3 + lm] = zo;
+                        static_for<0, NK>([&](auto q) { base[3 + n + (int)decltype(q)::value * n + lm] = K[16 * decltype(q)::value]; });
                     }
                     nsteps += 1;
                 }

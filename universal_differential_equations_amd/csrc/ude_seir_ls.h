@@ -285,10 +285,10 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls_adj_kernel(const KParams p,
 
     auto fetch_interval = [&](int s) {
         pf_s = s;
-        const double* base = p.dense + ((size_t)s * nfld) * p.Npad + gid;
+        const double* base = dense_rec<true>(p, s, nfld, gid);   // (record-major: ude_kernels.h)
         static_for<0, NPF>([&](auto i) {
             const int f = lm + 16 * (int)decltype(i)::value;
-            pf[i] = base[(size_t)(f < nfld ? f : 0) * p.Npad];
+            pf[i] = base[f < nfld ? f : 0];
         });
     };
     auto load_interval = [&](int s) {
