@@ -106,9 +106,10 @@ typedef struct {
 enum { UDE_PT_TSPAN = 1, UDE_PT_SAVEAT = 2,
        /* per-member PARAMETERS: theta is np x N (column j = member j's parameters) and grad_theta comes back np x N, one gradient per
         * member, nothing summed -- LotkaVolterra/run_loops.jl:55-62 runs 500 independent recoveries, each with its own data AND its own
-        * network; `loss` is still the sum, loss_per_traj the members' own.  LV-kind models whose kernel keeps the weights in registers
-        * (the default lane counts of scenario_1 / scenario_2 / hudson_bay's chains, Float64 and Float32), interpolating adjoint and the
-        * discrete sweep; UDE_ERR_UNSUPPORTED elsewhere.  May be combined with the two flags above. */
+        * network; `loss` is still the sum, loss_per_traj the members' own.  The compiled LV-kind instances (scenario_1 / scenario_2 /
+        * hudson_bay's chains, Float64 and Float32: the member's weights live in registers; the 2-32-2 net: read from the member's
+        * column at every use), interpolating adjoint and the discrete sweep; UDE_ERR_UNSUPPORTED elsewhere.  May be combined with
+        * the two flags above. */
        UDE_PT_THETA = 4 };
 
 /* launch/tuning knobs of the HIP back end (not part of the reference surface) */

@@ -341,7 +341,8 @@ def test_wide_gradient_matrix_reduction_path():
     assert abs(r.loss - ref["loss"]) < 1e-12 * ref["loss"]
 
 
-@pytest.mark.parametrize("case", ["s1_adjoint", "s1_discrete", "hudson_adjoint", "hudson_f32_discrete", "s1_vern7_pt_grids"])
+@pytest.mark.parametrize("case", ["s1_adjoint", "s1_discrete", "hudson_adjoint", "hudson_f32_discrete", "s1_vern7_pt_grids", "tanh32_adjoint",
+                                  "tanh32_discrete"])
 def test_per_member_parameters_are_n_independent_recoveries(golden, case):
     """LotkaVolterra/run_loops.jl:55-62 runs 500 INDEPENDENT recoveries -- every member its own data and its own network -- one after
     the other; `EnsembleProblem(prob, u0s, ps = thetas)` (UDE_PT_THETA) runs them as one ensemble: member j reads its own parameter
@@ -366,6 +367,9 @@ def test_per_member_parameters_are_n_independent_recoveries(golden, case):
         t = np.array(g["solution"]["t"])
         f, om = models.ude_dynamics(), O.lv_ude_s1()
         base = np.array(g["initial_parameters"])
+        if case.startswith("tanh32"):                        # the 2-32-2 net reads its weights at every use: the member's column in HBM
+            f, om = models.ude_dynamics(models.tanh32_chain()), O.lv_ude_tanh32()
+            base = 0.3 * models.tanh32_chain().glorot_uniform(rng) + 0.02 * rng.standard_normal(162)
         alg, oalg, tol = (U.Vern7, O.VERN7, 1e-7) if "vern7" in case else (U.Tsit5, O.TSIT5, 1e-6)
     N = 17                                                   # two wavefronts of 12 (5 lanes) / three of 8 (8 lanes), the last partial
     thetas = (base[None, :] * (1 + 0.2 * rng.standard_normal((N, base.size)))).astype(dt)
@@ -394,10 +398,10 @@ def test_per_member_parameters_are_n_independent_recoveries(golden, case):
     assert abs(float(r.loss) - total) <= 1e-6 * abs(total)
 
 
-def test_per_member_parameters_are_refused_where_theta_is_read_in_the_hot_loop():
-    f = models.ude_dynamics(models.tanh32_chain())          # 2-32-2: the weights stay in LDS (shared by the block's trajectories)
-    th = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(0))
-    u0 = np.array([[0.44, 4.6], [0.5, 4.2]])
+def test_per_member_parameters_are_refused_where_no_kernel_takes_them():
+    f = models.dudt_()                                      # SEIR exposure UDE: theta lives in register fragments of the whole block
+    th = models.seir_theta(np.random.default_rng(0)) if hasattr(models, "seir_theta") else 0.1 * np.random.default_rng(0).standard_normal(4481)
+    u0 = np.array([[12e6, 0, 0, 0, 14e6, 0, 0], [12.5e6, 0, 0, 0, 14e6, 0, 0]], dtype=np.float64)
     ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 1.0), th), u0, ps=np.stack([th, th]))
     with pytest.raises(U.UdeError, match="per-member parameters"):
-        U.loss_and_gradient(ens, U.Tsit5(), np.zeros((2, 3, 2)), saveat=[0.0, 0.5, 1.0])
+        U.loss_and_gradient(ens, U.Tsit5(), np.zeros((2, 3, 7)), saveat=[0.0, 0.5, 1.0])
