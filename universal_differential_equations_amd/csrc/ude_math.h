@@ -36,13 +36,16 @@ __device__ __forceinline__ float fastlog2(float x) {
     return fexp + t5;
 }
 
+// the integer-valued double k (|k| < 2^31) as int32 WITHOUT a float -> int cast: the low word of k + 1.5 * 2^52 (exact).  A cast
+// of a NaN is undefined in the language (poison in LLVM), and exp / tanh have no NaN test in front of it; this is defined for
+// every bit pattern (a NaN gives some integer, and ldexp(NaN, anything) is NaN) and costs the one v_add_f64 the v_cvt_i32_f64 did.
+__device__ __forceinline__ int exponent_of(double k) { return __double2loint(k + 6755399441055744.0); }
+
 // correctly-rounded-by-construction exp2 for Float32 arguments (Julia evaluates its Float32 exp2
 // kernel in Float64 and rounds once): Taylor-13 of e^z in Float64 with a fixed fma order.
 __device__ __forceinline__ float exp2_f32(float x) {
 #pragma clang fp contract(off)
-    if (x != x) return x;
-    if (x > 127.0f) return __builtin_inff();
-    if (x < -126.0f) return 0.0f;
+    // (branch-free like dexp below: the special cases are selects at the end, the arithmetic runs for every argument)
     const double xd = (double)x;
     const double n = __builtin_rint(xd);
     const double z = (xd - n) * 0.6931471805599453;  // xd - n is exact
@@ -60,7 +63,10 @@ __device__ __forceinline__ float exp2_f32(float x) {
     p = __builtin_fma(p, z, 0.5);
     p = __builtin_fma(p, z, 1.0);
     p = __builtin_fma(p, z, 1.0);
-    return (float)__builtin_ldexp(p, (int)n);
+    float res = (float)__builtin_ldexp(p, exponent_of(n));
+    res = x > 127.0f ? __builtin_inff() : res;
+    res = x < -126.0f ? 0.0f : res;
+    return x != x ? x : res;
 }
 
 __device__ __forceinline__ double fastpow(double x, double y) {
@@ -108,16 +114,12 @@ __device__ __forceinline__ double taylor_13_to_3(double r) {
     return p;
 }
 
-// the integer-valued double k (|k| < 2^31) as int32 WITHOUT a float -> int cast: the low word of k + 1.5 * 2^52 (exact).  A cast
-// of a NaN is undefined in the language (poison in LLVM), and exp / tanh have no NaN test in front of it; this is defined for
-// every bit pattern (a NaN gives some integer, and ldexp(NaN, anything) is NaN) and costs the one v_add_f64 the v_cvt_i32_f64 did.
-__device__ __forceinline__ int exponent_of(double k) { return __double2loint(k + 6755399441055744.0); }
-
 __device__ __forceinline__ double dexp(double x) {
-    // (a NaN argument fails both range tests and runs through every operation below as NaN: no test of its own, which the
-    // compiler turns into an EXEC-masked branch -- four issue slots per call)
-    if (x > 709.0) return __builtin_inf();
-    if (x < -745.0) return 0.0;
+    // ONE branch-free path: the two range tests are selects at the END (round 4: as early returns the compiler made each an
+    // EXEC-masked branch -- s_and_saveexec / s_cbranch_execz / s_or around the arithmetic -- and a basic-block boundary in the middle
+    // of every network layer; LV adj_kernel 1.27 -> 1.20 ms without them).  An out-of-range argument runs through the arithmetic
+    // (finite garbage, Inf or NaN -- nothing traps) and is replaced; a NaN fails both tests and comes out as NaN.  Same bits as before
+    // for every in-range argument: the same operations.
     const double k = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(-k, 0.6931471803691238, x);
     r = __builtin_fma(-k, 1.9082149292705877e-10, r);
@@ -125,7 +127,10 @@ __device__ __forceinline__ double dexp(double x) {
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    return __builtin_ldexp(p, exponent_of(k));
+    double res = __builtin_ldexp(p, exponent_of(k));
+    res = x > 709.0 ? __builtin_inf() : res;
+    res = x < -745.0 ? 0.0 : res;
+    return res;
 }
 
 // em / d for d = em + 2, 0 <= em < 2^58: the correctly rounded quotient, bit for bit what `em / d` returns, without the operand
