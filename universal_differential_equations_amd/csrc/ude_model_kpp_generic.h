@@ -155,7 +155,7 @@ struct KppGenericUde : LinearTheta {
         real out = real(0);
         const int i = c.r;
         if (i < n) {
-            const int im = (i + n - 1) % n, ip = (i + 1) % n;
+            const int im = wrap_prev(i, n), ip = wrap_next(i, n);
             const real ui = c.urow[i];
             const real y = forward(c, ui, false);
             const real cnn = c.w1 * c.urow[im] + c.w2 * ui + c.w3 * c.urow[ip];
@@ -173,7 +173,7 @@ struct KppGenericUde : LinearTheta {
         if (i < n) {
             forward(c, c.urow[i], true);
             gxi = backward(c, c.lrow[i]);
-            const int im = (i + n - 1) % n, ip = (i + 1) % n;
+            const int im = wrap_prev(i, n), ip = wrap_next(i, n);
             dlam[0] = gxi + c.D0 * (c.w1 * c.lrow[ip] + c.w2 * c.lrow[i] + c.w3 * c.lrow[im]);   // transpose of the periodic stencil
         } else {
             dlam[0] = real(0);
@@ -196,7 +196,7 @@ struct KppGenericUde : LinearTheta {
                 } else if (kd >= 1) {
                     real s = real(0);
                     for (int q = 0; q < n; ++q) {
-                        const int im = (q + n - 1) % n, ip = (q + 1) % n;
+                        const int im = wrap_prev(q, n), ip = wrap_next(q, n);
                         if (kd == 1) s = rfma(c.lrow[q], c.urow[im], s);
                         else if (kd == 2) s = rfma(c.lrow[q], c.urow[q], s);
                         else if (kd == 3) s = rfma(c.lrow[q], c.urow[ip], s);

@@ -13,6 +13,12 @@
 #endif
 namespace ude {
 
+// neighbours on a periodic grid of n points, for 0 <= i < n: (i - 1) mod n and (i + 1) mod n without the integer division a runtime
+// `% n` costs (~25 instructions each; round 4: two of them per stencil point sat in every Fisher-KPP loop)
+__device__ __forceinline__ int wrap_prev(int i, int n) { return i == 0 ? n - 1 : i - 1; }
+__device__ __forceinline__ int wrap_next(int i, int n) { return i + 1 == n ? 0 : i + 1; }
+
+
 struct ModelConsts {
     int32_t n_state, n_param, nn_offset, stencil_offset, d0_offset;
     int32_t kind, n_layers, dims[9], act[8];  // the descriptor's chain (read by the runtime-shape model only, ude_model_generic.h)
@@ -607,7 +613,7 @@ struct KppTrue : LinearTheta {
         static_for<0, PPL>([&](auto cc) {
             const int i = cc * G + c.r;
             if (i < n) {
-                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                const int im = wrap_prev(i, n), ip = wrap_next(i, n);
                 // ARITH-SPEC dense gemv model (oracle: UDEO_KIND_KPP_TRUE): the three nonzeros of the dense row in ascending
                 // column order, column blocks of 8 -- a fused chain from 0 inside a block, block sums added in block order
                 // (the shape that reproduces the Float32 golden 243 / 39 / 1, profiles/r03_f32_golden_search.md)
@@ -712,7 +718,7 @@ struct KppUde : LinearTheta {
             const int i = cc * G + c.r;
             real out = 0.0;
             if (i < n) {
-                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                const int im = wrap_prev(i, n), ip = wrap_next(i, n);
                 typename Mlp::Cache cache;
                 real y[1];
                 const real ui = c.urow[i];
@@ -754,7 +760,7 @@ struct KppUde : LinearTheta {
             }
             // transpose of the periodic stencil (the oracle's expression)
             if (i < n) {
-                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                const int im = wrap_prev(i, n), ip = wrap_next(i, n);
                 dlam[cc] = gxi + c.D0 * (c.w1 * c.lrow[ip] + c.w2 * c.lrow[i] + c.w3 * c.lrow[im]);
             } else {
                 dlam[cc] = 0.0;
@@ -795,7 +801,7 @@ struct KppUde : LinearTheta {
                     real s = 0.0, st = 0.0;
                     for (int i = 0; i < n; ++i) {
                         if (i > 0 && i % 256 == 0) { st = i == 256 ? s : st + s; s = 0.0; }
-                        const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                        const int im = wrap_prev(i, n), ip = wrap_next(i, n);
                         if (kd == 1) s = rfma(c.lrow[i], c.urow[im], s);
                         else if (kd == 2) s = rfma(c.lrow[i], c.urow[i], s);
                         else if (kd == 3) s = rfma(c.lrow[i], c.urow[ip], s);
@@ -967,7 +973,7 @@ struct KppUdeW : LinearTheta {
             double act[L][MAXR];
             const double y = forward_tile(c, ui, act);
             if (on) {
-                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                const int im = wrap_prev(i, n), ip = wrap_next(i, n);
                 const double cnn = c.w1 * c.urow[im] + c.w2 * ui + c.w3 * c.urow[ip];
                 c.orow[i] = y + c.D0 * cnn;
             }
@@ -1046,7 +1052,7 @@ struct KppUdeW : LinearTheta {
                 if constexpr (l > 0) static_for<0, 4 * MT(in)>([&](auto q) { dcur[q] = dprev[q]; });
             });
             if (on) {  // transpose of the periodic stencil (the oracle's expression)
-                const int im = (i + n - 1) % n, ip = (i + 1) % n;
+                const int im = wrap_prev(i, n), ip = wrap_next(i, n);
                 c.orow[i] = gxi + c.D0 * (c.w1 * c.lrow[ip] + c.w2 * c.lrow[i] + c.w3 * c.lrow[im]);
             }
             if constexpr (WANT_PARAM) {
@@ -1091,14 +1097,16 @@ struct KppUdeW : LinearTheta {
                 const int b0 = c.w * BLK;
 #pragma unroll 4
                 for (int s4 = 0; s4 < BLK / 4; ++s4) {
+                    // (branch-free: a point beyond the grid reads point 0 and contributes zeros -- as an `if (i < n)` body this was an
+                    //  EXEC-masked region per k-step, 64 of them per evaluation and wavefront)
                     const int i = b0 + 4 * s4 + kq;
-                    double av = 0.0, bv = 0.0;
-                    if (i < n) {
-                        const int im = (i + n - 1) % n, ip = (i + 1) % n;
-                        const double um = c.urow[im], u0 = c.urow[i], up = c.urow[ip];
-                        av = c.lrow[i];
-                        bv = l16 == 0 ? um : l16 == 1 ? u0 : l16 == 2 ? up : l16 == 3 ? (c.w1 * um + c.w2 * u0 + c.w3 * up) : 0.0;
-                    }
+                    const bool in = i < n;
+                    const int ic = in ? i : 0;
+                    const int im = wrap_prev(ic, n), ip = wrap_next(ic, n);
+                    const double um = c.urow[im], u0 = c.urow[ic], up = c.urow[ip];
+                    const double comb = c.w1 * um + c.w2 * u0 + c.w3 * up;
+                    const double bsel = l16 == 0 ? um : l16 == 1 ? u0 : l16 == 2 ? up : l16 == 3 ? comb : 0.0;
+                    const double av = in ? c.lrow[ic] : 0.0, bv = in ? bsel : 0.0;
                     sacc = mfma(av, bv, sacc);
                 }
             }
