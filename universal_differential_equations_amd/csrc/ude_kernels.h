@@ -365,9 +365,11 @@ struct Driver {
                 const real rem = rabs(tstop - t);  // modify_dt_for_tstops!
                 if (rabs(dt) > rem) dt = tdir * rem;
             }
-            if (uni(iter > o.maxiters)) { ret = RET_MAXITERS; break; }
-            if (uni(dt != dt)) { ret = RET_UNSTABLE; break; }
-            if (uni(rabs(dt) <= REAL_EPS * rabs(t) && rabs(dt) < rabs(tstop - t))) { ret = RET_DTLESSTHANMIN; break; }
+            {   // the three ways a solve stops here, behind ONE test (checked in upstream's order)
+                const bool b_it = iter > o.maxiters, b_nan = dt != dt;
+                const bool b_min = rabs(dt) <= REAL_EPS * rabs(t) && rabs(dt) < rabs(tstop - t);
+                if (uni(b_it || b_nan || b_min)) { ret = b_it ? RET_MAXITERS : b_nan ? RET_UNSTABLE : RET_DTLESSTHANMIN; break; }
+            }
 
             // ---- perform_step!: runtime stage loop (wave-uniform s) ----
             real znew[NR];
@@ -472,15 +474,17 @@ struct Driver {
 
             // ---- loopfooter!: PIController ----
             real q;
-            if (uni(EEst == real(0))) {
-                q = real(1) / o.qmax;
-            } else {
-                q11 = (real)fastpow((double)EEst, (double)o.beta1);
-                q = q11 / (real)fastpow((double)qold, (double)o.beta2);
-                q = q / o.gamma;
+            {   // (branch-free: EEst == 0 selects 1 / qmax and leaves q11 alone; fastpow has no special-case branches and runs for every
+                //  argument -- in the lane-group kernels an `if` here is an EXEC-masked region per step attempt)
+                const bool ez = EEst == real(0);
+                const real q11n = (real)fastpow((double)EEst, (double)o.beta1);
+                real qn = q11n / (real)fastpow((double)qold, (double)o.beta2);
+                qn = qn / o.gamma;
                 const real lo = real(1) / o.qmax, hi = real(1) / o.qmin;
-                if (q > hi) q = hi;
-                if (q < lo) q = lo;
+                if (qn > hi) qn = hi;
+                if (qn < lo) qn = lo;
+                q = ez ? lo : qn;
+                q11 = ez ? q11 : q11n;
             }
             accept = uni(EEst <= real(1));
             sys.trace(iter, t, dt, EEst, q, accept);
@@ -1003,8 +1007,10 @@ struct AdjSys {
     }
     // sol(t, continuity = :right): interval [s, s+1] with t_s <= t, clamped to the stored range
     __device__ __forceinline__ void locate(real t) {
-        while (uni(t < ts && sf > 0)) load_interval(sf - 1);
-        while (uni(t >= te && sf < nsteps - 1)) load_interval(sf + 1);
+        if (uni(t < ts || t >= te)) {   // (ONE test on the common path: the evaluation time lies inside the cached interval)
+            while (uni(t < ts && sf > 0)) load_interval(sf - 1);
+            while (uni(t >= te && sf < nsteps - 1)) load_interval(sf + 1);
+        }
     }
     // ---- deferred slots: slot state in HBM, two columns (current / candidate) that swap on acceptance ----
     real *mu_cur, *mu_new;
