@@ -43,6 +43,11 @@ HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 BOUND = {"lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
 
 
+# `roofline.traffic` is NOT measured inside this run (PMC passes cannot run inside a timed bench): it is read from the committed
+# rocprofv3 --pmc summary of the same command and binary
+TRAFFIC_SOURCE = "from profiles/: FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes of this command (tools/prof_r05.sh), not a counter read of this run"
+
+
 def mu_stream_bytes(stats, n_param):
     """algorithmic HBM bytes of one backward launch of a deferred-cotangent kernel: (accepted + rejected) step attempts x (read mu, write candidate)"""
     return float((stats[:, 5].sum() + stats[:, 6].sum()).item()) * 2.0 * n_param * 8.0
@@ -55,7 +60,7 @@ def headline_roofline(a, fkey, achieved_tflops, bwd_s, stats, n_param):
     if a.sensealg != "adjoint" or a.lanes not in (0, 16):
         bound = "valu" if bound == "hbm" else bound   # (the wavefront-per-trajectory / fast / discrete kernels of seir and node)
     r = {"bound": bound, "kernel": roofline_kernel_name(a), "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": pmc_traffic(a),
+         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": pmc_traffic(a), "traffic_source": TRAFFIC_SOURCE,
          "note": "bound: valu = FP64 vector unit, mfma = FP64 matrix cores (both 78.6 TF on this part), hbm = 8 TB/s; algorithmic %g flop per "
                  "adjoint eval; traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of the kernel from the separate rocprofv3 --pmc passes of this "
                  "command (profiles/r04_pmc_<workload>.md, tools/prof_r04.sh), null for non-default commands" % FLOPS[fkey][1]}
@@ -258,7 +263,8 @@ def run_hjb(a, rank, world, local, device, dist):
         achieved = nf * HJB_FLOP_PER_EVAL / fwd / 1e12
         out = {
             "metric": "ODE RHS-evals/s (fwd+adjoint)", "value": float(ev[0].item()) * a.steps / elapsed, "unit": "RHS-evals/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "n_gpus": world, "rccl_ranks": rccl_ranks(a, dist), "allreduce": None if dist is None else a.allreduce,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4] per-GPU share: highdim_pde/lambaem.jl deep-BSDE step (100-dim HJB, NNPDENS chains "
                                    "100-110-110-1 and 101-110-110-110-100 relu, 70171 params), %d trajectories per GPU, adaptive LambaEM "
@@ -269,7 +275,7 @@ def run_hjb(a, rank, world, local, device, dist):
                        "bwd_achieved_tflops": nacc * HJB_FLOP_PER_BWD_COL / (float(np.mean(bwd_ms)) * 1e-3) / 1e12},
             "roofline": {"bound": "mfma", "kernel": "hjb_fwd_kernel (three batched network evaluations per step attempt on v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": (pmc_traffic_file("r03_pmc_hjb.md", "hjb_fwd_kernel") or pmc_traffic_file("r02_pmc_hjb.md", "hjb_fwd_kernel")) if not a.traj and a.tol == 0.1 else None,
+                         "traffic": pmc_any("hjb", "hjb_fwd_kernel") if not a.traj and a.tol == 0.1 else None, "traffic_source": TRAFFIC_SOURCE,
                          "note": "FP32 matrix peak 157.3 TF; algorithmic %g flop per network evaluation x evaluations of live "
                                  "trajectories / forward kernel time (HIP events)" % HJB_FLOP_PER_EVAL},
         }
@@ -303,7 +309,7 @@ def cpu_baseline_hjb(theta_h, tol, seconds_target=15.0):
 
 def pmc_any(stem, kernel_prefix):
     """this round's PMC summary of a workload if it has been collected, else last round's"""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         v = pmc_traffic_file("%s_pmc_%s.md" % (rnd, stem), kernel_prefix)
         if v:
             return v
@@ -413,6 +419,32 @@ def quick_measure(name, device, steps=5, warmup=1):
     return out
 
 
+def rccl_ranks(a, dist):
+    """how many ranks an RCCL communicator of this run spans: the torch.distributed nccl group (= RCCL on ROCm) and / or libudecore's
+    own RCCL binding; 0 for a single process, for the gloo rehearsals and for `--allreduce p2p` over a gloo bootstrap"""
+    if dist is None:
+        return 0
+    if getattr(a, "dist_backend", "nccl") == "nccl" or a.allreduce == "udecore":
+        return dist.get_world_size()
+    return 0
+
+
+def self_launch(n):
+    """re-exec this command line under torch.distributed.run with n ranks on 127.0.0.1 (a free port unless MASTER_PORT is given)"""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -442,9 +474,16 @@ def main():
                          "one-shot cross-process P2P reducer (IPC windows, one kernel per rank, rank-ordered deterministic sum; no RCCL)")
     a = ap.parse_args()
 
+    # `python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- the same
+    # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` the driver uses, one process per GPU -- and pass its exit
+    # code on; rank 0 of the children prints the JSON line.  Under a launcher the world it set up must be the one asked for.
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and not os.environ.get("UDE_BENCH_FORCE_DIST"):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     # (rehearsal of the N > 1 path on a 1-GPU box: UDE_BENCH_DEVICE=0 puts every rank on that device, UDE_BENCH_BACKEND=gloo
     #  replaces RCCL, which refuses two ranks on one device; the driver's runs use neither)
     if os.environ.get("UDE_BENCH_DEVICE"):
@@ -463,6 +502,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()      # n_gpus on the JSON line = the ranks the process group really has
+        a.dist_backend = backend
 
     if a.workload == "hjb":
         return run_hjb(a, rank, world, local, device, dist)
@@ -586,6 +627,7 @@ def main():
         achieved = flops_bwd / bwd / 1e12
         out = {
             "metric": "ODE RHS-evals/s (fwd+adjoint)", "value": value, "unit": "RHS-evals/s", "n_gpus": world,
+            "rccl_ranks": rccl_ranks(a, dist), "allreduce": None if dist is None else a.allreduce,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name,
@@ -613,10 +655,18 @@ def main():
                 torch.cuda.empty_cache()
             out["config"]["other_workloads"] = others
         print(json.dumps(out))
+    if comm is not None and getattr(comm, "mp", False):
+        # a peer that arrived late ends a call in NaN + a counted timeout, and the communicator refuses every later call: a run
+        # with a timeout is not a measurement
+        nt = comm.p2p_timeouts()
+        if nt:
+            raise SystemExit("bench.py: rank %d: %d cross-process all-reduce call(s) timed out -- gradients were NaN" % (rank, nt))
     if dist is not None:
         dist.barrier()
+        if comm is not None:
+            comm.close(dist)
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

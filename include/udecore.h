@@ -60,7 +60,8 @@ enum { UDE_ALG_TSIT5 = 0 /* Tsit5() scenario_1.jl:191 */, UDE_ALG_VERN7 = 1 /* V
 enum { UDE_RET_SUCCESS = 0, UDE_RET_MAXITERS = 1, UDE_RET_DTLESSTHANMIN = 2, UDE_RET_UNSTABLE = 3,
        UDE_RET_DENSE_OVERFLOW = 4 /* forward pass exceeded opts.max_dense_steps (adjoint only) */ };
 enum { UDE_OK = 0, UDE_ERR_INVALID = -1, UDE_ERR_UNSUPPORTED = -2, UDE_ERR_HIP = -3, UDE_ERR_NOMEM = -4,
-       UDE_ERR_TRAJECTORY = -5 /* at least one trajectory has retcode != Success */ };
+       UDE_ERR_TRAJECTORY = -5 /* at least one trajectory has retcode != Success */,
+       UDE_ERR_TIMEOUT = -6 /* a cross-process all-reduce gave up waiting for a peer: the communicator is dead (sticky), make a new one */ };
 
 /* replaces: the RHS closure + Lux/FastChain/Flux model captured by ODEProblem(f, u0, tspan, p)
  * (scenario_1.jl:62-78, seir_exposure.jl:114-131, Fisher-KPP-CNN.jl:92-131) */
@@ -286,6 +287,9 @@ int ude_comm_unique_id(char id[128]);
 int ude_comm_create(ude_ctx* ctx, int32_t nranks, int32_t rank, const char id[128], ude_comm** out);
 int ude_comm_create_local(int32_t ndev, ude_ctx* const* ctxs, ude_comm** out /* ndev */);
 void ude_comm_destroy(ude_comm* comm);
+/* the tail of the double[np + 4] payload for a host without a device array library: payload_dev[np + 1 .. np + 3] = (sum nf, sum naccept,
+ * sum nreject) over the N trajectories of stats_dev (8 x N int64 as the gradient call left them; forward + backward), as doubles; enqueued */
+int ude_pack_counters_dev(ude_ctx* ctx, int64_t N, const int64_t* stats_dev, double* payload_dev, int32_t n_param);
 int ude_allreduce_grad(ude_comm* comm, double* buf_dev, int64_t n);
 int ude_allreduce_grad_local(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n);
 int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, double* const* bufs_dev, int64_t n);
@@ -294,11 +298,19 @@ int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, double* const* 
  * (torch.distributed / MPI / Distributed.jl -- 64 bytes per rank, once) and connects; per gradient ONE kernel per rank: publish the
  * payload, add all ranks' payloads in rank order (peer reads over xGMI, system-scope flags; identical bits on every rank), write the
  * sum back.  n <= n_max <= 8192 doubles.  A peer that never arrives: the result is NaN after UDE_P2P_TIMEOUT_MS (default 5000) and
- * ude_comm_p2p_status counts it -- never a hung GPU.  Needs no librccl. */
+ * ude_comm_p2p_status counts it -- never a hung GPU.  A timeout is STICKY: the rank stops publishing (its peers fail fast instead of
+ * summing a payload of another call), every later call of that communicator yields NaN on the device and, once the host has seen the
+ * count through ude_comm_p2p_status, UDE_ERR_TIMEOUT -- re-create the communicator.  Needs no librccl; needs fine-grained device memory
+ * for the window (UDE_ERR_UNSUPPORTED otherwise -- there is no coarse-grained fallback).
+ * Teardown: ude_comm_p2p_disconnect = stream-ordered handshake (every rank stores a "closed" word into every peer's window, then waits on
+ * its own window for all of them: no peer is still reading this rank's window, this rank reads no peer's) + unmap the peers' windows;
+ * ude_comm_destroy then frees the window (and runs the disconnect itself if the host did not).  A host with a barrier of its own calls
+ * disconnect on every rank, its barrier, then destroy, so that every importer has unmapped before any exporter frees. */
 int ude_comm_create_p2p(ude_ctx* ctx, int32_t nranks, int32_t rank, int64_t n_max, char handle_out[64], ude_comm** out);
 int ude_comm_p2p_connect(ude_comm* comm, const char* handles /* nranks x 64 bytes, rank order */);
 int ude_allreduce_grad_p2p_mp(ude_comm* comm, double* buf_dev, int64_t n);
 int ude_comm_p2p_status(ude_comm* comm, int32_t* timeouts);
+int ude_comm_p2p_disconnect(ude_comm* comm);
 
 /* Failure accounting of the most recent gradient call on this context (blocks on the context's stream): the number
  * of trajectories whose retcode is not Success.  Such trajectories contribute nothing to the gradient and the

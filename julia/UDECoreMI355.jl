@@ -183,26 +183,28 @@ function comms_for(devs::Vector{Int})
         end
     end
 end
-"every device's `payload` = double[np + 1] = [grad(np); loss] is filled by its own ude_loss_grad_ensemble_dev and then summed over
-the devices in ONE all-reduce (the per-trajectory counters stay in each device's `stats` array: the host adds them if it wants
-the ensemble-wide DEStats -- python's `pack_payload` appends them as three more doubles, this shim reduces np + 1 values)"
+"every device's `payload` = double[np + 4] = [grad(np); loss; Σnf; Σnaccept; Σnreject] (SURVEY.md 8(e), DESIGN 7): gradient and loss are
+written by the device's own ude_loss_grad_ensemble_dev, the three counters by ude_pack_counters_dev from the device's `stats` array
+(forward + backward, exact integer sums as doubles), and ONE all-reduce sums the np + 4 values over the devices -- the same payload
+python's `pack_payload` builds"
 function loss_grad_multi(m::UDEModel, alg, devs::Vector{Int}, dptr::Vector{<:NamedTuple}, tspan, ts::Vector{Float64}; p2p = true, kw...)
     np = Int(m.desc.n_param); nd = length(devs)
     ctxs = [ctx(dv) for dv in devs]
     comms = comms_for(devs)
     d = Ref(m.desc); o = Ref(opts(alg; kw...)); tsp = Float64[tspan[1], tspan[2]]
     for (k, dv) in enumerate(devs)       # enqueue on every device; nothing blocks
-        b = dptr[k]                      # (N, u0, theta, saveat, data, mask, payload = [grad(np); loss], gu0, u, stats, rc)
+        b = dptr[k]                      # (N, u0, theta, saveat, data, mask, payload = double[np + 4], gu0, u, stats, rc)
         check(ccall((:ude_loss_grad_ensemble_dev, libudecore), Cint,
             (Ptr{Cvoid}, Ref{ModelDesc}, Ref{SolveOpts}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
              Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int32}),
             ctxs[k], d, o, b.N, b.u0, tsp, b.theta, b.saveat, length(ts), b.data, b.mask, b.payload + 8np, C_NULL, b.payload, b.gu0, b.u,
             b.stats, b.rc), dv)
+        check(ccall((:ude_pack_counters_dev, libudecore), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Int32), ctxs[k], b.N, b.stats, b.payload, np), dv)
     end
     bufs = [b.payload for b in dptr]
     f = p2p ? :ude_allreduce_grad_p2p : :ude_allreduce_grad_local      # fixed-rank-order peer reads, or RCCL (grouped)
-    check(ccall((f, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Int64), nd, comms, bufs, np + 1), devs[1])
-    nothing                              # every device's payload now holds the ensemble-wide [grad; loss]
+    check(ccall((f, libudecore), Cint, (Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Int64), nd, comms, bufs, np + 4), devs[1])
+    nothing                              # every device's payload now holds the ensemble-wide [grad; loss; Σnf; Σnaccept; Σnreject]
 end
 
 # ---- highdim_pde/lambaem.jl: NNPDENS + LambaEM (SURVEY.md 8(f) N1) ---------------------------------------------------

@@ -111,6 +111,35 @@ def test_unprovable_moves_are_refused():
     assert rep["unhandled"] and not rep["fixed"]
 
 
+def test_only_pure_register_copies_may_move():
+    """round 5 (advisor): arithmetic, v_cmp (SGPR mask result), MFMA, DPP and memory instructions in front of the restore are
+    UNHANDLED -- the build fails -- even where the old register-disjointness test would have let them move; v_mov / v_accvgpr copies,
+    plain encodings, inline constants included, still move"""
+    T = tool()
+    head = KERNEL + "\ts_cbranch_execz .LBB0_1\n.LBB0_1:\n"
+    tail = "\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n"
+    for bad in ("v_add_f64 v[0:1], v[2:3], v[4:5]", "v_cmp_lt_f64_e64 s[6:7], v[0:1], v[2:3]",
+                "v_mfma_f64_16x16x4_f64 a[0:7], v[0:1], v[2:3], a[0:7]", "v_mov_b32_dpp v1, v2 row_shr:1 row_mask:0xf bank_mask:0xf",
+                "v_mov_b32_sdwa v1, v2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD",
+                "ds_write_b64 v8, v[66:67]", "global_load_dwordx2 v[0:1], v[4:5], off", "scratch_store_dword off, v3, off offset:16",
+                "v_cndmask_b32_e32 v1, v2, v3, vcc", "v_mov_b32_e32 v1, s5"):
+        _, rep = T.process(head + "\t" + bad + "\n" + tail)
+        assert rep["unhandled"] and not rep["fixed"], bad
+    for good in ("v_mov_b32_e32 v1, v2", "v_mov_b64_e32 v[0:1], v[2:3]", "v_accvgpr_write_b32 a3, v7", "v_accvgpr_read_b32 v7, a3",
+                 "v_accvgpr_mov_b32 a1, a2", "v_mov_b32_e32 v1, 0", "v_mov_b32_e32 v1, 0x3ff00000"):
+        _, rep = T.process(head + "\t" + good + "\n" + tail)
+        assert rep["fixed"] and not rep["unhandled"], good
+
+
+def test_vector_code_that_falls_through_a_label_into_a_restore_is_refused():
+    """copies in front of ANOTHER block's label whose first instruction is the restore stand in front of a join all the same, but
+    behind that label other predecessors arrive: not repairable, the build fails"""
+    T = tool()
+    src = KERNEL + "\ts_cbranch_execz .LBB0_1\n.LBB0_1:\n\tv_mov_b32_e32 v1, v2\n.LBB0_2:\n\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n"
+    _, rep = T.process(src)
+    assert rep["unhandled"] and not rep["fixed"]
+
+
 def test_region_tail_that_falls_into_its_join_is_not_a_site():
     """an else-body that falls through into its own `s_or_b64 exec` (no label in between, entered with its lanes ON) is ordinary code"""
     T = tool()

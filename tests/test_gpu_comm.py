@@ -45,6 +45,20 @@ def test_local_communicator_rccl_and_p2p_one_device():
     comm.close()
 
 
+def test_pack_counters_dev_matches_pack_payload():
+    """ude_pack_counters_dev (the Julia shim's way to the double[np + 4] payload) == parallel.pack_payload's torch reduction"""
+    eng = U.Engine.get(0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    for N in (1, 63, 6250):
+        stats = torch.randint(0, 100000, (N, 8), dtype=torch.int64, device="cuda:0")
+        grad_loss = torch.linspace(-2, 2, 88, dtype=torch.float64, device="cuda:0")
+        want = pack_payload(grad_loss, stats)
+        got = torch.cat([grad_loss, torch.full((3,), -1.0, dtype=torch.float64, device="cuda:0")])
+        eng.check(eng.L.ude_pack_counters_dev(eng.h, N, C.c_void_p(stats.data_ptr()), C.c_void_p(got.data_ptr()), 87))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+
+
 def _lv_inputs(n):
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "Scenario_1_recovery_0.005.json")))
     X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
@@ -110,18 +124,85 @@ for call in range(40):                                  # repeated calls: both s
     torch.cuda.synchronize()
     ok = ok and np.array_equal(buf.cpu().numpy(), want)
 assert comm.p2p_timeouts() == 0
-# a peer that never arrives: rank 1 skips a call; rank 0's result is NaN after the timeout, the GPU is not hung, the counter says so
+# a float32 / strided buffer is refused on the Python side (the C side would read numel() doubles from it)
+for bad in (torch.ones(8, dtype=torch.float32, device="cuda:0"), torch.ones(16, dtype=torch.float64, device="cuda:0")[::2]):
+    try:
+        comm.allreduce_mp(bad)
+        ok = False
+    except AssertionError:
+        pass
+# a peer that arrives too late: rank 1 sits out rank 0's call 41 until rank 0 has given up.
+#   rank 0: NaN after the timeout, the GPU is not hung, the counter says so; the timeout is STICKY -- the next call is NaN at once
+#           (nothing published: slot reuse is no longer safe), and once the host has read the count the call itself fails (-6)
+#   rank 1: its own call 41 still finds rank 0's payload OF CALL 41 (rank 0 never overwrote it) and sums it correctly; its call 42
+#           fails FAST (rank 0 has given up and says so in its window) instead of summing a slot of another call
+import time
+from universal_differential_equations_amd import _lib
 if rank == 0:
     buf = torch.ones(8, dtype=torch.float64, device="cuda:0")
     comm.allreduce_mp(buf)
     torch.cuda.synchronize()
-    lost = bool(torch.isnan(buf).all().item()) and comm.p2p_timeouts() == 1
+    lost = bool(torch.isnan(buf).all().item())
+    buf2 = torch.ones(8, dtype=torch.float64, device="cuda:0")
+    t0 = time.perf_counter()
+    comm.allreduce_mp(buf2)                               # host does not know yet: the kernel refuses by itself
+    torch.cuda.synchronize()
+    lost = lost and bool(torch.isnan(buf2).all().item()) and time.perf_counter() - t0 < 1.0
+    lost = lost and comm.p2p_timeouts() == 1
+    try:
+        comm.allreduce_mp(buf2)
+        lost = False
+    except _lib.UdeError as e:
+        lost = lost and e.code == _lib.UDE_ERR_TIMEOUT
+    dist.barrier()
+    dist.barrier()
 else:
-    lost = True
-dist.barrier()
+    dist.barrier()                                        # rank 0 has timed out
+    buf = torch.full((8,), 2.5, dtype=torch.float64, device="cuda:0")
+    comm.allreduce_mp(buf)                                # call 41 of this rank: rank 0's call-41 payload is still in its slot
+    torch.cuda.synchronize()
+    lost = bool((buf == 3.5).all().item())
+    t0 = time.perf_counter()
+    comm.allreduce_mp(buf)                                # call 42: rank 0 will never publish it
+    torch.cuda.synchronize()
+    lost = lost and bool(torch.isnan(buf).all().item()) and time.perf_counter() - t0 < 1.0 and comm.p2p_timeouts() == 1
+    dist.barrier()
+# REAL teardown (no os._exit): disconnect handshake on both ranks, the host group's barrier, then the windows are freed
+comm.close(dist)
+torch.cuda.synchronize()
 print("RESULT rank %%d ok %%s lost %%s" %% (rank, ok, lost), flush=True)
+dist.barrier()
 dist.destroy_process_group()
-os._exit(0)                                              # (the windows stay mapped in the peer: skip the destructors' ordering)
+"""
+
+
+P2P_TEARDOWN_CHILD = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import universal_differential_equations_amd as U
+from universal_differential_equations_amd.parallel import Comm
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["UDE_TEST_PORT"], rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+eng = U.Engine.get(0)
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+ok = True
+for rnd in range(3):                                    # create / use / destroy, three times: windows are really freed and re-made
+    comm = Comm.p2p_from_torch_dist(eng, dist, 128)
+    for call in range(5):
+        buf = torch.full((100,), float(rank + 1 + call), dtype=torch.float64, device="cuda:0")
+        comm.allreduce_mp(buf)
+    # NO synchronize: rank 1 goes straight into the teardown while rank 0 may still be inside its last call -- the handshake of
+    # ude_comm_destroy (no host barrier here: close() without the group) must keep rank 1's window alive until rank 0 is through
+    if rank == 0:
+        import time; time.sleep(0.2)
+    comm.close()
+    torch.cuda.synchronize()
+    want = sum(r + 1 + 4 for r in range(world))
+    ok = ok and bool((buf == want).all().item())
+print("RESULT rank %%d ok %%s" %% (rank, ok), flush=True)
+dist.barrier()
+dist.destroy_process_group()
 """
 
 
@@ -144,3 +225,23 @@ def test_cross_process_p2p_reducer_two_ranks_on_one_gpu(tmp_path):
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d: %s" % (rank, se[-2000:])
         assert "RESULT rank %d ok True lost True" % rank in so, (so[-500:], se[-1500:])
+
+
+def test_cross_process_p2p_teardown_without_host_barrier():
+    """ude_comm_destroy alone (no host barrier, ranks skewed, a call possibly still in flight on the peer): the device-side "closed"
+    handshake keeps every window alive until no peer reads it; three create / use / destroy rounds in two real processes that exit
+    through their normal destructors"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", UDE_TEST_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", P2P_TEARDOWN_CHILD % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d: %s" % (rank, se[-2000:])
+        assert "RESULT rank %d ok True" % rank in so, (so[-500:], se[-1500:])

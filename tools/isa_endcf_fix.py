@@ -17,13 +17,21 @@ What this tool does to a device assembly file (`hipcc -S --cuda-device-only`):
   * finds every point that is entered with EXEC == 0 -- a label targeted by `s_cbranch_execz`, the fall-through of
     `s_cbranch_execnz` -- and the first EXEC-restoring instruction R (`s_or_b64 exec, exec, X` / `s_or_saveexec_b64 A, B`) of that
     straight-line block;
-  * every EXEC-dependent vector instruction between the entry and R is moved BEHIND R (order kept), followed by `s_nop 4` (the
-    hazard distances of the block were computed for the old order); scalar instructions and lane-indexed moves
-    (v_readlane / v_writelane / v_readfirstlane: EXEC-independent) stay where they are;
+  * PURE REGISTER COPIES between the entry and R -- `v_mov_b32/b64 vD, vS`, `v_accvgpr_read_b32`, `v_accvgpr_write_b32`,
+    `v_accvgpr_mov_b32`, plain encodings only (no DPP / SDWA modifier, no lane select) -- are moved BEHIND R (order kept), followed by
+    `s_nop 4`.  These are what the register allocator's live-range splitting emits, they have no implicit operand (VCC / SCC / M0 /
+    EXEC-as-data), they are not matrix or memory instructions, and the hazard classes that involve a plain VALU register write
+    (VALU write -> DPP / readlane select / VMEM address / MFMA source) need at most 5 wait states, which `s_nop 4` provides; hazards
+    of instructions in FRONT of the block towards the copies only get longer distances by the move;
   * the move is only done when it is provably order-independent: no register is shared between a moved and a not-moved
-    instruction of the prefix (all operands of an instruction count as read AND written; implicit VCC / SCC included), R's mask
-    register is not touched by a moved instruction, no memory instruction is moved across an s_waitcnt.  Anything else is reported
-    as UNHANDLED and fails the build (exit code 2): a human has to look at it.
+    instruction of the prefix (all operands of an instruction count as read AND written), R's mask register is not touched by a
+    moved instruction;
+  * ANY OTHER EXEC-dependent vector instruction in front of R -- arithmetic, v_cmp (writes an SGPR mask), MFMA, DPP, LDS / global /
+    scratch memory instructions -- is reported as UNHANDLED and fails the build (exit code 2): a human has to look at it.  (Rounds 4
+    and 5 never met one; the gate exists so that such a site cannot be accepted silently.)  Scalar instructions and lane-indexed moves
+    (v_readlane / v_writelane / v_readfirstlane: EXEC-independent) stay where they are;
+  * a region ENTRY (EXEC narrowed further before any restore) behind an EXEC == 0 entry is NOT a join -- see `entry_site_is_dead`
+    for the argument that is checked, not assumed, for every such site.
 
 usage:  isa_endcf_fix.py in.s out.s        (repairs, prints a report, exit 2 on unhandled sites)
         isa_endcf_fix.py --audit file.s    (no output file: exit 1 if any site -- handled or not -- is present)"""
@@ -69,6 +77,16 @@ def is_vector(op):
     return op.startswith(VEC_PREFIX) and not op.startswith(LANE_OPS)
 
 
+COPY_OPS = ("v_mov_b32", "v_mov_b32_e32", "v_mov_b64", "v_mov_b64_e32", "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_accvgpr_mov_b32")
+RE_PLAIN_COPY = re.compile(r"^\s*[va](\d+|\[\d+:\d+\])\s*,\s*([va](\d+|\[\d+:\d+\])|-?\d+(\.\d+)?|0x[0-9a-fA-F]+)\s*$")
+
+
+def is_pure_copy(op, operands):
+    """a live-range split copy: vector register (or inline constant) -> vector register, plain encoding (a DPP / SDWA variant has
+    modifier text behind the operands and an opcode suffix; both are rejected by the exact opcode list and the operand pattern)"""
+    return op in COPY_OPS and RE_PLAIN_COPY.match(operands) is not None
+
+
 def writes_exec(op, operands):
     if op.startswith("v_cmpx"):
         return True
@@ -95,7 +113,8 @@ def process(text, repair=True):
         it = ins[i]
         if it and it[0] == "s_cbranch_execnz":
             entries.append(i + 1)
-    report = {"fixed": [], "unhandled": []}
+    report = {"fixed": [], "unhandled": [], "entry": 0}
+    entry_sites = []
     func = [None] * n
     cur = None
     for i, l in enumerate(lines):
@@ -117,7 +136,17 @@ def process(text, repair=True):
                 if i == start or (not prefix and own_label_ok):  # the entry's own label (fall-through entry onto a labelled block)
                     i += 1
                     continue
-                break  # another block starts: no restore in this straight-line piece
+                # another block starts.  If this piece falls through into a block that BEGINS with the restore, its vector instructions
+                # stand in front of a join all the same -- but they cannot be moved behind a restore that other predecessors also
+                # reach: refuse
+                k = i
+                while k < n and (ins[k] is None):
+                    k += 1
+                if k < n and any(is_vector(ins[j][0]) for j in prefix) and not ins[prefix[-1]][0].startswith(TERMINATORS):
+                    op2, opr2 = ins[k]
+                    if (op2 == "s_or_b64" and re.match(r"exec\s*,\s*exec\s*,", opr2)) or op2 == "s_or_saveexec_b64":
+                        bad = "falls through label `%s` into the restore `%s %s`" % (s, op2, opr2)
+                break
             it = ins[i]
             if it is None:
                 i += 1
@@ -133,11 +162,15 @@ def process(text, repair=True):
                 elif op == "s_mov_b64" and not saved:
                     R = i      # (`s_mov_b64 exec, sN`: the same restore where EXEC is known to be 0)
                 elif op in ("s_and_saveexec_b64", "s_andn2_b64", "s_and_b64") or (op == "s_mov_b64" and saved):
-                    # a region ENTRY (EXEC narrowed further, possibly open-coded: s_mov sY, exec; s_and sX, sY, c; s_mov exec, sX):
-                    # the lanes that arrive here with EXEC == 0 stay off until an outer join -- and what is defined in
-                    # between belongs to variables that live inside the outer region, where those lanes are off anyway
-                    # (the wave-level skip of a kernel body whose wavefront has no work)
-                    pass
+                    # a region ENTRY (EXEC narrowed further, possibly open-coded: s_mov sY, exec; s_and sX, sY, c; s_mov exec, sX).
+                    # Why this is not a site: both EXEC == 0 edges are WAVE-level (s_cbranch_execz is taken, s_cbranch_execnz falls
+                    # through, only when every lane is off), so on that edge the whole wave executes nothing here, the narrowing
+                    # saves and keeps EXEC == 0, and the lanes come back at the `s_or_b64 exec, exec, sM` of the mask sM that switched
+                    # them off -- an instruction that post-dominates this block in structured control flow and that this tool examines
+                    # as a site of its own.  The defect is a property of the JOIN block (the allocator inserts its split copies at the
+                    # top of the block that holds the restore): a block without a restore is not one, and a block that falls through
+                    # into one is refused above.  Counted in the report (`entry`) so that the number is visible in the build log.
+                    entry_sites.append(start)
                 else:
                     bad = "first EXEC write is `%s %s`" % (op, operands)
                 break
@@ -146,6 +179,8 @@ def process(text, repair=True):
         vec = [j for j in prefix if is_vector(ins[j][0])]
         if not vec:
             continue
+        if entry_sites and entry_sites[-1] == start:
+            report["entry"] += 1
         key = (vec[0], R)
         if key in done:
             continue
@@ -161,6 +196,9 @@ def process(text, repair=True):
         why = None
         for j in vec:
             rj = regs_of(*ins[j])
+            if not is_pure_copy(*ins[j]):
+                why = "`%s` is not a pure register copy (only v_mov / v_accvgpr_read / v_accvgpr_write may be moved)" % lines[j].strip()
+                break
             if rj & rregs:
                 why = "`%s` touches the mask register of the restore" % lines[j].strip()
             if ins[j][0].startswith(MEM_PREFIX) and any(ins[k][0] == "s_waitcnt" for k in prefix if k > j):

@@ -17,6 +17,7 @@ ACT = {"identity": 0, "tanh": 1, "rbf": 2, "relu": 3}
 ALG_TSIT5, ALG_VERN7 = 0, 1
 RETCODES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable", 4: "DenseOverflow"}
 UDE_ERR_TRAJECTORY = -5
+UDE_ERR_TIMEOUT = -6
 
 
 class ModelDesc(C.Structure):
@@ -72,7 +73,7 @@ EXPORTS = ["ude_version", "ude_create", "ude_destroy", "ude_last_error", "ude_se
            "ude_hjb_net", "ude_hjb_last_kernel_ms", "ude_hjb_debug_read", "ude_hjb_last_failures",
            "ude_comm_unique_id", "ude_comm_create", "ude_comm_create_local", "ude_comm_destroy", "ude_allreduce_grad",
            "ude_allreduce_grad_local", "ude_allreduce_grad_p2p", "ude_comm_create_p2p", "ude_comm_p2p_connect",
-           "ude_allreduce_grad_p2p_mp", "ude_comm_p2p_status"]
+           "ude_allreduce_grad_p2p_mp", "ude_comm_p2p_status", "ude_comm_p2p_disconnect", "ude_pack_counters_dev"]
 
 
 def load():
@@ -134,6 +135,8 @@ def load():
     L.ude_comm_p2p_connect.argtypes = [vp, vp]
     L.ude_allreduce_grad_p2p_mp.argtypes = [vp, vp, i64]
     L.ude_comm_p2p_status.argtypes = [vp, C.POINTER(i32)]
+    L.ude_comm_p2p_disconnect.argtypes = [vp]
+    L.ude_pack_counters_dev.argtypes = [vp, i64, vp, vp, i32]
     L.ude_hjb_debug_read.argtypes = [vp, i32, i64, i64, vp]
     L.ude_hjb_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ude_set_trace.argtypes = [vp, i64, i32]

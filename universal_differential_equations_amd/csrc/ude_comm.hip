@@ -95,11 +95,14 @@ struct P2PGroup {
 struct P2PMp {
     int nranks = 0, rank = 0;
     size_t nmax = 0;
-    char* win = nullptr;                  // this rank's window: [2][nmax] doubles | 2 x uint64 flags | uint32 timeout counter
+    char* win = nullptr;                  // this rank's window: [2][nmax] doubles | 64-byte control block (2 x uint64 call flags, uint32 timeout
+                                          // counter at +16) | nranks x uint64 "closed" words, word r written by rank r when it disconnects
     std::vector<char*> peer;              // every rank's window as mapped into this process (peer[rank] == win)
     char** peer_dev = nullptr;            // the same table in HBM
     uint64_t seq = 0;
-    static size_t bytes(size_t nmax) { return 2 * nmax * sizeof(double) + 64; }
+    bool broken = false;                  // a call of this rank timed out (seen by ude_comm_p2p_status / disconnect): every later call is refused
+    bool disconnected = false;            // the peers' windows are closed (ude_comm_p2p_disconnect): only ude_comm_destroy is left
+    static size_t bytes(size_t nmax, int nranks) { return 2 * nmax * sizeof(double) + 64 + sizeof(uint64_t) * (size_t)nranks; }
 };
 
 struct ude_comm {
@@ -190,18 +193,59 @@ extern "C" int ude_comm_create_local(int32_t ndev, ude_ctx* const* ctxs, ude_com
     return UDE_OK;
 }
 
+static int p2p_disconnect_impl(ude_comm* m);
+
+// Teardown of a cross-process communicator is a handshake, not a local free: a peer may still be inside its last call, reading this
+// rank's window.  ude_comm_p2p_disconnect (called here if the host did not): every rank, stream-ordered behind its own last call,
+// stores a "closed" word INTO every peer's window and then waits -- on its OWN window only -- until every peer's word has arrived;
+// from then on no peer touches this window again, and this rank never touches a peer's window again, so the mappings are closed
+// and the window is freed.  A dead peer ends the wait after the reducer's timeout.  (A host with an out-of-band barrier calls
+// ude_comm_p2p_disconnect on every rank, then its barrier, then ude_comm_destroy: every importer has unmapped before any exporter frees.)
 extern "C" void ude_comm_destroy(ude_comm* m) {
     if (!m) return;
     if (m->nccl && rccl()) (void)rccl()->CommDestroy(m->nccl);
-    if (m->mp) {   // close the peers' windows, release this rank's
+    if (m->mp) {
         (void)hipSetDevice(m->ctx->device);
+        (void)p2p_disconnect_impl(m);
         (void)hipDeviceSynchronize();
-        for (int r = 0; r < (int)m->mp->peer.size(); ++r)
-            if (r != m->mp->rank && m->mp->peer[r]) (void)hipIpcCloseMemHandle(m->mp->peer[r]);
         if (m->mp->peer_dev) (void)hipFree(m->mp->peer_dev);
         if (m->mp->win) (void)hipFree(m->mp->win);
     }
     delete m;
+}
+
+// payload[np + 1 .. np + 3] = (sum nf, sum naccept, sum nreject) of this device's trajectories, forward + backward, as doubles:
+// the tail of the double[np + 4] exchange payload for hosts without a device array library (integer sums: exact, order-free)
+namespace {
+__global__ void __launch_bounds__(1024) pack_counters_kernel(const long long* __restrict__ stats, long long N, double* __restrict__ out) {
+    __shared__ long long part[3][16];
+    long long a[3] = {0, 0, 0};
+    for (long long j = threadIdx.x; j < N; j += blockDim.x) {
+        const long long* s = stats + 8 * j;
+        a[0] += s[0] + s[4];
+        a[1] += s[1] + s[5];
+        a[2] += s[2] + s[6];
+    }
+    for (int k = 0; k < 3; ++k) {
+        long long v = a[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        long long v = 0;
+        for (int w = 0; w < 16; ++w) v += part[threadIdx.x][w];
+        out[threadIdx.x] = (double)v;
+    }
+}
+}  // namespace
+
+extern "C" int ude_pack_counters_dev(ude_ctx* c, int64_t N, const int64_t* stats_dev, double* payload_dev, int32_t n_param) {
+    if (!c || !stats_dev || !payload_dev || N <= 0 || n_param < 0) return UDE_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(pack_counters_kernel, dim3(1), dim3(1024), 0, c->stream, (const long long*)stats_dev, (long long)N, payload_dev + n_param + 1);
+    HIPCHK(c, hipGetLastError());
+    return UDE_OK;
 }
 
 extern "C" int ude_allreduce_grad(ude_comm* m, double* buf_dev, int64_t n) {
@@ -317,10 +361,20 @@ extern "C" int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, doub
 namespace {
 __device__ __forceinline__ uint64_t* p2p_flags(char* w, size_t nmax) { return (uint64_t*)(w + 2 * nmax * sizeof(double)); }
 
+__device__ __forceinline__ unsigned* p2p_timeouts(char* w, size_t nmax) { return (unsigned*)(p2p_flags(w, nmax) + 2); }
+__device__ __forceinline__ uint64_t* p2p_closed(char* w, size_t nmax) { return p2p_flags(w, nmax) + 8; }
+
 __global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nranks, int rank, size_t nmax, uint64_t seq, double* buf, int64_t n,
                                                       unsigned long long timeout_ticks) {
     const int q = (int)(seq & 1);
     char* mine = peers[rank];
+    // A timeout is STICKY: once a call of this rank has given up, the slot-reuse rule (seeing every peer's flag of call k + 1 proves
+    // every peer finished call k) no longer holds, so this rank never publishes again -- its slots keep the payloads of its last two
+    // good calls, a late peer can still finish THOSE calls correctly and then times out itself -- and every later call is NaN.
+    if (__hip_atomic_load(p2p_timeouts(mine, nmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) buf[i] = __builtin_nan("");
+        return;
+    }
     double* myslot = (double*)mine + (size_t)q * nmax;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
         __hip_atomic_store(myslot + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -335,10 +389,14 @@ __global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nr
     for (int r = 0; r < nranks; ++r) {
         if (threadIdx.x == 0) {
             const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(p2p_flags(peers[r], nmax) + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            uint64_t f;
+            while ((f = __hip_atomic_load(p2p_flags(peers[r], nmax) + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) < seq) {
+                // a peer that has given up will never publish: fail with it at once instead of after the full timeout
+                if (__hip_atomic_load(p2p_timeouts(peers[r], nmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { lost = 1; break; }
                 if (wall_clock64() - t0 > timeout_ticks) { lost = 1; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
+            if (f > seq) lost = 1;   // a slot that already holds a LATER call's payload: the ranks are out of step, never sum it
         }
         __syncthreads();
         if (lost) break;
@@ -359,9 +417,63 @@ __global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nr
         const int64_t i = (int64_t)threadIdx.x + (int64_t)u * blockDim.x;
         if (i < n) buf[i] = bad ? __builtin_nan("") : acc[u];
     }
-    if (bad && threadIdx.x == 0) atomicAdd((unsigned*)(p2p_flags(mine, nmax) + 2), 1u);
+    if (bad && threadIdx.x == 0) {
+        __hip_atomic_fetch_add(p2p_timeouts(mine, nmax), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// the teardown handshake (see ude_comm_destroy): push "closed" into every peer's window, wait for every peer's word in MY window
+__global__ void p2p_close_kernel(char* const* peers, int nranks, int rank, size_t nmax, unsigned long long timeout_ticks, int* incomplete) {
+    if (threadIdx.x != 0) return;
+    __threadfence_system();
+    for (int r = 0; r < nranks; ++r)
+        __hip_atomic_store(p2p_closed(peers[r], nmax) + rank, (uint64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    char* mine = peers[rank];
+    const unsigned long long t0 = wall_clock64();
+    for (int r = 0; r < nranks; ++r)
+        while (__hip_atomic_load(p2p_closed(mine, nmax) + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+            if (wall_clock64() - t0 > timeout_ticks) { *incomplete = 1; return; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+}
+
+unsigned long long p2p_timeout_ticks() {
+    static const unsigned long long ticks = [] {
+        const char* e = getenv("UDE_P2P_TIMEOUT_MS");
+        const unsigned long long ms = e ? strtoull(e, nullptr, 10) : 5000ull;
+        return ms * 100000ull;   // wall_clock64: 100 MHz
+    }();
+    return ticks;
 }
 }  // namespace
+
+static int p2p_disconnect_impl(ude_comm* m) {
+    ude_ctx* c = m->ctx;
+    P2PMp& mp = *m->mp;
+    if (mp.disconnected) return UDE_OK;
+    mp.disconnected = true;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = UDE_OK;
+    if (mp.peer_dev && (int)mp.peer.size() == mp.nranks) {
+        int* flag = nullptr;
+        HIPCHK(c, hipMalloc((void**)&flag, sizeof(int)));
+        HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(p2p_close_kernel, dim3(1), dim3(64), 0, c->stream, (char* const*)mp.peer_dev, mp.nranks, mp.rank, mp.nmax, p2p_timeout_ticks(), flag);
+        int inc = 0;
+        (void)hipMemcpyAsync(&inc, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(flag);
+        if (inc) rc = fail(c, UDE_ERR_TIMEOUT, "ude_comm_p2p_disconnect: a peer did not reach its own disconnect within the timeout (it may still map this rank's window)");
+    }
+    for (int r = 0; r < (int)mp.peer.size(); ++r)
+        if (r != mp.rank && mp.peer[r]) { (void)hipIpcCloseMemHandle(mp.peer[r]); mp.peer[r] = nullptr; }
+    return rc;
+}
+
+extern "C" int ude_comm_p2p_disconnect(ude_comm* m) {
+    if (!m || !m->mp) return UDE_ERR_INVALID;
+    return p2p_disconnect_impl(m);
+}
 
 extern "C" int ude_comm_create_p2p(ude_ctx* c, int32_t nranks, int32_t rank, int64_t n_max, char handle_out[64], ude_comm** out) {
     if (!c || !out || !handle_out || nranks < 1 || rank < 0 || rank >= nranks || n_max <= 0) return UDE_ERR_INVALID;
@@ -372,14 +484,16 @@ extern "C" int ude_comm_create_p2p(ude_ctx* c, int32_t nranks, int32_t rank, int
     auto mp = std::make_shared<P2PMp>();
     mp->nranks = nranks; mp->rank = rank; mp->nmax = (size_t)n_max;
     void* w = nullptr;
-    // fine-grained device memory: peer loads and stores at system scope are coherent while the kernels run (coarse-grained HBM is
-    // only guaranteed visible to other agents at kernel boundaries); plain hipMalloc if the runtime has no such pool
-    if (hipExtMallocWithFlags(&w, P2PMp::bytes(mp->nmax), hipDeviceMallocFinegrained) != hipSuccess) {
+    // fine-grained device memory: peer loads and stores at system scope are coherent while the kernels run.  Coarse-grained HBM is
+    // only guaranteed visible to other agents at kernel boundaries -- a spin-wait on it may read stale flags or payload -- so there
+    // is NO fallback to plain hipMalloc: without a fine-grained pool this transport is unsupported (use RCCL)
+    const size_t wbytes = P2PMp::bytes(mp->nmax, nranks);
+    if (hipExtMallocWithFlags(&w, wbytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
-        HIPCHK(c, hipMalloc(&w, P2PMp::bytes(mp->nmax)));
+        return fail(c, UDE_ERR_UNSUPPORTED, "no fine-grained device memory for the P2P exchange window (%zu bytes): the cross-process reducer needs it", wbytes);
     }
     mp->win = (char*)w;
-    HIPCHK(c, hipMemset(w, 0, P2PMp::bytes(mp->nmax)));
+    HIPCHK(c, hipMemset(w, 0, wbytes));
     hipIpcMemHandle_t h;
     hipError_t e = hipIpcGetMemHandle(&h, w);
     if (e != hipSuccess) {
@@ -419,12 +533,10 @@ extern "C" int ude_allreduce_grad_p2p_mp(ude_comm* m, double* buf_dev, int64_t n
     P2PMp& mp = *m->mp;
     if (!mp.peer_dev) return fail(c, UDE_ERR_INVALID, "ude_comm_p2p_connect has not been called");
     if ((size_t)n > mp.nmax) return fail(c, UDE_ERR_INVALID, "payload of %lld doubles exceeds the window (%zu)", (long long)n, mp.nmax);
+    if (mp.disconnected) return fail(c, UDE_ERR_INVALID, "this communicator has been disconnected");
+    if (mp.broken) return fail(c, UDE_ERR_TIMEOUT, "an earlier all-reduce of this communicator timed out: the ranks are out of step, create a new communicator");
     HIPCHK(c, hipSetDevice(c->device));
-    static const unsigned long long ticks = [] {
-        const char* e = getenv("UDE_P2P_TIMEOUT_MS");
-        const unsigned long long ms = e ? strtoull(e, nullptr, 10) : 5000ull;
-        return ms * 100000ull;   // wall_clock64: 100 MHz
-    }();
+    const unsigned long long ticks = p2p_timeout_ticks();
     mp.seq += 1;
     hipLaunchKernelGGL(p2p_mp_kernel, dim3(1), dim3(1024), 0, c->stream, (char* const*)mp.peer_dev, mp.nranks, mp.rank, mp.nmax, (uint64_t)mp.seq,
                        buf_dev, n, ticks);
@@ -441,5 +553,6 @@ extern "C" int ude_comm_p2p_status(ude_comm* m, int32_t* timeouts) {
     unsigned v = 0;
     HIPCHK(c, hipMemcpy(&v, m->mp->win + 2 * m->mp->nmax * sizeof(double) + 16, sizeof(unsigned), hipMemcpyDeviceToHost));
     *timeouts = (int32_t)v;
+    if (v) m->mp->broken = true;   // (the kernels refuse by themselves -- NaN, nothing published; from here on the host call fails too)
     return UDE_OK;
 }

@@ -84,7 +84,10 @@ class Comm:
         return comm
 
     def allreduce_mp(self, buf):
-        """the cross-process one-shot reducer (p2p_from_torch_dist): in place, on the context's stream"""
+        """the cross-process one-shot reducer (p2p_from_torch_dist): in place, on the context's stream.  `buf`: ONE contiguous
+        float64 device tensor (the C side reads numel() doubles from data_ptr(): any other dtype or a strided view is out of bounds)"""
+        assert buf.dtype.is_floating_point and buf.element_size() == 8 and buf.is_contiguous() and buf.is_cuda, \
+            "allreduce_mp needs a contiguous float64 CUDA tensor"
         self.engines[0].check(self.L.ude_allreduce_grad_p2p_mp(self.handles[0], C.c_void_p(buf.data_ptr()), buf.numel()))
         return buf
 
@@ -119,7 +122,15 @@ class Comm:
         self.engines[0].check(fn(n, comms, ptrs, cnt))
         return bufs
 
-    def close(self):
+    def close(self, dist=None):
+        """Teardown.  A cross-process P2P communicator is torn down in two steps with the host group's barrier between them:
+        every rank disconnects (device handshake: no peer is still inside a call on this rank's window; the peers' windows are
+        unmapped), barrier, then the windows are freed -- every importer has unmapped before any exporter frees."""
+        if getattr(self, "mp", False):
+            for h in self.handles:
+                self.L.ude_comm_p2p_disconnect(h)    # (a peer that died: reported, the local teardown goes on)
+            if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.barrier()
         for h in self.handles:
             self.L.ude_comm_destroy(h)
         self.handles = []

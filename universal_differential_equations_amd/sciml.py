@@ -361,7 +361,10 @@ def solve(prob, alg, ensemblealg=None, saveat=None, sensealg=None, trajectories=
     assert n == base.f.n_state
     if ens and getattr(prob, "ps", None) is not None:       # per-member parameters (EnsembleProblem(..., ps = ...))
         theta = _np(prob.ps, rt)
-        assert theta.shape[1] == base.f.n_param, "ps is (N, %d), model expects %d parameters" % (theta.shape[1], base.f.n_param)
+        # the C side reads N * n_param elements: the FULL shape is checked, not the column count alone (a 1-D ps or a row count
+        # other than N would be read out of bounds)
+        assert theta.ndim == 2 and theta.shape == (N, base.f.n_param), \
+            "ps has shape %s, expected (N, n_param) = (%d, %d)" % (theta.shape, N, base.f.n_param)
     else:
         theta = _np(base.p if base.p is not None else [], rt)
         assert theta.size == base.f.n_param, "theta has %d entries, model expects %d" % (theta.size, base.f.n_param)

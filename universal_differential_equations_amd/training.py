@@ -94,7 +94,8 @@ def bfgs(loss_grad, theta, initial_stepnorm=0.01, maxiters=1000, gtol=1e-8, call
 # ---------------------------------------------------------------------------------------------------------------
 class _HZ:
     delta, sigma, rho, epsilon, gamma, psi3, linesearchmax, alphamax = 0.1, 0.9, 5.0, 1e-6, 0.66, 0.1, 50, float("inf")
-    iterfinitemax = 1074  # LineSearches.jl: ceil(-log2(eps(Float64)-subnormal range)): the bound of both non-finite retry loops
+    iterfinitemax = 52    # LineSearches.jl HagerZhang: iterfinitemax = ceil(Int, -log2(eps(T))) = 52 for Float64 -- the bound of both
+                          # non-finite retry loops (recalled from the published source; LineSearches.jl is not under /root/reference)
 
 
 def _hz_wolfe(c, phi_c, dphi_c, phi_0, dphi_0, phi_lim):
@@ -195,17 +196,19 @@ def hagerzhang(phidphi, c, phi_0, dphi_0):
             ia, ib = bisect(0, ib)
             bracketed = True
         else:
+            cold, phi_cold = c, va[-1]
             c *= _HZ.rho
             phi_c, dphi_c = ev(c)
-            nfin = 0
-            while not (np.isfinite(phi_c) and np.isfinite(dphi_c)):
+            nfin = 1
+            # upstream: while !(isfinite(phi_c) && isfinite(dphi_c)) && c > nextfloat(cold) && iterfinite < iterfinitemax:
+            #               c = (cold + c) / 2 -- pull the expansion back towards the last good point
+            while not (np.isfinite(phi_c) and np.isfinite(dphi_c)) and c > np.nextafter(cold, np.inf) and nfin < _HZ.iterfinitemax:
                 nfin += 1
-                if nfin > _HZ.iterfinitemax:  # (upstream: "failed to achieve finite new evaluation point", returns the last good one)
-                    al.pop(); va.pop(); sl.pop()
-                    return al[-1], va[-1]
-                c = (al[-2] + c) / 2 if len(al) > 2 else c * _HZ.psi3
+                c = (cold + c) / 2
                 al.pop(); va.pop(); sl.pop()
                 phi_c, dphi_c = ev(c)
+            if not (np.isfinite(phi_c) and np.isfinite(dphi_c)):   # upstream returns the last good point: `return cold, phi(cold)`
+                return cold, phi_cold
         it += 1
     while it < _HZ.linesearchmax:
         a, b = al[ia], al[ib]
