@@ -40,7 +40,9 @@ HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 #   hbm   the lock-step SEIR / neural-ODE backward kernels in parity mode: the parameter cotangent mu (np doubles per slot) lives in
 #         HBM and every step attempt reads the current column and writes the candidate -- 2 * np * 8 B per attempt, the algorithmic
 #         stream SURVEY.md 8(d) C3 names ("HBM in parity mode"); their flop fraction is reported beside it (`flop_frac`)
-BOUND = {"lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
+# the headline command at other fillings of the chip / with the wavefront-per-trajectory layout: name -> (trajectories, lanes per trajectory)
+LV_VARIANTS = {"lv_sat40k": (40000, 0), "lv_sat160k": (160000, 0), "lv_wave64": (10000, 64)}
+BOUND = {"lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
 
 
 # `roofline.traffic` is NOT measured inside this run (PMC passes cannot run inside a timed bench): it is read from the committed
@@ -377,20 +379,27 @@ def quick_measure(name, device, steps=5, warmup=1):
                 "bound": "mfma", "achieved_tflops": ach, "peak_tflops": FP32_MFMA_PEAK_TFLOPS, "frac": ach / FP32_MFMA_PEAK_TFLOPS, "unit": "mfma-f32",
                 "failed_trajectories": int((bs.retcode != 0).sum().item()), "traffic": pmc_any("hjb", "hjb_fwd_kernel")}
     sense, wl, net = "adjoint", name, "s1"
+    lanes, n_lv = 0, 10000
     if name == "lv_tanh32":
         wl, net = "lv", "tanh32"
     elif name == "lv_discrete":
         wl, sense = "lv", "discrete"
+    elif name in LV_VARIANTS:
+        # the headline command with the chip FILLED (10 000 trajectories are 834 wavefronts on 1024 SIMDs: one partial round), and
+        # with north_star's literal "one wavefront per trajectory" layout (64 lanes, lane j = neuron j: the runtime-shape kernel)
+        wl, (n_lv, lanes) = "lv", LV_VARIANTS[name]
     mask = None
     if wl == "lv":
-        N = 10000
+        N = n_lv
         theta_h, u0_d, t, data = synth_inputs(N, 0, device)
         f_lv = models.ude_dynamics()
         if net == "tanh32":
             f_lv = models.ude_dynamics(models.tanh32_chain())
             theta_h = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(7))
-        ens = U.DeviceEnsemble(f_lv, U.Tsit5(), (0.0, 3.0), t, u0_d, data=data, abstol=1e-6, reltol=1e-6, sensealg=SENSE_OBJ(U, sense))
-        desc = "configs[1] with %s" % ("the 2-32-2 tanh net (BASELINE's literal '2-layer tanh MLP')" if net == "tanh32" else "the discretise-then-optimise gradient")
+        ens = U.DeviceEnsemble(f_lv, U.Tsit5(), (0.0, 3.0), t, u0_d, data=data, abstol=1e-6, reltol=1e-6, sensealg=SENSE_OBJ(U, sense), lanes_per_traj=lanes)
+        desc = "configs[1] with %s" % ("the 2-32-2 tanh net (BASELINE's literal '2-layer tanh MLP')" if net == "tanh32" else "the discretise-then-optimise gradient"
+                                      if sense == "discrete" else "%d trajectories per GPU, %s" % (N, "64 lanes per trajectory (one wavefront per trajectory)" if lanes == 64
+                                                                                                    else "5 lanes per trajectory (the headline kernel)"))
     else:
         N = {"seir": 6250, "kpp": 256, "node": 6250}[wl]
         w = synth_inputs_other(wl, N, 0, device)
@@ -409,10 +418,17 @@ def quick_measure(name, device, steps=5, warmup=1):
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
     kern = "dadj_kernel" if sense == "discrete" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "nodels::node_ls_adj_kernel" if wl == "node" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete") else wl
+    if name in LV_VARIANTS:
+        pm = "none"    # (no committed counter pass for these commands)
     out = {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
            "fwd_kernel_ms": f, "bound": BOUND[name], "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
            "unit": "mfma-f64" if wl == "kpp" else ("mfma-f64 + valu-f64" if wl in ("seir", "node") else "valu-f64"), "failed_trajectories": int((ens.retcode != 0).sum().item()),
            "traffic": pmc_any(pm, "`void " + kern + "<"), "setup_s": time.perf_counter() - t_setup}
+    if name in LV_VARIANTS:
+        per_wave = 1 if lanes == 64 else 64 // (lanes or 5)
+        waves = -(-N // per_wave)
+        out.update({"trajectories": N, "lanes_per_trajectory": lanes or 5, "wavefronts": waves, "wavefronts_per_simd": waves / 1024.0,
+                    "bwd_evals_per_s": nf_bwd / (b * 1e-3)})
     if BOUND[name] == "hbm":  # frac = against the roof that bounds the kernel; the flop fraction stays beside it
         gbps = mu_stream_bytes(ens.stats, len(theta_h)) / (b * 1e-3) / 1e9
         out.update({"flop_frac": out["frac"], "achieved_gbps": gbps, "peak_gbps": HBM_PEAK_GBPS, "frac": gbps / HBM_PEAK_GBPS})
@@ -647,7 +663,7 @@ def main():
             del ens
             torch.cuda.empty_cache()
             others = {}
-            for name in ("seir", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_discrete"):
+            for name in ("seir", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64"):
                 try:
                     others[name] = quick_measure(name, device)
                 except Exception as e:  # a failing secondary workload must not take the headline line with it

@@ -35,6 +35,26 @@ def test_bench_two_ranks_on_one_gpu(workload, traj, port, transport):
     assert d["value"] > per_rank * 3 / (d["ms_per_step"] * 3e-3) * 1.5
 
 
+@pytest.mark.parametrize("transport", ["torch", "p2p"])
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(transport):
+    """round 5: `python bench.py --gpus 2` with NO launcher around it (WORLD_SIZE unset -- the shape of the driver's N = 1 command with
+    another N): bench.py re-executes itself under torch.distributed.run with two ranks; the line says n_gpus = 2 = the size of the
+    process group, and names the transport; under a launcher whose world differs from --gpus it refuses"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(UDE_BENCH_DEVICE="0", UDE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--traj", "2000",
+           "--no-cpu-baseline", "--no-others", "--allreduce", transport]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["allreduce"] == transport and d["rccl_ranks"] == 0    # (gloo rehearsal: no RCCL communicator)
+    assert d["config"]["failed_trajectories"] == 0
+    bad = subprocess.run(cmd[:3] + ["4"] + cmd[4:], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert bad.returncode != 0 and "--gpus 4" in bad.stderr
+
+
 @pytest.mark.parametrize("workload", ["hjb", "lv"])
 def test_bench_collective_through_libudecore_single_rank(workload):
     """`bench.py --allreduce udecore`: the one all-reduce per gradient through libudecore's own RCCL binding (ude_comm_create from a

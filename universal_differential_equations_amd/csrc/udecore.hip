@@ -417,6 +417,18 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
                 break;
             }
     }
+    // lanes_per_traj = 64 on an LV-kind model that has no 64-lane instance of its own: "one wavefront per trajectory" is the
+    // runtime-shape kernel (lane j = neuron j of every layer) -- the layout north_star names; same bits as every other instance
+    if (!ok && G == 64 && W == 1 && m->kind == UDE_KIND_LV_UDE) {
+        const int gid = generic_id(m);
+        for (const InstanceRow& row : kInstances)
+            if (gid != MID_NONE && row.mid == gid && row.alg == o->alg && row.G == 64 && row.W == 1) {
+                row.get(&l);
+                ok = true;
+                if (generic) *generic = true;
+                break;
+            }
+    }
     if (!ok) return fail(c, UDE_ERR_UNSUPPORTED, "no kernel instance for model %d alg %d lanes_per_traj %d waves_per_simd %d", mid, o->alg, G, W);
     return UDE_OK;
 }
