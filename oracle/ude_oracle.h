@@ -42,7 +42,14 @@ enum { UDEO_ACT_IDENTITY = 0, UDEO_ACT_TANH = 1, UDEO_ACT_RBF = 2, UDEO_ACT_RELU
 enum { UDEO_ALG_TSIT5 = 0, UDEO_ALG_VERN7 = 1 };
 enum { UDEO_SENSE_INTERPOLATING_ADJOINT = 0, UDEO_SENSE_DISCRETE = 1,
        UDEO_SENSE_FAST = 2 /* interpolating adjoint with lambda-only error control (SURVEY 8(b) `fast`): the parameter
-                              cotangent rides along as a quadrature on the adjoint's own steps; not an upstream step sequence */ };
+                              cotangent rides along as a quadrature on the adjoint's own steps; not an upstream step sequence */,
+       UDEO_SENSE_FAST_MM = 4 /* the SAME lambda solve as FAST (identical step counts, dL/du0); only the ASSOCIATION of the parameter
+                              cotangent differs: the one the device's block-level matrix-core accumulation executes
+                              (csrc/ude_seir_lsf.h) -- every network parameter is one fused chain
+                                  mu = fma(-((dt b_s) delta), a, mu)
+                              over the stage evaluations in the order they are made, a rejected attempt being taken back by the
+                              same chain with the weights negated (its "replay") before the step is repeated.  Kinds whose
+                              parameters are all network parameters (SEIR exposure UDE, the neural ODE) */ };
 enum { UDEO_RET_SUCCESS = 0, UDEO_RET_MAXITERS = 1, UDEO_RET_DTLESSTHANMIN = 2, UDEO_RET_UNSTABLE = 3 };
 
 /* Same field layout as include/udecore.h:ude_model_desc so one ctypes.Structure serves both. */

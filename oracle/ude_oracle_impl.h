@@ -93,6 +93,14 @@ static void FN(mlp_forward)(const udeo_model_desc* m, const REAL* p, const REAL*
     }
 }
 
+/* FAST_MM: the per-layer factors (delta_l after the activation derivative, a_l = the layer's input) of the most recent reverse
+ * sweep of this thread, for the fused-chain accumulation of the parameter cotangent (FN(mm_*) below) */
+typedef struct {
+    REAL delta[UDEO_MAX_LAYERS][UDEO_MAXW];
+    REAL a[UDEO_MAX_LAYERS][UDEO_MAXW];
+} FN(vjpcap);
+static _Thread_local FN(vjpcap)* FN(cap_ptr) = 0;
+
 /* reverse sweep: gy = cotangent of the output; gx = cotangent of the input; gp += parameter cotangent */
 /* fma_acc: accumulate the parameter cotangent as gp = fma(delta, a, gp) (Fisher-KPP sums over grid points: the order
  * and fusing of v_mfma_f64_16x16x4, measured by tools/probe/mfma_order_probe.hip) instead of gp += delta * a */
@@ -111,6 +119,10 @@ static void FN(mlp_vjp_acc)(const udeo_model_desc* m, const REAL* p0, REAL zs[][
         const int in = m->dims[l], out = m->dims[l + 1];
         const REAL* W = p0 + offs[l];
         for (int j = 0; j < out; ++j) delta[j] *= FN(dact)(m->act[l], zs[l][j], as[l + 1][j]);
+        if (FN(cap_ptr)) {
+            for (int j = 0; j < out; ++j) FN(cap_ptr)->delta[l][j] = delta[j];
+            for (int k = 0; k < in; ++k) FN(cap_ptr)->a[l][k] = as[l][k];
+        }
         if (gp0) {
             REAL* gW = gp0 + offs[l];
             REAL* gb = gW + (size_t)in * out;
@@ -514,6 +526,12 @@ typedef struct {
     int alg, order, maxiters;
     int nerr; /* > 0: only the first nerr components enter the error norm and the initial-dt norms (the `fast` adjoint mode:
                * lambda-only error control, the parameter cotangent is carried as a quadrature) */
+    /* FAST_MM (null otherwise): told about every evaluation that defines a stage derivative and about every rejection */
+    void* mm;
+    void (*mm_eval)(void* mm, int sidx);                 /* the evaluation just made is k[sidx] (sidx = 0 also: f0, reset_fsal!) */
+    void (*mm_fsal)(void* mm, int from, int to);         /* k[to] = k[from] (FSAL hand-over on acceptance) */
+    void (*mm_stage)(void* mm, int sidx, REAL w);        /* stage sidx of an attempt enters the quadrature with weight w = dt b_s */
+    void (*mm_reject)(void* mm, REAL dt, const REAL* B, int S);   /* the attempt is taken back: the same stages with -w */
 } FN(ropts);
 
 static void FN(resolve_opts)(const udeo_solve_opts* o, REAL t0, REAL tf, FN(ropts)* r) {
@@ -531,6 +549,7 @@ static void FN(resolve_opts)(const udeo_solve_opts* o, REAL t0, REAL tf, FN(ropt
     r->beta1 = (REAL)(o->beta1 > 0 ? o->beta1 : 7.0 / (10.0 * r->order));
     r->dt0 = (REAL)o->dt0;
     r->nerr = 0;
+    r->mm = 0; r->mm_eval = 0; r->mm_fsal = 0; r->mm_stage = 0; r->mm_reject = 0;
 }
 
 /* ARITH-SPEC: the three norms of the initial-dt heuristic enter dt at full precision (no Float32 controller
@@ -618,13 +637,17 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
 
     if (r->dt0 > 0) {
         dt = tdir * r->dt0;
-        if (alg == UDEO_ALG_TSIT5) { f(fctx, t, uprev, kk[0]); nf += 1; }
+        if (alg == UDEO_ALG_TSIT5) { f(fctx, t, uprev, kk[0]); nf += 1; if (r->mm) r->mm_eval(r->mm, 0); }
     } else {
         int nanflag = 0;
         dt = FN(initdt)(r, f, fctx, uprev, t, tdir, nz, f0, w1, w2, &nanflag);
         nf += 2;
         if (nanflag) { ret = UDEO_RET_UNSTABLE; goto done; }
-        if (alg == UDEO_ALG_TSIT5) { memcpy(kk[0], f0, sizeof(REAL) * nz); nf += 1; } /* initialize!: fsalfirst = f(u0) */
+        if (alg == UDEO_ALG_TSIT5) {   /* initialize!: fsalfirst = f(u0) */
+            memcpy(kk[0], f0, sizeof(REAL) * nz); nf += 1;
+            /* (FAST_MM: the factors of f(u0) -- initdt evaluated it first, a second point after it: evaluate it again, same bits) */
+            if (r->mm) { f(fctx, t, uprev, kk[0]); r->mm_eval(r->mm, 0); }
+        }
     }
 
     while (its < ntstops) {
@@ -650,12 +673,17 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
             /* ---- perform_step! (table-driven; ARITH-SPEC fma chains) ---- */
             {
                 const int S = alg == UDEO_ALG_TSIT5 ? 7 : 10;
-                if (alg == UDEO_ALG_VERN7) f(fctx, t, uprev, kk[0]); /* not FSAL */
+                if (alg == UDEO_ALG_VERN7) { f(fctx, t, uprev, kk[0]); if (r->mm) r->mm_eval(r->mm, 0); } /* not FSAL */
+                if (r->mm && Btab[0] != 0) r->mm_stage(r->mm, 0, dt * Btab[0]);
                 for (int sidx = 1; sidx < S; ++sidx) {
                     const REAL* row = alg == UDEO_ALG_TSIT5 ? A5[sidx] : A7[sidx];
                     REAL* dst = (alg == UDEO_ALG_TSIT5 && sidx == S - 1) ? u : tmp;
                     FN(combine)(row, sidx, kk, dt, uprev, nz, dst);
                     f(fctx, t + Ctab[sidx] * dt, dst, kk[sidx]);
+                    if (r->mm) {
+                        r->mm_eval(r->mm, sidx);
+                        if (Btab[sidx] != 0) r->mm_stage(r->mm, sidx, dt * Btab[sidx]);
+                    }
                 }
                 nf += alg == UDEO_ALG_TSIT5 ? 6 : 10;
                 if (alg == UDEO_ALG_VERN7) FN(combine)(Btab, S, kk, dt, uprev, nz, u);
@@ -715,12 +743,13 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
                 }
                 dt = dtnew;
                 memcpy(uprev, u, sizeof(REAL) * nz);
-                if (alg == UDEO_ALG_TSIT5) memcpy(kk[0], kk[6], sizeof(REAL) * nz); /* FSAL */
+                if (alg == UDEO_ALG_TSIT5) { memcpy(kk[0], kk[6], sizeof(REAL) * nz); if (r->mm) r->mm_fsal(r->mm, 6, 0); } /* FSAL */
                 for (int i = 0; i < nz; ++i)
                     if (u[i] != u[i]) { ret = UDEO_RET_UNSTABLE; goto done; }
             } else {
                 nrej += 1;
                 if (EEst != EEst) { ret = UDEO_RET_UNSTABLE; goto done; }
+                if (r->mm) r->mm_reject(r->mm, dt, Btab, alg == UDEO_ALG_TSIT5 ? 7 : 10);
             }
         }
         /* ---- handle_tstop! + callbacks ---- */
@@ -729,6 +758,7 @@ static int FN(integrate)(const FN(ropts)* r, int nz, FN(rhs_fn) f, void* fctx, R
             if (on_tstop(tctx, t, uprev) && its < ntstops && alg == UDEO_ALG_TSIT5) {
                 f(fctx, t, uprev, kk[0]); /* reset_fsal! after u_modified! */
                 nf += 1;
+                if (r->mm) r->mm_eval(r->mm, 0);
             }
         }
     }
@@ -1001,6 +1031,47 @@ static int FN(discrete_sweep)(const udeo_model_desc* m, const REAL* theta, const
     return UDEO_RET_SUCCESS;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * UDEO_SENSE_FAST_MM: the parameter cotangent of the `fast` mode in the association of the device's block-level matrix-core
+ * accumulation (csrc/ude_seir_lsf.h).  Per network parameter ONE fused chain over the stage evaluations of the adjoint solve, in the
+ * order they are made:   W_l[j][k]: mu = fma(-((dt b_s) delta_l[j]), a_l[k], mu);   b_l[j]: the same with a = 1
+ * (what v_mfma_f64_16x16x4 executes on zero-padded operands: d = fma(a_k, b_k, d), k ascending).  The contribution of a stage is
+ * added when the stage is evaluated -- before the step is accepted or rejected --; a rejected attempt is taken back by the same
+ * chain with negated weights, stage 0 .. S-1, before the step is repeated (the device replays the attempt).  The lambda solve is
+ * untouched: same steps, same dL/du0 as UDEO_SENSE_FAST.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const udeo_model_desc* m;
+    REAL* acc;             /* np: the running parameter cotangent */
+    FN(vjpcap) last;       /* where the reverse sweeps of this thread leave their factors */
+    FN(vjpcap) fac[10];    /* the factors behind the stage derivatives k[0 .. S-1] */
+} FN(mmctx);
+
+static void FN(mm_apply)(FN(mmctx)* c, const FN(vjpcap)* F, REAL w) {
+    const udeo_model_desc* m = c->m;
+    REAL* g = c->acc + m->nn_offset;
+    size_t off = 0;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const int in = m->dims[l], out = m->dims[l + 1];
+        REAL* gW = g + off;
+        REAL* gb = gW + (size_t)in * out;
+        for (int j = 0; j < out; ++j) {
+            const REAL cj = -(w * F->delta[l][j]);
+            for (int k = 0; k < in; ++k) gW[j + (size_t)k * out] = R_FMA(cj, F->a[l][k], gW[j + (size_t)k * out]);
+            gb[j] = R_FMA(cj, (REAL)1, gb[j]);
+        }
+        off += (size_t)in * out + out;
+    }
+}
+static void FN(mm_eval)(void* mm, int sidx) { FN(mmctx)* c = (FN(mmctx)*)mm; c->fac[sidx] = c->last; }
+static void FN(mm_fsal)(void* mm, int from, int to) { FN(mmctx)* c = (FN(mmctx)*)mm; c->fac[to] = c->fac[from]; }
+static void FN(mm_stage)(void* mm, int sidx, REAL w) { FN(mmctx)* c = (FN(mmctx)*)mm; FN(mm_apply)(c, &c->fac[sidx], w); }
+static void FN(mm_reject)(void* mm, REAL dt, const REAL* B, int S) {
+    FN(mmctx)* c = (FN(mmctx)*)mm;
+    for (int sidx = 0; sidx < S; ++sidx)
+        if (B[sidx] != 0) FN(mm_apply)(c, &c->fac[sidx], -(dt * B[sidx]));
+}
+
 /* forward dense + backward; cot: n x ns.  grad_theta += ; grad_u0 (n) = */
 static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const REAL* theta,
                        const REAL* u0, REAL t0, REAL tf, const REAL* saveat, int ns,
@@ -1070,11 +1141,32 @@ static int FN(vjp_one)(const udeo_model_desc* m, const udeo_solve_opts* o, const
     FN(adj_tstop)(&ac, tf, z); /* init_cb: jump at t = tf before the first step */
     FN(ropts) r;
     FN(resolve_opts)(o, t0, tf, &r);
-    if (o->sensealg == UDEO_SENSE_FAST) r.nerr = n; /* lambda-only error control */
+    if (o->sensealg == UDEO_SENSE_FAST || o->sensealg == UDEO_SENSE_FAST_MM) r.nerr = n; /* lambda-only error control */
+    FN(mmctx)* mm = 0;
+    if (o->sensealg == UDEO_SENSE_FAST_MM) {
+        /* every parameter must be a network parameter (the fused chains are defined per layer factor) */
+        size_t nnp = 0;
+        for (int l = 0; l < m->n_layers; ++l) nnp += (size_t)m->dims[l] * m->dims[l + 1] + m->dims[l + 1];
+        if ((m->kind != UDEO_KIND_SEIR_UDE && m->kind != UDEO_KIND_SEIR_NODE) || m->nn_offset != 0 || (size_t)np != nnp) {
+            free(tst); free(ac.y); free(ac.gtheta); free(z); free(cot);
+            free(d.t); free(d.u); free(d.k); free(d.dt); free(pred);
+            return 99;
+        }
+        mm = (FN(mmctx)*)calloc(1, sizeof(FN(mmctx)));
+        mm->m = m;
+        mm->acc = (REAL*)calloc(np, sizeof(REAL));
+        FN(cap_ptr) = &mm->last;
+        r.mm = mm; r.mm_eval = FN(mm_eval); r.mm_fsal = FN(mm_fsal); r.mm_stage = FN(mm_stage); r.mm_reject = FN(mm_reject);
+    }
     /* a user `dt` reaches the adjoint solve too: _concrete_solve_adjoint hands the solve's keyword arguments on to
      * adjoint_sensitivities -> solve(adj_prob, alg; abstol, reltol, kwargs...) [UP?]; OrdinaryDiffEq takes dt = tdir * abs(dt) */
     ret = FN(integrate)(&r, nz, FN(adj_rhs), &ac, z, tf, tst, nt, 0, 0, FN(adj_tstop), &ac,
                         &stats[4], &stats[5], &stats[6], 0);
+    if (mm) {
+        FN(cap_ptr) = 0;
+        for (int i = 0; i < np; ++i) grad_theta[i] += mm->acc[i];
+        free(mm->acc); free(mm);
+    } else
     for (int i = 0; i < np; ++i) grad_theta[i] += z[n + i];
     if (grad_u0) for (int i = 0; i < n; ++i) grad_u0[i] = z[i];
     free(tst); free(ac.y); free(ac.gtheta); free(z); free(cot);

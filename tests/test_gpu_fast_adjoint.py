@@ -43,21 +43,76 @@ def test_lv_fast_mode_matches_oracle_and_parity_mode(golden, alg, oalg):
     assert_bitwise(one.grad_theta, ref1["grad_theta"], "dL/dtheta")
 
 
-def test_seir_fast_mode_matches_oracle():
-    """deferred parameter cotangent: the slot sums are formed on accepted steps only (commit_slots)"""
-    N = 8
+def _seir_fast_case(N, seed=11, scale=10.0):
     u0, t = seir_inputs(N)
     truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
-    th = models.seir_chain().glorot_uniform(np.random.default_rng(11))
-    th[-65:-1] *= 10.0
+    th = models.seir_chain().glorot_uniform(np.random.default_rng(seed))
+    th[-65:-1] *= scale
+    return u0, t, truth, th
+
+
+def test_seir_fast_mode_matches_oracle():
+    """the wavefront-per-trajectory kernel (lanes_per_traj = 64): deferred parameter cotangent, the slot sums are formed on accepted
+    steps only (commit_slots) -- the oracle's UDEO_SENSE_FAST association"""
+    N = 8
+    u0, t, truth, th = _seir_fast_case(N)
     ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 21.0), th), u0)
+    W64 = U.EnsembleMI355(lanes_per_traj=64)
     for alg, oalg in ((U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)):
-        r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST())
+        r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST(), ensemblealg=W64)
         ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6, sensealg=2), u0, [0.0, 21.0], th, t, truth, row_mask=MASK, nthreads=8)
         check_per_trajectory(r, ref)
         assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
         full = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
         assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
+
+
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+@pytest.mark.parametrize("kw", [{}, {"dt": 0.9}], ids=["auto-dt", "dt0.9-rejections"])
+def test_seir_fast_mode_block_level_matrix_core_accumulation(alg, oalg, kw):
+    """round 5: the DEFAULT fast-mode kernel of the SEIR exposure UDE (csrc/ude_seir_lsf.h): 16 trajectory slots in lock-step, the
+    parameter cotangent accumulated per trip on v_mfma_f64_16x16x4 into block-resident registers -- no mu in HBM, no per-trajectory
+    gradient row.  The lambda solve is the fast mode's (backward step counts and dL/du0 bit-identical to the oracle per trajectory);
+    the gradient is the oracle's UDEO_SENSE_FAST_MM association: ONE trajectory -> every one of the 4481 entries bit for bit (a
+    given dt = 0.9 makes the first attempts fail: rejected attempts are replayed with negated weights, oracle and device alike);
+    several trajectories interleave in the block's chains -> <= 1e-12; and against the parity mode: the solver tolerance."""
+    okw = {"dt0": kw["dt"]} if kw else {}
+    # one trajectory: bitwise, all entries
+    u0, t, truth, th = _seir_fast_case(3)
+    for j in (0, 2):
+        one = U.loss_and_gradient(U.ODEProblem(models.dudt_(), u0[j], (0.0, 21.0), th), alg(), truth[j:j + 1], row_mask=MASK, saveat=t,
+                                  abstol=1e-6, reltol=1e-6, sensealg=FAST(), **kw)
+        ref1 = O.loss_grad_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6, sensealg=4, **okw), u0[j], [0.0, 21.0], th, t, truth[j:j + 1], row_mask=MASK)
+        check_per_trajectory(one, ref1)
+        if kw:
+            assert ref1["stats"][:, 6].sum() > 0      # the case does contain rejected backward steps
+        assert_bitwise(one.grad_theta, ref1["grad_theta"], "dL/dtheta, single trajectory")
+    # partial block, one full block + a refill, several blocks
+    for N in (5, 37, 300):
+        u0, t, truth, th = _seir_fast_case(N)
+        ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 21.0), th), u0)
+        r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST(), **kw)
+        ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(oalg, 1e-6, 1e-6, sensealg=4, **okw), u0, [0.0, 21.0], th, t, truth, row_mask=MASK, nthreads=8)
+        check_per_trajectory(r, ref)
+        assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+        r2 = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST(), **kw)
+        assert_bitwise(r.grad_theta, r2.grad_theta, "two runs, same bits (no queue: the trajectories are dealt round-robin)")
+        if N == 37 and not kw:
+            full = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
+            assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
+
+
+def test_seir_fast_block_mode_user_cotangent():
+    """the pullback entry point (a user cotangent instead of data) through the block-level kernel"""
+    N = 20
+    u0, t, truth, th = _seir_fast_case(N)
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 21.0), th), u0)
+    cot = np.random.default_rng(3).standard_normal((N, len(t), 7)) * 1e-3
+    r = U.adjoint_pullback(ens, U.Vern7(), cot, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST())
+    ref = O.vjp_ensemble(O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=4), u0, [0.0, 21.0], th, t, cot, nthreads=8)
+    assert_bitwise(r.grad_u0, ref["grad_u0"], "dL/du0")
+    assert_bitwise(r.stats[:, 4:8], ref["stats"][:, 4:8], "backward counts")
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
 
 
 def test_node_and_kpp_fast_mode_match_oracle():

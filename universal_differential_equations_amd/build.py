@@ -237,6 +237,8 @@ def build(verbose=True, jobs=None):
     # the lock-step matrix-core adjoint of the SEIR exposure UDE
     work.append((os.path.join(CSRC, "ude_seir_ls.hip"), os.path.join(OBJ, "ude_seir_ls.o"), [], os.path.join(OBJ, "ude_seir_ls.log")))
     work.append((os.path.join(CSRC, "ude_node_ls.hip"), os.path.join(OBJ, "ude_node_ls.o"), [], os.path.join(OBJ, "ude_node_ls.log")))
+    # the `fast` mode of the lock-step kernels: parameter cotangent as a block-level matrix-core accumulation
+    work.append((os.path.join(CSRC, "ude_seir_lsf.hip"), os.path.join(OBJ, "ude_seir_lsf.o"), os.environ.get("UDE_LSF_DEFS", "").split(), os.path.join(OBJ, "ude_seir_lsf.log")))
     # the multi-GPU exchange step (RCCL bound with dlopen, one-shot P2P reducer), SURVEY.md 8(e)
     work.append((os.path.join(CSRC, "ude_comm.hip"), os.path.join(OBJ, "ude_comm.o"), [], os.path.join(OBJ, "ude_comm.log")))
     # debug variants of the two host-side units (see LIB_DBG)
