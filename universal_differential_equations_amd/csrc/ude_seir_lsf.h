@@ -59,6 +59,12 @@ using seirls::OFF_B3;
 #ifndef UDE_LSF_W2_RELOAD
 #define UDE_LSF_W2_RELOAD (UDE_LSF_PER_CU > 1)
 #endif
+#ifndef UDE_LSF_DEFER_SMALL
+#define UDE_LSF_DEFER_SMALL 0   // 1: db2, dW1 | db1, dW3 of trip T are formed in trip T + 1 next to the first layer's tanh (measured: slower)
+#endif
+#ifndef UDE_LSF_W2_EARLY
+#define UDE_LSF_W2_EARLY 0      // (with W2_RELOAD) 1: W2's fragment is requested in front of barrier 1 instead of behind it
+#endif
 #ifndef UDE_LSF_PREFETCH
 #define UDE_LSF_PREFETCH 1   // the record of the next-lower forward interval is fetched one interval ahead (16 registers per lane)
 #endif
@@ -67,7 +73,7 @@ enum { PH_IDLE = -4, PH_FLUSH = -3, PH_INIT0 = -2, PH_INIT1 = -1 };   // >= 0: s
 
 template <class Tab>
 constexpr int lds_doubles() {
-    return 4 * H * TLD + 4 * 16 + 16 + 16 + 3 * NSLOTS * 4 + NSLOTS * 16 + NSLOTS * 8 + TABL + 16 * 8 + NSLOTS * 8 + NSLOTS * kst<Tab>() + 3 * H +
+    return 4 * H * TLD + 2 * (4 * 16 + 16 + 16) + 3 * NSLOTS * 4 + NSLOTS * 16 + NSLOTS * 8 + TABL + 16 * 8 + NSLOTS * 8 + NSLOTS * kst<Tab>() + 3 * H +
            NSLOTS * Tab::S * 8 + NSLOTS + 2 * H;
 }
 
@@ -80,10 +86,11 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     double* T_D2 = T_A1 + H * TLD;            // delta2
     double* T_D1 = T_D2 + H * TLD;            // delta1
     double* T_A2 = T_D1 + H * TLD;            // a2
-    double* XIN = T_A2 + H * TLD;             // [4][16]: x0 x1 x2 1
-    double* D3S = XIN + 4 * 16;               // [16] delta3 of the slot
-    double* WSL = D3S + 16;                   // [16] weight dt b_s of the slot's evaluation (0: contributes nothing)
-    double* GXP = WSL + 16;                   // [3][16][4]: per wavefront partial sums of the input cotangent
+    // per-slot inputs of a trip, TWO copies (trip parity): the small products of the parameter cotangent of trip T are formed in trip
+    // T + 1, under the first layer's tanh (see "the parameter cotangent" below), when the slots' rows have already written trip T + 1's
+    double* XIN0 = T_A2 + H * TLD;            // [2][ [4][16]: x0 x1 x2 1 | [16] delta3 | [16] weight dt b_s (0: contributes nothing) ]
+    constexpr int XSZ = 4 * 16 + 16 + 16;
+    double* GXP = XIN0 + 2 * XSZ;             // [3][16][4]: per wavefront partial sums of the input cotangent
     double* BQ = GXP + 3 * NSLOTS * 4;        // [16][16]
     double* YS = BQ + NSLOTS * 16;            // [16][8]
     double* TB = YS + NSLOTS * 8;             // tableau: A[16][16], B, BT, C
@@ -125,12 +132,31 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     for (int i = tid; i < 3 * H; i += BLOCKT) W1L[i] = th[OFF_W1 + i];
     if (tid < H) { B2L[tid] = th[OFF_B2 + tid]; W3L[tid] = th[OFF_W3 + tid]; }
     const int u0r = 16 * w + 4 * kq;          // first of this lane's four units
+#if UDE_LSF_PER_CU == 1   // (512 registers per lane: b2 and w3 of this lane's units stay in registers; two blocks per CU: read from LDS)
+    double b2r[4], w3r[4];
+    static_for<0, 4>([&](auto r) { b2r[r] = th[OFF_B2 + u0r + decltype(r)::value]; w3r[r] = th[OFF_W3 + u0r + decltype(r)::value]; });
+#define LSF_B2(r) b2r[r]
+#define LSF_W3(r) w3r[r]
+#else
+#define LSF_B2(r) B2L[u0r + r]
+#define LSF_W3(r) W3L[u0r + r]
+#endif
     const double Fc = p.mc.consts[0], b0c = p.mc.consts[1], muc = p.mc.consts[4], sgc = p.mc.consts[5], gac = p.mc.consts[6],
                  dc = p.mc.consts[7], lac = p.mc.consts[8];
     // every column finite from the first trip on (a column without an evaluation multiplies its zero weight with what the tiles hold)
     for (int i = tid; i < 4 * H * TLD; i += BLOCKT) T_A1[i] = 0.0;
-    if (tid < 64) XIN[tid] = tid >= 48 ? 1.0 : 0.0;
-    if (tid < 16) { D3S[tid] = 0.0; WSL[tid] = 0.0; MB3[tid] = 0.0; }
+    if (tid < 2 * XSZ) XIN0[tid] = ((tid % XSZ) >= 48 && (tid % XSZ) < 64) ? 1.0 : 0.0;
+    if (tid < 16) MB3[tid] = 0.0;
+#if UDE_LSF_DEFER_SMALL
+    int par = 0;                              // parity of the trip
+    double* XIN = XIN0;
+    double* D3S = XIN + 4 * 16;
+    double* WSL = D3S + 16;
+#else
+    double* const XIN = XIN0;
+    double* const D3S = XIN + 4 * 16;
+    double* const WSL = D3S + 16;
+#endif
     for (int i = tid; i < 16 * 16; i += BLOCKT) TB[i] = tab->A[i >> 4][i & 15];
     if (tid < 16) { TB[256 + tid] = tab->B[tid]; TB[272 + tid] = tab->BT[tid]; TB[288 + tid] = tab->C[tid]; }
     for (int i = tid; i < NSLOTS * 8; i += BLOCKT) { YS[i] = 0.0; F0L[i] = 0.0; }
@@ -220,7 +246,30 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
         }
         if (p.grad_u0 && lm < NC) p.grad_u0[(size_t)gid * n + lm] = zo;
     };
+    // db2, dW1 | db1, dW3 of one trip from the tiles and that trip's copy of the slots' inputs
+    auto small_products = [&](const double* xin) {
+        const double* d3s = xin + 4 * 16;
+        const double* wsl = d3s + 16;
+        static_for<0, 4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const int k = 4 * q + kq;
+            const double wk = wsl[k];
+            const int rown = (16 * w + jc) * TLD + k;
+            const double Ad2 = -(wk * T_D2[rown]);
+            const double Ad1 = -(wk * T_D1[rown]);
+            const double Aa2 = T_A2[rown];
+            gB2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad2, jc == 0 ? 1.0 : 0.0, gB2, 0, 0, 0);
+            gW1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad1, jc < 4 ? xin[(jc & 3) * 16 + k] : 0.0, gW1, 0, 0, 0);
+            gW3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Aa2, jc == 0 ? -(wk * d3s[k]) : 0.0, gW3, 0, 0, 0);
+        });
+    };
     __syncthreads();
+#if defined(UDE_LSF_CLOCKS)   // timing experiment: cycles of wavefront 0 of block 0 per section of a trip (tools/exp/lsf_prof.py)
+    unsigned long long tk = __builtin_readcyclecounter(), tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntrip = 0;
+#define LSF_TICK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tsec[i] += now_ - tk; tk = now_; }
+#else
+#define LSF_TICK(i)
+#endif
 
     for (;;) {
         // ---- A. an idle slot takes its next trajectory: g = block + nblocks (slot + 16 j) ----
@@ -303,6 +352,7 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
         }
         double zs[NC];
         bcast(zsrc, zs);
+        LSF_TICK(0)
 
         // ---- C. the forward state at tev, the network inputs ----
         double y[NC];
@@ -341,16 +391,29 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
             D3S[slot] = 0.0;
             WSL[slot] = 0.0;
         }
-        if (!__syncthreads_or(ph != PH_IDLE)) break;   // (all slots idle, no trajectory left: done)
-        {
 #if UDE_LSF_W2_RELOAD
-            const double* thw = th + OFF_W2;
-            asm volatile("" : "+s"(thw));   // (a fresh pointer every trip: the loads below must not be hoisted out of the loop)
-            double W2A[16];
+        const double* thw = th + OFF_W2;
+        asm volatile("" : "+s"(thw));   // (a fresh pointer every trip: the loads below must not be hoisted out of the loop)
+        double W2A[16];
+#if UDE_LSF_W2_EARLY
+        static_for<0, 16>([&](auto sc) { W2A[sc] = thw[urow + (4 * (int)decltype(sc)::value + kq) * H]; });
+#endif
+#endif
+        LSF_TICK(1)
+        if (!__syncthreads_or(ph != PH_IDLE)) break;   // (all slots idle, no trajectory left: done)
+        LSF_TICK(2)
+        {
+#if UDE_LSF_W2_RELOAD && !UDE_LSF_W2_EARLY
             static_for<0, 16>([&](auto sc) { W2A[sc] = thw[urow + (4 * (int)decltype(sc)::value + kq) * H]; });
 #endif
             // layer 1 (3 inputs + bias in one k-step)
             v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(W1A, XIN[kq * 16 + jc], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            // the small products of the PREVIOUS trip's parameter cotangent (db2, dW1 | db1, dW3: 12 MFMAs whose operands -- the delta2,
+            // delta1, a2 tiles and the other copy of the slots' inputs -- are untouched until the next barrier): the matrix pipe works
+            // on them while the vector unit evaluates the four tanh below
+#if UDE_LSF_DEFER_SMALL
+            small_products(XIN0 + (1 - par) * XSZ);
+#endif
             double a1[4], dv1[4];
             static_for<0, 4>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
@@ -358,10 +421,14 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                 T_A1[(u0r + r) * TLD + jc] = a1[r];
             });
             __syncthreads();
+            LSF_TICK(3)
 #if UDE_LSF_PREFETCH
             if (pf_want >= 0) { fetch_interval(pf_want); pf_want = -1; }
 #endif
             // hidden layer: four 16-term chains (four MFMAs each) added left to right
+#if UDE_LSF_W2_RELOAD
+            double W2T[16];
+#endif
             {
                 v4d acc[4];
                 static_for<0, 4>([&](auto bc) {
@@ -372,20 +439,21 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                         acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
                     });
                 });
+#if UDE_LSF_W2_RELOAD
+                // (W2's fragment has had its last use: the registers take W2^T, the four tanh below cover the latency)
+                static_for<0, 16>([&](auto sc) { W2T[sc] = thw[(4 * (int)decltype(sc)::value + kq) + urow * H]; });
+#endif
                 const double d3j = D3S[jc];
                 static_for<0, 4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + B2L[u0r + r];
+                    const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + LSF_B2(r);
                     const double a2 = dtanh(z2);
-                    T_D2[(u0r + r) * TLD + jc] = __builtin_fma(W3L[u0r + r], d3j, 0.0) * __builtin_fma(-a2, a2, 1.0);
+                    T_D2[(u0r + r) * TLD + jc] = __builtin_fma(LSF_W3(r), d3j, 0.0) * __builtin_fma(-a2, a2, 1.0);
                     T_A2[(u0r + r) * TLD + jc] = a2;
                 });
             }
-#if UDE_LSF_W2_RELOAD
-            double W2T[16];
-            static_for<0, 16>([&](auto sc) { W2T[sc] = thw[(4 * (int)decltype(sc)::value + kq) + urow * H]; });
-#endif
             __syncthreads();
+            LSF_TICK(4)
             // transposed hidden layer on the deltas
             {
                 v4d acc[4];
@@ -415,25 +483,31 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                 });
                 if (kq == 0) static_for<0, 3>([&](auto mc) { GXP[(decltype(mc)::value * NSLOTS + jc) * 4 + w] = pg[decltype(mc)::value]; });
             }
-            // ---- the parameter cotangent of this trip: K = the sixteen slot columns, weights on the delta side ----
+            LSF_TICK(5)
+            // ---- the parameter cotangent of this trip: K = the sixteen slot columns, weights on the delta side.  dW2 here (a1 is
+            // overwritten by the next trip's first layer); the small products follow in the next trip (small_products) ----
             static_for<0, 4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 const int k = 4 * q + kq;
                 const double wk = WSL[k];
-                const int rown = (16 * w + jc) * TLD + k;     // A operand: row jc of this wavefront's tile = unit 16w + jc (not permuted)
-                const double Ad2 = -(wk * T_D2[rown]);
-                const double Ad1 = -(wk * T_D1[rown]);
-                const double Aa2 = T_A2[rown];
+                const double Ad2 = -(wk * T_D2[(16 * w + jc) * TLD + k]);     // A operand: row jc of this wavefront's tile = unit 16w + jc (not permuted)
                 static_for<0, 4>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
                     gW2[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad2, T_A1[(16 * c + jc) * TLD + k], gW2[c], 0, 0, 0);
                 });
-                gB2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad2, jc == 0 ? 1.0 : 0.0, gB2, 0, 0, 0);
-                gW1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad1, jc < 4 ? XIN[(jc & 3) * 16 + k] : 0.0, gW1, 0, 0, 0);
-                gW3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Aa2, jc == 0 ? -(wk * D3S[k]) : 0.0, gW3, 0, 0, 0);
             });
+#if !UDE_LSF_DEFER_SMALL
+            small_products(XIN);
+#endif
         }
         __syncthreads();
+#if UDE_LSF_DEFER_SMALL
+        par = 1 - par;
+        XIN = XIN0 + par * XSZ;
+        D3S = XIN + 4 * 16;
+        WSL = D3S + 16;
+#endif
+        LSF_TICK(6)
 
         // ---- D. the slot's row: state cotangent of this evaluation, then its state machine ----
         if (ph == PH_FLUSH) {
@@ -594,8 +668,21 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                 }
             }
         }
+        LSF_TICK(7)
+#if defined(UDE_LSF_CLOCKS)
+        ntrip += 1;
+#endif
     }
 
+#if UDE_LSF_DEFER_SMALL
+    small_products(XIN0 + (1 - par) * XSZ);   // (the last trip's)
+#endif
+#if defined(UDE_LSF_CLOCKS)
+    if (p.trace && blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 8; ++i) p.trace[i] = (double)tsec[i];
+        p.trace[8] = (double)ntrip;
+    }
+#endif
     // ---- the block's row of the partial-gradient matrix (every entry written: a block without trajectories writes zeros) ----
     __syncthreads();
     if (lm == 0) MB3[slot] = mb3;
