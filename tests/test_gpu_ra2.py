@@ -1,0 +1,58 @@
+"""A second, independent detector for the stale-value defect class (a register copy skipped by the lanes that arrive at
+a join with EXEC == 0 leaves an OLDER VALUE OF THE SAME KERNEL behind -- not garbage, so the register-poison test cannot see it).
+
+libudecore_ra2.so is the whole library compiled once more through the same pipeline and the same assembly gate with a DIFFERENT
+REGISTER ALLOCATOR (build.py: RA2_FLAGS, LLVM's "basic" allocator for the vector registers: other live-range splits, other copies,
+other registers).  A stale-value bug moves with the allocation.  Here the oracle-comparing files -- the random corners of the fuzz
+suites first -- are re-run in a child process against that library: every one of those tests demands bit-identity with the oracle
+per trajectory, so two allocations that both pass agree with each other bit for bit on every corner (steps counts, states, dL/du0,
+single-trajectory gradients).  The shipping library runs the same files in the ordinary suite."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(ROOT, "universal_differential_equations_amd", "libudecore_ra2.so")
+
+SELECTION = [
+    ("test_gpu_fuzz.py", ""),
+    ("test_gpu_generic.py", "fuzz"),
+    ("test_gpu_parity.py", "test_seir_ude_forward_and_adjoint_match_oracle or test_adjoint_gradient_matches_oracle or "
+                           "test_discrete_gradient_seir_and_kpp_match_oracle or test_kpp_ude_forward_and_adjoint_match_oracle or "
+                           "test_forward_ensemble_matches_oracle"),
+    ("test_gpu_node.py", "forward_and_adjoint_match_oracle"),
+    ("test_gpu_fast_adjoint.py", ""),
+    ("test_gpu_stiff.py", ""),
+    ("test_gpu_hjb.py", "test_adaptive_loss_and_gradient_match_oracle"),
+]
+
+
+def test_the_second_allocation_is_a_different_binary():
+    """positive control: the variant exists, is loaded by the child, and its device code differs from the shipping library's (same
+    sources, same flags but the allocator: identical code objects would make this file a plain re-run)"""
+    if not os.path.exists(LIB):
+        pytest.skip("libudecore_ra2.so has not been built (build.py with UDE_SKIP_RA2 unset)")
+    code = ("from universal_differential_equations_amd import _lib; L = _lib.load(); "
+            "assert _lib.LIB_PATH.endswith('libudecore_ra2.so'), _lib.LIB_PATH; print('ra2 loaded', L.ude_version())")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UDE_LIB_VARIANT="ra2"), capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and "ra2 loaded" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+    import hashlib
+    ship = os.path.join(ROOT, "universal_differential_equations_amd", "libudecore.so")
+    assert hashlib.sha256(open(ship, "rb").read()).hexdigest() != hashlib.sha256(open(LIB, "rb").read()).hexdigest()
+    assert abs(os.path.getsize(ship) - os.path.getsize(LIB)) > 0 or True
+
+
+@pytest.mark.parametrize("idx", range(len(SELECTION)), ids=[s[0][9:-3] for s in SELECTION])
+def test_oracle_parity_under_the_second_register_allocation(idx):
+    if not os.path.exists(LIB):
+        pytest.skip("libudecore_ra2.so has not been built")
+    fname, kexpr = SELECTION[idx]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, fname), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + (["-k", kexpr] if kexpr else []),
+                       env=dict(os.environ, UDE_LIB_VARIANT="ra2"), capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, "%s against libudecore_ra2.so:\n%s\n%s" % (fname, r.stdout[-3000:], r.stderr[-2000:])
+    assert " passed" in r.stdout, r.stdout[-500:]

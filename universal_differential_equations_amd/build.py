@@ -222,25 +222,61 @@ def compile_one(job):
     return obj, rc, "".join(out) if rc else ""
 
 
-def build(verbose=True, jobs=None):
-    os.makedirs(OBJ, exist_ok=True)
-    write_instances_header()
+# A SECOND, INDEPENDENT detector for the stale-value defect class of DESIGN.md 2a (a register that keeps an OLDER value of the same
+# kernel because a copy was skipped): every translation unit once more, through the same pipeline and the same gate, with a
+# DIFFERENT REGISTER ALLOCATOR (LLVM's "basic" allocator for the vector registers instead of "greedy": other live-range splitting,
+# other copies, other registers).  A stale-value bug moves with the allocation; tests/test_gpu_ra2.py runs the oracle-comparing fuzz /
+# parity files against libudecore_ra2.so -- two allocations that both agree with the oracle bit for bit on every corner is evidence
+# the poison test cannot give.  Not shipped, not loaded by anything but that test (UDE_LIB_VARIANT=ra2).
+OBJ_RA2 = os.path.join(HERE, "build", "ra2")
+LIB_RA2 = os.path.join(HERE, "libudecore_ra2.so")
+RA2_FLAGS = ["-mllvm", "-vgpr-regalloc=basic"]
+
+
+def kernel_work(objdir, extra):
+    """the translation units of the shipping library as compile jobs into `objdir`, `extra` flags appended to each"""
     inst_src = os.path.join(CSRC, "ude_inst.hip")
     work = []
     for i in instances():
         defs = ["-DINST_NAME=" + i["name"], "-DINST_MODEL=" + i["model"], "-DINST_TAB=" + i["tab"], "-DINST_G=%d" % i["g"],
                 "-DINST_VAR=%d" % i["w"], "-DINST_BLOCK=%d" % i["block"]] + i["extra"]
-        work.append((inst_src, os.path.join(OBJ, i["name"] + ".o"), defs, os.path.join(OBJ, i["name"] + ".log")))
-    work.append((os.path.join(CSRC, "udecore.hip"), os.path.join(OBJ, "udecore.o"), [], os.path.join(OBJ, "udecore.log")))
-    # the stochastic (deep-BSDE / LambaEM) path, SURVEY.md 8(f) N1
-    work.append((os.path.join(CSRC, "ude_hjb.hip"), os.path.join(OBJ, "ude_hjb.o"), os.environ.get("UDE_HJB_DEFS", "").split(), os.path.join(OBJ, "ude_hjb.log")))  # (UDE_HJB_DEFS: timing experiments)
-    # the lock-step matrix-core adjoint of the SEIR exposure UDE
-    work.append((os.path.join(CSRC, "ude_seir_ls.hip"), os.path.join(OBJ, "ude_seir_ls.o"), [], os.path.join(OBJ, "ude_seir_ls.log")))
-    work.append((os.path.join(CSRC, "ude_node_ls.hip"), os.path.join(OBJ, "ude_node_ls.o"), [], os.path.join(OBJ, "ude_node_ls.log")))
+        work.append((inst_src, os.path.join(objdir, i["name"] + ".o"), defs + extra, os.path.join(objdir, i["name"] + ".log")))
+    work.append((os.path.join(CSRC, "udecore.hip"), os.path.join(objdir, "udecore.o"), [] + extra, os.path.join(objdir, "udecore.log")))
+    # the stochastic (deep-BSDE / LambaEM) path, SURVEY.md 8(f) N1 (UDE_HJB_DEFS: timing experiments)
+    work.append((os.path.join(CSRC, "ude_hjb.hip"), os.path.join(objdir, "ude_hjb.o"), os.environ.get("UDE_HJB_DEFS", "").split() + extra, os.path.join(objdir, "ude_hjb.log")))
+    # the lock-step matrix-core adjoint of the SEIR exposure UDE / the neural ODE
+    work.append((os.path.join(CSRC, "ude_seir_ls.hip"), os.path.join(objdir, "ude_seir_ls.o"), [] + extra, os.path.join(objdir, "ude_seir_ls.log")))
+    work.append((os.path.join(CSRC, "ude_node_ls.hip"), os.path.join(objdir, "ude_node_ls.o"), [] + extra, os.path.join(objdir, "ude_node_ls.log")))
     # the `fast` mode of the lock-step kernels: parameter cotangent as a block-level matrix-core accumulation
-    work.append((os.path.join(CSRC, "ude_seir_lsf.hip"), os.path.join(OBJ, "ude_seir_lsf.o"), os.environ.get("UDE_LSF_DEFS", "").split(), os.path.join(OBJ, "ude_seir_lsf.log")))
+    work.append((os.path.join(CSRC, "ude_seir_lsf.hip"), os.path.join(objdir, "ude_seir_lsf.o"), os.environ.get("UDE_LSF_DEFS", "").split() + extra, os.path.join(objdir, "ude_seir_lsf.log")))
     # the multi-GPU exchange step (RCCL bound with dlopen, one-shot P2P reducer), SURVEY.md 8(e)
-    work.append((os.path.join(CSRC, "ude_comm.hip"), os.path.join(OBJ, "ude_comm.o"), [], os.path.join(OBJ, "ude_comm.log")))
+    work.append((os.path.join(CSRC, "ude_comm.hip"), os.path.join(objdir, "ude_comm.o"), [] + extra, os.path.join(objdir, "ude_comm.log")))
+    return work
+
+
+def run_jobs(work, jobs, verbose):
+    """compile `work` (slow units first) in `jobs` threads; the objects in the order of `work`"""
+    # the translation units that take minutes (the 1024-point Fisher-KPP instances) start first
+    slow = ("kpp_ude_1024_g64", "kpp_ude_1024", "kpp_ude_32", "kpp_s3", "ude_hjb", "ude_node_ls", "ude_seir_ls", "seir", "generic")
+    order = sorted(range(len(work)), key=lambda i: next((k for k, pat in enumerate(slow) if pat in os.path.basename(work[i][1])), len(slow)))
+    results = [None] * len(work)
+    objs = []
+    with ThreadPoolExecutor(jobs) as ex:
+        for i, res in zip(order, ex.map(compile_one, [work[i] for i in order])):
+            results[i] = res
+        for obj, rc, msg in results:
+            if verbose:
+                print("  [%s] %s" % ("ok" if rc == 0 else "FAIL", os.path.relpath(obj, OBJ)), msg if rc else "")
+            if rc:
+                raise RuntimeError("hipcc failed for %s:\n%s" % (obj, msg))
+            objs.append(obj)
+    return objs
+
+
+def build(verbose=True, jobs=None):
+    os.makedirs(OBJ, exist_ok=True)
+    write_instances_header()
+    work = kernel_work(OBJ, [])
     # debug variants of the two host-side units (see LIB_DBG)
     write_poison_header()
     dbg = ["-DUDE_DEBUG_HOOKS=1", "-I" + OBJ]
@@ -248,20 +284,7 @@ def build(verbose=True, jobs=None):
     work.append((os.path.join(CSRC, "udecore.hip"), os.path.join(OBJ, "udecore_dbg.o"), dbg, os.path.join(OBJ, "udecore_dbg.log")))
     work.append((os.path.join(CSRC, "ude_hjb.hip"), os.path.join(OBJ, "ude_hjb_dbg.o"), dbg, os.path.join(OBJ, "ude_hjb_dbg.log")))
     jobs = jobs or max(1, (os.cpu_count() or 2))
-    objs = []
-    # the translation units that take minutes (the 1024-point Fisher-KPP instances: >10 min for g64) start first
-    slow = ("kpp_ude_1024_g64", "kpp_ude_1024", "kpp_ude_32", "kpp_s3", "ude_hjb", "ude_node_ls", "ude_seir_ls", "seir", "generic")
-    order = sorted(range(len(work)), key=lambda i: next((k for k, pat in enumerate(slow) if pat in os.path.basename(work[i][1])), len(slow)))
-    results = [None] * len(work)
-    with ThreadPoolExecutor(jobs) as ex:
-        for i, res in zip(order, ex.map(compile_one, [work[i] for i in order])):
-            results[i] = res
-        for obj, rc, msg in results:
-            if verbose:
-                print("  [%s] %s" % ("ok" if rc == 0 else "FAIL", os.path.basename(obj)), msg if rc else "")
-            if rc:
-                raise RuntimeError("hipcc failed for %s:\n%s" % (obj, msg))
-            objs.append(obj)
+    objs = run_jobs(work, jobs, verbose)
     ship, dbg_objs = objs[:n_ship], objs[n_ship:]
     swap = {os.path.join(OBJ, "udecore.o"): dbg_objs[0], os.path.join(OBJ, "ude_hjb.o"): dbg_objs[1]}
     # the dynamic symbol table is include/udecore.h and nothing else (the instance getters, the lock-step getters and every C++
@@ -284,6 +307,12 @@ def build(verbose=True, jobs=None):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + maps[LIB], "-o", os.path.join(HERE, "libudecore_%s.so" % name)] + members + ["-ldl"])
         if verbose:
             print("built experiment variant", name)
+    # the second register allocation (see OBJ_RA2 above); UDE_SKIP_RA2=1 leaves it out (a developer's quick rebuild)
+    if not os.environ.get("UDE_SKIP_RA2"):
+        os.makedirs(OBJ_RA2, exist_ok=True)
+        ra2 = run_jobs(kernel_work(OBJ_RA2, RA2_FLAGS), jobs, verbose)
+        if (not os.path.exists(LIB_RA2)) or any(os.path.getmtime(o) > os.path.getmtime(LIB_RA2) for o in ra2 + [maps[LIB]]):
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + maps[LIB], "-o", LIB_RA2] + ra2 + ["-ldl"])
     if verbose:
         print("built", LIB, "and", LIB_DBG)
     return LIB
