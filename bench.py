@@ -42,7 +42,7 @@ HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 #         stream SURVEY.md 8(d) C3 names ("HBM in parity mode"); their flop fraction is reported beside it (`flop_frac`)
 # the headline command at other fillings of the chip / with the wavefront-per-trajectory layout: name -> (trajectories, lanes per trajectory)
 LV_VARIANTS = {"lv_sat40k": (40000, 0), "lv_sat160k": (160000, 0), "lv_wave64": (10000, 64)}
-BOUND = {"seir_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
+BOUND = {"seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
 
 
 # `roofline.traffic` is NOT measured inside this run (PMC passes cannot run inside a timed bench): it is read from the committed
@@ -59,7 +59,7 @@ def headline_roofline(a, fkey, achieved_tflops, bwd_s, stats, n_param):
     """the `roofline` object of the JSON line for the dominant (backward) kernel: `bound` names the roof that bounds it (BOUND above),
     achieved / peak / frac are against THAT roof; hbm-bound kernels carry their flop fraction beside it"""
     bound = BOUND["lv_tanh32" if fkey == "lv_tanh32" else a.workload]
-    if a.workload == "seir" and a.sensealg == "fast" and a.lanes in (0, 16):
+    if a.workload in ("seir", "node") and a.sensealg == "fast" and a.lanes in (0, 16):
         bound = "mfma"   # the block-level matrix-core accumulation: no mu in HBM at all (SURVEY.md 8(d) C3: "fast mode: FP64 MFMA is the bound")
     elif a.sensealg != "adjoint" or a.lanes not in (0, 16):
         bound = "valu" if bound == "hbm" else bound   # (the wavefront-per-trajectory / fast / discrete kernels of seir and node)
@@ -86,6 +86,9 @@ BWD_KERNEL = {"adjoint": "adj_kernel (interpolating adjoint)", "discrete": "dadj
 def roofline_kernel_name(a):
     """the dominant kernel of the command, as rocprofv3 names it, and the unit it runs on"""
     ls = a.sensealg == "adjoint" and a.lanes in (0, 16)
+    if a.workload == "node" and a.sensealg == "fast" and a.lanes in (0, 16):
+        return ("nodelf::node_lsf_adj_kernel (fast mode: lambda-only error control, 16 trajectories per block in lock-step, network AND "
+                "parameter cotangent on the FP64 matrix cores -- block-resident accumulators, no mu in HBM)")
     if a.workload == "seir" and a.sensealg == "fast" and a.lanes in (0, 16):
         return ("seirlf::seir_lsf_adj_kernel (fast mode: lambda-only error control, 16 trajectories per block in lock-step, network AND "
                 "parameter cotangent on the FP64 matrix cores -- block-resident accumulators, no mu in HBM)")
@@ -192,6 +195,8 @@ def pmc_traffic(a):
     PMC passes cannot run inside the timed bench itself.  None when the run is not that command or the summary is absent."""
     if a.workload == "seir" and a.sensealg == "fast" and not (a.lanes or a.waves or a.traj):
         return pmc_any("seir_fast", "seirlf::seir_lsf_adj_kernel<")
+    if a.workload == "node" and a.sensealg == "fast" and not (a.lanes or a.waves or a.traj):
+        return pmc_any("node_fast", "nodelf::node_lsf_adj_kernel<")
     if a.net != "s1" or a.alg != "tsit5" or a.lanes or a.waves or a.traj or a.sensealg == "fast":
         return None
     kern = "adj_kernel<" if a.sensealg == "adjoint" else "dadj_kernel<"
@@ -393,6 +398,8 @@ def quick_measure(name, device, steps=5, warmup=1):
         wl, sense = "lv", "discrete"
     elif name == "seir_fast":
         wl, sense = "seir", "fast"
+    elif name == "node_fast":
+        wl, sense = "node", "fast"
     elif name in LV_VARIANTS:
         # the headline command with the chip FILLED (10 000 trajectories are 834 wavefronts on 1024 SIMDs: one partial round), and
         # with north_star's literal "one wavefront per trajectory" layout (64 lanes, lane j = neuron j: the runtime-shape kernel)
@@ -416,7 +423,8 @@ def quick_measure(name, device, steps=5, warmup=1):
         ens = U.DeviceEnsemble(w["f"], w["alg"], w["tspan"], t, u0_d, data=data, row_mask=mask, sensealg=SENSE_OBJ(U, sense), **w["tol"])
         desc = {"seir": "configs[2] per-GPU share: SEIR exposure UDE, 6250 trajectories, Vern7 1e-6" +
                         (", fast mode (lambda-only error control; parameter cotangent = block-level matrix-core accumulation, no mu in HBM)" if sense == "fast" else ""),
-                "node": "SEIR neural ODE 7-64-64-64-7 on the configs[2] ensemble, 6250 trajectories, Vern7 1e-6",
+                "node": "SEIR neural ODE 7-64-64-64-7 on the configs[2] ensemble, 6250 trajectories, Vern7 1e-6" +
+                        (", fast mode (block-level matrix-core accumulation of the parameter cotangent)" if sense == "fast" else ""),
                 "kpp": "configs[3]: Fisher-KPP UDE, 1024 points x 256 PDEs, Tsit5"}[wl]
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)
     for _ in range(warmup):
@@ -426,8 +434,8 @@ def quick_measure(name, device, steps=5, warmup=1):
     nf_fwd, nf_bwd = int(ens.stats[:, 0].sum().item()), int(ens.stats[:, 4].sum().item())
     flop_key = "lv_tanh32" if name == "lv_tanh32" else wl
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
-    kern = "dadj_kernel" if sense == "discrete" else "seirlf::seir_lsf_adj_kernel" if name == "seir_fast" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "nodels::node_ls_adj_kernel" if wl == "node" else "adj_kernel"
-    pm = name if name in ("lv_tanh32", "lv_discrete", "seir_fast") else wl
+    kern = "dadj_kernel" if sense == "discrete" else "seirlf::seir_lsf_adj_kernel" if name == "seir_fast" else "nodelf::node_lsf_adj_kernel" if name == "node_fast" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "nodels::node_ls_adj_kernel" if wl == "node" else "adj_kernel"
+    pm = name if name in ("lv_tanh32", "lv_discrete", "seir_fast", "node_fast") else wl
     if name in LV_VARIANTS:
         pm = "none"    # (no committed counter pass for these commands)
     out = {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
@@ -673,7 +681,7 @@ def main():
             del ens
             torch.cuda.empty_cache()
             others = {}
-            for name in ("seir", "seir_fast", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64"):
+            for name in ("seir", "seir_fast", "node_fast", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64"):
                 try:
                     others[name] = quick_measure(name, device)
                 except Exception as e:  # a failing secondary workload must not take the headline line with it

@@ -102,6 +102,42 @@ def test_seir_fast_mode_block_level_matrix_core_accumulation(alg, oalg, kw):
             assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
 
 
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+@pytest.mark.parametrize("kw", [{}, {"dt": 0.9}], ids=["auto-dt", "dt0.9-rejections"])
+def test_node_fast_mode_block_level_matrix_core_accumulation(alg, oalg, kw):
+    """the neural ODE 7-64-64-64-7 (seir_exposure.jl:53-83) through csrc/ude_node_lsf.h, the default of its fast mode: one trajectory ->
+    every one of the 9287 gradient entries bit-identical to the oracle's UDEO_SENSE_FAST_MM association (with rejected, replayed
+    attempts under a given dt); ensembles: per trajectory bit-identical step counts and dL/du0, gradient <= 1e-12, two runs the same bits"""
+    okw = {"dt0": kw["dt"]} if kw else {}
+    scale = 4.0 if kw else 1.0     # (the rejection case: four times the Glorot weights, a right-hand side the given dt does not fit)
+    t = np.arange(0.0, 6.5, 1.0)
+    u0, th = node_case(3, 100.0)
+    th = th * scale
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 6.0], [], t)
+    for j in (0, 2):
+        one = U.loss_and_gradient(U.ODEProblem(models.dudt_node(), u0[j], (0.0, 6.0), th), alg(), truth[j:j + 1], row_mask=MASK, saveat=t,
+                                  abstol=1e-6, reltol=1e-6, sensealg=FAST(), **kw)
+        ref1 = O.loss_grad_ensemble(O.seir_node(), O.opts(oalg, 1e-6, 1e-6, sensealg=4, **okw), u0[j], [0.0, 6.0], th, t, truth[j:j + 1], row_mask=MASK)
+        check_per_trajectory(one, ref1)
+        if kw:
+            assert ref1["stats"][:, 6].sum() > 0      # the case does contain rejected backward steps
+        assert_bitwise(one.grad_theta, ref1["grad_theta"], "dL/dtheta, single trajectory")
+    for N in (7, 40, 300):
+        u0, th = node_case(N, 100.0)
+        th = th * scale
+        truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 6.0], [], t, nthreads=8)
+        ens = U.EnsembleProblem(U.ODEProblem(models.dudt_node(), u0[0], (0.0, 6.0), th), u0)
+        r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST(), **kw)
+        ref = O.loss_grad_ensemble(O.seir_node(), O.opts(oalg, 1e-6, 1e-6, sensealg=4, **okw), u0, [0.0, 6.0], th, t, truth, row_mask=MASK, nthreads=8)
+        check_per_trajectory(r, ref)
+        assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+        r2 = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST(), **kw)
+        assert_bitwise(r.grad_theta, r2.grad_theta, "two runs, same bits")
+        if N == 40 and not kw:
+            full = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
+            assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
+
+
 def test_seir_fast_block_mode_user_cotangent():
     """the pullback entry point (a user cotangent instead of data) through the block-level kernel"""
     N = 20
@@ -120,7 +156,8 @@ def test_node_and_kpp_fast_mode_match_oracle():
     t = np.arange(0.0, 6.5, 1.0)
     truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 6.0], [], t)
     ens = U.EnsembleProblem(U.ODEProblem(models.dudt_node(), u0[0], (0.0, 6.0), th), u0)
-    r = U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST())
+    # the wavefront-per-trajectory kernel (lanes_per_traj = 64): the oracle's UDEO_SENSE_FAST association
+    r = U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST(), ensemblealg=U.EnsembleMI355(lanes_per_traj=64))
     ref = O.loss_grad_ensemble(O.seir_node(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=2), u0, [0.0, 6.0], th, t, truth, row_mask=MASK, nthreads=3)
     check_per_trajectory(r, ref)
     assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])

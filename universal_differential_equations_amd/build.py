@@ -249,6 +249,7 @@ def kernel_work(objdir, extra):
     work.append((os.path.join(CSRC, "ude_node_ls.hip"), os.path.join(objdir, "ude_node_ls.o"), [] + extra, os.path.join(objdir, "ude_node_ls.log")))
     # the `fast` mode of the lock-step kernels: parameter cotangent as a block-level matrix-core accumulation
     work.append((os.path.join(CSRC, "ude_seir_lsf.hip"), os.path.join(objdir, "ude_seir_lsf.o"), os.environ.get("UDE_LSF_DEFS", "").split() + extra, os.path.join(objdir, "ude_seir_lsf.log")))
+    work.append((os.path.join(CSRC, "ude_node_lsf.hip"), os.path.join(objdir, "ude_node_lsf.o"), [] + extra, os.path.join(objdir, "ude_node_lsf.log")))
     # the multi-GPU exchange step (RCCL bound with dlopen, one-shot P2P reducer), SURVEY.md 8(e)
     work.append((os.path.join(CSRC, "ude_comm.hip"), os.path.join(objdir, "ude_comm.o"), [] + extra, os.path.join(objdir, "ude_comm.log")))
     return work

@@ -238,6 +238,7 @@ extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, i
 extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu);
 // the `fast` mode on the same architecture: parameter cotangent as a block-level matrix-core accumulation (csrc/ude_seir_lsf.h)
 extern "C" void ude_seir_lsf_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, int* blocks_per_cu);
+extern "C" void ude_node_lsf_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, int* blocks_per_cu);
 extern "C" void ude_node_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu);
 extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 
@@ -754,6 +755,9 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     // no mu in HBM, one gradient row per BLOCK (csrc/ude_seir_lsf.h); lanes_per_traj = 64 keeps the wavefront-per-trajectory kernel
     const bool seir_lsf = model_id(m) == MID_SEIR_UDE && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST && o->per_trajectory == 0 &&
                           (want_lanes == 16 || (want_lanes == 0 && UDE_SEIR_LS_DEFAULT));
+    const bool node_lsf = model_id(m) == MID_SEIR_NODE && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST && o->per_trajectory == 0 &&
+                          (want_lanes == 16 || (want_lanes == 0 && UDE_NODE_LS_DEFAULT));
+    const bool any_lsf = seir_lsf || node_lsf;
     const bool any_ls = seir_ls || node_ls;
     const int ls_slk = seir_ls ? 71 : 146;   // parameter slots per hidden row (mu: two columns of ls_slk x 64 per trajectory)
     if ((rc = resolve(c, m, o, l, G))) return rc;
@@ -776,8 +780,8 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     }
     int lsf_per_cu = 1;
     int64_t lsf_blocks = 0;
-    if (seir_lsf) {
-        ude_seir_lsf_get(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &lsf_per_cu);
+    if (any_lsf) {
+        (seir_lsf ? ude_seir_lsf_get : ude_node_lsf_get)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &lsf_per_cu);
         lsf_blocks = ls_blocks(c, N, lsf_per_cu);
         // more than one block per CU, but not enough full blocks for all of them: every CU gets the same number of (partly filled)
         // blocks -- the trajectories are dealt round-robin -- instead of some CUs two full blocks and the others one
@@ -870,14 +874,14 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)(pm ? N : nwaves) * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     ude_poison_chip(c->stream, true);
-    if (((seir_ls || seir_lsf) && UDE_SEIR_LS_FWD) || (node_ls && UDE_NODE_LS_FWD)) {
+    if (((seir_ls || seir_lsf) && UDE_SEIR_LS_FWD) || ((node_ls || node_lsf) && UDE_NODE_LS_FWD)) {
         void (*lf)(const KParams, int*) = nullptr;
         size_t lf_lds = 0;
         int lf_per_cu = 1;
-        (node_ls ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds, &lf_per_cu);
+        ((node_ls || node_lsf) ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds, &lf_per_cu);
         const int64_t nblk = ls_blocks(c, N);
-        if (seir_lsf && (rc = ensure(c, c->ls_fac, sizeof(double) * 2))) return rc;   // (only the forward kernel's queue counter lives there)
-        int* queue = (int*)((double*)c->ls_fac.p + (seir_lsf ? 0 : (size_t)nblk * ls_fac)) + 1;   // (the backward kernel's counter is the int in front of it)
+        if (any_lsf && (rc = ensure(c, c->ls_fac, sizeof(double) * 2))) return rc;   // (only the forward kernel's queue counter lives there)
+        int* queue = (int*)((double*)c->ls_fac.p + (any_lsf ? 0 : (size_t)nblk * ls_fac)) + 1;   // (the backward kernel's counter is the int in front of it)
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_lds));
         hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, lf_per_cu)), dim3(256), lf_lds, c->stream, p, queue);
@@ -899,7 +903,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)ls_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls_lds));
         hipLaunchKernelGGL(ls_kern, dim3((unsigned)nblk), dim3(256), ls_lds, c->stream, p, (double*)c->ls_fac.p, queue);
-    } else if (seir_lsf) {
+    } else if (any_lsf) {
         // persistent blocks, trajectories dealt round-robin (no queue: every sum is in the same order in every run)
         HIPCHK(c, hipFuncSetAttribute((const void*)ls_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls_lds));
         hipLaunchKernelGGL(ls_kern, dim3((unsigned)lsf_blocks), dim3(256), ls_lds, c->stream, p, (double*)nullptr, (int*)nullptr);
