@@ -1,5 +1,5 @@
 """The committed evidence under profiles/ is self-consistent: the bench line of a workload and the rocprofv3 kernel trace of the same
-command (tools/prof_r04.sh writes both in one pass) agree on the dominant kernel's average duration -- the roofline numerator of
+command (tools/prof_r05.sh writes both in one pass) agree on the dominant kernel's average duration -- the roofline numerator of
 the bench line (HIP events inside bench.py) can be reproduced from the trace the judge reads."""
 import json
 import os
@@ -13,7 +13,9 @@ P = os.path.join(ROOT, "profiles")
 # workload -> (kernel name prefix in the trace, key of the kernel time in the bench line's config)
 CASES = {"lv": ("adj_kernel<", "bwd_kernel_ms"), "lv_discrete": ("dadj_kernel<", "bwd_kernel_ms"), "lv_tanh32": ("adj_kernel<", "bwd_kernel_ms"),
          "seir": ("seirls::seir_ls_adj_kernel<", "bwd_kernel_ms"), "node": ("nodels::node_ls_adj_kernel<", "bwd_kernel_ms"),
-         "kpp": ("adj_kernel<", "bwd_kernel_ms")}
+         "kpp": ("adj_kernel<", "bwd_kernel_ms"), "seir_fast": ("seirlf::seir_lsf_adj_kernel<", "bwd_kernel_ms"),
+         "node_fast": ("nodelf::node_lsf_adj_kernel<", "bwd_kernel_ms")}
+ROUND = "r05" if os.path.exists(os.path.join(P, "r05_bench_lv.json")) else "r04"
 
 
 def trace_avg_us(path, prefix):
@@ -28,9 +30,9 @@ def trace_avg_us(path, prefix):
 
 @pytest.mark.parametrize("wl", sorted(CASES))
 def test_bench_kernel_time_agrees_with_the_committed_trace(wl):
-    bench, trace = os.path.join(P, "r04_bench_%s.json" % wl), os.path.join(P, "r04_kernel_stats_%s.md" % wl)
+    bench, trace = os.path.join(P, "%s_bench_%s.json" % (ROUND, wl)), os.path.join(P, "%s_kernel_stats_%s.md" % (ROUND, wl))
     if not (os.path.exists(bench) and os.path.exists(trace)):
-        pytest.skip("no round-4 profile of %s committed yet" % wl)
+        pytest.skip("no %s profile of %s committed yet" % (ROUND, wl))
     d = json.loads(open(bench).read().strip().splitlines()[-1])
     prefix, key = CASES[wl]
     ms = d["config"][key]
