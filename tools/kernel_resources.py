@@ -31,7 +31,8 @@ ROWS = [
     ("seir adjoint, parity mode (lock-step, round-3/4 kernel: not selected)", "ude_seir_ls.log", "seir_ls_adj_kernel<Vern7Tab>*"),
     ("seir adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_seir_lsf.log", "seir_lsf_adj_kernel<Vern7Tab>*"),
     ("node forward (lock-step)", "ude_node_ls.log", "node_ls_fwd_kernel<Vern7Tab>*"),
-    ("node adjoint, parity mode (lock-step)", "ude_node_ls.log", "node_ls_adj_kernel<Vern7Tab>*"),
+    ("node adjoint, parity mode (lock-step, second generation: the shipped one)", "ude_node_ls.log", "node_ls2_adj_kernel<Vern7Tab>*"),
+    ("node adjoint, parity mode (lock-step, round-3/4 kernel: not selected)", "ude_node_ls.log", "node_ls_adj_kernel<Vern7Tab>*"),
     ("node adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_node_lsf.log", "node_lsf_adj_kernel<Vern7Tab>*"),
     ("kpp forward (1024 points)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "fwd_kernel<*false, double>"),
     ("kpp adjoint (1024 points)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "adj_kernel<*false, 1, double>"),

@@ -193,7 +193,7 @@ def compile_one(job):
         out.append(r.stderr)
         return r.returncode
 
-    rc = run(base + ["--cuda-device-only", "-S", "-Rpass-analysis=kernel-resource-usage", "-MD", "-MF", dep, src, "-o", asm])
+    rc = run(base + ["--cuda-device-only", "-S", "-Rpass-analysis=kernel-resource-usage", src, "-o", asm])
     if rc == 0:
         text, rep = _endcf().process(open(asm).read())
         for where, r, v in rep["fixed"]:
@@ -212,7 +212,10 @@ def compile_one(job):
         rc = run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
                   "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + hsaco, "-output=" + fatbin])
     if rc == 0:
-        rc = run(base + ["--cuda-host-only", "-Wno-unused-command-line-argument", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", src, "-o", obj])
+        # (the dependency file is written HERE: the driver ignores -MD / -MF on the `-S --cuda-device-only` step -- round 5 found the
+        #  .d files of round 3 still in use, blind to every header added since; the host pass includes the same files)
+        rc = run(base + ["--cuda-host-only", "-Wno-unused-command-line-argument", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-MD", "-MF", dep,
+                         "-c", src, "-o", obj])
     open(log, "w").write("".join(out))
     for tmp in (asm, dev_o, hsaco, fatbin):  # (the repaired assembly stays: tests/test_build_gate_cpu.py audits it)
         if os.path.exists(tmp):
