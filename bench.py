@@ -67,7 +67,7 @@ def headline_roofline(a, fkey, achieved_tflops, bwd_s, stats, n_param):
          "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": pmc_traffic(a), "traffic_source": TRAFFIC_SOURCE,
          "note": "bound: valu = FP64 vector unit, mfma = FP64 matrix cores (both 78.6 TF on this part), hbm = 8 TB/s; algorithmic %g flop per "
                  "adjoint eval; traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of the kernel from the separate rocprofv3 --pmc passes of this "
-                 "command (profiles/r04_pmc_<workload>.md, tools/prof_r04.sh), null for non-default commands" % FLOPS[fkey][1]}
+                 "command (profiles/r05_pmc_<workload>.md, tools/prof_r05.sh), null for non-default commands" % FLOPS[fkey][1]}
     if bound == "hbm":
         gbps = mu_stream_bytes(stats, n_param) / bwd_s / 1e9
         r.update({"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
@@ -93,10 +93,10 @@ def roofline_kernel_name(a):
         return ("seirlf::seir_lsf_adj_kernel (fast mode: lambda-only error control, 16 trajectories per block in lock-step, network AND "
                 "parameter cotangent on the FP64 matrix cores -- block-resident accumulators, no mu in HBM)")
     if a.workload == "seir" and ls:
-        return ("seirls::seir_ls_adj_kernel (interpolating adjoint, 16 trajectories per block in lock-step), network on the FP64 matrix cores, "
+        return ("seirls2::seir_ls2_adj_kernel (interpolating adjoint, 16 trajectories per block in lock-step), network on the FP64 matrix cores, "
                 "parameter-slot sums / controller on the FP64 vector unit")
     if a.workload == "node" and ls:
-        return ("nodels::node_ls_adj_kernel (interpolating adjoint, 16 trajectories per block in lock-step), network on the FP64 matrix cores, "
+        return ("nodels2::node_ls2_adj_kernel (interpolating adjoint, 16 trajectories per block in lock-step), network on the FP64 matrix cores, "
                 "parameter-slot sums / controller on the FP64 vector unit")
     if a.workload == "kpp":
         return BWD_KERNEL[a.sensealg] + ", FP64 matrix cores"
@@ -201,9 +201,9 @@ def pmc_traffic(a):
         return None
     kern = "adj_kernel<" if a.sensealg == "adjoint" else "dadj_kernel<"
     if a.workload == "seir" and a.sensealg == "adjoint" and a.lanes in (0, 16):
-        kern = "seirls::seir_ls_adj_kernel<"     # the lock-step matrix-core backward kernel (the default)
+        kern = "seirls2::seir_ls2_adj_kernel<"     # the lock-step matrix-core backward kernel (the default)
     if a.workload == "node" and a.sensealg == "adjoint" and a.lanes in (0, 16):
-        kern = "nodels::node_ls_adj_kernel<"
+        kern = "nodels2::node_ls2_adj_kernel<"
     return pmc_any(a.workload, "`void " + kern)
 
 
@@ -429,12 +429,20 @@ def quick_measure(name, device, steps=5, warmup=1):
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)
     for _ in range(warmup):
         ens.loss_grad(theta)
-    ms = timed_steps(lambda i: ens.loss_grad(theta), steps)
-    f, b = ens.kernel_ms()
+    # (kernel times: the MEDIAN over the same steps, read after each step's synchronisation -- the last step alone is one sample)
+    kms = []
+
+    def one(i):
+        ens.loss_grad(theta)
+        torch.cuda.synchronize()
+        kms.append(ens.kernel_ms())
+
+    ms = timed_steps(one, steps)
+    f, b = float(np.median([k[0] for k in kms])), float(np.median([k[1] for k in kms]))
     nf_fwd, nf_bwd = int(ens.stats[:, 0].sum().item()), int(ens.stats[:, 4].sum().item())
     flop_key = "lv_tanh32" if name == "lv_tanh32" else wl
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
-    kern = "dadj_kernel" if sense == "discrete" else "seirlf::seir_lsf_adj_kernel" if name == "seir_fast" else "nodelf::node_lsf_adj_kernel" if name == "node_fast" else "seirls::seir_ls_adj_kernel" if wl == "seir" else "nodels::node_ls_adj_kernel" if wl == "node" else "adj_kernel"
+    kern = "dadj_kernel" if sense == "discrete" else "seirlf::seir_lsf_adj_kernel" if name == "seir_fast" else "nodelf::node_lsf_adj_kernel" if name == "node_fast" else "seirls2::seir_ls2_adj_kernel" if wl == "seir" else "nodels2::node_ls2_adj_kernel" if wl == "node" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete", "seir_fast", "node_fast") else wl
     if name in LV_VARIANTS:
         pm = "none"    # (no committed counter pass for these commands)

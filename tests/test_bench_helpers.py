@@ -19,10 +19,10 @@ def test_roofline_kernel_names_the_commands_own_dominant_kernel():
     assert bench.roofline_kernel_name(_args()).startswith("adj_kernel (interpolating adjoint)")
     assert "valu" in bench.roofline_kernel_name(_args()).lower()
     assert bench.roofline_kernel_name(_args(sensealg="discrete")).startswith("dadj_kernel")
-    assert bench.roofline_kernel_name(_args(workload="seir")).startswith("seirls::seir_ls_adj_kernel")
-    assert bench.roofline_kernel_name(_args(workload="seir", lanes=16)).startswith("seirls::seir_ls_adj_kernel")
+    assert bench.roofline_kernel_name(_args(workload="seir")).startswith("seirls2::seir_ls2_adj_kernel")
+    assert bench.roofline_kernel_name(_args(workload="seir", lanes=16)).startswith("seirls2::seir_ls2_adj_kernel")
     assert bench.roofline_kernel_name(_args(workload="seir", lanes=64)).startswith("adj_kernel")       # the wavefront-per-trajectory kernel
-    assert bench.roofline_kernel_name(_args(workload="node")).startswith("nodels::node_ls_adj_kernel")
+    assert bench.roofline_kernel_name(_args(workload="node")).startswith("nodels2::node_ls2_adj_kernel")
     assert "matrix cores" in bench.roofline_kernel_name(_args(workload="kpp"))
 
 

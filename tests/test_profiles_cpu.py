@@ -12,7 +12,7 @@ P = os.path.join(ROOT, "profiles")
 
 # workload -> (kernel name prefix in the trace, key of the kernel time in the bench line's config)
 CASES = {"lv": ("adj_kernel<", "bwd_kernel_ms"), "lv_discrete": ("dadj_kernel<", "bwd_kernel_ms"), "lv_tanh32": ("adj_kernel<", "bwd_kernel_ms"),
-         "seir": ("seirls::seir_ls_adj_kernel<", "bwd_kernel_ms"), "node": ("nodels::node_ls_adj_kernel<", "bwd_kernel_ms"),
+         "seir": ("seirls2::seir_ls2_adj_kernel<", "bwd_kernel_ms"), "node": ("nodels2::node_ls2_adj_kernel<", "bwd_kernel_ms"),
          "kpp": ("adj_kernel<", "bwd_kernel_ms"), "seir_fast": ("seirlf::seir_lsf_adj_kernel<", "bwd_kernel_ms"),
          "node_fast": ("nodelf::node_lsf_adj_kernel<", "bwd_kernel_ms")}
 ROUND = "r05" if os.path.exists(os.path.join(P, "r05_bench_lv.json")) else "r04"
