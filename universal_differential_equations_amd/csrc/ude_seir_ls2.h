@@ -19,6 +19,11 @@ namespace seirls2 {
 
 using namespace seirls;
 
+#ifndef UDE_LS2_MU_PREFETCH
+#define UDE_LS2_MU_PREFETCH 0   // 1: the mu words of the trip's first step-end request are fetched in front of the row phase D instead of at the
+#endif                          // start of the pass -- measured (round 5): 10.69 against 10.53 ms, 36 B of scratch appear: not kept
+
+
 template <class Tab>
 constexpr int lds_doubles() {
     constexpr int NSTC = popc(stage_mask<Tab>());
@@ -59,7 +64,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
     double* ZK = RQL + 16 * 8;                // [16 slots][16]: (unused half | ssrep, new own components are kept in registers)
     double* W1L = ZK + NSLOTS * 16;           // [3][64]
     double* KL = W1L + 3 * H;                 // [16 slots][S][8]: stage derivatives of lambda
-    (void)RCS; (void)REV; (void)ZK;
+    (void)REV; (void)ZK;
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int kq = l >> 4, jc = l & 15;       // matrix view
@@ -160,6 +165,12 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
         if (p.grad_u0 && lm < NC) p.grad_u0[(size_t)gid * n + lm] = zo;
     };
     __syncthreads();
+#if defined(UDE_LS2_CLOCKS)   // timing experiment: cycles of wavefront 0 of block 0 per section of a trip (tools/ls2_prof.py)
+    unsigned long long tk = __builtin_readcyclecounter(), tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntrip = 0;
+#define LS2_TICK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tsec[i] += now_ - tk; tk = now_; }
+#else
+#define LS2_TICK(i)
+#endif
 
     for (;;) {
         // ---- A. an idle slot takes the next trajectory of the ensemble ----
@@ -277,7 +288,14 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
                 xf[0] = x0; xf[1] = x1; xf[2] = x2; xf[3] = d3;
             }
         }
+        LS2_TICK(0)
+#if UDE_LS2_MU_PREFETCH
+        // which slots END A STEP with this trip is known now: the first of them has its current mu column fetched behind the matrix
+        // phase, in front of the row phase D (2.4 k cycles that the round trip hides behind), instead of at the start of its pass
+        if (lm == 0) { RCS[slot] = (ev && ph == S - 1 && !zero_req) ? 1 : 0; RG[slot] = gid; RCOL[slot] = col; }
+#endif
         if (!__syncthreads_or(ph != PH_IDLE)) break;
+        LS2_TICK(1)
         {
             v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(W1A, XIN[kq * 16 + jc], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
             double a1[4], dv1[4];
@@ -337,6 +355,19 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
             }
         }
         __syncthreads();
+        LS2_TICK(2)
+        int pf_mu = -1;   // slot whose mu words are already in mq
+#if UDE_LS2_MU_PREFETCH
+        {
+            const int q16 = l & 15;
+            const unsigned nx = (unsigned)__ballot(l < 16 && RCS[q16] != 0);
+            if (nx != 0u) {
+                pf_mu = __builtin_ctz(nx);
+                const long long g = RG[pf_mu];
+                mu_load(p.slot_glob + (size_t)g * (2 * NSLK * H) + l + (size_t)RCOL[pf_mu] * (NSLK * H));
+            }
+        }
+#endif
         // factors of this evaluation to the workspace, slot-major: wavefront w copies its own four slots (lane i = hidden unit i)
         {
             const int evi = ev ? 1 : 0;
@@ -417,7 +448,9 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
             REQI[slot] = req; REQZ[slot] = zero_req ? 1 : 0; RDT[slot] = dt; RG[slot] = gid; RCOL[slot] = col; ROK[slot] = ret == RET_SUCCESS ? 1 : 0;
         }
         zero_req = false;
+        LS2_TICK(3)
         __syncthreads();
+        LS2_TICK(4)
 
         // ---- E. the parameter-slot work the slots asked for: every request is worked on by all four wavefronts, a quarter of the
         // slots each (no cross-wavefront dependence: a wavefront only ever touches its own columns of mu) ----
@@ -454,7 +487,7 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
                 const double* a1s = A1P + sl * NSTC * H;
                 double* sw = SUMW + (sl * 4 + w) * 2;
                 if (mode == RQ_STEP) {
-                    mu_load(mcur);
+                    if (sl != pf_mu) mu_load(mcur);   // (the first step-end request of the trip: fetched in front of phase D)
                     const double ps = slot_pass<S, MASK, 0>(fb, a1s, XF, sl, l, w, TB + 256, TB + 272, dt_req, o.abstol, o.reltol, mq, mnew, hh, ll);
                     const double tot = group_sum<64>(ps);
                     if (l == 0) sw[0] = tot;
@@ -481,7 +514,9 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
                 }
             }
         }
+        LS2_TICK(5)
         __syncthreads();
+        LS2_TICK(6)
 
         // ---- F. what depended on the parameter pass: flush, initial-dt norms, the end of a step ----
         if (req == RQ_FLUSH) {
@@ -600,7 +635,17 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
                 ph = 0;
             }
         }
+        LS2_TICK(7)
+#if defined(UDE_LS2_CLOCKS)
+        ntrip += 1;
+#endif
     }
+#if defined(UDE_LS2_CLOCKS)
+    if (p.trace && blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 8; ++i) p.trace[i] = (double)tsec[i];
+        p.trace[8] = (double)ntrip;
+    }
+#endif
 }
 
 }  // namespace seirls2

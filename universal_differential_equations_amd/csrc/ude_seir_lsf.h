@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
         });
     };
     __syncthreads();
-#if defined(UDE_LSF_CLOCKS)   // timing experiment: cycles of wavefront 0 of block 0 per section of a trip (tools/exp/lsf_prof.py)
+#if defined(UDE_LSF_CLOCKS)   // timing experiment: cycles of wavefront 0 of block 0 per section of a trip (tools/lsf_prof.py)
     unsigned long long tk = __builtin_readcyclecounter(), tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntrip = 0;
 #define LSF_TICK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tsec[i] += now_ - tk; tk = now_; }
 #else
