@@ -138,6 +138,25 @@ def test_node_fast_mode_block_level_matrix_core_accumulation(alg, oalg, kw):
             assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
 
 
+def test_seir_fast_block_mode_backward_solves_that_stop_early():
+    """maxiters = 40: every forward solve succeeds (35 steps), every backward solve stops at MaxIters.  The block-level kernel must end
+    (no hang), report the failures loudly (UDE_ERR_TRAJECTORY, infinite loss) and hand back the oracle's return codes, step counts and
+    the lambda each solve had reached; the gradient of such a call is NOT the sum over successful members (evaluated
+    stages are already inside the block's accumulators) -- it only has to be finite"""
+    N = 6
+    u0, t, truth, th = _seir_fast_case(N)
+    ens = U.EnsembleProblem(U.ODEProblem(models.dudt_(), u0[0], (0.0, 21.0), th), u0)
+    with pytest.raises(U.UdeError, match="trajector"):
+        U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST(), maxiters=40)
+    r = U.loss_and_gradient(ens, U.Vern7(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST(), maxiters=40, allow_failures=True)
+    ref = O.loss_grad_ensemble(O.seir_ude(), O.opts(O.VERN7, 1e-6, 1e-6, sensealg=4, maxiters=40), u0, [0.0, 21.0], th, t, truth, row_mask=MASK, nthreads=6)
+    assert (ref["retcode"] == 1).all() and (ref["stats"][:, 1] < 40).all()
+    assert_bitwise(r.retcode, ref["retcode"], "retcode (MaxIters in the backward solve)")
+    assert_bitwise(r.stats[:, 4:7], ref["stats"][:, 4:7], "backward counts of the stopped solves")
+    assert_bitwise(r.grad_u0, ref["grad_u0"], "lambda where the solves stopped")
+    assert np.isinf(r.loss) and np.isfinite(r.grad_theta).all()
+
+
 def test_seir_fast_block_mode_user_cotangent():
     """the pullback entry point (a user cotangent instead of data) through the block-level kernel"""
     N = 20

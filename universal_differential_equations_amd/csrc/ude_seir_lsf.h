@@ -62,6 +62,10 @@ using seirls::OFF_B3;
 #ifndef UDE_LSF_DEFER_SMALL
 #define UDE_LSF_DEFER_SMALL 0   // 1: db2, dW1 | db1, dW3 of trip T are formed in trip T + 1 next to the first layer's tanh (measured: slower)
 #endif
+#ifndef UDE_LSF_SMALL_VALU
+#define UDE_LSF_SMALL_VALU 0   // 1: db2, dW1 | db1, dW3 are accumulated on the vector unit per SLOT COLUMN, in the registers of the lane that
+#endif                         //    holds (units 4kq .. 4kq+3, slot jc), and the sixteen columns are added at the end instead of by 12 more MFMAs
+                               //    per trip -- measured (round 5): 5.80 against 5.66 ms (the matrix pipe has the slack, the vector unit has not): not kept
 #ifndef UDE_LSF_W2_EARLY
 #define UDE_LSF_W2_EARLY 0      // (with W2_RELOAD) 1: W2's fragment is requested in front of barrier 1 instead of behind it
 #endif
@@ -168,6 +172,12 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     static_for<0, 4>([&](auto c) { gW2[c] = v4d{0.0, 0.0, 0.0, 0.0}; });
     gB2 = v4d{0.0, 0.0, 0.0, 0.0}; gW1 = gB2; gW3 = gB2;
     double mb3 = 0.0;   // (row view, lane 0 of the slot's row) db3 share of this slot: fma(-(w d3), 1, mb3)
+#if UDE_LSF_SMALL_VALU
+    // the small parameters per slot column: one chain per (unit, slot column) -- a single trajectory lives in one column, so its chain IS
+    // the oracle's; the columns are added in column order at the end (a different association of the sum over trajectories: <= 1e-12)
+    double mB2[4], mW3[4], mB1[4], mW1[3][4];
+    static_for<0, 4>([&](auto r) { mB2[r] = 0.0; mW3[r] = 0.0; mB1[r] = 0.0; mW1[0][r] = 0.0; mW1[1][r] = 0.0; mW1[2][r] = 0.0; });
+#endif
 
     // ---- per-slot state on the slot's row: component c on lane c ----
     const OptsR o(p.o);
@@ -444,12 +454,22 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                 static_for<0, 16>([&](auto sc) { W2T[sc] = thw[(4 * (int)decltype(sc)::value + kq) + urow * H]; });
 #endif
                 const double d3j = D3S[jc];
+#if UDE_LSF_SMALL_VALU
+                const double wj = WSL[jc];
+                const double c3 = -(wj * d3j);
+#endif
                 static_for<0, 4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + LSF_B2(r);
                     const double a2 = dtanh(z2);
-                    T_D2[(u0r + r) * TLD + jc] = __builtin_fma(LSF_W3(r), d3j, 0.0) * __builtin_fma(-a2, a2, 1.0);
+                    const double d2 = __builtin_fma(LSF_W3(r), d3j, 0.0) * __builtin_fma(-a2, a2, 1.0);
+                    T_D2[(u0r + r) * TLD + jc] = d2;
+#if UDE_LSF_SMALL_VALU
+                    mB2[r] = __builtin_fma(-(wj * d2), 1.0, mB2[r]);
+                    mW3[r] = __builtin_fma(c3, a2, mW3[r]);
+#else
                     T_A2[(u0r + r) * TLD + jc] = a2;
+#endif
                 });
             }
             __syncthreads();
@@ -470,7 +490,13 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                     constexpr int r = decltype(rc)::value;
                     const double s1 = ((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r];
                     dv1[r] = s1 * __builtin_fma(-a1[r], a1[r], 1.0);
+#if UDE_LSF_SMALL_VALU
+                    const double c1 = -(WSL[jc] * dv1[r]);
+                    mB1[r] = __builtin_fma(c1, 1.0, mB1[r]);
+                    static_for<0, 3>([&](auto mc) { mW1[mc][r] = __builtin_fma(c1, XIN[decltype(mc)::value * 16 + jc], mW1[mc][r]); });
+#else
                     T_D1[(u0r + r) * TLD + jc] = dv1[r];
+#endif
                 });
                 // input cotangent: rounded products W1[u][m] delta1[u] under the adjacent-pair tree over the 64 units
                 static_for<0, 3>([&](auto mc) {
@@ -496,7 +522,7 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                     gW2[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad2, T_A1[(16 * c + jc) * TLD + k], gW2[c], 0, 0, 0);
                 });
             });
-#if !UDE_LSF_DEFER_SMALL
+#if !UDE_LSF_DEFER_SMALL && !UDE_LSF_SMALL_VALU
             small_products(XIN);
 #endif
         }
@@ -692,10 +718,36 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
         constexpr int r = decltype(rc)::value;
         const int unit = 16 * w + kq + 4 * r;    // accumulator rows are NOT permuted: tile row i = kq + 4r is unit 16w + i
         static_for<0, 4>([&](auto cc) { row[OFF_W2 + unit + (16 * (int)decltype(cc)::value + jc) * H] = gW2[cc][r]; });
+#if !UDE_LSF_SMALL_VALU
         if (jc == 0) { row[OFF_B2 + unit] = gB2[r]; row[OFF_W3 + unit] = gW3[r]; }
         if (jc < 3) row[OFF_W1 + unit + jc * H] = gW1[r];
         if (jc == 3) row[OFF_B1 + unit] = gW1[r];
+#endif
     });
+#if UDE_LSF_SMALL_VALU
+    // the sixteen slot columns of the small parameters, added in column order: two passes of three quantities through the tiles' space
+    // ([quantity][unit][column]: 3 x 64 x 16 doubles)
+    static_for<0, 2>([&](auto pc) {
+        constexpr int ps = decltype(pc)::value;
+        __syncthreads();
+        static_for<0, 4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int un = u0r + r;
+            T_A1[(0 * H + un) * 16 + jc] = ps == 0 ? mB2[r] : mW1[0][r];
+            T_A1[(1 * H + un) * 16 + jc] = ps == 0 ? mW3[r] : mW1[1][r];
+            T_A1[(2 * H + un) * 16 + jc] = ps == 0 ? mB1[r] : mW1[2][r];
+        });
+        __syncthreads();
+        if (tid < 3 * H) {
+            const int qn = tid / H, un = tid % H;
+            const double* v = T_A1 + (qn * H + un) * 16;
+            double sum = v[0];
+            for (int i = 1; i < 16; ++i) sum += v[i];
+            const int idx = ps == 0 ? (qn == 0 ? OFF_B2 + un : qn == 1 ? OFF_W3 + un : OFF_B1 + un) : OFF_W1 + un + qn * H;
+            row[idx] = sum;
+        }
+    });
+#endif
     if (tid == 0) {
         double s = MB3[0];
         for (int i = 1; i < NSLOTS; ++i) s += MB3[i];
