@@ -2,7 +2,9 @@
 """SEIR_exposure/seir_exposure.jl, lines 16-38 and 111-161 ("Universal ODE Part 1"): the exposure term of a 7-state
 SEIR model replaced by ann = FastChain(FastDense(3,64,tanh), FastDense(64,64,tanh), FastDense(64,1)); Vern7 at 1e-6,
 InterpolatingAdjoint, loss on rows 2:4, ADAM(0.01).  Data = corona! solved at 1e-12 by the same engine (+1e-5 noise).
-Needs a GPU:  python examples/seir_exposure.py [adam_iters]"""
+Needs a GPU:  python examples/seir_exposure.py [adam_iters] [fast]
+`fast` (an opt-in, not the script's sensealg): U.FastInterpolatingAdjoint() -- lambda-only error control; for this model the parameter
+cotangent is then accumulated on the matrix cores per block (csrc/ude_seir_lsf.h), no mu column in HBM."""
 import os
 import sys
 
@@ -27,9 +29,12 @@ p = ann.glorot_uniform(rng)
 prob_nn = U.ODEProblem(models.dudt_(ann), u0, tspan, p)                             # seir_exposure.jl:117-131
 
 
+SENSEALG = U.FastInterpolatingAdjoint() if "fast" in sys.argv[2:] else U.InterpolatingAdjoint(autojacvec=U.ReverseDiffVJP())
+
+
 def loss_grad(theta):                                                               # seir_exposure.jl:137-147
     r = U.loss_and_gradient(U.remake(prob_nn, p=np.asarray(theta)), U.Vern7(), noisy_data.T[None], row_mask=[0, 1, 1, 1, 0, 0, 0],
-                            saveat=solution.t, abstol=1e-6, reltol=1e-6, sensealg=U.InterpolatingAdjoint(autojacvec=U.ReverseDiffVJP()))
+                            saveat=solution.t, abstol=1e-6, reltol=1e-6, sensealg=SENSEALG)
     return r.loss, r.grad_theta
 
 
