@@ -38,6 +38,7 @@ def theta_for(chain, rng, scale):
 
 def supported(f, alg=0, sense=0):
     eng = U.Engine.get(0)
+    eng.set_launch()   # library defaults (the engine is shared: a previous call's lanes_per_traj = 64 would report the runtime-shape kernel)
     o = _lib.SolveOpts()
     o.alg, o.sensealg = alg, sense
     return eng.L.ude_model_supported(eng.h, C.byref(f), C.byref(o), 1)
@@ -183,6 +184,55 @@ def test_fuzz_seir_kinds_random_shapes(seed):
     else:
         gn = np.linalg.norm(ref["grad_theta"])
         assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
+
+
+@pytest.mark.parametrize("dims", [[3, 64, 63, 1], [3, 16, 16, 1], [3, 33, 64, 1], [3, 64, 16, 1], [3, 17, 50, 1], [3, 63, 32, 1]],
+                         ids=lambda d: "-".join(map(str, d)))
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+def test_runtime_shape_exposure_chain_on_the_lockstep_matrix_core_kernel(dims, alg, oalg):
+    """round 5: an exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity; 16 <= H1, H2 <= 64, H1 != 32) WITHOUT a compiled instance
+    runs its forward and backward passes on the lock-step matrix-core kernels (csrc/ude_seir_ls_fwd.h / ude_seir_ls2.h, GEN: weights zero-padded to 64 x 64, a 64-term
+    product in four chains, a shorter one in ONE ascending chain, the input cotangent a tree for H1 = 64 and a chain otherwise) -- every
+    number per trajectory as the oracle has it, every gradient entry for a single trajectory, and the same bits as the
+    wavefront-per-trajectory runtime-shape kernel (lanes_per_traj = 64), which is 4x slower on the configs[2] share (47.6 vs 11 ms)"""
+    acts = ["tanh", "tanh", "identity"]
+    rng = np.random.default_rng(sum(dims))
+    chain = chain_of(dims, acts)
+    f = models.dudt_(chain)
+    om = O.make_model(O.KIND_SEIR_UDE, 7, dims, acts, consts=O.SEIR_P)
+    th = theta_for(chain, rng, 0.5)
+    assert supported(f) == 1
+    mask = [0, 1, 1, 1, 0, 0, 0]
+    tf = 4.0
+    t = np.arange(0.0, tf + 0.5, 1.0)
+    for N in (1, 21):
+        S0 = 100.0
+        u0 = np.zeros((N, 7))
+        u0[:, 0] = rng.uniform(0.8, 0.95, N) * S0
+        u0[:, 1] = rng.uniform(0.5, 2.0, N)
+        u0[:, 2] = rng.uniform(0.2, 1.0, N)
+        u0[:, 4] = S0
+        truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, tf], [], t)
+        ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, tf), th), u0)
+        # the plain solve: the lock-step forward kernel's runtime-shape instance (ude_seir_ls_fwd.h, GEN; H2 = 32 stays on the wavefront kernel)
+        sol = U.solve(ens, alg(), saveat=t, abstol=1e-6, reltol=1e-6)
+        out, st, rc = O.solve_ensemble(om, O.opts(oalg, 1e-6, 1e-6), u0, [0.0, tf], th, t)
+        assert (rc == 0).all() and (np.asarray(sol.retcodes) == 0).all()
+        assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts %s" % dims)
+        assert_bitwise(sol.u, out, "forward states %s" % dims)
+        r = U.loss_and_gradient(ens, alg(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6)
+        ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6), u0, [0.0, tf], th, t, truth, row_mask=mask, nthreads=8)
+        assert (r.retcode == 0).all() and (ref["retcode"] == 0).all()
+        check_per_trajectory(r, ref)
+        w64 = U.loss_and_gradient(ens, alg(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=U.EnsembleMI355(lanes_per_traj=64))
+        assert_bitwise(r.grad_u0, w64.grad_u0, "lock-step vs wavefront-per-trajectory: dL/du0")
+        assert_bitwise(r.stats, w64.stats, "lock-step vs wavefront-per-trajectory: counts")
+        gn = np.linalg.norm(ref["grad_theta"])
+        if N == 1:
+            assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta %s" % dims)
+            assert_bitwise(r.grad_theta, w64.grad_theta, "lock-step vs wavefront-per-trajectory: dL/dtheta")
+        else:
+            assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
 
 
 def test_generic_kernel_agrees_with_the_compiled_instance_of_the_same_shape():

@@ -31,7 +31,13 @@ constexpr int lds_doubles() {
            NSLOTS * NSTC * H + NSLOTS * kst<Tab>() + NSLOTS * 8 + 16 * 8 + NSLOTS * 16 + 3 * H + NSLOTS * Tab::S * 8;
 }
 
-template <class Tab>
+// GEN = true: the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity) with 16 <= H1, H2 <= 64, H1 != 32
+// (`Lux.Chain` / `FastChain` accept any chain upstream; ude_model_generic.h serves every other shape one wavefront per trajectory).  The
+// weights are zero-padded to 64 x 64 -- a padded unit has activation tanh(0) = 0 and delta 0, a padded parameter slot gradient and
+// residual 0: all exact -- and every product keeps the ORACLE'S association for ITS length (wide_dot): a 64-term product is four
+// 16-term chains added left to right, a shorter one is ONE ascending chain (sixteen k-steps into one accumulator; fma(0, x, acc) == acc
+// on the padding); the input cotangent is the adjacent-pair tree for H1 == 64 and an ascending chain over the units otherwise.
+template <class Tab, bool GEN = false>
 __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p, double* __restrict__ facws, int* __restrict__ queue) {
     constexpr int S = Tab::S, NK = Tab::NK;
     constexpr unsigned MASK = stage_mask<Tab>();
@@ -76,18 +82,26 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
     const int nfld = 3 + n + NK * n;
 
     // ---- weights: A-operand fragments with PERMUTED rows (ude_seir_lsf.h) ----
+    // layer widths and the offsets of theta = [W1 (H1 x 3) | b1 | W2 (H2 x H1) | b2 | W3 (1 x H2) | b3] (column-major, as Lux / FastChain / Flux lay it out)
+    const int H1 = GEN ? p.mc.dims[1] : H, H2 = GEN ? p.mc.dims[2] : H;
+    const int oW1 = 0, oB1 = 3 * H1, oW2 = oB1 + H1, oB2 = oW2 + H1 * H2, oW3 = oB2 + H2, oB3 = oW3 + H2;
+    const bool blk_fwd = H1 == H, blk_bwd = H2 == H;   // a 64-term product: four 16-term chains; a shorter one: ONE ascending chain
     double W2A[16], W2T[16];
     const int urow = 16 * w + 4 * (jc & 3) + (jc >> 2);
     static_for<0, 16>([&](auto sc) {
         const int col = 4 * decltype(sc)::value + kq;
-        W2A[sc] = th[OFF_W2 + urow + col * H];
-        W2T[sc] = th[OFF_W2 + col + urow * H];
+        W2A[sc] = (urow < H2 && col < H1) ? th[oW2 + urow + col * H2] : 0.0;      // A[i][k] = W2[unit2(i)][unit1 = 4s + k]
+        W2T[sc] = (col < H2 && urow < H1) ? th[oW2 + col + urow * H2] : 0.0;      // A[i][k] = W2[unit2 = 4s + k][unit1(i)]
     });
-    const double W1A = kq < 3 ? th[OFF_W1 + urow + kq * H] : th[OFF_B1 + urow];
-    for (int i = tid; i < 3 * H; i += BLOCKT) W1L[i] = th[OFF_W1 + i];
+    const double W1A = urow < H1 ? (kq < 3 ? th[oW1 + urow + kq * H1] : th[oB1 + urow]) : 0.0;
+    for (int i = tid; i < 3 * H; i += BLOCKT) W1L[i] = (i % H) < H1 ? th[oW1 + (i % H) + (i / H) * H1] : 0.0;
     const int u0r = 16 * w + 4 * kq;
     double b2r[4], w3r[4];
-    static_for<0, 4>([&](auto r) { b2r[r] = th[OFF_B2 + u0r + decltype(r)::value]; w3r[r] = th[OFF_W3 + u0r + decltype(r)::value]; });
+    static_for<0, 4>([&](auto r) {
+        const int un = u0r + decltype(r)::value;
+        b2r[r] = un < H2 ? th[oB2 + un] : 0.0;
+        w3r[r] = un < H2 ? th[oW3 + un] : 0.0;
+    });
     const double Fc = p.mc.consts[0], b0c = p.mc.consts[1], muc = p.mc.consts[4], sgc = p.mc.consts[5], gac = p.mc.consts[6],
                  dc = p.mc.consts[7], lac = p.mc.consts[8];
     if (tid < 16) XIN[3 * 16 + tid] = 1.0;
@@ -308,18 +322,26 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
             if (pf_want >= 0) { fetch_interval(pf_want); pf_want = -1; }
             {
                 v4d acc[4];
-                static_for<0, 4>([&](auto bc) {
-                    constexpr int b = decltype(bc)::value;
-                    acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
-                    static_for<0, 4>([&](auto q) {
-                        constexpr int s = 4 * b + decltype(q)::value;
-                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                if (!GEN || blk_fwd) {
+                    static_for<0, 4>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                        static_for<0, 4>([&](auto q) {
+                            constexpr int s = 4 * b + decltype(q)::value;
+                            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                        });
                     });
-                });
+                } else {   // fewer than 64 inputs: one ascending chain (the padded k-steps add fma(0, a, acc) == acc)
+                    acc[0] = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, 16>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[0], 0, 0, 0);
+                    });
+                }
                 const double d3j = D3S[jc];
                 static_for<0, 4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + b2r[r];
+                    const double z2 = ((!GEN || blk_fwd) ? (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) : acc[0][r]) + b2r[r];
                     const double a2 = dtanh(z2);
                     T_D2[(u0r + r) * TLD + jc] = __builtin_fma(w3r[r], d3j, 0.0) * __builtin_fma(-a2, a2, 1.0);
                     T_A2[(u0r + r) * TLD + jc] = a2;
@@ -328,18 +350,26 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
             __syncthreads();
             {
                 v4d acc[4];
-                static_for<0, 4>([&](auto bc) {
-                    constexpr int b = decltype(bc)::value;
-                    acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
-                    static_for<0, 4>([&](auto q) {
-                        constexpr int s = 4 * b + decltype(q)::value;
-                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                if (!GEN || blk_bwd) {
+                    static_for<0, 4>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                        static_for<0, 4>([&](auto q) {
+                            constexpr int s = 4 * b + decltype(q)::value;
+                            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                        });
                     });
-                });
+                } else {
+                    acc[0] = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, 16>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[0], 0, 0, 0);
+                    });
+                }
                 double pg[3] = {0.0, 0.0, 0.0};
                 static_for<0, 4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    const double s1 = ((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r];
+                    const double s1 = (!GEN || blk_bwd) ? (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) : acc[0][r];
                     dv1[r] = s1 * __builtin_fma(-a1[r], a1[r], 1.0);
                     T_D1[(u0r + r) * TLD + jc] = dv1[r];
                 });
@@ -400,6 +430,14 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
                 const double* g4 = GXP + (decltype(mm)::value * NSLOTS + slot) * 4;
                 gx[mm] = (g4[0] + g4[1]) + (g4[2] + g4[3]);
             });
+            if (GEN && !blk_fwd) {
+                // fewer than 64 units in the first layer: the input cotangent is ONE ascending chain over the units (wide_dot, n < 64;
+                // n = 32 is the tree case and not served), formed by lane m < 3 of the slot's row from the delta1 tile
+                double acc = 0.0;
+                const double* wl = W1L + (lm < 3 ? lm : 0) * H;
+                for (int u = 0; u < H1; ++u) acc = __builtin_fma(wl[u], T_D1[u * TLD + slot], acc);
+                static_for<0, 3>([&](auto mm) { gx[mm] = rshfl(acc, decltype(mm)::value); });
+            }
             const double Sv = y[0], Nv = y[4], Dv = y[5];
             const double cc = b0c * Fc / Nv;
             const double cN = b0c * Sv * Fc / (Nv * Nv);
@@ -503,11 +541,13 @@ __global__ void __launch_bounds__(BLOCKT, 1) seir_ls2_adj_kernel(const KParams p
                     const bool ok = rl32(r_ok, sl) != 0;
                     double* row = p.grad_part + (size_t)g * p.n_param;
 #pragma unroll 4
-                    for (int k = QW * w; k < QW * w + QW; ++k) row[OFF_W2 + l + k * H] = ok ? mcur[(size_t)k * H] : 0.0;
+                    for (int k = QW * w; k < QW * w + QW; ++k)
+                        if (!GEN || (l < H2 && k < H1)) row[oW2 + l + k * H2] = ok ? mcur[(size_t)k * H] : 0.0;
                     static_for<0, 7>([&](auto ec) {
                         constexpr int e = decltype(ec)::value;
                         if ((e >> 1) == w) {
-                            const int idx = e < 3 ? OFF_W1 + l + e * H : e == 3 ? OFF_B1 + l : e == 4 ? OFF_B2 + l : e == 5 ? OFF_W3 + l : (l == 0 ? OFF_B3 : -1);
+                            const int idx = e < 3 ? (l < H1 ? oW1 + l + e * H1 : -1) : e == 3 ? (l < H1 ? oB1 + l : -1) : e == 4 ? (l < H2 ? oB2 + l : -1) :
+                                            e == 5 ? (l < H2 ? oW3 + l : -1) : (l == 0 ? oB3 : -1);
                             if (idx >= 0) row[idx] = ok ? mcur[(size_t)(H + e) * H] : 0.0;
                         }
                     });

@@ -22,9 +22,13 @@ namespace seirls {
 enum { FPH_IDLE = -4, FPH_FSAL0 = -3, FPH_INIT0 = -2, FPH_INIT1 = -1 };   // >= 0: stage s; s >= S: lazy dense-output stage s - S
 
 template <class Tab>
-constexpr int fwd_lds_doubles() { return H * TLD + 4 * 16 + NSLOTS * PLD + TABL + NSLOTS * Tab::NK * 16 + 16; }
+constexpr int fwd_lds_doubles() { return H * TLD + 4 * 16 + NSLOTS * PLD + TABL + NSLOTS * Tab::NK * 16 + 16 + H; }
 
-template <class Tab>
+// GEN = true (round 5): the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), 16 <= H1, H2 <= 64,
+// H1 != 32, H2 != 32, weights zero-padded to 64 x 64, every product in the ORACLE'S association for its length (ude_seir_ls2.h): the hidden
+// product four 16-term chains for H1 == 64 and ONE ascending chain otherwise, the output layer the adjacent-pair tree of rounded products
+// for H2 == 64 and one ascending fma chain over the units otherwise
+template <class Tab, bool GEN = false>
 __global__ void __launch_bounds__(BLOCKT, UDE_LS_FWD_PER_CU) seir_ls_fwd_kernel(const KParams p, int* __restrict__ queue) {
     constexpr int S = Tab::S, NK = Tab::NK, NX = Tab::NEXTRA;
     constexpr int FIRST = Tab::FSAL ? 1 : 0;   // first stage an attempt evaluates (FSAL: stage 0 is handed over)
@@ -34,6 +38,7 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LS_FWD_PER_CU) seir_ls_fwd_kernel(
     double* PG = XIN + 4 * 16;               // [16][65]: w3[i] a2[i] of slot (column) and hidden row i
     double* TB = PG + NSLOTS * PLD;          // tableau: A[16][16], B, BT, C
     double* KSL = TB + TABL;                 // [16 slots][NK][16]: stage derivatives, component c of the slot on lane c of its row
+    double* W3L = KSL + NSLOTS * NK * 16 + 16;   // [64] w3 (GEN with H2 < 64: the output layer's chain reads it)
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int kq = l >> 4, jc = l & 15;      // matrix view
@@ -43,19 +48,26 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LS_FWD_PER_CU) seir_ls_fwd_kernel(
     const TabDev* __restrict__ tab = p.tab;
     const int n = NC;
 
+    const int H1 = GEN ? p.mc.dims[1] : H, H2 = GEN ? p.mc.dims[2] : H;
+    const int oW1 = 0, oB1 = 3 * H1, oW2 = oB1 + H1, oB2 = oW2 + H1 * H2, oW3 = oB2 + H2, oB3 = oW3 + H2;
+    const bool blk_hid = H1 == H, tree_out = H2 == H;
     double W2A[16];
     {
         const int row = 16 * w + jc;
-        static_for<0, 16>([&](auto sc) { W2A[sc] = th[OFF_W2 + row + (4 * decltype(sc)::value + kq) * H]; });
+        static_for<0, 16>([&](auto sc) {
+            const int col = 4 * decltype(sc)::value + kq;
+            W2A[sc] = (row < H2 && col < H1) ? th[oW2 + row + col * H2] : 0.0;
+        });
     }
-    const double W1A = kq < 3 ? th[OFF_W1 + (16 * w + jc) + kq * H] : th[OFF_B1 + 16 * w + jc];
+    const double W1A = (16 * w + jc) < H1 ? (kq < 3 ? th[oW1 + (16 * w + jc) + kq * H1] : th[oB1 + 16 * w + jc]) : 0.0;
     double b2r[4], w3r[4];
     static_for<0, 4>([&](auto r) {
         const int row = 16 * w + kq + 4 * decltype(r)::value;
-        b2r[r] = th[OFF_B2 + row];
-        w3r[r] = th[OFF_W3 + row];
+        b2r[r] = row < H2 ? th[oB2 + row] : 0.0;
+        w3r[r] = row < H2 ? th[oW3 + row] : 0.0;
     });
-    const double b3c = th[OFF_B3];
+    const double b3c = th[oB3];
+    if (tid < H) W3L[tid] = tid < H2 ? th[oW3 + tid] : 0.0;
     const double Fc = p.mc.consts[0], b0c = p.mc.consts[1], muc = p.mc.consts[4], sgc = p.mc.consts[5], gac = p.mc.consts[6],
                  dc = p.mc.consts[7], lac = p.mc.consts[8];
     if (tid < 16) XIN[3 * 16 + tid] = 1.0;
@@ -203,18 +215,27 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LS_FWD_PER_CU) seir_ls_fwd_kernel(
             });
             __syncthreads();
             v4d acc[4];
-            static_for<0, 4>([&](auto bc) {
-                constexpr int b = decltype(bc)::value;
-                acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
-                static_for<0, 4>([&](auto q) {
-                    constexpr int s = 4 * b + decltype(q)::value;
-                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+            if (!GEN || blk_hid) {
+                static_for<0, 4>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, 4>([&](auto q) {
+                        constexpr int s = 4 * b + decltype(q)::value;
+                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                    });
                 });
-            });
+            } else {   // fewer than 64 inputs: one ascending chain
+                acc[0] = v4d{0.0, 0.0, 0.0, 0.0};
+                static_for<0, 16>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[0], 0, 0, 0);
+                });
+            }
             static_for<0, 4>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + b2r[r];
-                PG[jc * PLD + 16 * w + kq + 4 * r] = w3r[r] * dtanh(z2);
+                const double z2 = ((!GEN || blk_hid) ? (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) : acc[0][r]) + b2r[r];
+                const double a2 = dtanh(z2);
+                PG[jc * PLD + 16 * w + kq + 4 * r] = (!GEN || tree_out) ? w3r[r] * a2 : a2;   // (chain case: the activation itself)
             });
         }
         __syncthreads();
@@ -222,7 +243,14 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LS_FWD_PER_CU) seir_ls_fwd_kernel(
         // ---- D. the slot's row: right-hand side of dudt_ ----
         if (ev) {
             const double* pr = PG + slot * PLD + 4 * lm;
-            const double zn = row_tree4(pr[0], pr[1], pr[2], pr[3]) + b3c;
+            double zn;
+            if (!GEN || tree_out) zn = row_tree4(pr[0], pr[1], pr[2], pr[3]) + b3c;
+            else {   // an output layer of fewer than 64 terms: one ascending fma chain over the units (every lane of the row the same chain)
+                double acc = 0.0;
+                const double* a2s = PG + slot * PLD;
+                for (int u = 0; u < H2; ++u) acc = __builtin_fma(W3L[u], a2s[u], acc);
+                zn = acc + b3c;
+            }
             const double Sv = zs[0], Ev = zs[1], Iv = zs[2], Rv = zs[3], Nv = zs[4], Dv = zs[5];
             kr[0] = -b0c * Sv * Fc / Nv - zn - muc * Sv;
             kr[1] = b0c * Sv * Fc / Nv + zn - (sgc + muc) * Ev;

@@ -236,6 +236,8 @@ extern "C" int ude_dbg_poison_selftest(ude_ctx* c, unsigned pat, unsigned* out_h
 // lock-step matrix-core adjoint of the SEIR exposure UDE (csrc/ude_seir_ls.hip)
 extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 extern "C" void ude_seir_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu);
+extern "C" void ude_seir_ls_get_fwd_gen(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu);
+extern "C" void ude_seir_ls_get_gen(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 // the `fast` mode on the same architecture: parameter cotangent as a block-level matrix-core accumulation (csrc/ude_seir_lsf.h)
 extern "C" void ude_seir_lsf_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, int* blocks_per_cu);
 extern "C" void ude_node_lsf_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, int* blocks_per_cu);
@@ -338,6 +340,18 @@ static int generic_id(const ude_model_desc* m) {
     if (m->kind == UDE_KIND_SEIR_NODE && m->n_state == 7 && in == 7 && out == 7) return m->n_layers <= 4 ? MID_GENERIC_7_L4 : MID_GENERIC_7;
     return MID_NONE;
 }
+
+// exposure-UDE chains WITHOUT a compiled instance that the lock-step matrix-core backward kernel serves all the same (csrc/ude_seir_ls2.h, GEN):
+// 3 -> H1 -> H2 -> 1 with tanh, tanh, identity, 16 <= H1, H2 <= 64, H1 != 32 (a 32-term input cotangent is the oracle's tree case), Float64
+static bool seir_gen_ls_shape(const ude_model_desc* m) {
+    if (m->kind != UDE_KIND_SEIR_UDE || m->dtype != 0 || m->n_state != 7 || m->n_layers != 3 || m->nn_offset != 0) return false;
+    const int h1 = m->dims[1], h2 = m->dims[2];
+    if (m->dims[0] != 3 || m->dims[3] != 1 || h1 < 16 || h1 > 64 || h1 == 32 || h2 < 16 || h2 > 64) return false;
+    if (m->act[0] != UDE_ACT_TANH || m->act[1] != UDE_ACT_TANH || m->act[2] != UDE_ACT_IDENTITY) return false;
+    return m->n_param == 3 * h1 + h1 + h1 * h2 + h2 + h2 + 1;
+}
+// ... and the ones the lock-step FORWARD kernel serves (ude_seir_ls_fwd.h, GEN): additionally H2 != 32 (a 32-term output layer is a tree case)
+static bool seir_gen_ls_fwd_shape(const ude_model_desc* m) { return seir_gen_ls_shape(m) && m->dims[2] != 32; }
 
 // blocks of the lock-step SEIR backward kernel: 16 trajectory slots each, at most one block per compute unit (the slots refill
 // from a queue)
@@ -707,7 +721,8 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     // SEIR exposure UDE / its neural ODE, Float64, shared time grid, lanes_per_traj 0 (default) or 16: the lock-step matrix-core forward kernel
     const bool is_node = model_id(m) == MID_SEIR_NODE;
-    const bool seir_ls = ((UDE_SEIR_LS_FWD && model_id(m) == MID_SEIR_UDE) || (UDE_NODE_LS_FWD && is_node)) && o->per_trajectory == 0 &&
+    const bool gen_ls = UDE_SEIR_LS_FWD && model_id(m) == MID_NONE && seir_gen_ls_fwd_shape(m);
+    const bool seir_ls = ((UDE_SEIR_LS_FWD && model_id(m) == MID_SEIR_UDE) || (UDE_NODE_LS_FWD && is_node) || gen_ls) && o->per_trajectory == 0 &&
                          (c->lo.lanes_per_traj == 16 || (c->lo.lanes_per_traj == 0 && (is_node ? UDE_NODE_LS_DEFAULT : UDE_SEIR_LS_DEFAULT)));
     if (seir_ls && (rc = ensure(c, c->ls_fac, 64))) return rc;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -716,7 +731,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
         void (*lf)(const KParams, int*) = nullptr;
         size_t lf_lds = 0;
         int lf_per_cu = 1;
-        (is_node ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds, &lf_per_cu);
+        (is_node ? ude_node_ls_get_fwd : gen_ls ? ude_seir_ls_get_fwd_gen : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds, &lf_per_cu);
         int* queue = (int*)c->ls_fac.p;
         HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(int), c->stream));
         HIPCHK(c, hipFuncSetAttribute((const void*)lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_lds));
@@ -758,8 +773,12 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     const bool node_lsf = model_id(m) == MID_SEIR_NODE && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST && o->per_trajectory == 0 &&
                           (want_lanes == 16 || (want_lanes == 0 && UDE_NODE_LS_DEFAULT));
     const bool any_lsf = seir_lsf || node_lsf;
-    const bool any_ls = seir_ls || node_ls;
-    const int ls_slk = seir_ls ? 71 : 146;   // parameter slots per hidden row (mu: two columns of ls_slk x 64 per trajectory)
+    // a runtime-shape exposure UDE 3 -> H1 -> H2 -> 1 (no compiled instance): its backward pass on the lock-step kernel, zero-padded to 64 x 64
+    // (round 5: 47.6 -> 11 ms for 3-64-63-1 on the configs[2] share), and so does its forward pass (H2 != 32: seir_gen_ls_fwd_shape)
+    const bool seir_gen_ls = model_id(m) == MID_NONE && seir_gen_ls_shape(m) && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT && o->per_trajectory == 0 &&
+                             (want_lanes == 16 || (want_lanes == 0 && UDE_SEIR_LS_DEFAULT));
+    const bool any_ls = seir_ls || node_ls || seir_gen_ls;
+    const int ls_slk = node_ls ? 146 : 71;   // parameter slots per hidden row (mu: two columns of ls_slk x 64 per trajectory)
     if ((rc = resolve(c, m, o, l, G))) return rc;
     KParams p;
     fill_params(p, m, o, tspan[0], tspan[1]);
@@ -775,7 +794,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     void (*ls_kern)(const KParams, double*, int*) = nullptr;
     size_t ls_lds = 0, ls_fac = 0;
     if (any_ls) {
-        (seir_ls ? ude_seir_ls_get : ude_node_ls_get)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &ls_fac);
+        (seir_gen_ls ? ude_seir_ls_get_gen : seir_ls ? ude_seir_ls_get : ude_node_ls_get)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &ls_fac);
         if (nwaves < N) nwaves = N;   // one gradient row per trajectory
     }
     int lsf_per_cu = 1;
@@ -874,11 +893,12 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)(pm ? N : nwaves) * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     ude_poison_chip(c->stream, true);
-    if (((seir_ls || seir_lsf) && UDE_SEIR_LS_FWD) || ((node_ls || node_lsf) && UDE_NODE_LS_FWD)) {
+    const bool gen_fwd = seir_gen_ls && UDE_SEIR_LS_FWD && seir_gen_ls_fwd_shape(m);
+    if (((seir_ls || seir_lsf || gen_fwd) && UDE_SEIR_LS_FWD) || ((node_ls || node_lsf) && UDE_NODE_LS_FWD)) {
         void (*lf)(const KParams, int*) = nullptr;
         size_t lf_lds = 0;
         int lf_per_cu = 1;
-        ((node_ls || node_lsf) ? ude_node_ls_get_fwd : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds, &lf_per_cu);
+        ((node_ls || node_lsf) ? ude_node_ls_get_fwd : gen_fwd ? ude_seir_ls_get_fwd_gen : ude_seir_ls_get_fwd)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &lf, &lf_lds, &lf_per_cu);
         const int64_t nblk = ls_blocks(c, N);
         if (any_lsf && (rc = ensure(c, c->ls_fac, sizeof(double) * 2))) return rc;   // (only the forward kernel's queue counter lives there)
         int* queue = (int*)((double*)c->ls_fac.p + (any_lsf ? 0 : (size_t)nblk * ls_fac)) + 1;   // (the backward kernel's counter is the int in front of it)
