@@ -26,9 +26,11 @@ ROWS = [
     ("lv discrete sweep", "ude_inst_lv_s1n_g5_w1_tsit5.log", "dadj_kernel<*false, double>"),
     ("lv_tanh32 adjoint", "ude_inst_lv_tanh32_g16_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("lv_wave64 adjoint (runtime shapes)", "ude_inst_generic_2_l4_g64_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
-    ("seir forward (lock-step)", "ude_seir_ls.log", "seir_ls_fwd_kernel<Vern7Tab>*"),
-    ("seir adjoint, parity mode (lock-step, second generation: the shipped one)", "ude_seir_ls.log", "seir_ls2_adj_kernel<Vern7Tab>*"),
+    ("seir forward (lock-step)", "ude_seir_ls.log", "seir_ls_fwd_kernel<Vern7Tab, false>*"),
+    ("seir adjoint, parity mode (lock-step, second generation: the shipped one)", "ude_seir_ls.log", "seir_ls2_adj_kernel<Vern7Tab, false>*"),
     ("seir adjoint, parity mode (lock-step, round-3/4 kernel: not selected)", "ude_seir_ls.log", "seir_ls_adj_kernel<Vern7Tab>*"),
+    ("runtime-shape exposure chain 3-H1-H2-1, forward (lock-step, GEN)", "ude_seir_ls.log", "seir_ls_fwd_kernel<Vern7Tab, true>*"),
+    ("runtime-shape exposure chain 3-H1-H2-1, adjoint (lock-step, GEN)", "ude_seir_ls.log", "seir_ls2_adj_kernel<Vern7Tab, true>*"),
     ("seir adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_seir_lsf.log", "seir_lsf_adj_kernel<Vern7Tab>*"),
     ("node forward (lock-step)", "ude_node_ls.log", "node_ls_fwd_kernel<Vern7Tab>*"),
     ("node adjoint, parity mode (lock-step, second generation: the shipped one)", "ude_node_ls.log", "node_ls2_adj_kernel<Vern7Tab>*"),
