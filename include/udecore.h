@@ -109,8 +109,9 @@ enum { UDE_PT_TSPAN = 1, UDE_PT_SAVEAT = 2,
         * member, nothing summed -- LotkaVolterra/run_loops.jl:55-62 runs 500 independent recoveries, each with its own data AND its own
         * network; `loss` is still the sum, loss_per_traj the members' own.  The compiled LV-kind instances (scenario_1 / scenario_2 /
         * hudson_bay's chains, Float64 and Float32: the member's weights live in registers; the 2-32-2 net: read from the member's
-        * column at every use), interpolating adjoint and the discrete sweep; UDE_ERR_UNSUPPORTED elsewhere.  May be combined with
-        * the two flags above. */
+        * column at every use) and the Fisher-KPP kinds (FisherKPP/Fisher-KPP-CNN-Small.jl:311-391: five trainings from five initial
+        * networks), interpolating adjoint and the discrete sweep; UDE_ERR_UNSUPPORTED elsewhere.  May be combined with the two
+        * flags above. */
        UDE_PT_THETA = 4 };
 
 /* launch/tuning knobs of the HIP back end (not part of the reference surface) */

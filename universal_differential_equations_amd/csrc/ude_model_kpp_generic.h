@@ -21,6 +21,7 @@ template <int G, int PPL>
 struct KppGenericUde : LinearTheta {
     static_assert(PPL == 1 && G == 32, "runtime-shape Fisher-KPP: one point per lane, grids of <= 32 points");
     static constexpr bool RECOMPUTE_OK = true;
+    static constexpr bool PER_MEMBER_THETA = true;   // UDE_PT_THETA: theta is read through init()'s pointer (the member's column in HBM)
     static __host__ __device__ constexpr int point(int c, int r) { return c * G + r; }
     static constexpr int NS = PPL;
     static constexpr int NSL = KG_NPMAX / G;

@@ -656,6 +656,9 @@ struct KppTrue : LinearTheta {
 template <class Net, int G, int PPL>
 struct KppUde : LinearTheta {
     static constexpr bool RECOMPUTE_OK = true;   // checkpointed adjoint available (AdjSys::RECOMPUTE)
+    // per-member parameters (UDE_PT_THETA; Fisher-KPP-CNN-Small.jl:311-391 repeats its training five times from five initial networks):
+    // theta is read through the pointer init() receives, so the member's own column in HBM stands in for the block's LDS copy
+    static constexpr bool PER_MEMBER_THETA = true;
     static __host__ __device__ constexpr int point(int c, int r) { return c * G + r; }
     using Mlp = CoopMlp<Net, 1>;
     static_assert(Net::dim(0) == 1 && Net::dim(Net::L) == 1, "pointwise reaction network R -> R");
@@ -850,6 +853,7 @@ struct KppUde : LinearTheta {
 template <class Net, int NWV_ = 4>
 struct KppUdeW : LinearTheta {
     static constexpr bool RECOMPUTE_OK = true;   // checkpointed adjoint available (AdjSys::RECOMPUTE)
+    static constexpr bool PER_MEMBER_THETA = true;   // (theta is only read by init(): operand tables and coefficients live in registers afterwards)
     static constexpr int NWV = NWV_, G = 64 * NWV, PPL = 1024 / G, TP = 64, BLK = TP * PPL, NTILE = BLK / 16;
     static_assert(NWV == 4 || NWV == 8, "1024 points on four or eight wavefronts");
     static constexpr int FWD_BLOCKS = NWV == 8 ? 2 : 1;
@@ -901,7 +905,7 @@ struct KppUdeW : LinearTheta {
         int r, lane, w, l16, kq, n, so, d0o, nno;
     };
     static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
-        const lds_t* th = (const lds_t*)th_lds;
+        const double* th = th_lds;   // (a generic pointer: the block's LDS copy, or -- UDE_PT_THETA -- the member's own column in HBM)
         lds_t* sc = (lds_t*)scratch;
         c.urow = sc; c.lrow = sc + NPT + 2; c.orow = sc + 2 * (NPT + 2);
         c.part = sc + 3 * (NPT + 2);  // [NWV][TILE]; wavefront w's tile = its block-sum row afterwards
@@ -909,7 +913,7 @@ struct KppUdeW : LinearTheta {
         c.tile = c.part + c.w * TILE;
         c.n = mc.n_state; c.so = mc.stencil_offset; c.d0o = mc.d0_offset; c.nno = mc.nn_offset;
         c.w1 = th[c.so]; c.w2 = th[c.so + 1]; c.w3 = th[c.so + 2]; c.D0 = th[c.d0o];
-        const lds_t* nn = th + mc.nn_offset;
+        const double* nn = th + mc.nn_offset;
         static_for<0, L>([&](auto lc) {
             constexpr int l = lc;
             constexpr int in = Net::dim(l), out = Net::dim(l + 1);

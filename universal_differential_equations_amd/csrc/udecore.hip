@@ -713,7 +713,7 @@ static int solve_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_o
     const size_t shmem = l.lds_bytes(m->n_param, false);
     if ((rc = setup_time_grids(c, o, N, tspan, p))) return rc;
     if (o->per_trajectory & UDE_PT_THETA) {
-        if (!l.per_member) return fail(c, UDE_ERR_UNSUPPORTED, "per-member parameters (UDE_PT_THETA): this model / lanes_per_traj has no per-member kernel (compiled LV-kind instances only)");
+        if (!l.per_member) return fail(c, UDE_ERR_UNSUPPORTED, "per-member parameters (UDE_PT_THETA): this model / lanes_per_traj has no per-member kernel (LV-kind compiled instances and the Fisher-KPP kinds have one)");
         p.theta_pm = m->n_param;
     }
     void (*kfwd)(const KParams) = o->per_trajectory ? l.fwd_pt : l.fwd;
@@ -813,8 +813,8 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     p.ckpt = ckpt ? 1 : 0;
     const bool pm = (o->per_trajectory & UDE_PT_THETA) != 0;   // per-member parameters: theta np x N in, grad_theta np x N out
     if (pm && (!l.per_member || any_ls || ckpt || o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST))
-        return fail(c, UDE_ERR_UNSUPPORTED, "per-member parameters (UDE_PT_THETA) exist for the compiled LV-kind instances (Model::PER_MEMBER_THETA: weights "
-                                            "in registers, or -- the 2-32-2 net at any lanes_per_traj -- read from the member's column in HBM at every use), "
+        return fail(c, UDE_ERR_UNSUPPORTED, "per-member parameters (UDE_PT_THETA) exist for the compiled LV-kind instances and the Fisher-KPP kinds (Model::PER_MEMBER_THETA: "
+                                            "weights in registers, or read from the member's column in HBM at every use), "
                                             "with the interpolating adjoint or the discrete sweep on the dense store");
     p.theta_pm = pm ? np : 0;
     p.N = N;
