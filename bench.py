@@ -42,7 +42,7 @@ HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 #         stream SURVEY.md 8(d) C3 names ("HBM in parity mode"); their flop fraction is reported beside it (`flop_frac`)
 # the headline command at other fillings of the chip / with the wavefront-per-trajectory layout: name -> (trajectories, lanes per trajectory)
 LV_VARIANTS = {"lv_sat40k": (40000, 0), "lv_sat160k": (160000, 0), "lv_wave64": (10000, 64)}
-BOUND = {"seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
+BOUND = {"seir_shape63": "hbm", "seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
 
 
 # `roofline.traffic` is NOT measured inside this run (PMC passes cannot run inside a timed bench): it is read from the committed
@@ -400,6 +400,8 @@ def quick_measure(name, device, steps=5, warmup=1):
         wl, sense = "seir", "fast"
     elif name == "node_fast":
         wl, sense = "node", "fast"
+    elif name == "seir_shape63":
+        wl = "seir"    # the exposure UDE with an EDITED network, 3-64-63-1: no compiled instance, the runtime-shape lock-step instances
     elif name in LV_VARIANTS:
         # the headline command with the chip FILLED (10 000 trajectories are 834 wavefronts on 1024 SIMDs: one partial round), and
         # with north_star's literal "one wavefront per trajectory" layout (64 lanes, lane j = neuron j: the runtime-shape kernel)
@@ -420,12 +422,17 @@ def quick_measure(name, device, steps=5, warmup=1):
         N = {"seir": 6250, "kpp": 256, "node": 6250}[wl]
         w = synth_inputs_other(wl, N, 0, device)
         theta_h, u0_d, t, data, mask = w["theta"], w["u0"], w["t"], w["data"], w["mask"]
+        if name == "seir_shape63":
+            chain63 = models.Chain(models.Dense(3, 64, "tanh"), models.Dense(64, 63, "tanh"), models.Dense(63, 1, "identity"))
+            w["f"], theta_h = models.dudt_(chain63), chain63.glorot_uniform(np.random.default_rng(0))
         ens = U.DeviceEnsemble(w["f"], w["alg"], w["tspan"], t, u0_d, data=data, row_mask=mask, sensealg=SENSE_OBJ(U, sense), **w["tol"])
         desc = {"seir": "configs[2] per-GPU share: SEIR exposure UDE, 6250 trajectories, Vern7 1e-6" +
                         (", fast mode (lambda-only error control; parameter cotangent = block-level matrix-core accumulation, no mu in HBM)" if sense == "fast" else ""),
                 "node": "SEIR neural ODE 7-64-64-64-7 on the configs[2] ensemble, 6250 trajectories, Vern7 1e-6" +
                         (", fast mode (block-level matrix-core accumulation of the parameter cotangent)" if sense == "fast" else ""),
                 "kpp": "configs[3]: Fisher-KPP UDE, 1024 points x 256 PDEs, Tsit5"}[wl]
+        if name == "seir_shape63":
+            desc = "configs[2] per-GPU share with the exposure network edited to 3-64-63-1 (no compiled instance: runtime-shape instances of the lock-step matrix-core kernels), 6250 trajectories, Vern7 1e-6"
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)
     for _ in range(warmup):
         ens.loss_grad(theta)
@@ -444,7 +451,7 @@ def quick_measure(name, device, steps=5, warmup=1):
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
     kern = "dadj_kernel" if sense == "discrete" else "seirlf::seir_lsf_adj_kernel" if name == "seir_fast" else "nodelf::node_lsf_adj_kernel" if name == "node_fast" else "seirls2::seir_ls2_adj_kernel" if wl == "seir" else "nodels2::node_ls2_adj_kernel" if wl == "node" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete", "seir_fast", "node_fast") else wl
-    if name in LV_VARIANTS:
+    if name in LV_VARIANTS or name == "seir_shape63":
         pm = "none"    # (no committed counter pass for these commands)
     out = {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
            "fwd_kernel_ms": f, "bound": BOUND[name], "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
@@ -689,7 +696,7 @@ def main():
             del ens
             torch.cuda.empty_cache()
             others = {}
-            for name in ("seir", "seir_fast", "node_fast", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64"):
+            for name in ("seir", "seir_fast", "seir_shape63", "node_fast", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64"):
                 try:
                     others[name] = quick_measure(name, device)
                 except Exception as e:  # a failing secondary workload must not take the headline line with it

@@ -454,3 +454,13 @@ def test_per_member_parameters_are_refused_where_no_kernel_takes_them():
     ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 1.0), th), u0, ps=np.stack([th, th]))
     with pytest.raises(U.UdeError, match="per-member parameters"):
         U.loss_and_gradient(ens, U.Tsit5(), np.zeros((2, 3, 7)), saveat=[0.0, 0.5, 1.0])
+    # ude_model_supported gives the same answer before any solve is attempted (and 0 / 1 for the kinds that have a per-member kernel)
+    import ctypes as C
+    from universal_differential_equations_amd import _lib
+    eng = U.Engine.get(0)
+    eng.set_launch()
+    o = _lib.SolveOpts()
+    o.per_trajectory = 4   # UDE_PT_THETA
+    assert eng.L.ude_model_supported(eng.h, C.byref(f), C.byref(o), 1) == -2   # UDE_ERR_UNSUPPORTED
+    assert eng.L.ude_model_supported(eng.h, C.byref(models.nn_ode(26, models.kpp_small_chain(3))), C.byref(o), 1) == 0
+    assert eng.L.ude_model_supported(eng.h, C.byref(models.ude_dynamics()), C.byref(o), 1) == 0

@@ -594,6 +594,8 @@ extern "C" int ude_model_supported(ude_ctx* c, const ude_model_desc* m, const ud
     if (rc) return rc;
     if (need_adjoint && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED && (!l.adj_ckpt || o->per_trajectory))
         return UDE_ERR_UNSUPPORTED;
+    if ((o->per_trajectory & UDE_PT_THETA) && !l.per_member)   // (the same answer the solve / gradient entry points give)
+        return fail(c, UDE_ERR_UNSUPPORTED, "per-member parameters (UDE_PT_THETA): this model / lanes_per_traj has no per-member kernel (LV-kind compiled instances and the Fisher-KPP kinds have one)");
     if (need_adjoint && o->sensealg == UDE_SENSE_DISCRETE && !l.dadj)
         return fail(c, UDE_ERR_UNSUPPORTED, "the runtime-shape kernel has no discretise-then-optimise sweep: use the interpolating adjoint");
     return generic ? 1 : UDE_OK;   // 0: compiled fast instance, 1: runtime-shape fallback kernel
