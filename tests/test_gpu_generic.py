@@ -186,7 +186,12 @@ def test_fuzz_seir_kinds_random_shapes(seed):
         assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
 
 
-@pytest.mark.parametrize("dims", [[3, 64, 63, 1], [3, 16, 16, 1], [3, 33, 64, 1], [3, 64, 16, 1], [3, 17, 50, 1], [3, 63, 32, 1]],
+@pytest.mark.parametrize("dims", [[3, 64, 63, 1], [3, 16, 16, 1], [3, 33, 64, 1], [3, 64, 16, 1], [3, 17, 50, 1], [3, 63, 32, 1],
+                                  # ... more corners of the family: H2 one above a tile, both lengths between tiles, the widest chain input
+                                  # with the narrowest output, H2 = 32 with a narrow H1 (forward on the wavefront kernel), and H1 = 32 (the
+                                  # tree case the lock-step instances exclude: both passes on the wavefront kernel, same oracle)
+                                  [3, 64, 33, 1], [3, 48, 48, 1], [3, 31, 47, 1], [3, 49, 64, 1], [3, 16, 64, 1], [3, 64, 17, 1], [3, 20, 32, 1],
+                                  [3, 32, 40, 1]],
                          ids=lambda d: "-".join(map(str, d)))
 @pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
 def test_runtime_shape_exposure_chain_on_the_lockstep_matrix_core_kernel(dims, alg, oalg):
