@@ -102,6 +102,42 @@ def test_seir_fast_mode_block_level_matrix_core_accumulation(alg, oalg, kw):
             assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
 
 
+@pytest.mark.parametrize("dims", [[3, 64, 63, 1], [3, 16, 16, 1], [3, 33, 64, 1], [3, 64, 17, 1], [3, 31, 47, 1], [3, 49, 32, 1]], ids=lambda d: "-".join(map(str, d)))
+@pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
+def test_runtime_shape_exposure_chain_fast_mode_on_the_lockstep_kernel(dims, alg, oalg):
+    """round 5: an exposure-UDE chain 3 -> H1 -> H2 -> 1 without a compiled instance in the `fast` mode: the runtime-shape instance of
+    csrc/ude_seir_lsf.h (weights zero-padded to 64 x 64, the block's accumulators hold the padded gradient).  One trajectory: every
+    gradient entry bit-identical to the oracle's UDEO_SENSE_FAST_MM association, also with rejected (replayed) attempts under a given
+    dt; ensembles: per trajectory the oracle's step counts and dL/du0, gradient <= 1e-12, two runs the same bits."""
+    acts = ["tanh", "tanh", "identity"]
+    chain = models.Chain(*[models.Dense(dims[i], dims[i + 1], acts[i]) for i in range(3)])
+    f = models.dudt_(chain)
+    om = O.make_model(O.KIND_SEIR_UDE, 7, dims, acts, consts=O.SEIR_P)
+    rng = np.random.default_rng(sum(dims))
+    th = chain.glorot_uniform(rng)
+    th[-(dims[2] + 1):-1] *= 10.0
+    for kw in ({}, {"dt": 0.9}):
+        okw = {"dt0": kw["dt"]} if kw else {}
+        u0, t = seir_inputs(3)
+        truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+        one = U.loss_and_gradient(U.ODEProblem(f, u0[1], (0.0, 21.0), th), alg(), truth[1:2], row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6,
+                                  sensealg=FAST(), **kw)
+        ref1 = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6, sensealg=4, **okw), u0[1], [0.0, 21.0], th, t, truth[1:2], row_mask=MASK)
+        check_per_trajectory(one, ref1)
+        assert_bitwise(one.grad_theta, ref1["grad_theta"], "dL/dtheta, single trajectory %s %s" % (dims, kw))
+    u0, t = seir_inputs(37)
+    truth, _, rc = O.solve_ensemble(O.seir_true(), O.opts(O.VERN7, 1e-12, 1e-12), u0, [0.0, 21.0], [], t)
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, 21.0), th), u0)
+    r = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST())
+    ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6, sensealg=4), u0, [0.0, 21.0], th, t, truth, row_mask=MASK, nthreads=8)
+    check_per_trajectory(r, ref)
+    assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
+    r2 = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=FAST())
+    assert_bitwise(r.grad_theta, r2.grad_theta, "two runs, same bits")
+    full = U.loss_and_gradient(ens, alg(), truth, row_mask=MASK, saveat=t, abstol=1e-6, reltol=1e-6)
+    assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
+
+
 @pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
 @pytest.mark.parametrize("kw", [{}, {"dt": 0.9}], ids=["auto-dt", "dt0.9-rejections"])
 def test_node_fast_mode_block_level_matrix_core_accumulation(alg, oalg, kw):

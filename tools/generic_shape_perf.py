@@ -9,7 +9,8 @@ for dims, acts in (([3, 64, 63, 1], ["tanh", "tanh", "identity"]), ([3, 16, 16, 
     chain = models.Chain(*[models.Dense(dims[i], dims[i + 1], acts[i]) for i in range(len(dims) - 1)])
     f = models.dudt_(chain)
     th = torch.tensor(chain.glorot_uniform(np.random.default_rng(0)), dtype=torch.float64, device=dev)
-    ens = U.DeviceEnsemble(f, w['alg'], w['tspan'], w['t'], w['u0'], data=w['data'], row_mask=w['mask'], **w['tol'])
-    for _ in range(3):
-        ens.loss_grad(th); torch.cuda.synchronize()
-    print(dims, 'kernel ms (fwd, bwd)', ens.kernel_ms(), 'failed', int((ens.retcode != 0).sum()))
+    for sense in ("adjoint", "fast"):
+        ens = U.DeviceEnsemble(f, w['alg'], w['tspan'], w['t'], w['u0'], data=w['data'], row_mask=w['mask'], sensealg=bench.SENSE_OBJ(U, sense), **w['tol'])
+        for _ in range(3):
+            ens.loss_grad(th); torch.cuda.synchronize()
+        print(dims, sense, 'kernel ms (fwd, bwd)', ens.kernel_ms(), 'failed', int((ens.retcode != 0).sum()))

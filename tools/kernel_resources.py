@@ -31,7 +31,8 @@ ROWS = [
     ("seir adjoint, parity mode (lock-step, round-3/4 kernel: not selected)", "ude_seir_ls.log", "seir_ls_adj_kernel<Vern7Tab>*"),
     ("runtime-shape exposure chain 3-H1-H2-1, forward (lock-step, GEN)", "ude_seir_ls.log", "seir_ls_fwd_kernel<Vern7Tab, true>*"),
     ("runtime-shape exposure chain 3-H1-H2-1, adjoint (lock-step, GEN)", "ude_seir_ls.log", "seir_ls2_adj_kernel<Vern7Tab, true>*"),
-    ("seir adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_seir_lsf.log", "seir_lsf_adj_kernel<Vern7Tab>*"),
+    ("seir adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_seir_lsf.log", "seir_lsf_adj_kernel<Vern7Tab, false>*"),
+    ("runtime-shape exposure chain 3-H1-H2-1, adjoint, fast mode (lock-step, GEN)", "ude_seir_lsf.log", "seir_lsf_adj_kernel<Vern7Tab, true>*"),
     ("node forward (lock-step)", "ude_node_ls.log", "node_ls_fwd_kernel<Vern7Tab>*"),
     ("node adjoint, parity mode (lock-step, second generation: the shipped one)", "ude_node_ls.log", "node_ls2_adj_kernel<Vern7Tab>*"),
     ("node adjoint, parity mode (lock-step, round-3/4 kernel: not selected)", "ude_node_ls.log", "node_ls_adj_kernel<Vern7Tab>*"),

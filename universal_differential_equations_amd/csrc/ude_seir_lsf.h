@@ -81,7 +81,10 @@ constexpr int lds_doubles() {
            NSLOTS * Tab::S * 8 + NSLOTS + 2 * H;
 }
 
-template <class Tab>
+// GEN = true (round 5): the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), 16 <= H1, H2 <= 64,
+// H1 != 32, weights zero-padded to 64 x 64, every product of the network in the association of ITS length (ude_seir_ls2.h); the block's
+// accumulators hold the padded 64 x 64 gradient (a padded unit has delta = 0 and a = 0: exact zeros), written through the runtime offsets
+template <class Tab, bool GEN = false>
 __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(const KParams p, double* __restrict__ /*unused: no factor workspace*/,
                                                                               int* __restrict__ /*unused: no queue*/) {
     constexpr int S = Tab::S, NK = Tab::NK;
@@ -124,21 +127,32 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     // the two A-operand fragments of W2 (32 doubles per lane).  UDE_LSF_W2_RELOAD = 1: fetched again in every trip, W2 at the start
     // of the matrix phase (the first layer's tanh covers the latency), W2^T behind the hidden layer -- 35 KB that every block reads
     // and that stay in L2; 64 registers per lane that are only occupied while the fragment is in use
+    // layer widths and the offsets of theta = [W1 (H1 x 3) | b1 | W2 (H2 x H1) | b2 | W3 (1 x H2) | b3] (column-major)
+    const int H1 = GEN ? p.mc.dims[1] : H, H2 = GEN ? p.mc.dims[2] : H;
+    const int oW1 = GEN ? 0 : OFF_W1, oB1 = GEN ? 3 * H1 : OFF_B1, oW2 = GEN ? oB1 + H1 : OFF_W2, oB2 = GEN ? oW2 + H1 * H2 : OFF_B2,
+              oW3 = GEN ? oB2 + H2 : OFF_W3, oB3 = GEN ? oW3 + H2 : OFF_B3;
+    const bool blk_fwd = H1 == H, blk_bwd = H2 == H;   // a 64-term product: four 16-term chains; a shorter one: ONE ascending chain
 #if !UDE_LSF_W2_RELOAD
     double W2A[16], W2T[16];
     static_for<0, 16>([&](auto sc) {
         const int col = 4 * decltype(sc)::value + kq;
-        W2A[sc] = th[OFF_W2 + urow + col * H];      // A[i][k] = W2[unit(i)][4s + k]
-        W2T[sc] = th[OFF_W2 + col + urow * H];      // A[i][k] = W2[4s + k][unit(i)]
+        W2A[sc] = (!GEN || (urow < H2 && col < H1)) ? th[oW2 + urow + col * H2] : 0.0;      // A[i][k] = W2[unit(i)][4s + k]
+        W2T[sc] = (!GEN || (col < H2 && urow < H1)) ? th[oW2 + col + urow * H2] : 0.0;      // A[i][k] = W2[4s + k][unit(i)]
     });
+#else
+    static_assert(!GEN, "the runtime-shape instance keeps W2's fragments resident");
 #endif
-    const double W1A = kq < 3 ? th[OFF_W1 + urow + kq * H] : th[OFF_B1 + urow];
-    for (int i = tid; i < 3 * H; i += BLOCKT) W1L[i] = th[OFF_W1 + i];
-    if (tid < H) { B2L[tid] = th[OFF_B2 + tid]; W3L[tid] = th[OFF_W3 + tid]; }
+    const double W1A = (!GEN || urow < H1) ? (kq < 3 ? th[oW1 + urow + kq * H1] : th[oB1 + urow]) : 0.0;
+    for (int i = tid; i < 3 * H; i += BLOCKT) W1L[i] = (!GEN || (i % H) < H1) ? th[oW1 + (i % H) + (i / H) * H1] : 0.0;
+    if (tid < H) { B2L[tid] = (!GEN || tid < H2) ? th[oB2 + tid] : 0.0; W3L[tid] = (!GEN || tid < H2) ? th[oW3 + tid] : 0.0; }
     const int u0r = 16 * w + 4 * kq;          // first of this lane's four units
 #if UDE_LSF_PER_CU == 1   // (512 registers per lane: b2 and w3 of this lane's units stay in registers; two blocks per CU: read from LDS)
     double b2r[4], w3r[4];
-    static_for<0, 4>([&](auto r) { b2r[r] = th[OFF_B2 + u0r + decltype(r)::value]; w3r[r] = th[OFF_W3 + u0r + decltype(r)::value]; });
+    static_for<0, 4>([&](auto r) {
+        const int un = u0r + decltype(r)::value;
+        b2r[r] = (!GEN || un < H2) ? th[oB2 + un] : 0.0;
+        w3r[r] = (!GEN || un < H2) ? th[oW3 + un] : 0.0;
+    });
 #define LSF_B2(r) b2r[r]
 #define LSF_W3(r) w3r[r]
 #else
@@ -441,14 +455,22 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
 #endif
             {
                 v4d acc[4];
-                static_for<0, 4>([&](auto bc) {
-                    constexpr int b = decltype(bc)::value;
-                    acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
-                    static_for<0, 4>([&](auto q) {
-                        constexpr int s = 4 * b + decltype(q)::value;
-                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                if (!GEN || blk_fwd) {
+                    static_for<0, 4>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                        static_for<0, 4>([&](auto q) {
+                            constexpr int s = 4 * b + decltype(q)::value;
+                            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                        });
                     });
-                });
+                } else {   // fewer than 64 inputs: one ascending chain (the trailing zero terms are exact)
+                    acc[0] = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, 16>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[0], 0, 0, 0);
+                    });
+                }
 #if UDE_LSF_W2_RELOAD
                 // (W2's fragment has had its last use: the registers take W2^T, the four tanh below cover the latency)
                 static_for<0, 16>([&](auto sc) { W2T[sc] = thw[(4 * (int)decltype(sc)::value + kq) + urow * H]; });
@@ -460,7 +482,7 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
 #endif
                 static_for<0, 4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    const double z2 = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + LSF_B2(r);
+                    const double z2 = ((!GEN || blk_fwd) ? (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) : acc[0][r]) + LSF_B2(r);
                     const double a2 = dtanh(z2);
                     const double d2 = __builtin_fma(LSF_W3(r), d3j, 0.0) * __builtin_fma(-a2, a2, 1.0);
                     T_D2[(u0r + r) * TLD + jc] = d2;
@@ -477,18 +499,26 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
             // transposed hidden layer on the deltas
             {
                 v4d acc[4];
-                static_for<0, 4>([&](auto bc) {
-                    constexpr int b = decltype(bc)::value;
-                    acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
-                    static_for<0, 4>([&](auto q) {
-                        constexpr int s = 4 * b + decltype(q)::value;
-                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                if (!GEN || blk_bwd) {
+                    static_for<0, 4>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+                        static_for<0, 4>([&](auto q) {
+                            constexpr int s = 4 * b + decltype(q)::value;
+                            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[b], 0, 0, 0);
+                        });
                     });
-                });
+                } else {
+                    acc[0] = v4d{0.0, 0.0, 0.0, 0.0};
+                    static_for<0, 16>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2T[s], T_D2[(4 * s + kq) * TLD + jc], acc[0], 0, 0, 0);
+                    });
+                }
                 double pg[3] = {0.0, 0.0, 0.0};
                 static_for<0, 4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    const double s1 = ((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r];
+                    const double s1 = (!GEN || blk_bwd) ? (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) : acc[0][r];
                     dv1[r] = s1 * __builtin_fma(-a1[r], a1[r], 1.0);
 #if UDE_LSF_SMALL_VALU
                     const double c1 = -(WSL[jc] * dv1[r]);
@@ -544,6 +574,14 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                 const double* g4 = GXP + (decltype(mm)::value * NSLOTS + slot) * 4;
                 gx[mm] = (g4[0] + g4[1]) + (g4[2] + g4[3]);   // levels 5, 6
             });
+            if (GEN && !blk_fwd) {
+                // fewer than 64 units in the first layer: the input cotangent is ONE ascending chain over the units (wide_dot, n < 64;
+                // n = 32 is the tree case and not served), formed by lane m < 3 of the slot's row from the delta1 tile
+                double acc = 0.0;
+                const double* wl = W1L + (lm < 3 ? lm : 0) * H;
+                for (int u = 0; u < H1; ++u) acc = __builtin_fma(wl[u], T_D1[u * TLD + slot], acc);
+                static_for<0, 3>([&](auto mm) { gx[mm] = rshfl(acc, decltype(mm)::value); });
+            }
             const double Sv = y[0], Nv = y[4], Dv = y[5];
             const double cc = b0c * Fc / Nv;
             const double cN = b0c * Sv * Fc / (Nv * Nv);
@@ -717,11 +755,16 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     static_for<0, 4>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         const int unit = 16 * w + kq + 4 * r;    // accumulator rows are NOT permuted: tile row i = kq + 4r is unit 16w + i
-        static_for<0, 4>([&](auto cc) { row[OFF_W2 + unit + (16 * (int)decltype(cc)::value + jc) * H] = gW2[cc][r]; });
+        static_for<0, 4>([&](auto cc) {
+            const int c1 = 16 * (int)decltype(cc)::value + jc;
+            if (!GEN || (unit < H2 && c1 < H1)) row[oW2 + unit + c1 * H2] = gW2[cc][r];
+        });
 #if !UDE_LSF_SMALL_VALU
-        if (jc == 0) { row[OFF_B2 + unit] = gB2[r]; row[OFF_W3 + unit] = gW3[r]; }
-        if (jc < 3) row[OFF_W1 + unit + jc * H] = gW1[r];
-        if (jc == 3) row[OFF_B1 + unit] = gW1[r];
+        if (jc == 0 && (!GEN || unit < H2)) { row[oB2 + unit] = gB2[r]; row[oW3 + unit] = gW3[r]; }
+        if (!GEN || unit < H1) {
+            if (jc < 3) row[oW1 + unit + jc * H1] = gW1[r];
+            if (jc == 3) row[oB1 + unit] = gW1[r];
+        }
 #endif
     });
 #if UDE_LSF_SMALL_VALU
@@ -751,7 +794,7 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     if (tid == 0) {
         double s = MB3[0];
         for (int i = 1; i < NSLOTS; ++i) s += MB3[i];
-        row[OFF_B3] = s;
+        row[oB3] = s;
     }
 }
 

@@ -17,3 +17,15 @@ extern "C" void ude_seir_lsf_get(int alg, void (**kern)(const KParams, double*, 
         *lds_bytes = sizeof(double) * seirlf::lds_doubles<Tsit5Tab>() + 16;
     }
 }
+
+// ... and its runtime-shape instance (exposure chains 3 -> H1 -> H2 -> 1 without a compiled instance: udecore.hip, seir_gen_ls_shape)
+extern "C" void ude_seir_lsf_get_gen(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, int* blocks_per_cu) {
+    *blocks_per_cu = UDE_LSF_PER_CU;
+    if (alg == 1) {
+        *kern = seirlf::seir_lsf_adj_kernel<Vern7Tab, true>;
+        *lds_bytes = sizeof(double) * seirlf::lds_doubles<Vern7Tab>() + 16;
+    } else {
+        *kern = seirlf::seir_lsf_adj_kernel<Tsit5Tab, true>;
+        *lds_bytes = sizeof(double) * seirlf::lds_doubles<Tsit5Tab>() + 16;
+    }
+}

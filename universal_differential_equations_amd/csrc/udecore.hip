@@ -240,6 +240,7 @@ extern "C" void ude_seir_ls_get_fwd_gen(int alg, void (**kern)(const KParams, in
 extern "C" void ude_seir_ls_get_gen(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
 // the `fast` mode on the same architecture: parameter cotangent as a block-level matrix-core accumulation (csrc/ude_seir_lsf.h)
 extern "C" void ude_seir_lsf_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, int* blocks_per_cu);
+extern "C" void ude_seir_lsf_get_gen(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, int* blocks_per_cu);
 extern "C" void ude_node_lsf_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, int* blocks_per_cu);
 extern "C" void ude_node_ls_get_fwd(int alg, void (**kern)(const KParams, int*), size_t* lds_bytes, int* blocks_per_cu);
 extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block);
@@ -774,7 +775,10 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
                           (want_lanes == 16 || (want_lanes == 0 && UDE_SEIR_LS_DEFAULT));
     const bool node_lsf = model_id(m) == MID_SEIR_NODE && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST && o->per_trajectory == 0 &&
                           (want_lanes == 16 || (want_lanes == 0 && UDE_NODE_LS_DEFAULT));
-    const bool any_lsf = seir_lsf || node_lsf;
+    // ... and a runtime-shape exposure chain (seir_gen_ls_shape) in the `fast` mode: the runtime-shape instance of the same kernel
+    const bool seir_gen_lsf = model_id(m) == MID_NONE && seir_gen_ls_shape(m) && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_FAST && o->per_trajectory == 0 &&
+                              (want_lanes == 16 || (want_lanes == 0 && UDE_SEIR_LS_DEFAULT));
+    const bool any_lsf = seir_lsf || node_lsf || seir_gen_lsf;
     // a runtime-shape exposure UDE 3 -> H1 -> H2 -> 1 (no compiled instance): its backward pass on the lock-step kernel, zero-padded to 64 x 64
     // (round 5: 47.6 -> 11 ms for 3-64-63-1 on the configs[2] share), and so does its forward pass (H2 != 32: seir_gen_ls_fwd_shape)
     const bool seir_gen_ls = model_id(m) == MID_NONE && seir_gen_ls_shape(m) && o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT && o->per_trajectory == 0 &&
@@ -802,7 +806,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     int lsf_per_cu = 1;
     int64_t lsf_blocks = 0;
     if (any_lsf) {
-        (seir_lsf ? ude_seir_lsf_get : ude_node_lsf_get)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &lsf_per_cu);
+        (seir_gen_lsf ? ude_seir_lsf_get_gen : seir_lsf ? ude_seir_lsf_get : ude_node_lsf_get)(o->alg == UDE_ALG_VERN7 ? 1 : 0, &ls_kern, &ls_lds, &lsf_per_cu);
         lsf_blocks = ls_blocks(c, N, lsf_per_cu);
         // more than one block per CU, but not enough full blocks for all of them: every CU gets the same number of (partly filled)
         // blocks -- the trajectories are dealt round-robin -- instead of some CUs two full blocks and the others one
@@ -895,7 +899,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     HIPCHK(c, hipMemsetAsync(p.grad_part, 0, es * (size_t)(pm ? N : nwaves) * np, c->stream));
     if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     ude_poison_chip(c->stream, true);
-    const bool gen_fwd = seir_gen_ls && UDE_SEIR_LS_FWD && seir_gen_ls_fwd_shape(m);
+    const bool gen_fwd = (seir_gen_ls || seir_gen_lsf) && UDE_SEIR_LS_FWD && seir_gen_ls_fwd_shape(m);
     if (((seir_ls || seir_lsf || gen_fwd) && UDE_SEIR_LS_FWD) || ((node_ls || node_lsf) && UDE_NODE_LS_FWD)) {
         void (*lf)(const KParams, int*) = nullptr;
         size_t lf_lds = 0;
