@@ -97,6 +97,84 @@ def test_fuzz_lv_kind_random_shapes(golden, seed):
         assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn
 
 
+LV_RT_CASES = [([2, 8, 8, 8, 2], ["tanh", "tanh", "tanh", "identity"], None), ([2, 6, 5, 7, 2], ["rbf", "tanh", "relu", "identity"], "both"),
+               ([2, 5, 5, 5, 2], ["tanh", "tanh", "tanh", "identity"], "delta"), ([2, 1, 1, 1, 2], ["rbf", "rbf", "rbf", "identity"], None),
+               ([2, 8, 8, 2], ["tanh", "rbf", "identity"], "both"), ([2, 3, 8, 2], ["relu", "tanh", "identity"], None),
+               ([2, 7, 2, 2], ["identity", "tanh", "identity"], "delta"), ([2, 8, 1, 8, 2], ["tanh", "identity", "rbf", "identity"], None)]
+
+
+@pytest.mark.parametrize("case", range(len(LV_RT_CASES)))
+def test_lv_kind_edited_network_on_the_lane_group_kernels(golden, case):
+    """round 5: the LV scripts' chain with EDITED widths / activations (`U = Lux.Chain(Dense(2,5,rbf), ...)` is a script variable:
+    scenario_1.jl:62-64) -- two or three hidden layers of width <= 8, linear output layer -- runs on the lane-group kernels of the
+    compiled instances (CoopMlp over NetCfgRt: the register copy of the weights zero-padded to width 8, eight lanes per trajectory)
+    instead of one wavefront per trajectory: forward solve, interpolating adjoint, discrete sweep, checkpointed adjoint, per-member
+    parameters.  Per trajectory every number is the oracle's (a single trajectory: every gradient entry), and the same bits as the
+    wavefront-per-trajectory runtime-shape kernel (lanes_per_traj = 64)."""
+    dims, acts, trainable = LV_RT_CASES[case]
+    rng = np.random.default_rng(4000 + case)
+    chain = chain_of(dims, acts)
+    f = models.ude_dynamics(chain, trainable=trainable)
+    nn_off = {None: 0, "delta": 1, "both": 2}[trainable]
+    om = O.make_model(O.KIND_LV_UDE, 2, dims, acts, nn_offset=nn_off,
+                      lin_idx={None: (-1, -1), "delta": (-1, 0), "both": (0, 1)}[trainable],
+                      lin_sign={None: (1.0, 1.0), "delta": (1.0, -1.0), "both": (1.0, -1.0)}[trainable],
+                      lin_const={None: (1.3, -1.8), "delta": (1.3, 0.0), "both": (0.0, 0.0)}[trainable])
+    lead = {None: [], "delta": [1.8], "both": [1.3, 1.8]}[trainable]
+    th = np.concatenate([lead, theta_for(chain, rng, 0.3)]).astype(np.float64)
+    assert supported(f) == 1 and f.n_param == th.size == om.n_param
+    g = golden("Scenario_1_recovery_0.005")
+    X = np.array(g["X"]["data_colmajor"]).reshape(31, 2)
+    t = np.array(g["solution"]["t"])
+    alg, oalg = (U.Tsit5, O.TSIT5) if case % 2 == 0 else (U.Vern7, O.VERN7)
+    W64 = U.EnsembleMI355(lanes_per_traj=64)
+    for N in (1, 13):
+        u0 = X[0] * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))
+        data = np.repeat(X[None], N, axis=0)
+        ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (t[0], t[-1]), th), u0)
+        sol = U.solve(ens, alg(), saveat=t, abstol=1e-6, reltol=1e-6)
+        out, st, rc = O.solve_ensemble(om, O.opts(oalg, 1e-6, 1e-6), u0, [t[0], t[-1]], th, t)
+        assert (rc == 0).all()
+        assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts %s %s" % (dims, acts))
+        assert_bitwise(sol.u, out, "forward states")
+        assert_bitwise(U.rhs(f, u0, th), np.array([O.rhs(om, th, u) for u in u0]), "rhs")
+        for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1), (U.InterpolatingAdjoint(checkpointing=True), 0)):
+            r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6, sensealg=sense)
+            ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6, sensealg=osense), u0, [t[0], t[-1]], th, t, data, nthreads=4)
+            what = "%s %s N %d sense %s" % (dims, acts, N, type(sense).__name__)
+            assert (r.retcode == 0).all(), what
+            if isinstance(sense, U.InterpolatingAdjoint):
+                # (the checkpointed forward pass builds Vern7's lazy stages only in steps that hold a save point: column 7 counts those)
+                assert_bitwise(r.stats[:, [0, 1, 2, 4, 5, 6]], ref["stats"][:, [0, 1, 2, 4, 5, 6]], what)
+                assert_bitwise(r.u, ref["u"], what)
+                assert_bitwise(r.grad_u0, ref["grad_u0"], what)
+            else:
+                check_per_trajectory(r, ref)
+            assert_bitwise(r.loss_per_traj, ref["loss_per_traj"], "per-trajectory loss " + what)
+            if N == 1:
+                assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta " + what)
+            else:
+                gn = np.linalg.norm(ref["grad_theta"])
+                assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn, what
+            if sense is None:
+                w64 = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=W64)
+                assert_bitwise(r.grad_u0, w64.grad_u0, "lane groups vs wavefront per trajectory: dL/du0")
+                assert_bitwise(r.stats, w64.stats, "lane groups vs wavefront per trajectory: counts")
+                if N == 1:
+                    assert_bitwise(r.grad_theta, w64.grad_theta, "lane groups vs wavefront per trajectory: dL/dtheta")
+    # per-member parameters (UDE_PT_THETA): every member its own weights, its own gradient row
+    N = 5
+    thetas = th[None, :] * (1 + 0.2 * rng.standard_normal((N, th.size)))
+    u0 = X[0] * (1 + 0.2 * rng.uniform(-1, 1, (N, 2)))
+    data = np.repeat(X[None], N, axis=0)
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (t[0], t[-1]), thetas[0]), u0, ps=thetas)
+    r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6)
+    for j in range(N):
+        ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-6, 1e-6), u0[j:j + 1], [t[0], t[-1]], thetas[j], t, data[j:j + 1])
+        assert_bitwise(r.stats[j], ref["stats"][0], "member %d counts" % j)
+        assert_bitwise(r.grad_theta[j], ref["grad_theta"], "member %d dL/dtheta" % j)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_fuzz_discrete_sweep_random_shapes(golden, seed):
     """round 4: `sensealg = ForwardDiffSensitivity()` -- what scenario_1.jl:86 / scenario_2.jl:108 request -- for ANY chain: the

@@ -25,6 +25,7 @@ ROWS = [
     ("lv (headline) adjoint", "ude_inst_lv_s1n_g5_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("lv discrete sweep", "ude_inst_lv_s1n_g5_w1_tsit5.log", "dadj_kernel<*false, double>"),
     ("lv_tanh32 adjoint", "ude_inst_lv_tanh32_g16_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
+    ("lv_shape8 adjoint (run-time shapes on 8-lane groups)", "ude_inst_lv_rt4_g8_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("lv_wave64 adjoint (runtime shapes)", "ude_inst_generic_2_l4_g64_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("seir forward (lock-step)", "ude_seir_ls.log", "seir_ls_fwd_kernel<Vern7Tab, false>*"),
     ("seir adjoint, parity mode (lock-step, second generation: the shipped one)", "ude_seir_ls.log", "seir_ls2_adj_kernel<Vern7Tab, false>*"),

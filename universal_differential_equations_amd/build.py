@@ -38,6 +38,9 @@ MODELS = [
     ("MID_LV_S1", "LvUde<NetS1,4>", 4, 1),
     ("MID_LV_S1", "LvUde<NetS1,8>", 8, 1),
     ("MID_LV_HUDSON", "LvUde<NetHudson,8>", 8, 1),
+    # run-time shapes of the LV kind (two / three hidden layers of width <= 8, any activation): padded register copy of the weights
+    ("MID_LV_RT3", "LvUde<NetLvRt3,8>", 8, 1),
+    ("MID_LV_RT4", "LvUde<NetLvRt4,8>", 8, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,8>", 8, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,16>", 16, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,32>", 32, 1),

@@ -195,8 +195,11 @@ struct IntList {
 
 // Dense-layer stack: dims D0 -> D1 -> ... -> DL, activation per layer.
 // theta layout per layer: [vec(W) column-major (out x in); b(out)]  (Lux / FastChain / Flux.destructure)
+enum { ACT_RT = 100 };   // an activation chosen at run time (NetCfgRt below)
+
 template <class DIMS, class ACTS>
 struct NetCfg {
+    static constexpr bool RT = false;
     static constexpr int L = DIMS::n - 1;
     static_assert(ACTS::n == L, "one activation per Dense layer");
     static constexpr int dim(int l) { return DIMS::at(l); }
@@ -212,6 +215,26 @@ struct NetCfg {
         for (int i = 0; i <= L; ++i) m = dim(i) > m ? dim(i) : m;
         return m;
     }
+};
+
+// A chain IN -> (L_ - 1 hidden layers of width <= W_) -> OUT whose hidden widths and activations are RUN-TIME values (round 5: an edited
+// LV network -- `Lux.Chain(Dense(2,5,rbf), ...)` is a script variable -- on the lane-group kernels instead of the wavefront-per-trajectory
+// fallback).  The compile-time shape is the PADDED one: the register copy of the weights (CoopMlp::WReg) is loaded with zeros beyond the
+// true widths, a padded neuron's activation is forced to 0, so every fma chain of the true chain is followed by exact no-op terms
+// (fma(0, 0, acc)) and every padded parameter slot holds 0: the bits of the true shape, whatever it is.  Linear last layer.
+template <int IN_, int OUT_, int L_, int W_>
+struct NetCfgRt {
+    static constexpr bool RT = true;
+    static constexpr int L = L_;
+    static constexpr int dim(int l) { return l == 0 ? IN_ : l == L_ ? OUT_ : W_; }
+    static constexpr int act(int l) { return l == L_ - 1 ? ACT_IDENTITY : ACT_RT; }
+    static constexpr int off(int l) {   // (offsets of the PADDED shape: never used to address theta -- WReg::rt holds the true ones)
+        int o = 0;
+        for (int i = 0; i < l; ++i) o += dim(i) * dim(i + 1) + dim(i + 1);
+        return o;
+    }
+    static constexpr int nparam = off(L_);
+    static constexpr int maxdim() { return W_ > IN_ ? (W_ > OUT_ ? W_ : OUT_) : (IN_ > OUT_ ? IN_ : OUT_); }
 };
 
 template <class N, int G>
@@ -301,12 +324,90 @@ struct CoopMlp {
     // Register-resident copy of the weights THIS lane touches: the rows of its neurons (forward), the columns of
     // the next layer at its neurons (backward) and the first layer (input cotangent).  Loaded once per kernel; takes
     // the LDS round trips of the weight fetches out of the per-evaluation latency chain.
+    struct RtInfo { int dim[L + 1], act[L], off[L]; };   // run-time shape of a NetCfgRt chain: true widths, activations, theta offsets
+    struct NoRt {};
     struct WReg {
         real row[L][MAXOWN][MAXD + 1];  // [l][m][k], bias at k = dim(l)
         real col[L][MAXOWN][MAXD];      // [l][m][i] = W_{l+1}[i, j]
         real w0[MAXD * MAXD];           // W_0[j + k*out]
         real last[REP_OUT][MAXD + 1];   // replicated last layer (rep_last): every row of W_{L-1}, bias at k = dim(L-1)
+        std::conditional_t<N::RT, RtInfo, NoRt> rt;
     };
+    // the register copy of a run-time shape (NetCfgRt): zeros beyond the true widths
+    template <class P, class MC>
+    static __device__ __forceinline__ void load_weights_rt(const P* th, int r, WReg& w, const MC& mc) {
+        int o = 0;
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            w.rt.dim[l] = mc.dims[l]; w.rt.act[l] = mc.act[l]; w.rt.off[l] = o;
+            o += mc.dims[l] * mc.dims[l + 1] + mc.dims[l + 1];
+        });
+        w.rt.dim[L] = mc.dims[L];
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            constexpr int in = N::dim(l), out = N::dim(l + 1);
+            const int inr = w.rt.dim[l], outr = w.rt.dim[l + 1];
+            const P* W = th + w.rt.off[l];
+            static_for<0, own(l)>([&](auto mc_) {
+                constexpr int m = mc_;
+                const int j = r + m * G;
+                const bool jv = j < outr;
+                const int jj = jv ? j : 0;
+                static_for<0, in>([&](auto k) { w.row[l][m][k] = (jv && (int)decltype(k)::value < inr) ? (real)W[jj + (int)decltype(k)::value * outr] : real(0); });
+                w.row[l][m][in] = jv ? (real)W[inr * outr + jj] : real(0);
+                if constexpr (l + 1 < L) {
+                    constexpr int out2 = N::dim(l + 2);
+                    const int out2r = w.rt.dim[l + 2];
+                    const P* W2 = th + w.rt.off[l + 1];
+                    static_for<0, out2>([&](auto i) { w.col[l][m][i] = (jv && (int)decltype(i)::value < out2r) ? (real)W2[(int)decltype(i)::value + jj * out2r] : real(0); });
+                }
+            });
+        });
+        {
+            constexpr int in = N::dim(0), out = N::dim(1);
+            const int outr = w.rt.dim[1];
+            static_for<0, in * out>([&](auto ic) {
+                constexpr int i = ic, j = i % out, k = i / out;
+                w.w0[i] = j < outr ? (real)th[w.rt.off[0] + j + k * outr] : real(0);
+            });
+        }
+        if constexpr (rep_last(L - 1)) {
+            constexpr int in = N::dim(L - 1), out = N::dim(L);
+            const int inr = w.rt.dim[L - 1];
+            const P* WL = th + w.rt.off[L - 1];
+            static_for<0, out>([&](auto i) {
+                static_for<0, in>([&](auto k) { w.last[i][k] = (int)decltype(k)::value < inr ? (real)WL[(int)decltype(i)::value + (int)decltype(k)::value * out] : real(0); });
+                w.last[i][in] = (real)WL[inr * out + (int)decltype(i)::value];
+            });
+        }
+    }
+    // activation of layer l and its derivative: compile-time, or (ACT_RT) the chain's run-time choice -- a wave-uniform branch
+    template <int l, class WS>
+    static __device__ __forceinline__ real actF(const WS& th, real z) {
+        if constexpr (N::act(l) == ACT_RT) {
+            const int a = th.rt.act[l];
+            if (a == ACT_TANH) return rtanh(z);
+            if (a == ACT_RBF) return rexp(-(z * z));
+            if (a == ACT_RELU) return z > real(0) ? z : real(0);
+            return z;
+        } else { (void)th; return act_fwd<N::act(l)>(z); }
+    }
+    template <int l, class WS>
+    static __device__ __forceinline__ real actB(const WS& th, real z, real a_) {
+        if constexpr (N::act(l) == ACT_RT) {
+            const int a = th.rt.act[l];
+            if (a == ACT_TANH) return rfma(-a_, a_, real(1));
+            if (a == ACT_RBF) return (real(-2) * z) * a_;
+            if (a == ACT_RELU) return z > real(0) ? real(1) : real(0);
+            return real(1);
+        } else { (void)th; return act_bwd<N::act(l)>(z, a_); }
+    }
+    // (run-time shapes: is neuron j of layer l one of the true chain's?)
+    template <int l, class WS>
+    static __device__ __forceinline__ bool rt_valid(const WS& th, int j) {
+        if constexpr (N::RT) return j < th.rt.dim[l + 1];
+        else { (void)th; (void)j; return true; }
+    }
     template <class P>
     static __device__ __forceinline__ void load_weights(const P* th, int r, WReg& w) {
         static_for<0, L>([&](auto lc) {
@@ -379,6 +480,7 @@ struct CoopMlp {
                 c.z[l][0] = zr;
                 c.ao[l][0] = r < out ? act_fwd<N::act(l)>(zr) : real(0);
                 static_for<0, out>([&](auto i) { c.a[l + 1][i] = act_fwd<N::act(l)>(zall[i]); });
+                static_assert(!N::RT, "run-time shapes: no tree layers");
             } else if constexpr (rep_last(l)) {
                 real zall[out];
                 static_for<0, out>([&](auto ic) {
@@ -407,7 +509,7 @@ struct CoopMlp {
                     acc += (real)th[N::off(l) + in * out + jj];
                 }
                 c.z[l][m] = acc;
-                c.ao[l][m] = valid ? act_fwd<N::act(l)>(acc) : 0.0;
+                c.ao[l][m] = (valid && rt_valid<l>(th, j)) ? actF<l>(th, acc) : 0.0;
             });
             // (the activations feed a tree layer above: it reads them where they are -- no gather)
             // (... unless its parameter slots go by input, KMAJ: then nothing else reads the replicated copy)
@@ -458,7 +560,7 @@ struct CoopMlp {
                         });
                     }
                 }
-                const real d = valid ? gp * act_bwd<N::act(l)>(c.z[l][m], c.ao[l][m]) : 0.0;
+                const real d = (valid && rt_valid<l>(th, j)) ? gp * actB<l>(th, c.z[l][m], c.ao[l][m]) : 0.0;
                 down[m] = d;
                 sink(l, m, d);
                 if constexpr (WANT_PARAM && !(KMAJ && l == L - 1)) {
@@ -528,6 +630,34 @@ struct CoopMlp {
                 const int j = r + m * G;
                 if (j < out) res = N::off(l) + (k < in ? j + k * out : in * out + j);
             }
+        });
+        return res;
+    }
+    // ... of a run-time shape (NetCfgRt): the slots are those of the padded shape, the theta indices those of the true one
+    template <class MC>
+    static __device__ __forceinline__ int slot_index_rt(const MC& mc, int r, int s) {
+        int res = -1, offr = 0;
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            constexpr int in = N::dim(l), out = N::dim(l + 1);
+            constexpr int lo = slot_off(l), hi = slot_off(l) + layer_slots(l);
+            const int inr = mc.dims[l], outr = mc.dims[l + 1];
+            if constexpr (KMAJ && l == L - 1) {
+                if (s >= lo && s < hi) {
+                    const int q = s - lo;
+                    if (q < OM * out) { const int k = r + (q / out) * G; if (k < inr) res = offr + q % out + k * outr; }
+                    else if (r < outr) res = offr + inr * outr + r;
+                }
+            } else
+            if (s >= lo && s < hi) {
+                const int m = (s - lo) / (in + 1), k = (s - lo) % (in + 1);
+                const int j = r + m * G;
+                if (j < outr) {
+                    if (k < inr) res = offr + j + k * outr;
+                    else if (k == in) res = offr + inr * outr + j;
+                }
+            }
+            offr += inr * outr + outr;
         });
         return res;
     }

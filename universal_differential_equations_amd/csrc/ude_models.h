@@ -121,7 +121,9 @@ struct LvUde : LinearTheta {
             c.lin[i] = mc.lin_idx[i] >= 0 ? (real)mc.lin_sign[i] * th_lds[mc.lin_idx[i]] : (real)mc.lin_const[i];
             c.lead_on[i] = (mc.lin_idx[i] >= 0 && r == 0) ? (real)mc.lin_sign[i] : real(0);
         }
-        if constexpr (REGW) Mlp::load_weights(c.nn, r, c.w);
+        static_assert(!Net::RT || REGW, "run-time shapes live in the register copy of the weights");
+        if constexpr (Net::RT) Mlp::load_weights_rt(c.nn, r, c.w, mc);
+        else if constexpr (REGW) Mlp::load_weights(c.nn, r, c.w);
     }
     static __device__ __forceinline__ void rhs(const Ctx& c, const real* u, real* du) {
         typename Mlp::Cache cache;
@@ -157,7 +159,9 @@ struct LvUde : LinearTheta {
             const int i = s - Mlp::NSLOT;
             return (r == 0 && mc.lin_idx[i] >= 0) ? mc.lin_idx[i] : -1;
         }
-        const int k = Mlp::slot_index(r, s);
+        int k;
+        if constexpr (Net::RT) k = Mlp::slot_index_rt(mc, r, s);
+        else k = Mlp::slot_index(r, s);
         return k < 0 ? -1 : mc.nn_offset + k;
     }
 };

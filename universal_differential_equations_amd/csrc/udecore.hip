@@ -311,7 +311,7 @@ static int model_id(const ude_model_desc* m) {
 
 // the runtime-shape fallback (csrc/ude_model_generic.h) takes any chain of 1..8 Dense layers of width 1..64 with activations
 // identity / tanh / rbf / relu whose ends fit the kind's wiring: LV 2 -> 2, SEIR exposure 3 -> 1, neural ODE 7 -> 7
-static int generic_id(const ude_model_desc* m) {
+static int generic_id(const ude_model_desc* m, bool narrow_ok = true) {
     if ((m->dtype != 0 && m->dtype != 1) || m->n_layers < 1 || m->n_layers > UDE_MAX_LAYERS || m->nn_offset < 0) return MID_NONE;
     if (m->dtype == 1 && m->kind != UDE_KIND_LV_UDE) return MID_NONE;   // Float32: the LV kind (the reference's Float32 ODE problems)
     int np = 0;
@@ -327,6 +327,14 @@ static int generic_id(const ude_model_desc* m) {
         for (int i = 0; i < 2; ++i)
             if (m->lin_idx[i] >= m->n_param || (m->lin_idx[i] >= m->nn_offset && m->lin_idx[i] < m->nn_offset + np)) return MID_NONE;
         if (m->dtype == 1) return m->n_layers <= 4 ? MID_GENERIC_2_L4_F32 : MID_GENERIC_2_F32;
+        // round 5: the scripts' own depth with EDITED widths / activations -- two or three hidden layers of width <= 8, linear output
+        // layer -- on the lane-group kernels of the compiled instances (NetCfgRt: padded register copy of the weights, eight lanes per
+        // trajectory) instead of one wavefront per trajectory
+        if (narrow_ok && (m->n_layers == 3 || m->n_layers == 4) && m->act[m->n_layers - 1] == UDE_ACT_IDENTITY) {
+            bool fits = true;
+            for (int l = 1; l < m->n_layers; ++l) fits = fits && m->dims[l] <= 8;
+            if (fits) return m->n_layers == 3 ? MID_LV_RT3 : MID_LV_RT4;
+        }
         return m->n_layers <= 4 ? MID_GENERIC_2_L4 : MID_GENERIC_2;   // (<= 4 layers: the instance with half the stage storage)
     }
     // nn_ode with a pointwise reaction network that has no compiled instance: <= 4 layers of width <= 32, <= 768 parameters in all,
@@ -381,6 +389,8 @@ static int default_lanes(int mid, bool discrete) {
         case MID_LV_TRUE: return 1;
         case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
         case MID_LV_HUDSON:
+        case MID_LV_RT3:
+        case MID_LV_RT4:
         case MID_LV_HUDSON_F32: return 8;
         case MID_LV_TANH32: return 16;  // two hidden neurons per lane, four trajectories per wavefront, 253 registers = two wavefronts per SIMD.
                                         // Round 4 (32-term tree sums by the group's butterfly, parameter slots by input): 10k-trajectory gradient
@@ -438,7 +448,7 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
     // lanes_per_traj = 64 on an LV-kind model that has no 64-lane instance of its own: "one wavefront per trajectory" is the
     // runtime-shape kernel (lane j = neuron j of every layer) -- the layout north_star names; same bits as every other instance
     if (!ok && G == 64 && W == 1 && m->kind == UDE_KIND_LV_UDE) {
-        const int gid = generic_id(m);
+        const int gid = generic_id(m, false);
         for (const InstanceRow& row : kInstances)
             if (gid != MID_NONE && row.mid == gid && row.alg == o->alg && row.G == 64 && row.W == 1) {
                 row.get(&l);
