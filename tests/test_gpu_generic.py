@@ -100,7 +100,8 @@ def test_fuzz_lv_kind_random_shapes(golden, seed):
 LV_RT_CASES = [([2, 8, 8, 8, 2], ["tanh", "tanh", "tanh", "identity"], None), ([2, 6, 5, 7, 2], ["rbf", "tanh", "relu", "identity"], "both"),
                ([2, 5, 5, 5, 2], ["tanh", "tanh", "tanh", "identity"], "delta"), ([2, 1, 1, 1, 2], ["rbf", "rbf", "rbf", "identity"], None),
                ([2, 8, 8, 2], ["tanh", "rbf", "identity"], "both"), ([2, 3, 8, 2], ["relu", "tanh", "identity"], None),
-               ([2, 7, 2, 2], ["identity", "tanh", "identity"], "delta"), ([2, 8, 1, 8, 2], ["tanh", "identity", "rbf", "identity"], None)]
+               ([2, 7, 2, 2], ["identity", "tanh", "identity"], "delta"), ([2, 8, 1, 8, 2], ["tanh", "identity", "rbf", "identity"], None),
+               ([2, 4, 5, 2], ["tanh", "relu", "identity"], "both"), ([2, 5, 3, 4, 2], ["relu", "rbf", "tanh", "identity"], None)]
 
 
 @pytest.mark.parametrize("case", range(len(LV_RT_CASES)))
@@ -156,6 +157,12 @@ def test_lv_kind_edited_network_on_the_lane_group_kernels(golden, case):
             else:
                 gn = np.linalg.norm(ref["grad_theta"])
                 assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn, what
+            if sense is None and max(dims[1:-1]) <= 5:   # width <= 5: five lanes per trajectory by default; eight on request -- the same bits
+                w8 = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=U.EnsembleMI355(lanes_per_traj=8))
+                assert_bitwise(r.grad_u0, w8.grad_u0, "five lanes vs eight lanes: dL/du0")
+                assert_bitwise(r.stats, w8.stats, "five lanes vs eight lanes: counts")
+                if N == 1:
+                    assert_bitwise(r.grad_theta, w8.grad_theta, "five lanes vs eight lanes: dL/dtheta")
             if sense is None:
                 w64 = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=W64)
                 assert_bitwise(r.grad_u0, w64.grad_u0, "lane groups vs wavefront per trajectory: dL/du0")

@@ -15,3 +15,11 @@ ens = U.DeviceEnsemble(models.ude_dynamics(chain8), U.Tsit5(), (0.0, 3.0), t, u0
 for _ in range(3):
     ens.loss_grad(th); torch.cuda.synchronize()
 print("2-8-8-8-2 on the wavefront-per-trajectory kernel (lanes 64): kernel ms", ens.kernel_ms())
+
+chain5 = models.Chain(models.Dense(2, 5, "tanh"), models.Dense(5, 5, "tanh"), models.Dense(5, 5, "tanh"), models.Dense(5, 2, "identity"))
+th5 = torch.tensor(0.3 * chain5.glorot_uniform(np.random.default_rng(7)), dtype=torch.float64, device=dev)
+for lanes in (0, 8, 64):
+    ens = U.DeviceEnsemble(models.ude_dynamics(chain5), U.Tsit5(), (0.0, 3.0), t, u0_d, data=data, abstol=1e-6, reltol=1e-6, lanes_per_traj=lanes)
+    for _ in range(3):
+        ens.loss_grad(th5); torch.cuda.synchronize()
+    print("2-5-5-5-2 tanh (the scripts' widths, edited activations), lanes_per_traj", lanes or "default (5)", ": kernel ms", ens.kernel_ms())

@@ -41,6 +41,8 @@ MODELS = [
     # run-time shapes of the LV kind (two / three hidden layers of width <= 8, any activation): padded register copy of the weights
     ("MID_LV_RT3", "LvUde<NetLvRt3,8>", 8, 1),
     ("MID_LV_RT4", "LvUde<NetLvRt4,8>", 8, 1),
+    ("MID_LV_RT3_W5", "LvUde<NetLvRt3W5,5>", 5, 1),
+    ("MID_LV_RT4_W5", "LvUde<NetLvRt4W5,5>", 5, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,8>", 8, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,16>", 16, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,32>", 32, 1),

@@ -100,6 +100,10 @@ using NetTanh32 = NetCfg<IntList<2, 32, 2>, IntList<ACT_TANH, ACT_IDENTITY>>;   
 // run-time shapes of the LV kind on the lane-group kernels: 2 -> (two / three hidden layers of width <= 8, any activation) -> 2
 using NetLvRt3 = NetCfgRt<2, 2, 3, 8>;
 using NetLvRt4 = NetCfgRt<2, 2, 4, 8>;
+// ... and of width <= 5 on FIVE lanes (the headline instance's layout: twelve trajectories per wavefront, the 10k ensemble in one round) --
+// what an edit of the activations alone needs
+using NetLvRt3W5 = NetCfgRt<2, 2, 3, 5>;
+using NetLvRt4W5 = NetCfgRt<2, 2, 4, 5>;
 
 enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, MID_SEIR_TRUE, MID_SEIR_UDE,
        MID_KPP_TRUE_32, MID_KPP_TRUE_1024, MID_KPP_UDE_32, MID_KPP_UDE_1024, MID_KPP_S3_32, MID_KPP_SMALL_32,
@@ -113,7 +117,8 @@ enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, 
        MID_GENERIC_2_L4, MID_GENERIC_7_L4 /* the runtime-shape fallback for chains of <= 4 layers: half the LDS, twice the wavefronts per CU */,
        MID_GENERIC_2_F32, MID_GENERIC_2_L4_F32 /* Float32 LV-kind problems with any chain (hudson_bay.jl:77-79) */,
        MID_KPP_GENERIC_32 /* nn_ode with any pointwise reaction chain of <= 4 layers, width <= 32 (ude_model_kpp_generic.h) */,
-       MID_LV_RT3, MID_LV_RT4 /* LV kind, run-time shape 2 -> (2 / 3 hidden layers of width <= 8, any activation) -> 2 on 8-lane groups (NetCfgRt) */ };
+       MID_LV_RT3, MID_LV_RT4 /* LV kind, run-time shape 2 -> (2 / 3 hidden layers of width <= 8, any activation) -> 2 on 8-lane groups (NetCfgRt) */,
+       MID_LV_RT3_W5, MID_LV_RT4_W5 /* ... of width <= 5 on 5-lane groups */ };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88

@@ -331,9 +331,10 @@ static int generic_id(const ude_model_desc* m, bool narrow_ok = true) {
         // layer -- on the lane-group kernels of the compiled instances (NetCfgRt: padded register copy of the weights, eight lanes per
         // trajectory) instead of one wavefront per trajectory
         if (narrow_ok && (m->n_layers == 3 || m->n_layers == 4) && m->act[m->n_layers - 1] == UDE_ACT_IDENTITY) {
-            bool fits = true;
-            for (int l = 1; l < m->n_layers; ++l) fits = fits && m->dims[l] <= 8;
-            if (fits) return m->n_layers == 3 ? MID_LV_RT3 : MID_LV_RT4;
+            int wmax = 0;
+            for (int l = 1; l < m->n_layers; ++l) wmax = m->dims[l] > wmax ? m->dims[l] : wmax;
+            if (wmax <= 5) return m->n_layers == 3 ? MID_LV_RT3_W5 : MID_LV_RT4_W5;   // five lanes per trajectory: the headline instance's layout
+            if (wmax <= 8) return m->n_layers == 3 ? MID_LV_RT3 : MID_LV_RT4;
         }
         return m->n_layers <= 4 ? MID_GENERIC_2_L4 : MID_GENERIC_2;   // (<= 4 layers: the instance with half the stage storage)
     }
@@ -387,6 +388,8 @@ static int64_t ls_blocks(ude_ctx* c, int64_t N, int per_cu = 1) {
 static int default_lanes(int mid, bool discrete) {
     switch (mid) {
         case MID_LV_TRUE: return 1;
+        case MID_LV_RT3_W5:
+        case MID_LV_RT4_W5:
         case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
         case MID_LV_HUDSON:
         case MID_LV_RT3:
@@ -431,6 +434,7 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
                                             "outside the runtime-shape fallbacks (LV / SEIR kinds: <= 8 layers of width <= 64; Fisher-KPP on <= 32 points: <= 4 layers of width <= 32, Float64)",
                     m->kind, m->dtype, m->n_layers);
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
+    if (G == 8 && (mid == MID_LV_RT3_W5 || mid == MID_LV_RT4_W5)) mid = mid == MID_LV_RT3_W5 ? MID_LV_RT3 : MID_LV_RT4;   // (an explicit lanes_per_traj = 8: the width-8 instance takes narrower chains too)
     if ((mid == MID_SEIR_UDE || mid == MID_SEIR_NODE) && G == 16) G = 64;  // (16 = the lock-step backward kernel of grad_dev_impl; every other kernel of that model: one wavefront per trajectory)
     const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
     bool ok = false;
