@@ -102,7 +102,8 @@ def test_seir_fast_mode_block_level_matrix_core_accumulation(alg, oalg, kw):
             assert np.linalg.norm(r.grad_theta - full.grad_theta) < 1e-3 * np.linalg.norm(full.grad_theta)
 
 
-@pytest.mark.parametrize("dims", [[3, 64, 63, 1], [3, 16, 16, 1], [3, 33, 64, 1], [3, 64, 17, 1], [3, 31, 47, 1], [3, 49, 32, 1]], ids=lambda d: "-".join(map(str, d)))
+@pytest.mark.parametrize("dims", [[3, 64, 63, 1], [3, 16, 16, 1], [3, 33, 64, 1], [3, 64, 17, 1], [3, 31, 47, 1], [3, 49, 32, 1], [3, 8, 8, 1], [3, 5, 40, 1]],
+                         ids=lambda d: "-".join(map(str, d)))
 @pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
 def test_runtime_shape_exposure_chain_fast_mode_on_the_lockstep_kernel(dims, alg, oalg):
     """round 5: an exposure-UDE chain 3 -> H1 -> H2 -> 1 without a compiled instance in the `fast` mode: the runtime-shape instance of

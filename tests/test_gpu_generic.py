@@ -276,11 +276,14 @@ def test_fuzz_seir_kinds_random_shapes(seed):
                                   # with the narrowest output, H2 = 32 with a narrow H1 (forward on the wavefront kernel), and H1 = 32 (the
                                   # tree case the lock-step instances exclude: both passes on the wavefront kernel, same oracle)
                                   [3, 64, 33, 1], [3, 48, 48, 1], [3, 31, 47, 1], [3, 49, 64, 1], [3, 16, 64, 1], [3, 64, 17, 1], [3, 20, 32, 1],
-                                  [3, 32, 40, 1]],
+                                  [3, 32, 40, 1],
+                                  # widths below a tile: served unless a 32- / 64-term product has fewer than 16 results (64-8 and 8-64 stay on
+                                  # the wavefront kernel, like 32-40)
+                                  [3, 8, 8, 1], [3, 5, 40, 1], [3, 63, 3, 1], [3, 1, 1, 1], [3, 64, 8, 1], [3, 8, 64, 1]],
                          ids=lambda d: "-".join(map(str, d)))
 @pytest.mark.parametrize("alg,oalg", [(U.Vern7, O.VERN7), (U.Tsit5, O.TSIT5)])
 def test_runtime_shape_exposure_chain_on_the_lockstep_matrix_core_kernel(dims, alg, oalg):
-    """round 5: an exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity; 16 <= H1, H2 <= 64, H1 != 32) WITHOUT a compiled instance
+    """round 5: an exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity; H1, H2 <= 64 without a 32- / 64-term product of fewer than 16 results) WITHOUT a compiled instance
     runs its forward and backward passes on the lock-step matrix-core kernels (csrc/ude_seir_ls_fwd.h / ude_seir_ls2.h, GEN: weights zero-padded to 64 x 64, a 64-term
     product in four chains, a shorter one in ONE ascending chain, the input cotangent a tree for H1 = 64 and a chain otherwise) -- every
     number per trajectory as the oracle has it, every gradient entry for a single trajectory, and the same bits as the

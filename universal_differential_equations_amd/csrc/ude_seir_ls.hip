@@ -35,8 +35,8 @@ extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, i
     }
 }
 
-// the runtime-shape instance of the second-generation kernel: any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), 16 <= H1, H2 <= 64,
-// H1 != 32 (ude_seir_ls2.h, GEN = true); the forward solve of such a model stays with the wavefront-per-trajectory runtime-shape kernel
+// the runtime-shape instance of the second-generation kernel: any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), H1, H2 <= 64,
+// that udecore.hip's seir_gen_ls_shape admits (ude_seir_ls2.h, GEN = true)
 extern "C" void ude_seir_ls_get_gen(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block) {
     *fac_doubles_per_block = alg == 1 ? seirls::fac_doubles_per_block<Vern7Tab>() : seirls::fac_doubles_per_block<Tsit5Tab>();
     *kern = alg == 1 ? seirls2::seir_ls2_adj_kernel<Vern7Tab, true> : seirls2::seir_ls2_adj_kernel<Tsit5Tab, true>;

@@ -31,7 +31,7 @@ constexpr int lds_doubles() {
            NSLOTS * NSTC * H + NSLOTS * kst<Tab>() + NSLOTS * 8 + 16 * 8 + NSLOTS * 16 + 3 * H + NSLOTS * Tab::S * 8;
 }
 
-// GEN = true: the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity) with 16 <= H1, H2 <= 64, H1 != 32
+// GEN = true: the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity) with H1, H2 <= 64 that udecore.hip's seir_gen_ls_shape admits (no 32- / 64-term product with < 16 results)
 // (`Lux.Chain` / `FastChain` accept any chain upstream; ude_model_generic.h serves every other shape one wavefront per trajectory).  The
 // weights are zero-padded to 64 x 64 -- a padded unit has activation tanh(0) = 0 and delta 0, a padded parameter slot gradient and
 // residual 0: all exact -- and every product keeps the ORACLE'S association for ITS length (wide_dot): a 64-term product is four

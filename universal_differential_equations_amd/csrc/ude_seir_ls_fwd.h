@@ -24,8 +24,8 @@ enum { FPH_IDLE = -4, FPH_FSAL0 = -3, FPH_INIT0 = -2, FPH_INIT1 = -1 };   // >= 
 template <class Tab>
 constexpr int fwd_lds_doubles() { return H * TLD + 4 * 16 + NSLOTS * PLD + TABL + NSLOTS * Tab::NK * 16 + 16 + H; }
 
-// GEN = true (round 5): the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), 16 <= H1, H2 <= 64,
-// H1 != 32, H2 != 32, weights zero-padded to 64 x 64, every product in the ORACLE'S association for its length (ude_seir_ls2.h): the hidden
+// GEN = true (round 5): the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), H1, H2 <= 64 (the set
+// udecore.hip's seir_gen_ls_fwd_shape admits: no 32- / 64-term product with fewer than 16 results), weights zero-padded to 64 x 64, every product in the ORACLE'S association for its length (ude_seir_ls2.h): the hidden
 // product four 16-term chains for H1 == 64 and ONE ascending chain otherwise, the output layer the adjacent-pair tree of rounded products
 // for H2 == 64 and one ascending fma chain over the units otherwise
 template <class Tab, bool GEN = false>

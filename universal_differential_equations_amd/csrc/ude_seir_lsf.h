@@ -81,8 +81,8 @@ constexpr int lds_doubles() {
            NSLOTS * Tab::S * 8 + NSLOTS + 2 * H;
 }
 
-// GEN = true (round 5): the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), 16 <= H1, H2 <= 64,
-// H1 != 32, weights zero-padded to 64 x 64, every product of the network in the association of ITS length (ude_seir_ls2.h); the block's
+// GEN = true (round 5): the RUNTIME-SHAPE instance -- any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), H1, H2 <= 64 (the set
+// udecore.hip's seir_gen_ls_shape admits), weights zero-padded to 64 x 64, every product of the network in the association of ITS length (ude_seir_ls2.h); the block's
 // accumulators hold the padded 64 x 64 gradient (a padded unit has delta = 0 and a = 0: exact zeros), written through the runtime offsets
 template <class Tab, bool GEN = false>
 __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(const KParams p, double* __restrict__ /*unused: no factor workspace*/,

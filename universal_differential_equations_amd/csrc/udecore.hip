@@ -352,11 +352,14 @@ static int generic_id(const ude_model_desc* m, bool narrow_ok = true) {
 }
 
 // exposure-UDE chains WITHOUT a compiled instance that the lock-step matrix-core backward kernel serves all the same (csrc/ude_seir_ls2.h, GEN):
-// 3 -> H1 -> H2 -> 1 with tanh, tanh, identity, 16 <= H1, H2 <= 64, H1 != 32 (a 32-term input cotangent is the oracle's tree case), Float64
+// 3 -> H1 -> H2 -> 1 with tanh, tanh, identity, H1, H2 <= 64, Float64 -- except the shapes with a product the kernels do not have in the
+// oracle's association (wide_dot: a product of 32 or 64 terms with fewer than 16 results is the adjacent-pair TREE): H1 = 32 (the
+// 32-term input cotangent), H1 = 64 with H2 < 16 (forward hidden layer), H2 = 32 or 64 with H1 < 16 (transposed hidden layer)
 static bool seir_gen_ls_shape(const ude_model_desc* m) {
     if (m->kind != UDE_KIND_SEIR_UDE || m->dtype != 0 || m->n_state != 7 || m->n_layers != 3 || m->nn_offset != 0) return false;
     const int h1 = m->dims[1], h2 = m->dims[2];
-    if (m->dims[0] != 3 || m->dims[3] != 1 || h1 < 16 || h1 > 64 || h1 == 32 || h2 < 16 || h2 > 64) return false;
+    if (m->dims[0] != 3 || m->dims[3] != 1 || h1 < 1 || h1 > 64 || h1 == 32 || h2 < 1 || h2 > 64) return false;
+    if ((h1 == 64 && h2 < 16) || ((h2 == 32 || h2 == 64) && h1 < 16)) return false;
     if (m->act[0] != UDE_ACT_TANH || m->act[1] != UDE_ACT_TANH || m->act[2] != UDE_ACT_IDENTITY) return false;
     return m->n_param == 3 * h1 + h1 + h1 * h2 + h2 + h2 + 1;
 }
