@@ -152,6 +152,47 @@ def test_f32_lv_kind_any_chain_matches_oracle(golden, seed):
             assert np.linalg.norm(r.grad_theta.astype(float) - ref["grad_theta"].astype(float)) < 2e-6 * np.linalg.norm(ref["grad_theta"].astype(float)), what
 
 
+@pytest.mark.parametrize("case", range(5))
+def test_f32_lv_kind_edited_network_on_the_lane_group_kernels(golden, case):
+    """round 5: hudson_bay.jl:77-104 with an EDITED FastChain (two / three hidden layers of width <= 8) as a Float32 problem: the
+    run-time-shape instances of the lane-group kernels (NetCfgRt, five or eight lanes per trajectory) on `real = float`; per trajectory
+    the Float32 oracle's bits, a single trajectory: every gradient entry; the same bits as the wavefront-per-trajectory Float32 kernel"""
+    from test_gpu_generic import chain_of, theta_for
+    dims, acts, trainable = [([2, 8, 8, 8, 2], ["tanh", "tanh", "tanh", "identity"], "both"), ([2, 5, 5, 5, 2], ["tanh", "tanh", "tanh", "identity"], None),
+                             ([2, 6, 4, 2], ["rbf", "tanh", "identity"], "both"), ([2, 3, 5, 2], ["relu", "rbf", "identity"], None),
+                             ([2, 7, 1, 8, 2], ["rbf", "identity", "tanh", "identity"], "both")][case]
+    rng = np.random.default_rng(700 + case)
+    chain = chain_of(dims, acts)
+    f = models.ude_dynamics(chain, trainable=trainable, dtype="float32")
+    om = O.make_model(O.KIND_LV_UDE, 2, dims, acts, nn_offset={None: 0, "both": 2}[trainable], lin_idx={None: (-1, -1), "both": (0, 1)}[trainable],
+                      lin_sign=(1.0, -1.0) if trainable else (1.0, 1.0), lin_const={None: (1.3, -1.8), "both": (0.0, 0.0)}[trainable], dtype=1)
+    th = np.concatenate([[1.3, 1.8] if trainable else [], theta_for(chain, rng, 0.3)]).astype(f32)
+    g = golden(HB)
+    X = np.array(g["X"]["data_colmajor"], dtype=f32).reshape(21, 2)[:13]
+    t = np.linspace(0.0, 3.0, 13).astype(f32)
+    alg, oalg = (U.Vern7, O.VERN7) if case % 2 else (U.Tsit5, O.TSIT5)
+    for N in (1, 9):
+        u0 = (X[0][None, :] * (1 + 0.1 * rng.uniform(-1, 1, (N, 2)))).astype(f32)
+        data = np.repeat(X[None], N, axis=0)
+        ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (float(t[0]), float(t[-1])), th), u0)
+        for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1)):
+            r = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-5, reltol=1e-5, sensealg=sense)
+            ref = O.loss_grad_ensemble(om, O.opts(oalg, 1e-5, 1e-5, sensealg=osense), u0, [t[0], t[-1]], th, t, data, dtype=f32, nthreads=4)
+            what = "%s %s N %d sense %d" % (dims, acts, N, osense)
+            assert (r.retcode == 0).all() and r.u.dtype == f32, what
+            assert np.array_equal(r.stats, ref["stats"]) and np.array_equal(r.u, ref["u"]) and np.array_equal(r.grad_u0, ref["grad_u0"]), what
+            assert np.array_equal(r.loss_per_traj, ref["loss_per_traj"]), what
+            if N == 1:
+                assert np.array_equal(r.grad_theta, ref["grad_theta"]), what
+            else:
+                assert np.linalg.norm(r.grad_theta.astype(float) - ref["grad_theta"].astype(float)) < 2e-6 * np.linalg.norm(ref["grad_theta"].astype(float)), what
+            if sense is None:
+                w64 = U.loss_and_gradient(ens, alg(), data, saveat=t, abstol=1e-5, reltol=1e-5, ensemblealg=U.EnsembleMI355(lanes_per_traj=64))
+                assert np.array_equal(r.stats, w64.stats) and np.array_equal(r.grad_u0, w64.grad_u0), what
+                if N == 1:
+                    assert np.array_equal(r.grad_theta, w64.grad_theta), what
+
+
 def test_device_resident_f32_ensemble_matches_host_buffer_path(golden):
     """DeviceEnsemble on float32 CUDA tensors (the `_dev` entry points with dtype = 1) == the host-buffer entry points"""
     import torch

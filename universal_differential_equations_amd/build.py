@@ -71,6 +71,10 @@ MODELS = [
     ("MID_KPP_UDE_1024", "KppUdeW<NetKpp>", 256, 1, 256),
     # Float32 problems (-DUDE_F32: the same kernels with real = float)
     ("MID_LV_HUDSON_F32", "LvUde<NetHudson,8>", 8, 1, 64, None, ("-DUDE_F32=1",)),
+    ("MID_LV_RT3_F32", "LvUde<NetLvRt3,8>", 8, 1, 64, None, ("-DUDE_F32=1",)),
+    ("MID_LV_RT4_F32", "LvUde<NetLvRt4,8>", 8, 1, 64, None, ("-DUDE_F32=1",)),
+    ("MID_LV_RT3_W5_F32", "LvUde<NetLvRt3W5,5>", 5, 1, 64, None, ("-DUDE_F32=1",)),
+    ("MID_LV_RT4_W5_F32", "LvUde<NetLvRt4W5,5>", 5, 1, 64, None, ("-DUDE_F32=1",)),
     ("MID_KPP_TRUE_32_F32", "KppTrue<32,1>", 32, 1, 32, None, ("-DUDE_F32=1",)),
     ("MID_KPP_S3_32_F32", "KppUde<NetKppS3,32,1>", 32, 1, 32, None, ("-DUDE_F32=1",)),
 ]

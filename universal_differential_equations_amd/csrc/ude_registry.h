@@ -118,7 +118,8 @@ enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, 
        MID_GENERIC_2_F32, MID_GENERIC_2_L4_F32 /* Float32 LV-kind problems with any chain (hudson_bay.jl:77-79) */,
        MID_KPP_GENERIC_32 /* nn_ode with any pointwise reaction chain of <= 4 layers, width <= 32 (ude_model_kpp_generic.h) */,
        MID_LV_RT3, MID_LV_RT4 /* LV kind, run-time shape 2 -> (2 / 3 hidden layers of width <= 8, any activation) -> 2 on 8-lane groups (NetCfgRt) */,
-       MID_LV_RT3_W5, MID_LV_RT4_W5 /* ... of width <= 5 on 5-lane groups */ };
+       MID_LV_RT3_W5, MID_LV_RT4_W5 /* ... of width <= 5 on 5-lane groups */,
+       MID_LV_RT3_F32, MID_LV_RT4_F32, MID_LV_RT3_W5_F32, MID_LV_RT4_W5_F32 /* ... as Float32 problems (hudson_bay.jl:77-104 with an edited FastChain) */ };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88

@@ -326,16 +326,17 @@ static int generic_id(const ude_model_desc* m, bool narrow_ok = true) {
     if (m->kind == UDE_KIND_LV_UDE && m->n_state == 2 && in == 2 && out == 2) {
         for (int i = 0; i < 2; ++i)
             if (m->lin_idx[i] >= m->n_param || (m->lin_idx[i] >= m->nn_offset && m->lin_idx[i] < m->nn_offset + np)) return MID_NONE;
-        if (m->dtype == 1) return m->n_layers <= 4 ? MID_GENERIC_2_L4_F32 : MID_GENERIC_2_F32;
         // round 5: the scripts' own depth with EDITED widths / activations -- two or three hidden layers of width <= 8, linear output
         // layer -- on the lane-group kernels of the compiled instances (NetCfgRt: padded register copy of the weights, eight lanes per
         // trajectory) instead of one wavefront per trajectory
         if (narrow_ok && (m->n_layers == 3 || m->n_layers == 4) && m->act[m->n_layers - 1] == UDE_ACT_IDENTITY) {
             int wmax = 0;
             for (int l = 1; l < m->n_layers; ++l) wmax = m->dims[l] > wmax ? m->dims[l] : wmax;
-            if (wmax <= 5) return m->n_layers == 3 ? MID_LV_RT3_W5 : MID_LV_RT4_W5;   // five lanes per trajectory: the headline instance's layout
-            if (wmax <= 8) return m->n_layers == 3 ? MID_LV_RT3 : MID_LV_RT4;
+            const bool f32 = m->dtype == 1;
+            if (wmax <= 5) return m->n_layers == 3 ? (f32 ? MID_LV_RT3_W5_F32 : MID_LV_RT3_W5) : (f32 ? MID_LV_RT4_W5_F32 : MID_LV_RT4_W5);   // five lanes per trajectory: the headline instance's layout
+            if (wmax <= 8) return m->n_layers == 3 ? (f32 ? MID_LV_RT3_F32 : MID_LV_RT3) : (f32 ? MID_LV_RT4_F32 : MID_LV_RT4);
         }
+        if (m->dtype == 1) return m->n_layers <= 4 ? MID_GENERIC_2_L4_F32 : MID_GENERIC_2_F32;
         return m->n_layers <= 4 ? MID_GENERIC_2_L4 : MID_GENERIC_2;   // (<= 4 layers: the instance with half the stage storage)
     }
     // nn_ode with a pointwise reaction network that has no compiled instance: <= 4 layers of width <= 32, <= 768 parameters in all,
@@ -393,10 +394,14 @@ static int default_lanes(int mid, bool discrete) {
         case MID_LV_TRUE: return 1;
         case MID_LV_RT3_W5:
         case MID_LV_RT4_W5:
+        case MID_LV_RT3_W5_F32:
+        case MID_LV_RT4_W5_F32:
         case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
         case MID_LV_HUDSON:
         case MID_LV_RT3:
         case MID_LV_RT4:
+        case MID_LV_RT3_F32:
+        case MID_LV_RT4_F32:
         case MID_LV_HUDSON_F32: return 8;
         case MID_LV_TANH32: return 16;  // two hidden neurons per lane, four trajectories per wavefront, 253 registers = two wavefronts per SIMD.
                                         // Round 4 (32-term tree sums by the group's butterfly, parameter slots by input): 10k-trajectory gradient
@@ -437,7 +442,9 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
                                             "outside the runtime-shape fallbacks (LV / SEIR kinds: <= 8 layers of width <= 64; Fisher-KPP on <= 32 points: <= 4 layers of width <= 32, Float64)",
                     m->kind, m->dtype, m->n_layers);
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
-    if (G == 8 && (mid == MID_LV_RT3_W5 || mid == MID_LV_RT4_W5)) mid = mid == MID_LV_RT3_W5 ? MID_LV_RT3 : MID_LV_RT4;   // (an explicit lanes_per_traj = 8: the width-8 instance takes narrower chains too)
+    if (G == 8) {   // (an explicit lanes_per_traj = 8: the width-8 instance takes narrower chains too)
+        mid = mid == MID_LV_RT3_W5 ? MID_LV_RT3 : mid == MID_LV_RT4_W5 ? MID_LV_RT4 : mid == MID_LV_RT3_W5_F32 ? MID_LV_RT3_F32 : mid == MID_LV_RT4_W5_F32 ? MID_LV_RT4_F32 : mid;
+    }
     if ((mid == MID_SEIR_UDE || mid == MID_SEIR_NODE) && G == 16) G = 64;  // (16 = the lock-step backward kernel of grad_dev_impl; every other kernel of that model: one wavefront per trajectory)
     const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
     bool ok = false;
