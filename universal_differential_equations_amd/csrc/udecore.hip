@@ -834,8 +834,7 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         lsf_blocks = ls_blocks(c, N, lsf_per_cu);
         // more than one block per CU, but not enough full blocks for all of them: every CU gets the same number of (partly filled)
         // blocks -- the trajectories are dealt round-robin -- instead of some CUs two full blocks and the others one
-        static const bool balance = !getenv("UDE_LSF_NO_BALANCE");   // (timing experiments)
-        if (balance && lsf_per_cu > 1 && lsf_blocks > c->ncu && lsf_blocks < (int64_t)lsf_per_cu * c->ncu) lsf_blocks = (int64_t)lsf_per_cu * c->ncu;
+        if (lsf_per_cu > 1 && lsf_blocks > c->ncu && lsf_blocks < (int64_t)lsf_per_cu * c->ncu) lsf_blocks = (int64_t)lsf_per_cu * c->ncu;
         nwaves = lsf_blocks;          // one gradient row per BLOCK
     }
     const bool ckpt = o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED;
