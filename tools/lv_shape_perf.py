@@ -23,3 +23,11 @@ for lanes in (0, 8, 64):
     for _ in range(3):
         ens.loss_grad(th5); torch.cuda.synchronize()
     print("2-5-5-5-2 tanh (the scripts' widths, edited activations), lanes_per_traj", lanes or "default (5)", ": kernel ms", ens.kernel_ms())
+
+chain16 = models.Chain(models.Dense(2, 16, "tanh"), models.Dense(16, 16, "tanh"), models.Dense(16, 16, "tanh"), models.Dense(16, 2, "identity"))
+th16 = torch.tensor(0.1 * chain16.glorot_uniform(np.random.default_rng(7)), dtype=torch.float64, device=dev)
+for lanes in (0, 64):
+    ens = U.DeviceEnsemble(models.ude_dynamics(chain16), U.Tsit5(), (0.0, 3.0), t, u0_d, data=data, abstol=1e-6, reltol=1e-6, lanes_per_traj=lanes)
+    for _ in range(3):
+        ens.loss_grad(th16); torch.cuda.synchronize()
+    print("2-16-16-16-2 tanh, lanes_per_traj", lanes or "default (16)", ": kernel ms", ens.kernel_ms())

@@ -43,6 +43,8 @@ MODELS = [
     ("MID_LV_RT4", "LvUde<NetLvRt4,8>", 8, 1),
     ("MID_LV_RT3_W5", "LvUde<NetLvRt3W5,5>", 5, 1),
     ("MID_LV_RT4_W5", "LvUde<NetLvRt4W5,5>", 5, 1),
+    ("MID_LV_RT3_W16", "LvUde<NetLvRt3W16,16>", 16, 1),
+    ("MID_LV_RT4_W16", "LvUde<NetLvRt4W16,16>", 16, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,8>", 8, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,16>", 16, 1),
     ("MID_LV_TANH32", "LvUde<NetTanh32,32>", 32, 1),

@@ -385,7 +385,7 @@ struct CoopMlp {
     template <int l, class WS>
     static __device__ __forceinline__ real actF(const WS& th, real z) {
         if constexpr (N::act(l) == ACT_RT) {
-            const int a = th.rt.act[l];
+            const int a = rt_of(th).act[l];
             if (a == ACT_TANH) return rtanh(z);
             if (a == ACT_RBF) return rexp(-(z * z));
             if (a == ACT_RELU) return z > real(0) ? z : real(0);
@@ -395,7 +395,7 @@ struct CoopMlp {
     template <int l, class WS>
     static __device__ __forceinline__ real actB(const WS& th, real z, real a_) {
         if constexpr (N::act(l) == ACT_RT) {
-            const int a = th.rt.act[l];
+            const int a = rt_of(th).act[l];
             if (a == ACT_TANH) return rfma(-a_, a_, real(1));
             if (a == ACT_RBF) return (real(-2) * z) * a_;
             if (a == ACT_RELU) return z > real(0) ? real(1) : real(0);
@@ -405,7 +405,7 @@ struct CoopMlp {
     // (run-time shapes: is neuron j of layer l one of the true chain's?)
     template <int l, class WS>
     static __device__ __forceinline__ bool rt_valid(const WS& th, int j) {
-        if constexpr (N::RT) return j < th.rt.dim[l + 1];
+        if constexpr (N::RT) return j < rt_of(th).dim[l + 1];
         else { (void)th; (void)j; return true; }
     }
     template <class P>
@@ -437,20 +437,47 @@ struct CoopMlp {
     }
 
     // WS = const P* (weights read from LDS/global at every use) or WReg (register-resident copy)
+    // a run-time shape whose weights are read where they lie at every use (widths > 8: no register copy): the pointer and the true shape
+    struct PtrRt {
+        const real* p;
+        const RtInfo* rtp;
+    };
+    template <class MC>
+    static __device__ __forceinline__ void load_rt_info(RtInfo& rt, const MC& mc) {
+        int o = 0;
+        static_for<0, L>([&](auto lc) {
+            constexpr int l = lc;
+            rt.dim[l] = mc.dims[l]; rt.act[l] = mc.act[l]; rt.off[l] = o;
+            o += mc.dims[l] * mc.dims[l + 1] + mc.dims[l + 1];
+        });
+        rt.dim[L] = mc.dims[L];
+    }
     template <class WS>
     static constexpr bool ws_is_reg = std::is_same<WS, WReg>::value;
+    template <class WS>
+    static constexpr bool ws_is_rtptr = std::is_same<WS, PtrRt>::value;
+    template <class WS>
+    static __device__ __forceinline__ const RtInfo& rt_of(const WS& th) {
+        if constexpr (ws_is_rtptr<WS>) return *th.rtp;
+        else return th.rt;
+    }
 
     // parameter `idx` of a pointer-like weight source (the tree layers read theta in place; they are compiled for pointer sources
     // only -- the register copy holds rows, a tree layer wants the columns at the lane's inputs)
     template <class WS>
     static __device__ __forceinline__ real th_at(const WS& th, int idx) {
-        if constexpr (ws_is_reg<WS>) { (void)th; (void)idx; return real(0); }
+        if constexpr (ws_is_reg<WS> || ws_is_rtptr<WS>) { (void)th; (void)idx; return real(0); }
         else return (real)th[idx];
     }
 
     template <int I, int K, class WS>
     static __device__ __forceinline__ real last_at(const WS& th) {   // W_{L-1}[I, K]; K = dim(L-1): the bias of output I
         if constexpr (ws_is_reg<WS>) return th.last[I][K];
+        else if constexpr (ws_is_rtptr<WS>) {
+            const RtInfo& rt = *th.rtp;
+            const int inr = rt.dim[L - 1];
+            return K == N::dim(L - 1) ? th.p[rt.off[L - 1] + inr * N::dim(L) + I] : (K < inr ? th.p[rt.off[L - 1] + I + K * N::dim(L)] : real(0));
+        }
         else return (real)th[N::off(L - 1) + I + K * N::dim(L)];
     }
 
@@ -461,7 +488,7 @@ struct CoopMlp {
         static_for<0, L>([&](auto lc) {
             constexpr int l = lc;
             constexpr int in = N::dim(l), out = N::dim(l + 1);
-            if constexpr (l > 0 && tree_dot(in, out) && tree_ok(in) && !ws_is_reg<WS>) {
+            if constexpr (l > 0 && tree_dot(in, out) && tree_ok(in) && !ws_is_reg<WS> && !N::RT) {
                 // a tree layer (2-32-2's output layer): every lane multiplies ITS inputs (the activations it produced in the layer
                 // below) with its weights, the group's butterfly does the rest: all `out` results arrive replicated
                 static_assert(own(l - 1) * G == in && own(l) == 1 && out <= G, "tree layer: inputs dealt evenly, one output neuron per lane at most");
@@ -504,6 +531,13 @@ struct CoopMlp {
                 if constexpr (ws_is_reg<WS>) {
                     static_for<0, in>([&](auto k) { acc = rfma(th.row[l][m][k], c.a[l][k], acc); });
                     acc += th.row[l][m][in];
+                } else if constexpr (ws_is_rtptr<WS>) {
+                    const RtInfo& rt = *th.rtp;
+                    const int inr = rt.dim[l], outr = rt.dim[l + 1];
+                    const int jr = j < outr ? j : 0;
+                    const real* W = th.p + rt.off[l];
+                    static_for<0, in>([&](auto k) { acc = rfma((int)decltype(k)::value < inr ? W[jr + (int)decltype(k)::value * outr] : real(0), c.a[l][k], acc); });
+                    acc += W[inr * outr + jr];
                 } else {
                     static_for<0, in>([&](auto k) { acc = rfma((real)th[N::off(l) + jj + k * out], c.a[l][k], acc); });
                     acc += (real)th[N::off(l) + in * out + jj];
@@ -513,7 +547,7 @@ struct CoopMlp {
             });
             // (the activations feed a tree layer above: it reads them where they are -- no gather)
             // (... unless its parameter slots go by input, KMAJ: then nothing else reads the replicated copy)
-            if constexpr (!(KMAJ && l + 2 == L && tree_dot(out, N::dim(L)) && tree_ok(out) && !ws_is_reg<WS>)) allgather<out>(c.gb, r, c.ao[l], c.a[l + 1]);
+            if constexpr (!(KMAJ && l + 2 == L && tree_dot(out, N::dim(L)) && tree_ok(out) && !ws_is_reg<WS> && !N::RT)) allgather<out>(c.gb, r, c.ao[l], c.a[l + 1]);
             }
         });
         static_for<0, N::dim(L)>([&](auto k) { y[k] = c.a[L][k]; });
@@ -554,6 +588,12 @@ struct CoopMlp {
                     gp = 0.0;  // column jj of the next layer's W (contiguous in theta)
                     if constexpr (ws_is_reg<WS>) {
                         static_for<0, out2>([&](auto i) { gp = rfma(th.col[l][m][i], dall[i], gp); });
+                    } else if constexpr (ws_is_rtptr<WS>) {
+                        const RtInfo& rt = *th.rtp;
+                        const int outr = rt.dim[l + 1], out2r = rt.dim[l + 2];
+                        const int jr = j < outr ? j : 0;
+                        const real* W2 = th.p + rt.off[l + 1];
+                        static_for<0, out2>([&](auto i) { gp = rfma((int)decltype(i)::value < out2r ? W2[(int)decltype(i)::value + jr * out2r] : real(0), dall[i], gp); });
                     } else {
                         static_for<0, out2>([&](auto i) {
                             gp = rfma((real)th[N::off(l + 1) + i + jj * out2], dall[i], gp);
@@ -583,7 +623,7 @@ struct CoopMlp {
             if constexpr (l > 0) {
                 // (the output layer is linear: its deltas ARE the replicated output cotangent, gy[j] * 1 -- dall holds them already)
                 if constexpr (l < L - 1) allgather<out>(c.gb, r, down, dall);
-            } else if constexpr (tree_dot(out, in) && tree_ok(out) && !ws_is_reg<WS>) {
+            } else if constexpr (tree_dot(out, in) && tree_ok(out) && !ws_is_reg<WS> && !N::RT) {
                 // input cotangent as a tree (wide-dot rule: `out` = 32 or 64 terms, `in` < 16 results): products where the deltas are
                 static_assert(own(0) * G == out, "tree: the first layer's neurons are dealt evenly");
                 static_for<0, in>([&](auto k) {
@@ -602,6 +642,11 @@ struct CoopMlp {
                     real s = 0.0;
                     if constexpr (ws_is_reg<WS>) {
                         static_for<0, out>([&](auto j) { s = rfma(th.w0[j + k * out], d0[j], s); });
+                    } else if constexpr (ws_is_rtptr<WS>) {
+                        const RtInfo& rt = *th.rtp;
+                        const int outr = rt.dim[1];
+                        const real* W0 = th.p + rt.off[0];
+                        static_for<0, out>([&](auto j) { s = rfma((int)decltype(j)::value < outr ? W0[(int)decltype(j)::value + (int)decltype(k)::value * outr] : real(0), d0[j], s); });
                     } else {
                         static_for<0, out>([&](auto j) { s = rfma((real)th[N::off(0) + j + k * out], d0[j], s); });
                     }

@@ -121,8 +121,8 @@ struct LvUde : LinearTheta {
             c.lin[i] = mc.lin_idx[i] >= 0 ? (real)mc.lin_sign[i] * th_lds[mc.lin_idx[i]] : (real)mc.lin_const[i];
             c.lead_on[i] = (mc.lin_idx[i] >= 0 && r == 0) ? (real)mc.lin_sign[i] : real(0);
         }
-        static_assert(!Net::RT || REGW, "run-time shapes live in the register copy of the weights");
-        if constexpr (Net::RT) Mlp::load_weights_rt(c.nn, r, c.w, mc);
+        if constexpr (Net::RT && REGW) Mlp::load_weights_rt(c.nn, r, c.w, mc);          // run-time shape, padded register copy
+        else if constexpr (Net::RT) Mlp::load_rt_info(c.w.rt, mc);                     // run-time shape, weights read where they lie (widths > 8)
         else if constexpr (REGW) Mlp::load_weights(c.nn, r, c.w);
     }
     static __device__ __forceinline__ void rhs(const Ctx& c, const real* u, real* du) {
@@ -130,6 +130,7 @@ struct LvUde : LinearTheta {
         cache.gb = c.gb;
         real y[2];
         if constexpr (REGW) Mlp::forward(c.w, c.r, u, cache, y);
+        else if constexpr (Net::RT) Mlp::forward(typename Mlp::PtrRt{c.nn, &c.w.rt}, c.r, u, cache, y);
         else Mlp::forward(c.nn, c.r, u, cache, y);
         du[0] = rfma(c.lin[0], u[0], y[0]);
         du[1] = rfma(c.lin[1], u[1], y[1]);
@@ -143,6 +144,10 @@ struct LvUde : LinearTheta {
         if constexpr (REGW) {
             Mlp::forward(c.w, c.r, u, cache, y);
             Mlp::template vjp<WANT_PARAM>(c.w, c.r, cache, lam, gx, g);
+        } else if constexpr (Net::RT) {
+            const typename Mlp::PtrRt pr{c.nn, &c.w.rt};
+            Mlp::forward(pr, c.r, u, cache, y);
+            Mlp::template vjp<WANT_PARAM>(pr, c.r, cache, lam, gx, g);
         } else {
             Mlp::forward(c.nn, c.r, u, cache, y);
             Mlp::template vjp<WANT_PARAM>(c.nn, c.r, cache, lam, gx, g);

@@ -102,6 +102,9 @@ using NetLvRt3 = NetCfgRt<2, 2, 3, 8>;
 using NetLvRt4 = NetCfgRt<2, 2, 4, 8>;
 // ... and of width <= 5 on FIVE lanes (the headline instance's layout: twelve trajectories per wavefront, the 10k ensemble in one round) --
 // what an edit of the activations alone needs
+// ... and of width <= 16 on SIXTEEN lanes (four trajectories per wavefront), the weights read from the block's LDS copy of theta at every use
+using NetLvRt3W16 = NetCfgRt<2, 2, 3, 16>;
+using NetLvRt4W16 = NetCfgRt<2, 2, 4, 16>;
 using NetLvRt3W5 = NetCfgRt<2, 2, 3, 5>;
 using NetLvRt4W5 = NetCfgRt<2, 2, 4, 5>;
 
@@ -119,7 +122,8 @@ enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, 
        MID_KPP_GENERIC_32 /* nn_ode with any pointwise reaction chain of <= 4 layers, width <= 32 (ude_model_kpp_generic.h) */,
        MID_LV_RT3, MID_LV_RT4 /* LV kind, run-time shape 2 -> (2 / 3 hidden layers of width <= 8, any activation) -> 2 on 8-lane groups (NetCfgRt) */,
        MID_LV_RT3_W5, MID_LV_RT4_W5 /* ... of width <= 5 on 5-lane groups */,
-       MID_LV_RT3_F32, MID_LV_RT4_F32, MID_LV_RT3_W5_F32, MID_LV_RT4_W5_F32 /* ... as Float32 problems (hudson_bay.jl:77-104 with an edited FastChain) */ };
+       MID_LV_RT3_F32, MID_LV_RT4_F32, MID_LV_RT3_W5_F32, MID_LV_RT4_W5_F32 /* ... as Float32 problems (hudson_bay.jl:77-104 with an edited FastChain) */,
+       MID_LV_RT3_W16, MID_LV_RT4_W16 /* ... of width <= 16 on 16-lane groups, weights read from the LDS copy of theta (Float64) */ };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88

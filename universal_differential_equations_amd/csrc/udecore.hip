@@ -335,6 +335,7 @@ static int generic_id(const ude_model_desc* m, bool narrow_ok = true) {
             const bool f32 = m->dtype == 1;
             if (wmax <= 5) return m->n_layers == 3 ? (f32 ? MID_LV_RT3_W5_F32 : MID_LV_RT3_W5) : (f32 ? MID_LV_RT4_W5_F32 : MID_LV_RT4_W5);   // five lanes per trajectory: the headline instance's layout
             if (wmax <= 8) return m->n_layers == 3 ? (f32 ? MID_LV_RT3_F32 : MID_LV_RT3) : (f32 ? MID_LV_RT4_F32 : MID_LV_RT4);
+            if (wmax <= 16 && !f32) return m->n_layers == 3 ? MID_LV_RT3_W16 : MID_LV_RT4_W16;   // sixteen lanes, weights from the LDS copy of theta
         }
         if (m->dtype == 1) return m->n_layers <= 4 ? MID_GENERIC_2_L4_F32 : MID_GENERIC_2_F32;
         return m->n_layers <= 4 ? MID_GENERIC_2_L4 : MID_GENERIC_2;   // (<= 4 layers: the instance with half the stage storage)
@@ -403,6 +404,8 @@ static int default_lanes(int mid, bool discrete) {
         case MID_LV_RT3_F32:
         case MID_LV_RT4_F32:
         case MID_LV_HUDSON_F32: return 8;
+        case MID_LV_RT3_W16:
+        case MID_LV_RT4_W16:
         case MID_LV_TANH32: return 16;  // two hidden neurons per lane, four trajectories per wavefront, 253 registers = two wavefronts per SIMD.
                                         // Round 4 (32-term tree sums by the group's butterfly, parameter slots by input): 10k-trajectory gradient
                                         // 1.98 ms against 2.27 ms with 8 lanes and 2.28 ms with 32; 16 lanes stay ahead from 5k to 40k trajectories
