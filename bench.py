@@ -45,7 +45,7 @@ HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 #         stream SURVEY.md 8(d) C3 names ("HBM in parity mode"); their flop fraction is reported beside it (`flop_frac`)
 # the headline command at other fillings of the chip / with the wavefront-per-trajectory layout: name -> (trajectories, lanes per trajectory)
 LV_VARIANTS = {"lv_sat40k": (40000, 0), "lv_sat160k": (160000, 0), "lv_wave64": (10000, 64)}
-BOUND = {"lv_shape8": "valu", "seir_shape63": "hbm", "seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
+BOUND = {"lv_tanh5": "valu", "lv_shape8": "valu", "seir_shape63": "hbm", "seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
 
 
 # `roofline.traffic` is NOT measured inside this run (PMC passes cannot run inside a timed bench): it is read from the committed
@@ -397,6 +397,8 @@ def quick_measure(name, device, steps=5, warmup=1):
     lanes, n_lv = 0, 10000
     if name == "lv_tanh32":
         wl, net = "lv", "tanh32"
+    elif name == "lv_tanh5":
+        wl, net = "lv", "tanh5"    # configs[1] with the ACTIVATIONS edited (rbf -> tanh), the scripts' widths: the five-lane run-time-shape instance
     elif name == "lv_shape8":
         wl, net = "lv", "shape8"   # configs[1] with an EDITED network, 2-8-8-8-2 tanh: no compiled instance, the run-time-shape lane-group instance
     elif name == "lv_discrete":
@@ -419,6 +421,10 @@ def quick_measure(name, device, steps=5, warmup=1):
         if net == "tanh32":
             f_lv = models.ude_dynamics(models.tanh32_chain())
             theta_h = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(7))
+        if net == "tanh5":
+            chain5 = models.Chain(models.Dense(2, 5, "tanh"), models.Dense(5, 5, "tanh"), models.Dense(5, 5, "tanh"), models.Dense(5, 2, "identity"))
+            f_lv = models.ude_dynamics(chain5)
+            theta_h = 0.3 * chain5.glorot_uniform(np.random.default_rng(7))
         if net == "shape8":
             chain8 = models.Chain(models.Dense(2, 8, "tanh"), models.Dense(8, 8, "tanh"), models.Dense(8, 8, "tanh"), models.Dense(8, 2, "identity"))
             f_lv = models.ude_dynamics(chain8)
@@ -426,6 +432,7 @@ def quick_measure(name, device, steps=5, warmup=1):
         ens = U.DeviceEnsemble(f_lv, U.Tsit5(), (0.0, 3.0), t, u0_d, data=data, abstol=1e-6, reltol=1e-6, sensealg=SENSE_OBJ(U, sense), lanes_per_traj=lanes)
         desc = "configs[1] with %s" % ("the 2-32-2 tanh net (BASELINE's literal '2-layer tanh MLP')" if net == "tanh32" else
                                       "the network edited to 2-8-8-8-2 tanh (no compiled instance: the run-time-shape instance of the lane-group kernels, 8 lanes per trajectory)" if net == "shape8" else
+                                      "the activations edited to tanh, 2-5-5-5-2 (no compiled instance: the run-time-shape instance on 5 lanes per trajectory, the headline layout)" if net == "tanh5" else
                                       "the discretise-then-optimise gradient"
                                       if sense == "discrete" else "%d trajectories per GPU, %s" % (N, "64 lanes per trajectory (one wavefront per trajectory)" if lanes == 64
                                                                                                     else "5 lanes per trajectory (the headline kernel)"))
@@ -458,11 +465,11 @@ def quick_measure(name, device, steps=5, warmup=1):
     ms = timed_steps(one, steps)
     f, b = float(np.median([k[0] for k in kms])), float(np.median([k[1] for k in kms]))
     nf_fwd, nf_bwd = int(ens.stats[:, 0].sum().item()), int(ens.stats[:, 4].sum().item())
-    flop_key = "lv_tanh32" if name == "lv_tanh32" else "lv_shape8" if name == "lv_shape8" else wl
+    flop_key = "lv_tanh32" if name == "lv_tanh32" else "lv_shape8" if name == "lv_shape8" else wl   # (lv_tanh5: the headline's 2-5-5-5-2 count)
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
     kern = "dadj_kernel" if sense == "discrete" else "seirlf::seir_lsf_adj_kernel" if name == "seir_fast" else "nodelf::node_lsf_adj_kernel" if name == "node_fast" else "seirls2::seir_ls2_adj_kernel" if wl == "seir" else "nodels2::node_ls2_adj_kernel" if wl == "node" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete", "seir_fast", "node_fast") else wl
-    if name in LV_VARIANTS or name in ("seir_shape63", "lv_shape8"):
+    if name in LV_VARIANTS or name in ("seir_shape63", "lv_shape8", "lv_tanh5"):
         pm = "none"    # (no committed counter pass for these commands)
     out = {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
            "fwd_kernel_ms": f, "bound": BOUND[name], "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
@@ -707,7 +714,7 @@ def main():
             del ens
             torch.cuda.empty_cache()
             others = {}
-            for name in ("seir", "seir_fast", "seir_shape63", "node_fast", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_shape8", "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64"):
+            for name in ("seir", "seir_fast", "seir_shape63", "node_fast", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_tanh5", "lv_shape8", "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64"):
                 try:
                     others[name] = quick_measure(name, device)
                 except Exception as e:  # a failing secondary workload must not take the headline line with it
