@@ -186,6 +186,56 @@ def test_lv_kind_edited_network_on_the_lane_group_kernels(golden, case):
         assert_bitwise(r.grad_theta[j], ref["grad_theta"], "member %d dL/dtheta" % j)
 
 
+@pytest.mark.parametrize("dims,nx", [([1, 16, 16, 16, 1], 1024), ([1, 8, 12, 5, 1], 300), ([1, 1, 1, 1, 1], 33), ([1, 10, 16, 10, 1], 257), ([1, 3, 2, 16, 1], 64)],
+                         ids=lambda v: "-".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_fisher_kpp_runtime_shape_reaction_network_on_large_grids(dims, nx):
+    """round 5: `nn_ode` (Fisher-KPP-CNN.jl:92-126) with an EDITED reaction network 1 -> a -> b -> c -> 1 (tanh hidden layers of width <= 16) on
+    grids of 33 .. 1024 points: the run-time-shape instance of the 1024-point matrix-core kernel (KppUdeW over NetCfgRt: operand tables
+    padded to width 16, block sums written to the true chain's parameter indices) -- forward solve, right-hand side, interpolating
+    adjoint, discrete sweep, per-member parameters; per PDE the oracle's bits (a single PDE: every gradient entry)."""
+    acts = ["tanh", "tanh", "tanh", "identity"]
+    rng = np.random.default_rng(sum(dims) + nx)
+    chain = chain_of(dims, acts)
+    f = models.nn_ode(nx, chain)
+    assert supported(f) == 1 and supported(f, alg=1) == -2       # (Tsit5; the Vern7 stage storage does not fit the LDS next to the padded tiles)
+    om = O.kpp_ude(nx, tuple(dims), tuple(acts))
+    th = models.kpp_theta(chain, rng)
+    for N in (1, 2):
+        u0 = np.clip(models.rho0(26)[None, :] * (1 + 0.1 * rng.uniform(-1, 1, (N, 1))) + 0.01 * rng.uniform(0, 1, (N, 26)), 0, None)
+        u0 = np.tile(u0, (1, 40))[:, :nx]
+        tf = 1.0
+        t = np.linspace(0.0, tf, 6)
+        data = rng.uniform(0.0, 1.0, (N, len(t), nx))
+        ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, tf), th), u0)
+        sol = U.solve(ens, U.Tsit5(), saveat=t)
+        out, st, rc = O.solve_ensemble(om, O.opts(O.TSIT5), u0, [0.0, tf], th, t)
+        assert (rc == 0).all()
+        assert_bitwise(sol.stats[:, :4], st[:, :4], "forward counts %s nx %d" % (dims, nx))
+        assert_bitwise(sol.u, out, "forward states")
+        assert_bitwise(U.rhs(f, u0, th), np.array([O.rhs(om, th, u) for u in u0]), "rhs")
+        for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1)):
+            r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t, sensealg=sense)
+            ref = O.loss_grad_ensemble(om, O.opts(O.TSIT5, sensealg=osense), u0, [0.0, tf], th, t, data, nthreads=2)
+            what = "%s nx %d N %d sense %d" % (dims, nx, N, osense)
+            assert (r.retcode == 0).all(), what
+            assert_bitwise(r.stats[:, [0, 1, 2, 4, 5, 6]], ref["stats"][:, [0, 1, 2, 4, 5, 6]], what)
+            assert_bitwise(r.u, ref["u"], what)
+            assert_bitwise(r.grad_u0, ref["grad_u0"], what)
+            if N == 1:
+                assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta " + what)
+            else:
+                gn = np.linalg.norm(ref["grad_theta"])
+                assert gn > 0 and np.linalg.norm(r.grad_theta - ref["grad_theta"]) < REL_GRAD_SUM * gn, what
+    # per-member parameters
+    thetas = np.stack([models.kpp_theta(chain, rng) for _ in range(2)])
+    ens = U.EnsembleProblem(U.ODEProblem(f, u0[0], (0.0, tf), thetas[0]), u0, ps=thetas)
+    r = U.loss_and_gradient(ens, U.Tsit5(), data, saveat=t)
+    for j in range(2):
+        ref = O.loss_grad_ensemble(om, O.opts(O.TSIT5), u0[j:j + 1], [0.0, tf], thetas[j], t, data[j:j + 1])
+        assert_bitwise(r.stats[j], ref["stats"][0], "member %d counts" % j)
+        assert_bitwise(r.grad_theta[j], ref["grad_theta"], "member %d dL/dtheta" % j)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_fuzz_discrete_sweep_random_shapes(golden, seed):
     """round 4: `sensealg = ForwardDiffSensitivity()` -- what scenario_1.jl:86 / scenario_2.jl:108 request -- for ANY chain: the

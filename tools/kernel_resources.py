@@ -40,6 +40,7 @@ ROWS = [
     ("node adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_node_lsf.log", "node_lsf_adj_kernel<Vern7Tab>*"),
     ("kpp forward (1024 points)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "fwd_kernel<*false, double>"),
     ("kpp adjoint (1024 points)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
+    ("kpp adjoint (1024 points), run-time-shape reaction network", "ude_inst_kpp_rt_1024_g256_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("hjb forward", "ude_hjb.log", "hjb_fwd_kernel*"),
     ("hjb backward", "ude_hjb.log", "hjb_bwd_kernel*"),
 ]

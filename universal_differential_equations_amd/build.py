@@ -71,6 +71,8 @@ MODELS = [
     ("MID_KPP_GENERIC_32", "KppGenericUde<32,1>", 32, 1, 32, None, ("-DUDE_INST_KPPGEN=1",)),
     ("MID_KPP_UDE_1024", "KppUde<NetKpp,64,16>", 64, 1, 64, ("UDE_ALG_TSIT5",)),
     ("MID_KPP_UDE_1024", "KppUdeW<NetKpp>", 256, 1, 256),
+    # run-time shape of the reaction network on the large grids (three tanh layers of width <= 16): padded operand tables
+    ("MID_KPP_RT_1024", "KppUdeW<NetKppRt16>", 256, 1, 256, ("UDE_ALG_TSIT5",)),
     # Float32 problems (-DUDE_F32: the same kernels with real = float)
     ("MID_LV_HUDSON_F32", "LvUde<NetHudson,8>", 8, 1, 64, None, ("-DUDE_F32=1",)),
     ("MID_LV_RT3_F32", "LvUde<NetLvRt3,8>", 8, 1, 64, None, ("-DUDE_F32=1",)),

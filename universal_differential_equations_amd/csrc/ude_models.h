@@ -876,10 +876,15 @@ struct KppUdeW : LinearTheta {
     static constexpr bool STATE_DISTRIBUTED = true;
     static constexpr int L = Net::L;
     static constexpr int NPT = G * PPL;
+    // a run-time shape (Net::RT, round 5: NetCfgRt<1, 1, 4, 16> -- any reaction chain 1 -> a -> b -> c -> 1 with tanh hidden layers of width
+    // <= 16 on the large grids): the compile-time shape is the padded one, init() builds the operand tables from the true chain (zeros
+    // beyond its widths: a padded unit has z = 0, a = tanh 0 = 0, delta = 0), the block sums go to the true chain's theta indices.
+    // The hidden activations are tanh by contract (udecore.hip checks the descriptor).
+    static constexpr int hact(int l) { return Net::RT ? (l + 1 < Net::L ? ACT_TANH : ACT_IDENTITY) : Net::act(l); }
     static constexpr bool acts_ok() {  // the reverse sweep rebuilds act' from the activation VALUE (tanh only)
         for (int l = 0; l + 1 < L; ++l)
-            if (Net::act(l) != ACT_TANH) return false;
-        return Net::act(L - 1) == ACT_IDENTITY;
+            if (hact(l) != ACT_TANH) return false;
+        return hact(L - 1) == ACT_IDENTITY;
     }
     static_assert(acts_ok(), "KppUdeW: tanh hidden layers (tanh(0) == 0 keeps the padding rows at zero), linear output");
     typedef double v4d __attribute__((ext_vector_type(4)));
@@ -912,6 +917,7 @@ struct KppUdeW : LinearTheta {
         lds_t *urow, *lrow, *orow, *tile, *part;
         double w1, w2, w3, D0;
         int r, lane, w, l16, kq, n, so, d0o, nno;
+        int rdim[Net::RT ? Net::L + 1 : 1], roff[Net::RT ? Net::L : 1], np;   // run-time shape: true widths, theta offsets of the layers; parameter count
     };
     static __device__ __forceinline__ void init(Ctx& c, double* th_lds, double* scratch, double*, int, const ModelConsts& mc, int r, const double* = nullptr) {
         const double* th = th_lds;   // (a generic pointer: the block's LDS copy, or -- UDE_PT_THETA -- the member's own column in HBM)
@@ -923,23 +929,35 @@ struct KppUdeW : LinearTheta {
         c.n = mc.n_state; c.so = mc.stencil_offset; c.d0o = mc.d0_offset; c.nno = mc.nn_offset;
         c.w1 = th[c.so]; c.w2 = th[c.so + 1]; c.w3 = th[c.so + 2]; c.D0 = th[c.d0o];
         const double* nn = th + mc.nn_offset;
+        c.np = mc.n_param;
+        if constexpr (Net::RT) {
+            int o = 0;
+            static_for<0, L>([&](auto lc) {
+                constexpr int l = lc;
+                c.rdim[l] = mc.dims[l]; c.roff[l] = o;
+                o += mc.dims[l] * mc.dims[l + 1] + mc.dims[l + 1];
+            });
+            c.rdim[L] = mc.dims[L];
+        }
         static_for<0, L>([&](auto lc) {
             constexpr int l = lc;
-            constexpr int in = Net::dim(l), out = Net::dim(l + 1);
-            static_for<0, MT(out)>([&](auto m) {
-                static_for<0, KS(in)>([&](auto s) {  // forward: A[i][k] = W_l[i][k]
+            constexpr int inp = Net::dim(l), outp = Net::dim(l + 1);   // (padded) compile-time widths: the tile structure
+            int in = inp, out = outp, off = Net::off(l);               // the widths and the offset theta is read through
+            if constexpr (Net::RT) { in = c.rdim[l]; out = c.rdim[l + 1]; off = c.roff[l]; }
+            static_for<0, MT(outp)>([&](auto m) {
+                static_for<0, KS(inp)>([&](auto s) {  // forward: A[i][k] = W_l[i][k]
                     const int i = c.l16 + 16 * decltype(m)::value, k = 4 * decltype(s)::value + c.kq;
-                    c.af[af_off(l) + decltype(m)::value * KS(in) + decltype(s)::value] = (i < out && k < in) ? (double)nn[Net::off(l) + i + k * out] : 0.0;
+                    c.af[af_off(l) + decltype(m)::value * KS(inp) + decltype(s)::value] = (i < out && k < in) ? (double)nn[off + i + k * out] : 0.0;
                 });
                 static_for<0, 4>([&](auto rr) {
                     const int i = c.kq + 4 * decltype(rr)::value + 16 * decltype(m)::value;
-                    c.bs[bs_off(l) + 4 * decltype(m)::value + decltype(rr)::value] = i < out ? (double)nn[Net::off(l) + in * out + i] : 0.0;
+                    c.bs[bs_off(l) + 4 * decltype(m)::value + decltype(rr)::value] = i < out ? (double)nn[off + in * out + i] : 0.0;
                 });
             });
-            static_for<0, MT(in)>([&](auto m) {
-                static_for<0, KS(out)>([&](auto s) {  // backward: A[i][k] = W_l[k][i]
+            static_for<0, MT(inp)>([&](auto m) {
+                static_for<0, KS(outp)>([&](auto s) {  // backward: A[i][k] = W_l[k][i]
                     const int i = c.l16 + 16 * decltype(m)::value, k = 4 * decltype(s)::value + c.kq;
-                    c.ab[ab_off(l) + decltype(m)::value * KS(out) + decltype(s)::value] = (i < in && k < out) ? (double)nn[Net::off(l) + k + i * out] : 0.0;
+                    c.ab[ab_off(l) + decltype(m)::value * KS(outp) + decltype(s)::value] = (i < in && k < out) ? (double)nn[off + k + i * out] : 0.0;
                 });
             });
         });
@@ -963,7 +981,7 @@ struct KppUdeW : LinearTheta {
                     constexpr int r0 = 4 * decltype(rr)::value + 16 * decltype(m)::value;  // first neuron of this register
                     if constexpr (r0 < out) {
                         const double z = d[decltype(rr)::value] + c.bs[bs_off(l) + 4 * decltype(m)::value + decltype(rr)::value];
-                        if constexpr (l + 1 < L) act[l + 1][4 * decltype(m)::value + decltype(rr)::value] = act_fwd<Net::act(l)>(z);
+                        if constexpr (l + 1 < L) act[l + 1][4 * decltype(m)::value + decltype(rr)::value] = act_fwd<hact(l)>(z);
                         else if constexpr (r0 == 0) y = z;
                     } else if constexpr (l + 1 < L) {
                         act[l + 1][4 * decltype(m)::value + decltype(rr)::value] = 0.0;
@@ -1055,7 +1073,7 @@ struct KppUdeW : LinearTheta {
                         constexpr int q = 4 * decltype(m)::value + decltype(rr)::value;
                         constexpr int r0 = 4 * decltype(rr)::value + 16 * decltype(m)::value;
                         if constexpr (l > 0) {
-                            if constexpr (r0 < in) dprev[q] = gq[decltype(rr)::value] * act_bwd<Net::act(l - 1)>(0.0, act[l][q]);
+                            if constexpr (r0 < in) dprev[q] = gq[decltype(rr)::value] * act_bwd<hact(l - 1)>(0.0, act[l][q]);
                             else dprev[q] = 0.0;
                         } else if constexpr (q == 0) {
                             gxi = gq[0];
@@ -1135,6 +1153,10 @@ struct KppUdeW : LinearTheta {
                         const int j = l16 + 16 * decltype(nn)::value;
                         static_for<0, 4>([&](auto rr) {
                             const int ii = kq + 4 * decltype(rr)::value + 16 * decltype(m)::value;
+                            if constexpr (Net::RT) {   // (the bias column of the padded shape is column `in`; the true chain's weights are the columns j < its width)
+                                const int inr = c.rdim[l], outr = c.rdim[l + 1];
+                                if (ii < outr && (j < inr || j == in)) prow[c.nno + c.roff[l] + (j < inr ? ii + j * outr : inr * outr + ii)] = acc[ai][decltype(rr)::value];
+                            } else
                             if (ii < out && j <= in) prow[c.nno + Net::off(l) + (j < in ? ii + j * out : in * out + ii)] = acc[ai][decltype(rr)::value];
                         });
                     });
@@ -1146,7 +1168,7 @@ struct KppUdeW : LinearTheta {
             static_for<0, NSL>([&](auto s) {
                 const int p = c.r + G * decltype(s)::value;
                 double v = 0.0;
-                if (p < NP) {
+                if (p < (Net::RT ? c.np : NP)) {
                     v = c.part[p];
                     static_for<1, NWV>([&](auto w) { v += c.part[decltype(w)::value * TILE + p]; });
                     if (p >= c.so && p < c.so + 3) v = c.D0 * v;

@@ -123,10 +123,12 @@ enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, 
        MID_LV_RT3, MID_LV_RT4 /* LV kind, run-time shape 2 -> (2 / 3 hidden layers of width <= 8, any activation) -> 2 on 8-lane groups (NetCfgRt) */,
        MID_LV_RT3_W5, MID_LV_RT4_W5 /* ... of width <= 5 on 5-lane groups */,
        MID_LV_RT3_F32, MID_LV_RT4_F32, MID_LV_RT3_W5_F32, MID_LV_RT4_W5_F32 /* ... as Float32 problems (hudson_bay.jl:77-104 with an edited FastChain) */,
-       MID_LV_RT3_W16, MID_LV_RT4_W16 /* ... of width <= 16 on 16-lane groups, weights read from the LDS copy of theta (Float64) */ };
+       MID_LV_RT3_W16, MID_LV_RT4_W16 /* ... of width <= 16 on 16-lane groups, weights read from the LDS copy of theta (Float64) */,
+       MID_KPP_RT_1024 /* nn_ode on 33 .. 1024 points with any reaction chain 1 -> a -> b -> c -> 1, tanh hidden layers of width <= 16 (KppUdeW over NetCfgRt) */ };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96
 using NetKppS3 = NetCfg<IntList<1, 5, 5, 5, 1>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, ACT_IDENTITY>>;      // scenario_3.jl:83-88
+using NetKppRt16 = NetCfgRt<1, 1, 4, 16>;   // run-time shape of the reaction network on the large grids: three tanh layers of width <= 16
 using NetKppSmall = NetCfg<IntList<1, 3, 1>, IntList<ACT_TANH, ACT_IDENTITY>>;                        // Fisher-KPP-CNN-Small.jl:89-94 (15 parameters)
 using NetKppSmall1 = NetCfg<IntList<1, 1, 1>, IntList<ACT_TANH, ACT_IDENTITY>>;                       // n_weights = 1 (:88, timing log :343-391)
 using NetKppSmall2 = NetCfg<IntList<1, 2, 1>, IntList<ACT_TANH, ACT_IDENTITY>>;                       // n_weights = 2

@@ -342,6 +342,12 @@ static int generic_id(const ude_model_desc* m, bool narrow_ok = true) {
     }
     // nn_ode with a pointwise reaction network that has no compiled instance: <= 4 layers of width <= 32, <= 768 parameters in all,
     // theta = [NN; w1 w2 w3 unused; D0] (Fisher-KPP-CNN.jl:100-109), grids of 3 .. 32 points, Float64
+    // ... and on the LARGE grids (33 .. 1024 points) a chain 1 -> a -> b -> c -> 1 with tanh hidden layers of width <= 16: the run-time-shape
+    // instance of the matrix-core kernel of the 1024-point instance (KppUdeW over NetCfgRt; Tsit5: the Vern7 stage storage does not fit)
+    if (m->kind == UDE_KIND_KPP_UDE && m->dtype == 0 && in == 1 && out == 1 && m->n_layers == 4 && m->nn_offset == 0 && m->n_state > 32 &&
+        m->n_state <= 1024 && m->n_param == np + 5 && m->stencil_offset == np && m->d0_offset == np + 4 && m->dims[1] <= 16 && m->dims[2] <= 16 &&
+        m->dims[3] <= 16 && m->act[0] == UDE_ACT_TANH && m->act[1] == UDE_ACT_TANH && m->act[2] == UDE_ACT_TANH && m->act[3] == UDE_ACT_IDENTITY)
+        return MID_KPP_RT_1024;
     if (m->kind == UDE_KIND_KPP_UDE && m->dtype == 0 && in == 1 && out == 1 && m->n_layers <= 4 && m->nn_offset == 0 && m->n_state >= 3 &&
         m->n_state <= 32 && m->n_param == np + 5 && m->n_param <= 768 && m->stencil_offset == np && m->d0_offset == np + 4) {
         for (int l = 0; l <= m->n_layers; ++l)
@@ -428,6 +434,7 @@ static int default_lanes(int mid, bool discrete) {
         case MID_KPP_S3_32_F32:
         case MID_KPP_GENERIC_32: return 32;
         case MID_KPP_TRUE_1024: return 64;
+        case MID_KPP_RT_1024:
         case MID_KPP_UDE_1024: return 256;  // 4 wavefronts per PDE
     }
     return 1;
@@ -442,7 +449,7 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
     }
     if (mid == MID_NONE)
         return fail(c, UDE_ERR_UNSUPPORTED, "no kernel for model kind=%d dtype=%d n_layers=%d: not a compiled instance (udecore.hip model table) and "
-                                            "outside the runtime-shape fallbacks (LV / SEIR kinds: <= 8 layers of width <= 64; Fisher-KPP on <= 32 points: <= 4 layers of width <= 32, Float64)",
+                                            "outside the runtime-shape fallbacks (LV / SEIR kinds: <= 8 layers of width <= 64; Fisher-KPP on <= 32 points: <= 4 layers of width <= 32, on 33 .. 1024 points: three tanh layers of width <= 16; Float64)",
                     m->kind, m->dtype, m->n_layers);
     G = c->lo.lanes_per_traj > 0 ? c->lo.lanes_per_traj : default_lanes(mid, o->sensealg == UDE_SENSE_DISCRETE);
     if (G == 8) {   // (an explicit lanes_per_traj = 8: the width-8 instance takes narrower chains too)
