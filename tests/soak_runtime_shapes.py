@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Soak of the run-time-shape instances against the CPU oracle: random LV chains of width <= 16 (lane-group instances) and random
-exposure chains 3-H1-H2-1 (lock-step instances), one trajectory each, every gradient entry compared bit for bit, parity and -- exposure
+"""Soak of the run-time-shape instances against the CPU oracle: random LV chains of width <= 16 (lane-group instances), random
+exposure chains 3-H1-H2-1 (lock-step instances) and random Fisher-KPP reaction chains on grids of 33 .. 199 points, one trajectory each, every gradient entry compared bit for bit, parity and -- exposure
 chains -- fast mode.  test_gpu_soak_runtime_shapes.py runs a short one under `-m gpu`; a long one:
     python tests/soak_runtime_shapes.py [rounds] [seed]      (needs a GPU)"""
 import os
@@ -79,6 +79,26 @@ def one_round(rng, it):
         if not ok:
             bad += 1
             print("MISMATCH seir", dims, alg.__name__, "sense", osense)
+    # ---- Fisher-KPP on a grid of more than 32 points, edited reaction network ----
+    dims = [1] + [int(rng.integers(1, 17)) for _ in range(3)] + [1]
+    acts = ["tanh", "tanh", "tanh", "identity"]
+    nx = int(rng.integers(33, 200))
+    chain = models.Chain(*[models.Dense(dims[i], dims[i + 1], acts[i]) for i in range(4)])
+    f = models.nn_ode(nx, chain)
+    om = O.kpp_ude(nx, tuple(dims), tuple(acts))
+    th = models.kpp_theta(chain, rng)
+    u0 = np.tile(np.clip(models.rho0(26) * (1 + 0.1 * rng.uniform(-1, 1)) + 0.01 * rng.uniform(0, 1, 26), 0, None), 8)[None, :nx]
+    t = np.linspace(0.0, 0.6, 4)
+    data = rng.uniform(0.0, 1.0, (1, len(t), nx))
+    for sense, osense in ((None, 0), (U.ForwardDiffSensitivity(), 1), (U.InterpolatingAdjoint(checkpointing=True), 0)):
+        r = U.loss_and_gradient(U.ODEProblem(f, u0[0], (0.0, 0.6), th), U.Tsit5(), data, saveat=t, sensealg=sense, allow_failures=True)
+        ref = O.loss_grad_ensemble(om, O.opts(O.TSIT5, sensealg=osense), u0, [0.0, 0.6], th, t, data)
+        ok = np.array_equal(r.retcode, ref["retcode"]) and np.array_equal(r.stats[:, [0, 1, 2, 4, 5, 6]], ref["stats"][:, [0, 1, 2, 4, 5, 6]]) and np.array_equal(r.u, ref["u"], equal_nan=True)
+        if (ref["retcode"] == 0).all():
+            ok = ok and np.array_equal(r.grad_theta, ref["grad_theta"]) and np.array_equal(r.grad_u0, ref["grad_u0"])
+        if not ok:
+            bad += 1
+            print("MISMATCH kpp", dims, nx, "sense", type(sense).__name__)
     return bad
 
 

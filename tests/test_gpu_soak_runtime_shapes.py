@@ -1,5 +1,5 @@
 """A short soak of the run-time-shape instances (tests/soak_runtime_shapes.py: random LV chains of width <= 16, random exposure chains
-3-H1-H2-1) against the oracle, every gradient entry bit for bit; SOAK_ROUNDS=n for a longer one."""
+3-H1-H2-1, random Fisher-KPP reaction chains on larger grids) against the oracle, every gradient entry bit for bit; SOAK_ROUNDS=n for a longer one."""
 import os
 
 import pytest
