@@ -29,7 +29,7 @@ def soak(n, seed):
 def one_round(rng, it):
     bad = 0
     # ---- LV kind ----
-    nh = int(rng.integers(2, 4))
+    nh = int(rng.integers(1, 4))
     wmax = int(rng.choice([5, 8, 16]))
     dims = [2] + [int(rng.integers(1, wmax + 1)) for _ in range(nh)] + [2]
     acts = [str(rng.choice(ACTS)) for _ in range(nh)] + ["identity"]

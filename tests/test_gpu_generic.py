@@ -104,13 +104,16 @@ LV_RT_CASES = [([2, 8, 8, 8, 2], ["tanh", "tanh", "tanh", "identity"], None), ([
                ([2, 4, 5, 2], ["tanh", "relu", "identity"], "both"), ([2, 5, 3, 4, 2], ["relu", "rbf", "tanh", "identity"], None),
                # widths 9 .. 16: sixteen lanes per trajectory, the weights read from the block's LDS copy of theta at every use
                ([2, 16, 16, 16, 2], ["tanh", "tanh", "tanh", "identity"], None), ([2, 9, 12, 2], ["rbf", "tanh", "identity"], "both"),
-               ([2, 3, 16, 7, 2], ["tanh", "relu", "rbf", "identity"], "delta"), ([2, 16, 1, 2], ["tanh", "tanh", "identity"], None)]
+               ([2, 3, 16, 7, 2], ["tanh", "relu", "rbf", "identity"], "delta"), ([2, 16, 1, 2], ["tanh", "tanh", "identity"], None),
+               # ONE hidden layer (BASELINE's "2-layer MLP" with an edited width)
+               ([2, 8, 2], ["tanh", "identity"], None), ([2, 3, 2], ["rbf", "identity"], "both"), ([2, 16, 2], ["tanh", "identity"], "delta"),
+               ([2, 11, 2], ["relu", "identity"], None)]
 
 
 @pytest.mark.parametrize("case", range(len(LV_RT_CASES)))
 def test_lv_kind_edited_network_on_the_lane_group_kernels(golden, case):
     """round 5: the LV scripts' chain with EDITED widths / activations (`U = Lux.Chain(Dense(2,5,rbf), ...)` is a script variable:
-    scenario_1.jl:62-64) -- two or three hidden layers of width <= 16, linear output layer -- runs on the lane-group kernels of the
+    scenario_1.jl:62-64) -- one, two or three hidden layers of width <= 16, linear output layer -- runs on the lane-group kernels of the
     compiled instances (CoopMlp over NetCfgRt: the register copy of the weights zero-padded to width 8 or 5, eight or five lanes per
     trajectory; widths 9 .. 16: sixteen lanes, masked reads of the LDS copy of theta)
     instead of one wavefront per trajectory: forward solve, interpolating adjoint, discrete sweep, checkpointed adjoint, per-member

@@ -39,6 +39,8 @@ MODELS = [
     ("MID_LV_S1", "LvUde<NetS1,8>", 8, 1),
     ("MID_LV_HUDSON", "LvUde<NetHudson,8>", 8, 1),
     # run-time shapes of the LV kind (two / three hidden layers of width <= 8, any activation): padded register copy of the weights
+    ("MID_LV_RT2", "LvUde<NetLvRt2,8>", 8, 1),
+    ("MID_LV_RT2_W16", "LvUde<NetLvRt2W16,16>", 16, 1),
     ("MID_LV_RT3", "LvUde<NetLvRt3,8>", 8, 1),
     ("MID_LV_RT4", "LvUde<NetLvRt4,8>", 8, 1),
     ("MID_LV_RT3_W5", "LvUde<NetLvRt3W5,5>", 5, 1),

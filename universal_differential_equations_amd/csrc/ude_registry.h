@@ -98,6 +98,8 @@ using NetS1 = NetCfg<IntList<2, 5, 5, 5, 2>, IntList<ACT_RBF, ACT_RBF, ACT_RBF, 
 using NetHudson = NetCfg<IntList<2, 5, 5, 5, 2>, IntList<ACT_RBF, ACT_RBF, ACT_TANH, ACT_IDENTITY>>;  // hudson_bay.jl:77-79
 using NetTanh32 = NetCfg<IntList<2, 32, 2>, IntList<ACT_TANH, ACT_IDENTITY>>;                         // BASELINE C2 "2-layer tanh"
 // run-time shapes of the LV kind on the lane-group kernels: 2 -> (two / three hidden layers of width <= 8, any activation) -> 2
+using NetLvRt2 = NetCfgRt<2, 2, 2, 8>;      // (one hidden layer: BASELINE's "2-layer MLP" with an edited width)
+using NetLvRt2W16 = NetCfgRt<2, 2, 2, 16>;
 using NetLvRt3 = NetCfgRt<2, 2, 3, 8>;
 using NetLvRt4 = NetCfgRt<2, 2, 4, 8>;
 // ... and of width <= 5 on FIVE lanes (the headline instance's layout: twelve trajectories per wavefront, the 10k ensemble in one round) --
@@ -124,6 +126,7 @@ enum { MID_NONE = -1, MID_LV_TRUE = 0, MID_LV_S1, MID_LV_HUDSON, MID_LV_TANH32, 
        MID_LV_RT3_W5, MID_LV_RT4_W5 /* ... of width <= 5 on 5-lane groups */,
        MID_LV_RT3_F32, MID_LV_RT4_F32, MID_LV_RT3_W5_F32, MID_LV_RT4_W5_F32 /* ... as Float32 problems (hudson_bay.jl:77-104 with an edited FastChain) */,
        MID_LV_RT3_W16, MID_LV_RT4_W16 /* ... of width <= 16 on 16-lane groups, weights read from the LDS copy of theta (Float64) */,
+       MID_LV_RT2, MID_LV_RT2_W16 /* LV kind, ONE hidden layer of width <= 8 / <= 16 (run-time shape) */,
        MID_KPP_RT_1024 /* nn_ode on 33 .. 1024 points with any reaction chain 1 -> a -> b -> c -> 1, tanh hidden layers of width <= 16 (KppUdeW over NetCfgRt) */ };
 
 using NetKpp = NetCfg<IntList<1, 10, 20, 10, 1>, IntList<ACT_TANH, ACT_TANH, ACT_TANH, ACT_IDENTITY>>;  // Fisher-KPP-CNN.jl:92-96

@@ -329,6 +329,8 @@ static int generic_id(const ude_model_desc* m, bool narrow_ok = true) {
         // round 5: the scripts' own depth with EDITED widths / activations -- two or three hidden layers of width <= 8, linear output
         // layer -- on the lane-group kernels of the compiled instances (NetCfgRt: padded register copy of the weights, eight lanes per
         // trajectory) instead of one wavefront per trajectory
+        if (narrow_ok && m->n_layers == 2 && m->act[1] == UDE_ACT_IDENTITY && m->dtype == 0 && m->dims[1] <= 16)   // one hidden layer
+            return m->dims[1] <= 8 ? MID_LV_RT2 : MID_LV_RT2_W16;
         if (narrow_ok && (m->n_layers == 3 || m->n_layers == 4) && m->act[m->n_layers - 1] == UDE_ACT_IDENTITY) {
             int wmax = 0;
             for (int l = 1; l < m->n_layers; ++l) wmax = m->dims[l] > wmax ? m->dims[l] : wmax;
@@ -405,11 +407,13 @@ static int default_lanes(int mid, bool discrete) {
         case MID_LV_RT4_W5_F32:
         case MID_LV_S1: return 5;  // 12 trajectories per wavefront: every lane of the 5-wide layers busy, C2 fits in one round
         case MID_LV_HUDSON:
+        case MID_LV_RT2:
         case MID_LV_RT3:
         case MID_LV_RT4:
         case MID_LV_RT3_F32:
         case MID_LV_RT4_F32:
         case MID_LV_HUDSON_F32: return 8;
+        case MID_LV_RT2_W16:
         case MID_LV_RT3_W16:
         case MID_LV_RT4_W16:
         case MID_LV_TANH32: return 16;  // two hidden neurons per lane, four trajectories per wavefront, 253 registers = two wavefronts per SIMD.
