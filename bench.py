@@ -364,6 +364,21 @@ def timed_steps(fn, steps):
     return float(np.median(ts))
 
 
+def edited_net(net):
+    """the EDITED networks of the run-time-shape lines: (model, theta, description)"""
+    from universal_differential_equations_amd import models
+    if net == "tanh5":
+        ch = models.Chain(models.Dense(2, 5, "tanh"), models.Dense(5, 5, "tanh"), models.Dense(5, 5, "tanh"), models.Dense(5, 2, "identity"))
+        return models.ude_dynamics(ch), 0.3 * ch.glorot_uniform(np.random.default_rng(7)), "2-5-5-5-2 tanh (activations edited), 87 params, 0.3 x glorot"
+    if net == "shape8":
+        ch = models.Chain(models.Dense(2, 8, "tanh"), models.Dense(8, 8, "tanh"), models.Dense(8, 8, "tanh"), models.Dense(8, 2, "identity"))
+        return models.ude_dynamics(ch), 0.1 * ch.glorot_uniform(np.random.default_rng(7)), "2-8-8-8-2 tanh (widths edited), 178 params, 0.1 x glorot"
+    if net == "shape63":
+        ch = models.Chain(models.Dense(3, 64, "tanh"), models.Dense(64, 63, "tanh"), models.Dense(63, 1, "identity"))
+        return models.dudt_(ch), ch.glorot_uniform(np.random.default_rng(0)), "3-64-63-1 tanh (one neuron edited away), 4352 params"
+    raise ValueError(net)
+
+
 def quick_measure(name, device, steps=5, warmup=1):
     """One of the OTHER workloads, measured in the same process as the headline (driver-observed): the median of `steps`
     individually synchronised steps after `warmup`, kernel times from the library's HIP events, algorithmic roofline fraction of the
@@ -421,14 +436,8 @@ def quick_measure(name, device, steps=5, warmup=1):
         if net == "tanh32":
             f_lv = models.ude_dynamics(models.tanh32_chain())
             theta_h = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(7))
-        if net == "tanh5":
-            chain5 = models.Chain(models.Dense(2, 5, "tanh"), models.Dense(5, 5, "tanh"), models.Dense(5, 5, "tanh"), models.Dense(5, 2, "identity"))
-            f_lv = models.ude_dynamics(chain5)
-            theta_h = 0.3 * chain5.glorot_uniform(np.random.default_rng(7))
-        if net == "shape8":
-            chain8 = models.Chain(models.Dense(2, 8, "tanh"), models.Dense(8, 8, "tanh"), models.Dense(8, 8, "tanh"), models.Dense(8, 2, "identity"))
-            f_lv = models.ude_dynamics(chain8)
-            theta_h = 0.1 * chain8.glorot_uniform(np.random.default_rng(7))
+        if net in ("tanh5", "shape8"):
+            f_lv, theta_h, _ = edited_net(net)
         ens = U.DeviceEnsemble(f_lv, U.Tsit5(), (0.0, 3.0), t, u0_d, data=data, abstol=1e-6, reltol=1e-6, sensealg=SENSE_OBJ(U, sense), lanes_per_traj=lanes)
         desc = "configs[1] with %s" % ("the 2-32-2 tanh net (BASELINE's literal '2-layer tanh MLP')" if net == "tanh32" else
                                       "the network edited to 2-8-8-8-2 tanh (no compiled instance: the run-time-shape instance of the lane-group kernels, 8 lanes per trajectory)" if net == "shape8" else
@@ -441,8 +450,7 @@ def quick_measure(name, device, steps=5, warmup=1):
         w = synth_inputs_other(wl, N, 0, device)
         theta_h, u0_d, t, data, mask = w["theta"], w["u0"], w["t"], w["data"], w["mask"]
         if name == "seir_shape63":
-            chain63 = models.Chain(models.Dense(3, 64, "tanh"), models.Dense(64, 63, "tanh"), models.Dense(63, 1, "identity"))
-            w["f"], theta_h = models.dudt_(chain63), chain63.glorot_uniform(np.random.default_rng(0))
+            w["f"], theta_h, _ = edited_net("shape63")
         ens = U.DeviceEnsemble(w["f"], w["alg"], w["tspan"], t, u0_d, data=data, row_mask=mask, sensealg=SENSE_OBJ(U, sense), **w["tol"])
         desc = {"seir": "configs[2] per-GPU share: SEIR exposure UDE, 6250 trajectories, Vern7 1e-6" +
                         (", fast mode (lambda-only error control; parameter cotangent = block-level matrix-core accumulation, no mu in HBM)" if sense == "fast" else ""),
@@ -529,8 +537,9 @@ def main():
     ap.add_argument("--sensealg", default="adjoint", choices=["adjoint", "discrete", "fast"],
                     help="adjoint = InterpolatingAdjoint (the north-star path); discrete = frozen-step reverse sweep (a9); "
                          "fast = interpolating adjoint with lambda-only error control (opt-in, not the reference's step sequence)")
-    ap.add_argument("--net", default="s1", choices=["s1", "tanh32"],
-                    help="lv workload: s1 = the reference 2-5-5-5-2 rbf chain (headline), tanh32 = BASELINE's '2-layer tanh' 2-32-2")
+    ap.add_argument("--net", default="s1", choices=["s1", "tanh32", "tanh5", "shape8", "shape63"],
+                    help="lv workload: s1 = the reference 2-5-5-5-2 rbf chain (headline), tanh32 = BASELINE's '2-layer tanh' 2-32-2, tanh5 / shape8 = "
+                         "the chain with edited activations / widths (run-time-shape instances); seir workload: shape63 = the exposure network edited to 3-64-63-1")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step (memset + forward + adjoint + reductions) "
                                                          "instead of launching the six operations individually")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -584,19 +593,23 @@ def main():
         theta_h, u0_d, t, data = synth_inputs(N, rank, device)
         alg = U.Tsit5() if a.alg == "tsit5" else U.Vern7()
         f_lv = models.ude_dynamics()
+        net_desc = "2-5-5-5-2 rbf, 87 params, theta_init of scenario_1" if a.net == "s1" else "2-32-2 tanh, 162 params, 0.1 x glorot"
         if a.net == "tanh32":
             f_lv = models.ude_dynamics(models.tanh32_chain())
             theta_h = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(7))
+        elif a.net in ("tanh5", "shape8"):
+            f_lv, theta_h, net_desc = edited_net(a.net)
         ens = U.DeviceEnsemble(f_lv, alg, (0.0, 3.0), t, u0_d, data=data, lanes_per_traj=a.lanes,
                                waves_per_simd=a.waves, abstol=1e-6, reltol=1e-6,
                                sensealg=SENSE_OBJ(U, a.sensealg))
         wl_name = ("BASELINE configs[1]: LV UDE (%s), %d trajectories per GPU, "
                    "%s abstol=reltol=1e-6, 31 save points, loss + %s gradient"
-                   % ("2-5-5-5-2 rbf, 87 params, theta_init of scenario_1" if a.net == "s1" else "2-32-2 tanh, 162 params, 0.1 x glorot", N, a.alg,
-                      SENSE_NAME[a.sensealg]))
+                   % (net_desc, N, a.alg, SENSE_NAME[a.sensealg]))
     else:
         w = synth_inputs_other(a.workload, N, rank, device)
         theta_h, u0_d, t, data, mask = w["theta"], w["u0"], w["t"], w["data"], w["mask"]
+        if a.workload == "seir" and a.net == "shape63":
+            w["f"], theta_h, w["desc_net"] = edited_net("shape63")
         ens = U.DeviceEnsemble(w["f"], w["alg"], w["tspan"], t, u0_d, data=data, row_mask=mask, lanes_per_traj=a.lanes,
                                sensealg=SENSE_OBJ(U, a.sensealg), **w["tol"])
         wl_name = {"seir": "BASELINE configs[2] per-GPU share: SEIR exposure UDE (7 states, NN 3-64-64-1 tanh, 4481 params), %d trajectories "
@@ -605,6 +618,8 @@ def main():
                            "trajectories per GPU, Vern7 abstol=reltol=1e-6, 22 save points, loss rows 2:4 + %s gradient",
                    "kpp": "BASELINE configs[3]: Fisher-KPP UDE, 1024 points (dx = 0.04), NN 1-10-20-10-1 tanh + 3-tap stencil (466 params), "
                           "%d PDEs per GPU, Tsit5 default tol, 11 save points, loss + %s gradient"}[a.workload] % (N, SENSE_NAME[a.sensealg])
+        if "desc_net" in w:   # (--net shape63: the exposure network edited, no compiled instance)
+            wl_name = wl_name.replace("NN 3-64-64-1 tanh, 4481 params", "NN " + w["desc_net"] + ": run-time-shape instances of the lock-step kernels")
     theta = torch.tensor(theta_h, dtype=torch.float64, device=device)
 
     # ONE collective per gradient: double[np + 4] = [grad; loss; sum nf; sum naccept; sum nreject].
@@ -689,7 +704,7 @@ def main():
 
     if rank == 0:
         bwd = float(np.mean(bwd_ms)) * 1e-3
-        fkey = "lv_tanh32" if (a.workload == "lv" and a.net == "tanh32") else a.workload
+        fkey = "lv_tanh32" if (a.workload == "lv" and a.net == "tanh32") else "lv_shape8" if (a.workload == "lv" and a.net == "shape8") else a.workload
         flops_bwd = nf_bwd * FLOPS[fkey][1]
         achieved = flops_bwd / bwd / 1e12
         out = {

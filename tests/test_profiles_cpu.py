@@ -14,7 +14,10 @@ P = os.path.join(ROOT, "profiles")
 CASES = {"lv": ("adj_kernel<", "bwd_kernel_ms"), "lv_discrete": ("dadj_kernel<", "bwd_kernel_ms"), "lv_tanh32": ("adj_kernel<", "bwd_kernel_ms"),
          "seir": ("seirls2::seir_ls2_adj_kernel<", "bwd_kernel_ms"), "node": ("nodels2::node_ls2_adj_kernel<", "bwd_kernel_ms"),
          "kpp": ("adj_kernel<", "bwd_kernel_ms"), "seir_fast": ("seirlf::seir_lsf_adj_kernel<", "bwd_kernel_ms"),
-         "node_fast": ("nodelf::node_lsf_adj_kernel<", "bwd_kernel_ms")}
+         "node_fast": ("nodelf::node_lsf_adj_kernel<", "bwd_kernel_ms"),
+         # the run-time-shape lines (edited networks): kernel trace + bench line, no counter passes
+         "lv_tanh5": ("adj_kernel<", "bwd_kernel_ms"), "lv_shape8": ("adj_kernel<", "bwd_kernel_ms"),
+         "seir_shape63": ("seirls2::seir_ls2_adj_kernel<", "bwd_kernel_ms")}
 ROUND = "r05" if os.path.exists(os.path.join(P, "r05_bench_lv.json")) else "r04"
 
 

@@ -8,7 +8,8 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 WL=${PROF_W:-"lv seir seir_fast kpp hjb node node_fast lv_tanh32 lv_discrete"}
 has() { case " $WL " in *" $1 "*) return 0;; *) return 1;; esac; }
-args() { case $1 in lv_tanh32) echo "--workload lv --net tanh32";; lv_discrete) echo "--workload lv --sensealg discrete";; seir_fast) echo "--workload seir --sensealg fast";;
+args() { case $1 in lv_tanh32) echo "--workload lv --net tanh32";; lv_tanh5) echo "--workload lv --net tanh5";; lv_shape8) echo "--workload lv --net shape8";;
+          seir_shape63) echo "--workload seir --net shape63";; lv_discrete) echo "--workload lv --sensealg discrete";; seir_fast) echo "--workload seir --sensealg fast";;
           node_fast) echo "--workload node --sensealg fast";; *) echo "--workload $1";; esac; }
 cd /tmp
 for W in $WL; do
