@@ -32,7 +32,7 @@ FLOPS = {"lv": (160.0, 550.0), "seir": (8744.0, 26000.0), "kpp": (0.87e6, 2.6e6)
          # adjoint = forward + the two transposed products + the 162 outer-product / bias entries
          "lv_tanh32": (258.0, 840.0),
          # the LV network edited to 2-8-8-8-2: forward 2*(2*8 + 2*8*8 + 8*2) + 2 = 322 flop; adjoint = forward + the transposed products (320) +
-         # the 178 outer-product / bias entries (2 flop each)
+         # the 186 outer-product / bias entries (2 flop each)
          "lv_shape8": (322.0, 1000.0)}
 
 
@@ -372,10 +372,10 @@ def edited_net(net):
         return models.ude_dynamics(ch), 0.3 * ch.glorot_uniform(np.random.default_rng(7)), "2-5-5-5-2 tanh (activations edited), 87 params, 0.3 x glorot"
     if net == "shape8":
         ch = models.Chain(models.Dense(2, 8, "tanh"), models.Dense(8, 8, "tanh"), models.Dense(8, 8, "tanh"), models.Dense(8, 2, "identity"))
-        return models.ude_dynamics(ch), 0.1 * ch.glorot_uniform(np.random.default_rng(7)), "2-8-8-8-2 tanh (widths edited), 178 params, 0.1 x glorot"
+        return models.ude_dynamics(ch), 0.1 * ch.glorot_uniform(np.random.default_rng(7)), "2-8-8-8-2 tanh (widths edited), 186 params, 0.1 x glorot"
     if net == "shape63":
         ch = models.Chain(models.Dense(3, 64, "tanh"), models.Dense(64, 63, "tanh"), models.Dense(63, 1, "identity"))
-        return models.dudt_(ch), ch.glorot_uniform(np.random.default_rng(0)), "3-64-63-1 tanh (one neuron edited away), 4352 params"
+        return models.dudt_(ch), ch.glorot_uniform(np.random.default_rng(0)), "3-64-63-1 tanh (one neuron edited away), 4415 params"
     raise ValueError(net)
 
 
