@@ -45,7 +45,17 @@ HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 #         stream SURVEY.md 8(d) C3 names ("HBM in parity mode"); their flop fraction is reported beside it (`flop_frac`)
 # the headline command at other fillings of the chip / with the wavefront-per-trajectory layout: name -> (trajectories, lanes per trajectory)
 LV_VARIANTS = {"lv_sat40k": (40000, 0), "lv_sat160k": (160000, 0), "lv_wave64": (10000, 64)}
-BOUND = {"lv_tanh5": "valu", "lv_shape8": "valu", "seir_shape63": "hbm", "seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
+# the workloads the default command measures beside the headline (config.other_workloads), in this order
+OTHER_WORKLOADS = ("lv_trained", "seir", "seir_fast", "seir_shape63", "node_fast", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_tanh5", "lv_shape8",
+                   "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64")
+
+
+def kernel_within_step(entry):
+    """a workload line is self-consistent when its dominant kernel's time -- and, where reported, forward + backward kernel together --
+    does not exceed the step it is part of (2 % for the clocks: HIP events against the host's wall clock)"""
+    ks = [entry.get("kernel_ms") or 0.0, (entry.get("kernel_ms") or 0.0) + (entry.get("fwd_kernel_ms") or entry.get("bwd_kernel_ms") or 0.0)]
+    return max(ks) <= 1.02 * entry["ms_per_step"]
+BOUND = {"lv_trained": "valu", "lv_tanh5": "valu", "lv_shape8": "valu", "seir_shape63": "hbm", "seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
 
 
 # `roofline.traffic` is NOT measured inside this run (PMC passes cannot run inside a timed bench): it is read from the committed
@@ -165,6 +175,19 @@ def synth_inputs(N, rank, device):
     return theta, u0_d, t, data
 
 
+def reference_julia():
+    """the reference's own DiffEqFlux path is timed "only if the GPU box provides it".  Observed, not assumed: is there
+    a `julia` on this box (PATH and the usual install prefixes)?  "absent" -> `cpu_baseline.kind` stays "port" (the oracle); a path ->
+    reported as found (its package depot is not in this image either: no network -- the scripts' Manifest cannot be instantiated)."""
+    import glob
+    import shutil
+    exe = shutil.which("julia")
+    if exe is None:
+        cand = sorted(glob.glob("/opt/julia*/bin/julia") + glob.glob("/usr/local/julia*/bin/julia") + glob.glob(os.path.expanduser("~/.juliaup/bin/julia")))
+        exe = cand[0] if cand else None
+    return "absent" if exe is None else "found at %s (not run: the scripts' Manifest.toml cannot be instantiated without a package server)" % exe
+
+
 def cpu_baseline(theta, u0, t, data, seconds_target=15.0, workload="lv", mask=None):
     """The CPU restatement (oracle, kind "port") on this box's host cores, bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -188,7 +211,7 @@ def cpu_baseline(theta, u0, t, data, seconds_target=15.0, workload="lv", mask=No
         dt = time.perf_counter() - t0
         n = n2
     evals = int(r["stats"][:, 0].sum() + r["stats"][:, 4].sum())
-    return {"value": evals / dt, "unit": "RHS-evals/s", "cores": cores, "kind": "port",
+    return {"value": evals / dt, "unit": "RHS-evals/s", "cores": cores, "kind": "port", "reference_julia": reference_julia(),
             "sample": "%d of the %d trajectories, one loss+adjoint-gradient pass, OpenMP over trajectories (%.1f s)" % (n, len(u0), dt)}
 
 
@@ -320,7 +343,7 @@ def cpu_baseline_hjb(theta_h, tol, seconds_target=15.0):
         dt = time.perf_counter() - t0
         n = n2
     evals = int(r["stats"][:, 0].sum() + r["stats"][:, 1].sum())
-    return {"value": evals / dt, "unit": "RHS-evals/s", "cores": cores, "kind": "port",
+    return {"value": evals / dt, "unit": "RHS-evals/s", "cores": cores, "kind": "port", "reference_julia": reference_julia(),
             "sample": "%d trajectories, one loss+gradient pass of the CPU restatement, OpenMP over trajectories (%.1f s)" % (n, dt)}
 
 
@@ -351,9 +374,9 @@ def pmc_traffic_file(fname, kernel_prefix):
     return None
 
 
-def timed_steps(fn, steps):
+def timed_steps(fn, steps, every=False):
     """median wall-clock of `steps` individually synchronised calls, in ms (a few steps only: one host hiccup -- a page fault, a
-    late code-object load -- must not become the number)"""
+    late code-object load -- must not become the number); every = True: all of them"""
     ts = []
     for i in range(steps):
         torch.cuda.synchronize()
@@ -361,7 +384,7 @@ def timed_steps(fn, steps):
         fn(i)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
-    return float(np.median(ts))
+    return ts if every else float(np.median(ts))
 
 
 def edited_net(net):
@@ -399,8 +422,17 @@ def quick_measure(name, device, steps=5, warmup=1):
             steps = min(steps, 2)
         for i in range(warmup):
             bs.loss_grad(theta, it=i)
-        ms = timed_steps(lambda i: bs.loss_grad(theta, it=i, check_store=False), steps)
-        f, b = bs.kernel_ms()
+        # (step and kernel time from the SAME calls -- the Philox iteration `it` changes the step count of the adaptive solve from call
+        #  to call: the median step of some calls next to the kernel time of the last one once reported a kernel longer than its step)
+        kms = []
+
+        def one_bsde(i):
+            bs.loss_grad(theta, it=i, check_store=False)
+            torch.cuda.synchronize()
+            kms.append(bs.kernel_ms())
+        ts = timed_steps(one_bsde, steps, every=True)
+        pick = int(np.argsort(ts)[len(ts) // 2])        # the median step, and ITS kernel times
+        ms, (f, b) = ts[pick], kms[pick]
         nf, nacc = int(bs.stats[:, 0].sum().item()), int(bs.stats[:, 1].sum().item())
         ach = nf * HJB_FLOP_PER_EVAL / (f * 1e-3) / 1e12
         return {"workload": "configs[4] per-GPU share: deep-BSDE step, 16384 trajectories, LambaEM tol 0.1" if name == "hjb" else
@@ -418,6 +450,8 @@ def quick_measure(name, device, steps=5, warmup=1):
         wl, net = "lv", "shape8"   # configs[1] with an EDITED network, 2-8-8-8-2 tanh: no compiled instance, the run-time-shape lane-group instance
     elif name == "lv_discrete":
         wl, sense = "lv", "discrete"
+    elif name == "lv_trained":
+        wl, net = "lv", "trained"   # "theta_init and theta_trained (two runs)" -- the headline command at the fixture's TRAINED parameters
     elif name == "seir_fast":
         wl, sense = "seir", "fast"
     elif name == "node_fast":
@@ -438,8 +472,11 @@ def quick_measure(name, device, steps=5, warmup=1):
             theta_h = 0.1 * models.tanh32_chain().glorot_uniform(np.random.default_rng(7))
         if net in ("tanh5", "shape8"):
             f_lv, theta_h, _ = edited_net(net)
+        if net == "trained":   # scenario_1.jl:113-126: the parameters ADAM + BFGS end at (the stored artifact's `trained_parameters`)
+            theta_h = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "Scenario_1_recovery_0.005.json")))["trained_parameters"])
         ens = U.DeviceEnsemble(f_lv, U.Tsit5(), (0.0, 3.0), t, u0_d, data=data, abstol=1e-6, reltol=1e-6, sensealg=SENSE_OBJ(U, sense), lanes_per_traj=lanes)
         desc = "configs[1] with %s" % ("the 2-32-2 tanh net (BASELINE's literal '2-layer tanh MLP')" if net == "tanh32" else
+                                      "theta_trained of the reference's stored run (scenario_1.jl:113-126) instead of theta_init: the second run of SURVEY 8(d) C2" if net == "trained" else
                                       "the network edited to 2-8-8-8-2 tanh (no compiled instance: the run-time-shape instance of the lane-group kernels, 8 lanes per trajectory)" if net == "shape8" else
                                       "the activations edited to tanh, 2-5-5-5-2 (no compiled instance: the run-time-shape instance on 5 lanes per trajectory, the headline layout)" if net == "tanh5" else
                                       "the discretise-then-optimise gradient"
@@ -473,11 +510,11 @@ def quick_measure(name, device, steps=5, warmup=1):
     ms = timed_steps(one, steps)
     f, b = float(np.median([k[0] for k in kms])), float(np.median([k[1] for k in kms]))
     nf_fwd, nf_bwd = int(ens.stats[:, 0].sum().item()), int(ens.stats[:, 4].sum().item())
-    flop_key = "lv_tanh32" if name == "lv_tanh32" else "lv_shape8" if name == "lv_shape8" else wl   # (lv_tanh5: the headline's 2-5-5-5-2 count)
+    flop_key = "lv_tanh32" if name == "lv_tanh32" else "lv_shape8" if name == "lv_shape8" else wl   # (lv_tanh5, lv_trained: the headline's 2-5-5-5-2 count)
     ach = nf_bwd * FLOPS[flop_key][1] / (b * 1e-3) / 1e12
     kern = "dadj_kernel" if sense == "discrete" else "seirlf::seir_lsf_adj_kernel" if name == "seir_fast" else "nodelf::node_lsf_adj_kernel" if name == "node_fast" else "seirls2::seir_ls2_adj_kernel" if wl == "seir" else "nodels2::node_ls2_adj_kernel" if wl == "node" else "adj_kernel"
     pm = name if name in ("lv_tanh32", "lv_discrete", "seir_fast", "node_fast") else wl
-    if name in LV_VARIANTS or name in ("seir_shape63", "lv_shape8", "lv_tanh5"):
+    if name in LV_VARIANTS or name in ("seir_shape63", "lv_shape8", "lv_tanh5", "lv_trained"):
         pm = "none"    # (no committed counter pass for these commands)
     out = {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
            "fwd_kernel_ms": f, "bound": BOUND[name], "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
@@ -729,9 +766,10 @@ def main():
             del ens
             torch.cuda.empty_cache()
             others = {}
-            for name in ("seir", "seir_fast", "seir_shape63", "node_fast", "kpp", "hjb", "hjb_script_tol", "node", "lv_tanh32", "lv_tanh5", "lv_shape8", "lv_discrete", "lv_sat40k", "lv_sat160k", "lv_wave64"):
+            for name in OTHER_WORKLOADS:
                 try:
                     others[name] = quick_measure(name, device)
+                    others[name]["kernel_within_step"] = kernel_within_step(others[name])
                 except Exception as e:  # a failing secondary workload must not take the headline line with it
                     others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()

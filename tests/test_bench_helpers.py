@@ -51,3 +51,27 @@ def test_roofline_bound_is_chosen_per_kernel():
     r = bench.headline_roofline(_args(workload="seir", lanes=64, alg="tsit5", waves=0, traj=0), "seir", 3.0, 18e-3, stats, 4481)
     assert r["bound"] == "valu"
     assert set(bench.BOUND.values()) <= {"valu", "mfma", "hbm"}
+
+
+def test_every_workload_line_has_its_kernels_inside_its_step():
+    """`kernel_within_step`: a workload's dominant kernel (and forward + backward kernel together) cannot take longer than the step that
+    contains them -- the check the deep-BSDE script-tolerance line once failed (kernel time of the LAST call beside the median step of
+    calls with other Philox iterations); every line of the committed driver-command record of this round must pass it"""
+    import glob
+    import json
+    assert bench.kernel_within_step({"ms_per_step": 10.0, "kernel_ms": 8.0, "fwd_kernel_ms": 1.9})
+    assert not bench.kernel_within_step({"ms_per_step": 2210.0, "kernel_ms": 2270.0, "bwd_kernel_ms": 1.0})     # round 5's hjb_script_tol
+    assert not bench.kernel_within_step({"ms_per_step": 10.0, "kernel_ms": 8.0, "fwd_kernel_ms": 2.5})
+    assert "lv_trained" in bench.OTHER_WORKLOADS and bench.BOUND["lv_trained"] == "valu"
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_bench_default_driver_command.json"))):
+        line = json.load(open(f))
+        assert line["config"]["bwd_kernel_ms"] + line["config"]["fwd_kernel_ms"] <= 1.02 * line["ms_per_step"]
+        for name, e in line["config"]["other_workloads"].items():
+            assert "error" not in e, (name, e)
+            assert bench.kernel_within_step(e), (name, e["ms_per_step"], e.get("kernel_ms"))
+        assert "reference_julia" in line["cpu_baseline"]
+
+
+def test_reference_julia_probe_reports_what_it_finds():
+    r = bench.reference_julia()
+    assert r == "absent" or r.startswith("found at ")

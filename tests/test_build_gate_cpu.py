@@ -168,3 +168,64 @@ def test_every_built_translation_unit_is_clean():
     for f in files:
         _, rep = T.process(open(f).read(), repair=False)
         assert not rep["fixed"] and not rep["unhandled"], "%s: %s" % (os.path.basename(f), (rep["fixed"] + rep["unhandled"])[:2])
+
+
+# ---- the second pass of the pipeline: wait states in front of the hand-written DPP instructions (tools/isa_dpp_hazard.py) ----
+def dpp_tool():
+    spec = importlib.util.spec_from_file_location("isa_dpp_hazard", os.path.join(ROOT, "tools", "isa_dpp_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+DPP = "\t;;#ASMSTART\n\tv_fmac_f64_dpp v[34:35], v[104:105], v[100:101] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t;;#ASMEND\n"
+
+
+def test_a_reload_of_the_dpp_operand_in_front_of_the_asm_statement_gets_its_wait_states():
+    """the site of the first `-amdgpu-mfma-vgpr-form` build of the Fisher-KPP vector kernel: a weight register brought back from an
+    AGPR directly in front of the v_fmac_f64_dpp that broadcasts out of it (VALU write -> DPP read: 2 wait states; the back end's
+    hazard recogniser does not look inside an asm statement)"""
+    T = dpp_tool()
+    src = KERNEL + "\tv_accvgpr_read_b32 v104, a20\n\tv_accvgpr_read_b32 v105, a21\n" + DPP + "\ts_endpgm\n"
+    text, rep = T.process(src)
+    assert rep["dpp"] == 1 and len(rep["inserted"]) == 1 and rep["inserted"][0][1] == 2 and not rep["errors"]
+    body = [l.strip() for l in text.split("\n") if l.strip()]
+    assert body[body.index(";;#ASMSTART") - 1] == "s_nop 1"      # in front of the asm statement, not inside it
+    assert not T.process(text, repair=False)[1]["inserted"]      # idempotent
+    # one instruction in between: one more wait state is missing
+    src = KERNEL + "\tv_accvgpr_read_b32 v105, a21\n\tv_add_u32_e32 v1, 1, v1\n" + DPP + "\ts_endpgm\n"
+    text, rep = T.process(src)
+    assert rep["inserted"][0][1] == 1 and "s_nop 0" in text
+    # two instructions (or an s_nop 1) in between: nothing to do; a write of ANOTHER register: nothing to do
+    for mid in ("\tv_add_u32_e32 v1, 1, v1\n\tv_add_u32_e32 v2, 1, v2\n", "\ts_nop 1\n"):
+        text, rep = T.process(KERNEL + "\tv_accvgpr_read_b32 v105, a21\n" + mid + DPP + "\ts_endpgm\n")
+        assert not rep["inserted"]
+    text, rep = T.process(KERNEL + "\tv_accvgpr_read_b32 v100, a21\n\tv_mov_b64_e32 v[34:35], 0\n" + DPP + "\ts_endpgm\n")
+    assert not rep["inserted"]                                   # (destination and second source are ordinary operands)
+
+
+def test_a_block_boundary_or_an_exec_write_in_the_window_is_padded_and_other_dpp_controls_are_refused():
+    T = dpp_tool()
+    text, rep = T.process(KERNEL + "\tv_add_u32_e32 v1, 1, v1\n.LBB0_7:\n" + DPP + "\ts_endpgm\n")
+    assert rep["inserted"] and rep["inserted"][0][1] == 2         # another predecessor could end in anything
+    text, rep = T.process(KERNEL + "\tv_cmpx_gt_f64_e32 v[0:1], v[2:3]\n\tv_add_u32_e32 v1, 1, v1\n" + DPP + "\ts_endpgm\n")
+    assert rep["inserted"][0][1] == 4                             # VALU write of EXEC -> DPP: 5 wait states, one instruction is in between
+    bad = KERNEL + "\t;;#ASMSTART\n\tv_fmac_f64_dpp v[0:1], v[2:3], v[4:5] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t;;#ASMEND\n"
+    assert T.process(bad)[1]["errors"]
+    # DPP instructions the compiler selected itself (outside an asm statement) are its own business
+    own = KERNEL + "\tv_mov_b32_e32 v3, v9\n\tv_mov_b32_dpp v2, v3 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_endpgm\n"
+    assert T.process(own)[1]["dpp"] == 0
+
+
+def test_every_built_translation_unit_has_its_dpp_wait_states():
+    files = sorted(glob.glob(os.path.join(ROOT, "universal_differential_equations_amd", "build", "*.fixed.s")) +
+                   glob.glob(os.path.join(ROOT, "universal_differential_equations_amd", "build", "ra2", "*.fixed.s")))
+    if not files:
+        pytest.skip("no build/ directory here (the GPU box receives the built library only)")
+    T = dpp_tool()
+    seen = 0
+    for f in files:
+        _, rep = T.process(open(f).read(), repair=False)
+        assert not rep["inserted"] and not rep["errors"], "%s: %s" % (os.path.basename(f), (rep["inserted"] + rep["errors"])[:2])
+        seen += rep["dpp"]
+    assert seen > 0   # (the Fisher-KPP vector kernel is made of them)

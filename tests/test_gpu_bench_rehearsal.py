@@ -72,3 +72,23 @@ def test_bench_collective_through_libudecore_single_rank(workload):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["failed_trajectories"] == 0
+
+
+@pytest.mark.parametrize("workload,traj", [("lv", "600"), ("seir", "96")])
+def test_bench_gpus_8_plain_command_through_the_cross_process_reducer(workload, traj):
+    """round 6: what the driver will run on a full node -- `python bench.py --gpus 8` as a plain command -- rehearsed with all eight
+    ranks on device 0 (gloo bootstrap, `--allreduce p2p`: eight IPC windows): the line says n_gpus = 8, nothing timed out, no
+    trajectory failed; `--workload seir` is the configuration north_star shards (configs[2])"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(UDE_BENCH_DEVICE="0", UDE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", UDE_P2P_TIMEOUT_MS="20000")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--traj", traj, "--workload", workload,
+           "--no-cpu-baseline", "--no-others", "--allreduce", "p2p"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]          # (a counted timeout makes bench.py exit non-zero)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["allreduce"] == "p2p" and d["scaling"] == "weak"
+    assert d["config"]["failed_trajectories"] == 0
+    per_rank = d["config"]["evals_per_step_fwd"] + d["config"]["evals_per_step_bwd"]
+    assert d["value"] > per_rank * 4 / (d["ms_per_step"] * 1e-3)     # whole-job value: eight ranks' evaluations over the slowest rank's time

@@ -245,3 +245,55 @@ def test_cross_process_p2p_teardown_without_host_barrier():
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d: %s" % (rank, se[-2000:])
         assert "RESULT rank %d ok True" % rank in so, (so[-500:], se[-1500:])
+
+
+P2P_EIGHT_CHILD = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import universal_differential_equations_amd as U
+from universal_differential_equations_amd.parallel import Comm
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["UDE_TEST_PORT"], rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+eng = U.Engine.get(0)                                   # all ranks on device 0: eight IPC windows, eight flag / closed words per window
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+comm = Comm.p2p_from_torch_dist(eng, dist, 9291)
+ok = True
+for call in range(24):                                  # the four payloads of the workloads: np + 4 for LV, Fisher-KPP, SEIR, the neural ODE
+    n = [91, 470, 4485, 9291][call %% 4]
+    rng = np.random.default_rng(7000 + call)
+    parts = [rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8) for _ in range(world)]
+    want = parts[0].copy()
+    for r in range(1, world):
+        want = want + parts[r]                          # rank order, left to right: the reducer's association
+    buf = torch.tensor(parts[rank], dtype=torch.float64, device="cuda:0")
+    comm.allreduce_mp(buf)
+    torch.cuda.synchronize()
+    ok = ok and np.array_equal(buf.cpu().numpy(), want)
+nt = comm.p2p_timeouts()
+comm.close(dist)                                        # the device-side "closed" handshake with seven peers + the host barrier
+torch.cuda.synchronize()
+print("RESULT rank %%d ok %%s timeouts %%d" %% (rank, ok, nt), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_cross_process_p2p_reducer_eight_ranks_on_one_gpu():
+    """round 6: the cross-process reducer with the EIGHT windows / flag words a full node needs (two ranks were all that had ever run):
+    eight processes on one device, 24 calls of the four payload sizes, every rank's result bit-identical to the left-to-right sum in
+    rank order, no timeout, real teardown"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="8", UDE_TEST_PORT=str(port), UDE_P2P_TIMEOUT_MS="20000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", P2P_EIGHT_CHILD % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d: %s" % (rank, se[-2000:])
+        assert "RESULT rank %d ok True timeouts 0" % rank in so, (so[-500:], se[-1500:])

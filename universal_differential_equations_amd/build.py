@@ -72,7 +72,10 @@ MODELS = [
     # runtime-shape pointwise reaction network (any chain 1 -> .. -> 1 of <= 4 layers, width <= 32) on grids of <= 32 points
     ("MID_KPP_GENERIC_32", "KppGenericUde<32,1>", 32, 1, 32, None, ("-DUDE_INST_KPPGEN=1",)),
     ("MID_KPP_UDE_1024", "KppUde<NetKpp,64,16>", 64, 1, 64, ("UDE_ALG_TSIT5",)),
-    ("MID_KPP_UDE_1024", "KppUdeW<NetKpp>", 256, 1, 256),
+    # round 6: the network on the vector unit (weights broadcast out of registers by DPP), packed matrix-core contraction
+    # (csrc/ude_model_kpp_vec.h); Vern7's ten stage rows leave the LDS room for the half-size transposition tile only
+    ("MID_KPP_UDE_1024", "KppUdeV<NetKpp>", 256, 1, 256, ("UDE_ALG_TSIT5",)),
+    ("MID_KPP_UDE_1024", "KppUdeV<NetKpp,4,32>", 256, 1, 256, ("UDE_ALG_VERN7",)),
     # run-time shape of the reaction network on the large grids (three tanh layers of width <= 16): padded operand tables
     ("MID_KPP_RT_1024", "KppUdeW<NetKppRt16>", 256, 1, 256, ("UDE_ALG_TSIT5",)),
     # Float32 problems (-DUDE_F32: the same kernels with real = float)
@@ -171,11 +174,20 @@ def write_poison_header():
 
 LLVM_BIN = os.environ.get("UDE_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 ENDCF_FIX = os.path.join(os.path.dirname(HERE), "tools", "isa_endcf_fix.py")
+DPP_HAZARD = os.path.join(os.path.dirname(HERE), "tools", "isa_dpp_hazard.py")
 
 
 def _endcf():
     import importlib.util
     spec = importlib.util.spec_from_file_location("isa_endcf_fix", ENDCF_FIX)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _dpp():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_dpp_hazard", DPP_HAZARD)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -195,7 +207,7 @@ def compile_one(job):
     # an object is current only if it is newer than the files it includes AND was built by this exact command line (an
     # edited MODELS row / flag keeps the instance name but must not keep the object) AND by this version of the repair tool
     stamp = obj + ".cmd"
-    sig = hashlib.sha256((" ".join(base + [src]) + open(ENDCF_FIX).read()).encode()).hexdigest()
+    sig = hashlib.sha256((" ".join(base + [src]) + open(ENDCF_FIX).read() + open(DPP_HAZARD).read()).encode()).hexdigest()
     if (os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_dep(dep))
             and os.path.exists(stamp) and open(stamp).read() == sig):
         return obj, 0, "up to date"
@@ -217,6 +229,15 @@ def compile_one(job):
             out.append("endcf-fix: UNHANDLED %s (%s): %s\n" % (where, why, "; ".join(v[:6])))
         _, again = _endcf().process(text, repair=False)
         if rep["unhandled"] or again["fixed"] or again["unhandled"]:
+            rc = 2
+        # second pass: the hand-written DPP instructions (inline assembly: the compiler's hazard recogniser does not see them) get
+        # the wait states their operands need (tools/isa_dpp_hazard.py; csrc/ude_model_kpp_vec.h is the only user)
+        text, drep = _dpp().process(text)
+        for ln, need, what in drep["inserted"]:
+            out.append("dpp-hazard: line %d: s_nop %d in front of `%s`\n" % (ln, need - 1, what))
+        for ln, why in drep["errors"]:
+            out.append("dpp-hazard: ERROR line %d: %s\n" % (ln, why))
+        if drep["errors"] or _dpp().process(text, repair=False)[1]["inserted"]:
             rc = 2
         open(fixed, "w").write(text)
     if rc == 0:
@@ -266,7 +287,7 @@ def kernel_work(objdir, extra):
     work.append((os.path.join(CSRC, "ude_seir_ls.hip"), os.path.join(objdir, "ude_seir_ls.o"), [] + extra, os.path.join(objdir, "ude_seir_ls.log")))
     work.append((os.path.join(CSRC, "ude_node_ls.hip"), os.path.join(objdir, "ude_node_ls.o"), [] + extra, os.path.join(objdir, "ude_node_ls.log")))
     # the `fast` mode of the lock-step kernels: parameter cotangent as a block-level matrix-core accumulation
-    work.append((os.path.join(CSRC, "ude_seir_lsf.hip"), os.path.join(objdir, "ude_seir_lsf.o"), os.environ.get("UDE_LSF_DEFS", "").split() + extra, os.path.join(objdir, "ude_seir_lsf.log")))
+    work.append((os.path.join(CSRC, "ude_seir_lsf.hip"), os.path.join(objdir, "ude_seir_lsf.o"), [] + extra, os.path.join(objdir, "ude_seir_lsf.log")))
     work.append((os.path.join(CSRC, "ude_node_lsf.hip"), os.path.join(objdir, "ude_node_lsf.o"), [] + extra, os.path.join(objdir, "ude_node_lsf.log")))
     # the multi-GPU exchange step (RCCL bound with dlopen, one-shot P2P reducer), SURVEY.md 8(e)
     work.append((os.path.join(CSRC, "ude_comm.hip"), os.path.join(objdir, "ude_comm.o"), [] + extra, os.path.join(objdir, "ude_comm.log")))

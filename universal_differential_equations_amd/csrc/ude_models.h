@@ -1189,3 +1189,4 @@ struct KppUdeW : LinearTheta {
 #endif  // UDE_F32
 
 }  // namespace ude
+#include "ude_model_kpp_vec.h"   // round 6: the 1024-point network on the vector unit, packed matrix-core contraction

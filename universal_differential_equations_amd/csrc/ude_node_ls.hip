@@ -1,11 +1,7 @@
 // ude_node_ls.hip -- translation unit of the lock-step matrix-core adjoint of the SEIR neural ODE (ude_node_ls.h).
 #include <hip/hip_runtime.h>
 #include "ude_node_ls.h"
-// second generation of the parity-mode backward kernel (ude_node_ls2.h, round 5: 13.82 -> 13.24 ms, 76 instead of 132 B of scratch): returned by the
-// getter below unless UDE_NODE_LS_V2 = 0 (the round-3/4 kernel of ude_node_ls.h, kept for comparison)
-#ifndef UDE_NODE_LS_V2
-#define UDE_NODE_LS_V2 1
-#endif
+// the parity-mode backward kernel (second generation, round 5: ude_node_ls2.h; ude_node_ls.h keeps what it shares with the fast mode)
 #include "ude_node_ls2.h"
 // two blocks of the forward kernel per compute unit (60 KB of LDS each, 256 registers per lane)
 #ifndef UDE_LS_FWD_PER_CU
@@ -14,14 +10,9 @@
 #include "ude_node_ls_fwd.h"
 using namespace ude;
 extern "C" void ude_node_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block) {
-#if UDE_NODE_LS_V2
     *fac_doubles_per_block = alg == 1 ? nodels::fac_doubles_per_block<Vern7Tab>() : nodels::fac_doubles_per_block<Tsit5Tab>();
     *kern = alg == 1 ? nodels2::node_ls2_adj_kernel<Vern7Tab> : nodels2::node_ls2_adj_kernel<Tsit5Tab>;
     *lds_bytes = sizeof(double) * (alg == 1 ? nodels2::lds_doubles<Vern7Tab>() : nodels2::lds_doubles<Tsit5Tab>()) + 16;
-    return;
-#endif
-    if (alg == 1) { *kern = nodels::node_ls_adj_kernel<Vern7Tab>; *lds_bytes = sizeof(double) * nodels::lds_doubles<Vern7Tab>() + 16; *fac_doubles_per_block = nodels::fac_doubles_per_block<Vern7Tab>(); }
-    else { *kern = nodels::node_ls_adj_kernel<Tsit5Tab>; *lds_bytes = sizeof(double) * nodels::lds_doubles<Tsit5Tab>() + 16; *fac_doubles_per_block = nodels::fac_doubles_per_block<Tsit5Tab>(); }
 }
 
 // the forward solve on the same architecture (ude_node_ls_fwd.h)

@@ -2,11 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ude_seir_ls.h"
-// second generation of the parity-mode backward kernel (ude_seir_ls2.h, round 5: 11.8 -> 10.6 ms on the configs[2] share, zero scratch):
-// the getter below returns it unless UDE_SEIR_LS_V2 = 0 (the round-3/4 kernel of ude_seir_ls.h, kept for comparison)
-#ifndef UDE_SEIR_LS_V2
-#define UDE_SEIR_LS_V2 1
-#endif
+// the parity-mode backward kernel (second generation, round 5: ude_seir_ls2.h; ude_seir_ls.h keeps what it shares with the fast mode)
 #include "ude_seir_ls2.h"
 // two blocks of the forward kernel per compute unit (256 registers per lane: 132 B of scratch in cold paths): 2.7 -> 1.8 ms
 #ifndef UDE_LS_FWD_PER_CU
@@ -18,21 +14,9 @@ using namespace ude;
 
 // kernel entry points for udecore.hip: alg 0 = Tsit5, 1 = Vern7
 extern "C" void ude_seir_ls_get(int alg, void (**kern)(const KParams, double*, int*), size_t* lds_bytes, size_t* fac_doubles_per_block) {
-#if UDE_SEIR_LS_V2
     *fac_doubles_per_block = alg == 1 ? seirls::fac_doubles_per_block<Vern7Tab>() : seirls::fac_doubles_per_block<Tsit5Tab>();
     *kern = alg == 1 ? seirls2::seir_ls2_adj_kernel<Vern7Tab> : seirls2::seir_ls2_adj_kernel<Tsit5Tab>;
     *lds_bytes = sizeof(double) * (alg == 1 ? seirls2::lds_doubles<Vern7Tab>() : seirls2::lds_doubles<Tsit5Tab>()) + 16;
-    return;
-#endif
-    if (alg == 1) {
-        *kern = seirls::seir_ls_adj_kernel<Vern7Tab>;
-        *lds_bytes = sizeof(double) * seirls::lds_doubles<Vern7Tab>() + 16;
-        *fac_doubles_per_block = seirls::fac_doubles_per_block<Vern7Tab>();
-    } else {
-        *kern = seirls::seir_ls_adj_kernel<Tsit5Tab>;
-        *lds_bytes = sizeof(double) * seirls::lds_doubles<Tsit5Tab>() + 16;
-        *fac_doubles_per_block = seirls::fac_doubles_per_block<Tsit5Tab>();
-    }
 }
 
 // the runtime-shape instance of the second-generation kernel: any exposure-UDE chain 3 -> H1 -> H2 -> 1 (tanh, tanh, identity), H1, H2 <= 64,

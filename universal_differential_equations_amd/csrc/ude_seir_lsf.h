@@ -53,25 +53,9 @@ using seirls::OFF_B2;
 using seirls::OFF_W3;
 using seirls::OFF_B3;
 
-#ifndef UDE_LSF_PER_CU
-#define UDE_LSF_PER_CU 1   // resident blocks per compute unit (launch bounds AND grid size)
-#endif
-#ifndef UDE_LSF_W2_RELOAD
-#define UDE_LSF_W2_RELOAD (UDE_LSF_PER_CU > 1)
-#endif
-#ifndef UDE_LSF_DEFER_SMALL
-#define UDE_LSF_DEFER_SMALL 0   // 1: db2, dW1 | db1, dW3 of trip T are formed in trip T + 1 next to the first layer's tanh (measured: slower)
-#endif
-#ifndef UDE_LSF_SMALL_VALU
-#define UDE_LSF_SMALL_VALU 0   // 1: db2, dW1 | db1, dW3 are accumulated on the vector unit per SLOT COLUMN, in the registers of the lane that
-#endif                         //    holds (units 4kq .. 4kq+3, slot jc), and the sixteen columns are added at the end instead of by 12 more MFMAs
-                               //    per trip -- measured (round 5): 5.80 against 5.66 ms (the matrix pipe has the slack, the vector unit has not): not kept
-#ifndef UDE_LSF_W2_EARLY
-#define UDE_LSF_W2_EARLY 0      // (with W2_RELOAD) 1: W2's fragment is requested in front of barrier 1 instead of behind it
-#endif
-#ifndef UDE_LSF_PREFETCH
-#define UDE_LSF_PREFETCH 1   // the record of the next-lower forward interval is fetched one interval ahead (16 registers per lane)
-#endif
+// (round 5 measured four variants of this kernel and kept none -- two blocks per CU with W2 re-fetched every trip, the small products deferred
+//  into the next trip, the small products on the vector unit, W2 requested in front of barrier 1: profiles/r05_experiments.md, HISTORY.md;
+//  their branches are gone from this source since round 6)
 
 enum { PH_IDLE = -4, PH_FLUSH = -3, PH_INIT0 = -2, PH_INIT1 = -1 };   // >= 0: stage s of a step attempt
 
@@ -85,7 +69,7 @@ constexpr int lds_doubles() {
 // udecore.hip's seir_gen_ls_shape admits), weights zero-padded to 64 x 64, every product of the network in the association of ITS length (ude_seir_ls2.h); the block's
 // accumulators hold the padded 64 x 64 gradient (a padded unit has delta = 0 and a = 0: exact zeros), written through the runtime offsets
 template <class Tab, bool GEN = false>
-__global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(const KParams p, double* __restrict__ /*unused: no factor workspace*/,
+__global__ void __launch_bounds__(BLOCKT, 1) seir_lsf_adj_kernel(const KParams p, double* __restrict__ /*unused: no factor workspace*/,
                                                                               int* __restrict__ /*unused: no queue*/) {
     constexpr int S = Tab::S, NK = Tab::NK;
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -124,29 +108,22 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     // the adjacent-pair tree of the input cotangent are in-lane, the next two are two lane exchanges, the last two cross the wavefronts
     // through 192 words of LDS -- no [slot][row] product tiles (25 KB) ----
     const int urow = 16 * w + 4 * (jc & 3) + (jc >> 2);   // the unit whose weights this lane supplies as A-operand row jc
-    // the two A-operand fragments of W2 (32 doubles per lane).  UDE_LSF_W2_RELOAD = 1: fetched again in every trip, W2 at the start
-    // of the matrix phase (the first layer's tanh covers the latency), W2^T behind the hidden layer -- 35 KB that every block reads
-    // and that stay in L2; 64 registers per lane that are only occupied while the fragment is in use
+    // the two A-operand fragments of W2 and of W2^T (2 x 32 doubles per lane), resident in registers for the whole launch
     // layer widths and the offsets of theta = [W1 (H1 x 3) | b1 | W2 (H2 x H1) | b2 | W3 (1 x H2) | b3] (column-major)
     const int H1 = GEN ? p.mc.dims[1] : H, H2 = GEN ? p.mc.dims[2] : H;
     const int oW1 = GEN ? 0 : OFF_W1, oB1 = GEN ? 3 * H1 : OFF_B1, oW2 = GEN ? oB1 + H1 : OFF_W2, oB2 = GEN ? oW2 + H1 * H2 : OFF_B2,
               oW3 = GEN ? oB2 + H2 : OFF_W3, oB3 = GEN ? oW3 + H2 : OFF_B3;
     const bool blk_fwd = H1 == H, blk_bwd = H2 == H;   // a 64-term product: four 16-term chains; a shorter one: ONE ascending chain
-#if !UDE_LSF_W2_RELOAD
     double W2A[16], W2T[16];
     static_for<0, 16>([&](auto sc) {
         const int col = 4 * decltype(sc)::value + kq;
         W2A[sc] = (!GEN || (urow < H2 && col < H1)) ? th[oW2 + urow + col * H2] : 0.0;      // A[i][k] = W2[unit(i)][4s + k]
         W2T[sc] = (!GEN || (col < H2 && urow < H1)) ? th[oW2 + col + urow * H2] : 0.0;      // A[i][k] = W2[4s + k][unit(i)]
     });
-#else
-    static_assert(!GEN, "the runtime-shape instance keeps W2's fragments resident");
-#endif
     const double W1A = (!GEN || urow < H1) ? (kq < 3 ? th[oW1 + urow + kq * H1] : th[oB1 + urow]) : 0.0;
     for (int i = tid; i < 3 * H; i += BLOCKT) W1L[i] = (!GEN || (i % H) < H1) ? th[oW1 + (i % H) + (i / H) * H1] : 0.0;
     if (tid < H) { B2L[tid] = (!GEN || tid < H2) ? th[oB2 + tid] : 0.0; W3L[tid] = (!GEN || tid < H2) ? th[oW3 + tid] : 0.0; }
     const int u0r = 16 * w + 4 * kq;          // first of this lane's four units
-#if UDE_LSF_PER_CU == 1   // (512 registers per lane: b2 and w3 of this lane's units stay in registers; two blocks per CU: read from LDS)
     double b2r[4], w3r[4];
     static_for<0, 4>([&](auto r) {
         const int un = u0r + decltype(r)::value;
@@ -155,26 +132,15 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     });
 #define LSF_B2(r) b2r[r]
 #define LSF_W3(r) w3r[r]
-#else
-#define LSF_B2(r) B2L[u0r + r]
-#define LSF_W3(r) W3L[u0r + r]
-#endif
     const double Fc = p.mc.consts[0], b0c = p.mc.consts[1], muc = p.mc.consts[4], sgc = p.mc.consts[5], gac = p.mc.consts[6],
                  dc = p.mc.consts[7], lac = p.mc.consts[8];
     // every column finite from the first trip on (a column without an evaluation multiplies its zero weight with what the tiles hold)
     for (int i = tid; i < 4 * H * TLD; i += BLOCKT) T_A1[i] = 0.0;
     if (tid < 2 * XSZ) XIN0[tid] = ((tid % XSZ) >= 48 && (tid % XSZ) < 64) ? 1.0 : 0.0;
     if (tid < 16) MB3[tid] = 0.0;
-#if UDE_LSF_DEFER_SMALL
-    int par = 0;                              // parity of the trip
-    double* XIN = XIN0;
-    double* D3S = XIN + 4 * 16;
-    double* WSL = D3S + 16;
-#else
     double* const XIN = XIN0;
     double* const D3S = XIN + 4 * 16;
     double* const WSL = D3S + 16;
-#endif
     for (int i = tid; i < 16 * 16; i += BLOCKT) TB[i] = tab->A[i >> 4][i & 15];
     if (tid < 16) { TB[256 + tid] = tab->B[tid]; TB[272 + tid] = tab->BT[tid]; TB[288 + tid] = tab->C[tid]; }
     for (int i = tid; i < NSLOTS * 8; i += BLOCKT) { YS[i] = 0.0; F0L[i] = 0.0; }
@@ -186,12 +152,6 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     static_for<0, 4>([&](auto c) { gW2[c] = v4d{0.0, 0.0, 0.0, 0.0}; });
     gB2 = v4d{0.0, 0.0, 0.0, 0.0}; gW1 = gB2; gW3 = gB2;
     double mb3 = 0.0;   // (row view, lane 0 of the slot's row) db3 share of this slot: fma(-(w d3), 1, mb3)
-#if UDE_LSF_SMALL_VALU
-    // the small parameters per slot column: one chain per (unit, slot column) -- a single trajectory lives in one column, so its chain IS
-    // the oracle's; the columns are added in column order at the end (a different association of the sum over trajectories: <= 1e-12)
-    double mB2[4], mW3[4], mB1[4], mW1[3][4];
-    static_for<0, 4>([&](auto r) { mB2[r] = 0.0; mW3[r] = 0.0; mB1[r] = 0.0; mW1[0][r] = 0.0; mW1[1][r] = 0.0; mW1[2][r] = 0.0; });
-#endif
 
     // ---- per-slot state on the slot's row: component c on lane c ----
     const OptsR o(p.o);
@@ -211,15 +171,12 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
     const double* const ksl = krec + 3 + (lm < NC ? lm : NC - 1);
     double* const kl = KL + (size_t)slot * S * 8 + (lm < NC ? lm : 7);   // K[j] of this lane's component at kl[8 j]
     double* const f0l = F0L + slot * 8;
-#if UDE_LSF_PREFETCH
     double pf[NPF];
     int pf_s = -1, pf_want = -1;
     static_for<0, NPF>([&](auto i) { pf[i] = 0.0; });
-#endif
     const double* cot = p.cot;
     size_t cot_si = 0, cot_sc = 0;
 
-#if UDE_LSF_PREFETCH
     auto fetch_interval = [&](int s) {
         pf_s = s;
         const double* base = dense_rec<true>(p, s, nfld, gid);
@@ -236,18 +193,6 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
         te = krec[1];
         pf_want = s - 1;   // fetched inside the matrix phase
     };
-#else
-    auto load_interval = [&](int s) {
-        sf = s;
-        const double* base = dense_rec<true>(p, s, nfld, gid);
-        static_for<0, NPF>([&](auto i) {
-            const int f = lm + 16 * (int)decltype(i)::value;
-            krec[f] = base[f < nfld ? f : 0];
-        });
-        ts = krec[0];
-        te = krec[1];
-    };
-#endif
     auto bcast = [&](double ownv, double (&out)[NC]) { static_for<0, NC>([&](auto c) { out[c] = rshfl(ownv, decltype(c)::value); }); };
     auto SV = [&](int i) { return p.saveat[i]; };
     auto tstop_from_cur = [&]() { return (cur >= 0 && SV(cur) > T0) ? SV(cur) : T0; };
@@ -307,9 +252,7 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                 if (p.cot_in) { cot = p.cot_in + (size_t)gid * p.ns * n; cot_si = n; cot_sc = 1; }
                 else { cot = p.cot + gid; cot_si = (size_t)n * p.Npad; cot_sc = p.Npad; }
                 nsteps = p.dense_n[gid];
-#if UDE_LSF_PREFETCH
                 pf_s = -1; pf_want = -1;
-#endif
                 cur = p.ns - 1;
                 zo = 0.0;
                 t = TF; qold = o.qoldinit; q11 = 1.0; accept = true; iter = 0; ret = RET_SUCCESS; replay = false;
@@ -415,29 +358,15 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
             D3S[slot] = 0.0;
             WSL[slot] = 0.0;
         }
-#if UDE_LSF_W2_RELOAD
-        const double* thw = th + OFF_W2;
-        asm volatile("" : "+s"(thw));   // (a fresh pointer every trip: the loads below must not be hoisted out of the loop)
-        double W2A[16];
-#if UDE_LSF_W2_EARLY
-        static_for<0, 16>([&](auto sc) { W2A[sc] = thw[urow + (4 * (int)decltype(sc)::value + kq) * H]; });
-#endif
-#endif
         LSF_TICK(1)
         if (!__syncthreads_or(ph != PH_IDLE)) break;   // (all slots idle, no trajectory left: done)
         LSF_TICK(2)
         {
-#if UDE_LSF_W2_RELOAD && !UDE_LSF_W2_EARLY
-            static_for<0, 16>([&](auto sc) { W2A[sc] = thw[urow + (4 * (int)decltype(sc)::value + kq) * H]; });
-#endif
             // layer 1 (3 inputs + bias in one k-step)
             v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(W1A, XIN[kq * 16 + jc], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
             // the small products of the PREVIOUS trip's parameter cotangent (db2, dW1 | db1, dW3: 12 MFMAs whose operands -- the delta2,
             // delta1, a2 tiles and the other copy of the slots' inputs -- are untouched until the next barrier): the matrix pipe works
             // on them while the vector unit evaluates the four tanh below
-#if UDE_LSF_DEFER_SMALL
-            small_products(XIN0 + (1 - par) * XSZ);
-#endif
             double a1[4], dv1[4];
             static_for<0, 4>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
@@ -446,13 +375,8 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
             });
             __syncthreads();
             LSF_TICK(3)
-#if UDE_LSF_PREFETCH
             if (pf_want >= 0) { fetch_interval(pf_want); pf_want = -1; }
-#endif
             // hidden layer: four 16-term chains (four MFMAs each) added left to right
-#if UDE_LSF_W2_RELOAD
-            double W2T[16];
-#endif
             {
                 v4d acc[4];
                 if (!GEN || blk_fwd) {
@@ -471,27 +395,14 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                         acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(W2A[s], T_A1[(4 * s + kq) * TLD + jc], acc[0], 0, 0, 0);
                     });
                 }
-#if UDE_LSF_W2_RELOAD
-                // (W2's fragment has had its last use: the registers take W2^T, the four tanh below cover the latency)
-                static_for<0, 16>([&](auto sc) { W2T[sc] = thw[(4 * (int)decltype(sc)::value + kq) + urow * H]; });
-#endif
                 const double d3j = D3S[jc];
-#if UDE_LSF_SMALL_VALU
-                const double wj = WSL[jc];
-                const double c3 = -(wj * d3j);
-#endif
                 static_for<0, 4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     const double z2 = ((!GEN || blk_fwd) ? (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) : acc[0][r]) + LSF_B2(r);
                     const double a2 = dtanh(z2);
                     const double d2 = __builtin_fma(LSF_W3(r), d3j, 0.0) * __builtin_fma(-a2, a2, 1.0);
                     T_D2[(u0r + r) * TLD + jc] = d2;
-#if UDE_LSF_SMALL_VALU
-                    mB2[r] = __builtin_fma(-(wj * d2), 1.0, mB2[r]);
-                    mW3[r] = __builtin_fma(c3, a2, mW3[r]);
-#else
                     T_A2[(u0r + r) * TLD + jc] = a2;
-#endif
                 });
             }
             __syncthreads();
@@ -520,13 +431,7 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                     constexpr int r = decltype(rc)::value;
                     const double s1 = (!GEN || blk_bwd) ? (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) : acc[0][r];
                     dv1[r] = s1 * __builtin_fma(-a1[r], a1[r], 1.0);
-#if UDE_LSF_SMALL_VALU
-                    const double c1 = -(WSL[jc] * dv1[r]);
-                    mB1[r] = __builtin_fma(c1, 1.0, mB1[r]);
-                    static_for<0, 3>([&](auto mc) { mW1[mc][r] = __builtin_fma(c1, XIN[decltype(mc)::value * 16 + jc], mW1[mc][r]); });
-#else
                     T_D1[(u0r + r) * TLD + jc] = dv1[r];
-#endif
                 });
                 // input cotangent: rounded products W1[u][m] delta1[u] under the adjacent-pair tree over the 64 units
                 static_for<0, 3>([&](auto mc) {
@@ -552,17 +457,9 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
                     gW2[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad2, T_A1[(16 * c + jc) * TLD + k], gW2[c], 0, 0, 0);
                 });
             });
-#if !UDE_LSF_DEFER_SMALL && !UDE_LSF_SMALL_VALU
             small_products(XIN);
-#endif
         }
         __syncthreads();
-#if UDE_LSF_DEFER_SMALL
-        par = 1 - par;
-        XIN = XIN0 + par * XSZ;
-        D3S = XIN + 4 * 16;
-        WSL = D3S + 16;
-#endif
         LSF_TICK(6)
 
         // ---- D. the slot's row: state cotangent of this evaluation, then its state machine ----
@@ -738,9 +635,6 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
 #endif
     }
 
-#if UDE_LSF_DEFER_SMALL
-    small_products(XIN0 + (1 - par) * XSZ);   // (the last trip's)
-#endif
 #if defined(UDE_LSF_CLOCKS)
     if (p.trace && blockIdx.x == 0 && tid == 0) {
         for (int i = 0; i < 8; ++i) p.trace[i] = (double)tsec[i];
@@ -759,38 +653,12 @@ __global__ void __launch_bounds__(BLOCKT, UDE_LSF_PER_CU) seir_lsf_adj_kernel(co
             const int c1 = 16 * (int)decltype(cc)::value + jc;
             if (!GEN || (unit < H2 && c1 < H1)) row[oW2 + unit + c1 * H2] = gW2[cc][r];
         });
-#if !UDE_LSF_SMALL_VALU
         if (jc == 0 && (!GEN || unit < H2)) { row[oB2 + unit] = gB2[r]; row[oW3 + unit] = gW3[r]; }
         if (!GEN || unit < H1) {
             if (jc < 3) row[oW1 + unit + jc * H1] = gW1[r];
             if (jc == 3) row[oB1 + unit] = gW1[r];
         }
-#endif
     });
-#if UDE_LSF_SMALL_VALU
-    // the sixteen slot columns of the small parameters, added in column order: two passes of three quantities through the tiles' space
-    // ([quantity][unit][column]: 3 x 64 x 16 doubles)
-    static_for<0, 2>([&](auto pc) {
-        constexpr int ps = decltype(pc)::value;
-        __syncthreads();
-        static_for<0, 4>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            const int un = u0r + r;
-            T_A1[(0 * H + un) * 16 + jc] = ps == 0 ? mB2[r] : mW1[0][r];
-            T_A1[(1 * H + un) * 16 + jc] = ps == 0 ? mW3[r] : mW1[1][r];
-            T_A1[(2 * H + un) * 16 + jc] = ps == 0 ? mB1[r] : mW1[2][r];
-        });
-        __syncthreads();
-        if (tid < 3 * H) {
-            const int qn = tid / H, un = tid % H;
-            const double* v = T_A1 + (qn * H + un) * 16;
-            double sum = v[0];
-            for (int i = 1; i < 16; ++i) sum += v[i];
-            const int idx = ps == 0 ? (qn == 0 ? OFF_B2 + un : qn == 1 ? OFF_W3 + un : OFF_B1 + un) : OFF_W1 + un + qn * H;
-            row[idx] = sum;
-        }
-    });
-#endif
     if (tid == 0) {
         double s = MB3[0];
         for (int i = 1; i < NSLOTS; ++i) s += MB3[i];
