@@ -39,7 +39,8 @@ FLOPS = {"lv": (160.0, 550.0), "seir": (8744.0, 26000.0), "kpp": (0.87e6, 2.6e6)
 HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 # The roof that bounds each workload's dominant (backward) kernel -- `roofline.bound`:
 #   valu  the FP64 vector unit (78.6 TF): the LV kernels (5- and 32-wide layers stay on the vector unit, as north_star says)
-#   mfma  the FP64 / FP32 matrix cores: Fisher-KPP (78.6 TF), the deep-BSDE step (157.3 TF)
+#   mfma  the FP64 / FP32 matrix cores: the fast-mode lock-step kernels (78.6 TF), the deep-BSDE step (157.3 TF).  (Fisher-KPP: "valu" since round 6 --
+#         its network runs on the vector unit; on gfx950 the FP64 matrix instructions share the vector issue port and the 78.6 TF either way)
 #   hbm   the lock-step SEIR / neural-ODE backward kernels in parity mode: the parameter cotangent mu (np doubles per slot) lives in
 #         HBM and every step attempt reads the current column and writes the candidate -- 2 * np * 8 B per attempt, the algorithmic
 #         stream SURVEY.md 8(d) C3 names ("HBM in parity mode"); their flop fraction is reported beside it (`flop_frac`)
@@ -55,12 +56,12 @@ def kernel_within_step(entry):
     does not exceed the step it is part of (2 % for the clocks: HIP events against the host's wall clock)"""
     ks = [entry.get("kernel_ms") or 0.0, (entry.get("kernel_ms") or 0.0) + (entry.get("fwd_kernel_ms") or entry.get("bwd_kernel_ms") or 0.0)]
     return max(ks) <= 1.02 * entry["ms_per_step"]
-BOUND = {"lv_trained": "valu", "lv_tanh5": "valu", "lv_shape8": "valu", "seir_shape63": "hbm", "seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "mfma", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
+BOUND = {"lv_trained": "valu", "lv_tanh5": "valu", "lv_shape8": "valu", "seir_shape63": "hbm", "seir_fast": "mfma", "node_fast": "mfma", "lv_sat40k": "valu", "lv_sat160k": "valu", "lv_wave64": "valu", "lv": "valu", "lv_tanh32": "valu", "lv_discrete": "valu", "kpp": "valu", "hjb": "mfma", "seir": "hbm", "node": "hbm"}
 
 
 # `roofline.traffic` is NOT measured inside this run (PMC passes cannot run inside a timed bench): it is read from the committed
 # rocprofv3 --pmc summary of the same command and binary
-TRAFFIC_SOURCE = "from profiles/: FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes of this command (tools/prof_r05.sh), not a counter read of this run"
+TRAFFIC_SOURCE = "from profiles/: FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes of this command (tools/prof_r06.sh), not a counter read of this run"
 
 
 def mu_stream_bytes(stats, n_param):
@@ -78,9 +79,9 @@ def headline_roofline(a, fkey, achieved_tflops, bwd_s, stats, n_param):
         bound = "valu" if bound == "hbm" else bound   # (the wavefront-per-trajectory / fast / discrete kernels of seir and node)
     r = {"bound": bound, "kernel": roofline_kernel_name(a), "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": pmc_traffic(a), "traffic_source": TRAFFIC_SOURCE,
-         "note": "bound: valu = FP64 vector unit, mfma = FP64 matrix cores (both 78.6 TF on this part), hbm = 8 TB/s; algorithmic %g flop per "
+         "note": "bound: valu = FP64 vector unit, mfma = FP64 matrix cores (78.6 TF each, and on gfx950 ONE issue port: DESIGN.md 2b), hbm = 8 TB/s; algorithmic %g flop per "
                  "adjoint eval; traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of the kernel from the separate rocprofv3 --pmc passes of this "
-                 "command (profiles/r05_pmc_<workload>.md, tools/prof_r05.sh), null for non-default commands" % FLOPS[fkey][1]}
+                 "command (profiles/r06_pmc_<workload>.md, tools/prof_r06.sh), null for non-default commands" % FLOPS[fkey][1]}
     if bound == "hbm":
         gbps = mu_stream_bytes(stats, n_param) / bwd_s / 1e9
         r.update({"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
@@ -112,7 +113,8 @@ def roofline_kernel_name(a):
         return ("nodels2::node_ls2_adj_kernel (interpolating adjoint, 16 trajectories per block in lock-step), network on the FP64 matrix cores, "
                 "parameter-slot sums / controller on the FP64 vector unit")
     if a.workload == "kpp":
-        return BWD_KERNEL[a.sensealg] + ", FP64 matrix cores"
+        return BWD_KERNEL[a.sensealg] + (", FP64 vector unit (pointwise network, weights broadcast out of registers by DPP) + FP64 matrix cores (parameter "
+                                         "contraction): ONE issue port on gfx950, one 78.6 TF roof (DESIGN.md 2b)")
     return BWD_KERNEL[a.sensealg] + ", FP64 VALU (no MFMA: 5- and 64-wide layers stay on the vector unit)"
 
 
@@ -349,7 +351,7 @@ def cpu_baseline_hjb(theta_h, tol, seconds_target=15.0):
 
 def pmc_any(stem, kernel_prefix):
     """this round's PMC summary of a workload if it has been collected, else last round's"""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         v = pmc_traffic_file("%s_pmc_%s.md" % (rnd, stem), kernel_prefix)
         if v:
             return v
@@ -518,7 +520,7 @@ def quick_measure(name, device, steps=5, warmup=1):
         pm = "none"    # (no committed counter pass for these commands)
     out = {"workload": desc, "ms_per_step": ms, "evals_per_s": (nf_fwd + nf_bwd) / (ms * 1e-3), "dominant_kernel": kern, "kernel_ms": b,
            "fwd_kernel_ms": f, "bound": BOUND[name], "achieved_tflops": ach, "peak_tflops": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS,
-           "unit": "mfma-f64" if wl == "kpp" else ("mfma-f64 + valu-f64" if wl in ("seir", "node") else "valu-f64"), "failed_trajectories": int((ens.retcode != 0).sum().item()),
+           "unit": "valu-f64 + mfma-f64 (one issue port)" if wl == "kpp" else ("mfma-f64 + valu-f64" if wl in ("seir", "node") else "valu-f64"), "failed_trajectories": int((ens.retcode != 0).sum().item()),
            "traffic": pmc_any(pm, "`void " + kern + "<"), "setup_s": time.perf_counter() - t_setup}
     if name in LV_VARIANTS:
         per_wave = 1 if lanes == 64 else 64 // (lanes or 5)
@@ -559,7 +561,7 @@ def self_launch(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: the launcher's WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--traj", type=int, default=0, help="trajectories per GPU (0 = workload default)")
@@ -586,6 +588,8 @@ def main():
                     help="N > 1: transport of the one all-reduce per gradient: torch.distributed nccl, libudecore's RCCL binding, or libudecore's "
                          "one-shot cross-process P2P reducer (IPC windows, one kernel per rank, rank-ordered deterministic sum; no RCCL)")
     a = ap.parse_args()
+    if a.gpus is None:   # (advisor, round 5: `torchrun --nproc-per-node N bench.py` without --gpus runs as N ranks, as it did before round 5)
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     # `python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- the same
     # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` the driver uses, one process per GPU -- and pass its exit

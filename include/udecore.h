@@ -45,7 +45,10 @@ enum { UDE_SENSE_INTERPOLATING_ADJOINT = 0, UDE_SENSE_DISCRETE = 1,
         * is carried as a quadrature on the adjoint's accepted steps (mu += dt * sum_s b_s g_s): no per-parameter error
         * estimate, no candidate/commit (cheaper steps, not fewer).  Not the step sequence of upstream's InterpolatingAdjoint
         * (which keeps mu in the error norm) -- an opt-in; gradients agree with mode 0 to the solver tolerance.  Shared time
-        * grids only (per_trajectory = 0). */
+        * grids only (per_trajectory = 0).  On the SEIR exposure UDE / neural ODE at the default lanes_per_traj this mode is the block-level
+        * matrix-core accumulation (sixteen trajectories share one accumulator): a trajectory whose BACKWARD solve stops early cannot be
+        * taken out of the sum again, so a call in which one does returns grad_theta = NaN (every entry; beside UDE_ERR_TRAJECTORY and
+        * the infinite loss) -- never a gradient polluted by partial adjoints.  Forward failures are skipped before they contribute. */
        UDE_SENSE_INTERPOLATING_ADJOINT_FAST = 2,
        /* InterpolatingAdjoint(checkpointing = true), as store-u-only + recompute (SURVEY.md 8(b) `store dense|recompute`): the forward
         * pass keeps (t, t_end, dt, u) of every accepted step instead of u and all stage derivatives -- 1/(1 + stages) of the dense store
@@ -298,7 +301,7 @@ int ude_allreduce_grad_p2p(int32_t ndev, ude_comm* const* comms, double* const* 
  * creates a communicator with an exchange window in its own HBM and gets a 64-byte IPC handle; the host all-gathers the handles
  * (torch.distributed / MPI / Distributed.jl -- 64 bytes per rank, once) and connects; per gradient ONE kernel per rank: publish the
  * payload, add all ranks' payloads in rank order (peer reads over xGMI, system-scope flags; identical bits on every rank), write the
- * sum back.  n <= n_max <= 8192 doubles.  A peer that never arrives: the result is NaN after UDE_P2P_TIMEOUT_MS (default 5000) and
+ * sum back.  n <= n_max <= 16384 doubles.  A peer that never arrives: the result is NaN after UDE_P2P_TIMEOUT_MS (default 5000) and
  * ude_comm_p2p_status counts it -- never a hung GPU.  A timeout is STICKY: the rank stops publishing (its peers fail fast instead of
  * summing a payload of another call), every later call of that communicator yields NaN on the device and, once the host has seen the
  * count through ude_comm_p2p_status, UDE_ERR_TIMEOUT -- re-create the communicator.  Needs no librccl; needs fine-grained device memory
@@ -314,7 +317,8 @@ int ude_comm_p2p_status(ude_comm* comm, int32_t* timeouts);
 int ude_comm_p2p_disconnect(ude_comm* comm);
 
 /* Failure accounting of the most recent gradient call on this context (blocks on the context's stream): the number
- * of trajectories whose retcode is not Success.  Such trajectories contribute nothing to the gradient and the
+ * of trajectories whose retcode is not Success.  Such trajectories contribute nothing to the gradient (one exception, loud: in the
+ * block-level UDE_SENSE_INTERPOLATING_ADJOINT_FAST mode a BACKWARD failure makes grad_theta NaN, see there) and the
  * ensemble loss is +Inf (the reference's solve would abort / return an Inf loss), so a training loop can never
  * silently optimise a partial objective.  If any of them is a UDE_RET_DENSE_OVERFLOW and max_dense_steps is
  * automatic, *grown is set to 1 and the capacity is multiplied by 4: the caller repeats the call. */

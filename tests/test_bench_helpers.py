@@ -42,7 +42,7 @@ def test_roofline_bound_is_chosen_per_kernel():
     r = bench.headline_roofline(a, "lv", 2.0, 1.3e-3, stats, 87)
     assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - 2.0 / 78.6) < 1e-12
     r = bench.headline_roofline(_args(workload="kpp", alg="tsit5", waves=0, traj=0), "kpp", 8.0, 25e-3, stats, 466)
-    assert r["bound"] == "mfma"
+    assert r["bound"] == "valu"      # (round 6: the network on the vector unit; FP64 matrix instructions share its issue port and its 78.6 TF)
     r = bench.headline_roofline(_args(workload="seir", alg="tsit5", waves=0, traj=0), "seir", 5.5, 12e-3, stats, 4481)
     want = 4 * 43 * 2 * 4481 * 8 / 12e-3 / 1e9
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["achieved"] - want) < 1e-6 * want and r["peak"] == 8000.0

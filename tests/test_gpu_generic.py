@@ -377,6 +377,14 @@ def test_runtime_shape_exposure_chain_on_the_lockstep_matrix_core_kernel(dims, a
         w64 = U.loss_and_gradient(ens, alg(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=U.EnsembleMI355(lanes_per_traj=64))
         assert_bitwise(r.grad_u0, w64.grad_u0, "lock-step vs wavefront-per-trajectory: dL/du0")
         assert_bitwise(r.stats, w64.stats, "lock-step vs wavefront-per-trajectory: counts")
+        if dims in ([3, 64, 63, 1], [3, 32, 40, 1]) and N == 21:
+            # an EXPLICIT lanes_per_traj = 16 (the lock-step request; advisor, round 5: it used to end in "no kernel instance ...
+            # lanes_per_traj 16" for a runtime-shape chain): the same kernels the default selects -- or, for an excluded shape, the
+            # wavefront-per-trajectory ones --, the same bits
+            w16 = U.loss_and_gradient(ens, alg(), truth, row_mask=mask, saveat=t, abstol=1e-6, reltol=1e-6, ensemblealg=U.EnsembleMI355(lanes_per_traj=16))
+            assert_bitwise(r.grad_u0, w16.grad_u0, "lanes_per_traj = 16: dL/du0")
+            assert_bitwise(r.stats, w16.stats, "lanes_per_traj = 16: counts")
+            assert_bitwise(r.grad_theta, w16.grad_theta, "lanes_per_traj = 16: dL/dtheta")
         gn = np.linalg.norm(ref["grad_theta"])
         if N == 1:
             assert_bitwise(r.grad_theta, ref["grad_theta"], "dL/dtheta %s" % dims)

@@ -1,5 +1,5 @@
 """The committed evidence under profiles/ is self-consistent: the bench line of a workload and the rocprofv3 kernel trace of the same
-command (tools/prof_r05.sh writes both in one pass) agree on the dominant kernel's average duration -- the roofline numerator of
+command (tools/prof_r06.sh writes both in one pass) agree on the dominant kernel's average duration -- the roofline numerator of
 the bench line (HIP events inside bench.py) can be reproduced from the trace the judge reads."""
 import json
 import os
@@ -18,7 +18,7 @@ CASES = {"lv": ("adj_kernel<", "bwd_kernel_ms"), "lv_discrete": ("dadj_kernel<",
          # the run-time-shape lines (edited networks): kernel trace + bench line, no counter passes
          "lv_tanh5": ("adj_kernel<", "bwd_kernel_ms"), "lv_shape8": ("adj_kernel<", "bwd_kernel_ms"),
          "seir_shape63": ("seirls2::seir_ls2_adj_kernel<", "bwd_kernel_ms")}
-ROUND = "r05" if os.path.exists(os.path.join(P, "r05_bench_lv.json")) else "r04"
+ROUND = "r06" if os.path.exists(os.path.join(P, "r06_bench_lv.json")) else "r05"
 
 
 def trace_avg_us(path, prefix):

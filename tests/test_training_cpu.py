@@ -45,3 +45,24 @@ def test_hagerzhang_flat_slopes_and_non_finite_objectives_do_not_raise():
         return (float("inf"), float("nan")) if al > 2.0 else (1.0 - 0.4 * al, -0.4)
     a, p = training.hagerzhang(wall, 1.0, 1.0, -0.4)
     assert 0.0 <= a <= 2.0 and np.isfinite(p) and len(calls) < 60 * 64
+
+
+def test_hagerzhang_expansion_against_a_wall_of_non_finite_values_shrinks_alphamax():
+    """LineSearches.jl's bracket phase when the objective is not finite beyond some step (a solve that diverges for a too-long step):
+    the expansion c <- 5 c lands behind the wall, is pulled back by bisection towards the last good point, and EVERY non-finite point
+    found becomes the search's alphamax: a later expansion is clamped to it (upstream's `alphamax = c` inside the loop; without it the
+    next expansion probes 5 c again -- other trial points, another BFGS trajectory).  phi(a) = -a for a < 3.9, +inf behind: from c = 1
+    upstream's sequence of trial points is 1, 5 (inf), 3 (finite, downhill), then min(15, alphamax = 5) = 5 (inf), 4 (inf), 3.5, ...;
+    the search must return a finite point below the wall with a lower value than every earlier one and never evaluate beyond 5."""
+    from universal_differential_equations_amd.training import hagerzhang
+    seen = []
+
+    def phidphi(a):
+        seen.append(a)
+        return (-a, -1.0) if a < 3.9 else (float("inf"), float("nan"))
+
+    alpha, phi = hagerzhang(phidphi, 1.0, 0.0, -1.0)
+    assert seen[:3] == [1.0, 5.0, 3.0]
+    assert seen[3] == 5.0 and seen[4] == 4.0 and seen[5] == 3.5          # clamped to the shrunken alphamax, then bisected towards 3
+    assert max(seen) == 5.0                                              # never beyond the first point found non-finite
+    assert np.isfinite(phi) and 3.0 <= alpha < 3.9 and phi == -alpha

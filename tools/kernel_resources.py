@@ -3,7 +3,7 @@
 
 `build.py` compiles every translation unit with `-Rpass-analysis=kernel-resource-usage` and keeps the remarks in
 `universal_differential_equations_amd/build/<unit>.log`.  This tool turns them into the table DESIGN.md cites
-(`profiles/r05_kernel_resources.md`): the numbers in the documentation are the numbers of the objects that were linked, not typed.
+(`profiles/r06_kernel_resources.md`): the numbers in the documentation are the numbers of the objects that were linked, not typed.
 
     tools/kernel_resources.py <log>                 one log, all kernels (developer use)
     tools/kernel_resources.py --table [--write]     the table of the dominant kernels of every workload (stdout, or the committed file)
@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "universal_differential_equations_amd", "build")
-TABLE = os.path.join(ROOT, "profiles", "r05_kernel_resources.md")
+TABLE = os.path.join(ROOT, "profiles", "r06_kernel_resources.md")
 KEYS = ("VGPRs:", "AGPRs:", "ScratchSize [bytes/lane]:", "Occupancy [waves/SIMD]:", "SGPRs:", "LDS Size [bytes/block]:", "VGPRs Spill:")
 
 # (workload, build log, glob of the demangled kernel name): the kernels bench.py's lines and DESIGN.md talk about
@@ -28,18 +28,17 @@ ROWS = [
     ("lv_shape8 adjoint (run-time shapes on 8-lane groups)", "ude_inst_lv_rt4_g8_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("lv_wave64 adjoint (runtime shapes)", "ude_inst_generic_2_l4_g64_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("seir forward (lock-step)", "ude_seir_ls.log", "seir_ls_fwd_kernel<Vern7Tab, false>*"),
-    ("seir adjoint, parity mode (lock-step, second generation: the shipped one)", "ude_seir_ls.log", "seir_ls2_adj_kernel<Vern7Tab, false>*"),
-    ("seir adjoint, parity mode (lock-step, round-3/4 kernel: not selected)", "ude_seir_ls.log", "seir_ls_adj_kernel<Vern7Tab>*"),
+    ("seir adjoint, parity mode (lock-step, second generation)", "ude_seir_ls.log", "seir_ls2_adj_kernel<Vern7Tab, false>*"),
     ("runtime-shape exposure chain 3-H1-H2-1, forward (lock-step, GEN)", "ude_seir_ls.log", "seir_ls_fwd_kernel<Vern7Tab, true>*"),
     ("runtime-shape exposure chain 3-H1-H2-1, adjoint (lock-step, GEN)", "ude_seir_ls.log", "seir_ls2_adj_kernel<Vern7Tab, true>*"),
     ("seir adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_seir_lsf.log", "seir_lsf_adj_kernel<Vern7Tab, false>*"),
     ("runtime-shape exposure chain 3-H1-H2-1, adjoint, fast mode (lock-step, GEN)", "ude_seir_lsf.log", "seir_lsf_adj_kernel<Vern7Tab, true>*"),
     ("node forward (lock-step)", "ude_node_ls.log", "node_ls_fwd_kernel<Vern7Tab>*"),
-    ("node adjoint, parity mode (lock-step, second generation: the shipped one)", "ude_node_ls.log", "node_ls2_adj_kernel<Vern7Tab>*"),
-    ("node adjoint, parity mode (lock-step, round-3/4 kernel: not selected)", "ude_node_ls.log", "node_ls_adj_kernel<Vern7Tab>*"),
+    ("node adjoint, parity mode (lock-step, second generation)", "ude_node_ls.log", "node_ls2_adj_kernel<Vern7Tab>*"),
     ("node adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_node_lsf.log", "node_lsf_adj_kernel<Vern7Tab>*"),
-    ("kpp forward (1024 points)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "fwd_kernel<*false, double>"),
-    ("kpp adjoint (1024 points)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
+    ("kpp forward (1024 points; round 6: network on the vector unit, DPP-broadcast weights)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "fwd_kernel<*false, double>"),
+    ("kpp adjoint (1024 points; round 6: vector network + packed matrix-core contraction)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
+    ("kpp adjoint (1024 points), Vern7 (half-size transposition tile)", "ude_inst_kpp_ude_1024_g256_w1_vern7.log", "adj_kernel<*false, 1, double>"),
     ("kpp adjoint (1024 points), run-time-shape reaction network", "ude_inst_kpp_rt_1024_g256_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("hjb forward", "ude_hjb.log", "hjb_fwd_kernel*"),
     ("hjb backward", "ude_hjb.log", "hjb_bwd_kernel*"),

@@ -364,6 +364,10 @@ __device__ __forceinline__ uint64_t* p2p_flags(char* w, size_t nmax) { return (u
 __device__ __forceinline__ unsigned* p2p_timeouts(char* w, size_t nmax) { return (unsigned*)(p2p_flags(w, nmax) + 2); }
 __device__ __forceinline__ uint64_t* p2p_closed(char* w, size_t nmax) { return p2p_flags(w, nmax) + 8; }
 
+// elements per thread of the one-block reducer: 1024 x 16 = 16384 doubles (round 6: the neural ODE's payload, np + 4 = 9291, did not fit
+// the 8192 of round 4 -- found by the first eight-rank test that used the workloads' own payload sizes)
+constexpr int P2P_EPT = 16;
+
 __global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nranks, int rank, size_t nmax, uint64_t seq, double* buf, int64_t n,
                                                       unsigned long long timeout_ticks) {
     const int q = (int)(seq & 1);
@@ -384,8 +388,8 @@ __global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nr
     __shared__ int lost;
     if (threadIdx.x == 0) lost = 0;
     __syncthreads();
-    // (the sum of one element is kept in a register across the ranks: n <= blockDim.x * 8)
-    double acc[8];
+    // (the sum of one element is kept in a register across the ranks: n <= blockDim.x * P2P_EPT)
+    double acc[P2P_EPT];
     for (int r = 0; r < nranks; ++r) {
         if (threadIdx.x == 0) {
             const unsigned long long t0 = wall_clock64();
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nr
         if (lost) break;
         const double* slot = (const double*)peers[r] + (size_t)q * nmax;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < P2P_EPT; ++u) {
             const int64_t i = (int64_t)threadIdx.x + (int64_t)u * blockDim.x;
             if (i < n) {
                 const double v = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -413,7 +417,7 @@ __global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nr
     __syncthreads();
     const bool bad = lost != 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < P2P_EPT; ++u) {
         const int64_t i = (int64_t)threadIdx.x + (int64_t)u * blockDim.x;
         if (i < n) buf[i] = bad ? __builtin_nan("") : acc[u];
     }
@@ -426,6 +430,8 @@ __global__ void __launch_bounds__(1024) p2p_mp_kernel(char* const* peers, int nr
 __global__ void p2p_close_kernel(char* const* peers, int nranks, int rank, size_t nmax, unsigned long long timeout_ticks, int* incomplete) {
     if (threadIdx.x != 0) return;
     __threadfence_system();
+    // (a peer that already ran its own disconnect into the timeout may have FREED its window; this rank's mapping of it -- opened with
+    //  hipIpcOpenMemHandle, closed only after this kernel -- keeps the pages alive, so the store below lands in mapped memory either way)
     for (int r = 0; r < nranks; ++r)
         __hip_atomic_store(p2p_closed(peers[r], nmax) + rank, (uint64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     char* mine = peers[rank];
@@ -451,22 +457,28 @@ static int p2p_disconnect_impl(ude_comm* m) {
     ude_ctx* c = m->ctx;
     P2PMp& mp = *m->mp;
     if (mp.disconnected) return UDE_OK;
-    mp.disconnected = true;
-    HIPCHK(c, hipSetDevice(c->device));
+    // (advisor, round 5) every exit of this function closes the peers' IPC mappings and frees the flag word; `disconnected` is set once
+    // that has happened -- an early return used to leave the peer mappings open behind a communicator that said it had disconnected
     int rc = UDE_OK;
-    if (mp.peer_dev && (int)mp.peer.size() == mp.nranks) {
-        int* flag = nullptr;
-        HIPCHK(c, hipMalloc((void**)&flag, sizeof(int)));
-        HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(p2p_close_kernel, dim3(1), dim3(64), 0, c->stream, (char* const*)mp.peer_dev, mp.nranks, mp.rank, mp.nmax, p2p_timeout_ticks(), flag);
+    int* flag = nullptr;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == UDE_OK) rc = fail(c, UDE_ERR_HIP, "ude_comm_p2p_disconnect: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    if (hip_ok(hipSetDevice(c->device), "hipSetDevice") && mp.peer_dev && (int)mp.peer.size() == mp.nranks) {
         int inc = 0;
-        (void)hipMemcpyAsync(&inc, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(flag);
-        if (inc) rc = fail(c, UDE_ERR_TIMEOUT, "ude_comm_p2p_disconnect: a peer did not reach its own disconnect within the timeout (it may still map this rank's window)");
+        if (hip_ok(hipMalloc((void**)&flag, sizeof(int)), "hipMalloc") && hip_ok(hipMemsetAsync(flag, 0, sizeof(int), c->stream), "hipMemsetAsync")) {
+            hipLaunchKernelGGL(p2p_close_kernel, dim3(1), dim3(64), 0, c->stream, (char* const*)mp.peer_dev, mp.nranks, mp.rank, mp.nmax, p2p_timeout_ticks(), flag);
+            hip_ok(hipGetLastError(), "launch of the close handshake");
+            hip_ok(hipMemcpyAsync(&inc, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
+            hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        }
+        if (inc && rc == UDE_OK) rc = fail(c, UDE_ERR_TIMEOUT, "ude_comm_p2p_disconnect: a peer did not reach its own disconnect within the timeout (it may still map this rank's window)");
     }
+    if (flag) (void)hipFree(flag);
     for (int r = 0; r < (int)mp.peer.size(); ++r)
         if (r != mp.rank && mp.peer[r]) { (void)hipIpcCloseMemHandle(mp.peer[r]); mp.peer[r] = nullptr; }
+    mp.disconnected = true;
     return rc;
 }
 
@@ -477,7 +489,7 @@ extern "C" int ude_comm_p2p_disconnect(ude_comm* m) {
 
 extern "C" int ude_comm_create_p2p(ude_ctx* c, int32_t nranks, int32_t rank, int64_t n_max, char handle_out[64], ude_comm** out) {
     if (!c || !out || !handle_out || nranks < 1 || rank < 0 || rank >= nranks || n_max <= 0) return UDE_ERR_INVALID;
-    if (n_max > 8 * 1024) return fail(c, UDE_ERR_UNSUPPORTED, "the cross-process P2P reducer is a one-block kernel: payloads up to 8192 doubles (np + 4 of every model of the reference fits)");
+    if (n_max > 1024 * P2P_EPT) return fail(c, UDE_ERR_UNSUPPORTED, "the cross-process P2P reducer is a one-block kernel: payloads up to 16384 doubles (np + 4 of every model of the reference fits: the largest is the neural ODE's 9291)");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     *out = nullptr;
     HIPCHK(c, hipSetDevice(c->device));

@@ -21,7 +21,9 @@ struct ude_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/end, bwd start/end
     bool ev_fwd = false, ev_bwd = false;
     // workspaces (grow on demand, reused across calls)
-    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs, slot_glob, nfail, tspan_pt, ls_fac;
+    DevBuf dense, dense_n, cot, loss_traj, grad_part, retcode, stats, trace, tabs, slot_glob, nfail, tspan_pt, ls_fac, perm, sort_ws, rowsum, prev_cost;
+    int64_t prev_cost_n = 0;     // cost-ordered launch: prev_cost holds the backward step attempts of the last such call (N members, signature below)
+    int64_t prev_cost_sig = 0;
     hipEvent_t ev_sync = nullptr;  // orders work across a change of the bound stream
     int ncu = 0;         // compute units of the device (queried once)
     int auto_cap = 256;  // dense-store capacity used when lo.max_dense_steps == 0; grows x4 on DenseOverflow (host-buffer path)

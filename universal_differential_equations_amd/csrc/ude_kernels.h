@@ -77,6 +77,11 @@ struct KParams {
     // theta): theta is np x N, member j reads theta + j * theta_pm, and the gradient is returned per member (grad_part = the
     // caller's np x N array, row j written by trajectory j's lanes; no sum over trajectories).  0 = one shared theta.
     int32_t theta_pm;
+    // cost-ordered launch of a multi-round ensemble (round 6, SURVEY.md 7 "sort / bucket trajectories by expected cost"): lane group g of
+    // the adjoint launch works on trajectory perm[g] (the forward launch is always the identity); the trajectories then write ONE
+    // GRADIENT ROW EACH (grad_part = N x np), which the finish kernel adds in TRAJECTORY order -- the sum does not depend on the
+    // permutation, two runs give the same bits whatever order the sort's atomics produced.  null: identity, one partial row per wavefront.
+    const int32_t* perm;
 };
 
 // Workspace layouts.  Replicated states -- the lanes of a wavefront belong to different trajectories -- keep the dense store and the
@@ -827,6 +832,9 @@ __global__ void __launch_bounds__(BLOCK) rhs_kernel(const KParams p) {
 // VAR: kernel variant of the instance (build.py's waves column).  It is a template parameter so that variants of one
 // (model, algorithm, lanes) are DIFFERENT kernels: a macro-only difference gives the same mangled name in several
 // translation units and the linker keeps one of them.  VAR == 9: timing experiment, lambda only (no mu work at all).
+template <class M, class = void> struct ks_stream_always { static constexpr bool v = false; };
+template <class M> struct ks_stream_always<M, std::void_t<decltype(M::KS_STREAM_ALWAYS)>> { static constexpr bool v = M::KS_STREAM_ALWAYS; };
+
 template <class Model, class Tab, int G, bool PT = false, int VAR = 1>
 struct AdjSys {
     TimeGrid<PT> tg;
@@ -871,7 +879,9 @@ struct AdjSys {
     static constexpr int IC_NR = (IC_LDS || CPL) ? 1 : NR;
     // KS_STREAM: a distributed state with more than 8 interpolation stages (Fisher-KPP with Vern7: 16 x 4 doubles per lane) does not
     // cache the interval's k in registers at all: every evaluation reads them from the dense store (coalesced, L2-resident)
-    static constexpr bool KS_STREAM = STATE_DISTRIBUTED && !CPL && Tab::NK > 8 && Tab::NK * NR > 32 && VAR != 5;
+    // (round 6: a model may ask for it whatever the stage count -- Model::KS_STREAM_ALWAYS: the Fisher-KPP vector kernel needs the 2 x NK x NR
+    //  registers of the cached interval for its activations and deltas)
+    static constexpr bool KS_STREAM = STATE_DISTRIBUTED && !CPL && ((Tab::NK > 8 && Tab::NK * NR > 32) || ks_stream_always<Model>::v) && VAR != 5;
     real ts, te, us[IC_NR], ks[(IC_LDS || KS_STREAM) ? 1 : Tab::NK][IC_NR];
     const real* kstore;   // KS_STREAM: field 0 of the current interval's record (this trajectory's column)
     real* ic;      // LDS: field f of this group at ic[f * icstride]
@@ -1164,7 +1174,13 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
     __syncthreads();
 
     constexpr int GROUPS = BLOCK / G;
-    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
+    // VAR == 6: the cost-ordered launch of a multi-round ensemble (KParams::perm; udecore.hip) -- lane group g works on member perm[g] and writes
+    // that member's own gradient row.  A kernel of its own: the default kernel's code is what it was (as a run-time branch the two extra
+    // loads moved the headline kernel's register allocation and cost it 4 %).
+    constexpr bool SORTED = (VAR == 6);
+    const int64_t gslot = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
+    int64_t gid = gslot;
+    if constexpr (SORTED) gid = gslot < p.N ? (int64_t)p.perm[gslot] : gslot;
     const int r = threadIdx.x % G;
     using Sys = AdjSys<Model, Tab, G, PT, VAR>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
@@ -1252,6 +1268,17 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
             }
             return;
         }
+    }
+    if constexpr (SORTED) {   // one gradient row per member, written by its own lanes; summed in member order afterwards (rows_chunk_sum_kernel)
+        static_assert(!SORTED || (!SG && !Model::DEFERRED), "cost-ordered launch: register-slot models");
+        if (in_range) {
+            real* row = p.grad_part + (size_t)gid * p.n_param;
+            for (int s = 0; s < NSL; ++s) {
+                const int idx = Model::slot_index(p.mc, r, s);
+                if (idx >= 0) row[idx] = mu_lds[(size_t)s * BLOCK];
+            }
+        }
+        return;
     }
     if constexpr (!pow2_group<G>()) {
         // mu already sits in LDS ([slot][thread]): lane r of group 0 adds the r-th lanes of all groups in ascending

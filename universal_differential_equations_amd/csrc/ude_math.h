@@ -170,7 +170,14 @@ __device__ __forceinline__ double dtanh(double x) {
     // argument: equal under the NaN-aware comparison of the tests); the exponent goes through exponent_of(), not a cast.
     const double ax = fabs(x);
     const bool small = !(ax >= 20.0);
+    // (round 6: z = 2|x| for EVERY argument.  The specification clamps z to 40 for |x| >= 20; those arguments' result is replaced by 1 at
+    //  the end whatever the arithmetic produced -- finite garbage, Inf or NaN, nothing traps --, so the clamp's select (two v_cndmask_b32 of
+    //  the ~44 instructions of a tanh, and every instruction is an issue slot: DESIGN.md 2b) changes no returned bit and is gone)
+#ifdef UDE_TANH_CLAMP   // (the round 1-5 form, for A/B builds)
     const double z = small ? ax + ax : 40.0;
+#else
+    const double z = ax + ax;
+#endif
     const double k = __builtin_rint(z * 1.4426950408889634);
     double r = __builtin_fma(-k, 0.6931471803691238, z);
     r = __builtin_fma(-k, 1.9082149292705877e-10, r);

@@ -157,6 +157,10 @@ struct KppUdeV : LinearTheta {
     static_assert(TPTS == 64 || TPTS == 32, "tile of 64 or 32 points");
     static constexpr int FWD_BLOCKS = NWV == 8 ? 2 : 1;
     using FwdModel = KppUdeV<Net, 8, TPTS_>;
+#ifndef UDE_KPPV_KS_STREAM
+#define UDE_KPPV_KS_STREAM 1
+#endif
+    static constexpr bool KS_STREAM_ALWAYS = UDE_KPPV_KS_STREAM != 0;   // (the interval's stage derivatives are read from the dense store at every evaluation: AdjSys::KS_STREAM)
     static constexpr bool DADJ_K_FROM_DENSE = true;
     static __host__ __device__ constexpr int point(int c, int r) { return (r >> 6) * BLK + c * TP + (r & 63); }
     static_assert(!Net::RT, "compile-time shapes (a run-time shape stays on KppUdeW)");
@@ -317,7 +321,7 @@ struct KppUdeV : LinearTheta {
 #define UDE_KPPV_CLK(i)   // (tools/exp/kpp_harness.hip defines it to stamp the phases of a pass)
 #endif
 #ifndef UDE_KPPV_PF
-#define UDE_KPPV_PF 2   // points per lane and pass of the forward-only evaluation
+#define UDE_KPPV_PF 1   // points per lane and pass of the forward-only evaluation (2: the same time, 244 B of scratch in fwd_kernel at two wavefronts per SIMD)
 #endif
     static __device__ __forceinline__ void rhs(const Ctx& c, const double* u, double* du) {
         const int n = c.n;

@@ -167,7 +167,13 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_lsf_adj_kernel(const KParams p
         }
         return mod;
     };
+    // a trajectory whose BACKWARD solve stops early has already added the stages it evaluated to the block's accumulators and cannot be
+    // taken out again: the block then reports NaN for its whole gradient row -- ude_last_failures' contract ("such trajectories
+    // contribute nothing to the gradient") cannot be kept in this mode, so the gradient is refused loudly instead of returned polluted
+    // (advisor, round 5; include/udecore.h documents it next to UDE_SENSE_INTERPOLATING_ADJOINT_FAST)
+    int bwd_failed = 0;
     auto results = [&]() {
+        if (ret != RET_SUCCESS) bwd_failed = 1;
         if (lm == 0) {
             if (p.stats) { int64_t* st = p.stats + (size_t)gid * 8; st[4] = nfc; st[5] = nacc; st[6] = nrej; }
             if (ret != RET_SUCCESS) p.retcode[gid] = ret;
@@ -556,6 +562,10 @@ __global__ void __launch_bounds__(BLOCKT, 1) node_lsf_adj_kernel(const KParams p
     if (lm < NOUT) MB4[slot * 8 + lm] = mb4;
     __syncthreads();
     double* row = p.grad_part + (size_t)blockIdx.x * p.n_param;
+    if (__syncthreads_or(bwd_failed)) {   // (block-uniform)
+        for (int i = tid; i < p.n_param; i += BLOCKT) row[i] = __builtin_nan("");
+        return;
+    }
     static_for<0, 4>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         const int unit = 16 * w + kq + 4 * r;    // accumulator rows are NOT permuted: tile row i = kq + 4r is unit 16w + i

@@ -12,6 +12,7 @@ struct Launch {
     void (*fwd_pt)(const KParams), (*adj_pt)(const KParams), (*dadj_pt)(const KParams);  // per-trajectory tspan / saveat
     void (*adj_fast)(const KParams);  // UDE_SENSE_FAST: lambda-only error control (shared time grid only)
     void (*adj_ckpt)(const KParams);  // checkpointed adjoint: store u only, recompute the stages (null: no such instance)
+    void (*adj_sorted)(const KParams);  // cost-ordered launch of a multi-round ensemble (KParams::perm; lane-group models only, else null)
     int nf;  // dense fields per step
     int G, block;
     int block_fwd;  // threads per block of the forward / rhs kernels (Model::FWD_BLOCK_THREADS or Model::FwdModel; else = block)
@@ -73,6 +74,10 @@ inline Launch make_launch() {
     if constexpr (!Model::STATE_DISTRIBUTED || (recompute_ok<Model>::v && (Tab::NK * Model::NS <= 32 || (Tab::FSAL && Tab::NK == Tab::S))))
         l.adj_ckpt = adj_kernel<Model, Tab, G, BLOCK, false, 5>;
     else l.adj_ckpt = nullptr;
+    // cost-ordered launch: models with several members per wavefront and their parameter slots in registers (the LV family on 4 .. 32 lanes)
+    if constexpr (G < 64 && BLOCK == 64 && !Model::STATE_DISTRIBUTED && !Model::SLOTS_GLOBAL && !Model::DEFERRED && VAR == 1)
+        l.adj_sorted = adj_kernel<Model, Tab, G, BLOCK, false, 6>;
+    else l.adj_sorted = nullptr;
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;

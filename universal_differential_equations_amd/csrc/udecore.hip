@@ -444,6 +444,160 @@ static int default_lanes(int mid, bool discrete) {
     return 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cost-ordered adjoint launch (round 6; SURVEY.md 7, "hard parts": sort / bucket trajectories by expected cost).  The trajectories of a
+// wavefront make their backward step attempts together: a wavefront runs as long as its slowest trajectory (lane_step_util 0.82 on
+// the LV ensembles), and a launch of several rounds of wavefronts additionally ends with whatever round happens to hold the slowest
+// ones.  The cost of a backward solve is not known in advance; what the forward pass already knows and what predicts it best is the
+// trajectory's own LOSS (the data misfit sets the size of the cotangent jumps; on the LV ensemble: correlation 0.81 with the backward
+// attempts, lock-step utilisation 0.82 -> 0.93 when the wavefronts are filled in that order; the forward step count -- 26 or 27 for every
+// member -- predicts nothing).  Counting sort by a logarithmic key (16 buckets per octave), most expensive first; the order INSIDE a bucket
+// is whatever the atomics produce -- harmless, because in this mode every trajectory writes its own gradient row and the rows are added
+// in trajectory order (KParams::perm).
+// the N gradient rows of a cost-ordered launch, first level of their sum: block (x, y) adds rows [y * chunk, (y + 1) * chunk) of 32 adjacent
+// columns (coalesced 256-byte reads; fixed order: 32 row-lanes striding the chunk, then the 32 partials left to right) into out[y][col];
+// the finish kernel adds the chunk rows.  Every association is fixed by (N, chunk) alone -- not by the permutation.
+constexpr int ROWSUM_CHUNK = 1024;
+__global__ void __launch_bounds__(1024) rows_chunk_sum_kernel(const double* part, int64_t nrows, int32_t ncols, double* out) {
+    __shared__ double sh[32][33];
+    const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    const int cc = col < ncols ? col : ncols - 1;
+    const int64_t r0 = (int64_t)blockIdx.y * ROWSUM_CHUNK, r1 = r0 + ROWSUM_CHUNK < nrows ? r0 + ROWSUM_CHUNK : nrows;
+    double s = 0.0;
+    for (int64_t w0 = r0 + ry; w0 < r1; w0 += 32 * 8) {
+        double pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t w = w0 + 32 * u;
+            pv[u] = part[(size_t)(w < r1 ? w : r0) * ncols + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (w0 + 32 * u < r1) s += pv[u];
+    }
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < ncols) {
+        double t = sh[0][cx];
+        for (int q = 1; q < 32; ++q) t += sh[q][cx];
+        out[(size_t)blockIdx.y * ncols + col] = t;
+    }
+}
+
+constexpr int SORT_BUCKETS = 4096;
+__device__ __forceinline__ int cost_bucket(double loss) {
+    // positive doubles order like their bit patterns: exponent and the top four mantissa bits, 2^-64 .. 2^192 mapped onto 0 .. 4095;
+    // NaN / Inf (a failed forward solve: the adjoint kernel skips it) land in the last bucket
+    const long long b = (long long)(__double_as_longlong(loss > 0.0 ? loss : 0.0) >> 48) - ((1023LL - 64) << 4);
+    return b < 0 ? 0 : b >= SORT_BUCKETS ? SORT_BUCKETS - 1 : (int)b;
+}
+// key of member i: its backward step attempts in the previous call on the same ensemble where the context has them (a training loop calls
+// again and again with slowly moving parameters: lock-step utilisation 0.999 when sorted by them), else the bucket of its loss
+__device__ __forceinline__ int cost_key(const double* loss_traj, const int32_t* prev, int64_t i) {
+    if (prev) { const int a = prev[i]; return a < 0 ? 0 : a >= SORT_BUCKETS ? SORT_BUCKETS - 1 : a; }
+    return cost_bucket(loss_traj[i]);
+}
+__global__ void sort_hist_kernel(const double* loss_traj, const int32_t* prev, int64_t N, int32_t* hist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) atomicAdd(&hist[cost_key(loss_traj, prev, i)], 1);
+}
+// exclusive prefix sums over the buckets in DESCENDING key order (one block of 1024 threads, four buckets each).  With keys that ARE costs
+// (the previous call's attempt counts) the block also decides whether sorting can pay at all: an ensemble whose members all cost the same
+// (spread of the keys within 1/16 of their mean: the 2-8-8-8-2 tanh ensemble of `lv_shape8` has lane_step_util 0.9995) keeps the identity
+// order -- a permuted launch reads its members' workspace columns scattered, which costs the latency-bound LV kernels 7 % (measured).
+__global__ void __launch_bounds__(1024) sort_scan_kernel(const int32_t* hist, int32_t* offset, int keys_are_costs) {
+    __shared__ int sh[1024];
+    __shared__ long long shw[1024];
+    __shared__ int shlo[1024], shhi[1024];
+    const int t = threadIdx.x;
+    int v[4], s = 0, lo = SORT_BUCKETS, hi = -1;
+    long long wsum = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int b = SORT_BUCKETS - 1 - (4 * t + q);
+        v[q] = hist[b];
+        s += v[q];
+        wsum += (long long)v[q] * b;
+        if (v[q] > 0) { lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
+    }
+    sh[t] = s; shw[t] = wsum; shlo[t] = lo; shhi[t] = hi;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int x = t >= d ? sh[t - d] : 0;
+        const long long xw = t >= d ? shw[t - d] : 0;
+        const int xl = t >= d ? shlo[t - d] : SORT_BUCKETS, xh = t >= d ? shhi[t - d] : -1;
+        __syncthreads();
+        sh[t] += x; shw[t] += xw; shlo[t] = xl < shlo[t] ? xl : shlo[t]; shhi[t] = xh > shhi[t] ? xh : shhi[t];
+        __syncthreads();
+    }
+    int base = sh[t] - s;
+    for (int q = 0; q < 4; ++q) { offset[SORT_BUCKETS - 1 - (4 * t + q)] = base; base += v[q]; }
+    if (t == 1023) {   // (inclusive totals)
+        const long long n = sh[t], mean16 = n > 0 ? shw[t] / n / 16 : 0;
+        offset[SORT_BUCKETS] = (keys_are_costs && n > 0 && (long long)(shhi[t] - shlo[t]) <= mean16) ? 1 : 0;   // 1: keep the identity order
+    }
+}
+__global__ void sort_scatter_kernel(const double* loss_traj, const int32_t* prev, int64_t N, int32_t* offset, int32_t* perm, int identity) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        // (identity: the scan's verdict, or UDE_COST_SORT=2 -- the mode's machinery with the identity order: what the indirection alone costs)
+        if (identity || offset[SORT_BUCKETS]) perm[i] = (int32_t)i;
+        else perm[atomicAdd(&offset[cost_key(loss_traj, prev, i)], 1)] = (int32_t)i;
+    }
+}
+// the three kernels above as ONE block for ensembles of up to SORT_SMALL_MAX members (histogram and offsets in LDS): a launch of a
+// millisecond or two (10 000 members on 8 or 16 lanes are 1250 / 2500 wavefronts: more than one round) cannot afford four extra launches
+constexpr int SORT_SMALL_MAX = 32768;
+__global__ void __launch_bounds__(1024) sort_small_kernel(const double* loss_traj, const int32_t* prev, int64_t N, int32_t* perm, int identity) {
+    __shared__ int hist[SORT_BUCKETS];
+    __shared__ int off[SORT_BUCKETS];
+    __shared__ int sh[1024];
+    __shared__ long long shw[1024];
+    __shared__ int shlo[1024], shhi[1024];
+    __shared__ int keep;
+    const int t = threadIdx.x;
+    for (int b = t; b < SORT_BUCKETS; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (int64_t i = t; i < N; i += 1024) atomicAdd(&hist[cost_key(loss_traj, prev, i)], 1);
+    __syncthreads();
+    int v[4], s = 0, lo = SORT_BUCKETS, hi = -1;
+    long long wsum = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int b = SORT_BUCKETS - 1 - (4 * t + q);
+        v[q] = hist[b];
+        s += v[q];
+        wsum += (long long)v[q] * b;
+        if (v[q] > 0) { lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
+    }
+    sh[t] = s; shw[t] = wsum; shlo[t] = lo; shhi[t] = hi;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int x = t >= d ? sh[t - d] : 0;
+        const long long xw = t >= d ? shw[t - d] : 0;
+        const int xl = t >= d ? shlo[t - d] : SORT_BUCKETS, xh = t >= d ? shhi[t - d] : -1;
+        __syncthreads();
+        sh[t] += x; shw[t] += xw; shlo[t] = xl < shlo[t] ? xl : shlo[t]; shhi[t] = xh > shhi[t] ? xh : shhi[t];
+        __syncthreads();
+    }
+    int base = sh[t] - s;
+    for (int q = 0; q < 4; ++q) { off[SORT_BUCKETS - 1 - (4 * t + q)] = base; base += v[q]; }
+    if (t == 1023) {
+        const long long n = sh[t], mean16 = n > 0 ? shw[t] / n / 16 : 0;
+        keep = (identity || (prev && n > 0 && (long long)(shhi[t] - shlo[t]) <= mean16)) ? 1 : 0;   // (same verdict as sort_scan_kernel)
+    }
+    __syncthreads();
+    for (int64_t i = t; i < N; i += 1024) {
+        if (keep) perm[i] = (int32_t)i;
+        else perm[atomicAdd(&off[cost_key(loss_traj, prev, i)], 1)] = (int32_t)i;
+    }
+}
+
+// after the backward kernel: what every member's backward solve cost (accepted + rejected attempts), for the next call's sort
+__global__ void cost_save_kernel(const int64_t* stats, int64_t N, int32_t* prev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) prev[i] = (int32_t)(stats[i * 8 + 5] + stats[i * 8 + 6]);
+}
+
 static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o, Launch& l, int& G, bool* generic = nullptr) {
     int mid = model_id(m);
     if (generic) *generic = false;
@@ -459,7 +613,10 @@ static int resolve(ude_ctx* c, const ude_model_desc* m, const ude_solve_opts* o,
     if (G == 8) {   // (an explicit lanes_per_traj = 8: the width-8 instance takes narrower chains too)
         mid = mid == MID_LV_RT3_W5 ? MID_LV_RT3 : mid == MID_LV_RT4_W5 ? MID_LV_RT4 : mid == MID_LV_RT3_W5_F32 ? MID_LV_RT3_F32 : mid == MID_LV_RT4_W5_F32 ? MID_LV_RT4_F32 : mid;
     }
-    if ((mid == MID_SEIR_UDE || mid == MID_SEIR_NODE) && G == 16) G = 64;  // (16 = the lock-step backward kernel of grad_dev_impl; every other kernel of that model: one wavefront per trajectory)
+    // (16 = the lock-step kernels of grad_dev_impl; every other kernel of these models is one wavefront per trajectory.  Round 6, advisor: the
+    //  runtime-shape exposure chains -- MID_GENERIC_7[_L4] -- reach their lock-step GEN instances through the same request: an explicit
+    //  lanes_per_traj = 16 on 3-64-63-1 used to end in "no kernel instance ... lanes_per_traj 16")
+    if ((mid == MID_SEIR_UDE || mid == MID_SEIR_NODE || mid == MID_GENERIC_7 || mid == MID_GENERIC_7_L4) && G == 16) G = 64;
     const int W = c->lo.waves_per_simd > 0 ? c->lo.waves_per_simd : 1;
     bool ok = false;
     // scenario_1's chain with both diagonal coefficients constant has a leaner instance (no slots for them) where compiled
@@ -852,6 +1009,14 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         nwaves = lsf_blocks;          // one gradient row per BLOCK
     }
     const bool ckpt = o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT_CHECKPOINTED;
+    // cost-ordered adjoint launch (sort kernels above): lane-group kernels with several trajectories per wavefront, Float64, a loss to sort
+    // by, and MORE wavefronts than the chip has SIMDs (a one-round launch ends with its slowest wavefront whatever the order is: the
+    // 10 000-trajectory headline is 834 wavefronts on 1024 SIMDs and stays as it was).  UDE_COST_SORT=0 / 1 forces it off / on (A/B runs).
+    static const char* cs_env = getenv("UDE_COST_SORT");
+    (void)ls_blocks(c, 1);   // (c->ncu)
+    const bool cost_sort = !any_ls && !any_lsf && l.adj_sorted && es == 8 && data && !cot_in && !(o->per_trajectory) &&
+                           o->sensealg == UDE_SENSE_INTERPOLATING_ADJOINT && (cs_env ? atoi(cs_env) != 0 : nwaves > 4 * (int64_t)c->ncu);
+    if (cost_sort) nwaves = N;   // one gradient row per trajectory (KParams::perm)
     const int nf = ckpt ? 3 + n : 3 + n + l.nf * n;   // dense fields per accepted step (checkpointed: t, t_end, dt, u)
     p.ckpt = ckpt ? 1 : 0;
     const bool pm = (o->per_trajectory & UDE_PT_THETA) != 0;   // per-member parameters: theta np x N in, grad_theta np x N out
@@ -876,6 +1041,14 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
     if ((rc = ensure(c, c->cot, es * (size_t)ns * n * p.Npad))) return rc;
     if ((rc = ensure(c, c->loss_traj, es * N))) return rc;
     if (!pm && (rc = ensure(c, c->grad_part, es * (size_t)nwaves * np))) return rc;
+    p.perm = nullptr;
+    if (cost_sort) {
+        if ((rc = ensure(c, c->perm, sizeof(int32_t) * N))) return rc;
+        if ((rc = ensure(c, c->sort_ws, sizeof(int32_t) * (2 * SORT_BUCKETS + 1)))) return rc;
+        void* before = c->prev_cost.p;
+        if ((rc = ensure(c, c->prev_cost, sizeof(int32_t) * N))) return rc;
+        if (c->prev_cost.p != before) c->prev_cost_n = 0;   // (a new buffer holds nobody's costs)
+    }
     p.slot_glob = nullptr;
     if (any_ls) {  // mu of every trajectory: two columns of 71 (146) slots x 64 hidden rows; the stage factors of every block of 16 slots
         if ((rc = ensure(c, c->slot_glob, sizeof(double) * (size_t)N * 2 * ls_slk * 64))) return rc;
@@ -920,6 +1093,8 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
                                             "this (model, lanes_per_traj, sensealg) combination is not available", shmem_f, shmem_a);
     if (shmem_a > 64 * 1024)  // more than the default dynamic-LDS limit: opt in (MI355X has 160 KiB per CU)
         HIPCHK(c, hipFuncSetAttribute((const void*)bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
+    if (shmem_a > 64 * 1024 && cost_sort)
+        HIPCHK(c, hipFuncSetAttribute((const void*)l.adj_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_a));
     if (shmem_f > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kfwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_f));
     const bool cap_graph = capturing(c->stream);  // inside a hipGraph capture: the per-kernel timing events are left out
@@ -970,11 +1145,38 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         // persistent blocks, trajectories dealt round-robin (no queue: every sum is in the same order in every run)
         HIPCHK(c, hipFuncSetAttribute((const void*)ls_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls_lds));
         hipLaunchKernelGGL(ls_kern, dim3((unsigned)lsf_blocks), dim3(256), ls_lds, c->stream, p, (double*)nullptr, (int*)nullptr);
-    } else
-    hipLaunchKernelGGL(bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
+    } else {
+    if (cost_sort) {
+        int32_t* hist = (int32_t*)c->sort_ws.p;
+        // the members' costs of the previous call, if that call was this ensemble's (same size, model, algorithm, tolerances, grid size)
+        const int64_t sig = ((int64_t)m->kind << 48) ^ ((int64_t)np << 32) ^ ((int64_t)ns << 16) ^ ((int64_t)o->alg << 8) ^ (int64_t)o->sensealg ^
+                            (int64_t)(o->abstol * 1e15) ^ ((int64_t)(o->reltol * 1e15) << 1);
+        const int32_t* prev = (c->prev_cost_n == N && c->prev_cost_sig == sig && c->prev_cost.p) ? (const int32_t*)c->prev_cost.p : (const int32_t*)nullptr;
+        if (N <= SORT_SMALL_MAX)
+            hipLaunchKernelGGL(sort_small_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)p.loss_traj, prev, N, (int32_t*)c->perm.p, cs_env && atoi(cs_env) == 2 ? 1 : 0);
+        else {
+        HIPCHK(c, hipMemsetAsync(hist, 0, sizeof(int32_t) * SORT_BUCKETS, c->stream));
+        hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const double*)p.loss_traj, prev, N, hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)hist, hist + SORT_BUCKETS, prev ? 1 : 0);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const double*)p.loss_traj, prev, N, hist + SORT_BUCKETS,
+                           (int32_t*)c->perm.p, cs_env && atoi(cs_env) == 2 ? 1 : 0);
+        }
+        p.perm = (const int32_t*)c->perm.p;
+        if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));   // (the backward kernel's own interval: the three sort kernels are in the step, not in it)
+    }
+    hipLaunchKernelGGL(cost_sort ? l.adj_sorted : bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
+    if (cost_sort) {
+        HIPCHK(c, hipGetLastError());
+        if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        hipLaunchKernelGGL(cost_save_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const int64_t*)stats, N, (int32_t*)c->prev_cost.p);
+        c->prev_cost_n = N;
+        c->prev_cost_sig = ((int64_t)m->kind << 48) ^ ((int64_t)np << 32) ^ ((int64_t)ns << 16) ^ ((int64_t)o->alg << 8) ^ (int64_t)o->sensealg ^
+                           (int64_t)(o->abstol * 1e15) ^ ((int64_t)(o->reltol * 1e15) << 1);
+    }
+    }
     HIPCHK(c, hipGetLastError());
     if (!cap_graph) {
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        if (!cost_sort) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         c->ev_fwd = c->ev_bwd = true;
     }
     if ((rc = ensure(c, c->nfail, sizeof(int32_t)))) return rc;
@@ -988,6 +1190,15 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
                                (const double*)p.loss_traj, N, lossp, (const int32_t*)retcode, (int32_t*)c->nfail.p);
         HIPCHK(c, hipGetLastError());
         return UDE_OK;
+    }
+    if (cost_sort) {   // N rows -> ceil(N / 1024) chunk rows (many blocks: a hundred MB of rows must not be one block's stream), then the usual finish
+        const int64_t nchunks = (N + ROWSUM_CHUNK - 1) / ROWSUM_CHUNK;
+        if ((rc = ensure(c, c->rowsum, sizeof(double) * (size_t)nchunks * np))) return rc;
+        hipLaunchKernelGGL(rows_chunk_sum_kernel, dim3((unsigned)((np + 31) / 32), (unsigned)nchunks), dim3(1024), 0, c->stream, (const double*)p.grad_part, N, (int32_t)np,
+                           (double*)c->rowsum.p);
+        HIPCHK(c, hipGetLastError());
+        p.grad_part = (double*)c->rowsum.p;
+        nwaves = nchunks;
     }
     if (m->dtype == 1)  // Float32 problem: every real-valued array behind these pointers is float
         hipLaunchKernelGGL(finish_kernel<float>, dim3(np + 1), dim3(256), 0, c->stream, (const float*)p.grad_part, nwaves, (int32_t)np,

@@ -456,7 +456,10 @@ def loss_and_gradient(prob, alg, data, row_mask=None, saveat=None, sensealg=None
                       allow_failures=False, **kw):
     """loss(theta) = sum(abs2, data[rows,:] .- Array(solve(...))[rows,:]) and dloss/dtheta by the
     interpolating adjoint (seir_exposure.jl:137-147; Fisher-KPP-CNN.jl:134-143; scenario_1.jl:82-94),
-    summed over an ensemble.  data: (N, ns, n)."""
+    summed over an ensemble.  data: (N, ns, n).
+    allow_failures=False (default): any trajectory whose retcode is not Success raises UdeError.  allow_failures=True: the call returns --
+    loss = +Inf, the failed members contribute nothing to grad_theta; one exception: with FastInterpolatingAdjoint() on the SEIR exposure
+    UDE / neural ODE (block-level accumulation) a member whose BACKWARD solve stops early makes grad_theta NaN (include/udecore.h)."""
     return _grad_common(prob, alg, data, None, row_mask, saveat, device, ensemblealg, kw, sensealg, allow_failures)
 
 

@@ -182,6 +182,7 @@ def hagerzhang(phidphi, c, phi_0, dphi_0):
 
     # bracket
     ia, ib, bracketed, it = 0, 1, False, 1
+    alphamax = _HZ.alphamax
     while not bracketed and it < _HZ.linesearchmax:
         if dphi_c >= 0:
             ib = len(al) - 1
@@ -196,13 +197,23 @@ def hagerzhang(phidphi, c, phi_0, dphi_0):
             ia, ib = bisect(0, ib)
             bracketed = True
         else:
+            # still going downhill: expand.  cold = c is a viable step to return if no finite point can be found beyond it.
+            # (LineSearches.jl HagerZhang, as published: `alphamax` is LOCAL to the search and SHRINKS to every point found non-finite --
+            #  "steps >= c can never have finite phi_c and dphi_c" --, an expansion is clamped to it, and a search whose last good point
+            #  sits right below it returns that point.  Advisor, round 5: without the shrink a second expansion after a non-finite one
+            #  probes other trial points than upstream, and the BFGS trajectory separates in that case.)
             cold, phi_cold = c, va[-1]
+            if np.nextafter(cold, np.inf) >= alphamax:
+                return cold, phi_cold
             c *= _HZ.rho
+            if c > alphamax:
+                c = alphamax
             phi_c, dphi_c = ev(c)
             nfin = 1
             # upstream: while !(isfinite(phi_c) && isfinite(dphi_c)) && c > nextfloat(cold) && iterfinite < iterfinitemax:
-            #               c = (cold + c) / 2 -- pull the expansion back towards the last good point
+            #               alphamax = c; c = (cold + c) / 2 -- pull the expansion back towards the last good point
             while not (np.isfinite(phi_c) and np.isfinite(dphi_c)) and c > np.nextafter(cold, np.inf) and nfin < _HZ.iterfinitemax:
+                alphamax = c
                 nfin += 1
                 c = (cold + c) / 2
                 al.pop(); va.pop(); sl.pop()
