@@ -1,6 +1,6 @@
 """Cost-ordered adjoint launch (round 6; SURVEY.md 7 "sort / bucket trajectories by expected cost"; csrc/udecore.hip sort kernels,
 KParams::perm): a multi-round ensemble on the lane-group kernels runs its backward solves with the wavefronts filled in the order of
-the trajectories' loss.  What must hold: every per-trajectory number is the one the identity order gives (bit for bit, and therefore
+what the members' backward solves cost in the previous call.  What must hold: every per-trajectory number is the one the identity order gives (bit for bit, and therefore
 the oracle's), the gradient -- now a sum of N per-trajectory rows in trajectory order -- agrees with the oracle to the summation
 tolerance, and two runs give the same bits although the counting sort's atomics fill a bucket in any order.
 
@@ -38,8 +38,9 @@ alg = U.Vern7() if alg_name == "vern7" else U.Tsit5()
 kw = dict(sensealg=U.FastInterpolatingAdjoint()) if sense == "fast" else {}
 r = U.loss_and_gradient(ens, alg, data, saveat=t, abstol=1e-6, reltol=1e-6, **kw)
 r2 = U.loss_and_gradient(ens, alg, data, saveat=t, abstol=1e-6, reltol=1e-6, **kw)
-np.savez(sys.argv[4], stats=r.stats, grad_u0=r.grad_u0, lpt=r.loss_per_traj, grad=r.grad_theta, grad2=r2.grad_theta, loss=r.loss, retcode=r.retcode,
-         kernel_ms=np.array(r.kernel_ms))
+r3 = U.loss_and_gradient(ens, alg, data, saveat=t, abstol=1e-6, reltol=1e-6, **kw)
+np.savez(sys.argv[4], stats=r.stats, grad_u0=r.grad_u0, lpt=r.loss_per_traj, grad=r.grad_theta, grad2=r2.grad_theta, grad3=r3.grad_theta, loss=r.loss, retcode=r.retcode,
+         stats2=r2.stats, grad_u0_2=r2.grad_u0, lpt2=r2.loss_per_traj, loss2=r2.loss, u2=r2.u, u=r.u, kernel_ms=np.array(r.kernel_ms))
 """
 
 
@@ -56,12 +57,16 @@ def test_cost_ordered_launch_changes_no_trajectory_and_is_deterministic(tmp_path
     a = run_child(tmp_path, "identity", N, alg, sense, 0)
     b = run_child(tmp_path, "sorted", N, alg, sense, 1)
     assert (a["retcode"] == 0).all() and (b["retcode"] == 0).all()
-    for key in ("stats", "grad_u0", "lpt"):          # per trajectory: the same solves, wherever they ran
+    for key in ("stats", "grad_u0", "lpt", "u"):     # per trajectory: the same solves, wherever they ran
         assert np.array_equal(a[key], b[key]), key
-    assert a["loss"] == b["loss"]
+    # the FIRST call of the mode has no costs to sort by (identity order through the mode's kernels); the second and third are ordered by the
+    # previous call's backward attempts -- forward AND backward kernel: every member's numbers are still its own
+    for key, key2 in (("stats", "stats2"), ("grad_u0", "grad_u0_2"), ("lpt", "lpt2"), ("u", "u2")):
+        assert np.array_equal(a[key], b[key2]), key2
+    assert a["loss"] == b["loss"] == b["loss2"]
     gn = np.linalg.norm(a["grad"])
     assert gn > 0 and np.linalg.norm(a["grad"] - b["grad"]) < 1e-12 * gn        # another association of the same N numbers per parameter
-    assert np.array_equal(b["grad"], b["grad2"])      # two runs, same bits: the row sum does not see the sort's atomics
+    assert np.array_equal(b["grad"], b["grad2"]) and np.array_equal(b["grad"], b["grad3"])   # identity order, sorted order, sorted again: same bits (the row sum does not see the order)
     assert np.array_equal(a["grad"], a["grad2"])
 
 
@@ -82,4 +87,6 @@ def test_cost_ordered_launch_agrees_with_the_oracle(tmp_path):
     data[N // 2] *= 0.4
     ref = O.loss_grad_ensemble(O.lv_ude_s1(), O.opts(O.TSIT5, 1e-6, 1e-6), u0, [0.0, 3.0], th, t, data, nthreads=8)
     assert np.array_equal(b["stats"], ref["stats"]) and np.array_equal(b["grad_u0"], ref["grad_u0"]) and np.array_equal(b["lpt"], ref["loss_per_traj"])
+    assert np.array_equal(b["stats2"], ref["stats"]) and np.array_equal(b["grad_u0_2"], ref["grad_u0"]) and np.array_equal(b["lpt2"], ref["loss_per_traj"])   # (the sorted call)
+    assert np.array_equal(b["u2"], ref["u"])
     assert np.linalg.norm(b["grad"] - ref["grad_theta"]) < 1e-12 * np.linalg.norm(ref["grad_theta"])

@@ -21,7 +21,7 @@ KEYS = ("VGPRs:", "AGPRs:", "ScratchSize [bytes/lane]:", "Occupancy [waves/SIMD]
 
 # (workload, build log, glob of the demangled kernel name): the kernels bench.py's lines and DESIGN.md talk about
 ROWS = [
-    ("lv (headline) forward", "ude_inst_lv_s1n_g5_w1_tsit5.log", "fwd_kernel<*false, double>"),
+    ("lv (headline) forward", "ude_inst_lv_s1n_g5_w1_tsit5.log", "fwd_kernel<*false, double, false>"),
     ("lv (headline) adjoint", "ude_inst_lv_s1n_g5_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("lv discrete sweep", "ude_inst_lv_s1n_g5_w1_tsit5.log", "dadj_kernel<*false, double>"),
     ("lv_tanh32 adjoint", "ude_inst_lv_tanh32_g16_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
@@ -36,7 +36,7 @@ ROWS = [
     ("node forward (lock-step)", "ude_node_ls.log", "node_ls_fwd_kernel<Vern7Tab>*"),
     ("node adjoint, parity mode (lock-step, second generation)", "ude_node_ls.log", "node_ls2_adj_kernel<Vern7Tab>*"),
     ("node adjoint, fast mode (lock-step, block-level MFMA accumulation)", "ude_node_lsf.log", "node_lsf_adj_kernel<Vern7Tab>*"),
-    ("kpp forward (1024 points; round 6: network on the vector unit, DPP-broadcast weights)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "fwd_kernel<*false, double>"),
+    ("kpp forward (1024 points; round 6: network on the vector unit, DPP-broadcast weights)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "fwd_kernel<*false, double, false>"),
     ("kpp adjoint (1024 points; round 6: vector network + packed matrix-core contraction)", "ude_inst_kpp_ude_1024_g256_w1_tsit5.log", "adj_kernel<*false, 1, double>"),
     ("kpp adjoint (1024 points), Vern7 (half-size transposition tile)", "ude_inst_kpp_ude_1024_g256_w1_vern7.log", "adj_kernel<*false, 1, double>"),
     ("kpp adjoint (1024 points), run-time-shape reaction network", "ude_inst_kpp_rt_1024_g256_w1_tsit5.log", "adj_kernel<*false, 1, double>"),

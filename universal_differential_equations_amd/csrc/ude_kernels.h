@@ -604,7 +604,14 @@ struct TimeGrid {
     __device__ __forceinline__ real DTMAX(const OptsR& o) const { if constexpr (PT) return dtmax_; else return o.dtmax; }
 };
 
-template <class Model, class Tab, int G, int BLOCKDIM, bool PT = false>
+template <bool SORTED>
+__device__ __forceinline__ int64_t member_of(const KParams& p, int64_t gslot) {
+    if constexpr (SORTED) return (int64_t)p.perm[gslot]; else return gslot;
+}
+
+// SORTED (cost-ordered launch, KParams::perm): `j` is the MEMBER the lane group works on (inputs and outputs are indexed by it), `jw` the
+// column of the internal workspaces (dense store, cotangent rows, step counts) = the lane group's own position: adjacent groups, adjacent words
+template <class Model, class Tab, int G, int BLOCKDIM, bool PT = false, bool SORTED = false>
 struct FwdSys {
     TimeGrid<PT> tg;
     __device__ __forceinline__ real dtmax(const OptsR& o) const { return tg.DTMAX(o); }
@@ -617,6 +624,8 @@ struct FwdSys {
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;      // trajectory
+    int64_t jw;     // (SORTED) its workspace column
+    __device__ __forceinline__ int64_t wcol() const { if constexpr (SORTED) return jw; else return j; }
     bool writer;    // lane 0 of the group
     int si, nsteps, r, n;
     real loss;
@@ -656,7 +665,7 @@ struct FwdSys {
                     // reach the loss -- the reference slices those rows away, seir_exposure.jl:146)
                     const real e = (p->row_mask && !p->row_mask[ci]) ? real(0) : (v[c] - d[ci]);
                     loss = rfma(e, e, loss);
-                    if (cwrite(c)) p->cot[STATE_DISTRIBUTED ? ((size_t)j * p->ns + i) * n + ci : ((size_t)i * n + ci) * p->Npad + j] = real(2) * e;
+                    if (cwrite(c)) p->cot[STATE_DISTRIBUTED ? ((size_t)j * p->ns + i) * n + ci : ((size_t)i * n + ci) * p->Npad + wcol()] = real(2) * e;
                 }
             });
         }
@@ -694,7 +703,7 @@ struct FwdSys {
             {
                 const int nf = p->ckpt ? 3 + n : 3 + n + Tab::NK * n;
                 const size_t DFS = dense_fs<STATE_DISTRIBUTED || CPL>(*p);
-                real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, nsteps, nf, j);
+                real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, nsteps, nf, wcol());
                 if (writer) {
                     base[0] = tprev;
                     base[(size_t)1 * DFS] = t;
@@ -747,7 +756,7 @@ struct Layout {
 };
 
 // RTag: the translation unit's scalar type in the kernel's NAME (the Float32 and Float64 builds of one instance are different symbols)
-template <class Model, class Tab, int G, int BLOCK, bool PT = false, class RTag = real>
+template <class Model, class Tab, int G, int BLOCK, bool PT = false, class RTag = real, bool SORTED = false>
 __global__ void __launch_bounds__(BLOCK, fwd_blocks<Model>::v) fwd_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using L = Layout<Model, Tab, G, BLOCK>;
@@ -759,16 +768,18 @@ __global__ void __launch_bounds__(BLOCK, fwd_blocks<Model>::v) fwd_kernel(const 
     __syncthreads();
 
     constexpr int GROUPS = BLOCK / G;  // trajectories per block (lanes beyond GROUPS*G idle when G is not a power of two)
-    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
+    const int64_t gslot = (int64_t)blockIdx.x * GROUPS + threadIdx.x / G;
     const int r = threadIdx.x % G;
-    if (gid >= p.N || (int)threadIdx.x >= GROUPS * G) return;  // whole groups leave together
-    using Sys = FwdSys<Model, Tab, G, BLOCK, PT>;
+    if (gslot >= p.N || (int)threadIdx.x >= GROUPS * G) return;  // whole groups leave together
+    const int64_t gid = member_of<SORTED>(p, gslot);   // (cost-ordered launch: the member this lane group works on)
+    using Sys = FwdSys<Model, Tab, G, BLOCK, PT, SORTED>;
     using Drv = Driver<Tab, Sys, G, BLOCK>;
     Sys sys;
     Model::init(sys.mctx, theta_of<Model, PT>(p, th, gid), scratch, nullptr, 0, p.mc, r, p.theta);
     sys.p = &p;
     sys.tg.init(p, gid);
     sys.j = gid;
+    sys.jw = gslot;
     sys.writer = (r == 0);
     sys.si = 0;
     sys.nsteps = 0;
@@ -794,7 +805,7 @@ __global__ void __launch_bounds__(BLOCK, fwd_blocks<Model>::v) fwd_kernel(const 
             s[4] = 0; s[5] = 0; s[6] = 0;
         }
         p.retcode[gid] = ret;
-        if (p.dense_n) p.dense_n[gid] = sys.nsteps;
+        if (p.dense_n) p.dense_n[sys.wcol()] = sys.nsteps;
         if (p.loss_traj) p.loss_traj[gid] = ret == RET_SUCCESS ? sys.loss : 0.0;
     }
 }
@@ -864,6 +875,8 @@ struct AdjSys {
     typename Model::Ctx mctx;
     const KParams* p;
     int64_t j;
+    int64_t jw;   // (VAR == 6, cost-ordered launch) workspace column of member j: the lane group's own position
+    __device__ __forceinline__ int64_t wcol() const { if constexpr (VAR == 6) return jw; else return j; }
     int nsteps, sf, cur, n;
     __device__ __forceinline__ int comp(int c) const {
         if constexpr (STATE_DISTRIBUTED) return Model::point(c, mctx.r); else return c;
@@ -908,7 +921,7 @@ struct AdjSys {
             pf_s = s;
             if (s >= 0) {
                 const int nf = 3 + n + Tab::NK * n;
-                const real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, s, nf, j);
+                const real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, s, nf, wcol());
                 pf_ts = base[0];
                 static_for<0, PF_N>([&](auto q) {
                     const int f = mctx.r + (int)decltype(q)::value * G;
@@ -936,7 +949,7 @@ struct AdjSys {
         sf = s;
         const int nf = RECOMPUTE ? 3 + n : 3 + n + Tab::NK * n;
         const size_t DFS = dense_fs<STATE_DISTRIBUTED || CPL>(*p);
-        const real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, s, nf, j);
+        const real* base = dense_rec<STATE_DISTRIBUTED || CPL>(*p, s, nf, wcol());
         ts = base[0];
         te = base[(size_t)1 * DFS];
         if constexpr (RECOMPUTE) {
@@ -1213,6 +1226,7 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         sys.p = &p;
         sys.tg.init(p, gid);
         sys.j = gid;
+        sys.jw = gslot;
         sys.n = p.n_state;
         if constexpr (Model::DEFERRED) sys.load_bth_table();
         if constexpr (model_gfac<Model>::v > 0) {   // stage factors a model keeps in HBM: this thread's words behind its two mu columns
@@ -1224,13 +1238,13 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         sys.ms = MS;
         sys.ic = icbase + threadIdx.x / G;
         sys.icstride = BLOCK / G;
-        sys.nsteps = p.dense_n[gid];
+        sys.nsteps = p.dense_n[sys.wcol()];
         if (p.cot_in || Model::STATE_DISTRIBUTED) {   // (distributed states keep a trajectory's cotangent rows contiguous)
             sys.cot = (p.cot_in ? p.cot_in : p.cot) + (size_t)gid * p.ns * p.n_state;
             sys.cot_si = p.n_state;
             sys.cot_sc = 1;
         } else {
-            sys.cot = p.cot + gid;
+            sys.cot = p.cot + sys.wcol();
             sys.cot_si = (size_t)p.n_state * p.Npad;
             sys.cot_sc = p.Npad;
         }

@@ -249,8 +249,17 @@ struct KppUdeV : LinearTheta {
         });
     }
     static __device__ __forceinline__ v4d mfma(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // the transposition tile is private to the wavefront, and the LDS executes one wavefront's instructions in order: a read behind a store
+    // (and a store behind the reads of the rows it overwrites) needs no wait -- only the COMPILER must keep the order.  UDE_KPPV_SYNC=1: the
+    // conservative form of the first version, s_waitcnt lgkmcnt(0) on both sides of every tile (6.96 k instead of 6.74 k clocks per pass).
+    // Measured and NOT kept (tools/exp/kpp_harness.hip): two half-size buffers with the next half's rows stored between the products of the
+    // current one -- LDS stores do not proceed under a running v_mfma_f64 either, and every masked store costs a full one: 8.9 k clocks.
     static __device__ __forceinline__ void wave_sync() {
+#if defined(UDE_KPPV_SYNC) && UDE_KPPV_SYNC
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+        asm volatile("" ::: "memory");
+#endif
         __builtin_amdgcn_wave_barrier();
     }
 

@@ -13,6 +13,7 @@ struct Launch {
     void (*adj_fast)(const KParams);  // UDE_SENSE_FAST: lambda-only error control (shared time grid only)
     void (*adj_ckpt)(const KParams);  // checkpointed adjoint: store u only, recompute the stages (null: no such instance)
     void (*adj_sorted)(const KParams);  // cost-ordered launch of a multi-round ensemble (KParams::perm; lane-group models only, else null)
+    void (*fwd_sorted)(const KParams);  // ... and its forward kernel: the same order, workspace columns = lane-group positions
     int nf;  // dense fields per step
     int G, block;
     int block_fwd;  // threads per block of the forward / rhs kernels (Model::FWD_BLOCK_THREADS or Model::FwdModel; else = block)
@@ -78,6 +79,9 @@ inline Launch make_launch() {
     if constexpr (G < 64 && BLOCK == 64 && !Model::STATE_DISTRIBUTED && !Model::SLOTS_GLOBAL && !Model::DEFERRED && VAR == 1)
         l.adj_sorted = adj_kernel<Model, Tab, G, BLOCK, false, 6>;
     else l.adj_sorted = nullptr;
+    if constexpr (G < 64 && BLOCK == 64 && !Model::STATE_DISTRIBUTED && !Model::SLOTS_GLOBAL && !Model::DEFERRED && VAR == 1 && !OWN_FWD)
+        l.fwd_sorted = fwd_kernel<FM, Tab, GF, FB, false, real, true>;
+    else { l.fwd_sorted = nullptr; l.adj_sorted = nullptr; }
     l.nf = Tab::NK;  // dense fields per step = 2 + n_state + NK * n_state (host adds the state size)
     l.G = G;
     l.block = BLOCK;

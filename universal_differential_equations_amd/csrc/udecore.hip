@@ -448,12 +448,12 @@ static int default_lanes(int mid, bool discrete) {
 // Cost-ordered adjoint launch (round 6; SURVEY.md 7, "hard parts": sort / bucket trajectories by expected cost).  The trajectories of a
 // wavefront make their backward step attempts together: a wavefront runs as long as its slowest trajectory (lane_step_util 0.82 on
 // the LV ensembles), and a launch of several rounds of wavefronts additionally ends with whatever round happens to hold the slowest
-// ones.  The cost of a backward solve is not known in advance; what the forward pass already knows and what predicts it best is the
-// trajectory's own LOSS (the data misfit sets the size of the cotangent jumps; on the LV ensemble: correlation 0.81 with the backward
-// attempts, lock-step utilisation 0.82 -> 0.93 when the wavefronts are filled in that order; the forward step count -- 26 or 27 for every
-// member -- predicts nothing).  Counting sort by a logarithmic key (16 buckets per octave), most expensive first; the order INSIDE a bucket
-// is whatever the atomics produce -- harmless, because in this mode every trajectory writes its own gradient row and the rows are added
-// in trajectory order (KParams::perm).
+// ones.  The cost of a backward solve is not known in advance -- but a gradient is asked for again and again with slowly moving parameters, and what
+// predicts a member's cost best is what it cost LAST TIME (lock-step utilisation 0.82 -> 0.999 when the wavefronts are filled in that order; the
+// member's loss: 0.93, its forward step count -- 26 or 27 for every member -- 0.84).  Counting sort by the previous call's backward attempt counts,
+// most expensive first, BEFORE the forward kernel: forward and backward kernel both run in that order, so the internal workspaces are indexed by lane-
+// group position and stay coalesced.  The order INSIDE a bucket is whatever the atomics produce -- harmless, because in this mode every member
+// writes its own gradient row and the rows are added in member order (KParams::perm).  The first call on an ensemble runs the identity order.
 // the N gradient rows of a cost-ordered launch, first level of their sum: block (x, y) adds rows [y * chunk, (y + 1) * chunk) of 32 adjacent
 // columns (coalesced 256-byte reads; fixed order: 32 row-lanes striding the chunk, then the 32 partials left to right) into out[y][col];
 // the finish kernel adds the chunk rows.  Every association is fixed by (N, chunk) alone -- not by the permutation.
@@ -498,9 +498,17 @@ __device__ __forceinline__ int cost_key(const double* loss_traj, const int32_t* 
     if (prev) { const int a = prev[i]; return a < 0 ? 0 : a >= SORT_BUCKETS ? SORT_BUCKETS - 1 : a; }
     return cost_bucket(loss_traj[i]);
 }
-__global__ void sort_hist_kernel(const double* loss_traj, const int32_t* prev, int64_t N, int32_t* hist) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) atomicAdd(&hist[cost_key(loss_traj, prev, i)], 1);
+// (histogram and scatter go through a block-private LDS histogram first: the keys of an ensemble fall into a few dozen buckets, and 160 000
+//  global atomics on forty addresses serialise -- the first version spent 1.3 ms of a 15 ms step in these two kernels)
+__global__ void __launch_bounds__(1024) sort_hist_kernel(const double* loss_traj, const int32_t* prev, int64_t N, int32_t* hist) {
+    __shared__ int lh[SORT_BUCKETS];
+    for (int b = threadIdx.x; b < SORT_BUCKETS; b += 1024) lh[b] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i < N) atomicAdd(&lh[cost_key(loss_traj, prev, i)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < SORT_BUCKETS; b += 1024)
+        if (lh[b]) atomicAdd(&hist[b], lh[b]);
 }
 // exclusive prefix sums over the buckets in DESCENDING key order (one block of 1024 threads, four buckets each).  With keys that ARE costs
 // (the previous call's attempt counts) the block also decides whether sorting can pay at all: an ensemble whose members all cost the same
@@ -537,13 +545,26 @@ __global__ void __launch_bounds__(1024) sort_scan_kernel(const int32_t* hist, in
         offset[SORT_BUCKETS] = (keys_are_costs && n > 0 && (long long)(shhi[t] - shlo[t]) <= mean16) ? 1 : 0;   // 1: keep the identity order
     }
 }
-__global__ void sort_scatter_kernel(const double* loss_traj, const int32_t* prev, int64_t N, int32_t* offset, int32_t* perm, int identity) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) {
-        // (identity: the scan's verdict, or UDE_COST_SORT=2 -- the mode's machinery with the identity order: what the indirection alone costs)
-        if (identity || offset[SORT_BUCKETS]) perm[i] = (int32_t)i;
-        else perm[atomicAdd(&offset[cost_key(loss_traj, prev, i)], 1)] = (int32_t)i;
+__global__ void __launch_bounds__(1024) sort_scatter_kernel(const double* loss_traj, const int32_t* prev, int64_t N, int32_t* offset, int32_t* perm, int identity) {
+    // block-private ranks: a member's position inside its bucket = (the block's reservation in the bucket) + (its rank among the block's
+    // members of that bucket); one global atomic per (block, non-empty bucket)
+    __shared__ int lh[SORT_BUCKETS];
+    __shared__ int lbase[SORT_BUCKETS];
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    // (identity: the scan's verdict, or UDE_COST_SORT=2 -- the mode's machinery with the identity order: what the indirection alone costs)
+    if (identity || offset[SORT_BUCKETS]) {
+        if (i < N) perm[i] = (int32_t)i;
+        return;
     }
+    for (int b = threadIdx.x; b < SORT_BUCKETS; b += 1024) lh[b] = 0;
+    __syncthreads();
+    int key = 0, rank = 0;
+    if (i < N) { key = cost_key(loss_traj, prev, i); rank = atomicAdd(&lh[key], 1); }
+    __syncthreads();
+    for (int b = threadIdx.x; b < SORT_BUCKETS; b += 1024)
+        if (lh[b]) lbase[b] = atomicAdd(&offset[b], lh[b]);
+    __syncthreads();
+    if (i < N) perm[lbase[key] + rank] = (int32_t)i;
 }
 // the three kernels above as ONE block for ensembles of up to SORT_SMALL_MAX members (histogram and offsets in LDS): a launch of a
 // millisecond or two (10 000 members on 8 or 16 lanes are 1250 / 2500 wavefronts: more than one round) cannot afford four extra launches
@@ -556,6 +577,10 @@ __global__ void __launch_bounds__(1024) sort_small_kernel(const double* loss_tra
     __shared__ int shlo[1024], shhi[1024];
     __shared__ int keep;
     const int t = threadIdx.x;
+    if (identity) {   // (no costs of a previous call yet, or UDE_COST_SORT=2: the mode's machinery with the identity order)
+        for (int64_t i = t; i < N; i += 1024) perm[i] = (int32_t)i;
+        return;
+    }
     for (int b = t; b < SORT_BUCKETS; b += 1024) hist[b] = 0;
     __syncthreads();
     for (int64_t i = t; i < N; i += 1024) atomicAdd(&hist[cost_key(loss_traj, prev, i)], 1);
@@ -583,7 +608,7 @@ __global__ void __launch_bounds__(1024) sort_small_kernel(const double* loss_tra
     for (int q = 0; q < 4; ++q) { off[SORT_BUCKETS - 1 - (4 * t + q)] = base; base += v[q]; }
     if (t == 1023) {
         const long long n = sh[t], mean16 = n > 0 ? shw[t] / n / 16 : 0;
-        keep = (identity || (prev && n > 0 && (long long)(shhi[t] - shlo[t]) <= mean16)) ? 1 : 0;   // (same verdict as sort_scan_kernel)
+        keep = (prev && n > 0 && (long long)(shhi[t] - shlo[t]) <= mean16) ? 1 : 0;   // (same verdict as sort_scan_kernel)
     }
     __syncthreads();
     for (int64_t i = t; i < N; i += 1024) {
@@ -1125,8 +1150,33 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         hipLaunchKernelGGL(lf, dim3((unsigned)ls_blocks(c, N, lf_per_cu)), dim3(256), lf_lds, c->stream, p, queue);
     } else
     {   // (the forward kernel may run with fewer threads per block than the adjoint: Launch::block_fwd)
+        if (cost_sort) {
+            // the members in the order of what their backward solves cost in the PREVIOUS call on this ensemble (same size, model, algorithm,
+            // tolerances, grid size), most expensive first; without such a call: the identity.  Forward and backward kernel run in that order,
+            // the internal workspaces are indexed by the lane group's position (adjacent groups, adjacent words: a first version permuted
+            // the backward launch alone and read its workspace columns scattered, +7 % on these latency-bound kernels)
+            int32_t* hist = (int32_t*)c->sort_ws.p;
+            const int64_t sig = ((int64_t)m->kind << 48) ^ ((int64_t)np << 32) ^ ((int64_t)ns << 16) ^ ((int64_t)o->alg << 8) ^ (int64_t)o->sensealg ^
+                                (int64_t)(o->abstol * 1e15) ^ ((int64_t)(o->reltol * 1e15) << 1);
+            const int32_t* prev = (c->prev_cost_n == N && c->prev_cost_sig == sig && c->prev_cost.p) ? (const int32_t*)c->prev_cost.p : (const int32_t*)nullptr;
+            const int ident = (!prev || (cs_env && atoi(cs_env) == 2)) ? 1 : 0;
+            if (N <= SORT_SMALL_MAX)
+                hipLaunchKernelGGL(sort_small_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)nullptr, prev, N, (int32_t*)c->perm.p, ident);
+            else {
+                HIPCHK(c, hipMemsetAsync(hist, 0, sizeof(int32_t) * (2 * SORT_BUCKETS + 1), c->stream));
+                if (!ident) {
+                    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)((N + 1023) / 1024)), dim3(1024), 0, c->stream, (const double*)nullptr, prev, N, hist);
+                    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)hist, hist + SORT_BUCKETS, 1);
+                }
+                hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)((N + 1023) / 1024)), dim3(1024), 0, c->stream, (const double*)nullptr, prev, N, hist + SORT_BUCKETS,
+                                   (int32_t*)c->perm.p, ident);
+            }
+            p.perm = (const int32_t*)c->perm.p;
+            c->prev_cost_sig = sig;
+            if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));   // (the forward kernel's own interval)
+        }
         const int64_t gpb_f = l.block_fwd / l.G_fwd;
-        hipLaunchKernelGGL(kfwd, dim3((unsigned)((N + gpb_f - 1) / gpb_f)), dim3(l.block_fwd), shmem_f, c->stream, p);
+        hipLaunchKernelGGL(cost_sort ? l.fwd_sorted : kfwd, dim3((unsigned)((N + gpb_f - 1) / gpb_f)), dim3(l.block_fwd), shmem_f, c->stream, p);
     }
     HIPCHK(c, hipGetLastError());
     if (!cap_graph) {
@@ -1146,32 +1196,13 @@ static int grad_dev_impl(ude_ctx* c, const ude_model_desc* m, const ude_solve_op
         HIPCHK(c, hipFuncSetAttribute((const void*)ls_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls_lds));
         hipLaunchKernelGGL(ls_kern, dim3((unsigned)lsf_blocks), dim3(256), ls_lds, c->stream, p, (double*)nullptr, (int*)nullptr);
     } else {
-    if (cost_sort) {
-        int32_t* hist = (int32_t*)c->sort_ws.p;
-        // the members' costs of the previous call, if that call was this ensemble's (same size, model, algorithm, tolerances, grid size)
-        const int64_t sig = ((int64_t)m->kind << 48) ^ ((int64_t)np << 32) ^ ((int64_t)ns << 16) ^ ((int64_t)o->alg << 8) ^ (int64_t)o->sensealg ^
-                            (int64_t)(o->abstol * 1e15) ^ ((int64_t)(o->reltol * 1e15) << 1);
-        const int32_t* prev = (c->prev_cost_n == N && c->prev_cost_sig == sig && c->prev_cost.p) ? (const int32_t*)c->prev_cost.p : (const int32_t*)nullptr;
-        if (N <= SORT_SMALL_MAX)
-            hipLaunchKernelGGL(sort_small_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)p.loss_traj, prev, N, (int32_t*)c->perm.p, cs_env && atoi(cs_env) == 2 ? 1 : 0);
-        else {
-        HIPCHK(c, hipMemsetAsync(hist, 0, sizeof(int32_t) * SORT_BUCKETS, c->stream));
-        hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const double*)p.loss_traj, prev, N, hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)hist, hist + SORT_BUCKETS, prev ? 1 : 0);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const double*)p.loss_traj, prev, N, hist + SORT_BUCKETS,
-                           (int32_t*)c->perm.p, cs_env && atoi(cs_env) == 2 ? 1 : 0);
-        }
-        p.perm = (const int32_t*)c->perm.p;
-        if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));   // (the backward kernel's own interval: the three sort kernels are in the step, not in it)
-    }
+    if (cost_sort && !cap_graph) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(cost_sort ? l.adj_sorted : bwd, dim3(grid), dim3(BLOCK), shmem_a, c->stream, p);
     if (cost_sort) {
         HIPCHK(c, hipGetLastError());
         if (!cap_graph) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         hipLaunchKernelGGL(cost_save_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const int64_t*)stats, N, (int32_t*)c->prev_cost.p);
         c->prev_cost_n = N;
-        c->prev_cost_sig = ((int64_t)m->kind << 48) ^ ((int64_t)np << 32) ^ ((int64_t)ns << 16) ^ ((int64_t)o->alg << 8) ^ (int64_t)o->sensealg ^
-                           (int64_t)(o->abstol * 1e15) ^ ((int64_t)(o->reltol * 1e15) << 1);
     }
     }
     HIPCHK(c, hipGetLastError());
