@@ -5,6 +5,7 @@ must refuse, and -- when this container has built the library -- that every repa
 import glob
 import importlib.util
 import os
+import re
 
 import pytest
 
@@ -229,3 +230,25 @@ def test_every_built_translation_unit_has_its_dpp_wait_states():
         assert not rep["inserted"] and not rep["errors"], "%s: %s" % (os.path.basename(f), (rep["inserted"] + rep["errors"])[:2])
         seen += rep["dpp"]
     assert seen > 0   # (the Fisher-KPP vector kernel is made of them)
+
+
+def test_the_no_rewriter_objects_never_saw_the_rewriter():
+    """libudecore_nrw.so's swapped-in objects (build.py: OBJ_NRW; tests/test_gpu_ra2.py runs the oracle-comparing files against them) are
+    what a plain `hipcc -c -O0` wrote: no assembly text in their directory, no line of either assembly tool in their logs, and the
+    structural work-around is visible -- without live-range splitting the long-lived values of these kernels live in scratch"""
+    objdir = os.path.join(ROOT, "universal_differential_equations_amd", "build", "nrw")
+    logs = glob.glob(os.path.join(objdir, "*.log"))
+    if not logs:
+        pytest.skip("the no-rewriter variant has not been built (UDE_BUILD_NRW=1 / __graft_entry__.build())")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ude_build", os.path.join(ROOT, "universal_differential_equations_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.NRW_FLAGS == ["-O0"]
+    assert sorted(os.path.basename(x)[:-4] for x in logs) == sorted(b.NRW_UNITS)
+    assert not glob.glob(os.path.join(objdir, "*.s")), "no assembly text may exist next to objects that come out of `hipcc -c`"
+    for lg in logs:
+        txt = open(lg).read()
+        assert "endcf-fix" not in txt and "dpp-hazard" not in txt, lg
+    scratch = [int(x) for lg in logs for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", open(lg).read())]
+    assert scratch and max(scratch) > 1000

@@ -9,6 +9,7 @@ import hashlib
 import os
 import subprocess
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -214,6 +215,10 @@ def compile_one(job):
     stem = obj[:-2]
     asm, fixed, dev_o, hsaco, fatbin = stem + ".s", stem + ".fixed.s", stem + ".dev.o", stem + ".hsaco", stem + ".hipfb"
     out = []
+    # the object carries the time its compile STARTED (os.utime below): a header edited while a minutes-long unit was compiling is
+    # then newer than the object, and the unit is rebuilt -- round 6 found second-allocation objects compiled from the headers of
+    # five minutes earlier that the plain mtime comparison called current (kernels missing a template parameter: a launch aborted)
+    t_start = time.time()
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -257,6 +262,7 @@ def compile_one(job):
         if os.path.exists(tmp):
             os.remove(tmp)
     if rc == 0:
+        os.utime(obj, (t_start, t_start))
         open(stamp, "w").write(sig)
     return obj, rc, "".join(out) if rc else ""
 
@@ -270,6 +276,49 @@ def compile_one(job):
 OBJ_RA2 = os.path.join(HERE, "build", "ra2")
 LIB_RA2 = os.path.join(HERE, "libudecore_ra2.so")
 RA2_FLAGS = ["-mllvm", "-vgpr-regalloc=basic"]
+
+
+# A THIRD detector, one that shares NOTHING with the assembly pipeline above (round-5 review, item 8: the second allocation is gated by
+# the same tools/isa_endcf_fix.py, so a defect of the rewriter common to both builds is invisible to it).  One representative
+# translation unit per kernel family is compiled by a PLAIN `hipcc -c -O0` -- no -S, no rewriter, no hazard pass, the compiler's own
+# assembler, and NO OPTIMISATION: at -O0 LLVM allocates registers with its "fast" allocator, which has no live-range splitting (every
+# value that lives across a block boundary is stored to scratch where it is defined and reloaded in front of its use), so the defect
+# class of DESIGN.md 2a (a SPLIT COPY emitted in front of a join block's EXEC restore) cannot be generated at all -- the work-around
+# is structural, not a repair -- and neither the machine scheduler nor any other -O3 pass has touched the code.  The objects replace
+# their shipping counterparts in libudecore_nrw.so (every other object is the shipping one); tests/test_gpu_ra2.py runs the
+# oracle-comparing files against it: bit-identity with the oracle per trajectory = bit-identity with the rewritten shipping objects.
+# Kilobytes of scratch per lane: a checker, never shipped, never timed.
+# (Measured first and NOT usable: `-O3 -mllvm -vgpr-regalloc=fast` -- the fast allocator behind the optimising pipeline.  It compiles,
+#  finds no site, and computes wrong results: the LV kernel fails on scenario_2's wiring only, the deep-BSDE forward kernel everywhere,
+#  while -O0 builds of the same units are bit-identical to the oracle -- a code-generation problem of that unsupported combination,
+#  not of these sources; profiles/r06_probes.md.)
+# (csrc/ude_model_kpp_vec.h is not represented: its hand-written DPP instructions NEED the hazard pass; the 32-point instance of the
+#  same model family is.)
+OBJ_NRW = os.path.join(HERE, "build", "nrw")
+LIB_NRW = os.path.join(HERE, "libudecore_nrw.so")
+NRW_FLAGS = ["-O0"]   # (after FLAGS' -O3: the last -O wins)
+NRW_UNITS = ["udecore", "ude_hjb", "ude_seir_ls", "ude_node_ls", "ude_seir_lsf", "ude_node_lsf",
+             "ude_inst_lv_s1_g5_w1_tsit5", "ude_inst_lv_s1_g5_w1_vern7", "ude_inst_lv_tanh32_g8_w1_tsit5", "ude_inst_lv_hudson_g8_w1_tsit5",
+             "ude_inst_seir_ude_g64_w1_vern7", "ude_inst_seir_node_g64_w1_vern7", "ude_inst_kpp_ude_32_g32_w1_tsit5",
+             "ude_inst_generic_7_g64_w1_tsit5", "ude_inst_generic_2_g64_w1_tsit5"]
+
+
+def compile_plain(job):
+    """`hipcc -c` and nothing else (see OBJ_NRW): no assembly text, no tool of tools/ between the compiler and the object"""
+    src, obj, defs, log = job
+    cmd = [HIPCC] + FLAGS + defs + ["-Rpass-analysis=kernel-resource-usage", "-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
+    stamp = obj + ".cmd"
+    sig = hashlib.sha256(" ".join(cmd).encode()).hexdigest()
+    if (os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_dep(obj + ".d"))
+            and os.path.exists(stamp) and open(stamp).read() == sig):
+        return obj, 0, "up to date"
+    t_start = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    open(log, "w").write(r.stderr)
+    if r.returncode == 0:
+        os.utime(obj, (t_start, t_start))   # (see compile_one)
+        open(stamp, "w").write(sig)
+    return obj, r.returncode, r.stderr if r.returncode else ""
 
 
 def kernel_work(objdir, extra):
@@ -355,6 +404,22 @@ def build(verbose=True, jobs=None, ra2=False):
         ra2_objs = run_jobs(kernel_work(OBJ_RA2, RA2_FLAGS), jobs, verbose)
         if (not os.path.exists(LIB_RA2)) or any(os.path.getmtime(o) > os.path.getmtime(LIB_RA2) for o in ra2_objs + [maps[LIB]]):
             subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + maps[LIB], "-o", LIB_RA2] + ra2_objs + ["-ldl"])
+    # the no-rewriter variant (see OBJ_NRW above): built with the second allocation, or UDE_BUILD_NRW=1
+    if (ra2 or os.environ.get("UDE_BUILD_NRW")) and not os.environ.get("UDE_SKIP_NRW"):
+        os.makedirs(OBJ_NRW, exist_ok=True)
+        by_name = {os.path.basename(w[1])[:-2]: w for w in kernel_work(OBJ_NRW, NRW_FLAGS)}
+        nrw = {}
+        with ThreadPoolExecutor(jobs) as ex:
+            for obj, rc, msg in ex.map(compile_plain, [by_name[n] for n in sorted(NRW_UNITS, key=lambda n: "kpp" not in n)]):
+                if verbose:
+                    print("  [%s] nrw/%s" % ("ok" if rc == 0 else "FAIL", os.path.basename(obj)), msg if rc else "")
+                if rc:
+                    raise RuntimeError("hipcc failed for %s:\n%s" % (obj, msg))
+                nrw[os.path.basename(obj)] = obj
+        members = [nrw.get(os.path.basename(o), o) for o in ship]
+        assert sum(os.path.basename(o) in nrw for o in ship) == len(NRW_UNITS), "NRW_UNITS names a unit the shipping library does not have"
+        if (not os.path.exists(LIB_NRW)) or any(os.path.getmtime(o) > os.path.getmtime(LIB_NRW) for o in members + [maps[LIB]]):
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + maps[LIB], "-o", LIB_NRW] + members + ["-ldl"])
     if verbose:
         print("built", LIB, "and", LIB_DBG)
     return LIB
