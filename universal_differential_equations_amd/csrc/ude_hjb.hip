@@ -143,7 +143,8 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
 
     const size_t sh_f = sizeof(float) * fwd_lds_floats<KD, KH>() + 16;
     const size_t sh_b = sizeof(float) * bwd_lds_floats<KD, KH>() + 16;
-    HIPCHK(c, hipFuncSetAttribute((const void*)hjb_fwd_kernel<KD, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_f));
+    HIPCHK(c, hipFuncSetAttribute((const void*)hjb_fwd_kernel<KD, KH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_f));
+    HIPCHK(c, hipFuncSetAttribute((const void*)hjb_fwd_kernel<KD, KH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_f));
     hipLaunchKernelGGL((hjb_prep_kernel<KD, KH>), dim3(1), dim3(128), 0, c->stream, p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->hj_ev[0], c->stream));
@@ -169,7 +170,8 @@ extern "C" int ude_hjb_loss_grad_dev(ude_ctx* c, const ude_hjb_desc* D, int64_t 
         HIPCHK(c, hipMemsetAsync(p.prof, 0, sizeof(unsigned long long) * 16, c->stream));
     }
     ude_poison_chip(c->stream, true);
-    hipLaunchKernelGGL((hjb_fwd_kernel<KD, KH>), dim3((unsigned)nblk_f), dim3(256), sh_f, c->stream, p);
+    if (p.adaptive) hipLaunchKernelGGL((hjb_fwd_kernel<KD, KH, true>), dim3((unsigned)nblk_f), dim3(256), sh_f, c->stream, p);
+    else hipLaunchKernelGGL((hjb_fwd_kernel<KD, KH, false>), dim3((unsigned)nblk_f), dim3(256), sh_f, c->stream, p);
     HIPCHK(c, hipGetLastError());
     if (prof) {
         unsigned long long h[16];

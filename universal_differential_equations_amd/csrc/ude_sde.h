@@ -199,6 +199,60 @@ __device__ __forceinline__ void layer(const float (&wf)[KS], const float* in, fl
     }
 }
 
+// The first layer of the evaluations at (X, t) and (X, t + dt) of one step attempt (column tiles 0 and 1): the two input columns of a
+// trajectory differ in the TIME row only, and that row is the LAST term of the layer's chain (k = D, with the zero pad row k = D + 1 the
+// operands of the last matrix instruction s = KS - 1).  The chain over k < D is therefore computed ONCE and both tiles finish it with their
+// own last instruction: 1 + 1 instead of KS + KS matrix instructions for tile 1 (round 6; the same fmaf chain in the same order, so the
+// same bits as layer<KS, true>(.., 0, 2, ..) and as the oracle's Dense layer).  Tile 1 of `in` needs its time and pad rows only.
+template <int KS>
+__device__ __forceinline__ void layer1_shared_t(const float (&wf)[KS], const float* in, float* out, const float* bias, int w, int l, float* rec,
+                                                int recLD, const int* naccS, const int* doneS, const int* jS, int cap) {
+    const int rbase = 32 * w + 4 * (l >> 5);
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias[rbase + (r & 3) + 8 * (r >> 2)];
+    const float* bp = in + (l >> 5) * LDA + (l & 31);
+    constexpr int PF = KS < 6 ? KS : 6;
+    float bq[PF];
+    static_for<0, PF>([&](auto ic) { bq[ic] = bp[2 * decltype(ic)::value * LDA]; });
+    const float b1 = bp[2 * (KS - 1) * LDA + 32];   // tile 1's operand of the last instruction: rows D (t + dt) and D + 1 (0)
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, KS - 1>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const float b = bq[s % PF];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s], b, acc, 0, 0, 0);
+        if constexpr (s + PF < KS) bq[s % PF] = bp[2 * (s + PF) * LDA];
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    // (tile 1 first, into registers of its own; tile 0 in place: 32 accumulator registers live for two instructions, 16 otherwise)
+    v16f acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[KS - 1], b1, acc, 0, 0, 0);
+    v16f acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[KS - 1], bq[(KS - 1) % PF], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    float* op = out + rbase * LDA + (l & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) op[((r & 3) + 8 * (r >> 2)) * LDA + 32] = relu_enc(acc1[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = relu_enc(acc0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) op[((r & 3) + 8 * (r >> 2)) * LDA] = acc0[r];
+    if (rec) {  // activations of the (X, t) evaluation: speculative record of the step under way (as layer())
+        const int tr = l & 31;
+        const int slot = naccS[tr];
+        if (!doneS[tr] && slot < cap) {
+            float* rp = rec + ((size_t)jS[tr] * cap + slot) * recLD;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row0 = rbase + 8 * g;
+                if (row0 < recLD) {
+                    float4 v = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+                    *reinterpret_cast<float4*>(rp + row0) = v;
+                }
+            }
+        }
+    }
+}
+
 template <int D, int H>
 __device__ __forceinline__ void load_fwd_weights(const float* th, int w, int l, float (&wf1)[Cfg<D, H>::KS1], float (&wf2)[Cfg<D, H>::KSH],
                                                  float (&wf3)[Cfg<D, H>::KSH], float (&wf4)[Cfg<D, H>::KSH]) {
@@ -276,7 +330,9 @@ __device__ __forceinline__ void normals8(uint64_t seed, uint32_t iter, uint32_t 
 // Scalar phases: a wavefront handles four of its eight slots at a time, one per 16-lane row, lane m of the row holding
 // components 8m .. 8m+7 (reductions = 3 in-lane + 4 DPP levels of the adjacent-pair tree; no LDS shuffles).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D, int H>
+// ADAPTIVE: LambaEM's adaptive stepping (three evaluations per attempt) or the fixed-step Euler-Maruyama mode (one) -- a template parameter
+// since round 6: the kernel of each mode carries only its own code (the run-time branch kept both first-layer forms alive)
+template <int D, int H, bool ADAPTIVE>
 __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
     using C = Cfg<D, H>;
     static_assert(D % 4 == 0 && D + 2 <= 128, "component octets per lane");
@@ -334,7 +390,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                     Xs[tr * XLD + c] = x;
                     dWs[tr * XLD + c] = s * nrm[i];
                     bufA[c * LDA + tr] = x;
-                    bufA[c * LDA + 32 + tr] = x;
+                    // (no X rows for tile 1: the evaluation at t + dt shares tile 0's chain over them -- layer1_shared_t)
                 } else if (c == D) {
                     bufA[c * LDA + tr] = p.t0;
                     bufA[c * LDA + 32 + tr] = p.t0 + dt;
@@ -359,7 +415,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
     }
     __syncthreads();
 
-    const int nA = p.adaptive ? 2 : 1;
+    constexpr int nA = ADAPTIVE ? 2 : 1;
     // debug phase clocks (s_memtime; one lane of block 0): [0] evaluations 1+2, [1] S1, [2] evaluation 3, [3] S2, [4] loop-end barrier
     const bool prof = p.prof != nullptr && blockIdx.x == 0 && tid == 0;
     unsigned long long tk = prof ? __builtin_readcyclecounter() : 0ull;
@@ -372,7 +428,8 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
     };
     for (;;) {
         if (prof) p.prof[8] += 1;
-        layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, nA, w, l, p.record ? p.rA1 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
+        if constexpr (ADAPTIVE) layer1_shared_t<C::KS1>(wf1, bufA, bufB, biasS, w, l, p.record ? p.rA1 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
+        else layer<C::KS1, true>(wf1, bufA, bufB, biasS, 0, 1, w, l, p.record ? p.rA1 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
         __syncthreads();
         layer<C::KSH, true>(wf2, bufB, bufA, biasS + 128, 0, nA, w, l, p.record ? p.rA2 : nullptr, C::RA, iNacc, iDone, iJ, p.cap);
         __syncthreads();
@@ -381,7 +438,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
         layer<C::KSH, false>(wf4, bufB, bufA, biasS + 384, 0, nA, w, l, nullptr, 0, iNacc, iDone, iJ, p.cap);
         __syncthreads();
         tick(0);
-        if (p.adaptive) {
+        if constexpr (ADAPTIVE) {
             // ---- S1: the Lamba probe point utilde = K + ||G||_F sqrt(dt): input column of the third evaluation ----
             for (int ps = 0; ps < 2; ++ps) {
                 const int tr = w * 8 + ps * 4 + rr;
@@ -465,7 +522,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                 const float un = __builtin_fmaf(dt, F, u) + zdW;
                 float EE = 0.0f, qq = 1.0f;
                 bool accept = true;
-                if (p.adaptive) {
+                if constexpr (ADAPTIVE) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float y = (cb + i < D) ? bufA[(cb + i) * LDA + 32 + tr] : 0.0f;
@@ -555,7 +612,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                             fin = true;
                         } else {
                             float dtn = dt;
-                            if (p.adaptive) {
+                            if constexpr (ADAPTIVE) {
                                 qold = EE > p.qoldinit ? EE : p.qoldinit;
                                 dtn = dt / qq;
                                 if (dtn > p.dtmax) dtn = p.dtmax;
@@ -670,7 +727,7 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                     p.nacc[j] = nacc;
                     if (p.stats) {
                         int64_t* s = p.stats + (size_t)j * 4;
-                        s[0] = (int64_t)it * (p.adaptive ? 3 : 1); s[1] = nacc; s[2] = nrej; s[3] = ndraw;
+                        s[0] = (int64_t)it * (ADAPTIVE ? 3 : 1); s[1] = nacc; s[2] = nrej; s[3] = ndraw;
                     }
                 }
                 // the slot takes the next trajectory of the ensemble, if any
@@ -693,7 +750,6 @@ __global__ void __launch_bounds__(256) hjb_fwd_kernel(const HjbParams p) {
                             Xs[tr * XLD + c] = X[i];
                             dWs[tr * XLD + c] = dW[i];
                             bufA[c * LDA + tr] = X[i];
-                            bufA[c * LDA + 32 + tr] = X[i];
                         } else if (c == D) {
                             bufA[c * LDA + tr] = t;
                             bufA[c * LDA + 32 + tr] = t + dt;
