@@ -407,6 +407,7 @@ struct Driver {
                     });
                 }
                 if (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
+                if constexpr (Sys::ACT_CACHE) sys.store_hint = (s + 1 < S) && (tab->C[s + 1] == tab->C[s]);   // (false again after the last stage)
                 if constexpr (DEFER) sys.eval_store(t + tab->C[s] * dt, zs, kr, s);
                 else sys.eval(t + tab->C[s] * dt, zs, kr, gs);
                 if constexpr (CPL) K1(s) = own_of(kr);
@@ -611,8 +612,22 @@ __device__ __forceinline__ int64_t member_of(const KParams& p, int64_t gslot) {
 
 // SORTED (cost-ordered launch, KParams::perm): `j` is the MEMBER the lane group works on (inputs and outputs are indexed by it), `jw` the
 // column of the internal workspaces (dense store, cotangent rows, step counts) = the lane group's own position: adjacent groups, adjacent words
+// Models that can hand the activations of one adjoint evaluation to the next one AT THE SAME TIME (round 6): the network input of an adjoint
+// evaluation is the interpolated forward state u(t) -- a function of t alone -- and both tableaux end with two stages at t + dt (Tsit5: c6 = c7 = 1,
+// Vern7: c9 = c10 = 1; the evaluation after a save-time jump is at that time once more).  A model with ACT_CACHE_WORDS (words per thread of an HBM
+// row it owns: KParams::slot_glob, unused by register-slot models) is told when to store (the next stage has the same c) and when to load
+// (t equals the stored evaluation's t BIT FOR BIT: same t, same interval, same interpolant, same activations -- nothing is approximated).
+// ... and models whose activations fit the registers keep the LAST evaluation's there (Model::ActCache, Model::vjp_c): an evaluation at the same
+// time as the one before it (per lane group) skips its forward pass (LvUde with register-resident weights, ude_models.h).
+template <class M, class = void> struct act_reg { static constexpr bool v = false; struct type {}; };
+template <class M> struct act_reg<M, std::void_t<typename M::ActCache>> { static constexpr bool v = true; using type = typename M::ActCache; };
+template <class M, class = void> struct act_cache { static constexpr int v = 0; };
+template <class M> struct act_cache<M, std::void_t<decltype(M::ACT_CACHE_WORDS)>> { static constexpr int v = M::ACT_CACHE_WORDS; };
+// (the modes ACT_NONE / ACT_STORE / ACT_LOAD: ude_model_kpp_vec.h, in front of the model that implements them)
+
 template <class Model, class Tab, int G, int BLOCKDIM, bool PT = false, bool SORTED = false>
 struct FwdSys {
+    static constexpr bool ACT_CACHE = false;
     TimeGrid<PT> tg;
     __device__ __forceinline__ real dtmax(const OptsR& o) const { return tg.DTMAX(o); }
     static constexpr int NR = Model::NS, NSL = 0;
@@ -852,6 +867,11 @@ struct AdjSys {
     __device__ __forceinline__ real dtmax(const OptsR& o) const { return tg.DTMAX(o); }
     static constexpr bool DEFERRED = Model::DEFERRED;
     static constexpr bool FAST = (VAR == 3);  // UDE_SENSE_FAST: lambda-only error control
+    static constexpr bool ACT_CACHE = act_cache<Model>::v > 0 && !Model::DEFERRED;   // (see act_cache above)
+    real cache_t;       // time of the evaluation whose activations the model's HBM row holds (NaN: none)
+    static constexpr bool ACT_REG = act_reg<Model>::v && !Model::DEFERRED;
+    typename act_reg<Model>::type areg;   // (empty unless ACT_REG)
+    bool store_hint;    // Driver: the NEXT evaluation is at the same time as this one (two stages with the same c)
     // VAR == 5: InterpolatingAdjoint(checkpointing = true) in its store-u-only form.  The forward store holds (t, t_end, dt, u)
     // per accepted step; entering an interval the kernel re-runs that step's stages from u with the stored dt -- the SAME
     // operation sequence as Driver::run's perform_step (and, for Vern7, its six lazy dense-output stages) on the same inputs, so
@@ -1106,6 +1126,15 @@ struct AdjSys {
             const real acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
             y[c] = rfma(dtf, acc, US(c));
         });
+        if constexpr (ACT_REG) {
+            const bool same = t == cache_t;   // (per lane group: its lanes hold the same t)
+            cache_t = t;
+            Model::template vjp_c<(NSL > 0)>(mctx, y, lam, dl, g, areg, same);
+        } else if constexpr (ACT_CACHE) {
+            const int mode = uni(t == cache_t) ? ACT_LOAD : (store_hint ? ACT_STORE : ACT_NONE);
+            if (mode == ACT_STORE) cache_t = t;
+            Model::template vjp<(NSL > 0)>(mctx, y, lam, dl, g, mode);
+        } else
         Model::template vjp<(NSL > 0)>(mctx, y, lam, dl, g);
         static_for<0, NR>([&](auto c) { klam[c] = -dl[c]; });
         static_for<0, NSL>([&](auto c) { g[c] = -g[c]; });
@@ -1228,6 +1257,12 @@ __global__ void __launch_bounds__(BLOCK, (VAR == 2 ? 2 : 1)) adj_kernel(const KP
         sys.j = gid;
         sys.jw = gslot;
         sys.n = p.n_state;
+        if constexpr (Sys::ACT_REG) sys.cache_t = __builtin_nan("");
+        if constexpr (Sys::ACT_CACHE) {
+            sys.cache_t = __builtin_nan("");
+            sys.store_hint = false;
+            sys.mctx.acache = p.slot_glob + (size_t)blockIdx.x * (size_t)act_cache<Model>::v * BLOCK;   // this block's row
+        }
         if constexpr (Model::DEFERRED) sys.load_bth_table();
         if constexpr (model_gfac<Model>::v > 0) {   // stage factors a model keeps in HBM: this thread's words behind its two mu columns
             sys.mctx.gfac = mu_lds + (size_t)(2 * Model::NSL) * MS;

@@ -29,6 +29,10 @@
 
 namespace ude {
 
+// what an adjoint evaluation does with its hidden activations (AdjSys::ACT_CACHE, ude_kernels.h): nothing, store them for the next evaluation
+// at the same time, or load the ones the previous evaluation at this time stored
+enum { ACT_NONE = 0, ACT_STORE = 1, ACT_LOAD = 2 };
+
 #ifndef UDE_F32
 // greedy first-fit-decreasing packing of the layers' outer-product rectangles into 16 x 16 output tiles (compile time)
 template <int MAXT>
@@ -196,11 +200,17 @@ struct KppUdeV : LinearTheta {
     static constexpr int NPP = (NP + 1) & ~1;  // block-sum row (aliases the tile once the points are consumed)
     static_assert(NPP <= TILE, "block sums must fit the tile they alias");
     static constexpr int SCRATCH = 3 * (NPT + 2) + NWV * TILE;  // u, lambda, result rows + tiles
+    // round 6: the hidden activations of an adjoint evaluation (ROWS_A - 1 numbers per point) can be handed to the next evaluation at the
+    // same time through an HBM row of the block (AdjSys::ACT_CACHE in ude_kernels.h): the second of the two stages at t + dt, and the
+    // evaluation after a save-time jump, then skip the forward pass -- 40 `tanh` of the 1-10-20-10-1 net per point -- and read what the
+    // stage before them computed from the same u.  Row r of point i at acache[(r - 1) * NPT + i] (lane = point: coalesced).
+    static constexpr int ACT_CACHE_WORDS = (ROWS_A - 1) * PPL;
     static constexpr int SCRATCH_FWD = 3 * (NPT + 2);
     struct Ctx {
         double wr[NWR];               // the network's parameters: theta index f in lane f % 16 (of every row) of wr[f / 16]
         double one;                   // 1.0 in a register (the bias is added as fma(b, 1, z) = RN(z + b): the DPP form of the add)
         lds_t *urow, *lrow, *orow, *tile, *part;
+        double* acache;               // this block's activation row in HBM (ACT_CACHE_WORDS x block threads doubles; set by adj_kernel)
         double w1, w2, w3, D0;
         int r, lane, w, l16, kq, n, so, d0o, nno;
         int arow[NT], bcol[NT];       // this lane's operand slots of the contraction: delta row of output row l16, [a ; 1] column of output column l16
@@ -363,7 +373,7 @@ struct KppUdeV : LinearTheta {
     }
 
     template <bool WANT_PARAM>
-    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam, double* g) {
+    static __device__ __forceinline__ void vjp(const Ctx& c, const double* u, const double* lam, double* dlam, double* g, int mode = ACT_NONE) {
         const int n = c.n;
         __syncthreads();
         static_for<0, PPL>([&](auto cc) {
@@ -384,7 +394,12 @@ struct KppUdeV : LinearTheta {
             a[0][0] = on ? c.urow[ic] : 0.0;
             li[0] = on ? c.lrow[ic] : 0.0;
             UDE_KPPV_CLK(0);
-            net_forward<1>(c, a, y);
+            if (mode == ACT_LOAD) {   // (wave-uniform: a scalar branch) the activations the previous evaluation at this very time stored
+                static_for<1, ROWS_A>([&](auto rc) { a[0][rc] = c.acache[(size_t)(decltype(rc)::value - 1) * NPT + ic]; });
+            } else {
+                net_forward<1>(c, a, y);
+                if (mode == ACT_STORE && on) static_for<1, ROWS_A>([&](auto rc) { c.acache[(size_t)(decltype(rc)::value - 1) * NPT + ic] = a[0][rc]; });   // (a lane beyond the grid has ic = 0: not its slot)
+            }
             UDE_KPPV_CLK(1);
             net_backward<1>(c, a, li, d, gx);
             UDE_KPPV_CLK(2);

@@ -88,8 +88,12 @@ struct LvTrue : LinearTheta {
 // NLIN: slots for trainable diagonal coefficients (2: scenario_2's delta / hudson_bay's p1, p2 may be trained; 0: both
 // diagonal coefficients are constants as in scenario_1.jl:69-73 -- no slots, no accumulators, no divisions for them)
 // WREG = false: the weights stay in LDS (the register budget of the two-wavefronts-per-SIMD instances)
+// (LvUde's register activation cache exists exactly where its weights are register-resident: the member type AdjSys looks for)
+template <bool ON, class Mlp> struct LvActReg {};
+template <class Mlp> struct LvActReg<true, Mlp> { using ActCache = typename Mlp::Cache; };
+
 template <class Net, int G, int NLIN = 2, bool WREG = true>
-struct LvUde : LinearTheta {
+struct LvUde : LinearTheta, LvActReg<(WREG && (G >= 5) && (Net::maxdim() <= 8)), CoopMlp<Net, G>> {
     using Mlp = CoopMlp<Net, G>;
     static_assert(Net::dim(0) == 2 && Net::dim(Net::L) == 2, "LV UDE network maps R^2 -> R^2");
     static_assert(NLIN == 0 || NLIN == 2, "none or both diagonal slots");
@@ -152,6 +156,25 @@ struct LvUde : LinearTheta {
             Mlp::forward(c.nn, c.r, u, cache, y);
             Mlp::template vjp<WANT_PARAM>(c.nn, c.r, cache, lam, gx, g);
         }
+        dlam[0] = rfma(c.lin[0], lam[0], gx[0]);
+        dlam[1] = rfma(c.lin[1], lam[1], gx[1]);
+        if constexpr (WANT_PARAM && NLIN == 2) {
+            g[Mlp::NSLOT + 0] = (c.lead_on[0] * u[0]) * lam[0];
+            g[Mlp::NSLOT + 1] = (c.lead_on[1] * u[1]) * lam[1];
+        }
+    }
+    // round 6: the activations of the LAST adjoint evaluation stay in registers (AdjSys::ACT_REG, ude_kernels.h): the network input of an adjoint
+    // evaluation is the interpolated forward state u(t), a function of t alone, so an evaluation at the same time as the one before it -- the
+    // second of the two stages at t + dt that both tableaux end with, the evaluation after a save-time jump -- skips its forward pass (three
+    // `exp` / `tanh` per lane, the layer dots and their gathers) and runs the reverse sweep on the activations it finds.  Same numbers, same bits.
+    // Only where the weights are register-resident too (narrow nets on >= 5 lanes: ActCache comes from LvActReg below); configs[1]: adj_kernel -4.5 %.
+    template <bool WANT_PARAM, class AC>
+    static __device__ __forceinline__ void vjp_c(const Ctx& c, const real* u, const real* lam, real* dlam, real* g, AC& cache, bool same) {
+        static_assert(REGW, "register-resident weights");
+        cache.gb = c.gb;
+        real y[2], gx[2];
+        if (!same) Mlp::forward(c.w, c.r, u, cache, y);
+        Mlp::template vjp<WANT_PARAM>(c.w, c.r, cache, lam, gx, g);
         dlam[0] = rfma(c.lin[0], lam[0], gx[0]);
         dlam[1] = rfma(c.lin[1], lam[1], gx[1]);
         if constexpr (WANT_PARAM && NLIN == 2) {

@@ -96,7 +96,7 @@ inline Launch make_launch() {
     l.k_doubles_d = Layout<Model, Tab, G, BLOCK, false>::K_DOUBLES;
     l.dadj_k_dense = Model::DADJ_K_FROM_DENSE;
     l.slots_reg = (Model::SLOTS_GLOBAL ? 0 : (Tab::FSAL ? 3 : 2) * (Model::NSL > 0 ? Model::NSL : 1) * BLOCK) + Layout<Model, Tab, G, BLOCK>::IC_DOUBLES;
-    l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL + gfac_words<Model>::v : 0;
+    l.slot_glob = Model::SLOTS_GLOBAL ? (Model::DEFERRED ? 2 : 1) * Model::NSL + gfac_words<Model>::v : act_cache<Model>::v;   // (or the model's activation row: AdjSys::ACT_CACHE)
     l.elem = (int)sizeof(real);
     l.per_member = per_member<Model>::v && !Model::SLOTS_GLOBAL;
     return l;
