@@ -2,6 +2,8 @@
 tolerances, time span, ragged save grids (with and without the end points), ensemble size, lanes per trajectory, network
 variant, sensitivity algorithm, row mask, per-trajectory spans.  Every draw must agree per trajectory bit for bit (step
 counts forward and backward, saved states, dL/du0, per-trajectory loss) and to summation order in the ensemble sums."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,9 @@ from universal_differential_equations_amd import models
 from test_gpu_parity import REL_GRAD_SUM, assert_bitwise, check_per_trajectory
 
 pytestmark = pytest.mark.gpu
+
+# UDE_FUZZ_SCALE=k multiplies the number of seeds of every randomised test below (soak runs of a final binary: profiles/r06_fuzz_soak.log)
+SCALE = int(os.environ.get("UDE_FUZZ_SCALE", "1"))
 
 NETS = {
     "s1": (lambda: models.ude_dynamics(), O.lv_ude_s1, lambda rng, g: np.array(g["initial_parameters"]) * (1 + 0.1 * rng.standard_normal(87)), (0, 1, 4, 5, 8)),
@@ -23,7 +28,7 @@ NETS = {
 }
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * SCALE))
 def test_random_corner_matches_oracle(golden, seed):
     g = golden("Scenario_1_recovery_0.005")
     rng = np.random.default_rng(1000 + seed)
@@ -77,7 +82,7 @@ KPP = {
 }
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_random_fisher_kpp_grid_matches_oracle(seed):
     """ragged grids (3 ... 32 points, periodic stencil), random stencil / D0 / tolerances, Float64 and the Float32 instance"""
     rng = np.random.default_rng(2000 + seed)
@@ -110,7 +115,7 @@ def test_random_fisher_kpp_grid_matches_oracle(seed):
     assert np.linalg.norm(r.grad_theta.astype(float) - ref["grad_theta"].astype(float)) <= rel * np.linalg.norm(ref["grad_theta"].astype(float)), what
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * SCALE))
 def test_random_seir_and_neural_ode_match_oracle(seed):
     """64-wide tanh networks (SEIR exposure UDE 3-64-64-1, neural ODE 7-64-64-64-7): random population scale, horizon, save
     grid, row mask, tolerance, algorithm and sensitivity mode"""
@@ -144,7 +149,7 @@ def test_random_seir_and_neural_ode_match_oracle(seed):
     assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) <= REL_GRAD_SUM * max(gn, 1e-300), what
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_random_deep_bsde_step_matches_oracle(seed):
     """highdim_pde/lambaem.jl: random Philox seed / training iteration / ensemble size (below, at and above one 32-slot block,
     so the slot queue is exercised) / tolerances / controller settings / lambda / horizon / x0, adaptive LambaEM and fixed EM"""
@@ -195,7 +200,7 @@ def test_ragged_large_fisher_kpp_grids_match_oracle(nx):
         assert np.linalg.norm(r.grad_theta - ref["grad_theta"]) <= REL_GRAD_SUM * np.linalg.norm(ref["grad_theta"])
 
 
-@pytest.mark.parametrize("seed", range(18))
+@pytest.mark.parametrize("seed", range(18 * SCALE))
 def test_random_solver_keywords_match_oracle(golden, seed):
     """the solve keywords the scripts can pass besides the tolerances -- dt, dtmax, qmin / qmax / gamma, beta1 / beta2, qoldinit --
     over every kernel family: LV lane groups, the SEIR kernels (one wavefront per trajectory, and the lock-step matrix-core
