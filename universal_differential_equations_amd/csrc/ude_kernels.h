@@ -179,6 +179,10 @@ __device__ __forceinline__ int64_t part_row() {
     else return BLOCK >= 64 ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / 64 : (int64_t)blockIdx.x;
 }
 
+// (see Driver::run: a system whose tableau loads go through the constant address space)
+template <class S, class = void> struct sys_tab_scalar { static constexpr bool v = false; };
+template <class S> struct sys_tab_scalar<S, std::void_t<decltype(S::TAB_SCALAR)>> { static constexpr bool v = S::TAB_SCALAR; };
+
 template <class Tab, class Sys, int G, int BLOCK>
 struct Driver {
     static constexpr int NR = Sys::NR, NSL = Sys::NSL, NSLA = NSL > 0 ? NSL : 1;
@@ -223,6 +227,14 @@ struct Driver {
         // by the initial-dt heuristic, and -- FSAL tableaux -- handed over from the last stage of an accepted step
         // (gtmp2 receives the last stage's slot derivative; the two rows swap on acceptance)
         const OptsR o(oin);
+        // Systems that ask for it (Sys::TAB_SCALAR: the adjoint of the LV models with register-resident weights) read the tableau through the
+        // CONSTANT address space: uniform loads of it are then scalar loads into SGPRs (s_load, operands of the vector instructions as they are)
+        // instead of vector loads of one address by 64 lanes -- the kernels store to global memory, so the compiler cannot prove a plain global
+        // load invariant.  The table is written by the host before the launch and never by a kernel.  Measured per kernel family (round 6,
+        // profiles/r06_probes.md): configs[1] adj_kernel -1.5 %, 40 000 members -2.7 %, the 8-lane run-time shapes -3 %; the 2-32-2 net on 16 lanes
+        // +2.4 %, the forward kernels and Fisher-KPP unchanged -- so it is a property of the system, not of the driver.
+        typedef std::conditional_t<sys_tab_scalar<Sys>::v, const __attribute__((address_space(4))) TabDev, const TabDev> CTabDev;
+        CTabDev* const ct = (CTabDev*)tab;
         real accb[NSLA], acce[NSLA];
         const real dtmax = sys.dtmax(o);  // (per-trajectory when the time grids are)
         real t = t0, dt, qold = o.qoldinit, q11 = real(1);
@@ -380,7 +392,7 @@ struct Driver {
             real znew[NR];
             [[maybe_unused]] const real zo = CPL ? own_of(z) : real(0);  // this lane's component of z
             if constexpr (SLOT_FSAL) {
-                const real bs = tab->B[0], es = tab->BT[0];
+                const real bs = ct->B[0], es = ct->BT[0];
                 static_for<0, NSL>([&](auto c) {
                     const real g0 = gtmp[c * BLOCK];
                     accb[c] = bs * g0;
@@ -392,28 +404,28 @@ struct Driver {
                 if (s == 0) {
                     static_for<0, NR>([&](auto c) { zs[c] = z[c]; });
                 } else if constexpr (CPL) {
-                    real acc = tab->A[s][0] * K1(0);
+                    real acc = ct->A[s][0] * K1(0);
 #pragma unroll 4
-                    for (int j = 1; j < s; ++j) acc = rfma(tab->A[s][j], K1(j), acc);  // (a_sj = 0 for j >= s)
+                    for (int j = 1; j < s; ++j) acc = rfma(ct->A[s][j], K1(j), acc);  // (a_sj = 0 for j >= s)
                     bcast_all(rfma(dt, acc, zo), zs);
                 } else {
                     static_for<0, NR>([&](auto c) {
                         // all S-1 possible terms, unrolled: the coefficients of stages >= s are zero in the table and the
                         // (zero-initialised, always finite) k storage makes fma(0, k, acc) == acc exact -- one batch of
                         // scalar + LDS loads and one wait per stage instead of a load-wait-fma round trip per term
-                        real acc = tab->A[s][0] * K(0, c);
-                        static_for<1, S - 1>([&](auto j) { acc = rfma(tab->A[s][j], K(j, c), acc); });
+                        real acc = ct->A[s][0] * K(0, c);
+                        static_for<1, S - 1>([&](auto j) { acc = rfma(ct->A[s][j], K(j, c), acc); });
                         zs[c] = rfma(dt, acc, z[c]);
                     });
                 }
                 if (Tab::FSAL && s == S - 1) static_for<0, NR>([&](auto c) { znew[c] = zs[c]; });
-                if constexpr (Sys::ACT_CACHE) sys.store_hint = (s + 1 < S) && (tab->C[s + 1] == tab->C[s]);   // (false again after the last stage)
-                if constexpr (DEFER) sys.eval_store(t + tab->C[s] * dt, zs, kr, s);
-                else sys.eval(t + tab->C[s] * dt, zs, kr, gs);
+                if constexpr (Sys::ACT_CACHE) sys.store_hint = (s + 1 < S) && (ct->C[s + 1] == ct->C[s]);   // (false again after the last stage)
+                if constexpr (DEFER) sys.eval_store(t + ct->C[s] * dt, zs, kr, s);
+                else sys.eval(t + ct->C[s] * dt, zs, kr, gs);
                 if constexpr (CPL) K1(s) = own_of(kr);
                 else static_for<0, NR>([&](auto c) { K(s, c) = kr[c]; });
                 if constexpr (NSL > 0) {
-                    const real bs = tab->B[s], es = tab->BT[s];
+                    const real bs = ct->B[s], es = ct->BT[s];
                     if (s == 0) {
                         static_for<0, NSL>([&](auto c) {
                             accb[c] = bs * gs[c];
@@ -432,31 +444,31 @@ struct Driver {
             }
             st.nf += Tab::FSAL ? S - 1 : S;
             if constexpr (!Tab::FSAL && CPL) {
-                real acc = tab->B[0] * K1(0);
+                real acc = ct->B[0] * K1(0);
 #pragma unroll 3
-                for (int j = 1; j < S; ++j) acc = rfma(tab->B[j], K1(j), acc);
+                for (int j = 1; j < S; ++j) acc = rfma(ct->B[j], K1(j), acc);
                 bcast_all(rfma(dt, acc, zo), znew);
             } else if constexpr (!Tab::FSAL) {
                 static_for<0, NR>([&](auto c) {
-                    real acc = tab->B[0] * K(0, c);
-                    for (int j = 1; j < S; ++j) acc = rfma(tab->B[j], K(j, c), acc);
+                    real acc = ct->B[0] * K(0, c);
+                    for (int j = 1; j < S; ++j) acc = rfma(ct->B[j], K(j, c), acc);
                     znew[c] = rfma(dt, acc, z[c]);
                 });
             }
             // calculate_residuals + ODE_DEFAULT_NORM
             acc_t ss = 0.0;  // (ude_real.h: Float64 accumulation for both scalar types)
             if constexpr (CPL) {
-                real acc = tab->BT[0] * K1(0);
+                real acc = ct->BT[0] * K1(0);
 #pragma unroll 3
-                for (int j = 1; j < S; ++j) acc = rfma(tab->BT[j], K1(j), acc);
+                for (int j = 1; j < S; ++j) acc = rfma(ct->BT[j], K1(j), acc);
                 const real a0 = rabs(zo), a1 = rabs(own_of(znew));
                 real res[NR];
                 bcast_all((dt * acc) / rfma((a0 > a1 ? a0 : a1), o.reltol, o.abstol), res);
                 static_for<0, NR>([&](auto c) { ss = afma(res[c], res[c], ss); });
             } else
             static_for<0, NR>([&](auto c) {
-                real acc = tab->BT[0] * K(0, c);
-                for (int j = 1; j < S; ++j) acc = rfma(tab->BT[j], K(j, c), acc);
+                real acc = ct->BT[0] * K(0, c);
+                for (int j = 1; j < S; ++j) acc = rfma(ct->BT[j], K(j, c), acc);
                 const real a0 = rabs(z[c]), a1 = rabs(znew[c]);
                 real res = (dt * acc) / rfma((a0 > a1 ? a0 : a1), o.reltol, o.abstol);
                 if constexpr (Sys::STATE_DISTRIBUTED) res *= sys.state_on(c);
@@ -515,17 +527,17 @@ struct Driver {
                                     real zs[NR], kr[NR], gs[NSLA];
                                     const int row = S + e;
                                     if constexpr (CPL) {
-                                        real acc = tab->A[row][0] * K1(0);
+                                        real acc = ct->A[row][0] * K1(0);
 #pragma unroll 3
-                                        for (int j = 1; j < row; ++j) acc = rfma(tab->A[row][j], K1(j), acc);
+                                        for (int j = 1; j < row; ++j) acc = rfma(ct->A[row][j], K1(j), acc);
                                         bcast_all(rfma(dt, acc, zo), zs);
                                     } else
                                     static_for<0, NR>([&](auto c) {
-                                        real acc = tab->A[row][0] * K(0, c);
-                                        for (int j = 1; j < row; ++j) acc = rfma(tab->A[row][j], K(j, c), acc);
+                                        real acc = ct->A[row][0] * K(0, c);
+                                        for (int j = 1; j < row; ++j) acc = rfma(ct->A[row][j], K(j, c), acc);
                                         zs[c] = rfma(dt, acc, z[c]);
                                     });
-                                    sys.eval(tprev + tab->C[row] * dt, zs, kr, gs);
+                                    sys.eval(tprev + ct->C[row] * dt, zs, kr, gs);
                                     if constexpr (CPL) K1(row) = own_of(kr);
                                     else static_for<0, NR>([&](auto c) { K(row, c) = kr[c]; });
                                 }
@@ -870,6 +882,7 @@ struct AdjSys {
     static constexpr bool ACT_CACHE = act_cache<Model>::v > 0 && !Model::DEFERRED;   // (see act_cache above)
     real cache_t;       // time of the evaluation whose activations the model's HBM row holds (NaN: none)
     static constexpr bool ACT_REG = act_reg<Model>::v && !Model::DEFERRED;
+    static constexpr bool TAB_SCALAR = ACT_REG;   // (the models with register-resident weights: Driver::run, where the tableau is read)
     typename act_reg<Model>::type areg;   // (empty unless ACT_REG)
     bool store_hint;    // Driver: the NEXT evaluation is at the same time as this one (two stages with the same c)
     // VAR == 5: InterpolatingAdjoint(checkpointing = true) in its store-u-only form.  The forward store holds (t, t_end, dt, u)
