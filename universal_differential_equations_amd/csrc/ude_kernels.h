@@ -1129,28 +1129,16 @@ struct AdjSys {
     }
     __device__ __forceinline__ void eval(real t, const real* lam, real* klam, real* g) {
       if constexpr (!DEFERRED) {
-#ifdef UDE_EXP_NOCLOBBER
-        if constexpr (!ACT_REG)
-#endif
         asm volatile("" ::: "memory");  // keep the LDS-staged weights in LDS (no hoisting into registers)
-        real b[Tab::NK], y[NR], dl[NR];
-#ifdef UDE_EXP_SKIPY
-        bool need_y = true;
-        if constexpr (ACT_REG && !Model::VJP_NEEDS_U) need_y = __builtin_amdgcn_ballot_w64(t != cache_t) != 0;   // (wave-uniform)
-        static_for<0, NR>([&](auto c) { y[c] = real(0); });
-        if (need_y) {
-#endif
         locate(t);
         const real dtf = te - ts;
         const real th = (t - ts) / dtf;
+        real b[Tab::NK], y[NR], dl[NR];
         Tab::bth(th, b);
         static_for<0, NR>([&](auto c) {
             const real acc = chain2<RowDense<Tab>, Tab::NK>([&](auto q) { return KS(q, c); }, [&](auto q) { return b[q]; });
             y[c] = rfma(dtf, acc, US(c));
         });
-#ifdef UDE_EXP_SKIPY
-        }
-#endif
         if constexpr (ACT_REG) {
             const bool same = t == cache_t;   // (per lane group: its lanes hold the same t)
             cache_t = t;

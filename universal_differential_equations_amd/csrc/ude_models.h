@@ -102,7 +102,6 @@ struct LvUde : LinearTheta, LvActReg<(WREG && (G >= 5) && (Net::maxdim() <= 8)),
     static constexpr bool STATE_DISTRIBUTED = false;
     // weights in registers when the lane's share is small (narrow layers spread over >= 5 lanes), else read from LDS
     static constexpr bool REGW = WREG && (G >= 5) && (Net::maxdim() <= 8);
-    static constexpr bool VJP_NEEDS_U = NLIN == 2;   // (vjp_c reads the state itself only for the diagonal slots)
     // per-member parameters (UDE_PT_THETA): with the weights in registers theta is only read by init(); wide nets (2-32-2), whose
     // weights are read where they lie at every use, read the member's own column in HBM instead of the block's LDS copy then
     // (every lane of a group reads the same words: broadcast loads, L2-resident -- slower than the shared-theta path, same bits)
